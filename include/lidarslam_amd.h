@@ -1,0 +1,292 @@
+/*
+ * lidarslam_amd.h -- C ABI of liblidarslam_amd.so: the MI355X-native
+ * implementation of the per-frame scan-matching hot path of
+ * Perception4D/LidarSlam (slam_lib).
+ *
+ * The reference has no FFI layer: the path sits behind the C++ API of
+ * libLidarSlam.  This header is the seam a maintainer binds
+ * instead of the four internal call sites listed below.  Plain pointers and
+ * sizes only -- no STL / Eigen / PCL / torch types cross this boundary.  All
+ * device memory is owned by the context; the host never sees device pointers.
+ *
+ * All functions return 0 on success and a negative LSA_E_* code on failure;
+ * lsa_last_error() returns a human readable message for the last failure of
+ * that context.  There is NO CPU fallback: when no HIP device is usable,
+ * lsa_ctx_create fails with LSA_E_NO_DEVICE and nothing else can be called.
+ *
+ * file:line citations are relative to /root/reference.
+ */
+#ifndef LIDARSLAM_AMD_H
+#define LIDARSLAM_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LSA_OK 0
+#define LSA_E_NO_DEVICE (-1)
+#define LSA_E_HIP (-2)
+#define LSA_E_ARG (-3)
+#define LSA_E_STATE (-4)
+#define LSA_E_CAPACITY (-5)
+
+/* Keypoint types -- slam_lib/include/LidarSlam/Enums.h:30-36 */
+#define LSA_EDGE 0
+#define LSA_PLANE 1
+#define LSA_BLOB 2
+
+/* The 32-byte PCL point of the reference, byte for byte
+ * -- slam_lib/include/LidarSlam/LidarPoint.h:31-64 (registered :68-77). */
+typedef struct lsa_point_t
+{
+  float x, y, z, w;   /* PCL_ADD_POINT4D: data[4], w == 1 */
+  double time;        /* offset in seconds to the frame stamp */
+  float intensity;
+  uint16_t laser_id;  /* ring, 0 = lowest */
+  uint8_t device_id;
+  uint8_t label;
+} lsa_point_t;
+
+/* Match status values -- slam_lib/include/LidarSlam/KeypointsMatcher.h:82-93 */
+enum
+{
+  LSA_MATCH_SUCCESS = 0,
+  LSA_MATCH_BAD_MODEL_PARAMETRIZATION = 1,
+  LSA_MATCH_NOT_ENOUGH_NEIGHBORS = 2,
+  LSA_MATCH_NEIGHBORS_TOO_FAR = 3,
+  LSA_MATCH_BAD_PCA_STRUCTURE = 4,
+  LSA_MATCH_INVALID_NUMERICAL = 5,
+  LSA_MATCH_MSE_TOO_LARGE = 6,
+  LSA_MATCH_UNKOWN = 7,
+  LSA_MATCH_NSTATUS = 8
+};
+
+/* Parameters of SpinningSensorKeypointExtractor, same names and defaults as its
+ * setters -- slam_lib/include/LidarSlam/SpinningSensorKeypointExtractor.h:44-70, 125-157 */
+typedef struct lsa_extract_params_t
+{
+  int32_t neighbor_width;            /* NeighborWidth = 4 */
+  float min_distance_to_sensor;      /* MinDistanceToSensor = 1.5 m */
+  float min_beam_surface_angle;      /* MinBeamSurfaceAngle = 10 deg */
+  float plane_sin_angle_threshold;   /* PlaneSinAngleThreshold = 0.5 */
+  float edge_sin_angle_threshold;    /* EdgeSinAngleThreshold = 0.86 */
+  float dist_to_line_threshold;      /* DistToLineThreshold = 0.20 m */
+  float edge_depth_gap_threshold;    /* EdgeDepthGapThreshold = 0.15 m */
+  float edge_saliency_threshold;     /* EdgeSaliencyThreshold = 1.5 m */
+  float edge_intensity_gap_threshold;/* EdgeIntensityGapThreshold = 50 */
+} lsa_extract_params_t;
+
+/* KeypointsMatcher::Parameters -- slam_lib/include/LidarSlam/KeypointsMatcher.h:43-77 */
+typedef struct lsa_match_params_t
+{
+  int32_t single_edge_per_ring;      /* SingleEdgePerRing */
+  int32_t edge_nb_neighbors;         /* EdgeNbNeighbors */
+  int32_t edge_min_nb_neighbors;     /* EdgeMinNbNeighbors */
+  int32_t plane_nb_neighbors;        /* PlaneNbNeighbors */
+  int32_t blob_nb_neighbors;         /* BlobNbNeighbors */
+  int32_t reserved;
+  double max_neighbors_distance;     /* MaxNeighborsDistance */
+  double edge_max_model_error;       /* EdgeMaxModelError */
+  double planarity_threshold;        /* PlanarityThreshold */
+  double plane_max_model_error;      /* PlaneMaxModelError */
+  double saturation_distance;        /* SaturationDistance (Tukey scale) */
+} lsa_match_params_t;
+
+/* Which device-resident keypoint set an operation reads */
+#define LSA_SET_RAW_CURRENT 0   /* Slam::CurrentRawKeypoints           (Slam.h:516) */
+#define LSA_SET_RAW_PREVIOUS 1  /* Slam::PreviousRawKeypoints          (Slam.h:517) */
+#define LSA_SET_WORKING 2       /* Slam::CurrentUndistortedKeypoints   (Slam.h:520) */
+
+/* ------------------------------------------------------------------------- */
+/* Context: one per Slam instance, bound to one HIP device and one stream.    */
+typedef struct lsa_ctx lsa_ctx;
+
+int lsa_device_count(void);
+int lsa_ctx_create(int device_id, lsa_ctx** out);
+void lsa_ctx_destroy(lsa_ctx* ctx);
+const char* lsa_last_error(const lsa_ctx* ctx);
+/* Blocks until everything queued on the context's stream has finished. */
+int lsa_sync(lsa_ctx* ctx);
+
+/* ------------------------------------------------------------------------- */
+/* Seam 1: SpinningSensorKeypointExtractor::ComputeKeyPoints(pc)
+ * -- slam_lib/src/SpinningSensorKeypointExtractor.cxx:118-136, called from
+ *    Slam::ExtractKeypoints, slam_lib/src/Slam.cxx:784.                       */
+
+/* Copies one scan (firing order, rings interleaved) to the device and makes it
+ * the current frame.  On the first usable frame the azimuthal resolution is
+ * estimated on the host exactly as EstimateAzimuthalResolution does
+ * (SSKE.cxx:593-637) and then frozen in the context (SSKE.cxx:169-170). */
+int lsa_upload_frame(lsa_ctx* ctx, const lsa_point_t* pts, int n);
+
+/* Frame store: keeps scans resident in HBM so that a replay (bench.py) can
+ * time the path without the PCIe copy.  Slots are created on demand. */
+int lsa_frame_store_put(lsa_ctx* ctx, int slot, const lsa_point_t* pts, int n);
+int lsa_frame_store_use(lsa_ctx* ctx, int slot);
+
+float lsa_get_azimuthal_resolution(const lsa_ctx* ctx);
+void lsa_set_azimuthal_resolution(lsa_ctx* ctx, float rad);
+
+/* Runs a3-a8 of SURVEY.md 8a on the current frame.  The previous call's
+ * keypoints become LSA_SET_RAW_PREVIOUS (Slam.cxx:751).  counts[k] = number of
+ * keypoints of type k; keypoints stay on the device, ordered ring-major /
+ * index-ascending as SSKE.cxx:575-589 pushes them. */
+int lsa_extract_keypoints(lsa_ctx* ctx, const lsa_extract_params_t* params, int counts[3]);
+
+/* Copies a device keypoint set to the host.  Returns the number of points
+ * written (<= capacity) or a negative error. */
+int lsa_download_keypoints(lsa_ctx* ctx, int set, int type, lsa_point_t* out, int capacity);
+int lsa_keypoint_count(const lsa_ctx* ctx, int set, int type);
+
+/* SpinningSensorKeypointExtractor::GetDebugArray() (SSKE.cxx:640-680), one
+ * array per call, in scan order.  array_id: 0 sin_angle, 1 saliency,
+ * 2 depth_gap, 3 intensity_gap, 4/5/6 edge/plane/blob_keypoint,
+ * 7/8/9 edge/plane/blob_validity. */
+int lsa_download_debug(lsa_ctx* ctx, int array_id, float* out, int capacity);
+int lsa_nb_laser_rings(const lsa_ctx* ctx);
+
+/* Rigidly transforms a raw-current keypoint set in place (LIDAR -> BASE,
+ * Slam::AggregateFrames(..., false), Slam.cxx:1551-1573) and adds time_offset
+ * to every point's time. T is a row-major 4x4. */
+int lsa_transform_keypoints(lsa_ctx* ctx, int set, int type, const double T[16], double time_offset);
+
+/* ------------------------------------------------------------------------- */
+/* Seam 2: KeypointsMatcher::BuildMatchResiduals(currPoints, kdtree, type)
+ * -- slam_lib/src/KeypointsMatcher.cxx:33-74; the kd-tree build it replaces is
+ *    KDTreePCLAdaptor::Reset, slam_lib/include/LidarSlam/KDTreePCLAdaptor.h:57-65. */
+
+/* Sets the kNN target of one keypoint type from host points (the sub-map the
+ * host-side RollingGrid produced, Slam.cxx:1003-1037) and builds the device
+ * search grid.  Point order is kept: indices seen by the PCA are these. */
+int lsa_set_target(lsa_ctx* ctx, int type, const lsa_point_t* pts, int m);
+/* Same, from a device-resident keypoint set (ego-motion registers on the
+ * previous frame's raw keypoints, Slam.cxx:845-860): no PCIe traffic. */
+int lsa_set_target_from_set(lsa_ctx* ctx, int type, int set);
+int lsa_target_size(const lsa_ctx* ctx, int type);
+
+/* Replaces a device keypoint set by host points (used by tests and by callers
+ * that aggregate several LiDAR devices on the host). */
+int lsa_set_keypoints(lsa_ctx* ctx, int set, int type, const lsa_point_t* pts, int k);
+
+/* For every keypoint of `type` in `query_set`: world = pose * X, exact kNN in
+ * the target, neighbourhood filtering, PCA model fit, validity tests, residual
+ * record (A, P, X, weight).  Records stay on the device for lsa_accumulate.
+ * pose = PosePrior, row-major 4x4.  histogram[s] = number of keypoints with
+ * MatchStatus s (MatchingResults::RejectionsHistogram). */
+int lsa_match(lsa_ctx* ctx, int type, int query_set, const lsa_match_params_t* params, const double pose[16],
+              int histogram[LSA_MATCH_NSTATUS]);
+
+/* MatchingResults::Rejections / Weights of the last lsa_match of `type`
+ * (exported by Slam::GetDebugArray, Slam.cxx:635-657).  records (optional,
+ * may be NULL) receives 16 doubles per keypoint: A[9] row-major, P[3], X[3],
+ * weight; rows of unmatched keypoints are zero. */
+int lsa_download_match(lsa_ctx* ctx, int type, uint8_t* status, double* weights, double* records, int capacity);
+
+/* ------------------------------------------------------------------------- */
+/* Seam 3: LocalOptimizer::Solve() -- slam_lib/src/LocalOptimizer.cxx:74-102.
+ * The device evaluates what Ceres evaluates per LM step for the residual
+ * blocks of the last lsa_match calls of the types in type_mask (bit k = type
+ * k), in the order EDGE, PLANE, BLOB (Slam.cxx:936-937, 1120-1121):
+ *   r_i = A_i (R(rpy) X_i + t - P_i),  rho = weight_i * Tukey(|r_i|^2)
+ *   cost = 1/2 sum rho,  g = sum rho' J^T r,  H = sum rho' J^T J (upper part
+ *   mirrored, row-major 6x6), w = (x, y, z, rx, ry, rz).
+ * The 6-dof trust-region control flow itself stays on the host (it is a
+ * 6x6 solve); see lidarslam_amd/csrc/host/lsa_lm.cpp. */
+int lsa_accumulate(lsa_ctx* ctx, unsigned type_mask, const double w[6], int want_jacobian, double* cost, double g[6],
+                   double H[36], int* n_valid);
+
+/* ------------------------------------------------------------------------- */
+/* Seam 4: undistortion / transforms.                                         */
+
+/* CurrentUndistortedKeypoints = CurrentRawKeypoints (Slam.cxx:984). */
+int lsa_reset_working_keypoints(lsa_ctx* ctx);
+
+/* Slam::RefineUndistortion's per-point loop (Slam.cxx:1342-1351): every point
+ * of every LSA_SET_WORKING type is transformed in place by the pose
+ * interpolated at its `time` between H0 (at t0) and H1 (at t1)
+ * (LinearTransformInterpolator::operator(), MotionModel.h:115-129).
+ * H0/H1 row-major 4x4.  If t0 == t1 or H0 ~ H1 the interpolator is invalid and
+ * H0 is applied to every point, as in the reference. */
+int lsa_undistort(lsa_ctx* ctx, const double H0[16], const double H1[16], double t0, double t1);
+
+/* min/max of the `time` field over the working keypoints (Slam::InitUndistortion,
+ * Slam.cxx:1291-1300) and bounding box of pose * working keypoints of one type
+ * (Slam.cxx:1026-1029). */
+int lsa_working_time_range(lsa_ctx* ctx, double* tmin, double* tmax);
+int lsa_working_bbox(lsa_ctx* ctx, int type, const double pose[16], float mn[3], float mx[3]);
+
+/* Slam::TransformPointCloud (Slam.cxx:1491-1509) on a device keypoint set:
+ * writes pose * set to `out` on the host. */
+int lsa_download_transformed(lsa_ctx* ctx, int set, int type, const double pose[16], lsa_point_t* out, int capacity);
+
+/* Slam::AggregateFrames(frames, true) (Slam.cxx:1512-1578): the whole current
+ * frame to WORLD.  interpolate != 0: per-point pose between H0 (t0) and H1
+ * (t1); else rigid H0. */
+int lsa_transform_frame(lsa_ctx* ctx, int interpolate, const double H0[16], const double H1[16], double t0, double t1,
+                        lsa_point_t* out, int capacity);
+
+/* ------------------------------------------------------------------------- */
+/* Per-kernel timing of the last call sequence (HIP events on the context's   */
+/* stream), for bench.py's roofline block.                                    */
+typedef struct lsa_kernel_stat_t
+{
+  char name[48];
+  uint32_t launches;
+  double total_ms;
+  double bytes;   /* algorithmic bytes summed over the launches */
+} lsa_kernel_stat_t;
+int lsa_profile_enable(lsa_ctx* ctx, int on);
+int lsa_profile_reset(lsa_ctx* ctx);
+int lsa_profile_get(lsa_ctx* ctx, lsa_kernel_stat_t* out, int capacity);
+
+/* ------------------------------------------------------------------------- */
+/* Pipeline level: LidarSlam::Slam behind a C handle (what a ctypes / cgo /
+ * JNI user binds).  Mirrors Slam::AddFrame / GetWorldTransform
+ * -- slam_lib/include/LidarSlam/Slam.h:111-146.                              */
+typedef struct lsa_slam lsa_slam;
+
+int lsa_slam_create(int device_id, lsa_slam** out);
+void lsa_slam_destroy(lsa_slam* s);
+const char* lsa_slam_last_error(const lsa_slam* s);
+/* Generic parameter access by the reference's setter name without "Set",
+ * e.g. "EgoMotion", "Undistortion", "LocalizationICPMaxIter", "NbThreads",
+ * "VoxelGridLeafSizeEdges" ...  Returns LSA_E_ARG for an unknown name. */
+int lsa_slam_set_param(lsa_slam* s, const char* name, double value);
+int lsa_slam_get_param(const lsa_slam* s, const char* name, double* value);
+void lsa_slam_reset(lsa_slam* s, int reset_log);
+/* Slam::AddFrame: frame = host scan, stamp_us = pcl header.stamp, seq = header.seq. */
+int lsa_slam_add_frame(lsa_slam* s, const lsa_point_t* pts, int n, uint64_t stamp_us, uint32_t seq);
+/* Same on a scan already resident in the frame store of the underlying context. */
+int lsa_slam_store_frame(lsa_slam* s, int slot, const lsa_point_t* pts, int n);
+int lsa_slam_add_stored_frame(lsa_slam* s, int slot, uint64_t stamp_us, uint32_t seq);
+/* Slam::GetWorldTransform: row-major 4x4 + time [s]. */
+int lsa_slam_get_world_transform(const lsa_slam* s, double T[16], double* time);
+int lsa_slam_get_covariance(const lsa_slam* s, double cov[36]);
+/* Slam::GetKeypoints(k, world): number of points written. */
+int lsa_slam_get_keypoints(lsa_slam* s, int type, int world, lsa_point_t* out, int capacity);
+/* Slam::GetRegisteredFrame. */
+int lsa_slam_get_registered_frame(lsa_slam* s, lsa_point_t* out, int capacity);
+/* Slam::GetDebugArray entries "EgoMotion: <type> matches" / "Localization: ...". */
+int lsa_slam_get_match_status(lsa_slam* s, int localization, int type, uint8_t* status, double* weights, int capacity);
+/* Slam::GetDebugInformation-like counters and stage timings [s]:
+ * out[0] total, [1] extract, [2] ego_icp, [3] ego_lm, [4] loc_icp, [5] loc_lm,
+ * [6] undistort, [7] submap, [8] maps, [9] ego_iters, [10] loc_iters,
+ * [11] lm_evals, [12] total matched, [13] keyframe counter. */
+int lsa_slam_get_stats(const lsa_slam* s, double out[16]);
+lsa_ctx* lsa_slam_context(lsa_slam* s);
+
+/* ------------------------------------------------------------------------- */
+/* Synthetic spinning-LiDAR sequences; host only, no GPU.      */
+/* model: 16 (VLP-16, 16x1800), 64 (HDL-64, 64x2048), 128 (VLS-128, 128x2048) */
+int lsa_synth_sensor(int model, int* nrings, int* ncols, double* el_min_deg, double* el_max_deg);
+/* Returns the number of points written, -1 unknown model, -2 capacity. */
+int lsa_synth_frame(int model, uint64_t seed, int frame, lsa_point_t* out, int capacity, uint64_t* stamp_us);
+/* Ground-truth BASE pose at the stamp of `frame` relative to frame 0. */
+void lsa_synth_pose(int frame, double T[16]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LIDARSLAM_AMD_H */

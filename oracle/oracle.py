@@ -1,0 +1,252 @@
+"""ORACLE -- TEST INFRASTRUCTURE ONLY.  PARITY UNPINNED (see orc_math.hpp).
+
+ctypes front-end of oracle/liboracle.so, the CPU restatement of the reference's
+scan-matching hot path.  Importable only from tests/, __graft_entry__.smoke()
+and bench.py's cpu_baseline leg; the product never imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB = os.path.join(HERE, "liboracle.so")
+
+import sys
+
+sys.path.insert(0, os.path.dirname(HERE))
+from lidarslam_amd._native import POINT_DTYPE, ExtractParams, MatchParams, ptr, pose16  # noqa: E402
+
+
+def build(force=False):
+    srcs = [os.path.join(HERE, f) for f in os.listdir(HERE) if f.endswith((".cpp", ".hpp"))]
+    srcs += [os.path.join(HERE, "..", "include", f) for f in ("lsa_pmath.h", "lidarslam_amd.h")]
+    if force or not os.path.exists(LIB) or any(os.path.getmtime(s) > os.path.getmtime(LIB) for s in srcs):
+        subprocess.check_call(["make", "-C", HERE, "-s", "-B", "liboracle.so"])
+    return LIB
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB):
+            build()
+        L = C.CDLL(LIB)
+        vp, i32, f64 = C.c_void_p, C.c_int, C.c_double
+        L.orc_extractor_create.restype = vp
+        L.orc_extractor_destroy.argtypes = [vp]
+        L.orc_extractor_set_threads.argtypes = [vp, i32]
+        L.orc_extractor_get_azimuthal_resolution.restype = C.c_float
+        L.orc_extractor_get_azimuthal_resolution.argtypes = [vp]
+        L.orc_extractor_set_azimuthal_resolution.argtypes = [vp, C.c_float]
+        L.orc_extractor_compute.argtypes = [vp, C.POINTER(ExtractParams), vp, i32, vp]
+        L.orc_extractor_keypoints.argtypes = [vp, i32, vp, i32]
+        L.orc_extractor_debug.argtypes = [vp, i32, vp, i32]
+        L.orc_extractor_nb_rings.argtypes = [vp]
+        L.orc_knn.argtypes = [vp, i32, vp, i32, i32, vp, vp, vp]
+        L.orc_knn_brute.argtypes = [vp, i32, vp, i32, i32, vp, vp, vp]
+        L.orc_match.argtypes = [vp, i32, vp, i32, i32, C.POINTER(MatchParams), vp, i32, vp, vp, vp, vp]
+        L.orc_accumulate.argtypes = [vp, vp, i32, f64, vp, i32, vp, vp, vp, vp]
+        L.orc_lm_solve.argtypes = [vp, vp, i32, f64, vp, i32, i32, vp, vp, vp, vp]
+        L.orc_covariance.argtypes = [vp, vp, i32, f64, vp, vp, vp]
+        L.orc_undistort.argtypes = [vp, i32, vp, vp, f64, f64]
+        L.orc_transform.argtypes = [vp, i32, vp]
+        L.orc_slam_create.restype = vp
+        L.orc_slam_destroy.argtypes = [vp]
+        L.orc_slam_reset.argtypes = [vp, i32]
+        L.orc_slam_set_param.argtypes = [vp, C.c_char_p, f64]
+        L.orc_slam_add_frame.argtypes = [vp, vp, i32, C.c_uint64, C.c_uint32]
+        L.orc_slam_get_world_transform.argtypes = [vp, vp, vp]
+        L.orc_slam_get_covariance.argtypes = [vp, vp]
+        L.orc_slam_get_keypoints.argtypes = [vp, i32, i32, vp, i32]
+        L.orc_slam_get_registered_frame.argtypes = [vp, vp, i32]
+        L.orc_slam_get_match_status.argtypes = [vp, i32, i32, vp, vp, i32]
+        L.orc_slam_get_stats.argtypes = [vp, vp]
+        L.orc_slam_get_submap.argtypes = [vp, i32, vp, i32]
+        _lib = L
+    return _lib
+
+
+DEBUG_NAMES = [
+    "sin_angle", "saliency", "depth_gap", "intensity_gap", "edge_keypoint", "plane_keypoint", "blob_keypoint",
+    "edge_validity", "plane_validity", "blob_validity",
+]
+
+
+class Extractor:
+    def __init__(self, threads=1):
+        self.h = lib().orc_extractor_create()
+        lib().orc_extractor_set_threads(self.h, threads)
+        self.n = 0
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_extractor_destroy(self.h)
+            self.h = None
+
+    @property
+    def azimuthal_resolution(self):
+        return lib().orc_extractor_get_azimuthal_resolution(self.h)
+
+    @azimuthal_resolution.setter
+    def azimuthal_resolution(self, v):
+        lib().orc_extractor_set_azimuthal_resolution(self.h, v)
+
+    def compute(self, pts, params=None):
+        params = params or ExtractParams()
+        pts = np.ascontiguousarray(pts)
+        counts = np.zeros(3, np.int32)
+        lib().orc_extractor_compute(self.h, C.byref(params), ptr(pts), pts.size, ptr(counts))
+        self.n = pts.size
+        self.counts = counts
+        return counts
+
+    def keypoints(self, k):
+        out = np.zeros(int(self.counts[k]), POINT_DTYPE)
+        lib().orc_extractor_keypoints(self.h, k, ptr(out), out.size)
+        return out
+
+    def debug(self, i):
+        out = np.zeros(self.n, np.float32)
+        lib().orc_extractor_debug(self.h, i, ptr(out), out.size)
+        return out
+
+    def nb_rings(self):
+        return lib().orc_extractor_nb_rings(self.h)
+
+
+def knn(target, queries, k, brute=False):
+    target = np.ascontiguousarray(target)
+    q = np.ascontiguousarray(queries, np.float64).reshape(-1, 3)
+    idx = np.full((q.shape[0], k), -1, np.int32)
+    d2 = np.zeros((q.shape[0], k), np.float32)
+    cnt = np.zeros(q.shape[0], np.int32)
+    f = lib().orc_knn_brute if brute else lib().orc_knn
+    f(ptr(target), target.size, ptr(q), q.shape[0], k, ptr(idx), ptr(d2), ptr(cnt))
+    return idx, d2, cnt
+
+
+def match(cur, tgt, ktype, mp, pose, threads=1):
+    cur = np.ascontiguousarray(cur)
+    tgt = np.ascontiguousarray(tgt)
+    n = cur.size
+    status = np.zeros(n, np.uint8)
+    weights = np.zeros(n, np.float64)
+    records = np.zeros((n, 16), np.float64)
+    hist = np.zeros(8, np.int32)
+    lib().orc_match(ptr(cur), n, ptr(tgt), tgt.size, ktype, C.byref(mp), ptr(pose16(pose)), threads, ptr(status), ptr(weights),
+                    ptr(records), ptr(hist))
+    return status, weights, records, hist
+
+
+def accumulate(records, status, sat, w, jac=True):
+    records = np.ascontiguousarray(records, np.float64)
+    status = np.ascontiguousarray(status, np.uint8)
+    w = np.ascontiguousarray(w, np.float64)
+    cost = C.c_double()
+    nv = C.c_int()
+    g = np.zeros(6)
+    H = np.zeros((6, 6))
+    lib().orc_accumulate(ptr(records), ptr(status), status.size, sat, ptr(w), int(jac), C.byref(cost), ptr(g), ptr(H), C.byref(nv))
+    return cost.value, g, H, nv.value
+
+
+def lm_solve(records, status, sat, pose, max_iter=15, two_d=False):
+    records = np.ascontiguousarray(records, np.float64)
+    status = np.ascontiguousarray(status, np.uint8)
+    out = np.zeros(16)
+    w = np.zeros(6)
+    summ = np.zeros(4, np.int32)
+    costs = np.zeros(2)
+    lib().orc_lm_solve(ptr(records), ptr(status), status.size, sat, ptr(pose16(pose)), max_iter, int(two_d), ptr(out), ptr(w), ptr(summ),
+                       ptr(costs))
+    return out.reshape(4, 4), w, summ, costs
+
+
+def covariance(records, status, sat, pose):
+    records = np.ascontiguousarray(records, np.float64)
+    status = np.ascontiguousarray(status, np.uint8)
+    cov = np.zeros((6, 6))
+    err = np.zeros(2)
+    lib().orc_covariance(ptr(records), ptr(status), status.size, sat, ptr(pose16(pose)), ptr(cov), ptr(err))
+    return cov, err
+
+
+def undistort(pts, H0, H1, t0, t1):
+    out = np.ascontiguousarray(pts).copy()
+    lib().orc_undistort(ptr(out), out.size, ptr(pose16(H0)), ptr(pose16(H1)), t0, t1)
+    return out
+
+
+def transform(pts, T):
+    out = np.ascontiguousarray(pts).copy()
+    lib().orc_transform(ptr(out), out.size, ptr(pose16(T)))
+    return out
+
+
+class Slam:
+    """Mirror of the product's lidarslam_amd.Slam for the oracle."""
+
+    def __init__(self, **params):
+        self.h = lib().orc_slam_create()
+        for k, v in params.items():
+            self.set_param(k, v)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_slam_destroy(self.h)
+            self.h = None
+
+    def set_param(self, name, value):
+        if lib().orc_slam_set_param(self.h, name.encode(), float(value)) != 0:
+            raise KeyError(name)
+
+    def reset(self, reset_log=True):
+        lib().orc_slam_reset(self.h, int(reset_log))
+
+    def add_frame(self, pts, stamp_us, seq=0):
+        pts = np.ascontiguousarray(pts)
+        self._n = pts.size
+        lib().orc_slam_add_frame(self.h, ptr(pts), pts.size, stamp_us, seq)
+
+    def world_transform(self):
+        T = np.zeros(16)
+        t = C.c_double()
+        lib().orc_slam_get_world_transform(self.h, ptr(T), C.byref(t))
+        return T.reshape(4, 4)
+
+    def covariance(self):
+        c = np.zeros((6, 6))
+        lib().orc_slam_get_covariance(self.h, ptr(c))
+        return c
+
+    def keypoints(self, k, which=0, cap=400000):
+        """which: 0 undistorted BASE, 1 WORLD, 2 raw BASE."""
+        out = np.zeros(cap, POINT_DTYPE)
+        n = lib().orc_slam_get_keypoints(self.h, k, which, ptr(out), cap)
+        return out[:n].copy()
+
+    def registered_frame(self):
+        out = np.zeros(self._n, POINT_DTYPE)
+        n = lib().orc_slam_get_registered_frame(self.h, ptr(out), out.size)
+        return out[:n]
+
+    def match_status(self, localization, k, cap=400000):
+        st = np.zeros(cap, np.uint8)
+        w = np.zeros(cap)
+        n = lib().orc_slam_get_match_status(self.h, int(localization), k, ptr(st), ptr(w), cap)
+        return st[:n].copy(), w[:n].copy()
+
+    def stats(self):
+        o = np.zeros(16)
+        lib().orc_slam_get_stats(self.h, ptr(o))
+        return o
+
+    def submap(self, k, cap=4000000):
+        out = np.zeros(cap, POINT_DTYPE)
+        n = lib().orc_slam_get_submap(self.h, k, ptr(out), cap)
+        return out[:n].copy()

@@ -1,0 +1,376 @@
+// ORACLE -- TEST INFRASTRUCTURE ONLY (see orc_math.hpp header).  PARITY UNPINNED.
+//
+// extern "C" surface of the oracle so that tests/ (ctypes) and bench.py's
+// cpu_baseline leg can drive it.  The POD parameter structs are the ones of
+// include/lidarslam_amd.h so that a test passes the very same bytes to the HIP
+// path and to the oracle.
+#include <cstring>
+#include <string>
+#include <vector>
+#include "../include/lidarslam_amd.h"
+#include "orc_slam.hpp"
+
+using namespace orc;
+static_assert(sizeof(lsa_point_t) == sizeof(Point), "point layout");
+
+namespace
+{
+Iso IsoFromRowMajor(const double T[16])
+{
+  Iso r;
+  for (int i = 0; i < 3; ++i)
+  {
+    for (int j = 0; j < 3; ++j) r.R[i * 3 + j] = T[i * 4 + j];
+    r.t[i] = T[i * 4 + 3];
+  }
+  return r;
+}
+void IsoToRowMajor(const Iso& a, double T[16])
+{
+  for (int i = 0; i < 3; ++i)
+  {
+    for (int j = 0; j < 3; ++j) T[i * 4 + j] = a.R[i * 3 + j];
+    T[i * 4 + 3] = a.t[i];
+  }
+  T[12] = T[13] = T[14] = 0; T[15] = 1;
+}
+void ApplyExtractParams(Extractor& e, const lsa_extract_params_t* p)
+{
+  e.P.NeighborWidth = p->neighbor_width;
+  e.P.MinDistanceToSensor = p->min_distance_to_sensor;
+  e.P.MinBeamSurfaceAngle = p->min_beam_surface_angle;
+  e.P.PlaneSinAngleThreshold = p->plane_sin_angle_threshold;
+  e.P.EdgeSinAngleThreshold = p->edge_sin_angle_threshold;
+  e.P.DistToLineThreshold = p->dist_to_line_threshold;
+  e.P.EdgeDepthGapThreshold = p->edge_depth_gap_threshold;
+  e.P.EdgeSaliencyThreshold = p->edge_saliency_threshold;
+  e.P.EdgeIntensityGapThreshold = p->edge_intensity_gap_threshold;
+}
+MatchParams ToMatchParams(const lsa_match_params_t* p, int nbThreads)
+{
+  MatchParams m;
+  m.NbThreads = nbThreads;
+  m.SingleEdgePerRing = p->single_edge_per_ring != 0;
+  m.MaxNeighborsDistance = p->max_neighbors_distance;
+  m.EdgeNbNeighbors = p->edge_nb_neighbors;
+  m.EdgeMinNbNeighbors = p->edge_min_nb_neighbors;
+  m.EdgeMaxModelError = p->edge_max_model_error;
+  m.PlaneNbNeighbors = p->plane_nb_neighbors;
+  m.PlanarityThreshold = p->planarity_threshold;
+  m.PlaneMaxModelError = p->plane_max_model_error;
+  m.BlobNbNeighbors = p->blob_nb_neighbors;
+  m.SaturationDistance = p->saturation_distance;
+  return m;
+}
+struct ExtractorHandle
+{
+  Extractor e;
+  std::vector<Point> scan;
+};
+struct SlamHandle
+{
+  Slam s;
+  std::vector<Point> frame;
+};
+std::vector<Residual> RecordsToResiduals(const double* records, const uint8_t* status, int n, double sat)
+{
+  std::vector<Residual> out(n);
+  for (int i = 0; i < n; ++i)
+  {
+    if (status[i] != SUCCESS) continue;
+    Residual& r = out[i];
+    r.valid = true;
+    std::memcpy(r.A, records + 16 * i, 9 * sizeof(double));
+    std::memcpy(r.P, records + 16 * i + 9, 3 * sizeof(double));
+    std::memcpy(r.X, records + 16 * i + 12, 3 * sizeof(double));
+    r.weight = records[16 * i + 15];
+    r.sat = sat;
+  }
+  return out;
+}
+}  // namespace
+
+extern "C" {
+
+// ---- extractor ------------------------------------------------------------
+void* orc_extractor_create() { return new ExtractorHandle; }
+void orc_extractor_destroy(void* h) { delete (ExtractorHandle*)h; }
+void orc_extractor_set_threads(void* h, int n) { ((ExtractorHandle*)h)->e.P.NbThreads = n; }
+float orc_extractor_get_azimuthal_resolution(void* h) { return ((ExtractorHandle*)h)->e.AzimuthalResolution; }
+void orc_extractor_set_azimuthal_resolution(void* h, float v) { ((ExtractorHandle*)h)->e.AzimuthalResolution = v; }
+int orc_extractor_compute(void* h, const lsa_extract_params_t* p, const lsa_point_t* pts, int n, int counts[3])
+{
+  ExtractorHandle* eh = (ExtractorHandle*)h;
+  ApplyExtractParams(eh->e, p);
+  eh->scan.assign((const Point*)pts, (const Point*)pts + n);
+  eh->e.ComputeKeyPoints(eh->scan);
+  for (int k = 0; k < 3; ++k) counts[k] = (int)eh->e.Keypoints[k].size();
+  return 0;
+}
+int orc_extractor_keypoints(void* h, int type, lsa_point_t* out, int capacity)
+{
+  const auto& k = ((ExtractorHandle*)h)->e.Keypoints[type];
+  int n = std::min<int>(capacity, k.size());
+  std::memcpy(out, k.data(), n * sizeof(Point));
+  return n;
+}
+int orc_extractor_debug(void* h, int id, float* out, int capacity)
+{
+  std::vector<float> v = ((ExtractorHandle*)h)->e.DebugArray(id);
+  int n = std::min<int>(capacity, v.size());
+  std::memcpy(out, v.data(), n * sizeof(float));
+  return n;
+}
+int orc_extractor_nb_rings(void* h) { return ((ExtractorHandle*)h)->e.NbLaserRings; }
+
+// ---- kNN --------------------------------------------------------------------
+int orc_knn(const lsa_point_t* tgt, int m, const double* queries, int nq, int k, int* idx, float* d2, int* counts)
+{
+  std::vector<Point> cloud((const Point*)tgt, (const Point*)tgt + m);
+  KDTree tree;
+  tree.Reset(&cloud);
+  for (int i = 0; i < nq; ++i)
+    counts[i] = tree.KnnSearch(queries + 3 * i, k, idx + (size_t)i * k, d2 + (size_t)i * k);
+  return 0;
+}
+// brute force with the same (distance, index) order, to check the tree itself
+int orc_knn_brute(const lsa_point_t* tgt, int m, const double* queries, int nq, int k, int* idx, float* d2, int* counts)
+{
+  const Point* c = (const Point*)tgt;
+  std::vector<std::pair<float, int>> all(m);
+  for (int i = 0; i < nq; ++i)
+  {
+    float q[3] = {(float)queries[3 * i], (float)queries[3 * i + 1], (float)queries[3 * i + 2]};
+    for (int j = 0; j < m; ++j) all[j] = {KDTree::Dist2(q, c[j]), j};
+    int kk = std::min(k, m);
+    std::partial_sort(all.begin(), all.begin() + kk, all.end());
+    for (int j = 0; j < kk; ++j) { idx[(size_t)i * k + j] = all[j].second; d2[(size_t)i * k + j] = all[j].first; }
+    counts[i] = kk;
+  }
+  return 0;
+}
+
+// ---- matcher ----------------------------------------------------------------
+int orc_match(const lsa_point_t* cur, int n, const lsa_point_t* tgt, int m, int type, const lsa_match_params_t* mp,
+              const double pose[16], int nbThreads, uint8_t* status, double* weights, double* records, int hist[8])
+{
+  std::vector<Point> c((const Point*)cur, (const Point*)cur + n), t((const Point*)tgt, (const Point*)tgt + m);
+  KDTree tree;
+  tree.Reset(&t);
+  KeypointsMatcher matcher(ToMatchParams(mp, nbThreads), IsoFromRowMajor(pose));
+  MatchingResults r = matcher.BuildMatchResiduals(c, tree, (Keypoint)type);
+  for (int i = 0; i < n; ++i)
+  {
+    status[i] = r.Rejections[i];
+    weights[i] = r.Weights[i];
+    if (records)
+    {
+      double* o = records + 16 * (size_t)i;
+      std::memset(o, 0, 16 * sizeof(double));
+      if (r.Residuals[i].valid)
+      {
+        std::memcpy(o, r.Residuals[i].A, 9 * sizeof(double));
+        std::memcpy(o + 9, r.Residuals[i].P, 3 * sizeof(double));
+        std::memcpy(o + 12, r.Residuals[i].X, 3 * sizeof(double));
+        o[15] = r.Residuals[i].weight;
+      }
+    }
+  }
+  for (int s = 0; s < 8; ++s) hist[s] = r.RejectionsHistogram[s];
+  return 0;
+}
+
+// ---- normal equations / LM -----------------------------------------------------
+int orc_accumulate(const double* records, const uint8_t* status, int n, double sat, const double w[6], int jac, double* cost,
+                   double g[6], double H[36], int* nvalid)
+{
+  std::vector<Residual> res = RecordsToResiduals(records, status, n, sat);
+  NormalEq e;
+  EvaluateResiduals(res.data(), res.size(), w, jac != 0, e);
+  *cost = e.cost;
+  std::memcpy(g, e.g, sizeof(e.g));
+  std::memcpy(H, e.H, sizeof(e.H));
+  *nvalid = e.nValid;
+  return 0;
+}
+// summary[0] num_successful_steps, [1] num_unsuccessful, [2] iterations, [3] evaluations
+int orc_lm_solve(const double* records, const uint8_t* status, int n, double sat, const double pose_in[16], int maxIter,
+                 int twoD, double pose_out[16], double w_out[6], int summary[4], double costs[2])
+{
+  LocalOptimizer opt;
+  opt.SetTwoDMode(twoD != 0);
+  opt.SetLMMaxIter(maxIter);
+  opt.SetPosePrior(IsoFromRowMajor(pose_in));
+  opt.AddResiduals(RecordsToResiduals(records, status, n, sat));
+  LMSummary s = opt.Solve();
+  IsoToRowMajor(opt.GetOptimizedPose(), pose_out);
+  std::memcpy(w_out, opt.GetPoseArray(), 6 * sizeof(double));
+  summary[0] = s.num_successful_steps; summary[1] = s.num_unsuccessful_steps;
+  summary[2] = s.num_iterations; summary[3] = s.num_evaluations;
+  costs[0] = s.initial_cost; costs[1] = s.final_cost;
+  return 0;
+}
+int orc_covariance(const double* records, const uint8_t* status, int n, double sat, const double pose[16], double cov[36], double err[2])
+{
+  LocalOptimizer opt;
+  opt.SetPosePrior(IsoFromRowMajor(pose));
+  opt.AddResiduals(RecordsToResiduals(records, status, n, sat));
+  RegistrationError e = opt.EstimateRegistrationError();
+  std::memcpy(cov, e.Covariance, sizeof(e.Covariance));
+  err[0] = e.PositionError; err[1] = e.OrientationError;
+  return 0;
+}
+
+// ---- undistortion ------------------------------------------------------------------
+int orc_undistort(lsa_point_t* pts, int n, const double H0[16], const double H1[16], double t0, double t1)
+{
+  Interpolator it;
+  it.SetTimes(t0, t1);
+  it.SetTransforms(IsoFromRowMajor(H0), IsoFromRowMajor(H1));
+  Point* p = (Point*)pts;
+  for (int i = 0; i < n; ++i) transform_point(p[i], it(p[i].time));
+  return 0;
+}
+int orc_transform(lsa_point_t* pts, int n, const double T[16])
+{
+  Iso a = IsoFromRowMajor(T);
+  Point* p = (Point*)pts;
+  for (int i = 0; i < n; ++i) transform_point(p[i], a);
+  return 0;
+}
+
+// ---- full pipeline ---------------------------------------------------------------------
+void* orc_slam_create() { return new SlamHandle; }
+void orc_slam_destroy(void* h) { delete (SlamHandle*)h; }
+void orc_slam_reset(void* h, int resetLog) { ((SlamHandle*)h)->s.Reset(resetLog != 0); }
+int orc_slam_set_param(void* h, const char* name, double v)
+{
+  Slam& s = ((SlamHandle*)h)->s;
+  std::string n(name);
+#define P(NAME, EXPR) if (n == NAME) { EXPR; return 0; }
+  P("NbThreads", s.NbThreads = (int)v)
+  P("UseBlobs", s.UseKeypoints[BLOB] = v != 0)
+  P("EgoMotion", s.EgoMotion = (EgoMotionMode)(int)v)
+  P("Undistortion", s.Undistortion = (UndistortionMode)(int)v)
+  P("TwoDMode", s.TwoDMode = v != 0)
+  P("EgoMotionICPMaxIter", s.EgoMotionICPMaxIter = (unsigned)v)
+  P("LocalizationICPMaxIter", s.LocalizationICPMaxIter = (unsigned)v)
+  P("EgoMotionLMMaxIter", s.EgoMotionLMMaxIter = (unsigned)v)
+  P("LocalizationLMMaxIter", s.LocalizationLMMaxIter = (unsigned)v)
+  P("EgoMotionMaxNeighborsDistance", s.EgoMotionMaxNeighborsDistance = v)
+  P("LocalizationMaxNeighborsDistance", s.LocalizationMaxNeighborsDistance = v)
+  P("EgoMotionEdgeNbNeighbors", s.EgoMotionEdgeNbNeighbors = (unsigned)v)
+  P("EgoMotionEdgeMinNbNeighbors", s.EgoMotionEdgeMinNbNeighbors = (unsigned)v)
+  P("EgoMotionEdgeMaxModelError", s.EgoMotionEdgeMaxModelError = v)
+  P("EgoMotionPlaneNbNeighbors", s.EgoMotionPlaneNbNeighbors = (unsigned)v)
+  P("EgoMotionPlanarityThreshold", s.EgoMotionPlanarityThreshold = v)
+  P("EgoMotionPlaneMaxModelError", s.EgoMotionPlaneMaxModelError = v)
+  P("EgoMotionInitSaturationDistance", s.EgoMotionInitSaturationDistance = v)
+  P("EgoMotionFinalSaturationDistance", s.EgoMotionFinalSaturationDistance = v)
+  P("LocalizationEdgeNbNeighbors", s.LocalizationEdgeNbNeighbors = (unsigned)v)
+  P("LocalizationEdgeMinNbNeighbors", s.LocalizationEdgeMinNbNeighbors = (unsigned)v)
+  P("LocalizationEdgeMaxModelError", s.LocalizationEdgeMaxModelError = v)
+  P("LocalizationPlaneNbNeighbors", s.LocalizationPlaneNbNeighbors = (unsigned)v)
+  P("LocalizationPlanarityThreshold", s.LocalizationPlanarityThreshold = v)
+  P("LocalizationPlaneMaxModelError", s.LocalizationPlaneMaxModelError = v)
+  P("LocalizationBlobNbNeighbors", s.LocalizationBlobNbNeighbors = (unsigned)v)
+  P("LocalizationInitSaturationDistance", s.LocalizationInitSaturationDistance = v)
+  P("LocalizationFinalSaturationDistance", s.LocalizationFinalSaturationDistance = v)
+  P("MaxExtrapolationRatio", s.MaxExtrapolationRatio = v)
+  P("MinNbMatchedKeypoints", s.MinNbMatchedKeypoints = (unsigned)v)
+  P("KfDistanceThreshold", s.KfDistanceThreshold = v)
+  P("KfAngleThreshold", s.KfAngleThreshold = v)
+  P("MapUpdate", s.MapUpdate = (MappingMode)(int)v)
+  P("VoxelGridLeafSizeEdges", s.LocalMaps[EDGE]->SetLeafSize(v))
+  P("VoxelGridLeafSizePlanes", s.LocalMaps[PLANE]->SetLeafSize(v))
+  P("VoxelGridLeafSizeBlobs", s.LocalMaps[BLOB]->SetLeafSize(v))
+  P("VoxelGridSize", for (int k = 0; k < 3; ++k) s.LocalMaps[k]->SetGridSize((int)v))
+  P("VoxelGridResolution", for (int k = 0; k < 3; ++k) s.LocalMaps[k]->SetVoxelResolution(v))
+  P("VoxelGridMinFramesPerVoxel", for (int k = 0; k < 3; ++k) s.LocalMaps[k]->SetMinFramesPerVoxel((unsigned)v))
+  P("VoxelGridDecayingThreshold", for (int k = 0; k < 3; ++k) s.LocalMaps[k]->SetDecayingThreshold(v))
+  P("VoxelGridSamplingMode", for (int k = 0; k < 3; ++k) s.LocalMaps[k]->SetSampling((SamplingMode)(int)v))
+  P("NeighborWidth", s.KeyPointsExtractor.P.NeighborWidth = (int)v)
+  P("MinDistanceToSensor", s.KeyPointsExtractor.P.MinDistanceToSensor = (float)v)
+  P("MinBeamSurfaceAngle", s.KeyPointsExtractor.P.MinBeamSurfaceAngle = (float)v)
+  P("PlaneSinAngleThreshold", s.KeyPointsExtractor.P.PlaneSinAngleThreshold = (float)v)
+  P("EdgeSinAngleThreshold", s.KeyPointsExtractor.P.EdgeSinAngleThreshold = (float)v)
+  P("EdgeDepthGapThreshold", s.KeyPointsExtractor.P.EdgeDepthGapThreshold = (float)v)
+  P("EdgeSaliencyThreshold", s.KeyPointsExtractor.P.EdgeSaliencyThreshold = (float)v)
+  P("EdgeIntensityGapThreshold", s.KeyPointsExtractor.P.EdgeIntensityGapThreshold = (float)v)
+  P("AzimuthalResolution", s.KeyPointsExtractor.AzimuthalResolution = (float)v)
+#undef P
+  return -3;
+}
+int orc_slam_add_frame(void* h, const lsa_point_t* pts, int n, uint64_t stampUs, uint32_t seq)
+{
+  SlamHandle* sh = (SlamHandle*)h;
+  std::vector<Point> f((const Point*)pts, (const Point*)pts + n);
+  // the frame must outlive the call (GetRegisteredFrame reads it lazily)
+  sh->frame.swap(f);
+  sh->s.AddFrame(sh->frame, stampUs, seq);
+  return 0;
+}
+int orc_slam_get_world_transform(void* h, double T[16], double* time)
+{
+  Slam& s = ((SlamHandle*)h)->s;
+  IsoToRowMajor(s.GetWorldTransform(), T);
+  if (time) *time = s.LogTrajectory.empty() ? 0. : s.LogTrajectory.back().time;
+  return 0;
+}
+int orc_slam_get_covariance(void* h, double cov[36])
+{
+  std::memcpy(cov, ((SlamHandle*)h)->s.GetTransformCovariance(), 36 * sizeof(double));
+  return 0;
+}
+int orc_slam_get_keypoints(void* h, int type, int which, lsa_point_t* out, int capacity)
+{
+  Slam& s = ((SlamHandle*)h)->s;
+  std::vector<Point> world;
+  const std::vector<Point>* src;
+  if (which == 0) src = &s.CurrentUndistortedKeypoints[type];
+  else if (which == 2) src = &s.CurrentRawKeypoints[type];
+  else
+  {
+    world = s.CurrentUndistortedKeypoints[type];
+    for (auto& p : world) transform_point(p, s.Tworld);
+    src = &world;
+  }
+  int n = std::min<int>(capacity, src->size());
+  std::memcpy(out, src->data(), n * sizeof(Point));
+  return n;
+}
+int orc_slam_get_registered_frame(void* h, lsa_point_t* out, int capacity)
+{
+  std::vector<Point> f = ((SlamHandle*)h)->s.GetRegisteredFrame();
+  int n = std::min<int>(capacity, f.size());
+  std::memcpy(out, f.data(), n * sizeof(Point));
+  return n;
+}
+int orc_slam_get_match_status(void* h, int localization, int type, uint8_t* status, double* weights, int capacity)
+{
+  Slam& s = ((SlamHandle*)h)->s;
+  if (!localization && type > 1) return 0;
+  const MatchingResults& r = localization ? s.LocalizationMatchingResults[type] : s.EgoMotionMatchingResults[type];
+  int n = std::min<int>(capacity, r.Rejections.size());
+  for (int i = 0; i < n; ++i) { status[i] = r.Rejections[i]; weights[i] = r.Weights[i]; }
+  return n;
+}
+int orc_slam_get_stats(void* h, double out[16])
+{
+  Slam& s = ((SlamHandle*)h)->s;
+  const StageTimes& t = s.Times;
+  double v[16] = {t.total, t.extract, t.ego_icp, t.ego_lm, t.loc_icp, t.loc_lm, t.undistort, t.submap, t.maps,
+                  (double)t.ego_iters, (double)t.loc_iters, (double)t.lm_evals, (double)s.TotalMatchedKeypoints, (double)s.KfCounter,
+                  0, 0};
+  std::memcpy(out, v, sizeof(v));
+  return 0;
+}
+int orc_slam_get_submap(void* h, int type, lsa_point_t* out, int capacity)
+{
+  const std::vector<Point>& m = ((SlamHandle*)h)->s.LocalMaps[type]->GetSubMap();
+  int n = std::min<int>(capacity, m.size());
+  std::memcpy(out, m.data(), n * sizeof(Point));
+  return n;
+}
+
+}  // extern "C"

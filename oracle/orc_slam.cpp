@@ -1,0 +1,415 @@
+// ORACLE -- TEST INFRASTRUCTURE ONLY (see orc_math.hpp header).  PARITY UNPINNED.
+//
+// CPU restatement of slam_lib/src/Slam.cxx (hot-path subset, see orc_slam.hpp).
+#include "orc_slam.hpp"
+#include <chrono>
+#include <cstdio>
+
+namespace orc
+{
+namespace
+{
+struct Tick
+{
+  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+  double Stop() const { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
+};
+inline double StampToSec(uint64_t us) { return us * 1e-6; }
+}  // namespace
+
+// Slam.cxx:143-161
+Slam::Slam()
+{
+  for (int k = 0; k < 3; ++k) LocalMaps[k] = std::make_shared<RollingGrid>();
+  for (int k = 0; k < 3; ++k) LocalMaps[k]->SetVoxelResolution(10.);
+  for (int k = 0; k < 3; ++k) LocalMaps[k]->SetGridSize(50);
+  LocalMaps[EDGE]->SetLeafSize(0.30);
+  LocalMaps[PLANE]->SetLeafSize(0.60);
+  LocalMaps[BLOB]->SetLeafSize(0.30);
+  Reset();
+}
+
+// Slam.cxx:164-210
+void Slam::Reset(bool resetLog)
+{
+  for (int k = 0; k < 3; ++k) LocalMaps[k]->Reset();
+  KfLastPose = iso_identity();
+  KfCounter = 0;
+  Tworld = PreviousTworld = Trelative = iso_identity();
+  WithinFrameMotion.SetTransforms(iso_identity(), iso_identity());
+  LocalizationUncertainty = RegistrationError();
+  CurrentFrame = nullptr;
+  CurrentStamp = 0;  // the "previous" frame after a reset is an empty cloud with stamp 0
+  for (int k = 0; k < 3; ++k)
+  {
+    CurrentRawKeypoints[k].clear();
+    CurrentUndistortedKeypoints[k].clear();
+    CurrentWorldKeypoints[k].clear();
+  }
+  for (int k = 0; k < 2; ++k) EgoMotionMatchingResults[k] = MatchingResults();
+  for (int k = 0; k < 3; ++k) LocalizationMatchingResults[k] = MatchingResults();
+  if (resetLog)
+  {
+    NbrFrameProcessed = 0;
+    LogTrajectory.clear();
+  }
+}
+
+// Slam.cxx:709-743
+bool Slam::CheckFrame(const std::vector<Point>& frame, uint64_t stampUs)
+{
+  if (frame.empty())
+    return false;
+  if (stampUs == CurrentStamp)
+    return false;
+  return true;
+}
+
+// Slam.cxx:230-344
+void Slam::AddFrame(const std::vector<Point>& frame, uint64_t stampUs, unsigned)
+{
+  Tick total;
+  Times = StageTimes();
+  if (!CheckFrame(frame, stampUs))
+    return;
+  CurrentFrame = &frame;
+  CurrentStamp = stampUs;
+  CurrentTime = StampToSec(stampUs);
+
+  { Tick t; ExtractKeypoints(); Times.extract = t.Stop(); }
+  ComputeEgoMotion();
+  Localization();
+  if (MapUpdate == MappingMode::ADD_KPTS_TO_FIXED_MAP || MapUpdate == MappingMode::UPDATE)
+  {
+    Tick t;
+    UpdateMapsUsingTworld();
+    Times.maps = t.Stop();
+  }
+  LogCurrentFrameState(CurrentTime);
+  NbrFrameProcessed++;
+  Times.total = total.Stop();
+}
+
+// Slam.cxx:1512-1578 with worldCoordinates == false
+std::vector<Point> Slam::AggregateKeypoints(const std::vector<Point>& kpts) const
+{
+  std::vector<Point> out = kpts;
+  const double timeOffset = 0.;  // single frame: frame stamp == aggregated stamp
+  if (iso_is_approx(BaseToLidarOffset, iso_identity()))
+  {
+    for (auto& p : out) p.time += timeOffset;
+  }
+  else
+  {
+    for (auto& p : out)
+    {
+      p.time += timeOffset;
+      transform_point(p, BaseToLidarOffset);
+    }
+  }
+  return out;
+}
+
+// Slam.cxx:746-810
+void Slam::ExtractKeypoints()
+{
+  for (int k = 0; k < 3; ++k) PreviousRawKeypoints[k] = std::move(CurrentRawKeypoints[k]);
+  KeyPointsExtractor.P.NbThreads = NbThreads;
+  KeyPointsExtractor.ComputeKeyPoints(*CurrentFrame);
+  for (int k = 0; k < 3; ++k)
+  {
+    if (UseKeypoints[k])
+      CurrentRawKeypoints[k] = AggregateKeypoints(KeyPointsExtractor.Keypoints[k]);
+    else
+      CurrentRawKeypoints[k].clear();
+  }
+}
+
+// Slam.cxx:813-972
+void Slam::ComputeEgoMotion()
+{
+  Trelative = iso_identity();
+  if (LogTrajectory.size() >= 2 &&
+      (EgoMotion == EgoMotionMode::MOTION_EXTRAPOLATION || EgoMotion == EgoMotionMode::MOTION_EXTRAPOLATION_AND_REGISTRATION))
+  {
+    const double t = StampToSec(CurrentStamp);
+    const double t1 = LogTrajectory[LogTrajectory.size() - 1].time;
+    const double t0 = LogTrajectory[LogTrajectory.size() - 2].time;
+    if (!(std::abs((t - t1) / (t1 - t0)) > MaxExtrapolationRatio))
+    {
+      Iso next = linear_interpolation(PreviousTworld, Tworld, t, t0, t1);
+      Trelative = iso_mul(iso_inverse(Tworld), next);
+    }
+  }
+
+  if (EgoMotion == EgoMotionMode::REGISTRATION || EgoMotion == EgoMotionMode::MOTION_EXTRAPOLATION_AND_REGISTRATION)
+  {
+    for (int k : {EDGE, PLANE}) EgoTrees[k].Reset(&PreviousRawKeypoints[k]);
+    TotalMatchedKeypoints = 0;
+
+    MatchParams mp;
+    mp.NbThreads = NbThreads;
+    mp.SingleEdgePerRing = true;
+    mp.MaxNeighborsDistance = EgoMotionMaxNeighborsDistance;
+    mp.EdgeNbNeighbors = EgoMotionEdgeNbNeighbors;
+    mp.EdgeMinNbNeighbors = EgoMotionEdgeMinNbNeighbors;
+    mp.EdgeMaxModelError = EgoMotionEdgeMaxModelError;
+    mp.PlaneNbNeighbors = EgoMotionPlaneNbNeighbors;
+    mp.PlanarityThreshold = EgoMotionPlanarityThreshold;
+    mp.PlaneMaxModelError = EgoMotionPlaneMaxModelError;
+
+    for (unsigned icpIter = 0; icpIter < EgoMotionICPMaxIter; ++icpIter)
+    {
+      Tick ticp;
+      double iterRatio = icpIter / static_cast<double>(EgoMotionICPMaxIter - 1);
+      mp.SaturationDistance = (1 - iterRatio) * EgoMotionInitSaturationDistance + iterRatio * EgoMotionFinalSaturationDistance;
+      KeypointsMatcher matcher(mp, Trelative);
+      for (int k : {EDGE, PLANE})
+        EgoMotionMatchingResults[k] = matcher.BuildMatchResiduals(CurrentRawKeypoints[k], EgoTrees[k], (Keypoint)k);
+      TotalMatchedKeypoints = 0;
+      for (int k : {EDGE, PLANE}) TotalMatchedKeypoints += EgoMotionMatchingResults[k].NbMatches();
+      Times.ego_icp += ticp.Stop();
+      Times.ego_iters++;
+      if (TotalMatchedKeypoints < MinNbMatchedKeypoints)
+        break;
+
+      Tick tlm;
+      LocalOptimizer optimizer;
+      optimizer.SetTwoDMode(TwoDMode);
+      optimizer.SetPosePrior(Trelative);
+      optimizer.SetLMMaxIter(EgoMotionLMMaxIter);
+      optimizer.SetNbThreads(NbThreads);
+      for (int k : {EDGE, PLANE}) optimizer.AddResiduals(EgoMotionMatchingResults[k].Residuals);
+      LMSummary summary = optimizer.Solve();
+      Trelative = optimizer.GetOptimizedPose();
+      Times.ego_lm += tlm.Stop();
+      Times.lm_evals += summary.num_evaluations;
+      if (summary.num_successful_steps == 1)
+        break;
+    }
+  }
+}
+
+// Slam.cxx:975-1175
+void Slam::Localization()
+{
+  PreviousTworld = Tworld;
+  Tworld = iso_mul(PreviousTworld, Trelative);
+  for (int k = 0; k < 3; ++k) CurrentUndistortedKeypoints[k] = CurrentRawKeypoints[k];
+
+  if (Undistortion)
+  {
+    Tick t;
+    InitUndistortion();
+    RefineUndistortion();
+    Times.undistort += t.Stop();
+  }
+
+  {
+    Tick t;
+    for (int k = 0; k < 3; ++k)
+    {
+      if (UseKeypoints[k] && !LocalMaps[k]->IsSubMapKdTreeValid())
+      {
+        if (MapUpdate == MappingMode::NONE)
+          LocalMaps[k]->BuildSubMapKdTree();
+        else
+        {
+          if (LocalMaps[k]->IsTimeThreshold())
+            LocalMaps[k]->ClearOldPoints(CurrentTime);
+          std::vector<Point> currWorld = CurrentUndistortedKeypoints[k];
+          float mn[3], mx[3];
+          for (int i = 0; i < 3; ++i) { mn[i] = std::numeric_limits<float>::max(); mx[i] = -std::numeric_limits<float>::max(); }
+          for (auto& p : currWorld)
+          {
+            transform_point(p, Tworld);
+            const float v[3] = {p.x, p.y, p.z};
+            for (int i = 0; i < 3; ++i) { mn[i] = std::min(mn[i], v[i]); mx[i] = std::max(mx[i], v[i]); }
+          }
+          LocalMaps[k]->BuildSubMapKdTree(mn, mx, currWorld.size() / 2);
+        }
+      }
+    }
+    Times.submap += t.Stop();
+  }
+
+  TotalMatchedKeypoints = 0;
+  MatchParams mp;
+  mp.NbThreads = NbThreads;
+  mp.SingleEdgePerRing = false;
+  mp.MaxNeighborsDistance = LocalizationMaxNeighborsDistance;
+  mp.EdgeNbNeighbors = LocalizationEdgeNbNeighbors;
+  mp.EdgeMinNbNeighbors = LocalizationEdgeMinNbNeighbors;
+  mp.EdgeMaxModelError = LocalizationEdgeMaxModelError;
+  mp.PlaneNbNeighbors = LocalizationPlaneNbNeighbors;
+  mp.PlanarityThreshold = LocalizationPlanarityThreshold;
+  mp.PlaneMaxModelError = LocalizationPlaneMaxModelError;
+  mp.BlobNbNeighbors = LocalizationBlobNbNeighbors;
+
+  for (unsigned icpIter = 0; icpIter < LocalizationICPMaxIter; ++icpIter)
+  {
+    Tick ticp;
+    double iterRatio = icpIter / static_cast<double>(LocalizationICPMaxIter - 1);
+    mp.SaturationDistance = (1 - iterRatio) * LocalizationInitSaturationDistance + iterRatio * LocalizationFinalSaturationDistance;
+    KeypointsMatcher matcher(mp, Tworld);
+    for (int k = 0; k < 3; ++k)
+      LocalizationMatchingResults[k] = matcher.BuildMatchResiduals(CurrentUndistortedKeypoints[k], LocalMaps[k]->GetSubMapKdTree(), (Keypoint)k);
+    TotalMatchedKeypoints = 0;
+    for (int k = 0; k < 3; ++k) TotalMatchedKeypoints += LocalizationMatchingResults[k].NbMatches();
+    Times.loc_icp += ticp.Stop();
+    Times.loc_iters++;
+
+    if (TotalMatchedKeypoints < MinNbMatchedKeypoints)
+    {
+      Trelative = iso_identity();
+      Tworld = PreviousTworld;
+      if (Undistortion)
+        WithinFrameMotion.SetTransforms(iso_identity(), iso_identity());
+      break;
+    }
+
+    Tick tlm;
+    LocalOptimizer optimizer;
+    optimizer.SetTwoDMode(TwoDMode);
+    optimizer.SetPosePrior(Tworld);
+    optimizer.SetLMMaxIter(LocalizationLMMaxIter);
+    optimizer.SetNbThreads(NbThreads);
+    for (int k = 0; k < 3; ++k) optimizer.AddResiduals(LocalizationMatchingResults[k].Residuals);
+    LMSummary summary = optimizer.Solve();
+    Times.lm_evals += summary.num_evaluations;
+    Tworld = optimizer.GetOptimizedPose();
+    Trelative = iso_mul(iso_inverse(PreviousTworld), Tworld);
+    if (Undistortion == UNDIST_REFINED)
+      RefineUndistortion();
+    Times.loc_lm += tlm.Stop();
+
+    if ((summary.num_successful_steps == 1) || (icpIter == LocalizationICPMaxIter - 1))
+    {
+      LocalizationUncertainty = optimizer.EstimateRegistrationError();
+      break;
+    }
+  }
+}
+
+// Slam.cxx:1178-1222
+void Slam::UpdateMapsUsingTworld()
+{
+  Iso motionSinceLastKf = iso_mul(iso_inverse(KfLastPose), Tworld);
+  double transSinceLastKf = std::sqrt((motionSinceLastKf.t[0] * motionSinceLastKf.t[0] + motionSinceLastKf.t[1] * motionSinceLastKf.t[1]) +
+                                      motionSinceLastKf.t[2] * motionSinceLastKf.t[2]);
+  // Eigen::AngleAxisd(R).angle(): 2 atan2(|q.vec|, |q.w|)
+  Quat q = quat_from_matrix(motionSinceLastKf.R);
+  double n = std::sqrt((q.x * q.x + q.y * q.y) + q.z * q.z);
+  double rotSinceLastKf = (n != 0.) ? 2. * std::atan2(n, std::abs(q.w)) : 0.;
+
+  constexpr double MIN_KF_NB = 10.;
+  double thresholdCoef = std::min(KfCounter / MIN_KF_NB, 1.);
+  unsigned nbMapKpts = 0;
+  for (int k = 0; k < 3; ++k) nbMapKpts += LocalMaps[k]->Size();
+  bool isNewKeyFrame = nbMapKpts < MinNbMatchedKeypoints * 10 || transSinceLastKf >= thresholdCoef * KfDistanceThreshold ||
+                       rotSinceLastKf >= (thresholdCoef * KfAngleThreshold) / 180. * M_PI;
+  if (!isNewKeyFrame)
+    return;
+  KfCounter++;
+  KfLastPose = Tworld;
+  for (int k = 0; k < 3; ++k)
+  {
+    CurrentWorldKeypoints[k] = CurrentUndistortedKeypoints[k];
+    for (auto& p : CurrentWorldKeypoints[k]) transform_point(p, Tworld);
+  }
+  for (int k = 0; k < 3; ++k)
+    if (UseKeypoints[k])
+      LocalMaps[k]->Add(CurrentWorldKeypoints[k], false, CurrentTime);
+}
+
+// Slam.cxx:1225-1264 with LoggingTimeout == 0 (default): keep the last two poses
+void Slam::LogCurrentFrameState(double time)
+{
+  LogTrajectory.push_back({Tworld, time});
+  while (LogTrajectory.size() > 2) LogTrajectory.pop_front();
+}
+
+// Slam.cxx:1271-1285
+Iso Slam::InterpolateScanPose(double time)
+{
+  if (LogTrajectory.empty())
+    return Tworld;
+  const double prevPoseTime = LogTrajectory.back().time;
+  const double currPoseTime = StampToSec(CurrentStamp);
+  if (std::abs(time / (currPoseTime - prevPoseTime)) > MaxExtrapolationRatio)
+    return Tworld;
+  return linear_interpolation(PreviousTworld, Tworld, currPoseTime + time, prevPoseTime, currPoseTime);
+}
+
+// Slam.cxx:1288-1319
+void Slam::InitUndistortion()
+{
+  double frameFirstTime = std::numeric_limits<double>::max();
+  double frameLastTime = std::numeric_limits<double>::lowest();
+  for (int k = 0; k < 3; ++k)
+    for (const auto& p : CurrentUndistortedKeypoints[k])
+    {
+      frameFirstTime = std::min(frameFirstTime, p.time);
+      frameLastTime = std::max(frameLastTime, p.time);
+    }
+  WithinFrameMotion.SetTimes(frameFirstTime, frameLastTime);
+  WithinFrameMotion.SetTransforms(iso_identity(), iso_identity());
+  if (WithinFrameMotion.GetTimeRange() < 1e-6)
+    WithinFrameMotion.SetTimes(0., 0.);
+}
+
+// Slam.cxx:1322-1352
+void Slam::RefineUndistortion()
+{
+  Iso previousBaseBegin = WithinFrameMotion.GetH0();
+  Iso previousBaseEnd = WithinFrameMotion.GetH1();
+  Iso worldToBaseBegin = InterpolateScanPose(WithinFrameMotion.Time0);
+  Iso worldToBaseEnd = InterpolateScanPose(WithinFrameMotion.Time1);
+  Iso baseToWorld = iso_inverse(Tworld);
+  Iso newBaseBegin = iso_mul(baseToWorld, worldToBaseBegin);
+  Iso newBaseEnd = iso_mul(baseToWorld, worldToBaseEnd);
+  WithinFrameMotion.SetTransforms(newBaseBegin, newBaseEnd);
+
+  Interpolator interp = WithinFrameMotion;
+  interp.SetTransforms(iso_mul(newBaseBegin, iso_inverse(previousBaseBegin)), iso_mul(newBaseEnd, iso_inverse(previousBaseEnd)));
+  for (int k = 0; k < 3; ++k)
+  {
+    int nb = CurrentUndistortedKeypoints[k].size();
+    #pragma omp parallel for num_threads(NbThreads)
+    for (int i = 0; i < nb; ++i)
+    {
+      Point& p = CurrentUndistortedKeypoints[k][i];
+      transform_point(p, interp(p.time));
+    }
+  }
+}
+
+// Slam.cxx:660-667 + 1512-1578 with worldCoordinates == true
+std::vector<Point> Slam::GetRegisteredFrame()
+{
+  std::vector<Point> out;
+  if (!CurrentFrame) return out;
+  out = *CurrentFrame;
+  if (Undistortion)
+  {
+    Interpolator interp = WithinFrameMotion;
+    interp.SetTransforms(iso_mul(iso_mul(Tworld, WithinFrameMotion.GetH0()), BaseToLidarOffset),
+                         iso_mul(iso_mul(Tworld, WithinFrameMotion.GetH1()), BaseToLidarOffset));
+    int nb = out.size();
+    #pragma omp parallel for num_threads(NbThreads)
+    for (int i = 0; i < nb; ++i) transform_point(out[i], interp(out[i].time));
+  }
+  else
+  {
+    Iso tf = iso_mul(Tworld, BaseToLidarOffset);
+    if (!iso_is_approx(tf, iso_identity()))
+    {
+      int nb = out.size();
+      #pragma omp parallel for num_threads(NbThreads)
+      for (int i = 0; i < nb; ++i) transform_point(out[i], tf);
+    }
+  }
+  return out;
+}
+
+}  // namespace orc

@@ -1,0 +1,110 @@
+// ORACLE -- TEST INFRASTRUCTURE ONLY (see orc_math.hpp header).  PARITY UNPINNED.
+//
+// CPU restatement of the per-frame pipeline of LidarSlam::Slam
+//   slam_lib/src/Slam.cxx:143-210 (ctor/Reset), 230-344 (AddFrames), 709-810
+//   (CheckFrames, ExtractKeypoints), 813-972 (ComputeEgoMotion), 975-1175
+//   (Localization), 1178-1264 (maps update, logging), 1271-1352 (undistortion),
+//   1491-1578 (transform helpers); defaults slam_lib/include/LidarSlam/Slam.h:403-694.
+// One LiDAR device per call (AddFrame); sensor constraints, pose graph, PCD IO,
+// overlap estimator and motion limits are outside the hot path.
+#pragma once
+#include <deque>
+#include <map>
+#include <memory>
+#include <string>
+#include "orc_math.hpp"
+#include "orc_extractor.hpp"
+#include "orc_matcher.hpp"
+#include "orc_lm.hpp"
+#include "orc_rolling_grid.hpp"
+
+namespace orc
+{
+
+enum UndistortionMode { UNDIST_NONE = 0, UNDIST_ONCE = 1, UNDIST_REFINED = 2 };
+enum class EgoMotionMode { NONE = 0, MOTION_EXTRAPOLATION = 1, REGISTRATION = 2, MOTION_EXTRAPOLATION_AND_REGISTRATION = 3 };
+enum class MappingMode { NONE = 0, ADD_KPTS_TO_FIXED_MAP = 1, UPDATE = 2 };
+
+struct StampedPose { Iso pose; double time; };
+
+// wall-clock seconds per stage, placed like the reference's Utils::Timer calls
+struct StageTimes
+{
+  double total = 0, extract = 0, ego_icp = 0, ego_lm = 0, loc_icp = 0, loc_lm = 0, undistort = 0, submap = 0, maps = 0;
+  int ego_iters = 0, loc_iters = 0, lm_evals = 0;
+};
+
+class Slam
+{
+public:
+  Slam();
+  void Reset(bool resetLog = true);
+  void AddFrame(const std::vector<Point>& frame, uint64_t stampUs, unsigned seq = 0);
+
+  Iso GetWorldTransform() const { return LogTrajectory.empty() ? iso_identity() : LogTrajectory.back().pose; }
+  const double* GetTransformCovariance() const { return LocalizationUncertainty.Covariance; }
+
+  // parameters (Slam.h:403-694)
+  int NbThreads = 1;
+  bool UseKeypoints[3] = {true, true, false};
+  EgoMotionMode EgoMotion = EgoMotionMode::MOTION_EXTRAPOLATION;
+  UndistortionMode Undistortion = UNDIST_REFINED;
+  bool TwoDMode = false;
+  unsigned EgoMotionICPMaxIter = 4, LocalizationICPMaxIter = 3;
+  unsigned EgoMotionLMMaxIter = 15, LocalizationLMMaxIter = 15;
+  double EgoMotionMaxNeighborsDistance = 5., LocalizationMaxNeighborsDistance = 5.;
+  unsigned EgoMotionEdgeNbNeighbors = 8, EgoMotionEdgeMinNbNeighbors = 3;
+  double EgoMotionEdgeMaxModelError = 0.2;
+  unsigned LocalizationEdgeNbNeighbors = 10, LocalizationEdgeMinNbNeighbors = 4;
+  double LocalizationEdgeMaxModelError = 0.2;
+  unsigned EgoMotionPlaneNbNeighbors = 5;
+  double EgoMotionPlanarityThreshold = 0.04, EgoMotionPlaneMaxModelError = 0.2;
+  unsigned LocalizationPlaneNbNeighbors = 5;
+  double LocalizationPlanarityThreshold = 0.04, LocalizationPlaneMaxModelError = 0.2;
+  unsigned LocalizationBlobNbNeighbors = 10;
+  double EgoMotionInitSaturationDistance = 5., EgoMotionFinalSaturationDistance = 1.;
+  double LocalizationInitSaturationDistance = 2., LocalizationFinalSaturationDistance = 0.5;
+  double MaxExtrapolationRatio = 3.;
+  unsigned MinNbMatchedKeypoints = 20;
+  double KfDistanceThreshold = 0.5, KfAngleThreshold = 5.;
+  MappingMode MapUpdate = MappingMode::UPDATE;
+  Iso BaseToLidarOffset = iso_identity();
+
+  Extractor KeyPointsExtractor;
+  std::shared_ptr<RollingGrid> LocalMaps[3];
+
+  // state readable by the tests
+  Iso Tworld, PreviousTworld, Trelative;
+  std::vector<Point> CurrentRawKeypoints[3], PreviousRawKeypoints[3], CurrentUndistortedKeypoints[3], CurrentWorldKeypoints[3];
+  MatchingResults EgoMotionMatchingResults[2], LocalizationMatchingResults[3];
+  RegistrationError LocalizationUncertainty;
+  unsigned TotalMatchedKeypoints = 0;
+  unsigned NbrFrameProcessed = 0;
+  int KfCounter = 0;
+  StageTimes Times;
+  std::deque<StampedPose> LogTrajectory;
+
+  std::vector<Point> GetRegisteredFrame();
+
+private:
+  bool CheckFrame(const std::vector<Point>& frame, uint64_t stampUs);
+  void ExtractKeypoints();
+  void ComputeEgoMotion();
+  void Localization();
+  void UpdateMapsUsingTworld();
+  void LogCurrentFrameState(double time);
+  Iso InterpolateScanPose(double time);
+  void InitUndistortion();
+  void RefineUndistortion();
+  std::vector<Point> AggregateKeypoints(const std::vector<Point>& kpts) const;
+
+  const std::vector<Point>* CurrentFrame = nullptr;
+  uint64_t CurrentStamp = 0;
+  bool HasFrame = false;
+  double CurrentTime = 0.;
+  Interpolator WithinFrameMotion;
+  Iso KfLastPose;
+  KDTree EgoTrees[2];
+};
+
+}  // namespace orc

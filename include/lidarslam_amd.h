@@ -126,6 +126,9 @@ int lsa_upload_frame(lsa_ctx* ctx, const lsa_point_t* pts, int n);
 int lsa_frame_store_put(lsa_ctx* ctx, int slot, const lsa_point_t* pts, int n);
 int lsa_frame_store_use(lsa_ctx* ctx, int slot);
 
+/* Number of points of the current frame. */
+int lsa_frame_size(const lsa_ctx* ctx);
+
 float lsa_get_azimuthal_resolution(const lsa_ctx* ctx);
 void lsa_set_azimuthal_resolution(lsa_ctx* ctx, float rad);
 
@@ -165,6 +168,11 @@ int lsa_set_target(lsa_ctx* ctx, int type, const lsa_point_t* pts, int m);
  * previous frame's raw keypoints, Slam.cxx:845-860): no PCIe traffic. */
 int lsa_set_target_from_set(lsa_ctx* ctx, int type, int set);
 int lsa_target_size(const lsa_ctx* ctx, int type);
+/* Edge length [m] of the search-grid cells used by the next lsa_set_target* of this type
+ * (default 1.0; it is enlarged automatically when the grid would exceed 2^21 cells). */
+int lsa_set_target_cell_size(lsa_ctx* ctx, int type, float cell);
+/* Diagnostics: queries of the last lsa_match that needed the exhaustive fall-back. */
+int lsa_match_slow_queries(lsa_ctx* ctx);
 
 /* Replaces a device keypoint set by host points (used by tests and by callers
  * that aggregate several LiDAR devices on the host). */

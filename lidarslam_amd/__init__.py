@@ -1,0 +1,398 @@
+"""lidarslam_amd -- MI355X-native scan-matching hot path of Perception4D/LidarSlam.
+
+Python front-end (ctypes) of liblidarslam_amd.so.  Two levels, both thin:
+
+* :class:`Context`  -- the kernel-level C ABI (include/lidarslam_amd.h): upload a scan, extract
+  keypoints, set a kNN target, match, accumulate normal equations, undistort.
+* :class:`Slam`     -- the pipeline: ``add_frame`` / ``world_transform`` mirror
+  ``LidarSlam::Slam::AddFrame`` / ``GetWorldTransform`` (slam_lib/include/LidarSlam/Slam.h:111-146).
+
+There is no CPU fallback: without the built library or without a HIP device every constructor
+raises.  The CPU oracle under ``oracle/`` is test infrastructure and is never imported from here.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from ._native import (  # noqa: F401
+    BLOB,
+    EDGE,
+    LIB_PATH,
+    MATCH_NSTATUS,
+    PLANE,
+    POINT_DTYPE,
+    SET_RAW_CURRENT,
+    SET_RAW_PREVIOUS,
+    SET_WORKING,
+    ExtractParams,
+    KernelStat,
+    MatchParams,
+    pose16,
+    ptr,
+    synth_frame,
+    synth_pose,
+)
+
+__all__ = ["Context", "Slam", "ExtractParams", "MatchParams", "POINT_DTYPE", "lib", "LsaError"]
+
+DEBUG_NAMES = [
+    "sin_angle", "saliency", "depth_gap", "intensity_gap", "edge_keypoint", "plane_keypoint", "blob_keypoint",
+    "edge_validity", "plane_validity", "blob_validity",
+]
+
+# every symbol include/lidarslam_amd.h declares (tests/test_abi.py checks the .so exports them all)
+ABI_SYMBOLS = [
+    "lsa_device_count", "lsa_ctx_create", "lsa_ctx_destroy", "lsa_last_error", "lsa_sync", "lsa_upload_frame",
+    "lsa_frame_store_put", "lsa_frame_store_use", "lsa_frame_size", "lsa_get_azimuthal_resolution",
+    "lsa_set_azimuthal_resolution", "lsa_extract_keypoints", "lsa_download_keypoints", "lsa_keypoint_count",
+    "lsa_download_debug", "lsa_nb_laser_rings", "lsa_transform_keypoints", "lsa_set_target", "lsa_set_target_from_set",
+    "lsa_target_size", "lsa_set_target_cell_size", "lsa_match_slow_queries", "lsa_set_keypoints", "lsa_match",
+    "lsa_download_match", "lsa_accumulate", "lsa_reset_working_keypoints", "lsa_undistort", "lsa_working_time_range",
+    "lsa_working_bbox", "lsa_download_transformed", "lsa_transform_frame", "lsa_profile_enable", "lsa_profile_reset",
+    "lsa_profile_get", "lsa_slam_create", "lsa_slam_destroy", "lsa_slam_last_error", "lsa_slam_set_param",
+    "lsa_slam_get_param", "lsa_slam_reset", "lsa_slam_add_frame", "lsa_slam_store_frame", "lsa_slam_add_stored_frame",
+    "lsa_slam_get_world_transform", "lsa_slam_get_covariance", "lsa_slam_get_keypoints", "lsa_slam_get_registered_frame",
+    "lsa_slam_get_match_status", "lsa_slam_get_stats", "lsa_slam_context", "lsa_synth_sensor", "lsa_synth_frame",
+    "lsa_synth_pose",
+]
+
+
+class LsaError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """Loads liblidarslam_amd.so (built in-tree by __graft_entry__.build()); raises if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise LsaError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'`")
+    L = C.CDLL(LIB_PATH)
+    vp, i32, f64 = C.c_void_p, C.c_int, C.c_double
+    L.lsa_ctx_create.argtypes = [i32, C.POINTER(vp)]
+    L.lsa_ctx_destroy.argtypes = [vp]
+    L.lsa_last_error.restype = C.c_char_p
+    L.lsa_last_error.argtypes = [vp]
+    L.lsa_sync.argtypes = [vp]
+    L.lsa_upload_frame.argtypes = [vp, vp, i32]
+    L.lsa_frame_store_put.argtypes = [vp, i32, vp, i32]
+    L.lsa_frame_store_use.argtypes = [vp, i32]
+    L.lsa_frame_size.argtypes = [vp]
+    L.lsa_get_azimuthal_resolution.restype = C.c_float
+    L.lsa_get_azimuthal_resolution.argtypes = [vp]
+    L.lsa_set_azimuthal_resolution.argtypes = [vp, C.c_float]
+    L.lsa_extract_keypoints.argtypes = [vp, C.POINTER(ExtractParams), vp]
+    L.lsa_download_keypoints.argtypes = [vp, i32, i32, vp, i32]
+    L.lsa_keypoint_count.argtypes = [vp, i32, i32]
+    L.lsa_download_debug.argtypes = [vp, i32, vp, i32]
+    L.lsa_nb_laser_rings.argtypes = [vp]
+    L.lsa_transform_keypoints.argtypes = [vp, i32, i32, vp, f64]
+    L.lsa_set_target.argtypes = [vp, i32, vp, i32]
+    L.lsa_set_target_from_set.argtypes = [vp, i32, i32]
+    L.lsa_target_size.argtypes = [vp, i32]
+    L.lsa_set_target_cell_size.argtypes = [vp, i32, C.c_float]
+    L.lsa_match_slow_queries.argtypes = [vp]
+    L.lsa_set_keypoints.argtypes = [vp, i32, i32, vp, i32]
+    L.lsa_match.argtypes = [vp, i32, i32, C.POINTER(MatchParams), vp, vp]
+    L.lsa_download_match.argtypes = [vp, i32, vp, vp, vp, i32]
+    L.lsa_accumulate.argtypes = [vp, C.c_uint, vp, i32, vp, vp, vp, vp]
+    L.lsa_reset_working_keypoints.argtypes = [vp]
+    L.lsa_undistort.argtypes = [vp, vp, vp, f64, f64]
+    L.lsa_working_time_range.argtypes = [vp, vp, vp]
+    L.lsa_working_bbox.argtypes = [vp, i32, vp, vp, vp]
+    L.lsa_download_transformed.argtypes = [vp, i32, i32, vp, vp, i32]
+    L.lsa_transform_frame.argtypes = [vp, i32, vp, vp, f64, f64, vp, i32]
+    L.lsa_profile_enable.argtypes = [vp, i32]
+    L.lsa_profile_reset.argtypes = [vp]
+    L.lsa_profile_get.argtypes = [vp, vp, i32]
+    L.lsa_slam_create.argtypes = [i32, C.POINTER(vp)]
+    L.lsa_slam_destroy.argtypes = [vp]
+    L.lsa_slam_last_error.restype = C.c_char_p
+    L.lsa_slam_last_error.argtypes = [vp]
+    L.lsa_slam_set_param.argtypes = [vp, C.c_char_p, f64]
+    L.lsa_slam_get_param.argtypes = [vp, C.c_char_p, vp]
+    L.lsa_slam_reset.argtypes = [vp, i32]
+    L.lsa_slam_add_frame.argtypes = [vp, vp, i32, C.c_uint64, C.c_uint32]
+    L.lsa_slam_store_frame.argtypes = [vp, i32, vp, i32]
+    L.lsa_slam_add_stored_frame.argtypes = [vp, i32, C.c_uint64, C.c_uint32]
+    L.lsa_slam_get_world_transform.argtypes = [vp, vp, vp]
+    L.lsa_slam_get_covariance.argtypes = [vp, vp]
+    L.lsa_slam_get_keypoints.argtypes = [vp, i32, i32, vp, i32]
+    L.lsa_slam_get_registered_frame.argtypes = [vp, vp, i32]
+    L.lsa_slam_get_match_status.argtypes = [vp, i32, i32, vp, vp, i32]
+    L.lsa_slam_get_stats.argtypes = [vp, vp]
+    L.lsa_slam_context.restype = vp
+    L.lsa_slam_context.argtypes = [vp]
+    _lib = L
+    return L
+
+
+def _profile(L, h):
+    buf = (KernelStat * 64)()
+    n = L.lsa_profile_get(h, buf, 64)
+    return [
+        {"name": buf[i].name.decode(), "launches": buf[i].launches, "total_ms": buf[i].total_ms, "bytes": buf[i].bytes}
+        for i in range(max(n, 0))
+    ]
+
+
+class Context:
+    """Kernel-level operations of one device context (see include/lidarslam_amd.h)."""
+
+    def __init__(self, device=0, handle=None):
+        self.L = lib()
+        self._owned = handle is None
+        if handle is None:
+            h = C.c_void_p()
+            rc = self.L.lsa_ctx_create(device, C.byref(h))
+            if rc != 0:
+                raise LsaError(f"lsa_ctx_create({device}) failed with {rc}: no usable HIP device (no CPU fallback)")
+            handle = h
+        self.h = handle
+
+    def close(self):
+        if getattr(self, "h", None) and self._owned:
+            self.L.lsa_ctx_destroy(self.h)
+        self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def _check(self, rc, what):
+        if rc < 0:
+            raise LsaError(f"{what} failed ({rc}): {self.L.lsa_last_error(self.h).decode()}")
+        return rc
+
+    # ---- frame / extraction
+    def upload_frame(self, pts):
+        pts = np.ascontiguousarray(pts)
+        assert pts.dtype == POINT_DTYPE
+        self._check(self.L.lsa_upload_frame(self.h, ptr(pts), pts.size), "lsa_upload_frame")
+
+    def store_frame(self, slot, pts):
+        pts = np.ascontiguousarray(pts)
+        self._check(self.L.lsa_frame_store_put(self.h, slot, ptr(pts), pts.size), "lsa_frame_store_put")
+
+    def use_stored_frame(self, slot):
+        self._check(self.L.lsa_frame_store_use(self.h, slot), "lsa_frame_store_use")
+
+    @property
+    def azimuthal_resolution(self):
+        return self.L.lsa_get_azimuthal_resolution(self.h)
+
+    @azimuthal_resolution.setter
+    def azimuthal_resolution(self, v):
+        self.L.lsa_set_azimuthal_resolution(self.h, v)
+
+    def extract_keypoints(self, params=None):
+        params = params or ExtractParams()
+        counts = np.zeros(3, np.int32)
+        self._check(self.L.lsa_extract_keypoints(self.h, C.byref(params), ptr(counts)), "lsa_extract_keypoints")
+        return counts
+
+    def keypoints(self, kset, ktype):
+        n = self.L.lsa_keypoint_count(self.h, kset, ktype)
+        out = np.zeros(max(n, 0), POINT_DTYPE)
+        if n > 0:
+            self._check(self.L.lsa_download_keypoints(self.h, kset, ktype, ptr(out), n), "lsa_download_keypoints")
+        return out
+
+    def set_keypoints(self, kset, ktype, pts):
+        pts = np.ascontiguousarray(pts)
+        self._check(self.L.lsa_set_keypoints(self.h, kset, ktype, ptr(pts) if pts.size else None, pts.size), "lsa_set_keypoints")
+
+    def debug_array(self, array_id):
+        n = self.L.lsa_frame_size(self.h)
+        out = np.zeros(n, np.float32)
+        self._check(self.L.lsa_download_debug(self.h, array_id, ptr(out), n), "lsa_download_debug")
+        return out
+
+    def nb_laser_rings(self):
+        return self.L.lsa_nb_laser_rings(self.h)
+
+    def transform_keypoints(self, kset, ktype, T, time_offset=0.0):
+        self._check(self.L.lsa_transform_keypoints(self.h, kset, ktype, ptr(pose16(T)), time_offset), "lsa_transform_keypoints")
+
+    # ---- matching
+    def set_target(self, ktype, pts, cell=None):
+        pts = np.ascontiguousarray(pts)
+        if cell is not None:
+            self.L.lsa_set_target_cell_size(self.h, ktype, cell)
+        self._check(self.L.lsa_set_target(self.h, ktype, ptr(pts) if pts.size else None, pts.size), "lsa_set_target")
+
+    def set_target_from_set(self, ktype, kset, cell=None):
+        if cell is not None:
+            self.L.lsa_set_target_cell_size(self.h, ktype, cell)
+        self._check(self.L.lsa_set_target_from_set(self.h, ktype, kset), "lsa_set_target_from_set")
+
+    def match(self, ktype, query_set, params, pose):
+        hist = np.zeros(MATCH_NSTATUS, np.int32)
+        self._check(self.L.lsa_match(self.h, ktype, query_set, C.byref(params), ptr(pose16(pose)), ptr(hist)), "lsa_match")
+        return hist
+
+    def match_results(self, ktype, query_set=None, records=True):
+        n = self.L.lsa_keypoint_count(self.h, SET_WORKING if query_set is None else query_set, ktype)
+        n = max(n, 0)
+        status = np.zeros(n, np.uint8)
+        weights = np.zeros(n, np.float64)
+        rec = np.zeros((n, 16), np.float64) if records else None
+        got = self._check(
+            self.L.lsa_download_match(self.h, ktype, ptr(status), ptr(weights), ptr(rec) if records else None, n), "lsa_download_match"
+        )
+        return status[:got], weights[:got], (rec[:got] if records else None)
+
+    def slow_queries(self):
+        return self.L.lsa_match_slow_queries(self.h)
+
+    def accumulate(self, type_mask, w, jac=True):
+        w = np.ascontiguousarray(w, np.float64)
+        cost = C.c_double()
+        nv = C.c_int()
+        g = np.zeros(6)
+        H = np.zeros((6, 6))
+        self._check(self.L.lsa_accumulate(self.h, type_mask, ptr(w), int(jac), C.byref(cost), ptr(g), ptr(H), C.byref(nv)), "lsa_accumulate")
+        return cost.value, g, H, nv.value
+
+    # ---- undistortion / transforms
+    def reset_working_keypoints(self):
+        self._check(self.L.lsa_reset_working_keypoints(self.h), "lsa_reset_working_keypoints")
+
+    def undistort(self, H0, H1, t0, t1):
+        self._check(self.L.lsa_undistort(self.h, ptr(pose16(H0)), ptr(pose16(H1)), t0, t1), "lsa_undistort")
+
+    def working_time_range(self):
+        a, b = C.c_double(), C.c_double()
+        self._check(self.L.lsa_working_time_range(self.h, C.byref(a), C.byref(b)), "lsa_working_time_range")
+        return a.value, b.value
+
+    def working_bbox(self, ktype, pose):
+        mn, mx = np.zeros(3, np.float32), np.zeros(3, np.float32)
+        self._check(self.L.lsa_working_bbox(self.h, ktype, ptr(pose16(pose)), ptr(mn), ptr(mx)), "lsa_working_bbox")
+        return mn, mx
+
+    def transformed_keypoints(self, kset, ktype, pose):
+        n = max(self.L.lsa_keypoint_count(self.h, kset, ktype), 0)
+        out = np.zeros(n, POINT_DTYPE)
+        if n:
+            self._check(self.L.lsa_download_transformed(self.h, kset, ktype, ptr(pose16(pose)), ptr(out), n), "lsa_download_transformed")
+        return out
+
+    def transform_frame(self, H0, H1=None, t0=0.0, t1=0.0):
+        n = self.L.lsa_frame_size(self.h)
+        out = np.zeros(n, POINT_DTYPE)
+        interp = H1 is not None
+        self._check(
+            self.L.lsa_transform_frame(self.h, int(interp), ptr(pose16(H0)), ptr(pose16(H1)) if interp else None, t0, t1, ptr(out), n),
+            "lsa_transform_frame",
+        )
+        return out
+
+    # ---- profiling
+    def profile(self, on=True):
+        self.L.lsa_profile_enable(self.h, int(on))
+
+    def profile_reset(self):
+        self.L.lsa_profile_reset(self.h)
+
+    def profile_stats(self):
+        return _profile(self.L, self.h)
+
+    def sync(self):
+        self._check(self.L.lsa_sync(self.h), "lsa_sync")
+
+
+class Slam:
+    """LidarSlam::Slam on one MI355X.  Parameters use the reference's names (``EgoMotion=3`` ...)."""
+
+    def __init__(self, device=0, **params):
+        self.L = lib()
+        h = C.c_void_p()
+        rc = self.L.lsa_slam_create(device, C.byref(h))
+        if rc != 0:
+            raise LsaError(f"lsa_slam_create({device}) failed with {rc}: no usable HIP device (there is no CPU fallback)")
+        self.h = h
+        self._n = 0
+        for k, v in params.items():
+            self.set_param(k, v)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.lsa_slam_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def _check(self, rc, what):
+        if rc < 0:
+            raise LsaError(f"{what} failed ({rc}): {self.L.lsa_slam_last_error(self.h).decode()}")
+        return rc
+
+    def set_param(self, name, value):
+        if self.L.lsa_slam_set_param(self.h, name.encode(), float(value)) != 0:
+            raise KeyError(name)
+
+    def get_param(self, name):
+        v = C.c_double()
+        if self.L.lsa_slam_get_param(self.h, name.encode(), C.byref(v)) != 0:
+            raise KeyError(name)
+        return v.value
+
+    def reset(self, reset_log=True):
+        self.L.lsa_slam_reset(self.h, int(reset_log))
+
+    def add_frame(self, pts, stamp_us, seq=0):
+        """Slam::AddFrame: host scan -> pose."""
+        pts = np.ascontiguousarray(pts)
+        assert pts.dtype == POINT_DTYPE
+        self._n = pts.size
+        self._check(self.L.lsa_slam_add_frame(self.h, ptr(pts), pts.size, stamp_us, seq), "lsa_slam_add_frame")
+
+    def store_frame(self, slot, pts):
+        pts = np.ascontiguousarray(pts)
+        self._check(self.L.lsa_slam_store_frame(self.h, slot, ptr(pts), pts.size), "lsa_slam_store_frame")
+
+    def add_stored_frame(self, slot, stamp_us, seq=0):
+        self._check(self.L.lsa_slam_add_stored_frame(self.h, slot, stamp_us, seq), "lsa_slam_add_stored_frame")
+
+    def world_transform(self):
+        T = np.zeros(16)
+        t = C.c_double()
+        self.L.lsa_slam_get_world_transform(self.h, ptr(T), C.byref(t))
+        return T.reshape(4, 4)
+
+    def covariance(self):
+        c = np.zeros((6, 6))
+        self.L.lsa_slam_get_covariance(self.h, ptr(c))
+        return c
+
+    def keypoints(self, ktype, which=0, cap=400000):
+        """which: 0 undistorted BASE, 1 WORLD, 2 raw BASE."""
+        out = np.zeros(cap, POINT_DTYPE)
+        n = self._check(self.L.lsa_slam_get_keypoints(self.h, ktype, which, ptr(out), cap), "lsa_slam_get_keypoints")
+        return out[:n].copy()
+
+    def registered_frame(self, cap=None):
+        cap = cap or max(self._n, 1 << 19)
+        out = np.zeros(cap, POINT_DTYPE)
+        n = self._check(self.L.lsa_slam_get_registered_frame(self.h, ptr(out), cap), "lsa_slam_get_registered_frame")
+        return out[:n]
+
+    def match_status(self, localization, ktype, cap=400000):
+        st = np.zeros(cap, np.uint8)
+        w = np.zeros(cap)
+        n = self.L.lsa_slam_get_match_status(self.h, int(localization), ktype, ptr(st), ptr(w), cap)
+        return st[:n].copy(), w[:n].copy()
+
+    def stats(self):
+        o = np.zeros(16)
+        self.L.lsa_slam_get_stats(self.h, ptr(o))
+        return o
+
+    def context(self):
+        return Context(handle=C.c_void_p(self.L.lsa_slam_context(self.h)))

@@ -1,0 +1,62 @@
+// lsa_lm.h -- LidarSlam::LocalOptimizer for the MI355X path
+// (slam_lib/include/LidarSlam/LocalOptimizer.h, slam_lib/src/LocalOptimizer.cxx).
+//
+// The residual blocks live on the device (lsa_match wrote them); every evaluation the
+// trust-region loop asks for is one lsa_accumulate call (cost, gradient, J^T J reduced on
+// the GPU, 29 doubles read back).  The 6-dof Levenberg-Marquardt control flow of Ceres
+// (unpinned master >= 2.0 in the reference CI) is restated on the host: Jacobi scaling,
+// LM diagonal, step acceptance, radius update, termination tests.
+#pragma once
+#include <array>
+#include "../lsa_ctx.h"
+#include "lsa_hostmath.h"
+
+namespace lsa
+{
+namespace host
+{
+
+// counterpart of ceres::Solver::Summary fields the reference reads (Slam.cxx:950, 1151)
+struct SolveSummary
+{
+  int num_successful_steps = 0;
+  int num_unsuccessful_steps = 0;
+  int num_iterations = 0;
+  int num_evaluations = 0;
+  double initial_cost = 0., final_cost = 0.;
+  const char* message = "";
+};
+
+// LocalOptimizer::RegistrationError (LocalOptimizer.h:36-52)
+struct RegistrationError
+{
+  double PositionError = 0.;
+  double PositionErrorDirection[3] = {0, 0, 0};
+  double OrientationError = 0.;
+  double OrientationErrorDirection[3] = {0, 0, 0};
+  std::array<double, 36> Covariance{};
+};
+
+class LocalOptimizer
+{
+public:
+  explicit LocalOptimizer(lsa_ctx* ctx) : Ctx(ctx) {}
+  void SetTwoDMode(bool b) { TwoDMode = b; }
+  void SetLMMaxIter(unsigned n) { LMMaxIter = n; }
+  void SetPosePrior(const Pose& prior) { ToXYZRPY(prior, PoseArray); }
+  // residual blocks = the device records of the last lsa_match of every type in the mask
+  void UseDeviceResiduals(unsigned typeMask) { TypeMask = typeMask; }
+  int Solve(SolveSummary& summary);
+  Pose GetOptimizedPose() const { return FromXYZRPY(PoseArray); }
+  int EstimateRegistrationError(RegistrationError& err);
+
+private:
+  lsa_ctx* Ctx;
+  unsigned TypeMask = 7;
+  bool TwoDMode = false;
+  unsigned LMMaxIter = 15;
+  double PoseArray[6] = {0, 0, 0, 0, 0, 0};
+};
+
+}  // namespace host
+}  // namespace lsa

@@ -1,0 +1,313 @@
+// lsa_rolling_grid.cpp -- see lsa_rolling_grid.h.  Float/double mixing follows Eigen's scalar
+// promotion in the reference (an Array3f combined with a double scalar casts the scalar to float).
+#include "lsa_rolling_grid.h"
+#include <algorithm>
+#include <cmath>
+#include <limits>
+
+namespace lsa
+{
+namespace host
+{
+namespace
+{
+// Utils::PositionToVoxel (RollingGrid.h:39-42): round((p - origin) / resolution)
+inline void ToVoxel(const float p[3], const float origin[3], double resolution, int out[3])
+{
+  const float r = static_cast<float>(resolution);
+  for (int i = 0; i < 3; ++i) out[i] = static_cast<int>(std::round((p[i] - origin[i]) / r));
+}
+inline void BoundingBox(const RollingGrid::PointCloud& c, float mn[3], float mx[3])
+{
+  for (int i = 0; i < 3; ++i)
+  {
+    mn[i] = std::numeric_limits<float>::max();
+    mx[i] = -std::numeric_limits<float>::max();
+  }
+  for (const lsa_point_t& p : c)
+  {
+    mn[0] = std::min(mn[0], p.x); mx[0] = std::max(mx[0], p.x);
+    mn[1] = std::min(mn[1], p.y); mx[1] = std::max(mx[1], p.y);
+    mn[2] = std::min(mn[2], p.z); mx[2] = std::max(mx[2], p.z);
+  }
+}
+inline float Dist(const lsa_point_t& p, const float c[3])
+{
+  const float dx = p.x - c[0], dy = p.y - c[1], dz = p.z - c[2];
+  return std::sqrt(dx * dx + (dy * dy + dz * dz));
+}
+}  // namespace
+
+void RollingGrid::To3d(int id, int v[3]) const
+{
+  const int z = id / (GridSize * GridSize);
+  id -= z * GridSize * GridSize;
+  const int y = id / GridSize;
+  id -= y * GridSize;
+  v[0] = id; v[1] = y; v[2] = z;
+}
+
+void RollingGrid::GridOrigin(float o[3]) const
+{
+  // RollingGrid.cxx:177: centre of voxel (0,0,0)
+  for (int i = 0; i < 3; ++i) o[i] = VoxelGridPosition[i] - static_cast<float>(int(GridSize / 2) * VoxelResolution);
+}
+
+// RollingGrid.cxx:40-48
+void RollingGrid::Reset(const float position[3])
+{
+  this->Clear();
+  const float r = static_cast<float>(VoxelResolution);
+  for (int i = 0; i < 3; ++i) VoxelGridPosition[i] = std::floor((position ? position[i] : 0.f) / r) * r;
+}
+
+// RollingGrid.cxx:51-56
+void RollingGrid::Clear()
+{
+  NbPoints = 0;
+  Voxels.clear();
+  SubMapValid = false;
+}
+
+// RollingGrid.cxx:59-70
+void RollingGrid::SetGridSize(int size)
+{
+  GridSize = size;
+  PointCloud prev = this->Get();
+  this->Clear();
+  if (!prev.empty()) this->Add(prev);
+}
+
+// RollingGrid.cxx:73-88
+void RollingGrid::SetVoxelResolution(double resolution)
+{
+  VoxelResolution = int(resolution / LeafSize) * LeafSize;
+  const float r = static_cast<float>(VoxelResolution);
+  for (int i = 0; i < 3; ++i) VoxelGridPosition[i] = std::floor(VoxelGridPosition[i] / r) * r;
+  PointCloud prev = this->Get();
+  this->Clear();
+  if (!prev.empty()) this->Add(prev);
+}
+
+// RollingGrid.cxx:95-114
+RollingGrid::PointCloud RollingGrid::Get(bool clean) const
+{
+  PointCloud pc;
+  pc.reserve(NbPoints);
+  for (const auto& out : Voxels)
+    for (const auto& in : out.second)
+      if (!clean || in.second.count > MinFramesPerVoxel) pc.push_back(in.second.point);
+  return pc;
+}
+
+// RollingGrid.cxx:117-157
+void RollingGrid::Roll(const float minPoint[3], const float maxPoint[3])
+{
+  const float half = static_cast<float>(static_cast<double>(GridSize) / 2 * VoxelResolution);
+  const float res = static_cast<float>(VoxelResolution);
+  int shift[3];
+  bool move = false;
+  for (int i = 0; i < 3; ++i)
+  {
+    const float down = minPoint[i] - (VoxelGridPosition[i] - half);
+    const float up = maxPoint[i] - (VoxelGridPosition[i] + half);
+    float off = (up + down) / 2.f;
+    off = std::min(std::max(off, std::min(down, 0.f)), std::max(up, 0.f));
+    shift[i] = static_cast<int>(std::round(off / res));
+    move = move || shift[i] != 0;
+  }
+  if (!move) return;
+  unsigned int kept = 0;
+  RollingVG rolled;
+  for (auto& out : Voxels)
+  {
+    int v[3];
+    this->To3d(out.first, v);
+    bool inside = true;
+    for (int i = 0; i < 3; ++i)
+    {
+      v[i] -= shift[i];
+      inside = inside && 0 <= v[i] && v[i] < GridSize;
+    }
+    if (inside)
+    {
+      kept += out.second.size();
+      rolled[this->To1d(v)] = std::move(out.second);
+    }
+  }
+  NbPoints = kept;
+  Voxels.swap(rolled);
+  for (int i = 0; i < 3; ++i) VoxelGridPosition[i] += static_cast<float>(shift[i]) * res;
+}
+
+// RollingGrid.cxx:160-318
+void RollingGrid::Add(const PointCloud& pointcloud, bool fixed, double currentTime, bool roll)
+{
+  if (pointcloud.empty()) return;
+  if (roll)
+  {
+    float mn[3], mx[3];
+    BoundingBox(pointcloud, mn, mx);
+    this->Roll(mn, mx);
+  }
+  const float res = static_cast<float>(VoxelResolution);
+  const float leaf = static_cast<float>(LeafSize);
+  float origin[3];
+  this->GridOrigin(origin);
+
+  std::unordered_map<int, std::unordered_map<int, bool>> seen;
+  std::unordered_map<int, std::unordered_map<int, Voxel>> meanPts;
+  bool updated = false;
+  for (const lsa_point_t& point : pointcloud)
+  {
+    const float p[3] = {point.x, point.y, point.z};
+    int vo[3];
+    ToVoxel(p, origin, VoxelResolution, vo);
+    if (!(0 <= vo[0] && vo[0] < GridSize && 0 <= vo[1] && vo[1] < GridSize && 0 <= vo[2] && vo[2] < GridSize)) continue;
+    float centerIn[3];
+    for (int i = 0; i < 3; ++i) centerIn[i] = static_cast<float>(vo[i]) * res + origin[i];
+    int vi[3];
+    ToVoxel(p, centerIn, LeafSize, vi);
+    const unsigned int idxOut = this->To1d(vo);
+    const unsigned int idxIn = this->To1d(vi);
+    if (!Voxels.count(idxOut) || !Voxels[idxOut].count(idxIn))
+    {
+      Voxels[idxOut][idxIn].point = point;
+      ++NbPoints;
+      updated = true;
+    }
+    else
+    {
+      Voxel& voxel = Voxels[idxOut][idxIn];
+      if (voxel.point.label == 1) continue;  // fixed map point
+      switch (Sampling)
+      {
+        case SamplingMode::FIRST:
+          break;
+        case SamplingMode::LAST:
+          voxel.point = point;
+          updated = true;
+          break;
+        case SamplingMode::MAX_INTENSITY:
+          if (point.intensity > voxel.point.intensity)
+          {
+            voxel.point = point;
+            updated = true;
+          }
+          break;
+        case SamplingMode::CENTER_POINT:
+        {
+          float c[3];
+          for (int i = 0; i < 3; ++i) c[i] = centerIn[i] - static_cast<float>(VoxelResolution / 2.f) + leaf * static_cast<float>(vi[i]);
+          if (Dist(point, c) < Dist(voxel.point, c))
+          {
+            voxel.point = point;
+            updated = true;
+          }
+          break;
+        }
+        case SamplingMode::CENTROID:
+        {
+          Voxel& v = meanPts[idxOut][idxIn];
+          const float k = static_cast<float>(v.count), k1 = static_cast<float>(v.count + 1);
+          v.point.x = (v.point.x * k + point.x) / k1;
+          v.point.y = (v.point.y * k + point.y) / k1;
+          v.point.z = (v.point.z * k + point.z) / k1;
+          ++v.count;
+          break;
+        }
+      }
+    }
+    if (Sampling == SamplingMode::CENTROID)
+    {
+      // the reference runs this block for every added point (RollingGrid.cxx:282-297)
+      for (auto& mo : meanPts)
+        for (auto& mi : mo.second)
+        {
+          Voxel& voxel = Voxels[mo.first][mi.first];
+          const float k = static_cast<float>(voxel.count), k1 = static_cast<float>(voxel.count + 1);
+          voxel.point.x = (voxel.point.x * k + mi.second.point.x) / k1;
+          voxel.point.y = (voxel.point.y * k + mi.second.point.y) / k1;
+          voxel.point.z = (voxel.point.z * k + mi.second.point.z) / k1;
+        }
+    }
+    Voxel& voxel = Voxels[idxOut][idxIn];
+    voxel.point.time = currentTime;
+    voxel.point.label = fixed ? 1 : 0;
+    if (!seen.count(idxOut) || !seen[idxOut].count(idxIn))
+    {
+      ++voxel.count;
+      seen[idxOut][idxIn] = true;
+    }
+  }
+  if (updated) SubMapValid = false;  // KdTree.Reset() in the reference
+}
+
+// RollingGrid.cxx:325-351
+void RollingGrid::ClearOldPoints(double currentTime)
+{
+  for (auto out = Voxels.begin(); out != Voxels.end();)
+  {
+    for (auto in = out->second.begin(); in != out->second.end();)
+    {
+      const Voxel& voxel = in->second;
+      if (!voxel.point.label && currentTime - voxel.point.time > DecayingThreshold) in = out->second.erase(in);
+      else ++in;
+    }
+    if (out->second.empty()) out = Voxels.erase(out);
+    else ++out;
+  }
+}
+
+// RollingGrid.cxx:354-360
+void RollingGrid::BuildSubMap()
+{
+  SubMap = this->Get();
+  SubMapValid = true;
+}
+
+// RollingGrid.cxx:363-442
+void RollingGrid::BuildSubMap(const float minPoint[3], const float maxPoint[3], int minNbPoints)
+{
+  float origin[3];
+  this->GridOrigin(origin);
+  int lo[3], hi[3];
+  ToVoxel(minPoint, origin, VoxelResolution, lo);
+  ToVoxel(maxPoint, origin, VoxelResolution, hi);
+  for (int i = 0; i < 3; ++i)
+  {
+    lo[i] = std::max(lo[i], 0);
+    hi[i] = std::min(hi[i], GridSize - 1);
+  }
+  auto intersects = [&](int id) {
+    int v[3];
+    this->To3d(id, v);
+    return lo[0] <= v[0] && v[0] <= hi[0] && lo[1] <= v[1] && v[1] <= hi[1] && lo[2] <= v[2] && v[2] <= hi[2];
+  };
+  SubMap.clear();
+  SubMap.reserve(NbPoints);
+  if (minNbPoints < 0 || MinFramesPerVoxel <= 1)
+  {
+    for (const auto& out : Voxels)
+      if (intersects(out.first))
+        for (const auto& in : out.second) SubMap.push_back(in.second.point);
+  }
+  else
+  {
+    for (const auto& out : Voxels)
+      if (intersects(out.first))
+        for (const auto& in : out.second)
+          if (in.second.count >= MinFramesPerVoxel || in.second.point.label == 1) SubMap.push_back(in.second.point);
+    if (static_cast<int>(SubMap.size()) < minNbPoints)
+    {
+      for (const auto& out : Voxels)
+        if (intersects(out.first))
+          for (const auto& in : out.second)
+            if (in.second.count < MinFramesPerVoxel && in.second.point.label != 1) SubMap.push_back(in.second.point);
+    }
+  }
+  SubMapValid = true;
+}
+
+}  // namespace host
+}  // namespace lsa

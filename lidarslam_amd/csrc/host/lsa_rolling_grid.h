@@ -1,0 +1,84 @@
+// lsa_rolling_grid.h -- LidarSlam::RollingGrid on the host
+// (slam_lib/include/LidarSlam/RollingGrid.h, slam_lib/src/RollingGrid.cxx).
+//
+// map maintenance stays on the host in this round (it runs once per keyframe
+// and is hash-map bound); its OUTPUT, the sub-map cloud and its point order, is the kNN target
+// that lsa_set_target uploads.  The containers are the reference's own
+// std::unordered_map<int, std::unordered_map<int, Voxel>> so that libstdc++'s iteration order --
+// which decides the order of the sub-map points and with it the PCA summation order -- is kept.
+#pragma once
+#include <unordered_map>
+#include <vector>
+#include "../../../include/lidarslam_amd.h"
+
+namespace lsa
+{
+namespace host
+{
+
+enum class SamplingMode { FIRST = 0, LAST = 1, MAX_INTENSITY = 2, CENTER_POINT = 3, CENTROID = 4 };
+
+class RollingGrid
+{
+public:
+  using PointCloud = std::vector<lsa_point_t>;
+  struct Voxel
+  {
+    lsa_point_t point{};
+    unsigned int count = 0;
+  };
+  using SamplingVG = std::unordered_map<int, Voxel>;
+  using RollingVG = std::unordered_map<int, SamplingVG>;
+
+  RollingGrid() { this->Reset(); }
+  void Reset(const float position[3] = nullptr);
+  void Clear();
+
+  void SetGridSize(int size);
+  int GetGridSize() const { return this->GridSize; }
+  void SetVoxelResolution(double resolution);
+  double GetVoxelResolution() const { return this->VoxelResolution; }
+  void SetLeafSize(double s) { this->LeafSize = s; }
+  double GetLeafSize() const { return this->LeafSize; }
+  void SetMinFramesPerVoxel(unsigned int n) { this->MinFramesPerVoxel = n; }
+  unsigned int GetMinFramesPerVoxel() const { return this->MinFramesPerVoxel; }
+  void SetSampling(SamplingMode m) { this->Sampling = m; }
+  SamplingMode GetSampling() const { return this->Sampling; }
+  void SetDecayingThreshold(double d) { this->DecayingThreshold = d; }
+  double GetDecayingThreshold() const { return this->DecayingThreshold; }
+  bool IsTimeThreshold() const { return this->DecayingThreshold > 0; }
+
+  PointCloud Get(bool clean = false) const;
+  unsigned int Size() const { return this->NbPoints; }
+  void Roll(const float minPoint[3], const float maxPoint[3]);
+  void Add(const PointCloud& pointcloud, bool fixed = false, double currentTime = -1., bool roll = true);
+
+  // The reference builds a nanoflann kd-tree here; the MI355X path only materialises the
+  // sub-map cloud, the device search grid is built by lsa_set_target.
+  void BuildSubMap();
+  void BuildSubMap(const float minPoint[3], const float maxPoint[3], int minNbPoints = -1);
+  // IsSubMapKdTreeValid(): false after every map modification until the next BuildSubMap
+  bool IsSubMapValid() const { return this->SubMapValid && !this->SubMap.empty(); }
+  const PointCloud& GetSubMap() const { return this->SubMap; }
+  void ClearOldPoints(double currentTime);
+
+private:
+  int GridSize = 50;
+  double VoxelResolution = 10.;
+  double LeafSize = 0.2;
+  RollingVG Voxels;
+  float VoxelGridPosition[3] = {0.f, 0.f, 0.f};
+  unsigned int NbPoints = 0;
+  PointCloud SubMap;
+  bool SubMapValid = false;
+  unsigned int MinFramesPerVoxel = 0;
+  SamplingMode Sampling = SamplingMode::MAX_INTENSITY;
+  double DecayingThreshold = -1;
+
+  int To1d(const int v[3]) const { return v[2] * GridSize * GridSize + v[1] * GridSize + v[0]; }
+  void To3d(int id, int v[3]) const;
+  void GridOrigin(float o[3]) const;
+};
+
+}  // namespace host
+}  // namespace lsa

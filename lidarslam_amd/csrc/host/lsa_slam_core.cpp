@@ -1,0 +1,567 @@
+// lsa_slam_core.cpp -- see lsa_slam_core.h.
+#include "lsa_slam_core.h"
+#include <chrono>
+#include <cmath>
+#include <cstring>
+
+namespace lsa
+{
+namespace host
+{
+namespace
+{
+struct Tick
+{
+  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+  double Stop() const { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
+};
+inline double StampToSec(uint64_t us) { return us * 1e-6; }  // Utils::PclStampToSec
+}  // namespace
+
+#define LSA_TRY(call)                          \
+  do                                           \
+  {                                            \
+    int rc__ = (call);                         \
+    if (rc__ < 0) return Fail(rc__, #call);    \
+  } while (0)
+
+// Slam::Slam (Slam.cxx:143-161)
+SlamCore::SlamCore(int device)
+{
+  ExtractParams.neighbor_width = 4;
+  ExtractParams.min_distance_to_sensor = 1.5f;
+  ExtractParams.min_beam_surface_angle = 10.f;
+  ExtractParams.plane_sin_angle_threshold = 0.5f;
+  ExtractParams.edge_sin_angle_threshold = 0.86f;
+  ExtractParams.dist_to_line_threshold = 0.20f;
+  ExtractParams.edge_depth_gap_threshold = 0.15f;
+  ExtractParams.edge_saliency_threshold = 1.5f;
+  ExtractParams.edge_intensity_gap_threshold = 50.f;
+  for (int k = 0; k < 3; ++k) LocalMaps[k] = std::make_shared<RollingGrid>();
+  for (int k = 0; k < 3; ++k) LocalMaps[k]->SetVoxelResolution(10.);
+  for (int k = 0; k < 3; ++k) LocalMaps[k]->SetGridSize(50);
+  LocalMaps[LSA_EDGE]->SetLeafSize(0.30);
+  LocalMaps[LSA_PLANE]->SetLeafSize(0.60);
+  LocalMaps[LSA_BLOB]->SetLeafSize(0.30);
+  const int rc = lsa_ctx_create(device, &Ctx);
+  if (rc != LSA_OK)
+  {
+    Ctx = nullptr;
+    LastError = rc == LSA_E_NO_DEVICE ? "no usable HIP device (there is no CPU fallback)" : "lsa_ctx_create failed";
+  }
+  Reset();
+}
+
+SlamCore::~SlamCore()
+{
+  if (Ctx) lsa_ctx_destroy(Ctx);
+}
+
+int SlamCore::Fail(int rc, const char* where)
+{
+  LastError = std::string(where) + ": " + (Ctx ? lsa_last_error(Ctx) : "no context");
+  return rc;
+}
+
+// Slam::Reset (Slam.cxx:164-210)
+void SlamCore::Reset(bool resetLog)
+{
+  for (int k = 0; k < 3; ++k) LocalMaps[k]->Reset();
+  KfLastPose = Pose::Identity();
+  KfCounter = 0;
+  Tworld = PreviousTworld = Trelative = Pose::Identity();
+  Motion = WithinFrameMotion();
+  LocalizationUncertainty = RegistrationError();
+  CurrentStamp = 0;  // the "previous frame" after a reset is an empty cloud with stamp 0
+  HaveFrame = false;
+  if (Ctx)
+    for (int s = 0; s < 3; ++s)
+      for (int k = 0; k < 3; ++k) lsa_set_keypoints(Ctx, s, k, nullptr, 0);
+  for (int k = 0; k < 3; ++k) { EgoDebug[k] = MatchDebug(); LocDebug[k] = MatchDebug(); KeypointCounts[k] = 0; }
+  if (resetLog)
+  {
+    NbrFrameProcessed = 0;
+    LogTrajectory.clear();
+  }
+}
+
+Pose SlamCore::GetWorldTransform(double* time) const
+{
+  if (time) *time = LogTrajectory.empty() ? 0. : LogTrajectory.back().time;
+  return LogTrajectory.empty() ? Pose::Identity() : LogTrajectory.back().pose;
+}
+
+// Slam::AddFrames (Slam.cxx:230-344) + CheckFrames (:709-743)
+int SlamCore::AddFrame(const lsa_point_t* pts, int n, uint64_t stampUs, uint32_t)
+{
+  if (!Ctx) return LSA_E_NO_DEVICE;
+  Tick total;
+  Stats = FrameStats();
+  if (!pts || n <= 0) { LastError = "SLAM input only contains empty pointclouds : exiting."; return LSA_OK; }
+  if (stampUs == CurrentStamp) { LastError = "SLAM frames have the same timestamp as previous ones : frames ignored."; return LSA_OK; }
+  LSA_TRY(lsa_upload_frame(Ctx, pts, n));
+  int rc = ProcessCurrentFrame(stampUs);
+  Stats.total = total.Stop();
+  return rc;
+}
+
+int SlamCore::AddStoredFrame(int slot, uint64_t stampUs, uint32_t)
+{
+  if (!Ctx) return LSA_E_NO_DEVICE;
+  Tick total;
+  Stats = FrameStats();
+  if (stampUs == CurrentStamp) { LastError = "SLAM frames have the same timestamp as previous ones : frames ignored."; return LSA_OK; }
+  LSA_TRY(lsa_frame_store_use(Ctx, slot));
+  int rc = ProcessCurrentFrame(stampUs);
+  Stats.total = total.Stop();
+  return rc;
+}
+
+int SlamCore::ProcessCurrentFrame(uint64_t stampUs)
+{
+  CurrentStamp = stampUs;
+  CurrentTime = StampToSec(stampUs);
+  HaveFrame = true;
+  {
+    Tick t;
+    int rc = ExtractKeypoints();
+    if (rc < 0) return rc;
+    Stats.extract = t.Stop();
+  }
+  int rc = ComputeEgoMotion();
+  if (rc < 0) return rc;
+  rc = Localization();
+  if (rc < 0) return rc;
+  if (MapUpdate == MappingMode::ADD_KPTS_TO_FIXED_MAP || MapUpdate == MappingMode::UPDATE)
+  {
+    Tick t;
+    rc = UpdateMapsUsingTworld();
+    if (rc < 0) return rc;
+    Stats.maps = t.Stop();
+  }
+  LogCurrentFrameState(CurrentTime);
+  NbrFrameProcessed++;
+  return LSA_OK;
+}
+
+// Slam::ExtractKeypoints (Slam.cxx:746-810)
+int SlamCore::ExtractKeypoints()
+{
+  int counts[3];
+  LSA_TRY(lsa_extract_keypoints(Ctx, &ExtractParams, counts));  // also: PreviousRawKeypoints = CurrentRawKeypoints
+  for (int k = 0; k < 3; ++k)
+  {
+    if (!UseKeypoints[k])
+    {
+      LSA_TRY(lsa_set_keypoints(Ctx, LSA_SET_RAW_CURRENT, k, nullptr, 0));
+      counts[k] = 0;
+    }
+    KeypointCounts[k] = counts[k];
+  }
+  // AggregateFrames(keypoints, false): LIDAR -> BASE (Slam.cxx:1551-1573); skipped when identity
+  if (!IsApprox(BaseToLidarOffset, Pose::Identity()))
+    for (int k = 0; k < 3; ++k)
+      if (counts[k] > 0) LSA_TRY(lsa_transform_keypoints(Ctx, LSA_SET_RAW_CURRENT, k, BaseToLidarOffset.m, 0.));
+  return LSA_OK;
+}
+
+lsa_match_params_t SlamCore::EgoMatchParams() const
+{
+  lsa_match_params_t p;
+  std::memset(&p, 0, sizeof(p));
+  p.single_edge_per_ring = 1;  // Slam.cxx:879
+  p.max_neighbors_distance = EgoMotionMaxNeighborsDistance;
+  p.edge_nb_neighbors = EgoMotionEdgeNbNeighbors;
+  p.edge_min_nb_neighbors = EgoMotionEdgeMinNbNeighbors;
+  p.edge_max_model_error = EgoMotionEdgeMaxModelError;
+  p.plane_nb_neighbors = EgoMotionPlaneNbNeighbors;
+  p.planarity_threshold = EgoMotionPlanarityThreshold;
+  p.plane_max_model_error = EgoMotionPlaneMaxModelError;
+  p.blob_nb_neighbors = 10;
+  p.saturation_distance = 1.;
+  return p;
+}
+lsa_match_params_t SlamCore::LocMatchParams() const
+{
+  lsa_match_params_t p;
+  std::memset(&p, 0, sizeof(p));
+  p.single_edge_per_ring = 0;  // Slam.cxx:1057
+  p.max_neighbors_distance = LocalizationMaxNeighborsDistance;
+  p.edge_nb_neighbors = LocalizationEdgeNbNeighbors;
+  p.edge_min_nb_neighbors = LocalizationEdgeMinNbNeighbors;
+  p.edge_max_model_error = LocalizationEdgeMaxModelError;
+  p.plane_nb_neighbors = LocalizationPlaneNbNeighbors;
+  p.planarity_threshold = LocalizationPlanarityThreshold;
+  p.plane_max_model_error = LocalizationPlaneMaxModelError;
+  p.blob_nb_neighbors = LocalizationBlobNbNeighbors;
+  p.saturation_distance = 1.;
+  return p;
+}
+
+// Slam::ComputeEgoMotion (Slam.cxx:813-972)
+int SlamCore::ComputeEgoMotion()
+{
+  Trelative = Pose::Identity();
+  if (LogTrajectory.size() >= 2 &&
+      (EgoMotion == EgoMotionMode::MOTION_EXTRAPOLATION || EgoMotion == EgoMotionMode::MOTION_EXTRAPOLATION_AND_REGISTRATION))
+  {
+    const double t = StampToSec(CurrentStamp);
+    const double t1 = LogTrajectory[LogTrajectory.size() - 1].time;
+    const double t0 = LogTrajectory[LogTrajectory.size() - 2].time;
+    if (!(std::abs((t - t1) / (t1 - t0)) > MaxExtrapolationRatio))
+    {
+      const Pose next = LinearInterpolation(PreviousTworld, Tworld, t, t0, t1);
+      Trelative = Inverse(Tworld) * next;
+    }
+  }
+  if (!(EgoMotion == EgoMotionMode::REGISTRATION || EgoMotion == EgoMotionMode::MOTION_EXTRAPOLATION_AND_REGISTRATION))
+    return LSA_OK;
+
+  // kd-trees on the previous frame's raw keypoints -> device search grids, no PCIe traffic
+  for (int k : {LSA_EDGE, LSA_PLANE}) LSA_TRY(lsa_set_target_from_set(Ctx, k, LSA_SET_RAW_PREVIOUS));
+  TotalMatchedKeypoints = 0;
+  lsa_match_params_t mp = EgoMatchParams();
+
+  for (unsigned icpIter = 0; icpIter < EgoMotionICPMaxIter; ++icpIter)
+  {
+    Tick ticp;
+    const double iterRatio = icpIter / static_cast<double>(EgoMotionICPMaxIter - 1);
+    mp.saturation_distance = (1 - iterRatio) * EgoMotionInitSaturationDistance + iterRatio * EgoMotionFinalSaturationDistance;
+    TotalMatchedKeypoints = 0;
+    for (int k : {LSA_EDGE, LSA_PLANE})
+    {
+      int hist[LSA_MATCH_NSTATUS];
+      LSA_TRY(lsa_match(Ctx, k, LSA_SET_RAW_CURRENT, &mp, Trelative.m, hist));
+      TotalMatchedKeypoints += hist[LSA_MATCH_SUCCESS];
+    }
+    Stats.ego_icp += ticp.Stop();
+    Stats.ego_iters++;
+    if (TotalMatchedKeypoints < MinNbMatchedKeypoints) break;  // "Not enough keypoints, EgoMotion skipped for this frame."
+
+    Tick tlm;
+    LocalOptimizer optimizer(Ctx);
+    optimizer.SetTwoDMode(TwoDMode);
+    optimizer.SetPosePrior(Trelative);
+    optimizer.SetLMMaxIter(EgoMotionLMMaxIter);
+    optimizer.UseDeviceResiduals((1u << LSA_EDGE) | (1u << LSA_PLANE));
+    SolveSummary summary;
+    LSA_TRY(optimizer.Solve(summary));
+    Trelative = optimizer.GetOptimizedPose();
+    Stats.ego_lm += tlm.Stop();
+    Stats.lm_evals += summary.num_evaluations;
+    if (summary.num_successful_steps == 1) break;
+  }
+  if (KeepMatchDebug)
+    for (int k : {LSA_EDGE, LSA_PLANE})
+    {
+      const int n = lsa_keypoint_count(Ctx, LSA_SET_RAW_CURRENT, k);
+      EgoDebug[k].status.assign(n, LSA_MATCH_UNKOWN);
+      EgoDebug[k].weights.assign(n, 0.);
+      if (n > 0) LSA_TRY(lsa_download_match(Ctx, k, EgoDebug[k].status.data(), EgoDebug[k].weights.data(), nullptr, n));
+    }
+  return LSA_OK;
+}
+
+// Slam::Localization (Slam.cxx:975-1175)
+int SlamCore::Localization()
+{
+  PreviousTworld = Tworld;
+  Tworld = PreviousTworld * Trelative;
+  LSA_TRY(lsa_reset_working_keypoints(Ctx));  // CurrentUndistortedKeypoints = CurrentRawKeypoints
+
+  if (Undistortion)
+  {
+    Tick t;
+    int rc = InitUndistortion();
+    if (rc < 0) return rc;
+    rc = RefineUndistortion();
+    if (rc < 0) return rc;
+    Stats.undistort += t.Stop();
+  }
+
+  {
+    Tick t;
+    for (int k = 0; k < 3; ++k)
+    {
+      if (!(UseKeypoints[k] && !LocalMaps[k]->IsSubMapValid())) continue;
+      if (MapUpdate == MappingMode::NONE)
+        LocalMaps[k]->BuildSubMap();
+      else
+      {
+        if (LocalMaps[k]->IsTimeThreshold()) LocalMaps[k]->ClearOldPoints(CurrentTime);
+        float mn[3], mx[3];
+        LSA_TRY(lsa_working_bbox(Ctx, k, Tworld.m, mn, mx));
+        LocalMaps[k]->BuildSubMap(mn, mx, KeypointCounts[k] / 2);
+      }
+      const auto& sub = LocalMaps[k]->GetSubMap();
+      // kNN grid cell ~ twice the map leaf size: ~1 map point per leaf on a surface
+      lsa_set_target_cell_size(Ctx, k, static_cast<float>(std::max(0.5, 2.0 * LocalMaps[k]->GetLeafSize())));
+      LSA_TRY(lsa_set_target(Ctx, k, sub.data(), static_cast<int>(sub.size())));
+    }
+    Stats.submap += t.Stop();
+  }
+
+  TotalMatchedKeypoints = 0;
+  lsa_match_params_t mp = LocMatchParams();
+  for (unsigned icpIter = 0; icpIter < LocalizationICPMaxIter; ++icpIter)
+  {
+    Tick ticp;
+    const double iterRatio = icpIter / static_cast<double>(LocalizationICPMaxIter - 1);
+    mp.saturation_distance = (1 - iterRatio) * LocalizationInitSaturationDistance + iterRatio * LocalizationFinalSaturationDistance;
+    TotalMatchedKeypoints = 0;
+    for (int k = 0; k < 3; ++k)
+    {
+      int hist[LSA_MATCH_NSTATUS];
+      LSA_TRY(lsa_match(Ctx, k, LSA_SET_WORKING, &mp, Tworld.m, hist));
+      TotalMatchedKeypoints += hist[LSA_MATCH_SUCCESS];
+    }
+    Stats.loc_icp += ticp.Stop();
+    Stats.loc_iters++;
+    if (TotalMatchedKeypoints < MinNbMatchedKeypoints)
+    {
+      // reset state to previous one to avoid instability (Slam.cxx:1098-1107)
+      Trelative = Pose::Identity();
+      Tworld = PreviousTworld;
+      if (Undistortion) Motion.SetTransforms(Pose::Identity(), Pose::Identity());
+      LastError = "Not enough keypoints matched, Localization skipped for this frame.";
+      break;
+    }
+
+    Tick tlm;
+    LocalOptimizer optimizer(Ctx);
+    optimizer.SetTwoDMode(TwoDMode);
+    optimizer.SetPosePrior(Tworld);
+    optimizer.SetLMMaxIter(LocalizationLMMaxIter);
+    optimizer.UseDeviceResiduals(7u);
+    SolveSummary summary;
+    LSA_TRY(optimizer.Solve(summary));
+    Stats.lm_evals += summary.num_evaluations;
+    Tworld = optimizer.GetOptimizedPose();
+    Trelative = Inverse(PreviousTworld) * Tworld;
+    if (Undistortion == UNDISTORTION_REFINED)
+    {
+      int rc = RefineUndistortion();
+      if (rc < 0) return rc;
+    }
+    Stats.loc_lm += tlm.Stop();
+    if ((summary.num_successful_steps == 1) || (icpIter == LocalizationICPMaxIter - 1))
+    {
+      LSA_TRY(optimizer.EstimateRegistrationError(LocalizationUncertainty));
+      break;
+    }
+  }
+  if (KeepMatchDebug)
+    for (int k = 0; k < 3; ++k)
+    {
+      const int n = lsa_keypoint_count(Ctx, LSA_SET_WORKING, k);
+      LocDebug[k].status.assign(n, LSA_MATCH_UNKOWN);
+      LocDebug[k].weights.assign(n, 0.);
+      if (n > 0) LSA_TRY(lsa_download_match(Ctx, k, LocDebug[k].status.data(), LocDebug[k].weights.data(), nullptr, n));
+    }
+  return LSA_OK;
+}
+
+// Slam::UpdateMapsUsingTworld (Slam.cxx:1178-1222)
+int SlamCore::UpdateMapsUsingTworld()
+{
+  const Pose motion = Inverse(KfLastPose) * Tworld;
+  const double trans = std::sqrt((motion(0, 3) * motion(0, 3) + motion(1, 3) * motion(1, 3)) + motion(2, 3) * motion(2, 3));
+  const double rot = RotationAngle(motion);
+  constexpr double MIN_KF_NB = 10.;
+  const double thresholdCoef = std::min(KfCounter / MIN_KF_NB, 1.);
+  unsigned nbMapKpts = 0;
+  for (int k = 0; k < 3; ++k) nbMapKpts += LocalMaps[k]->Size();
+  const bool isNewKeyFrame = nbMapKpts < MinNbMatchedKeypoints * 10 || trans >= thresholdCoef * KfDistanceThreshold ||
+                             rot >= (thresholdCoef * KfAngleThreshold) / 180. * M_PI;
+  if (!isNewKeyFrame) return LSA_OK;
+  KfCounter++;
+  KfLastPose = Tworld;
+  for (int k = 0; k < 3; ++k)
+  {
+    if (!UseKeypoints[k]) continue;
+    const int n = lsa_keypoint_count(Ctx, LSA_SET_WORKING, k);
+    Scratch.resize(std::max(n, 0));
+    if (n > 0) LSA_TRY(lsa_download_transformed(Ctx, LSA_SET_WORKING, k, Tworld.m, Scratch.data(), n));
+    LocalMaps[k]->Add(Scratch, false, CurrentTime);
+  }
+  return LSA_OK;
+}
+
+// Slam::LogCurrentFrameState with LoggingTimeout == 0 (Slam.cxx:1257-1263)
+void SlamCore::LogCurrentFrameState(double time)
+{
+  LogTrajectory.push_back({Tworld, time});
+  while (LogTrajectory.size() > 2) LogTrajectory.pop_front();
+}
+
+// Slam::InterpolateScanPose (Slam.cxx:1271-1285)
+Pose SlamCore::InterpolateScanPose(double time) const
+{
+  if (LogTrajectory.empty()) return Tworld;
+  const double prevPoseTime = LogTrajectory.back().time;
+  const double currPoseTime = StampToSec(CurrentStamp);
+  if (std::abs(time / (currPoseTime - prevPoseTime)) > MaxExtrapolationRatio) return Tworld;
+  return LinearInterpolation(PreviousTworld, Tworld, currPoseTime + time, prevPoseTime, currPoseTime);
+}
+
+// Slam::InitUndistortion (Slam.cxx:1288-1319)
+int SlamCore::InitUndistortion()
+{
+  double t0, t1;
+  LSA_TRY(lsa_working_time_range(Ctx, &t0, &t1));
+  Motion.SetTimes(t0, t1);
+  Motion.SetTransforms(Pose::Identity(), Pose::Identity());
+  if (Motion.GetTimeRange() < 1e-6) Motion.SetTimes(0., 0.);
+  return LSA_OK;
+}
+
+// Slam::RefineUndistortion (Slam.cxx:1322-1352)
+int SlamCore::RefineUndistortion()
+{
+  const Pose previousBaseBegin = Motion.GetH0();
+  const Pose previousBaseEnd = Motion.GetH1();
+  const Pose worldToBaseBegin = InterpolateScanPose(Motion.Time0);
+  const Pose worldToBaseEnd = InterpolateScanPose(Motion.Time1);
+  const Pose baseToWorld = Inverse(Tworld);
+  const Pose newBaseBegin = baseToWorld * worldToBaseBegin;
+  const Pose newBaseEnd = baseToWorld * worldToBaseEnd;
+  Motion.SetTransforms(newBaseBegin, newBaseEnd);
+  const Pose d0 = newBaseBegin * Inverse(previousBaseBegin);
+  const Pose d1 = newBaseEnd * Inverse(previousBaseEnd);
+  LSA_TRY(lsa_undistort(Ctx, d0.m, d1.m, Motion.Time0, Motion.Time1));
+  return LSA_OK;
+}
+
+int SlamCore::GetKeypoints(int type, bool world, std::vector<lsa_point_t>& out)
+{
+  if (!Ctx) return LSA_E_NO_DEVICE;
+  const int n = lsa_keypoint_count(Ctx, LSA_SET_WORKING, type);
+  out.resize(std::max(n, 0));
+  if (n <= 0) return 0;
+  if (world) LSA_TRY(lsa_download_transformed(Ctx, LSA_SET_WORKING, type, Tworld.m, out.data(), n));
+  else LSA_TRY(lsa_download_keypoints(Ctx, LSA_SET_WORKING, type, out.data(), n));
+  return n;
+}
+
+int SlamCore::GetRawKeypoints(int type, std::vector<lsa_point_t>& out)
+{
+  if (!Ctx) return LSA_E_NO_DEVICE;
+  const int n = lsa_keypoint_count(Ctx, LSA_SET_RAW_CURRENT, type);
+  out.resize(std::max(n, 0));
+  if (n > 0) LSA_TRY(lsa_download_keypoints(Ctx, LSA_SET_RAW_CURRENT, type, out.data(), n));
+  return n;
+}
+
+// Slam::GetRegisteredFrame -> AggregateFrames(CurrentFrames, true) (Slam.cxx:660-667, 1512-1578)
+int SlamCore::GetRegisteredFrame(std::vector<lsa_point_t>& out)
+{
+  if (!Ctx) return LSA_E_NO_DEVICE;
+  out.clear();
+  if (!HaveFrame) return 0;
+  const int n = lsa_frame_size(Ctx);
+  if (n <= 0) return 0;
+  out.resize(n);
+  if (Undistortion)
+  {
+    const Pose H0 = (Tworld * Motion.GetH0()) * BaseToLidarOffset;
+    const Pose H1 = (Tworld * Motion.GetH1()) * BaseToLidarOffset;
+    LSA_TRY(lsa_transform_frame(Ctx, 1, H0.m, H1.m, Motion.Time0, Motion.Time1, out.data(), n));
+  }
+  else
+  {
+    // the reference skips the work when the transform is identity; applying identity gives the same points
+    const Pose tf = Tworld * BaseToLidarOffset;
+    LSA_TRY(lsa_transform_frame(Ctx, 0, tf.m, nullptr, 0., 0., out.data(), n));
+  }
+  return n;
+}
+
+// name -> member table shared by SetParam / GetParam
+#define LSA_PARAMS(X)                                                                                   \
+  X("UseBlobs", UseKeypoints[LSA_BLOB], bool)                                                          \
+  X("UseEdges", UseKeypoints[LSA_EDGE], bool)                                                          \
+  X("UsePlanes", UseKeypoints[LSA_PLANE], bool)                                                        \
+  X("TwoDMode", TwoDMode, bool)                                                                        \
+  X("EgoMotionICPMaxIter", EgoMotionICPMaxIter, unsigned)                                              \
+  X("LocalizationICPMaxIter", LocalizationICPMaxIter, unsigned)                                        \
+  X("EgoMotionLMMaxIter", EgoMotionLMMaxIter, unsigned)                                                \
+  X("LocalizationLMMaxIter", LocalizationLMMaxIter, unsigned)                                          \
+  X("EgoMotionMaxNeighborsDistance", EgoMotionMaxNeighborsDistance, double)                            \
+  X("LocalizationMaxNeighborsDistance", LocalizationMaxNeighborsDistance, double)                      \
+  X("EgoMotionEdgeNbNeighbors", EgoMotionEdgeNbNeighbors, unsigned)                                    \
+  X("EgoMotionEdgeMinNbNeighbors", EgoMotionEdgeMinNbNeighbors, unsigned)                              \
+  X("EgoMotionEdgeMaxModelError", EgoMotionEdgeMaxModelError, double)                                  \
+  X("EgoMotionPlaneNbNeighbors", EgoMotionPlaneNbNeighbors, unsigned)                                  \
+  X("EgoMotionPlanarityThreshold", EgoMotionPlanarityThreshold, double)                                \
+  X("EgoMotionPlaneMaxModelError", EgoMotionPlaneMaxModelError, double)                                \
+  X("EgoMotionInitSaturationDistance", EgoMotionInitSaturationDistance, double)                        \
+  X("EgoMotionFinalSaturationDistance", EgoMotionFinalSaturationDistance, double)                      \
+  X("LocalizationEdgeNbNeighbors", LocalizationEdgeNbNeighbors, unsigned)                              \
+  X("LocalizationEdgeMinNbNeighbors", LocalizationEdgeMinNbNeighbors, unsigned)                        \
+  X("LocalizationEdgeMaxModelError", LocalizationEdgeMaxModelError, double)                            \
+  X("LocalizationPlaneNbNeighbors", LocalizationPlaneNbNeighbors, unsigned)                            \
+  X("LocalizationPlanarityThreshold", LocalizationPlanarityThreshold, double)                          \
+  X("LocalizationPlaneMaxModelError", LocalizationPlaneMaxModelError, double)                          \
+  X("LocalizationBlobNbNeighbors", LocalizationBlobNbNeighbors, unsigned)                              \
+  X("LocalizationInitSaturationDistance", LocalizationInitSaturationDistance, double)                  \
+  X("LocalizationFinalSaturationDistance", LocalizationFinalSaturationDistance, double)                \
+  X("MaxExtrapolationRatio", MaxExtrapolationRatio, double)                                            \
+  X("MinNbMatchedKeypoints", MinNbMatchedKeypoints, unsigned)                                          \
+  X("KfDistanceThreshold", KfDistanceThreshold, double)                                                \
+  X("KfAngleThreshold", KfAngleThreshold, double)                                                      \
+  X("KeepMatchDebug", KeepMatchDebug, bool)                                                            \
+  X("NeighborWidth", ExtractParams.neighbor_width, int)                                                \
+  X("MinDistanceToSensor", ExtractParams.min_distance_to_sensor, float)                                \
+  X("MinBeamSurfaceAngle", ExtractParams.min_beam_surface_angle, float)                                \
+  X("PlaneSinAngleThreshold", ExtractParams.plane_sin_angle_threshold, float)                          \
+  X("EdgeSinAngleThreshold", ExtractParams.edge_sin_angle_threshold, float)                            \
+  X("DistToLineThreshold", ExtractParams.dist_to_line_threshold, float)                                \
+  X("EdgeDepthGapThreshold", ExtractParams.edge_depth_gap_threshold, float)                            \
+  X("EdgeSaliencyThreshold", ExtractParams.edge_saliency_threshold, float)                             \
+  X("EdgeIntensityGapThreshold", ExtractParams.edge_intensity_gap_threshold, float)
+
+int SlamCore::SetParam(const std::string& name, double v)
+{
+#define X(NAME, MEMBER, TYPE) if (name == NAME) { MEMBER = static_cast<TYPE>(v); return LSA_OK; }
+  LSA_PARAMS(X)
+#undef X
+  if (name == "NbThreads") return LSA_OK;  // OpenMP thread count of the reference: no meaning on the device path
+  if (name == "Verbosity") return LSA_OK;
+  if (name == "EgoMotion") { EgoMotion = static_cast<EgoMotionMode>(static_cast<int>(v)); return LSA_OK; }
+  if (name == "Undistortion") { Undistortion = static_cast<UndistortionMode>(static_cast<int>(v)); return LSA_OK; }
+  if (name == "MapUpdate") { MapUpdate = static_cast<MappingMode>(static_cast<int>(v)); return LSA_OK; }
+  if (name == "AzimuthalResolution") { if (Ctx) lsa_set_azimuthal_resolution(Ctx, static_cast<float>(v)); return LSA_OK; }
+  if (name == "VoxelGridLeafSizeEdges") { LocalMaps[LSA_EDGE]->SetLeafSize(v); return LSA_OK; }
+  if (name == "VoxelGridLeafSizePlanes") { LocalMaps[LSA_PLANE]->SetLeafSize(v); return LSA_OK; }
+  if (name == "VoxelGridLeafSizeBlobs") { LocalMaps[LSA_BLOB]->SetLeafSize(v); return LSA_OK; }
+  if (name == "VoxelGridSize") { for (auto& m : LocalMaps) m->SetGridSize(static_cast<int>(v)); return LSA_OK; }
+  if (name == "VoxelGridResolution") { for (auto& m : LocalMaps) m->SetVoxelResolution(v); return LSA_OK; }
+  if (name == "VoxelGridMinFramesPerVoxel") { for (auto& m : LocalMaps) m->SetMinFramesPerVoxel(static_cast<unsigned>(v)); return LSA_OK; }
+  if (name == "VoxelGridDecayingThreshold") { for (auto& m : LocalMaps) m->SetDecayingThreshold(v); return LSA_OK; }
+  if (name == "VoxelGridSamplingMode") { for (auto& m : LocalMaps) m->SetSampling(static_cast<SamplingMode>(static_cast<int>(v))); return LSA_OK; }
+  LastError = "unknown parameter " + name;
+  return LSA_E_ARG;
+}
+
+int SlamCore::GetParam(const std::string& name, double* v) const
+{
+  if (!v) return LSA_E_ARG;
+#define X(NAME, MEMBER, TYPE) if (name == NAME) { *v = static_cast<double>(MEMBER); return LSA_OK; }
+  LSA_PARAMS(X)
+#undef X
+  if (name == "EgoMotion") { *v = static_cast<int>(EgoMotion); return LSA_OK; }
+  if (name == "Undistortion") { *v = static_cast<int>(Undistortion); return LSA_OK; }
+  if (name == "MapUpdate") { *v = static_cast<int>(MapUpdate); return LSA_OK; }
+  if (name == "AzimuthalResolution") { *v = Ctx ? lsa_get_azimuthal_resolution(Ctx) : 0.; return LSA_OK; }
+  if (name == "VoxelGridLeafSizeEdges") { *v = LocalMaps[LSA_EDGE]->GetLeafSize(); return LSA_OK; }
+  if (name == "VoxelGridLeafSizePlanes") { *v = LocalMaps[LSA_PLANE]->GetLeafSize(); return LSA_OK; }
+  if (name == "VoxelGridLeafSizeBlobs") { *v = LocalMaps[LSA_BLOB]->GetLeafSize(); return LSA_OK; }
+  if (name == "VoxelGridSize") { *v = LocalMaps[0]->GetGridSize(); return LSA_OK; }
+  if (name == "VoxelGridResolution") { *v = LocalMaps[0]->GetVoxelResolution(); return LSA_OK; }
+  if (name == "NbrFrameProcessed") { *v = NbrFrameProcessed; return LSA_OK; }
+  if (name == "TotalMatchedKeypoints") { *v = TotalMatchedKeypoints; return LSA_OK; }
+  return LSA_E_ARG;
+}
+
+}  // namespace host
+}  // namespace lsa

@@ -1,0 +1,139 @@
+// lsa_slam_core.h -- per-frame pipeline of LidarSlam::Slam on top of the C ABI
+// (slam_lib/src/Slam.cxx: AddFrames :230-344, ExtractKeypoints :746-810, ComputeEgoMotion
+//  :813-972, Localization :975-1175, UpdateMapsUsingTworld :1178-1222, LogCurrentFrameState
+//  :1225-1264, undistortion :1271-1352; defaults slam_lib/include/LidarSlam/Slam.h:403-694).
+//
+// Host keeps what SURVEY.md 8 leaves on the host: frame checks, pose bookkeeping, the
+// 6-dof trust-region control flow, the rolling voxel maps.  Everything per point / per
+// keypoint runs on the device through lidarslam_amd.h.
+#pragma once
+#include <array>
+#include <deque>
+#include <memory>
+#include <string>
+#include <vector>
+#include "../../../include/lidarslam_amd.h"
+#include "lsa_hostmath.h"
+#include "lsa_lm.h"
+#include "lsa_rolling_grid.h"
+
+namespace lsa
+{
+namespace host
+{
+
+enum UndistortionMode { UNDISTORTION_NONE = 0, UNDISTORTION_ONCE = 1, UNDISTORTION_REFINED = 2 };
+enum class EgoMotionMode { NONE = 0, MOTION_EXTRAPOLATION = 1, REGISTRATION = 2, MOTION_EXTRAPOLATION_AND_REGISTRATION = 3 };
+enum class MappingMode { NONE = 0, ADD_KPTS_TO_FIXED_MAP = 1, UPDATE = 2 };
+
+struct StampedPose
+{
+  Pose pose;
+  double time;
+};
+
+struct FrameStats
+{
+  double total = 0, extract = 0, ego_icp = 0, ego_lm = 0, loc_icp = 0, loc_lm = 0, undistort = 0, submap = 0, maps = 0;
+  int ego_iters = 0, loc_iters = 0, lm_evals = 0;
+};
+
+struct MatchDebug
+{
+  std::vector<uint8_t> status;
+  std::vector<double> weights;
+};
+
+class SlamCore
+{
+public:
+  explicit SlamCore(int device);
+  ~SlamCore();
+  SlamCore(const SlamCore&) = delete;
+  SlamCore& operator=(const SlamCore&) = delete;
+
+  bool Ok() const { return Ctx != nullptr; }
+  const std::string& Error() const { return LastError; }
+  lsa_ctx* Context() { return Ctx; }
+
+  void Reset(bool resetLog = true);
+  // Slam::AddFrame on a host scan / on a scan resident in the frame store
+  int AddFrame(const lsa_point_t* pts, int n, uint64_t stampUs, uint32_t seq);
+  int AddStoredFrame(int slot, uint64_t stampUs, uint32_t seq);
+
+  Pose GetWorldTransform(double* time = nullptr) const;
+  const std::array<double, 36>& GetTransformCovariance() const { return LocalizationUncertainty.Covariance; }
+  int GetKeypoints(int type, bool world, std::vector<lsa_point_t>& out);
+  int GetRawKeypoints(int type, std::vector<lsa_point_t>& out);
+  int GetRegisteredFrame(std::vector<lsa_point_t>& out);
+  const MatchDebug& GetMatchDebug(bool localization, int type) const { return localization ? LocDebug[type] : EgoDebug[type]; }
+
+  int SetParam(const std::string& name, double v);
+  int GetParam(const std::string& name, double* v) const;
+
+  // ---- parameters (names = the reference's members) ----
+  bool UseKeypoints[3] = {true, true, false};
+  EgoMotionMode EgoMotion = EgoMotionMode::MOTION_EXTRAPOLATION;
+  UndistortionMode Undistortion = UNDISTORTION_REFINED;
+  bool TwoDMode = false;
+  unsigned EgoMotionICPMaxIter = 4, LocalizationICPMaxIter = 3;
+  unsigned EgoMotionLMMaxIter = 15, LocalizationLMMaxIter = 15;
+  double EgoMotionMaxNeighborsDistance = 5., LocalizationMaxNeighborsDistance = 5.;
+  unsigned EgoMotionEdgeNbNeighbors = 8, EgoMotionEdgeMinNbNeighbors = 3;
+  double EgoMotionEdgeMaxModelError = 0.2;
+  unsigned LocalizationEdgeNbNeighbors = 10, LocalizationEdgeMinNbNeighbors = 4;
+  double LocalizationEdgeMaxModelError = 0.2;
+  unsigned EgoMotionPlaneNbNeighbors = 5;
+  double EgoMotionPlanarityThreshold = 0.04, EgoMotionPlaneMaxModelError = 0.2;
+  unsigned LocalizationPlaneNbNeighbors = 5;
+  double LocalizationPlanarityThreshold = 0.04, LocalizationPlaneMaxModelError = 0.2;
+  unsigned LocalizationBlobNbNeighbors = 10;
+  double EgoMotionInitSaturationDistance = 5., EgoMotionFinalSaturationDistance = 1.;
+  double LocalizationInitSaturationDistance = 2., LocalizationFinalSaturationDistance = 0.5;
+  double MaxExtrapolationRatio = 3.;
+  unsigned MinNbMatchedKeypoints = 20;
+  double KfDistanceThreshold = 0.5, KfAngleThreshold = 5.;
+  MappingMode MapUpdate = MappingMode::UPDATE;
+  Pose BaseToLidarOffset = Pose::Identity();
+  lsa_extract_params_t ExtractParams;
+  bool KeepMatchDebug = false;  // download MatchingResults::Rejections/Weights every frame (Slam::GetDebugArray)
+
+  std::shared_ptr<RollingGrid> LocalMaps[3];
+
+  // ---- state ----
+  Pose Tworld, PreviousTworld, Trelative;
+  RegistrationError LocalizationUncertainty;
+  unsigned TotalMatchedKeypoints = 0;
+  unsigned NbrFrameProcessed = 0;
+  int KfCounter = 0;
+  FrameStats Stats;
+  std::deque<StampedPose> LogTrajectory;
+  int KeypointCounts[3] = {0, 0, 0};
+
+private:
+  int ProcessCurrentFrame(uint64_t stampUs);
+  int ExtractKeypoints();
+  int ComputeEgoMotion();
+  int Localization();
+  int UpdateMapsUsingTworld();
+  void LogCurrentFrameState(double time);
+  Pose InterpolateScanPose(double time) const;
+  int InitUndistortion();
+  int RefineUndistortion();
+  int Fail(int rc, const char* where);
+  lsa_match_params_t EgoMatchParams() const;
+  lsa_match_params_t LocMatchParams() const;
+
+  lsa_ctx* Ctx = nullptr;
+  std::string LastError;
+  uint64_t CurrentStamp = 0;
+  bool HaveFrame = false;
+  double CurrentTime = 0.;
+  WithinFrameMotion Motion;
+  Pose KfLastPose;
+  MatchDebug EgoDebug[3], LocDebug[3];
+  std::vector<lsa_point_t> Scratch;
+};
+
+}  // namespace host
+}  // namespace lsa

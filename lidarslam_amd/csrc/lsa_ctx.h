@@ -1,0 +1,176 @@
+// lsa_ctx.h -- device context of liblidarslam_amd (one per Slam instance).
+//
+// Data layout in HBM (all owned by the context, sized once per capacity step):
+//   frame        AoS lsa_point_t[N]           the scan as handed over (32 B / point)
+//   ring-major   float4 xyzi[N]               x,y,z,intensity bucketed by laser ring,
+//                uint32 orig[N], uint16 ring_of[N]     arrival order kept inside a ring
+//   scores       float angle/depth_gap/saliency/intensity_gap [N], uint8 valid[N], label[N]
+//   keypoints    AoS lsa_point_t [3 sets][3 types][N]  raw current / raw previous / working
+//   target[k]    AoS points + float4 xyz|laser (gather friendly) + dense search grid
+//                (cell_start[ncells+1], cell-sorted float4 xyz|index)
+//   match[k]     SoA residual records rec[16][K] (A 9, P 3, X 3, weight), status[K]
+//   reduce       per-block partials of the normal equations, 29 doubles each
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "../../include/lidarslam_amd.h"
+
+namespace lsa
+{
+
+constexpr int kMaxRings = 512;            // laser_id < kMaxRings (largest spinning sensors have 128)
+constexpr int kMaxRingPoints = 8192;      // points per ring handled by the in-LDS labelling kernel
+constexpr int kBucketChunk = 1024;        // points per block of the ring bucketing kernels
+constexpr int kCellCap = 1 << 21;         // max cells of one kNN search grid
+constexpr int kAccumBlocks = 120;         // grid of the normal-equation kernel (grid-stride)
+constexpr int kAccumVals = 29;            // cost, g[6], H upper[21], nvalid
+
+struct GridDesc
+{
+  float origin[3];
+  float cell;
+  float inv_cell;
+  int dims[3];
+  int ncells;
+  int npoints;
+};
+
+struct Target
+{
+  lsa_point_t* pts = nullptr;   // AoS as given (order kept)
+  float4* xyzl = nullptr;       // x,y,z, laser_id bits
+  float4* sorted = nullptr;     // cell-sorted x,y,z, index bits
+  uint32_t* cell_of = nullptr;  // cell id per point
+  uint32_t* cell_start = nullptr;  // kCellCap + 1
+  uint32_t* cell_fill = nullptr;   // kCellCap
+  uint32_t* block_sums = nullptr;
+  GridDesc* desc = nullptr;     // device
+  int* bbox_bits = nullptr;     // 6 ordered ints
+  int m = 0;
+  int cap = 0;
+  float cell_hint = 1.0f;
+};
+
+struct MatchBuf
+{
+  double* rec = nullptr;       // [16][cap]
+  uint8_t* status = nullptr;   // [cap]
+  int k = 0;                   // number of queries of the last match
+  int cap = 0;
+  double sat = 1.0;
+  bool valid = false;
+};
+
+struct KernelStat
+{
+  std::string name;
+  uint32_t launches = 0;
+  double total_ms = 0;
+  double bytes = 0;
+};
+
+struct PendingEvent
+{
+  int stat;
+  hipEvent_t a, b;
+};
+
+}  // namespace lsa
+
+struct lsa_ctx
+{
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string error;
+
+  // frame
+  lsa_point_t* frame = nullptr;      // current frame (may alias a store slot)
+  lsa_point_t* frame_own = nullptr;  // buffer owned for lsa_upload_frame
+  int frame_n = 0;
+  int cap_n = 0;  // capacity of all N-sized buffers
+  std::vector<std::pair<lsa_point_t*, int>> store;
+  float az_res = 0.f;
+  int nb_rings_seen = 0;
+
+  // ring-major
+  float4* xyzi = nullptr;
+  uint32_t* orig = nullptr;
+  uint16_t* ring_of = nullptr;
+  uint32_t* block_hist = nullptr;  // [nblocks][kMaxRings]
+  int* ring_start = nullptr;       // [kMaxRings + 1]
+  int* ring_len = nullptr;         // [kMaxRings]
+  int* ring_meta = nullptr;        // [0] nrings, [1] max laser id, [2] error flags
+  float* score[4] = {nullptr, nullptr, nullptr, nullptr};  // angle, depth_gap, saliency, intensity_gap
+  uint8_t* valid = nullptr;
+  uint8_t* label = nullptr;
+  int* ring_counts = nullptr;  // [kMaxRings][3]
+  int* kp_count_dev = nullptr; // [3]
+
+  // keypoint sets [set][type]
+  lsa_point_t* kp[3][3] = {};
+  int kp_n[3][3] = {};
+
+  lsa::Target target[3];
+  lsa::MatchBuf match[3];
+
+  double* partials = nullptr;  // [kAccumBlocks][kAccumVals]
+  double* reduce_out = nullptr;
+  double* host_pinned = nullptr;  // >= 64 doubles, pinned
+  int* hist_dev = nullptr;        // [8] + slow-query counter
+  void* scratch_out = nullptr;    // device staging for transformed downloads
+  size_t scratch_cap = 0;
+  unsigned long long* range_bits = nullptr;  // time range / bbox reductions
+
+  // profiling
+  bool profiling = false;
+  std::vector<lsa::KernelStat> stats;
+  std::vector<lsa::PendingEvent> pending;
+  std::vector<hipEvent_t> event_pool;
+
+  int fail(int code, const std::string& msg)
+  {
+    error = msg;
+    return code;
+  }
+};
+
+namespace lsa
+{
+#define LSA_HIP(ctx, call)                                                                              \
+  do                                                                                                    \
+  {                                                                                                     \
+    hipError_t e__ = (call);                                                                            \
+    if (e__ != hipSuccess)                                                                              \
+      return (ctx)->fail(LSA_E_HIP, std::string(#call) + ": " + hipGetErrorString(e__));                \
+  } while (0)
+
+int ensure_capacity(lsa_ctx* ctx, int n);
+int ensure_target(lsa_ctx* ctx, int type, int m);
+int ensure_match(lsa_ctx* ctx, int type, int k);
+int ensure_scratch(lsa_ctx* ctx, size_t bytes);
+
+// RAII helper: times the enclosed launches with HIP events on the ctx stream when profiling
+struct ProfScope
+{
+  lsa_ctx* ctx;
+  int stat = -1;
+  hipEvent_t a = nullptr, b = nullptr;
+  ProfScope(lsa_ctx* c, const char* name, double bytes);
+  ~ProfScope();
+};
+void profile_collect(lsa_ctx* ctx);
+
+// host-side 4x4 row-major -> Rigid
+inline void row_major_to_rt(const double T[16], double R[9], double t[3])
+{
+  for (int i = 0; i < 3; ++i)
+  {
+    for (int j = 0; j < 3; ++j) R[i * 3 + j] = T[i * 4 + j];
+    t[i] = T[i * 4 + 3];
+  }
+}
+}  // namespace lsa

@@ -1,0 +1,330 @@
+// lsa_ctx.hip -- context lifetime, device buffers, frame upload / frame store,
+// host-side azimuthal resolution estimate, per-kernel HIP-event profiling.
+#include <algorithm>
+#include <cmath>
+#include "lsa_ctx.h"
+
+using namespace lsa;
+
+namespace lsa
+{
+
+template <typename T> static hipError_t dev_alloc(T** p, size_t count)
+{
+  if (*p) { (void)hipFree(*p); *p = nullptr; }
+  return hipMalloc((void**)p, std::max<size_t>(count, 1) * sizeof(T));
+}
+
+int ensure_capacity(lsa_ctx* ctx, int n)
+{
+  if (n <= ctx->cap_n) return LSA_OK;
+  // grow geometrically so that a sequence with slightly varying scan sizes allocates once
+  int cap = std::max(n + n / 8, 4096);
+  LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  // keypoint sets must survive a growth (raw previous is still needed): copy them over
+  lsa_point_t* old_kp[3][3];
+  for (int s = 0; s < 3; ++s)
+    for (int k = 0; k < 3; ++k) { old_kp[s][k] = ctx->kp[s][k]; ctx->kp[s][k] = nullptr; }
+  for (int s = 0; s < 3; ++s)
+    for (int k = 0; k < 3; ++k)
+    {
+      LSA_HIP(ctx, dev_alloc(&ctx->kp[s][k], (size_t)cap));
+      if (old_kp[s][k] && ctx->kp_n[s][k] > 0)
+        LSA_HIP(ctx, hipMemcpy(ctx->kp[s][k], old_kp[s][k], (size_t)ctx->kp_n[s][k] * sizeof(lsa_point_t), hipMemcpyDeviceToDevice));
+      if (old_kp[s][k]) (void)hipFree(old_kp[s][k]);
+    }
+  LSA_HIP(ctx, dev_alloc(&ctx->frame_own, (size_t)cap));
+  LSA_HIP(ctx, dev_alloc(&ctx->xyzi, (size_t)cap));
+  LSA_HIP(ctx, dev_alloc(&ctx->orig, (size_t)cap));
+  LSA_HIP(ctx, dev_alloc(&ctx->ring_of, (size_t)cap));
+  int nblocks = (cap + kBucketChunk - 1) / kBucketChunk;
+  LSA_HIP(ctx, dev_alloc(&ctx->block_hist, (size_t)nblocks * kMaxRings));
+  for (int i = 0; i < 4; ++i) LSA_HIP(ctx, dev_alloc(&ctx->score[i], (size_t)cap));
+  LSA_HIP(ctx, dev_alloc(&ctx->valid, (size_t)cap));
+  LSA_HIP(ctx, dev_alloc(&ctx->label, (size_t)cap));
+  ctx->cap_n = cap;
+  return LSA_OK;
+}
+
+int ensure_target(lsa_ctx* ctx, int type, int m)
+{
+  Target& t = ctx->target[type];
+  if (!t.cell_start)
+  {
+    LSA_HIP(ctx, dev_alloc(&t.cell_start, (size_t)kCellCap + 1));
+    LSA_HIP(ctx, dev_alloc(&t.cell_fill, (size_t)kCellCap));
+    LSA_HIP(ctx, dev_alloc(&t.block_sums, (size_t)kCellCap / 1024 + 1));
+    LSA_HIP(ctx, dev_alloc(&t.desc, 1));
+    LSA_HIP(ctx, dev_alloc(&t.bbox_bits, 8));
+  }
+  if (m <= t.cap) return LSA_OK;
+  int cap = std::max(m + m / 4, 4096);
+  LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  LSA_HIP(ctx, dev_alloc(&t.pts, (size_t)cap));
+  LSA_HIP(ctx, dev_alloc(&t.xyzl, (size_t)cap));
+  LSA_HIP(ctx, dev_alloc(&t.sorted, (size_t)cap));
+  LSA_HIP(ctx, dev_alloc(&t.cell_of, (size_t)cap));
+  t.cap = cap;
+  return LSA_OK;
+}
+
+int ensure_match(lsa_ctx* ctx, int type, int k)
+{
+  MatchBuf& b = ctx->match[type];
+  if (k <= b.cap) return LSA_OK;
+  int cap = std::max(k + k / 4, 4096);
+  LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  LSA_HIP(ctx, dev_alloc(&b.rec, (size_t)cap * 16));
+  LSA_HIP(ctx, dev_alloc(&b.status, (size_t)cap));
+  b.cap = cap;
+  return LSA_OK;
+}
+
+int ensure_scratch(lsa_ctx* ctx, size_t bytes)
+{
+  if (bytes <= ctx->scratch_cap) return LSA_OK;
+  LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (ctx->scratch_out) (void)hipFree(ctx->scratch_out);
+  ctx->scratch_out = nullptr;
+  LSA_HIP(ctx, hipMalloc(&ctx->scratch_out, bytes + bytes / 4));
+  ctx->scratch_cap = bytes + bytes / 4;
+  return LSA_OK;
+}
+
+ProfScope::ProfScope(lsa_ctx* c, const char* name, double bytes) : ctx(c)
+{
+  if (!ctx->profiling) return;
+  for (size_t i = 0; i < ctx->stats.size(); ++i)
+    if (ctx->stats[i].name == name) { stat = (int)i; break; }
+  if (stat < 0)
+  {
+    ctx->stats.push_back({name, 0, 0, 0});
+    stat = (int)ctx->stats.size() - 1;
+  }
+  ctx->stats[stat].launches++;
+  ctx->stats[stat].bytes += bytes;
+  auto get = [&]() {
+    hipEvent_t e;
+    if (!ctx->event_pool.empty()) { e = ctx->event_pool.back(); ctx->event_pool.pop_back(); }
+    else (void)hipEventCreate(&e);
+    return e;
+  };
+  a = get();
+  b = get();
+  (void)hipEventRecord(a, ctx->stream);
+}
+ProfScope::~ProfScope()
+{
+  if (stat < 0) return;
+  (void)hipEventRecord(b, ctx->stream);
+  ctx->pending.push_back({stat, a, b});
+}
+void profile_collect(lsa_ctx* ctx)
+{
+  for (auto& p : ctx->pending)
+  {
+    (void)hipEventSynchronize(p.b);
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) ctx->stats[p.stat].total_ms += ms;
+    ctx->event_pool.push_back(p.a);
+    ctx->event_pool.push_back(p.b);
+  }
+  ctx->pending.clear();
+}
+
+// SpinningSensorKeypointExtractor::EstimateAzimuthalResolution (SSKE.cxx:593-637), run on
+// the host once, on the first usable frame: its float arithmetic (acos) feeds a threshold of
+// the invalidation pass, so it must be the libm the reference itself would use.
+static float estimate_azimuthal_resolution(const lsa_point_t* pts, int n)
+{
+  // last point seen per ring (arrival order inside a ring is the scan order)
+  std::vector<int> last(kMaxRings, -1);
+  std::vector<std::vector<float>> perRing(kMaxRings);
+  for (int i = 0; i < n; ++i)
+  {
+    unsigned r = pts[i].laser_id;
+    if (r >= (unsigned)kMaxRings) continue;
+    if (last[r] >= 0)
+    {
+      const lsa_point_t& a = pts[last[r]];
+      const lsa_point_t& b = pts[i];
+      float d = a.x * b.x + a.y * b.y;
+      float na = std::sqrt(a.x * a.x + a.y * a.y), nb = std::sqrt(b.x * b.x + b.y * b.y);
+      float angle = std::abs(std::acos(d / (na * nb)));
+      if (angle > 1e-4) perRing[r].push_back(angle);
+    }
+    last[r] = i;
+  }
+  std::vector<float> angles;
+  angles.reserve(n);
+  for (auto& v : perRing) angles.insert(angles.end(), v.begin(), v.end());
+  if (angles.size() < 100) return 0.f;
+  std::sort(angles.begin(), angles.end());
+  unsigned maxInliersIdx = angles.size();
+  float maxAngle = float(5. / 180. * M_PI);
+  float medianAngle = 0.f;
+  while (maxAngle > 1.8 * medianAngle)
+  {
+    maxInliersIdx = std::upper_bound(angles.begin(), angles.begin() + maxInliersIdx, maxAngle) - angles.begin();
+    medianAngle = angles[maxInliersIdx / 2];
+    maxAngle = std::min(medianAngle * 2., maxAngle / 1.8);
+  }
+  return medianAngle;
+}
+
+static void maybe_estimate_resolution(lsa_ctx* ctx, const lsa_point_t* pts, int n)
+{
+  if (ctx->az_res < 1e-6 || M_PI / 4. < ctx->az_res)
+  {
+    float v = estimate_azimuthal_resolution(pts, n);
+    if (v > 0.f) ctx->az_res = v;
+  }
+}
+
+}  // namespace lsa
+
+extern "C" {
+
+int lsa_device_count(void)
+{
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int lsa_ctx_create(int device_id, lsa_ctx** out)
+{
+  if (!out) return LSA_E_ARG;
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device_id < 0 || device_id >= n)
+    return LSA_E_NO_DEVICE;  // no CPU fallback: the caller must fail loudly
+  if (hipSetDevice(device_id) != hipSuccess) return LSA_E_HIP;
+  lsa_ctx* ctx = new lsa_ctx;
+  ctx->device = device_id;
+  if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return LSA_E_HIP; }
+  bool ok = true;
+  ok &= hipMalloc((void**)&ctx->ring_start, (kMaxRings + 1) * sizeof(int)) == hipSuccess;
+  ok &= hipMalloc((void**)&ctx->ring_len, kMaxRings * sizeof(int)) == hipSuccess;
+  ok &= hipMalloc((void**)&ctx->ring_meta, 8 * sizeof(int)) == hipSuccess;
+  ok &= hipMalloc((void**)&ctx->ring_counts, kMaxRings * 3 * sizeof(int)) == hipSuccess;
+  ok &= hipMalloc((void**)&ctx->kp_count_dev, 4 * sizeof(int)) == hipSuccess;
+  ok &= hipMalloc((void**)&ctx->partials, (size_t)kAccumBlocks * kAccumVals * sizeof(double)) == hipSuccess;
+  ok &= hipMalloc((void**)&ctx->reduce_out, 64 * sizeof(double)) == hipSuccess;
+  ok &= hipMalloc((void**)&ctx->hist_dev, 16 * sizeof(int)) == hipSuccess;
+  ok &= hipMalloc((void**)&ctx->range_bits, 16 * sizeof(unsigned long long)) == hipSuccess;
+  ok &= hipHostMalloc((void**)&ctx->host_pinned, 256 * sizeof(double), hipHostMallocDefault) == hipSuccess;
+  if (!ok) { lsa_ctx_destroy(ctx); return LSA_E_HIP; }
+  *out = ctx;
+  return LSA_OK;
+}
+
+void lsa_ctx_destroy(lsa_ctx* ctx)
+{
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  profile_collect(ctx);
+  for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
+  auto fr = [](void* p) { if (p) (void)hipFree(p); };
+  fr(ctx->frame_own); fr(ctx->xyzi); fr(ctx->orig); fr(ctx->ring_of); fr(ctx->block_hist);
+  fr(ctx->ring_start); fr(ctx->ring_len); fr(ctx->ring_meta);
+  for (int i = 0; i < 4; ++i) fr(ctx->score[i]);
+  fr(ctx->valid); fr(ctx->label); fr(ctx->ring_counts); fr(ctx->kp_count_dev);
+  for (int s = 0; s < 3; ++s) for (int k = 0; k < 3; ++k) fr(ctx->kp[s][k]);
+  for (int k = 0; k < 3; ++k)
+  {
+    Target& t = ctx->target[k];
+    fr(t.pts); fr(t.xyzl); fr(t.sorted); fr(t.cell_of); fr(t.cell_start); fr(t.cell_fill); fr(t.block_sums); fr(t.desc); fr(t.bbox_bits);
+    fr(ctx->match[k].rec); fr(ctx->match[k].status);
+  }
+  fr(ctx->partials); fr(ctx->reduce_out); fr(ctx->hist_dev); fr(ctx->scratch_out); fr(ctx->range_bits);
+  for (auto& s : ctx->store) fr(s.first);
+  if (ctx->host_pinned) (void)hipHostFree(ctx->host_pinned);
+  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+const char* lsa_last_error(const lsa_ctx* ctx) { return ctx ? ctx->error.c_str() : "null context"; }
+
+int lsa_sync(lsa_ctx* ctx)
+{
+  if (!ctx) return LSA_E_ARG;
+  LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return LSA_OK;
+}
+
+int lsa_upload_frame(lsa_ctx* ctx, const lsa_point_t* pts, int n)
+{
+  if (!ctx || !pts || n <= 0) return ctx ? ctx->fail(LSA_E_ARG, "lsa_upload_frame: empty frame") : LSA_E_ARG;
+  LSA_HIP(ctx, hipSetDevice(ctx->device));
+  int rc = ensure_capacity(ctx, n);
+  if (rc) return rc;
+  maybe_estimate_resolution(ctx, pts, n);
+  LSA_HIP(ctx, hipMemcpyAsync(ctx->frame_own, pts, (size_t)n * sizeof(lsa_point_t), hipMemcpyHostToDevice, ctx->stream));
+  ctx->frame = ctx->frame_own;
+  ctx->frame_n = n;
+  return LSA_OK;
+}
+
+int lsa_frame_store_put(lsa_ctx* ctx, int slot, const lsa_point_t* pts, int n)
+{
+  if (!ctx || !pts || n <= 0 || slot < 0 || slot > 65536) return ctx ? ctx->fail(LSA_E_ARG, "lsa_frame_store_put: bad argument") : LSA_E_ARG;
+  LSA_HIP(ctx, hipSetDevice(ctx->device));
+  int rc = ensure_capacity(ctx, n);
+  if (rc) return rc;
+  if ((int)ctx->store.size() <= slot) ctx->store.resize(slot + 1, {nullptr, 0});
+  if (ctx->store[slot].first) { (void)hipFree(ctx->store[slot].first); ctx->store[slot] = {nullptr, 0}; }
+  lsa_point_t* d = nullptr;
+  LSA_HIP(ctx, hipMalloc((void**)&d, (size_t)n * sizeof(lsa_point_t)));
+  LSA_HIP(ctx, hipMemcpy(d, pts, (size_t)n * sizeof(lsa_point_t), hipMemcpyHostToDevice));
+  ctx->store[slot] = {d, n};
+  maybe_estimate_resolution(ctx, pts, n);
+  return LSA_OK;
+}
+
+int lsa_frame_store_use(lsa_ctx* ctx, int slot)
+{
+  if (!ctx || slot < 0 || slot >= (int)ctx->store.size() || !ctx->store[slot].first)
+    return ctx ? ctx->fail(LSA_E_ARG, "lsa_frame_store_use: empty slot") : LSA_E_ARG;
+  ctx->frame = ctx->store[slot].first;
+  ctx->frame_n = ctx->store[slot].second;
+  return LSA_OK;
+}
+
+int lsa_frame_size(const lsa_ctx* ctx) { return ctx ? ctx->frame_n : 0; }
+float lsa_get_azimuthal_resolution(const lsa_ctx* ctx) { return ctx ? ctx->az_res : 0.f; }
+void lsa_set_azimuthal_resolution(lsa_ctx* ctx, float rad) { if (ctx) ctx->az_res = rad; }
+int lsa_nb_laser_rings(const lsa_ctx* ctx) { return ctx ? ctx->nb_rings_seen : 0; }
+
+int lsa_profile_enable(lsa_ctx* ctx, int on)
+{
+  if (!ctx) return LSA_E_ARG;
+  ctx->profiling = on != 0;
+  return LSA_OK;
+}
+int lsa_profile_reset(lsa_ctx* ctx)
+{
+  if (!ctx) return LSA_E_ARG;
+  profile_collect(ctx);
+  ctx->stats.clear();
+  return LSA_OK;
+}
+int lsa_profile_get(lsa_ctx* ctx, lsa_kernel_stat_t* out, int capacity)
+{
+  if (!ctx) return LSA_E_ARG;
+  (void)hipStreamSynchronize(ctx->stream);
+  profile_collect(ctx);
+  int n = std::min<int>(capacity, ctx->stats.size());
+  for (int i = 0; i < n; ++i)
+  {
+    std::memset(&out[i], 0, sizeof(out[i]));
+    std::strncpy(out[i].name, ctx->stats[i].name.c_str(), sizeof(out[i].name) - 1);
+    out[i].launches = ctx->stats[i].launches;
+    out[i].total_ms = ctx->stats[i].total_ms;
+    out[i].bytes = ctx->stats[i].bytes;
+  }
+  return n;
+}
+
+}  // extern "C"

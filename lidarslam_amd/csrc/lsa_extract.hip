@@ -1,0 +1,733 @@
+// lsa_extract.hip -- SpinningSensorKeypointExtractor::ComputeKeyPoints on the GPU
+// (slam_lib/src/SpinningSensorKeypointExtractor.cxx:118-136 and everything it calls).
+//
+// Kernels (all HBM-bound gather / stencil / scan work, no MFMA):
+//   k_ring_hist / k_ring_scan / k_ring_scatter   ConvertAndSortScanLines (SSKE.cxx:139-171):
+//       stable counting sort of the firing-order AoS scan into ring-major float4 SoA
+//   k_invalidate                                 InvalidateNotUsablePoints (SSKE.cxx:207-308)
+//   k_curvature<MAXW>                            ComputeCurvature + LineFitting (SSKE.cxx:33-115, 311-471)
+//   k_label                                      SetKeyPointsLabels (SSKE.cxx:474-573): the greedy, sorted
+//       non-maximum selection is evaluated WITHOUT sorting, as the fixed point of a local rule in LDS
+//       (a candidate wins once no undecided higher-priority candidate is left in its window)
+//   k_compact                                    keypoint clouds, ring-major / index ascending (SSKE.cxx:575-589)
+#include <cmath>
+#include "lsa_ctx.h"
+#include "lsa_device_math.h"
+
+using namespace lsa;
+
+namespace
+{
+
+struct ExtractConst
+{
+  int W;
+  float min_dist;
+  float max_pos_diff_coeff;
+  float line_max_sin;
+  float line_sq_max_dist;
+  float sq_dist_to_line_thr;
+  float plane_thr;
+  float edge_angle_thr;
+  float sq_depth_gap_thr;
+  float sq_saliency_thr;
+  float intensity_thr;
+};
+
+__device__ __forceinline__ unsigned laser_of(const float4& second) { return __float_as_uint(second.w) & 0xffffu; }
+
+// --------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_ring_hist(const float4* __restrict__ frame, int n, uint32_t* __restrict__ block_hist,
+                                                   int* __restrict__ ring_meta)
+{
+  __shared__ uint32_t h[kMaxRings];
+  for (int r = threadIdx.x; r < kMaxRings; r += blockDim.x) h[r] = 0;
+  __syncthreads();
+  const int base = blockIdx.x * kBucketChunk;
+  int mx = -1;
+  for (int i = threadIdx.x; i < kBucketChunk; i += blockDim.x)
+  {
+    int g = base + i;
+    if (g < n)
+    {
+      unsigned id = laser_of(frame[2 * (size_t)g + 1]);
+      if (id < (unsigned)kMaxRings)
+      {
+        atomicAdd(&h[id], 1u);
+        mx = max(mx, (int)id);
+      }
+      else
+        atomicOr(&ring_meta[2], 1);
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) mx = max(mx, __shfl_down(mx, o));
+  if ((threadIdx.x & 63) == 0 && mx >= 0) atomicMax(&ring_meta[1], mx);
+  __syncthreads();
+  for (int r = threadIdx.x; r < kMaxRings; r += blockDim.x) block_hist[(size_t)blockIdx.x * kMaxRings + r] = h[r];
+}
+
+__global__ __launch_bounds__(kMaxRings) void k_ring_scan(uint32_t* __restrict__ block_hist, int nblocks, int* __restrict__ ring_start,
+                                                         int* __restrict__ ring_len, int* __restrict__ ring_meta)
+{
+  __shared__ int s[kMaxRings];
+  const int r = threadIdx.x;
+  uint32_t sum = 0;
+  for (int b = 0; b < nblocks; ++b)
+  {
+    uint32_t v = block_hist[(size_t)b * kMaxRings + r];
+    block_hist[(size_t)b * kMaxRings + r] = sum;
+    sum += v;
+  }
+  ring_len[r] = (int)sum;
+  s[r] = (int)sum;
+  __syncthreads();
+  for (int o = 1; o < kMaxRings; o <<= 1)
+  {
+    int v = (r >= o) ? s[r - o] : 0;
+    __syncthreads();
+    s[r] += v;
+    __syncthreads();
+  }
+  ring_start[r] = s[r] - (int)sum;
+  if (r == kMaxRings - 1) ring_start[kMaxRings] = s[r];
+  if (r == 0) ring_meta[0] = ring_meta[1] + 1;  // NbLaserRings = max laser_id + 1 (SSKE.cxx:153-164)
+}
+
+__global__ __launch_bounds__(256) void k_ring_scatter(const float4* __restrict__ frame, int n, const uint32_t* __restrict__ block_hist,
+                                                      const int* __restrict__ ring_start, const int* __restrict__ ring_meta,
+                                                      float4* __restrict__ xyzi, uint32_t* __restrict__ orig, uint16_t* __restrict__ ring_of,
+                                                      uint8_t* __restrict__ valid)
+{
+  __shared__ uint16_t ids[kBucketChunk];
+  __shared__ uint32_t dest[kBucketChunk];
+  const int base = blockIdx.x * kBucketChunk;
+  const int cnt = min(kBucketChunk, n - base);
+  for (int i = threadIdx.x; i < cnt; i += blockDim.x) ids[i] = (uint16_t)laser_of(frame[2 * (size_t)(base + i) + 1]);
+  __syncthreads();
+  const int nrings = ring_meta[0];
+  // one thread owns one ring of the chunk and walks it in arrival order: stable by construction
+  for (int r = threadIdx.x; r < nrings; r += blockDim.x)
+  {
+    uint32_t d = (uint32_t)ring_start[r] + block_hist[(size_t)blockIdx.x * kMaxRings + r];
+    for (int i = 0; i < cnt; ++i)
+      if (ids[i] == r) dest[i] = d++;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < cnt; i += blockDim.x)
+  {
+    if (ids[i] >= kMaxRings) continue;
+    const float4 a = frame[2 * (size_t)(base + i)];
+    const float4 b = frame[2 * (size_t)(base + i) + 1];
+    const uint32_t d = dest[i];
+    xyzi[d] = make_float4(a.x, a.y, a.z, b.z);
+    orig[d] = (uint32_t)(base + i);
+    ring_of[d] = ids[i];
+    valid[d] = 7;
+  }
+}
+
+// --------------------------------------------------------------------------------------------
+__device__ __forceinline__ float sqdist3(const float4& a, const float4& b)
+{
+  Vec3<float> d = {a.x - b.x, a.y - b.y, a.z - b.z};
+  return vsqnorm(d);
+}
+__device__ __forceinline__ float norm3(const float4& a)
+{
+  Vec3<float> d = {a.x, a.y, a.z};
+  return vnorm(d);
+}
+
+__global__ __launch_bounds__(256) void k_invalidate(const float4* __restrict__ xyzi, const uint16_t* __restrict__ ring_of,
+                                                    const int* __restrict__ ring_start, const int* __restrict__ ring_len, int n,
+                                                    ExtractConst c, uint8_t* __restrict__ valid)
+{
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const int r = ring_of[j];
+  const int idx = j - ring_start[r];
+  const int np = ring_len[r];
+  const int W = c.W;
+  if (np < 2 * W + 1 || idx < W || idx >= np - W)
+  {
+    valid[j] = 0;
+    return;
+  }
+  const float4 cur = xyzi[j];
+  const float L = norm3(cur);
+  if (L < c.min_dist) valid[j] = 0;
+  const float lp = L * c.max_pos_diff_coeff;
+  const float maxPosDiff = (lp < 0.02f) ? 0.02f : lp;  // std::max(L * coeff, 0.02f)
+  const float sq = maxPosDiff * maxPosDiff;
+  const float4 nxt = xyzi[j + 1];
+  if (sqdist3(nxt, cur) > sq)
+  {
+    if (L < norm3(nxt))
+    {
+      valid[j + 1] = 0;
+      for (int i = 1; i < W; ++i)
+      {
+        if (sqdist3(xyzi[j + i + 1], xyzi[j + i]) > sq) break;
+        valid[j + i + 1] = 0;
+      }
+    }
+    else
+    {
+      valid[j] = 0;
+      for (int i = 1; i < W; ++i)
+      {
+        if (sqdist3(xyzi[j - i + 1], xyzi[j - i]) > sq) break;
+        valid[j - i] = 0;
+      }
+    }
+  }
+}
+
+// --------------------------------------------------------------------------------------------
+struct Line
+{
+  Vec3<float> dir, pos;
+};
+__device__ __forceinline__ float line_sqdist(const Line& l, const Vec3<float>& p) { return vsqnorm(vcross(vsub(p, l.pos), l.dir)); }
+
+// LineFitting::FitPCA on an accumulated covariance (SSKE.cxx:59-70)
+__device__ __forceinline__ void line_from_cov(CovAccum<float>& acc, int cnt, Line& l)
+{
+  Sym3<float> cov;
+  acc.finish(cnt, l.pos, cov);
+  Vec3<float> e0, e1;
+  float l0, l1, l2;
+  eigen33<float>(cov, e0, e1, l.dir, l0, l1, l2);
+}
+
+// LineFitting::FitPCAAndCheckConsistency (SSKE.cxx:87-108) on the W neighbours of one side,
+// p[0] nearest to the centre
+template <int MAXW>
+__device__ __forceinline__ bool fit_side(const Vec3<float> (&p)[MAXW], int W, const ExtractConst& c, Line& l)
+{
+  Vec3<float> last = p[0];
+#pragma unroll
+  for (int i = 1; i < MAXW; ++i)
+    if (i == W - 1) last = p[i];
+  const Vec3<float> U = normalized3(vsub(last, p[0]));
+  bool straight = true;
+#pragma unroll
+  for (int i = 0; i + 1 < MAXW; ++i)
+  {
+    if (i + 1 < W && straight)
+    {
+      const Vec3<float> V = normalized3(vsub(p[i + 1], p[i]));
+      const float sinAngle = vnorm(vcross(U, V));
+      if (sinAngle > c.line_max_sin) straight = false;
+    }
+  }
+  if (!straight) return false;
+  CovAccum<float> acc;
+#pragma unroll
+  for (int i = 0; i < MAXW; ++i)
+    if (i < W) acc.add(p[i].x, p[i].y, p[i].z);
+  line_from_cov(acc, W, l);
+  bool ok = true;
+#pragma unroll
+  for (int i = 0; i < MAXW; ++i)
+    if (i < W && ok && line_sqdist(l, p[i]) > c.line_sq_max_dist) ok = false;
+  return ok;
+}
+
+template <int MAXW>
+__global__ __launch_bounds__(128) void k_curvature(const float4* __restrict__ xyzi, const uint16_t* __restrict__ ring_of,
+                                                   const int* __restrict__ ring_start, const int* __restrict__ ring_len, int n,
+                                                   ExtractConst c, const uint8_t* __restrict__ valid, float* __restrict__ o_angle,
+                                                   float* __restrict__ o_gap, float* __restrict__ o_sal, float* __restrict__ o_int)
+{
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  float angle = 0.f, gap = 0.f, sal = 0.f, igap = 0.f;
+  const int r = ring_of[j];
+  const int idx = j - ring_start[r];
+  const int np = ring_len[r];
+  const int W = c.W;
+  if (!(np < 2 * W + 1) && idx >= W && idx + W < np && valid[j] != 0)
+  {
+    const float4 ctr4 = xyzi[j];
+    const Vec3<float> ctr = {ctr4.x, ctr4.y, ctr4.z};
+    Vec3<float> lp[MAXW], rp[MAXW];
+    float i_prev = 0.f, i_next = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXW; ++i)
+    {
+      if (i < W)
+      {
+        const float4 a = xyzi[j - 1 - i];
+        const float4 b = xyzi[j + 1 + i];
+        lp[i] = {a.x, a.y, a.z};
+        rp[i] = {b.x, b.y, b.z};
+        if (i == 0) { i_prev = a.w; i_next = b.w; }
+      }
+      else
+      {
+        lp[i] = {0.f, 0.f, 0.f};
+        rp[i] = {0.f, 0.f, 0.f};
+      }
+    }
+    igap = fabsf(i_next - i_prev);
+
+    Line ll, rl;
+    const bool leftFlat = fit_side<MAXW>(lp, W, c, ll);
+    const bool rightFlat = fit_side<MAXW>(rp, W, c, rl);
+    float distLeft = 0.f, distRight = 0.f;
+    if (leftFlat && rightFlat)
+    {
+      distLeft = line_sqdist(ll, ctr);
+      distRight = line_sqdist(rl, ctr);
+      if ((distLeft < c.sq_dist_to_line_thr) && (distRight < c.sq_dist_to_line_thr)) angle = vnorm(vcross(ll.dir, rl.dir));
+    }
+    else if (!leftFlat && rightFlat)
+    {
+      distLeft = 3.40282346638528859812e+38f;
+#pragma unroll
+      for (int i = 0; i < MAXW; ++i)
+        if (i < W)
+        {
+          const float d = line_sqdist(rl, lp[i]);
+          distLeft = (d < distLeft) ? d : distLeft;  // std::min(distLeft, d)
+        }
+      distLeft *= 0.25f;
+    }
+    else if (leftFlat && !rightFlat)
+    {
+      distRight = 3.40282346638528859812e+38f;
+#pragma unroll
+      for (int i = 0; i < MAXW; ++i)
+        if (i < W)
+        {
+          const float d = line_sqdist(ll, rp[i]);
+          distRight = (d < distRight) ? d : distRight;
+        }
+      distRight *= 0.25f;
+    }
+    else
+    {
+      // saliency: contiguous far neighbours (depth gap > 1.5 in squared norm), left then right,
+      // accumulated straight into the covariance sums in the order the reference lists them
+      const float sqCurrDepth = vsqnorm(ctr);
+      CovAccum<float> acc;
+      int cnt = 0;
+      bool seen = false, stop = false;
+#pragma unroll
+      for (int i = 0; i < MAXW; ++i)
+        if (i < W && !stop)
+        {
+          if (fabsf(vsqnorm(lp[i]) - sqCurrDepth) > 1.5f) { seen = true; acc.add(lp[i].x, lp[i].y, lp[i].z); ++cnt; }
+          else if (seen) stop = true;
+        }
+      seen = false; stop = false;
+#pragma unroll
+      for (int i = 0; i < MAXW; ++i)
+        if (i < W && !stop)
+        {
+          if (fabsf(vsqnorm(rp[i]) - sqCurrDepth) > 1.5f) { seen = true; acc.add(rp[i].x, rp[i].y, rp[i].z); ++cnt; }
+          else if (seen) stop = true;
+        }
+      if (cnt > W)
+      {
+        Line fl;
+        line_from_cov(acc, cnt, fl);
+        sal = line_sqdist(fl, ctr);
+      }
+    }
+    gap = (distLeft < distRight) ? distRight : distLeft;  // std::max(distLeft, distRight)
+  }
+  o_angle[j] = angle;
+  o_gap[j] = gap;
+  o_sal[j] = sal;
+  o_int[j] = igap;
+}
+
+// --------------------------------------------------------------------------------------------
+// Greedy non-maximum selection as a fixed point.  st: 0 = out, 1 = undecided candidate, 2 = selected.
+// prio(k) > prio(j):  EDGE  score desc, index asc   (Utils::SortIdx(v, false) + stable tie-break)
+//                     PLANE score asc,  index desc  (the same sorted array walked backwards)
+template <bool PLANE>
+__device__ uint8_t* nms_fixed_point(const float* sc, uint8_t* st, uint8_t* st2, int np, int hw)
+{
+  while (true)
+  {
+    int undecided = 0;
+    for (int j = threadIdx.x; j < np; j += blockDim.x)
+    {
+      uint8_t s = st[j];
+      if (s == 1)
+      {
+        const float v = sc[j];
+        const int b = max(0, j - hw), e = min(np - 1, j + hw);
+        bool selNear = false, higher = false;
+        for (int k = b; k <= e; ++k)
+        {
+          if (k == j) continue;
+          const uint8_t sk = st[k];
+          if (sk == 2) selNear = true;
+          else if (sk == 1)
+          {
+            const float vk = sc[k];
+            const bool hk = PLANE ? (vk < v || (vk == v && k > j)) : (vk > v || (vk == v && k < j));
+            if (hk) higher = true;
+          }
+        }
+        if (selNear) s = 0;
+        else if (!higher) s = 2;
+        else undecided = 1;
+      }
+      st2[j] = s;
+    }
+    const int any = __syncthreads_or(undecided);
+    uint8_t* t = st; st = st2; st2 = t;
+    if (!any) break;
+  }
+  return st;  // final state (the buffers were swapped once per round)
+}
+
+// after a selection round: label the winners, clear the validity bit `vbit` within +-hw of them
+__device__ void nms_apply(const uint8_t* st, uint8_t* flags, int np, int hw, uint8_t vbit, uint8_t lbit)
+{
+  for (int j = threadIdx.x; j < np; j += blockDim.x)
+  {
+    const int b = max(0, j - hw), e = min(np - 1, j + hw);
+    bool near = false;
+    for (int k = b; k <= e; ++k) near |= (st[k] == 2);
+    uint8_t f = flags[j];
+    if (st[j] == 2) f |= lbit;
+    if (near) f &= ~vbit;
+    flags[j] = f;
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void k_label(const float* __restrict__ g_angle, const float* __restrict__ g_gap,
+                                               const float* __restrict__ g_sal, const float* __restrict__ g_int,
+                                               const int* __restrict__ ring_start, const int* __restrict__ ring_len,
+                                               int* __restrict__ ring_meta, ExtractConst c, uint8_t* __restrict__ valid,
+                                               uint8_t* __restrict__ label, int* __restrict__ ring_counts)
+{
+  __shared__ float sc[kMaxRingPoints];
+  __shared__ uint8_t stA[kMaxRingPoints];
+  __shared__ uint8_t stB[kMaxRingPoints];
+  __shared__ uint8_t flags[kMaxRingPoints];  // bits 0-2 validity E/P/B, bits 3-5 label E/P/B
+  __shared__ int cnt[3];
+  const int r = blockIdx.x;
+  if (r >= ring_meta[0]) return;
+  const int s0 = ring_start[r];
+  const int np = ring_len[r];
+  if (threadIdx.x < 3) cnt[threadIdx.x] = 0;
+  if (np > kMaxRingPoints)
+  {
+    if (threadIdx.x == 0) atomicOr(&ring_meta[2], 2);
+    return;
+  }
+  const int W = c.W;
+  if (np < 2 * W + 1)
+  {
+    // IsScanLineAlmostEmpty: nothing is labelled, validity stays cleared (SSKE.cxx:487-490)
+    for (int j = threadIdx.x; j < np; j += blockDim.x) label[s0 + j] = 0;
+    if (threadIdx.x < 3) ring_counts[r * 3 + threadIdx.x] = 0;
+    return;
+  }
+  for (int j = threadIdx.x; j < np; j += blockDim.x) flags[j] = valid[s0 + j] & 7;
+  __syncthreads();
+
+  // --- edges: depth gap, angle, saliency, intensity gap, in this order (SSKE.cxx:526-533)
+  for (int crit = 0; crit < 4; ++crit)
+  {
+    const float* src = crit == 0 ? g_gap : crit == 1 ? g_angle : crit == 2 ? g_sal : g_int;
+    const float thr = crit == 0 ? c.sq_depth_gap_thr : crit == 1 ? c.edge_angle_thr : crit == 2 ? c.sq_saliency_thr : c.intensity_thr;
+    const int hw = crit == 1 ? W : crit == 3 ? 1 : W - 1;
+    for (int j = threadIdx.x; j < np; j += blockDim.x)
+    {
+      const float v = src[s0 + j];
+      sc[j] = v;
+      stA[j] = ((v >= thr) && (flags[j] & 1)) ? 1 : 0;  // NaN never qualifies
+    }
+    __syncthreads();
+    nms_apply(nms_fixed_point<false>(sc, stA, stB, np, hw), flags, np, hw, 1, 8);
+  }
+
+  // --- planes: ascending sin angle, skip < 1e-6, stop above the threshold, +-4 window (SSKE.cxx:536-563)
+  {
+    const int hw = 4;
+    for (int j = threadIdx.x; j < np; j += blockDim.x)
+    {
+      const float v = g_angle[s0 + j];
+      sc[j] = v;
+      const bool cand = (flags[j] & 2) && !((double)v < 1e-6) && (v <= c.plane_thr);  // NaN fails v <= thr
+      stA[j] = cand ? 1 : 0;
+    }
+    __syncthreads();
+    nms_apply(nms_fixed_point<true>(sc, stA, stB, np, hw), flags, np, hw, 2, 16);
+  }
+
+  // --- blobs (SSKE.cxx:568-572) + validity bit set back for labelled points (:584) + counts
+  int ce = 0, cp = 0, cb = 0;
+  for (int j = threadIdx.x; j < np; j += blockDim.x)
+  {
+    uint8_t f = flags[j];
+    if ((j % 3) == 0 && (f & 4)) f |= 32;
+    const uint8_t lab = (f >> 3) & 7;
+    label[s0 + j] = lab;
+    valid[s0 + j] = (f & 7) | lab;
+    ce += lab & 1; cp += (lab >> 1) & 1; cb += (lab >> 2) & 1;
+  }
+  for (int o = 32; o > 0; o >>= 1)
+  {
+    ce += __shfl_down(ce, o); cp += __shfl_down(cp, o); cb += __shfl_down(cb, o);
+  }
+  if ((threadIdx.x & 63) == 0)
+  {
+    atomicAdd(&cnt[0], ce); atomicAdd(&cnt[1], cp); atomicAdd(&cnt[2], cb);
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) ring_counts[r * 3 + threadIdx.x] = cnt[threadIdx.x];
+}
+
+// --------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_compact(const float4* __restrict__ frame, const uint32_t* __restrict__ orig,
+                                                 const uint8_t* __restrict__ label, const int* __restrict__ ring_start,
+                                                 const int* __restrict__ ring_len, const int* __restrict__ ring_meta,
+                                                 const int* __restrict__ ring_counts, float4* __restrict__ out_e,
+                                                 float4* __restrict__ out_p, float4* __restrict__ out_b, int* __restrict__ kp_count)
+{
+  __shared__ int base[3];
+  __shared__ unsigned long long part[256];
+  const int r = blockIdx.x;
+  const int nr = ring_meta[0];
+  if (r >= nr) return;
+  if (threadIdx.x < 3)
+  {
+    int s = 0;
+    for (int q = 0; q < r; ++q) s += ring_counts[q * 3 + threadIdx.x];
+    base[threadIdx.x] = s;
+    if (r == nr - 1) kp_count[threadIdx.x] = s + ring_counts[r * 3 + threadIdx.x];
+  }
+  const int s0 = ring_start[r];
+  const int np = ring_len[r];
+  const int per = (np + blockDim.x - 1) / blockDim.x;
+  const int jb = min(np, (int)threadIdx.x * per), je = min(np, jb + per);
+  unsigned long long mine = 0;
+  for (int j = jb; j < je; ++j)
+  {
+    const uint8_t l = label[s0 + j];
+    mine += (unsigned long long)(l & 1) | ((unsigned long long)((l >> 1) & 1) << 21) | ((unsigned long long)((l >> 2) & 1) << 42);
+  }
+  part[threadIdx.x] = mine;
+  __syncthreads();
+  for (int o = 1; o < 256; o <<= 1)
+  {
+    unsigned long long v = (threadIdx.x >= (unsigned)o) ? part[threadIdx.x - o] : 0ull;
+    __syncthreads();
+    part[threadIdx.x] += v;
+    __syncthreads();
+  }
+  unsigned long long excl = part[threadIdx.x] - mine;
+  int pe = base[0] + (int)(excl & 0x1fffff);
+  int pp = base[1] + (int)((excl >> 21) & 0x1fffff);
+  int pb = base[2] + (int)((excl >> 42) & 0x1fffff);
+  for (int j = jb; j < je; ++j)
+  {
+    const uint8_t l = label[s0 + j];
+    if (!l) continue;
+    const size_t o = orig[s0 + j];
+    const float4 a = frame[2 * o], b = frame[2 * o + 1];
+    if (l & 1) { out_e[2 * (size_t)pe] = a; out_e[2 * (size_t)pe + 1] = b; ++pe; }
+    if (l & 2) { out_p[2 * (size_t)pp] = a; out_p[2 * (size_t)pp + 1] = b; ++pp; }
+    if (l & 4) { out_b[2 * (size_t)pb] = a; out_b[2 * (size_t)pb + 1] = b; ++pb; }
+  }
+}
+
+__global__ void k_debug_gather(const uint32_t* __restrict__ orig, int n, int id, const float* __restrict__ src,
+                               const uint8_t* __restrict__ bits, int bit, float* __restrict__ out)
+{
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  out[orig[j]] = (id < 4) ? src[j] : (float)((bits[j] >> bit) & 1);
+}
+
+__global__ void k_transform_points(float4* __restrict__ pts, int n, Rigid T, double time_offset)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float4 a = pts[2 * (size_t)i];
+  float4 b = pts[2 * (size_t)i + 1];
+  double ox, oy, oz;
+  rigid_apply(T, (double)a.x, (double)a.y, (double)a.z, ox, oy, oz);
+  a.x = (float)ox; a.y = (float)oy; a.z = (float)oz;
+  double t = __hiloint2double(__float_as_int(b.y), __float_as_int(b.x)) + time_offset;
+  b.x = __int_as_float(__double2loint(t));
+  b.y = __int_as_float(__double2hiint(t));
+  pts[2 * (size_t)i] = a;
+  pts[2 * (size_t)i + 1] = b;
+}
+
+ExtractConst make_const(const lsa_extract_params_t* p, float az_res)
+{
+  // host-side constants of InvalidateNotUsablePoints / LineFitting, evaluated with the same libm
+  // float functions the reference uses (SSKE.cxx:52-55, 90, 210-222, 313, 476-477)
+  ExtractConst c;
+  c.W = p->neighbor_width;
+  c.min_dist = p->min_distance_to_sensor;
+  const float angleBeamNormal = float((90 - p->min_beam_surface_angle) / 180. * M_PI);
+  float az = az_res;
+  if (az < 1e-6 || M_PI / 4 < az) az = float(0.2 / 180. * M_PI);
+  c.max_pos_diff_coeff = std::sin(az) / std::cos(az + angleBeamNormal);
+  const float lineMaxAngle = float(40. * 0.017453293);
+  c.line_max_sin = std::sin(lineMaxAngle);
+  const float lineMaxDist = 0.02f;
+  c.line_sq_max_dist = lineMaxDist * lineMaxDist;
+  c.sq_dist_to_line_thr = p->dist_to_line_threshold * p->dist_to_line_threshold;
+  c.plane_thr = p->plane_sin_angle_threshold;
+  c.edge_angle_thr = p->edge_sin_angle_threshold;
+  c.sq_depth_gap_thr = p->edge_depth_gap_threshold * p->edge_depth_gap_threshold;
+  c.sq_saliency_thr = p->edge_saliency_threshold * p->edge_saliency_threshold;
+  c.intensity_thr = p->edge_intensity_gap_threshold;
+  return c;
+}
+
+}  // namespace
+
+extern "C" {
+
+int lsa_extract_keypoints(lsa_ctx* ctx, const lsa_extract_params_t* params, int counts[3])
+{
+  if (!ctx || !params || !counts) return ctx ? ctx->fail(LSA_E_ARG, "lsa_extract_keypoints: null argument") : LSA_E_ARG;
+  if (!ctx->frame || ctx->frame_n <= 0) return ctx->fail(LSA_E_STATE, "lsa_extract_keypoints: no frame uploaded");
+  if (params->neighbor_width < 1 || params->neighbor_width > 8)
+    return ctx->fail(LSA_E_ARG, "lsa_extract_keypoints: NeighborWidth must be in [1, 8]");
+  LSA_HIP(ctx, hipSetDevice(ctx->device));
+  const int n = ctx->frame_n;
+  int rc = ensure_capacity(ctx, n);
+  if (rc) return rc;
+  hipStream_t st = ctx->stream;
+  const ExtractConst c = make_const(params, ctx->az_res);
+
+  // Slam::ExtractKeypoints: current keypoints become the previous ones (Slam.cxx:751)
+  for (int k = 0; k < 3; ++k)
+  {
+    std::swap(ctx->kp[LSA_SET_RAW_CURRENT][k], ctx->kp[LSA_SET_RAW_PREVIOUS][k]);
+    ctx->kp_n[LSA_SET_RAW_PREVIOUS][k] = ctx->kp_n[LSA_SET_RAW_CURRENT][k];
+    ctx->kp_n[LSA_SET_RAW_CURRENT][k] = 0;
+  }
+
+  const int nblocks = (n + kBucketChunk - 1) / kBucketChunk;
+  const float4* frame4 = reinterpret_cast<const float4*>(ctx->frame);
+  LSA_HIP(ctx, hipMemsetAsync(ctx->ring_meta, 0, 8 * sizeof(int), st));
+  LSA_HIP(ctx, hipMemsetAsync(ctx->ring_meta + 1, 0xff, sizeof(int), st));  // max laser id = -1
+  LSA_HIP(ctx, hipMemsetAsync(ctx->kp_count_dev, 0, 4 * sizeof(int), st));
+  {
+    ProfScope ps(ctx, "ring_bucket", (double)n * (4 + 32 + 16 + 4 + 2 + 1));
+    hipLaunchKernelGGL(k_ring_hist, dim3(nblocks), dim3(256), 0, st, frame4, n, ctx->block_hist, ctx->ring_meta);
+    hipLaunchKernelGGL(k_ring_scan, dim3(1), dim3(kMaxRings), 0, st, ctx->block_hist, nblocks, ctx->ring_start, ctx->ring_len, ctx->ring_meta);
+    hipLaunchKernelGGL(k_ring_scatter, dim3(nblocks), dim3(256), 0, st, frame4, n, ctx->block_hist, ctx->ring_start, ctx->ring_meta,
+                       ctx->xyzi, ctx->orig, ctx->ring_of, ctx->valid);
+  }
+  {
+    ProfScope ps(ctx, "invalidate", (double)n * (16 + 2 + 1));
+    hipLaunchKernelGGL(k_invalidate, dim3((n + 255) / 256), dim3(256), 0, st, ctx->xyzi, ctx->ring_of, ctx->ring_start, ctx->ring_len, n, c,
+                       ctx->valid);
+  }
+  {
+    ProfScope ps(ctx, "curvature", (double)n * (16 + 2 + 1 + 16));
+    if (c.W <= 4)
+      hipLaunchKernelGGL(k_curvature<4>, dim3((n + 127) / 128), dim3(128), 0, st, ctx->xyzi, ctx->ring_of, ctx->ring_start, ctx->ring_len, n, c,
+                         ctx->valid, ctx->score[0], ctx->score[1], ctx->score[2], ctx->score[3]);
+    else
+      hipLaunchKernelGGL(k_curvature<8>, dim3((n + 127) / 128), dim3(128), 0, st, ctx->xyzi, ctx->ring_of, ctx->ring_start, ctx->ring_len, n, c,
+                         ctx->valid, ctx->score[0], ctx->score[1], ctx->score[2], ctx->score[3]);
+  }
+  {
+    ProfScope ps(ctx, "label_nms", (double)n * (16 + 1 + 1 + 1));
+    hipLaunchKernelGGL(k_label, dim3(kMaxRings), dim3(256), 0, st, ctx->score[0], ctx->score[1], ctx->score[2], ctx->score[3], ctx->ring_start,
+                       ctx->ring_len, ctx->ring_meta, c, ctx->valid, ctx->label, ctx->ring_counts);
+  }
+  {
+    ProfScope ps(ctx, "compact", (double)n * (1 + 4));
+    hipLaunchKernelGGL(k_compact, dim3(kMaxRings), dim3(256), 0, st, frame4, ctx->orig, ctx->label, ctx->ring_start, ctx->ring_len,
+                       ctx->ring_meta, ctx->ring_counts, reinterpret_cast<float4*>(ctx->kp[LSA_SET_RAW_CURRENT][0]),
+                       reinterpret_cast<float4*>(ctx->kp[LSA_SET_RAW_CURRENT][1]), reinterpret_cast<float4*>(ctx->kp[LSA_SET_RAW_CURRENT][2]),
+                       ctx->kp_count_dev);
+  }
+  int* hp = reinterpret_cast<int*>(ctx->host_pinned);
+  LSA_HIP(ctx, hipMemcpyAsync(hp, ctx->kp_count_dev, 3 * sizeof(int), hipMemcpyDeviceToHost, st));
+  LSA_HIP(ctx, hipMemcpyAsync(hp + 4, ctx->ring_meta, 3 * sizeof(int), hipMemcpyDeviceToHost, st));
+  LSA_HIP(ctx, hipStreamSynchronize(st));
+  if (hp[6] & 1) return ctx->fail(LSA_E_CAPACITY, "lsa_extract_keypoints: laser_id >= 512 is not supported");
+  if (hp[6] & 2) return ctx->fail(LSA_E_CAPACITY, "lsa_extract_keypoints: more than 8192 points on one laser ring");
+  ctx->nb_rings_seen = std::max(ctx->nb_rings_seen, hp[4]);
+  for (int k = 0; k < 3; ++k)
+  {
+    counts[k] = hp[k];
+    ctx->kp_n[LSA_SET_RAW_CURRENT][k] = hp[k];
+  }
+  return LSA_OK;
+}
+
+int lsa_keypoint_count(const lsa_ctx* ctx, int set, int type)
+{
+  if (!ctx || set < 0 || set > 2 || type < 0 || type > 2) return LSA_E_ARG;
+  return ctx->kp_n[set][type];
+}
+
+int lsa_download_keypoints(lsa_ctx* ctx, int set, int type, lsa_point_t* out, int capacity)
+{
+  if (!ctx || set < 0 || set > 2 || type < 0 || type > 2 || (!out && capacity > 0)) return ctx ? ctx->fail(LSA_E_ARG, "lsa_download_keypoints: bad argument") : LSA_E_ARG;
+  const int n = std::min(capacity, ctx->kp_n[set][type]);
+  if (n <= 0) return 0;
+  LSA_HIP(ctx, hipMemcpyAsync(out, ctx->kp[set][type], (size_t)n * sizeof(lsa_point_t), hipMemcpyDeviceToHost, ctx->stream));
+  LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return n;
+}
+
+int lsa_set_keypoints(lsa_ctx* ctx, int set, int type, const lsa_point_t* pts, int k)
+{
+  if (!ctx || set < 0 || set > 2 || type < 0 || type > 2 || k < 0 || (!pts && k > 0)) return ctx ? ctx->fail(LSA_E_ARG, "lsa_set_keypoints: bad argument") : LSA_E_ARG;
+  LSA_HIP(ctx, hipSetDevice(ctx->device));
+  int rc = ensure_capacity(ctx, k);
+  if (rc) return rc;
+  if (k > 0)
+  {
+    LSA_HIP(ctx, hipMemcpyAsync(ctx->kp[set][type], pts, (size_t)k * sizeof(lsa_point_t), hipMemcpyHostToDevice, ctx->stream));
+    LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));  // pts may be pageable and reused by the caller
+  }
+  ctx->kp_n[set][type] = k;
+  return LSA_OK;
+}
+
+int lsa_download_debug(lsa_ctx* ctx, int array_id, float* out, int capacity)
+{
+  if (!ctx || !out || array_id < 0 || array_id > 9) return ctx ? ctx->fail(LSA_E_ARG, "lsa_download_debug: bad argument") : LSA_E_ARG;
+  const int n = ctx->frame_n;
+  if (capacity < n) return ctx->fail(LSA_E_CAPACITY, "lsa_download_debug: capacity < frame size");
+  int rc = ensure_scratch(ctx, (size_t)n * sizeof(float));
+  if (rc) return rc;
+  // reference names: 0 sin_angle(Angles) 1 saliency 2 depth_gap 3 intensity_gap
+  const float* src = array_id == 0 ? ctx->score[0] : array_id == 1 ? ctx->score[2] : array_id == 2 ? ctx->score[1] : ctx->score[3];
+  const uint8_t* bits = array_id < 7 ? ctx->label : ctx->valid;
+  const int bit = array_id < 4 ? 0 : array_id < 7 ? array_id - 4 : array_id - 7;
+  hipLaunchKernelGGL(k_debug_gather, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->orig, n, array_id, src, bits, bit,
+                     (float*)ctx->scratch_out);
+  LSA_HIP(ctx, hipMemcpyAsync(out, ctx->scratch_out, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+  LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return n;
+}
+
+int lsa_transform_keypoints(lsa_ctx* ctx, int set, int type, const double T[16], double time_offset)
+{
+  if (!ctx || !T || set < 0 || set > 2 || type < 0 || type > 2) return ctx ? ctx->fail(LSA_E_ARG, "lsa_transform_keypoints: bad argument") : LSA_E_ARG;
+  const int n = ctx->kp_n[set][type];
+  if (n <= 0) return LSA_OK;
+  Rigid R;
+  row_major_to_rt(T, R.R, R.t);
+  ProfScope ps(ctx, "transform_keypoints", (double)n * 64);
+  hipLaunchKernelGGL(k_transform_points, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, reinterpret_cast<float4*>(ctx->kp[set][type]), n, R,
+                     time_offset);
+  return LSA_OK;
+}
+
+}  // extern "C"

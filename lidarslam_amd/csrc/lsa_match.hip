@@ -1,0 +1,885 @@
+// lsa_match.hip -- KeypointsMatcher::BuildMatchResiduals and the per-LM-step evaluation of
+// the residual blocks on the GPU.
+//
+//   target grid     replaces KDTreePCLAdaptor::Reset (nanoflann kd-tree build,
+//                   slam_lib/include/LidarSlam/KDTreePCLAdaptor.h:57-65) by a dense uniform grid:
+//                   bbox reduce -> cell count -> exclusive scan -> cell-sorted float4 copy
+//   k_match<...>    one thread per keypoint (slam_lib/src/KeypointsMatcher.cxx:106-346):
+//                   world = pose * X, EXACT k-NN by expanding Chebyshev shells of grid cells (rows of
+//                   cells are contiguous in the cell-sorted array, so a shell row is one coalesced
+//                   range), neighbourhood filter (per-ring :349-405 / RANSAC line :408-480, candidates
+//                   staged in LDS), PCA in double, validity tests, residual record (A, P, X, weight)
+//   k_accumulate    what Ceres evaluates per LM step for these blocks
+//                   (slam_lib/include/LidarSlam/CeresCostFunctions.h:105-152 + TukeyLoss/ScaledLoss,
+//                   KeypointsMatcher.cxx:84-101): cost, g = J^T r, H = J^T J with a fixed-order
+//                   wavefront + block + grid reduction (bitwise reproducible run to run)
+// kNN order: ascending (float squared distance, target index); the distance is evaluated exactly like
+// nanoflann's L2_Simple_Adaptor: ((dx*dx)+dy*dy)+dz*dz with d = query - point.
+#include <cfloat>
+#include <cmath>
+#include "lsa_ctx.h"
+#include "lsa_device_math.h"
+
+using namespace lsa;
+
+namespace
+{
+
+__device__ __forceinline__ int f2o(float f)
+{
+  int i = __float_as_int(f);
+  return i >= 0 ? i : i ^ 0x7fffffff;
+}
+__device__ __forceinline__ float o2f(int i) { return __int_as_float(i >= 0 ? i : i ^ 0x7fffffff); }
+
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_target_prep(const float4* __restrict__ pts, int m, float4* __restrict__ xyzl, int* __restrict__ bbox)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+  if (i < m)
+  {
+    const float4 a = pts[2 * (size_t)i];
+    const float4 b = pts[2 * (size_t)i + 1];
+    xyzl[i] = make_float4(a.x, a.y, a.z, __uint_as_float(__float_as_uint(b.w) & 0xffffu));
+    mn[0] = mx[0] = a.x; mn[1] = mx[1] = a.y; mn[2] = mx[2] = a.z;
+  }
+  for (int d = 0; d < 3; ++d)
+  {
+    for (int o = 32; o > 0; o >>= 1)
+    {
+      mn[d] = fminf(mn[d], __shfl_down(mn[d], o));
+      mx[d] = fmaxf(mx[d], __shfl_down(mx[d], o));
+    }
+  }
+  if ((threadIdx.x & 63) == 0)
+  {
+    for (int d = 0; d < 3; ++d)
+    {
+      atomicMin(&bbox[d], f2o(mn[d]));
+      atomicMax(&bbox[3 + d], f2o(mx[d]));
+    }
+  }
+}
+
+__global__ void k_grid_setup(const int* __restrict__ bbox, int m, float cell_hint, GridDesc* __restrict__ desc)
+{
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  GridDesc g;
+  float mn[3], mx[3];
+  for (int d = 0; d < 3; ++d) { mn[d] = o2f(bbox[d]); mx[d] = o2f(bbox[3 + d]); }
+  float cell = cell_hint;
+  int dims[3];
+  while (true)
+  {
+    double total = 1;
+    for (int d = 0; d < 3; ++d)
+    {
+      dims[d] = (int)floorf((mx[d] - mn[d]) / cell) + 1;
+      total *= dims[d];
+    }
+    if (total <= (double)kCellCap) break;
+    cell *= 1.26f;
+  }
+  for (int d = 0; d < 3; ++d) { g.origin[d] = mn[d]; g.dims[d] = dims[d]; }
+  g.cell = cell;
+  g.inv_cell = 1.0f / cell;
+  g.ncells = dims[0] * dims[1] * dims[2];
+  g.npoints = m;
+  *desc = g;
+}
+
+__device__ __forceinline__ int cell_coord(float v, float o, float inv, int n)
+{
+  int c = (int)floorf((v - o) * inv);
+  return min(max(c, 0), n - 1);
+}
+
+__global__ __launch_bounds__(256) void k_grid_zero(const GridDesc* __restrict__ desc, uint32_t* __restrict__ cell_start, uint32_t* __restrict__ cell_fill)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int nc = desc->ncells;
+  if (i <= nc) cell_start[i] = 0;
+  if (i < nc) cell_fill[i] = 0;
+}
+
+__global__ __launch_bounds__(256) void k_grid_count(const float4* __restrict__ xyzl, int m, const GridDesc* __restrict__ desc,
+                                                    uint32_t* __restrict__ cell_of, uint32_t* __restrict__ cell_start)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  const GridDesc g = *desc;
+  const float4 p = xyzl[i];
+  const int cx = cell_coord(p.x, g.origin[0], g.inv_cell, g.dims[0]);
+  const int cy = cell_coord(p.y, g.origin[1], g.inv_cell, g.dims[1]);
+  const int cz = cell_coord(p.z, g.origin[2], g.inv_cell, g.dims[2]);
+  const uint32_t cid = (uint32_t)((cz * g.dims[1] + cy) * g.dims[0] + cx);
+  cell_of[i] = cid;
+  atomicAdd(&cell_start[cid], 1u);
+}
+
+// exclusive scan of cell_start[0 .. ncells] in three passes (1024 elements per block)
+__global__ __launch_bounds__(256) void k_scan_block(const GridDesc* __restrict__ desc, uint32_t* __restrict__ data, uint32_t* __restrict__ sums)
+{
+  __shared__ uint32_t s[256];
+  const int total = desc->ncells + 1;
+  const int base = blockIdx.x * 1024;
+  if (base >= total) return;
+  uint32_t v[4], t = 0;
+  for (int q = 0; q < 4; ++q)
+  {
+    const int i = base + threadIdx.x * 4 + q;
+    v[q] = (i < total) ? data[i] : 0;
+    t += v[q];
+  }
+  s[threadIdx.x] = t;
+  __syncthreads();
+  for (int o = 1; o < 256; o <<= 1)
+  {
+    uint32_t a = (threadIdx.x >= (unsigned)o) ? s[threadIdx.x - o] : 0;
+    __syncthreads();
+    s[threadIdx.x] += a;
+    __syncthreads();
+  }
+  uint32_t run = s[threadIdx.x] - t;
+  for (int q = 0; q < 4; ++q)
+  {
+    const int i = base + threadIdx.x * 4 + q;
+    if (i < total) data[i] = run;
+    run += v[q];
+  }
+  if (threadIdx.x == 255) sums[blockIdx.x] = s[255];
+}
+__global__ __launch_bounds__(1024) void k_scan_sums(const GridDesc* __restrict__ desc, uint32_t* __restrict__ sums)
+{
+  __shared__ uint32_t s[1024];
+  const int nb = (desc->ncells + 1 + 1023) / 1024;
+  const int per = (nb + 1023) / 1024;
+  const int b = min(nb, (int)threadIdx.x * per), e = min(nb, b + per);
+  uint32_t t = 0;
+  for (int i = b; i < e; ++i) t += sums[i];
+  s[threadIdx.x] = t;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1)
+  {
+    uint32_t a = (threadIdx.x >= (unsigned)o) ? s[threadIdx.x - o] : 0;
+    __syncthreads();
+    s[threadIdx.x] += a;
+    __syncthreads();
+  }
+  uint32_t run = s[threadIdx.x] - t;
+  for (int i = b; i < e; ++i)
+  {
+    uint32_t v = sums[i];
+    sums[i] = run;
+    run += v;
+  }
+}
+__global__ __launch_bounds__(256) void k_scan_add(const GridDesc* __restrict__ desc, uint32_t* __restrict__ data, const uint32_t* __restrict__ sums)
+{
+  const int total = desc->ncells + 1;
+  const int base = blockIdx.x * 1024;
+  if (base >= total) return;
+  const uint32_t add = sums[blockIdx.x];
+  for (int q = 0; q < 4; ++q)
+  {
+    const int i = base + threadIdx.x * 4 + q;
+    if (i < total) data[i] += add;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_grid_scatter(const float4* __restrict__ xyzl, int m, const uint32_t* __restrict__ cell_of,
+                                                      const uint32_t* __restrict__ cell_start, uint32_t* __restrict__ cell_fill,
+                                                      float4* __restrict__ sorted)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  const uint32_t cid = cell_of[i];
+  const uint32_t pos = cell_start[cid] + atomicAdd(&cell_fill[cid], 1u);
+  const float4 p = xyzl[i];
+  sorted[pos] = make_float4(p.x, p.y, p.z, __int_as_float(i));
+}
+
+// ------------------------------------------------------------------------------------------
+struct MatchConst
+{
+  Rigid pose;
+  int type;
+  int k;                 // neighbours requested
+  int min_neighbors;     // EdgeMinNbNeighbors
+  int single_edge_per_ring;
+  double max_dist2;      // MaxNeighborsDistance^2
+  double max_model_err;  // Edge/PlaneMaxModelError
+  double planarity;
+  float ransac_sq_inlier;  // float(EdgeMaxModelError^2)
+  int bad_param;           // BAD_MODEL_PARAMETRIZATION for every keypoint
+};
+
+constexpr int kShellCap = 8;  // shells searched before the exhaustive fall-back
+
+template <int KMAX> struct KnnSet
+{
+  float d2[KMAX];
+  int idx[KMAX];
+  float worst_d;
+  int worst_i;
+  int count;
+  int k;
+  __device__ __forceinline__ void init(int kk)
+  {
+#pragma unroll
+    for (int s = 0; s < KMAX; ++s) { d2[s] = INFINITY; idx[s] = 0x7fffffff; }
+    worst_d = INFINITY; worst_i = 0x7fffffff; count = 0; k = kk;
+  }
+  __device__ __forceinline__ void offer(float d, int i)
+  {
+    if (!(d < worst_d || (d == worst_d && i < worst_i))) return;
+    float cd = d; int ci = i;
+#pragma unroll
+    for (int s = 0; s < KMAX; ++s)
+    {
+      if (s < k)
+      {
+        const bool lt = cd < d2[s] || (cd == d2[s] && ci < idx[s]);
+        if (lt)
+        {
+          const float td = d2[s]; const int ti = idx[s];
+          d2[s] = cd; idx[s] = ci; cd = td; ci = ti;
+        }
+        if (s == k - 1) { worst_d = d2[s]; worst_i = idx[s]; }
+      }
+    }
+    if (count < k) ++count;
+  }
+};
+
+template <int KMAX>
+__device__ __forceinline__ void scan_range(KnnSet<KMAX>& ks, const float4* __restrict__ sorted, uint32_t b, uint32_t e, float qx, float qy, float qz)
+{
+  for (uint32_t t = b; t < e; ++t)
+  {
+    const float4 p = sorted[t];
+    const float dx = qx - p.x, dy = qy - p.y, dz = qz - p.z;
+    const float d = (dx * dx + dy * dy) + dz * dz;
+    ks.offer(d, __float_as_int(p.w));
+  }
+}
+
+template <int KMAX>
+__device__ void knn_search(KnnSet<KMAX>& ks, const GridDesc& g, const uint32_t* __restrict__ cell_start, const float4* __restrict__ sorted,
+                           float qx, float qy, float qz, int* __restrict__ slow_counter)
+{
+  const int nx = g.dims[0], ny = g.dims[1], nz = g.dims[2];
+  const int cx = cell_coord(qx, g.origin[0], g.inv_cell, nx);
+  const int cy = cell_coord(qy, g.origin[1], g.inv_cell, ny);
+  const int cz = cell_coord(qz, g.origin[2], g.inv_cell, nz);
+  // squared distance from the query to the grid box (0 inside)
+  float outd2 = 0.f;
+  {
+    const float q[3] = {qx, qy, qz};
+    for (int d = 0; d < 3; ++d)
+    {
+      const float lo = g.origin[d], hi = g.origin[d] + g.dims[d] * g.cell;
+      float e = 0.f;
+      if (q[d] < lo) e = lo - q[d];
+      else if (q[d] > hi) e = q[d] - hi;
+      outd2 += e * e;
+    }
+    outd2 *= 0.999f;
+  }
+  for (int r = 0;; ++r)
+  {
+    const int z0 = max(0, cz - r), z1 = min(nz - 1, cz + r);
+    const int y0 = max(0, cy - r), y1 = min(ny - 1, cy + r);
+    const int x0 = max(0, cx - r), x1 = min(nx - 1, cx + r);
+    for (int z = z0; z <= z1; ++z)
+      for (int y = y0; y <= y1; ++y)
+      {
+        const int row = (z * ny + y) * nx;
+        const bool shell = (abs(z - cz) == r) || (abs(y - cy) == r);
+        if (shell)
+          scan_range(ks, sorted, cell_start[row + x0], cell_start[row + x1 + 1], qx, qy, qz);
+        else
+        {
+          if (cx - r >= 0) scan_range(ks, sorted, cell_start[row + cx - r], cell_start[row + cx - r + 1], qx, qy, qz);
+          if (cx + r < nx) scan_range(ks, sorted, cell_start[row + cx + r], cell_start[row + cx + r + 1], qx, qy, qz);
+        }
+      }
+    // every point closer than r cells (minus a 0.1 % guard for float cell assignment) has been seen
+    if (ks.count == ks.k && r >= 1)
+    {
+      const float br = ((float)r - 0.001f) * g.cell;
+      if (ks.worst_d < outd2 + br * br) return;
+    }
+    if (x0 == 0 && y0 == 0 && z0 == 0 && x1 == nx - 1 && y1 == ny - 1 && z1 == nz - 1) return;  // whole grid visited
+    if (r >= kShellCap) break;
+  }
+  // sparse neighbourhood: exhaustive scan keeps the result exact
+  atomicAdd(slow_counter, 1);
+  ks.init(ks.k);
+  scan_range(ks, sorted, 0u, (uint32_t)g.npoints, qx, qy, qz);
+}
+
+__device__ __forceinline__ void write_record(double* __restrict__ rec, int cap, int i, const double A[9], const Vec3<double>& P,
+                                             double bx, double by, double bz, double w)
+{
+#pragma unroll
+  for (int f = 0; f < 9; ++f) rec[(size_t)f * cap + i] = A[f];
+  rec[(size_t)9 * cap + i] = P.x; rec[(size_t)10 * cap + i] = P.y; rec[(size_t)11 * cap + i] = P.z;
+  rec[(size_t)12 * cap + i] = bx; rec[(size_t)13 * cap + i] = by; rec[(size_t)14 * cap + i] = bz;
+  rec[(size_t)15 * cap + i] = w;
+}
+
+constexpr int kMatchBlock = 128;
+
+template <int KMAX, int TYPE>
+__global__ __launch_bounds__(kMatchBlock) void k_match(const float4* __restrict__ queries, int nq, MatchConst c,
+                                                       const GridDesc* __restrict__ desc, const uint32_t* __restrict__ cell_start,
+                                                       const float4* __restrict__ sorted, const float4* __restrict__ xyzl,
+                                                       double* __restrict__ rec, uint8_t* __restrict__ status, int cap,
+                                                       int* __restrict__ hist)
+{
+  __shared__ int lh[LSA_MATCH_NSTATUS];
+  __shared__ float4 nb[TYPE == LSA_EDGE ? KMAX : 1][kMatchBlock];  // edge candidates staged in LDS
+  if (threadIdx.x < LSA_MATCH_NSTATUS) lh[threadIdx.x] = 0;
+  __syncthreads();
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  int st = -1;
+  if (i < nq)
+  {
+    st = LSA_MATCH_SUCCESS;
+    double w = 0.;
+    if (c.bad_param)
+      st = LSA_MATCH_BAD_MODEL_PARAMETRIZATION;
+    else
+    {
+      const float4 q4 = queries[2 * (size_t)i];
+      const double bx = (double)q4.x, by = (double)q4.y, bz = (double)q4.z;
+      double wx, wy, wz;
+      rigid_apply(c.pose, bx, by, bz, wx, wy, wz);
+      const float qx = (float)wx, qy = (float)wy, qz = (float)wz;
+      const GridDesc g = *desc;
+      KnnSet<KMAX> ks;
+      ks.init(c.k);
+      knn_search<KMAX>(ks, g, cell_start, sorted, qx, qy, qz, hist + LSA_MATCH_NSTATUS);
+
+      Vec3<double> mean, e0, e1, e2;
+      double l0 = 0, l1 = 0, l2 = 0;
+      CovAccum<double> acc;
+      int nsel = 0;
+      float last_d2 = 0.f;
+
+      if (TYPE == LSA_EDGE)
+      {
+        // stage the candidates (ascending distance) in LDS: the filters index them dynamically
+#pragma unroll
+        for (int s = 0; s < KMAX; ++s)
+          if (s < ks.count) nb[TYPE == LSA_EDGE ? s : 0][threadIdx.x] = xyzl[ks.idx[s]];
+        const int n = ks.count;
+        if (c.single_edge_per_ring)
+        {
+          // GetPerRingLineNeighbors (KeypointsMatcher.cxx:349-405): drop the closest point's own ring and
+          // rings more than 4 away, then keep the nearest point of every remaining ring
+          if (n > 0)
+          {
+            const int closest = (int)__float_as_uint(nb[0][threadIdx.x].w);
+            for (int t = 0; t < n; ++t)
+            {
+              const float4 p = nb[TYPE == LSA_EDGE ? t : 0][threadIdx.x];
+              const int lid = (int)__float_as_uint(p.w);
+              bool keep = (lid != closest) && (abs(closest - lid) <= 4);
+              for (int s = 0; s < t && keep; ++s)
+                if ((int)__float_as_uint(nb[TYPE == LSA_EDGE ? s : 0][threadIdx.x].w) == lid) keep = false;
+              if (keep)
+              {
+                acc.add(p.x, p.y, p.z);
+                ++nsel;
+#pragma unroll
+                for (int s = 0; s < KMAX; ++s)
+                  if (s == t) last_d2 = ks.d2[s];
+              }
+            }
+          }
+        }
+        else
+        {
+          // GetRansacLineNeighbors (KeypointsMatcher.cxx:408-480)
+          if (n >= 2)
+          {
+            const float4 p1 = nb[0][threadIdx.x];
+            const Vec3<float> P1 = {p1.x, p1.y, p1.z};
+            int best = -1, bestCount = 0;
+            for (int pi = 1; pi < n; ++pi)
+            {
+              const float4 p2 = nb[TYPE == LSA_EDGE ? pi : 0][threadIdx.x];
+              const Vec3<float> dir = normalized3(vsub(Vec3<float>{p2.x, p2.y, p2.z}, P1));
+              int cnt = 0;
+              for (int ci = 1; ci < n; ++ci)
+              {
+                if (ci == pi) { ++cnt; continue; }
+                const float4 pc = nb[TYPE == LSA_EDGE ? ci : 0][threadIdx.x];
+                if (vsqnorm(vcross(vsub(Vec3<float>{pc.x, pc.y, pc.z}, P1), dir)) < c.ransac_sq_inlier) ++cnt;
+              }
+              if (cnt > bestCount) { bestCount = cnt; best = pi; }
+            }
+            const float4 pb = nb[TYPE == LSA_EDGE ? best : 0][threadIdx.x];
+            const Vec3<float> dir = normalized3(vsub(Vec3<float>{pb.x, pb.y, pb.z}, P1));
+            acc.add(p1.x, p1.y, p1.z);
+            nsel = 1;
+            int lastSel = 0;
+            for (int ci = 1; ci < n; ++ci)
+            {
+              const float4 pc = nb[TYPE == LSA_EDGE ? ci : 0][threadIdx.x];
+              const bool in = (ci == best) || (vsqnorm(vcross(vsub(Vec3<float>{pc.x, pc.y, pc.z}, P1), dir)) < c.ransac_sq_inlier);
+              if (in) { acc.add(pc.x, pc.y, pc.z); ++nsel; lastSel = ci; }
+            }
+#pragma unroll
+            for (int s = 0; s < KMAX; ++s)
+              if (s == lastSel) last_d2 = ks.d2[s];
+          }
+        }
+        if (nsel < c.min_neighbors) st = LSA_MATCH_NOT_ENOUGH_NEIGHBORS;
+      }
+      else
+      {
+        if (ks.count < c.k) st = LSA_MATCH_NOT_ENOUGH_NEIGHBORS;
+        else
+        {
+#pragma unroll
+          for (int s = 0; s < KMAX; ++s)
+            if (s < c.k)
+            {
+              const float4 p = xyzl[ks.idx[s]];
+              acc.add(p.x, p.y, p.z);
+            }
+          nsel = c.k;
+          last_d2 = ks.worst_d;
+        }
+      }
+
+      if (st == LSA_MATCH_SUCCESS && (double)last_d2 > c.max_dist2) st = LSA_MATCH_NEIGHBORS_TOO_FAR;
+      if (st == LSA_MATCH_SUCCESS)
+      {
+        Sym3<double> cov;
+        acc.finish(nsel, mean, cov);
+        eigen33<double>(cov, e0, e1, e2, l0, l1, l2);
+        double A[9];
+        if (TYPE == LSA_EDGE)
+        {
+          const double n[3] = {e2.x, e2.y, e2.z};
+#pragma unroll
+          for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) A[a * 3 + b] = (a == b ? 1. : 0.) - n[a] * n[b];
+          if (!isfinite(A[0])) st = LSA_MATCH_INVALID_NUMERICAL;
+          else
+          {
+            const double mse = l0 + l1;
+            if (mse >= c.max_model_err * c.max_model_err) st = LSA_MATCH_MSE_TOO_LARGE;
+            else w = (mse <= 1e-6) ? 1. : 1. - __builtin_sqrt(mse) / c.max_model_err;
+          }
+        }
+        else if (TYPE == LSA_PLANE)
+        {
+          if (l1 / l2 < c.planarity) st = LSA_MATCH_BAD_PCA_STRUCTURE;
+          else
+          {
+            const double n[3] = {e0.x, e0.y, e0.z};
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+              for (int b = 0; b < 3; ++b) A[a * 3 + b] = n[a] * n[b];
+            if (!isfinite(A[0])) st = LSA_MATCH_INVALID_NUMERICAL;
+            else
+            {
+              const double mse = l0;
+              if (mse >= c.max_model_err * c.max_model_err) st = LSA_MATCH_MSE_TOO_LARGE;
+              else w = (mse <= 1e-6) ? 1. : 1. - __builtin_sqrt(mse) / c.max_model_err;
+            }
+          }
+        }
+        else
+        {
+          if (l0 <= 0. || l1 <= 0.) st = LSA_MATCH_BAD_PCA_STRUCTURE;
+          else
+          {
+            const double d0 = 1. / __builtin_sqrt(l0), d1 = 1. / __builtin_sqrt(l1), d2 = 1. / __builtin_sqrt(l2);
+            const double V[3][3] = {{e0.x, e1.x, e2.x}, {e0.y, e1.y, e2.y}, {e0.z, e1.z, e2.z}};
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+              for (int b = 0; b < 3; ++b)
+                A[a * 3 + b] = ((V[a][0] * d0) * V[b][0] + (V[a][1] * d1) * V[b][1]) + (V[a][2] * d2) * V[b][2];
+            if (!isfinite(A[0]) || !isfinite(d0 * d1 * d2)) st = LSA_MATCH_INVALID_NUMERICAL;
+            else w = 1.0;
+          }
+        }
+        if (st == LSA_MATCH_SUCCESS) write_record(rec, cap, i, A, mean, bx, by, bz, w);
+      }
+    }
+    if (st != LSA_MATCH_SUCCESS) rec[(size_t)15 * cap + i] = 0.;  // Weights[i] = 0 for rejected keypoints
+    status[i] = (uint8_t)st;
+    atomicAdd(&lh[st], 1);
+  }
+  __syncthreads();
+  if (threadIdx.x < LSA_MATCH_NSTATUS && lh[threadIdx.x]) atomicAdd(&hist[threadIdx.x], lh[threadIdx.x]);
+}
+
+__global__ void k_fill_status(uint8_t* __restrict__ status, double* __restrict__ rec, int cap, int n, uint8_t v)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) { status[i] = v; rec[(size_t)15 * cap + i] = 0.; }
+}
+
+// ------------------------------------------------------------------------------------------
+struct AccumConst
+{
+  double R[9], dRx[9], dRy[9], dRz[9];
+  double t[3];
+  const double* rec[3];
+  const uint8_t* status[3];
+  int count[3];
+  int cap[3];
+  double sat2[3];  // Tukey a^2 per type
+  int jac;
+};
+
+__device__ __forceinline__ void mv3(const double M[9], double x, double y, double z, double& ox, double& oy, double& oz)
+{
+  ox = (M[0] * x + M[1] * y) + M[2] * z;
+  oy = (M[3] * x + M[4] * y) + M[5] * z;
+  oz = (M[6] * x + M[7] * y) + M[8] * z;
+}
+
+__global__ __launch_bounds__(256) void k_accumulate(AccumConst c, double* __restrict__ partials)
+{
+  double acc[kAccumVals];
+#pragma unroll
+  for (int v = 0; v < kAccumVals; ++v) acc[v] = 0.;
+  const int total = c.count[0] + c.count[1] + c.count[2];
+  for (int gidx = blockIdx.x * blockDim.x + threadIdx.x; gidx < total; gidx += gridDim.x * blockDim.x)
+  {
+    int t = 0, i = gidx;
+    if (i >= c.count[0]) { i -= c.count[0]; t = 1; if (i >= c.count[1]) { i -= c.count[1]; t = 2; } }
+    if (c.status[t][i] != LSA_MATCH_SUCCESS) continue;
+    const double* rec = c.rec[t];
+    const size_t cap = (size_t)c.cap[t];
+    double A[9];
+#pragma unroll
+    for (int f = 0; f < 9; ++f) A[f] = rec[f * cap + i];
+    const double Px = rec[9 * cap + i], Py = rec[10 * cap + i], Pz = rec[11 * cap + i];
+    const double Xx = rec[12 * cap + i], Xy = rec[13 * cap + i], Xz = rec[14 * cap + i];
+    const double weight = rec[15 * cap + i];
+    double yx, yy, yz;
+    mv3(c.R, Xx, Xy, Xz, yx, yy, yz);
+    const double dx = (yx + c.t[0]) - Px, dy = (yy + c.t[1]) - Py, dz = (yz + c.t[2]) - Pz;
+    double r0, r1, r2;
+    mv3(A, dx, dy, dz, r0, r1, r2);
+    const double s = (r0 * r0 + r1 * r1) + r2 * r2;
+    const double a2 = c.sat2[t];
+    double rho0, rho1;
+    if (s <= a2)
+    {
+      const double value = 1.0 - s / a2;
+      const double value_sq = value * value;
+      rho0 = a2 / 3.0 * (1.0 - value_sq * value);
+      rho1 = value_sq;
+    }
+    else { rho0 = a2 / 3.0; rho1 = 0.0; }
+    rho0 *= weight; rho1 *= weight;
+    acc[0] += 0.5 * rho0;
+    acc[28] += 1.0;
+    if (!c.jac) continue;
+    double J[3][6];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int b = 0; b < 3; ++b) J[a][b] = A[a * 3 + b];
+    double vx, vy, vz, cx, cy, cz;
+    mv3(c.dRx, Xx, Xy, Xz, vx, vy, vz); mv3(A, vx, vy, vz, cx, cy, cz); J[0][3] = cx; J[1][3] = cy; J[2][3] = cz;
+    mv3(c.dRy, Xx, Xy, Xz, vx, vy, vz); mv3(A, vx, vy, vz, cx, cy, cz); J[0][4] = cx; J[1][4] = cy; J[2][4] = cz;
+    mv3(c.dRz, Xx, Xy, Xz, vx, vy, vz); mv3(A, vx, vy, vz, cx, cy, cz); J[0][5] = cx; J[1][5] = cy; J[2][5] = cz;
+    int h = 7;
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+    {
+      acc[1 + a] += rho1 * ((J[0][a] * r0 + J[1][a] * r1) + J[2][a] * r2);
+#pragma unroll
+      for (int b = a; b < 6; ++b) acc[h++] += rho1 * ((J[0][a] * J[0][b] + J[1][a] * J[1][b]) + J[2][a] * J[2][b]);
+    }
+  }
+  // fixed-order reduction: wavefront shuffles, then the 4 waves through LDS
+  __shared__ double wsum[4][kAccumVals];
+#pragma unroll
+  for (int v = 0; v < kAccumVals; ++v)
+  {
+    double x = acc[v];
+    for (int o = 32; o > 0; o >>= 1) x += __shfl_down(x, o);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6][v] = x;
+  }
+  __syncthreads();
+  if (threadIdx.x < kAccumVals)
+    partials[(size_t)blockIdx.x * kAccumVals + threadIdx.x] =
+      ((wsum[0][threadIdx.x] + wsum[1][threadIdx.x]) + wsum[2][threadIdx.x]) + wsum[3][threadIdx.x];
+}
+
+__global__ void k_accumulate_final(const double* __restrict__ partials, int nblocks, double* __restrict__ out)
+{
+  const int v = threadIdx.x;
+  if (v >= kAccumVals) return;
+  double s = 0.;
+  for (int b = 0; b < nblocks; ++b) s += partials[(size_t)b * kAccumVals + v];
+  out[v] = s;
+}
+
+__global__ void k_records_to_aos(const double* __restrict__ rec, const uint8_t* __restrict__ status, int cap, int n, double* __restrict__ out,
+                                 double* __restrict__ weights)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const bool ok = status[i] == LSA_MATCH_SUCCESS;
+  if (out)
+    for (int f = 0; f < 16; ++f) out[(size_t)i * 16 + f] = ok ? rec[(size_t)f * cap + i] : 0.;
+  weights[i] = ok ? rec[(size_t)15 * cap + i] : 0.;
+}
+
+int build_grid(lsa_ctx* ctx, int type)
+{
+  Target& t = ctx->target[type];
+  hipStream_t st = ctx->stream;
+  const int m = t.m;
+  const int init[8] = {0x7fffffff, 0x7fffffff, 0x7fffffff, (int)0x80000000, (int)0x80000000, (int)0x80000000, 0, 0};
+  LSA_HIP(ctx, hipMemcpyAsync(t.bbox_bits, init, sizeof(init), hipMemcpyHostToDevice, st));
+  ProfScope ps(ctx, "target_grid_build", (double)m * (32 + 16 + 16 + 4 + 4 + 16 + 16));
+  const int gb = (m + 255) / 256;
+  hipLaunchKernelGGL(k_target_prep, dim3(gb), dim3(256), 0, st, reinterpret_cast<const float4*>(t.pts), m, t.xyzl, t.bbox_bits);
+  hipLaunchKernelGGL(k_grid_setup, dim3(1), dim3(1), 0, st, t.bbox_bits, m, t.cell_hint, t.desc);
+  const int cb = (kCellCap + 1 + 255) / 256;
+  hipLaunchKernelGGL(k_grid_zero, dim3(cb), dim3(256), 0, st, t.desc, t.cell_start, t.cell_fill);
+  hipLaunchKernelGGL(k_grid_count, dim3(gb), dim3(256), 0, st, t.xyzl, m, t.desc, t.cell_of, t.cell_start);
+  const int sb = (kCellCap + 1 + 1023) / 1024;
+  hipLaunchKernelGGL(k_scan_block, dim3(sb), dim3(256), 0, st, t.desc, t.cell_start, t.block_sums);
+  hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, st, t.desc, t.block_sums);
+  hipLaunchKernelGGL(k_scan_add, dim3(sb), dim3(256), 0, st, t.desc, t.cell_start, t.block_sums);
+  hipLaunchKernelGGL(k_grid_scatter, dim3(gb), dim3(256), 0, st, t.xyzl, m, t.cell_of, t.cell_start, t.cell_fill, t.sorted);
+  return LSA_OK;
+}
+
+template <int KMAX, int TYPE>
+void launch_match(lsa_ctx* ctx, const lsa_point_t* q, int nq, const MatchConst& mc, int type)
+{
+  Target& t = ctx->target[type];
+  MatchBuf& mb = ctx->match[type];
+  hipLaunchKernelGGL((k_match<KMAX, TYPE>), dim3((nq + kMatchBlock - 1) / kMatchBlock), dim3(kMatchBlock), 0, ctx->stream,
+                     reinterpret_cast<const float4*>(q), nq, mc, t.desc, t.cell_start, t.sorted, t.xyzl, mb.rec, mb.status, mb.cap,
+                     ctx->hist_dev);
+}
+
+}  // namespace
+
+extern "C" {
+
+int lsa_set_target(lsa_ctx* ctx, int type, const lsa_point_t* pts, int m)
+{
+  if (!ctx || type < 0 || type > 2 || m < 0 || (!pts && m > 0)) return ctx ? ctx->fail(LSA_E_ARG, "lsa_set_target: bad argument") : LSA_E_ARG;
+  LSA_HIP(ctx, hipSetDevice(ctx->device));
+  int rc = ensure_target(ctx, type, m);
+  if (rc) return rc;
+  Target& t = ctx->target[type];
+  t.m = m;
+  if (m == 0) return LSA_OK;
+  {
+    ProfScope ps(ctx, "target_upload_h2d", (double)m * 32);
+    LSA_HIP(ctx, hipMemcpyAsync(t.pts, pts, (size_t)m * sizeof(lsa_point_t), hipMemcpyHostToDevice, ctx->stream));
+  }
+  rc = build_grid(ctx, type);
+  if (rc) return rc;
+  LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the host buffer may be pageable and go away
+  return LSA_OK;
+}
+
+int lsa_set_target_from_set(lsa_ctx* ctx, int type, int set)
+{
+  if (!ctx || type < 0 || type > 2 || set < 0 || set > 2) return ctx ? ctx->fail(LSA_E_ARG, "lsa_set_target_from_set: bad argument") : LSA_E_ARG;
+  LSA_HIP(ctx, hipSetDevice(ctx->device));
+  const int m = ctx->kp_n[set][type];
+  int rc = ensure_target(ctx, type, m);
+  if (rc) return rc;
+  Target& t = ctx->target[type];
+  t.m = m;
+  if (m == 0) return LSA_OK;
+  LSA_HIP(ctx, hipMemcpyAsync(t.pts, ctx->kp[set][type], (size_t)m * sizeof(lsa_point_t), hipMemcpyDeviceToDevice, ctx->stream));
+  return build_grid(ctx, type);
+}
+
+int lsa_target_size(const lsa_ctx* ctx, int type) { return (ctx && type >= 0 && type <= 2) ? ctx->target[type].m : LSA_E_ARG; }
+
+int lsa_set_target_cell_size(lsa_ctx* ctx, int type, float cell)
+{
+  if (!ctx || type < 0 || type > 2 || !(cell > 0.f)) return LSA_E_ARG;
+  ctx->target[type].cell_hint = cell;
+  return LSA_OK;
+}
+
+int lsa_match(lsa_ctx* ctx, int type, int query_set, const lsa_match_params_t* p, const double pose[16], int histogram[LSA_MATCH_NSTATUS])
+{
+  if (!ctx || !p || !pose || type < 0 || type > 2 || query_set < 0 || query_set > 2)
+    return ctx ? ctx->fail(LSA_E_ARG, "lsa_match: bad argument") : LSA_E_ARG;
+  LSA_HIP(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  const int nq = ctx->kp_n[query_set][type];
+  MatchBuf& mb = ctx->match[type];
+  int rc = ensure_match(ctx, type, nq);
+  if (rc) return rc;
+  mb.k = nq;
+  mb.sat = p->saturation_distance;
+  mb.valid = true;
+  if (histogram) std::memset(histogram, 0, LSA_MATCH_NSTATUS * sizeof(int));
+  if (nq == 0) return LSA_OK;
+  Target& t = ctx->target[type];
+  if (t.m == 0)
+  {
+    // empty target: MatchingResults::Reset leaves every keypoint UNKOWN and the histogram empty
+    // (KeypointsMatcher.cxx:53-58)
+    hipLaunchKernelGGL(k_fill_status, dim3((nq + 255) / 256), dim3(256), 0, st, mb.status, mb.rec, mb.cap, nq, (uint8_t)LSA_MATCH_UNKOWN);
+    return LSA_OK;
+  }
+  MatchConst mc;
+  row_major_to_rt(pose, mc.pose.R, mc.pose.t);
+  mc.type = type;
+  mc.single_edge_per_ring = p->single_edge_per_ring;
+  mc.min_neighbors = p->edge_min_nb_neighbors;
+  mc.max_dist2 = p->max_neighbors_distance * p->max_neighbors_distance;
+  mc.planarity = p->planarity_threshold;
+  mc.bad_param = 0;
+  const double e2 = p->edge_max_model_error * p->edge_max_model_error;
+  mc.ransac_sq_inlier = (float)e2;
+  if (type == LSA_EDGE)
+  {
+    mc.k = p->edge_nb_neighbors;
+    mc.max_model_err = p->edge_max_model_error;
+    if (p->edge_nb_neighbors < 2 || p->edge_min_nb_neighbors < 2) mc.bad_param = 1;
+  }
+  else if (type == LSA_PLANE)
+  {
+    mc.k = p->plane_nb_neighbors;
+    mc.max_model_err = p->plane_max_model_error;
+    if (p->plane_nb_neighbors < 3) mc.bad_param = 1;
+  }
+  else
+  {
+    mc.k = p->blob_nb_neighbors;
+    mc.max_model_err = 0.;
+    if (p->blob_nb_neighbors < 4) mc.bad_param = 1;
+  }
+  if (mc.k > 16) return ctx->fail(LSA_E_ARG, "lsa_match: more than 16 neighbours requested");
+  if (mc.k < 1) mc.k = 1;
+  LSA_HIP(ctx, hipMemsetAsync(ctx->hist_dev, 0, 16 * sizeof(int), st));
+  const lsa_point_t* q = ctx->kp[query_set][type];
+  {
+    ProfScope ps(ctx, type == LSA_EDGE ? "match_edge" : type == LSA_PLANE ? "match_plane" : "match_blob",
+                 (double)nq * (32 + mc.k * 32 + 136));
+    if (type == LSA_EDGE)
+    {
+      if (mc.k <= 8) launch_match<8, LSA_EDGE>(ctx, q, nq, mc, type);
+      else launch_match<16, LSA_EDGE>(ctx, q, nq, mc, type);
+    }
+    else if (type == LSA_PLANE)
+    {
+      if (mc.k <= 8) launch_match<8, LSA_PLANE>(ctx, q, nq, mc, type);
+      else launch_match<16, LSA_PLANE>(ctx, q, nq, mc, type);
+    }
+    else
+    {
+      if (mc.k <= 8) launch_match<8, LSA_BLOB>(ctx, q, nq, mc, type);
+      else launch_match<16, LSA_BLOB>(ctx, q, nq, mc, type);
+    }
+  }
+  if (histogram)
+  {
+    int* hp = reinterpret_cast<int*>(ctx->host_pinned) + 32;
+    LSA_HIP(ctx, hipMemcpyAsync(hp, ctx->hist_dev, 16 * sizeof(int), hipMemcpyDeviceToHost, st));
+    LSA_HIP(ctx, hipStreamSynchronize(st));
+    for (int s = 0; s < LSA_MATCH_NSTATUS; ++s) histogram[s] = hp[s];
+  }
+  return LSA_OK;
+}
+
+int lsa_download_match(lsa_ctx* ctx, int type, uint8_t* status, double* weights, double* records, int capacity)
+{
+  if (!ctx || type < 0 || type > 2 || !status || !weights) return ctx ? ctx->fail(LSA_E_ARG, "lsa_download_match: bad argument") : LSA_E_ARG;
+  MatchBuf& mb = ctx->match[type];
+  if (!mb.valid) return 0;
+  const int n = std::min(capacity, mb.k);
+  if (n <= 0) return 0;
+  const size_t bytes = (size_t)n * (16 + 1) * sizeof(double);
+  int rc = ensure_scratch(ctx, bytes);
+  if (rc) return rc;
+  double* drec = (double*)ctx->scratch_out;
+  double* dw = drec + (size_t)n * 16;
+  hipLaunchKernelGGL(k_records_to_aos, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, mb.rec, mb.status, mb.cap, n, records ? drec : nullptr, dw);
+  if (records) LSA_HIP(ctx, hipMemcpyAsync(records, drec, (size_t)n * 16 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  LSA_HIP(ctx, hipMemcpyAsync(weights, dw, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  LSA_HIP(ctx, hipMemcpyAsync(status, mb.status, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+  LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return n;
+}
+
+int lsa_match_slow_queries(lsa_ctx* ctx)
+{
+  if (!ctx) return LSA_E_ARG;
+  int v = 0;
+  if (hipMemcpy(&v, ctx->hist_dev + LSA_MATCH_NSTATUS, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return LSA_E_HIP;
+  return v;
+}
+
+int lsa_accumulate(lsa_ctx* ctx, unsigned type_mask, const double w[6], int want_jacobian, double* cost, double g[6], double H[36], int* n_valid)
+{
+  if (!ctx || !w || !cost) return ctx ? ctx->fail(LSA_E_ARG, "lsa_accumulate: bad argument") : LSA_E_ARG;
+  LSA_HIP(ctx, hipSetDevice(ctx->device));
+  AccumConst c;
+  // R = Rz Ry Rx and its partial derivatives (CeresCostFunctions.h:67-79), once per evaluation on the host
+  {
+    const double cx = std::cos(w[3]), sx = std::sin(w[3]);
+    const double cy = std::cos(w[4]), sy = std::sin(w[4]);
+    const double cz = std::cos(w[5]), sz = std::sin(w[5]);
+    const double R[9] = {cy * cz, sx * sy * cz - cx * sz, cx * sy * cz + sx * sz, cy * sz, sx * sy * sz + cx * cz, cx * sy * sz - sx * cz, -sy, sx * cy, cx * cy};
+    const double dRx[9] = {0, cx * sy * cz + sx * sz, -sx * sy * cz + cx * sz, 0, cx * sy * sz - sx * cz, -sx * sy * sz - cx * cz, 0, cx * cy, -sx * cy};
+    const double dRy[9] = {-sy * cz, sx * cy * cz, cx * cy * cz, -sy * sz, sx * cy * sz, cx * cy * sz, -cy, -sx * sy, -cx * sy};
+    const double dRz[9] = {-cy * sz, -sx * sy * sz - cx * cz, -cx * sy * sz + sx * cz, cy * cz, sx * sy * cz - cx * sz, cx * sy * cz + sx * sz, 0, 0, 0};
+    std::memcpy(c.R, R, sizeof(R)); std::memcpy(c.dRx, dRx, sizeof(R)); std::memcpy(c.dRy, dRy, sizeof(R)); std::memcpy(c.dRz, dRz, sizeof(R));
+    c.t[0] = w[0]; c.t[1] = w[1]; c.t[2] = w[2];
+  }
+  int total = 0;
+  for (int k = 0; k < 3; ++k)
+  {
+    MatchBuf& mb = ctx->match[k];
+    const bool use = (type_mask >> k) & 1u && mb.valid && mb.k > 0;
+    c.rec[k] = mb.rec; c.status[k] = mb.status; c.cap[k] = mb.cap;
+    c.count[k] = use ? mb.k : 0;
+    c.sat2[k] = mb.sat * mb.sat;
+    total += c.count[k];
+  }
+  c.jac = want_jacobian;
+  hipStream_t st = ctx->stream;
+  {
+    ProfScope ps(ctx, want_jacobian ? "accumulate_jac" : "accumulate_cost", (double)total * (want_jacobian ? 129 : 129));
+    hipLaunchKernelGGL(k_accumulate, dim3(kAccumBlocks), dim3(256), 0, st, c, ctx->partials);
+    hipLaunchKernelGGL(k_accumulate_final, dim3(1), dim3(64), 0, st, ctx->partials, kAccumBlocks, ctx->reduce_out);
+  }
+  double* hp = ctx->host_pinned + 64;
+  LSA_HIP(ctx, hipMemcpyAsync(hp, ctx->reduce_out, kAccumVals * sizeof(double), hipMemcpyDeviceToHost, st));
+  LSA_HIP(ctx, hipStreamSynchronize(st));
+  *cost = hp[0];
+  if (n_valid) *n_valid = (int)hp[28];
+  if (g) for (int a = 0; a < 6; ++a) g[a] = hp[1 + a];
+  if (H)
+  {
+    int h = 7;
+    for (int a = 0; a < 6; ++a)
+      for (int b = a; b < 6; ++b) { H[a * 6 + b] = hp[h]; H[b * 6 + a] = hp[h]; ++h; }
+  }
+  return LSA_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,326 @@
+// lsa_transform.hip -- undistortion and rigid / interpolated transforms of device point sets.
+//   k_undistort          Slam::RefineUndistortion per-point loop (slam_lib/src/Slam.cxx:1342-1351)
+//   k_transform_out      Slam::TransformPointCloud (:1491-1509) / AggregateFrames(..., true) (:1512-1578)
+//   k_time_range, k_bbox Slam::InitUndistortion (:1291-1300), getMinMax3D of the world keypoints (:1026-1029)
+// All arithmetic in double, stored as float (Utils::TransformPoint, Utilities.h:274-278).
+#include <cfloat>
+#include <cmath>
+#include <limits>
+#include "lsa_ctx.h"
+#include "lsa_device_math.h"
+
+using namespace lsa;
+
+namespace
+{
+
+__device__ __forceinline__ double point_time(const float4& b) { return __hiloint2double(__float_as_int(b.y), __float_as_int(b.x)); }
+
+__global__ __launch_bounds__(256) void k_undistort(float4* __restrict__ pts, int n, InterpConst c)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float4 a = pts[2 * (size_t)i];
+  const float4 b = pts[2 * (size_t)i + 1];
+  Rigid T;
+  interp_eval(c, point_time(b), T);
+  double ox, oy, oz;
+  rigid_apply(T, (double)a.x, (double)a.y, (double)a.z, ox, oy, oz);
+  a.x = (float)ox; a.y = (float)oy; a.z = (float)oz;
+  pts[2 * (size_t)i] = a;
+}
+
+// out = T(point) for a whole set; interpolate != 0 -> per-point pose
+__global__ __launch_bounds__(256) void k_transform_out(const float4* __restrict__ in, int n, int interpolate, InterpConst c, Rigid R,
+                                                       float4* __restrict__ out)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float4 a = in[2 * (size_t)i];
+  const float4 b = in[2 * (size_t)i + 1];
+  Rigid T = R;
+  if (interpolate) interp_eval(c, point_time(b), T);
+  double ox, oy, oz;
+  rigid_apply(T, (double)a.x, (double)a.y, (double)a.z, ox, oy, oz);
+  a.x = (float)ox; a.y = (float)oy; a.z = (float)oz;
+  out[2 * (size_t)i] = a;
+  out[2 * (size_t)i + 1] = b;
+}
+
+// monotone encoding of doubles for 64-bit atomicMin/Max
+__device__ __forceinline__ unsigned long long d2o(double d)
+{
+  unsigned long long u = (unsigned long long)__double_as_longlong(d);
+  return (u & 0x8000000000000000ull) ? ~u : (u | 0x8000000000000000ull);
+}
+__host__ inline double o2d_host(unsigned long long u)
+{
+  u = (u & 0x8000000000000000ull) ? (u & 0x7fffffffffffffffull) : ~u;
+  double d;
+  std::memcpy(&d, &u, sizeof(d));
+  return d;
+}
+
+__global__ __launch_bounds__(256) void k_time_range(const float4* __restrict__ pts, int n, unsigned long long* __restrict__ bits)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned long long lo = ~0ull, hi = 0ull;
+  if (i < n)
+  {
+    const unsigned long long o = d2o(point_time(pts[2 * (size_t)i + 1]));
+    lo = hi = o;
+  }
+  for (int s = 32; s > 0; s >>= 1)
+  {
+    const unsigned long long l2 = __shfl_down(lo, s), h2 = __shfl_down(hi, s);
+    lo = l2 < lo ? l2 : lo;
+    hi = h2 > hi ? h2 : hi;
+  }
+  if ((threadIdx.x & 63) == 0 && i < n + 64)
+  {
+    atomicMin(&bits[0], lo);
+    atomicMax(&bits[1], hi);
+  }
+}
+
+__device__ __forceinline__ unsigned f2ou(float f)
+{
+  unsigned u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__host__ inline float ou2f_host(unsigned u)
+{
+  u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+  float f;
+  std::memcpy(&f, &u, sizeof(f));
+  return f;
+}
+
+__global__ __launch_bounds__(256) void k_bbox(const float4* __restrict__ pts, int n, Rigid T, unsigned* __restrict__ bits)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned lo[3] = {~0u, ~0u, ~0u}, hi[3] = {0u, 0u, 0u};
+  if (i < n)
+  {
+    const float4 a = pts[2 * (size_t)i];
+    double ox, oy, oz;
+    rigid_apply(T, (double)a.x, (double)a.y, (double)a.z, ox, oy, oz);
+    const float v[3] = {(float)ox, (float)oy, (float)oz};
+    for (int d = 0; d < 3; ++d) lo[d] = hi[d] = f2ou(v[d]);
+  }
+  for (int d = 0; d < 3; ++d)
+    for (int s = 32; s > 0; s >>= 1)
+    {
+      const unsigned l2 = __shfl_down(lo[d], s), h2 = __shfl_down(hi[d], s);
+      lo[d] = l2 < lo[d] ? l2 : lo[d];
+      hi[d] = h2 > hi[d] ? h2 : hi[d];
+    }
+  if ((threadIdx.x & 63) == 0)
+    for (int d = 0; d < 3; ++d)
+    {
+      atomicMin(&bits[d], lo[d]);
+      atomicMax(&bits[3 + d], hi[d]);
+    }
+}
+
+// host-side quaternion helpers (Eigen::Quaternion(Matrix3d), slam_lib/include/LidarSlam/MotionModel.h:64-76)
+void quat_from_matrix(const double R[9], double q[4])
+{
+  double t = R[0] + R[4] + R[8];
+  if (t > 0.0)
+  {
+    t = std::sqrt(t + 1.0);
+    q[0] = 0.5 * t;
+    t = 0.5 / t;
+    q[1] = (R[7] - R[5]) * t;
+    q[2] = (R[2] - R[6]) * t;
+    q[3] = (R[3] - R[1]) * t;
+  }
+  else
+  {
+    int i = 0;
+    if (R[4] > R[0]) i = 1;
+    if (R[8] > R[i * 3 + i]) i = 2;
+    const int j = (i + 1) % 3, k = (j + 1) % 3;
+    t = std::sqrt(R[i * 3 + i] - R[j * 3 + j] - R[k * 3 + k] + 1.0);
+    double v[3];
+    v[i] = 0.5 * t;
+    t = 0.5 / t;
+    q[0] = (R[k * 3 + j] - R[j * 3 + k]) * t;
+    v[j] = (R[j * 3 + i] + R[i * 3 + j]) * t;
+    v[k] = (R[k * 3 + i] + R[i * 3 + k]) * t;
+    q[1] = v[0]; q[2] = v[1]; q[3] = v[2];
+  }
+}
+void quat_to_matrix(const double q[4], double R[9])
+{
+  const double w = q[0], x = q[1], y = q[2], z = q[3];
+  const double tx = 2.0 * x, ty = 2.0 * y, tz = 2.0 * z;
+  const double twx = tx * w, twy = ty * w, twz = tz * w;
+  const double txx = tx * x, txy = ty * x, txz = tz * x;
+  const double tyy = ty * y, tyz = tz * y, tzz = tz * z;
+  R[0] = 1.0 - (tyy + tzz); R[1] = txy - twz;         R[2] = txz + twy;
+  R[3] = txy + twz;         R[4] = 1.0 - (txx + tzz); R[5] = tyz - twx;
+  R[6] = txz - twy;         R[7] = tyz + twx;         R[8] = 1.0 - (txx + tyy);
+}
+
+// Everything of LinearTransformInterpolator that is independent of the point: SetTransforms
+// (quaternion round trip), IsInterpolatorValid (isApprox, prec 1e-12), slerp constants.
+InterpConst make_interp(const double H0[16], const double H1[16], double t0, double t1)
+{
+  InterpConst c;
+  double R0[9], R1[9];
+  row_major_to_rt(H0, R0, c.trans0);
+  row_major_to_rt(H1, R1, c.trans1);
+  quat_from_matrix(R0, c.qa);
+  quat_from_matrix(R1, c.qb);
+  c.time0 = t0; c.time1 = t1;
+  // GetH0 / GetH1 go through the quaternions
+  double G0[9], G1[9];
+  quat_to_matrix(c.qa, G0);
+  quat_to_matrix(c.qb, G1);
+  std::memcpy(c.h0.R, G0, sizeof(G0));
+  std::memcpy(c.h0.t, c.trans0, sizeof(c.trans0));
+  double d = 0, na = 1, nb = 1;
+  for (int i = 0; i < 9; ++i) { double e = G0[i] - G1[i]; d += e * e; na += G0[i] * G0[i]; nb += G1[i] * G1[i]; }
+  for (int i = 0; i < 3; ++i) { double e = c.trans0[i] - c.trans1[i]; d += e * e; na += c.trans0[i] * c.trans0[i]; nb += c.trans1[i] * c.trans1[i]; }
+  const bool approx = d <= 1e-12 * 1e-12 * std::min(na, nb);
+  c.invalid = (t0 == t1 || approx) ? 1 : 0;
+  c.d = (c.qa[1] * c.qb[1] + c.qa[3] * c.qb[3]) + (c.qa[2] * c.qb[2] + c.qa[0] * c.qb[0]);
+  const double one = 1.0 - std::numeric_limits<double>::epsilon();
+  const double absD = std::abs(c.d);
+  c.linear = absD >= one ? 1 : 0;
+  c.theta = c.linear ? 0.0 : std::acos(absD);
+  c.sin_theta = c.linear ? 1.0 : lsa_sin(c.theta);
+  return c;
+}
+
+}  // namespace
+
+extern "C" {
+
+int lsa_reset_working_keypoints(lsa_ctx* ctx)
+{
+  if (!ctx) return LSA_E_ARG;
+  LSA_HIP(ctx, hipSetDevice(ctx->device));
+  for (int k = 0; k < 3; ++k)
+  {
+    const int n = ctx->kp_n[LSA_SET_RAW_CURRENT][k];
+    ctx->kp_n[LSA_SET_WORKING][k] = n;
+    if (n > 0)
+      LSA_HIP(ctx, hipMemcpyAsync(ctx->kp[LSA_SET_WORKING][k], ctx->kp[LSA_SET_RAW_CURRENT][k], (size_t)n * sizeof(lsa_point_t),
+                                  hipMemcpyDeviceToDevice, ctx->stream));
+  }
+  return LSA_OK;
+}
+
+int lsa_undistort(lsa_ctx* ctx, const double H0[16], const double H1[16], double t0, double t1)
+{
+  if (!ctx || !H0 || !H1) return ctx ? ctx->fail(LSA_E_ARG, "lsa_undistort: bad argument") : LSA_E_ARG;
+  LSA_HIP(ctx, hipSetDevice(ctx->device));
+  const InterpConst c = make_interp(H0, H1, t0, t1);
+  for (int k = 0; k < 3; ++k)
+  {
+    const int n = ctx->kp_n[LSA_SET_WORKING][k];
+    if (n <= 0) continue;
+    ProfScope ps(ctx, "undistort", (double)n * 48);
+    hipLaunchKernelGGL(k_undistort, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, reinterpret_cast<float4*>(ctx->kp[LSA_SET_WORKING][k]), n, c);
+  }
+  return LSA_OK;
+}
+
+int lsa_working_time_range(lsa_ctx* ctx, double* tmin, double* tmax)
+{
+  if (!ctx || !tmin || !tmax) return ctx ? ctx->fail(LSA_E_ARG, "lsa_working_time_range: bad argument") : LSA_E_ARG;
+  LSA_HIP(ctx, hipSetDevice(ctx->device));
+  const unsigned long long init[2] = {~0ull, 0ull};
+  LSA_HIP(ctx, hipMemcpyAsync(ctx->range_bits, init, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
+  int total = 0;
+  for (int k = 0; k < 3; ++k)
+  {
+    const int n = ctx->kp_n[LSA_SET_WORKING][k];
+    if (n <= 0) continue;
+    total += n;
+    hipLaunchKernelGGL(k_time_range, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, reinterpret_cast<const float4*>(ctx->kp[LSA_SET_WORKING][k]), n,
+                       ctx->range_bits);
+  }
+  unsigned long long* hp = reinterpret_cast<unsigned long long*>(ctx->host_pinned + 128);
+  LSA_HIP(ctx, hipMemcpyAsync(hp, ctx->range_bits, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+  LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (total == 0)
+  {
+    *tmin = std::numeric_limits<double>::max();
+    *tmax = std::numeric_limits<double>::lowest();
+    return LSA_OK;
+  }
+  *tmin = o2d_host(hp[0]);
+  *tmax = o2d_host(hp[1]);
+  return LSA_OK;
+}
+
+int lsa_working_bbox(lsa_ctx* ctx, int type, const double pose[16], float mn[3], float mx[3])
+{
+  if (!ctx || !pose || type < 0 || type > 2) return ctx ? ctx->fail(LSA_E_ARG, "lsa_working_bbox: bad argument") : LSA_E_ARG;
+  LSA_HIP(ctx, hipSetDevice(ctx->device));
+  const int n = ctx->kp_n[LSA_SET_WORKING][type];
+  for (int d = 0; d < 3; ++d) { mn[d] = FLT_MAX; mx[d] = -FLT_MAX; }
+  if (n <= 0) return LSA_OK;
+  unsigned* bits = reinterpret_cast<unsigned*>(ctx->range_bits + 4);
+  const unsigned init[6] = {~0u, ~0u, ~0u, 0u, 0u, 0u};
+  LSA_HIP(ctx, hipMemcpyAsync(bits, init, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
+  Rigid T;
+  row_major_to_rt(pose, T.R, T.t);
+  hipLaunchKernelGGL(k_bbox, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, reinterpret_cast<const float4*>(ctx->kp[LSA_SET_WORKING][type]), n, T, bits);
+  unsigned* hp = reinterpret_cast<unsigned*>(ctx->host_pinned + 136);
+  LSA_HIP(ctx, hipMemcpyAsync(hp, bits, 6 * sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
+  LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  for (int d = 0; d < 3; ++d) { mn[d] = ou2f_host(hp[d]); mx[d] = ou2f_host(hp[3 + d]); }
+  return LSA_OK;
+}
+
+int lsa_download_transformed(lsa_ctx* ctx, int set, int type, const double pose[16], lsa_point_t* out, int capacity)
+{
+  if (!ctx || !pose || set < 0 || set > 2 || type < 0 || type > 2) return ctx ? ctx->fail(LSA_E_ARG, "lsa_download_transformed: bad argument") : LSA_E_ARG;
+  LSA_HIP(ctx, hipSetDevice(ctx->device));
+  const int n = std::min(capacity, ctx->kp_n[set][type]);
+  if (n <= 0) return 0;
+  int rc = ensure_scratch(ctx, (size_t)n * sizeof(lsa_point_t));
+  if (rc) return rc;
+  Rigid T;
+  row_major_to_rt(pose, T.R, T.t);
+  InterpConst dummy{};
+  {
+    ProfScope ps(ctx, "transform_keypoints_out", (double)n * 64);
+    hipLaunchKernelGGL(k_transform_out, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, reinterpret_cast<const float4*>(ctx->kp[set][type]), n, 0, dummy,
+                       T, reinterpret_cast<float4*>(ctx->scratch_out));
+  }
+  LSA_HIP(ctx, hipMemcpyAsync(out, ctx->scratch_out, (size_t)n * sizeof(lsa_point_t), hipMemcpyDeviceToHost, ctx->stream));
+  LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return n;
+}
+
+int lsa_transform_frame(lsa_ctx* ctx, int interpolate, const double H0[16], const double H1[16], double t0, double t1, lsa_point_t* out,
+                        int capacity)
+{
+  if (!ctx || !H0 || (interpolate && !H1) || !out) return ctx ? ctx->fail(LSA_E_ARG, "lsa_transform_frame: bad argument") : LSA_E_ARG;
+  if (!ctx->frame || ctx->frame_n <= 0) return ctx->fail(LSA_E_STATE, "lsa_transform_frame: no frame");
+  LSA_HIP(ctx, hipSetDevice(ctx->device));
+  const int n = ctx->frame_n;
+  if (capacity < n) return ctx->fail(LSA_E_CAPACITY, "lsa_transform_frame: capacity < frame size");
+  int rc = ensure_scratch(ctx, (size_t)n * sizeof(lsa_point_t));
+  if (rc) return rc;
+  Rigid T;
+  row_major_to_rt(H0, T.R, T.t);
+  InterpConst c{};
+  if (interpolate) c = make_interp(H0, H1, t0, t1);
+  {
+    ProfScope ps(ctx, "transform_frame", (double)n * 64);
+    hipLaunchKernelGGL(k_transform_out, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, reinterpret_cast<const float4*>(ctx->frame), n, interpolate, c, T,
+                       reinterpret_cast<float4*>(ctx->scratch_out));
+  }
+  LSA_HIP(ctx, hipMemcpyAsync(out, ctx->scratch_out, (size_t)n * sizeof(lsa_point_t), hipMemcpyDeviceToHost, ctx->stream));
+  LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return n;
+}
+
+}  // extern "C"

@@ -265,7 +265,8 @@ template <typename T> inline void eigen33(const M3<T>& mat, M3<T>& evecs, T eval
     max_el = len > mmax[max_el] ? 0 : max_el;
     unsigned mid_el = 3 - min_el - max_el;
     e[min_el] = normalized(cross(e[(min_el + 1) % 3], e[(min_el + 2) % 3]));
-    e[mid_el] = normalized(cross(e[(mid_el + 1) % 3], e[(mid_el + 2) % 3]));
+    if (mid_el < 3)  // NaN input leaves min_el == max_el: the reference then indexes out of range
+      e[mid_el] = normalized(cross(e[(mid_el + 1) % 3], e[(mid_el + 2) % 3]));
     setcol(evecs, 0, e[0]); setcol(evecs, 1, e[1]); setcol(evecs, 2, e[2]);
   }
   evals[0] *= scale; evals[1] *= scale; evals[2] *= scale;

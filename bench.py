@@ -1,0 +1,221 @@
+#!/usr/bin/env python3
+"""bench.py -- LiDAR frames/s of Slam::AddFrame (end to end) on synthetic VLS-128 sequences.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A step = one AddFrame (keypoint extraction + ego-motion ICP + localization ICP + map update) on one
+VLS-128-shaped scan (128 x 2048 firings, ~260k points) that is already resident in HBM (frame
+store); every rank replays its own independent sequence (seed 1000 + rank) on its own GPU -- the
+path shards by sequence, so scaling is weak and the only exchange is the RCCL
+all-gather of the 4x4 pose + stamp of every sequence after each step.
+Rank 0 prints ONE JSON line (contract in the task description) with two extra objects:
+  roofline      achieved algorithmic GB/s of the dominant kernel (HIP events on the context's own
+                stream, live during the timed region) against the 8 TB/s HBM peak
+  cpu_baseline  the CPU oracle ("port": restatement of the reference algorithm, OpenMP where the
+                reference has it) on a bounded sample of the same sequence, on the host cores
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--model", type=int, default=128, help="16 VLP-16, 64 HDL-64, 128 VLS-128 (headline)")
+    ap.add_argument("--cpu-frames", type=int, default=10, help="frames of the CPU baseline sample (0 disables)")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="0 = all host cores available to this process")
+    ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events in the timed region")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    import torch
+    import torch.distributed as dist
+
+    import lidarslam_amd as L
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    distributed = world > 1
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+
+    # ---- inputs: one independent sequence per rank, generated on the host, made resident in HBM
+    total = args.warmup + args.steps
+    slam = L.Slam(local_rank, EgoMotion=3)  # MOTION_EXTRAPOLATION_AND_REGISTRATION: the default mode skips the ego-motion ICP
+    seed = 1000 + rank
+    stamps, npts = [], 0
+    for f in range(total):
+        pts, stamp = L.synth_frame(args.model, seed, f)
+        slam.store_frame(f, pts)
+        stamps.append(stamp)
+        npts += pts.size
+    ctx = slam.context()
+
+    pose_buf = torch.zeros(17, dtype=torch.float64, device="cuda")
+    pose_all = torch.zeros(17 * world, dtype=torch.float64, device="cuda")
+    pose_host = torch.zeros(17, dtype=torch.float64).pin_memory()
+    side = torch.cuda.Stream()
+
+    def exchange(stamp):
+        # RCCL pose broadcast of the north star: every rank ends up with every sequence's pose table
+        if not distributed:
+            return None
+        pose_host[:16] = torch.from_numpy(slam.world_transform().reshape(16))
+        pose_host[16] = stamp * 1e-6
+        with torch.cuda.stream(side):
+            pose_buf.copy_(pose_host, non_blocking=True)
+            return dist.all_gather_into_tensor(pose_all, pose_buf, async_op=True)
+
+    def step(f):
+        slam.add_stored_frame(f, stamps[f], f)
+        return exchange(stamps[f])
+
+    for f in range(args.warmup):
+        h = step(f)
+        if h is not None:
+            h.wait()
+
+    stats_acc = np.zeros(16)
+    if not args.no_profile:
+        ctx.profile(True)
+        ctx.profile_reset()
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ctx.sync()
+    t0 = time.perf_counter()
+    pending = None
+    for f in range(args.warmup, total):
+        h = step(f)
+        if pending is not None:
+            pending.wait()
+        pending = h
+        stats_acc += slam.stats()
+    if pending is not None:
+        pending.wait()
+    ctx.sync()
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    kernels = [] if args.no_profile else ctx.profile_stats()
+    ctx.profile(False)
+
+    if rank == 0:
+        out = {
+            "metric": "LiDAR frames/sec (AddFrame end-to-end), VLS-128 scan" if args.model == 128 else f"LiDAR frames/sec (AddFrame end-to-end), model {args.model}",
+            "value": world * args.steps / elapsed,
+            "unit": "frames/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32+f64",
+            "data": "synthetic",
+            "config": {
+                "workload": {128: "VLS-128", 64: "HDL-64", 16: "VLP-16"}.get(args.model, str(args.model))
+                + " synthetic spinning scan, street canyon, 5 m/s, EgoMotion=MOTION_EXTRAPOLATION_AND_REGISTRATION, Undistortion=REFINED, library defaults",
+                "points_per_frame": npts // total,
+                "sequences": world,
+                "parallelism": f"1 sequence per GPU x {world}, RCCL all-gather of poses",
+                "frames_resident_in_hbm": True,
+            },
+        }
+        n = args.steps
+        icp_iters = max(stats_acc[9] + stats_acc[10], 1)
+        out["ms_per_icp_iter"] = 1e3 * (stats_acc[2] + stats_acc[3] + stats_acc[4] + stats_acc[5]) / icp_iters
+        out["stage_ms_per_frame"] = {
+            k: 1e3 * stats_acc[i] / n
+            for i, k in enumerate(["total", "extract", "ego_icp", "ego_lm", "loc_icp", "loc_lm", "undistort", "submap", "maps"])
+        }
+        if kernels:
+            dom = max(kernels, key=lambda k: k["total_ms"])
+            ach = dom["bytes"] / (dom["total_ms"] * 1e-3) / 1e9 if dom["total_ms"] > 0 else 0.0
+            out["roofline"] = {
+                "bound": "hbm",
+                "kernel": dom["name"],
+                "achieved": ach,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": ach / HBM_PEAK_GBS,
+                "traffic": None,
+                "avg_launch_us": 1e3 * dom["total_ms"] / max(dom["launches"], 1),
+                "algorithmic_bytes_per_launch": dom["bytes"] / max(dom["launches"], 1),
+            }
+            out["kernels"] = {
+                k["name"]: {
+                    "launches_per_frame": k["launches"] / n,
+                    "us_per_launch": 1e3 * k["total_ms"] / max(k["launches"], 1),
+                    "GBps": (k["bytes"] / (k["total_ms"] * 1e-3) / 1e9) if k["total_ms"] > 0 else 0.0,
+                }
+                for k in sorted(kernels, key=lambda k: -k["total_ms"])
+            }
+        if world == 1 and args.cpu_frames > 0:
+            out["cpu_baseline"] = cpu_baseline(args, seed)
+        print(json.dumps(out), flush=True)
+    slam.close()
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(args, seed):
+    """The CPU oracle (restatement of the reference algorithm, OpenMP over rings / keypoints like the
+    reference) on the first frames of the same sequence, timed on this box's host cores."""
+    from oracle import oracle as O
+
+    import lidarslam_amd as L
+
+    threads = args.cpu_threads or len(os.sched_getaffinity(0))
+    s = O.Slam(EgoMotion=3, NbThreads=threads)
+    times = []
+    skip = 2  # the first frames build the map from nothing and are not representative
+    for f in range(args.cpu_frames + skip):
+        pts, stamp = L.synth_frame(args.model, seed, f)
+        t = time.perf_counter()
+        s.add_frame(pts, stamp, f)
+        times.append(time.perf_counter() - t)
+    t = np.array(times[skip:])
+    return {
+        "value": float(len(t) / t.sum()),
+        "unit": "frames/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": f"frames {skip}..{skip + len(t) - 1} of the same sequence (seed {seed}), median {1e3 * float(np.median(t)):.1f} ms/frame",
+    }
+
+
+if __name__ == "__main__":
+    main()

@@ -25,7 +25,9 @@ namespace lsa
 constexpr int kMaxRings = 512;            // laser_id < kMaxRings (largest spinning sensors have 128)
 constexpr int kMaxRingPoints = 8192;      // points per ring handled by the in-LDS labelling kernel
 constexpr int kBucketChunk = 1024;        // points per block of the ring bucketing kernels
-constexpr int kCellCap = 1 << 21;         // max cells of one kNN search grid
+constexpr int kCellCap = 1 << 21;         // max cells of the fine kNN search grid
+constexpr int kCellCapCoarse = 1 << 15;   // max cells of the coarse level (cell x 8)
+constexpr int kKnnMax = 16;               // neighbours per query the kNN buffers hold
 constexpr int kAccumBlocks = 120;         // grid of the normal-equation kernel (grid-stride)
 constexpr int kAccumVals = 29;            // cost, g[6], H upper[21], nvalid
 
@@ -39,16 +41,24 @@ struct GridDesc
   int npoints;
 };
 
+// One resolution of the search grid.  Level 0 (cell = hint) answers dense neighbourhoods, level 1
+// (cell = 8 x hint) lets sparse ones expand over empty space in a few shells instead of thousands.
+struct GridLevel
+{
+  float4* sorted = nullptr;        // cell-sorted x,y,z, index bits
+  uint32_t* cell_of = nullptr;     // cell id per point
+  uint32_t* cell_start = nullptr;  // max_cells + 1
+  uint32_t* cell_fill = nullptr;   // max_cells
+  uint32_t* block_sums = nullptr;
+  int max_cells = 0;
+};
+
 struct Target
 {
   lsa_point_t* pts = nullptr;   // AoS as given (order kept)
   float4* xyzl = nullptr;       // x,y,z, laser_id bits
-  float4* sorted = nullptr;     // cell-sorted x,y,z, index bits
-  uint32_t* cell_of = nullptr;  // cell id per point
-  uint32_t* cell_start = nullptr;  // kCellCap + 1
-  uint32_t* cell_fill = nullptr;   // kCellCap
-  uint32_t* block_sums = nullptr;
-  GridDesc* desc = nullptr;     // device
+  GridLevel lv[2];
+  GridDesc* desc = nullptr;     // device, [2]
   int* bbox_bits = nullptr;     // 6 ordered ints
   int m = 0;
   int cap = 0;
@@ -59,6 +69,9 @@ struct MatchBuf
 {
   double* rec = nullptr;       // [16][cap]
   uint8_t* status = nullptr;   // [cap]
+  int* knn_idx = nullptr;      // [kKnnMax][cap] neighbour indices, ascending (distance, index)
+  float* knn_d2 = nullptr;     // [kKnnMax][cap]
+  int* knn_cnt = nullptr;      // [cap]
   int k = 0;                   // number of queries of the last match
   int cap = 0;
   double sat = 1.0;

@@ -49,12 +49,17 @@ int ensure_capacity(lsa_ctx* ctx, int n)
 int ensure_target(lsa_ctx* ctx, int type, int m)
 {
   Target& t = ctx->target[type];
-  if (!t.cell_start)
+  if (!t.desc)
   {
-    LSA_HIP(ctx, dev_alloc(&t.cell_start, (size_t)kCellCap + 1));
-    LSA_HIP(ctx, dev_alloc(&t.cell_fill, (size_t)kCellCap));
-    LSA_HIP(ctx, dev_alloc(&t.block_sums, (size_t)kCellCap / 1024 + 1));
-    LSA_HIP(ctx, dev_alloc(&t.desc, 1));
+    for (int l = 0; l < 2; ++l)
+    {
+      GridLevel& g = t.lv[l];
+      g.max_cells = l == 0 ? kCellCap : kCellCapCoarse;
+      LSA_HIP(ctx, dev_alloc(&g.cell_start, (size_t)g.max_cells + 1));
+      LSA_HIP(ctx, dev_alloc(&g.cell_fill, (size_t)g.max_cells));
+      LSA_HIP(ctx, dev_alloc(&g.block_sums, (size_t)g.max_cells / 1024 + 2));
+    }
+    LSA_HIP(ctx, dev_alloc(&t.desc, 2));
     LSA_HIP(ctx, dev_alloc(&t.bbox_bits, 8));
   }
   if (m <= t.cap) return LSA_OK;
@@ -62,8 +67,11 @@ int ensure_target(lsa_ctx* ctx, int type, int m)
   LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
   LSA_HIP(ctx, dev_alloc(&t.pts, (size_t)cap));
   LSA_HIP(ctx, dev_alloc(&t.xyzl, (size_t)cap));
-  LSA_HIP(ctx, dev_alloc(&t.sorted, (size_t)cap));
-  LSA_HIP(ctx, dev_alloc(&t.cell_of, (size_t)cap));
+  for (int l = 0; l < 2; ++l)
+  {
+    LSA_HIP(ctx, dev_alloc(&t.lv[l].sorted, (size_t)cap));
+    LSA_HIP(ctx, dev_alloc(&t.lv[l].cell_of, (size_t)cap));
+  }
   t.cap = cap;
   return LSA_OK;
 }
@@ -76,6 +84,9 @@ int ensure_match(lsa_ctx* ctx, int type, int k)
   LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
   LSA_HIP(ctx, dev_alloc(&b.rec, (size_t)cap * 16));
   LSA_HIP(ctx, dev_alloc(&b.status, (size_t)cap));
+  LSA_HIP(ctx, dev_alloc(&b.knn_idx, (size_t)cap * kKnnMax));
+  LSA_HIP(ctx, dev_alloc(&b.knn_d2, (size_t)cap * kKnnMax));
+  LSA_HIP(ctx, dev_alloc(&b.knn_cnt, (size_t)cap));
   b.cap = cap;
   return LSA_OK;
 }
@@ -235,8 +246,9 @@ void lsa_ctx_destroy(lsa_ctx* ctx)
   for (int k = 0; k < 3; ++k)
   {
     Target& t = ctx->target[k];
-    fr(t.pts); fr(t.xyzl); fr(t.sorted); fr(t.cell_of); fr(t.cell_start); fr(t.cell_fill); fr(t.block_sums); fr(t.desc); fr(t.bbox_bits);
-    fr(ctx->match[k].rec); fr(ctx->match[k].status);
+    fr(t.pts); fr(t.xyzl); fr(t.desc); fr(t.bbox_bits);
+    for (int l = 0; l < 2; ++l) { fr(t.lv[l].sorted); fr(t.lv[l].cell_of); fr(t.lv[l].cell_start); fr(t.lv[l].cell_fill); fr(t.lv[l].block_sums); }
+    fr(ctx->match[k].rec); fr(ctx->match[k].status); fr(ctx->match[k].knn_idx); fr(ctx->match[k].knn_d2); fr(ctx->match[k].knn_cnt);
   }
   fr(ctx->partials); fr(ctx->reduce_out); fr(ctx->hist_dev); fr(ctx->scratch_out); fr(ctx->range_bits);
   for (auto& s : ctx->store) fr(s.first);

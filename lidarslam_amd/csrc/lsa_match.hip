@@ -2,13 +2,18 @@
 // the residual blocks on the GPU.
 //
 //   target grid     replaces KDTreePCLAdaptor::Reset (nanoflann kd-tree build,
-//                   slam_lib/include/LidarSlam/KDTreePCLAdaptor.h:57-65) by a dense uniform grid:
-//                   bbox reduce -> cell count -> exclusive scan -> cell-sorted float4 copy
-//   k_match<...>    one thread per keypoint (slam_lib/src/KeypointsMatcher.cxx:106-346):
-//                   world = pose * X, EXACT k-NN by expanding Chebyshev shells of grid cells (rows of
-//                   cells are contiguous in the cell-sorted array, so a shell row is one coalesced
-//                   range), neighbourhood filter (per-ring :349-405 / RANSAC line :408-480, candidates
-//                   staged in LDS), PCA in double, validity tests, residual record (A, P, X, weight)
+//                   slam_lib/include/LidarSlam/KDTreePCLAdaptor.h:57-65) by a two-level dense uniform
+//                   grid: bbox reduce -> per level { cell count -> exclusive scan -> cell-sorted float4 copy }
+//   k_knn<KMAX>     EXACT k-nearest neighbours (KDTreePCLAdaptor::KnnSearch, :79-105), 8 lanes per
+//                   query: Chebyshev shells of grid cells are expanded until the k-th distance is
+//                   provably inside the searched radius; the rows of a shell (contiguous runs of the
+//                   cell-sorted array) are dealt to the 8 lanes, each keeps a private top-k in registers,
+//                   the stop test is a 3-step shuffle sum of "how many of my entries are inside the
+//                   bound", the private lists are merged by shuffles at the end.  Sparse neighbourhoods
+//                   escalate to the coarse level (cell x 8) and, at last, to a cooperative exhaustive scan.
+//   k_model<..>     one thread per keypoint (slam_lib/src/KeypointsMatcher.cxx:106-346): neighbourhood
+//                   filter (per-ring :349-405 / RANSAC line :408-480, candidates staged in LDS), PCA in
+//                   double, validity tests, residual record (A, P, X, weight)
 //   k_accumulate    what Ceres evaluates per LM step for these blocks
 //                   (slam_lib/include/LidarSlam/CeresCostFunctions.h:105-152 + TukeyLoss/ScaledLoss,
 //                   KeypointsMatcher.cxx:84-101): cost, g = J^T r, H = J^T J with a fixed-order
@@ -62,31 +67,37 @@ __global__ __launch_bounds__(256) void k_target_prep(const float4* __restrict__ 
   }
 }
 
+// desc[0]: cell = hint (grown until the grid fits kCellCap); desc[1]: cell x 8 (grown until it fits
+// kCellCapCoarse)
 __global__ void k_grid_setup(const int* __restrict__ bbox, int m, float cell_hint, GridDesc* __restrict__ desc)
 {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  GridDesc g;
   float mn[3], mx[3];
   for (int d = 0; d < 3; ++d) { mn[d] = o2f(bbox[d]); mx[d] = o2f(bbox[3 + d]); }
   float cell = cell_hint;
-  int dims[3];
-  while (true)
+  for (int level = 0; level < 2; ++level)
   {
-    double total = 1;
-    for (int d = 0; d < 3; ++d)
+    const double cap = level == 0 ? (double)kCellCap : (double)kCellCapCoarse;
+    if (level == 1) cell *= 8.0f;
+    GridDesc g;
+    while (true)
     {
-      dims[d] = (int)floorf((mx[d] - mn[d]) / cell) + 1;
-      total *= dims[d];
+      double total = 1;
+      for (int d = 0; d < 3; ++d)
+      {
+        g.dims[d] = (int)floorf((mx[d] - mn[d]) / cell) + 1;
+        total *= g.dims[d];
+      }
+      if (total <= cap) break;
+      cell *= 1.26f;
     }
-    if (total <= (double)kCellCap) break;
-    cell *= 1.26f;
+    for (int d = 0; d < 3; ++d) g.origin[d] = mn[d];
+    g.cell = cell;
+    g.inv_cell = 1.0f / cell;
+    g.ncells = g.dims[0] * g.dims[1] * g.dims[2];
+    g.npoints = m;
+    desc[level] = g;
   }
-  for (int d = 0; d < 3; ++d) { g.origin[d] = mn[d]; g.dims[d] = dims[d]; }
-  g.cell = cell;
-  g.inv_cell = 1.0f / cell;
-  g.ncells = dims[0] * dims[1] * dims[2];
-  g.npoints = m;
-  *desc = g;
 }
 
 __device__ __forceinline__ int cell_coord(float v, float o, float inv, int n)
@@ -201,35 +212,23 @@ __global__ __launch_bounds__(256) void k_grid_scatter(const float4* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------
-struct MatchConst
-{
-  Rigid pose;
-  int type;
-  int k;                 // neighbours requested
-  int min_neighbors;     // EdgeMinNbNeighbors
-  int single_edge_per_ring;
-  double max_dist2;      // MaxNeighborsDistance^2
-  double max_model_err;  // Edge/PlaneMaxModelError
-  double planarity;
-  float ransac_sq_inlier;  // float(EdgeMaxModelError^2)
-  int bad_param;           // BAD_MODEL_PARAMETRIZATION for every keypoint
-};
+constexpr int kGroup = 8;         // lanes cooperating on one query
+constexpr int kShellCapFine = 6;  // shells searched at level 0 before escalating
+constexpr int kShellCapCoarse = 8;
 
-constexpr int kShellCap = 8;  // shells searched before the exhaustive fall-back
-
+// private top-k of one lane, ascending (distance, index); empty slots hold (+inf, INT_MAX)
 template <int KMAX> struct KnnSet
 {
   float d2[KMAX];
   int idx[KMAX];
   float worst_d;
   int worst_i;
-  int count;
   int k;
   __device__ __forceinline__ void init(int kk)
   {
 #pragma unroll
     for (int s = 0; s < KMAX; ++s) { d2[s] = INFINITY; idx[s] = 0x7fffffff; }
-    worst_d = INFINITY; worst_i = 0x7fffffff; count = 0; k = kk;
+    worst_d = INFINITY; worst_i = 0x7fffffff; k = kk;
   }
   __device__ __forceinline__ void offer(float d, int i)
   {
@@ -249,14 +248,22 @@ template <int KMAX> struct KnnSet
         if (s == k - 1) { worst_d = d2[s]; worst_i = idx[s]; }
       }
     }
-    if (count < k) ++count;
+  }
+  __device__ __forceinline__ int count_below(float bound2) const
+  {
+    int c = 0;
+#pragma unroll
+    for (int s = 0; s < KMAX; ++s)
+      if (s < k && d2[s] < bound2) ++c;
+    return c;
   }
 };
 
 template <int KMAX>
-__device__ __forceinline__ void scan_range(KnnSet<KMAX>& ks, const float4* __restrict__ sorted, uint32_t b, uint32_t e, float qx, float qy, float qz)
+__device__ __forceinline__ void scan_range(KnnSet<KMAX>& ks, const float4* __restrict__ sorted, uint32_t b, uint32_t e, uint32_t stride,
+                                           float qx, float qy, float qz)
 {
-  for (uint32_t t = b; t < e; ++t)
+  for (uint32_t t = b; t < e; t += stride)
   {
     const float4 p = sorted[t];
     const float dx = qx - p.x, dy = qy - p.y, dz = qz - p.z;
@@ -265,60 +272,166 @@ __device__ __forceinline__ void scan_range(KnnSet<KMAX>& ks, const float4* __res
   }
 }
 
-template <int KMAX>
-__device__ void knn_search(KnnSet<KMAX>& ks, const GridDesc& g, const uint32_t* __restrict__ cell_start, const float4* __restrict__ sorted,
-                           float qx, float qy, float qz, int* __restrict__ slow_counter)
+struct GridView
 {
-  const int nx = g.dims[0], ny = g.dims[1], nz = g.dims[2];
-  const int cx = cell_coord(qx, g.origin[0], g.inv_cell, nx);
-  const int cy = cell_coord(qy, g.origin[1], g.inv_cell, ny);
-  const int cz = cell_coord(qz, g.origin[2], g.inv_cell, nz);
-  // squared distance from the query to the grid box (0 inside)
-  float outd2 = 0.f;
+  GridDesc g;
+  const uint32_t* cell_start;
+  const float4* sorted;
+  int cx, cy, cz;
+  float outd2;
+};
+__device__ __forceinline__ void grid_view(GridView& v, const GridDesc* desc, const uint32_t* cs, const float4* sorted, float qx, float qy, float qz)
+{
+  v.g = *desc;
+  v.cell_start = cs;
+  v.sorted = sorted;
+  v.cx = cell_coord(qx, v.g.origin[0], v.g.inv_cell, v.g.dims[0]);
+  v.cy = cell_coord(qy, v.g.origin[1], v.g.inv_cell, v.g.dims[1]);
+  v.cz = cell_coord(qz, v.g.origin[2], v.g.inv_cell, v.g.dims[2]);
+  // squared distance from the query to the grid box (0 inside), shrunk by a guard factor
+  const float q[3] = {qx, qy, qz};
+  float o = 0.f;
+  for (int d = 0; d < 3; ++d)
   {
-    const float q[3] = {qx, qy, qz};
-    for (int d = 0; d < 3; ++d)
-    {
-      const float lo = g.origin[d], hi = g.origin[d] + g.dims[d] * g.cell;
-      float e = 0.f;
-      if (q[d] < lo) e = lo - q[d];
-      else if (q[d] > hi) e = q[d] - hi;
-      outd2 += e * e;
-    }
-    outd2 *= 0.999f;
+    const float lo = v.g.origin[d], hi = v.g.origin[d] + v.g.dims[d] * v.g.cell;
+    float e = 0.f;
+    if (q[d] < lo) e = lo - q[d];
+    else if (q[d] > hi) e = q[d] - hi;
+    o += e * e;
   }
-  for (int r = 0;; ++r)
-  {
-    const int z0 = max(0, cz - r), z1 = min(nz - 1, cz + r);
-    const int y0 = max(0, cy - r), y1 = min(ny - 1, cy + r);
-    const int x0 = max(0, cx - r), x1 = min(nx - 1, cx + r);
-    for (int z = z0; z <= z1; ++z)
-      for (int y = y0; y <= y1; ++y)
-      {
-        const int row = (z * ny + y) * nx;
-        const bool shell = (abs(z - cz) == r) || (abs(y - cy) == r);
-        if (shell)
-          scan_range(ks, sorted, cell_start[row + x0], cell_start[row + x1 + 1], qx, qy, qz);
-        else
-        {
-          if (cx - r >= 0) scan_range(ks, sorted, cell_start[row + cx - r], cell_start[row + cx - r + 1], qx, qy, qz);
-          if (cx + r < nx) scan_range(ks, sorted, cell_start[row + cx + r], cell_start[row + cx + r + 1], qx, qy, qz);
-        }
-      }
-    // every point closer than r cells (minus a 0.1 % guard for float cell assignment) has been seen
-    if (ks.count == ks.k && r >= 1)
-    {
-      const float br = ((float)r - 0.001f) * g.cell;
-      if (ks.worst_d < outd2 + br * br) return;
-    }
-    if (x0 == 0 && y0 == 0 && z0 == 0 && x1 == nx - 1 && y1 == ny - 1 && z1 == nz - 1) return;  // whole grid visited
-    if (r >= kShellCap) break;
-  }
-  // sparse neighbourhood: exhaustive scan keeps the result exact
-  atomicAdd(slow_counter, 1);
-  ks.init(ks.k);
-  scan_range(ks, sorted, 0u, (uint32_t)g.npoints, qx, qy, qz);
+  v.outd2 = o * 0.999f;
 }
+
+// neighbour lists are written SoA: idx[s * cap + q]
+template <int KMAX>
+__global__ __launch_bounds__(256) void k_knn(const float4* __restrict__ queries, int nq, Rigid pose, int k, const GridDesc* __restrict__ desc,
+                                             const uint32_t* __restrict__ cs0, const float4* __restrict__ sorted0,
+                                             const uint32_t* __restrict__ cs1, const float4* __restrict__ sorted1, int* __restrict__ knn_idx,
+                                             float* __restrict__ knn_d2, int* __restrict__ knn_cnt, int cap, int* __restrict__ slow_counter)
+{
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int q = tid / kGroup;
+  const int lane = tid % kGroup;
+  const bool active = q < nq;
+  float qx = 0.f, qy = 0.f, qz = 0.f;
+  if (active)
+  {
+    // KeypointsMatcher: worldPoint = PosePrior * basePoint in double, narrowed to float for the search
+    const float4 q4 = queries[2 * (size_t)q];
+    double wx, wy, wz;
+    rigid_apply(pose, (double)q4.x, (double)q4.y, (double)q4.z, wx, wy, wz);
+    qx = (float)wx; qy = (float)wy; qz = (float)wz;
+  }
+  KnnSet<KMAX> ks;
+  ks.init(k);
+  GridView gv;
+  grid_view(gv, desc, cs0, sorted0, qx, qy, qz);
+  int level = 0, r = 0;
+  bool done = !active;
+  while (true)
+  {
+    float bound2 = -1.f;
+    bool covered = false;
+    if (!done)
+    {
+      if (level < 2)
+      {
+        const int nx = gv.g.dims[0], ny = gv.g.dims[1], nz = gv.g.dims[2];
+        const int z0 = max(0, gv.cz - r), z1 = min(nz - 1, gv.cz + r);
+        const int y0 = max(0, gv.cy - r), y1 = min(ny - 1, gv.cy + r);
+        const int x0 = max(0, gv.cx - r), x1 = min(nx - 1, gv.cx + r);
+        const int ys = y1 - y0 + 1;
+        const int nrows = (z1 - z0 + 1) * ys;
+        for (int ri = lane; ri < nrows; ri += kGroup)
+        {
+          const int z = z0 + ri / ys, y = y0 + ri % ys;
+          const int row = (z * ny + y) * nx;
+          const bool shell = (abs(z - gv.cz) == r) || (abs(y - gv.cy) == r);
+          if (shell)
+            scan_range(ks, gv.sorted, gv.cell_start[row + x0], gv.cell_start[row + x1 + 1], 1u, qx, qy, qz);
+          else
+          {
+            if (gv.cx - r >= 0) scan_range(ks, gv.sorted, gv.cell_start[row + gv.cx - r], gv.cell_start[row + gv.cx - r + 1], 1u, qx, qy, qz);
+            if (gv.cx + r < nx) scan_range(ks, gv.sorted, gv.cell_start[row + gv.cx + r], gv.cell_start[row + gv.cx + r + 1], 1u, qx, qy, qz);
+          }
+        }
+        // every point closer than r cells (minus a 0.1 % guard for the float cell assignment) has been seen
+        if (r >= 1)
+        {
+          const float br = ((float)r - 0.001f) * gv.g.cell;
+          bound2 = gv.outd2 + br * br;
+        }
+        covered = (x0 == 0 && y0 == 0 && z0 == 0 && x1 == nx - 1 && y1 == ny - 1 && z1 == nz - 1);
+      }
+      else
+      {
+        scan_range(ks, gv.sorted, (uint32_t)lane, (uint32_t)gv.g.npoints, (uint32_t)kGroup, qx, qy, qz);
+        covered = true;
+      }
+    }
+    // wave-convergent: how many candidates of the whole group lie inside the proven radius
+    int c = done ? 0 : ks.count_below(bound2);
+    c += __shfl_xor(c, 1, kGroup);
+    c += __shfl_xor(c, 2, kGroup);
+    c += __shfl_xor(c, 4, kGroup);
+    if (!done)
+    {
+      if (covered || c >= k) done = true;
+      else if (r >= (level == 0 ? kShellCapFine : kShellCapCoarse))
+      {
+        ++level;
+        r = 0;
+        ks.init(k);
+        if (level == 1) grid_view(gv, desc + 1, cs1, sorted1, qx, qy, qz);
+        else if (lane == 0) atomicAdd(slow_counter, 1);
+      }
+      else ++r;
+    }
+    if (__all(done)) break;
+  }
+  // merge the 8 private lists (disjoint by construction) with a butterfly of shuffles
+#pragma unroll
+  for (int mask = 1; mask < kGroup; mask <<= 1)
+  {
+    float td[KMAX]; int ti[KMAX];
+#pragma unroll
+    for (int s = 0; s < KMAX; ++s) { td[s] = ks.d2[s]; ti[s] = ks.idx[s]; }
+#pragma unroll
+    for (int s = 0; s < KMAX; ++s)
+    {
+      const float od = __shfl_xor(td[s], mask, kGroup);
+      const int oi = __shfl_xor(ti[s], mask, kGroup);
+      if (s < k) ks.offer(od, oi);
+    }
+  }
+  if (active && lane == 0)
+  {
+    int cnt = 0;
+#pragma unroll
+    for (int s = 0; s < KMAX; ++s)
+      if (s < k)
+      {
+        knn_idx[(size_t)s * cap + q] = ks.idx[s];
+        knn_d2[(size_t)s * cap + q] = ks.d2[s];
+        if (ks.idx[s] != 0x7fffffff) ++cnt;
+      }
+    knn_cnt[q] = cnt;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+struct MatchConst
+{
+  int type;
+  int k;                 // neighbours requested
+  int min_neighbors;     // EdgeMinNbNeighbors
+  int single_edge_per_ring;
+  double max_dist2;      // MaxNeighborsDistance^2
+  double max_model_err;  // Edge/PlaneMaxModelError
+  double planarity;
+  float ransac_sq_inlier;  // float(EdgeMaxModelError^2)
+  int bad_param;           // BAD_MODEL_PARAMETRIZATION for every keypoint
+};
 
 __device__ __forceinline__ void write_record(double* __restrict__ rec, int cap, int i, const double A[9], const Vec3<double>& P,
                                              double bx, double by, double bz, double w)
@@ -330,17 +443,17 @@ __device__ __forceinline__ void write_record(double* __restrict__ rec, int cap, 
   rec[(size_t)15 * cap + i] = w;
 }
 
-constexpr int kMatchBlock = 128;
+constexpr int kModelBlock = 128;
 
 template <int KMAX, int TYPE>
-__global__ __launch_bounds__(kMatchBlock) void k_match(const float4* __restrict__ queries, int nq, MatchConst c,
-                                                       const GridDesc* __restrict__ desc, const uint32_t* __restrict__ cell_start,
-                                                       const float4* __restrict__ sorted, const float4* __restrict__ xyzl,
-                                                       double* __restrict__ rec, uint8_t* __restrict__ status, int cap,
-                                                       int* __restrict__ hist)
+__global__ __launch_bounds__(kModelBlock) void k_model(const float4* __restrict__ queries, int nq, MatchConst c, const int* __restrict__ knn_idx,
+                                                       const float* __restrict__ knn_d2, const int* __restrict__ knn_cnt,
+                                                       const float4* __restrict__ xyzl, double* __restrict__ rec,
+                                                       uint8_t* __restrict__ status, int cap, int* __restrict__ hist)
 {
   __shared__ int lh[LSA_MATCH_NSTATUS];
-  __shared__ float4 nb[TYPE == LSA_EDGE ? KMAX : 1][kMatchBlock];  // edge candidates staged in LDS
+  __shared__ float4 nb[TYPE == LSA_EDGE ? KMAX : 1][kModelBlock];  // edge candidates staged in LDS
+  __shared__ float nd[TYPE == LSA_EDGE ? KMAX : 1][kModelBlock];
   if (threadIdx.x < LSA_MATCH_NSTATUS) lh[threadIdx.x] = 0;
   __syncthreads();
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -355,14 +468,7 @@ __global__ __launch_bounds__(kMatchBlock) void k_match(const float4* __restrict_
     {
       const float4 q4 = queries[2 * (size_t)i];
       const double bx = (double)q4.x, by = (double)q4.y, bz = (double)q4.z;
-      double wx, wy, wz;
-      rigid_apply(c.pose, bx, by, bz, wx, wy, wz);
-      const float qx = (float)wx, qy = (float)wy, qz = (float)wz;
-      const GridDesc g = *desc;
-      KnnSet<KMAX> ks;
-      ks.init(c.k);
-      knn_search<KMAX>(ks, g, cell_start, sorted, qx, qy, qz, hist + LSA_MATCH_NSTATUS);
-
+      const int n = knn_cnt[i];
       Vec3<double> mean, e0, e1, e2;
       double l0 = 0, l1 = 0, l2 = 0;
       CovAccum<double> acc;
@@ -374,8 +480,11 @@ __global__ __launch_bounds__(kMatchBlock) void k_match(const float4* __restrict_
         // stage the candidates (ascending distance) in LDS: the filters index them dynamically
 #pragma unroll
         for (int s = 0; s < KMAX; ++s)
-          if (s < ks.count) nb[TYPE == LSA_EDGE ? s : 0][threadIdx.x] = xyzl[ks.idx[s]];
-        const int n = ks.count;
+          if (s < n)
+          {
+            nb[TYPE == LSA_EDGE ? s : 0][threadIdx.x] = xyzl[knn_idx[(size_t)s * cap + i]];
+            nd[TYPE == LSA_EDGE ? s : 0][threadIdx.x] = knn_d2[(size_t)s * cap + i];
+          }
         if (c.single_edge_per_ring)
         {
           // GetPerRingLineNeighbors (KeypointsMatcher.cxx:349-405): drop the closest point's own ring and
@@ -394,9 +503,7 @@ __global__ __launch_bounds__(kMatchBlock) void k_match(const float4* __restrict_
               {
                 acc.add(p.x, p.y, p.z);
                 ++nsel;
-#pragma unroll
-                for (int s = 0; s < KMAX; ++s)
-                  if (s == t) last_d2 = ks.d2[s];
+                last_d2 = nd[TYPE == LSA_EDGE ? t : 0][threadIdx.x];
               }
             }
           }
@@ -426,34 +533,31 @@ __global__ __launch_bounds__(kMatchBlock) void k_match(const float4* __restrict_
             const Vec3<float> dir = normalized3(vsub(Vec3<float>{pb.x, pb.y, pb.z}, P1));
             acc.add(p1.x, p1.y, p1.z);
             nsel = 1;
-            int lastSel = 0;
+            last_d2 = nd[0][threadIdx.x];
             for (int ci = 1; ci < n; ++ci)
             {
               const float4 pc = nb[TYPE == LSA_EDGE ? ci : 0][threadIdx.x];
               const bool in = (ci == best) || (vsqnorm(vcross(vsub(Vec3<float>{pc.x, pc.y, pc.z}, P1), dir)) < c.ransac_sq_inlier);
-              if (in) { acc.add(pc.x, pc.y, pc.z); ++nsel; lastSel = ci; }
+              if (in) { acc.add(pc.x, pc.y, pc.z); ++nsel; last_d2 = nd[TYPE == LSA_EDGE ? ci : 0][threadIdx.x]; }
             }
-#pragma unroll
-            for (int s = 0; s < KMAX; ++s)
-              if (s == lastSel) last_d2 = ks.d2[s];
           }
         }
         if (nsel < c.min_neighbors) st = LSA_MATCH_NOT_ENOUGH_NEIGHBORS;
       }
       else
       {
-        if (ks.count < c.k) st = LSA_MATCH_NOT_ENOUGH_NEIGHBORS;
+        if (n < c.k) st = LSA_MATCH_NOT_ENOUGH_NEIGHBORS;
         else
         {
 #pragma unroll
           for (int s = 0; s < KMAX; ++s)
             if (s < c.k)
             {
-              const float4 p = xyzl[ks.idx[s]];
+              const float4 p = xyzl[knn_idx[(size_t)s * cap + i]];
               acc.add(p.x, p.y, p.z);
             }
           nsel = c.k;
-          last_d2 = ks.worst_d;
+          last_d2 = knn_d2[(size_t)(c.k - 1) * cap + i];
         }
       }
 
@@ -466,11 +570,11 @@ __global__ __launch_bounds__(kMatchBlock) void k_match(const float4* __restrict_
         double A[9];
         if (TYPE == LSA_EDGE)
         {
-          const double n[3] = {e2.x, e2.y, e2.z};
+          const double nn[3] = {e2.x, e2.y, e2.z};
 #pragma unroll
           for (int a = 0; a < 3; ++a)
 #pragma unroll
-            for (int b = 0; b < 3; ++b) A[a * 3 + b] = (a == b ? 1. : 0.) - n[a] * n[b];
+            for (int b = 0; b < 3; ++b) A[a * 3 + b] = (a == b ? 1. : 0.) - nn[a] * nn[b];
           if (!isfinite(A[0])) st = LSA_MATCH_INVALID_NUMERICAL;
           else
           {
@@ -484,11 +588,11 @@ __global__ __launch_bounds__(kMatchBlock) void k_match(const float4* __restrict_
           if (l1 / l2 < c.planarity) st = LSA_MATCH_BAD_PCA_STRUCTURE;
           else
           {
-            const double n[3] = {e0.x, e0.y, e0.z};
+            const double nn[3] = {e0.x, e0.y, e0.z};
 #pragma unroll
             for (int a = 0; a < 3; ++a)
 #pragma unroll
-              for (int b = 0; b < 3; ++b) A[a * 3 + b] = n[a] * n[b];
+              for (int b = 0; b < 3; ++b) A[a * 3 + b] = nn[a] * nn[b];
             if (!isfinite(A[0])) st = LSA_MATCH_INVALID_NUMERICAL;
             else
             {
@@ -650,29 +754,44 @@ int build_grid(lsa_ctx* ctx, int type)
   const int m = t.m;
   const int init[8] = {0x7fffffff, 0x7fffffff, 0x7fffffff, (int)0x80000000, (int)0x80000000, (int)0x80000000, 0, 0};
   LSA_HIP(ctx, hipMemcpyAsync(t.bbox_bits, init, sizeof(init), hipMemcpyHostToDevice, st));
-  ProfScope ps(ctx, "target_grid_build", (double)m * (32 + 16 + 16 + 4 + 4 + 16 + 16));
+  ProfScope ps(ctx, "target_grid_build", (double)m * (32 + 16 + 2 * (16 + 4 + 4 + 16 + 16)));
   const int gb = (m + 255) / 256;
   hipLaunchKernelGGL(k_target_prep, dim3(gb), dim3(256), 0, st, reinterpret_cast<const float4*>(t.pts), m, t.xyzl, t.bbox_bits);
   hipLaunchKernelGGL(k_grid_setup, dim3(1), dim3(1), 0, st, t.bbox_bits, m, t.cell_hint, t.desc);
-  const int cb = (kCellCap + 1 + 255) / 256;
-  hipLaunchKernelGGL(k_grid_zero, dim3(cb), dim3(256), 0, st, t.desc, t.cell_start, t.cell_fill);
-  hipLaunchKernelGGL(k_grid_count, dim3(gb), dim3(256), 0, st, t.xyzl, m, t.desc, t.cell_of, t.cell_start);
-  const int sb = (kCellCap + 1 + 1023) / 1024;
-  hipLaunchKernelGGL(k_scan_block, dim3(sb), dim3(256), 0, st, t.desc, t.cell_start, t.block_sums);
-  hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, st, t.desc, t.block_sums);
-  hipLaunchKernelGGL(k_scan_add, dim3(sb), dim3(256), 0, st, t.desc, t.cell_start, t.block_sums);
-  hipLaunchKernelGGL(k_grid_scatter, dim3(gb), dim3(256), 0, st, t.xyzl, m, t.cell_of, t.cell_start, t.cell_fill, t.sorted);
+  for (int l = 0; l < 2; ++l)
+  {
+    GridLevel& g = t.lv[l];
+    const GridDesc* d = t.desc + l;
+    const int cb = (g.max_cells + 1 + 255) / 256;
+    hipLaunchKernelGGL(k_grid_zero, dim3(cb), dim3(256), 0, st, d, g.cell_start, g.cell_fill);
+    hipLaunchKernelGGL(k_grid_count, dim3(gb), dim3(256), 0, st, t.xyzl, m, d, g.cell_of, g.cell_start);
+    const int sb = (g.max_cells + 1 + 1023) / 1024;
+    hipLaunchKernelGGL(k_scan_block, dim3(sb), dim3(256), 0, st, d, g.cell_start, g.block_sums);
+    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, st, d, g.block_sums);
+    hipLaunchKernelGGL(k_scan_add, dim3(sb), dim3(256), 0, st, d, g.cell_start, g.block_sums);
+    hipLaunchKernelGGL(k_grid_scatter, dim3(gb), dim3(256), 0, st, t.xyzl, m, g.cell_of, g.cell_start, g.cell_fill, g.sorted);
+  }
   return LSA_OK;
 }
 
-template <int KMAX, int TYPE>
-void launch_match(lsa_ctx* ctx, const lsa_point_t* q, int nq, const MatchConst& mc, int type)
+template <int KMAX>
+void launch_knn(lsa_ctx* ctx, const lsa_point_t* q, int nq, const Rigid& pose, int k, int type)
 {
   Target& t = ctx->target[type];
   MatchBuf& mb = ctx->match[type];
-  hipLaunchKernelGGL((k_match<KMAX, TYPE>), dim3((nq + kMatchBlock - 1) / kMatchBlock), dim3(kMatchBlock), 0, ctx->stream,
-                     reinterpret_cast<const float4*>(q), nq, mc, t.desc, t.cell_start, t.sorted, t.xyzl, mb.rec, mb.status, mb.cap,
-                     ctx->hist_dev);
+  const int threads = nq * kGroup;
+  hipLaunchKernelGGL((k_knn<KMAX>), dim3((threads + 255) / 256), dim3(256), 0, ctx->stream, reinterpret_cast<const float4*>(q), nq, pose, k, t.desc,
+                     t.lv[0].cell_start, t.lv[0].sorted, t.lv[1].cell_start, t.lv[1].sorted, mb.knn_idx, mb.knn_d2, mb.knn_cnt, mb.cap,
+                     ctx->hist_dev + LSA_MATCH_NSTATUS);
+}
+
+template <int KMAX, int TYPE>
+void launch_model(lsa_ctx* ctx, const lsa_point_t* q, int nq, const MatchConst& mc, int type)
+{
+  Target& t = ctx->target[type];
+  MatchBuf& mb = ctx->match[type];
+  hipLaunchKernelGGL((k_model<KMAX, TYPE>), dim3((nq + kModelBlock - 1) / kModelBlock), dim3(kModelBlock), 0, ctx->stream,
+                     reinterpret_cast<const float4*>(q), nq, mc, mb.knn_idx, mb.knn_d2, mb.knn_cnt, t.xyzl, mb.rec, mb.status, mb.cap, ctx->hist_dev);
 }
 
 }  // namespace
@@ -745,7 +864,8 @@ int lsa_match(lsa_ctx* ctx, int type, int query_set, const lsa_match_params_t* p
     return LSA_OK;
   }
   MatchConst mc;
-  row_major_to_rt(pose, mc.pose.R, mc.pose.t);
+  Rigid rp;
+  row_major_to_rt(pose, rp.R, rp.t);
   mc.type = type;
   mc.single_edge_per_ring = p->single_edge_per_ring;
   mc.min_neighbors = p->edge_min_nb_neighbors;
@@ -776,23 +896,29 @@ int lsa_match(lsa_ctx* ctx, int type, int query_set, const lsa_match_params_t* p
   if (mc.k < 1) mc.k = 1;
   LSA_HIP(ctx, hipMemsetAsync(ctx->hist_dev, 0, 16 * sizeof(int), st));
   const lsa_point_t* q = ctx->kp[query_set][type];
+  if (!mc.bad_param)
   {
-    ProfScope ps(ctx, type == LSA_EDGE ? "match_edge" : type == LSA_PLANE ? "match_plane" : "match_blob",
-                 (double)nq * (32 + mc.k * 32 + 136));
+    ProfScope ps(ctx, type == LSA_EDGE ? "knn_edge" : type == LSA_PLANE ? "knn_plane" : "knn_blob", (double)nq * (32 + mc.k * 16 + mc.k * 8));
+    if (mc.k <= 8) launch_knn<8>(ctx, q, nq, rp, mc.k, type);
+    else launch_knn<16>(ctx, q, nq, rp, mc.k, type);
+  }
+  {
+    ProfScope ps(ctx, type == LSA_EDGE ? "model_edge" : type == LSA_PLANE ? "model_plane" : "model_blob",
+                 (double)nq * (32 + mc.k * 8 + mc.k * 16 + 136));
     if (type == LSA_EDGE)
     {
-      if (mc.k <= 8) launch_match<8, LSA_EDGE>(ctx, q, nq, mc, type);
-      else launch_match<16, LSA_EDGE>(ctx, q, nq, mc, type);
+      if (mc.k <= 8) launch_model<8, LSA_EDGE>(ctx, q, nq, mc, type);
+      else launch_model<16, LSA_EDGE>(ctx, q, nq, mc, type);
     }
     else if (type == LSA_PLANE)
     {
-      if (mc.k <= 8) launch_match<8, LSA_PLANE>(ctx, q, nq, mc, type);
-      else launch_match<16, LSA_PLANE>(ctx, q, nq, mc, type);
+      if (mc.k <= 8) launch_model<8, LSA_PLANE>(ctx, q, nq, mc, type);
+      else launch_model<16, LSA_PLANE>(ctx, q, nq, mc, type);
     }
     else
     {
-      if (mc.k <= 8) launch_match<8, LSA_BLOB>(ctx, q, nq, mc, type);
-      else launch_match<16, LSA_BLOB>(ctx, q, nq, mc, type);
+      if (mc.k <= 8) launch_model<8, LSA_BLOB>(ctx, q, nq, mc, type);
+      else launch_model<16, LSA_BLOB>(ctx, q, nq, mc, type);
     }
   }
   if (histogram)

@@ -54,6 +54,7 @@ def main():
     import torch.distributed as dist
 
     import lidarslam_amd as L
+    from lidarslam_amd.replay import PoseExchange, sequence_seed
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the product path has no CPU fallback")
@@ -66,7 +67,7 @@ def main():
     # ---- inputs: one independent sequence per rank, generated on the host, made resident in HBM
     total = args.warmup + args.steps
     slam = L.Slam(local_rank, EgoMotion=3)  # MOTION_EXTRAPOLATION_AND_REGISTRATION: the default mode skips the ego-motion ICP
-    seed = 1000 + rank
+    seed = sequence_seed(rank)
     stamps, npts = [], 0
     for f in range(total):
         pts, stamp = L.synth_frame(args.model, seed, f)
@@ -75,24 +76,12 @@ def main():
         npts += pts.size
     ctx = slam.context()
 
-    pose_buf = torch.zeros(17, dtype=torch.float64, device="cuda")
-    pose_all = torch.zeros(17 * world, dtype=torch.float64, device="cuda")
-    pose_host = torch.zeros(17, dtype=torch.float64).pin_memory()
-    side = torch.cuda.Stream()
-
-    def exchange(stamp):
-        # RCCL pose broadcast of the north star: every rank ends up with every sequence's pose table
-        if not distributed:
-            return None
-        pose_host[:16] = torch.from_numpy(slam.world_transform().reshape(16))
-        pose_host[16] = stamp * 1e-6
-        with torch.cuda.stream(side):
-            pose_buf.copy_(pose_host, non_blocking=True)
-            return dist.all_gather_into_tensor(pose_all, pose_buf, async_op=True)
+    # RCCL pose broadcast of the north star: every rank ends up with every sequence's pose table
+    exchange = PoseExchange(world, device="cuda")
 
     def step(f):
         slam.add_stored_frame(f, stamps[f], f)
-        return exchange(stamps[f])
+        return exchange.post(slam.world_transform(), stamps[f] * 1e-6) if distributed else None
 
     for f in range(args.warmup):
         h = step(f)
@@ -198,7 +187,8 @@ def cpu_baseline(args, seed):
 
     import lidarslam_amd as L
 
-    threads = args.cpu_threads or len(os.sched_getaffinity(0))
+    # the GPU box gives one GPU job a share of 16 host cores, whatever the affinity mask says
+    threads = args.cpu_threads or min(16, len(os.sched_getaffinity(0)))
     s = O.Slam(EgoMotion=3, NbThreads=threads)
     times = []
     skip = 2  # the first frames build the map from nothing and are not representative

@@ -160,17 +160,24 @@ int lsa_transform_keypoints(lsa_ctx* ctx, int set, int type, const double T[16],
  * -- slam_lib/src/KeypointsMatcher.cxx:33-74; the kd-tree build it replaces is
  *    KDTreePCLAdaptor::Reset, slam_lib/include/LidarSlam/KDTreePCLAdaptor.h:57-65. */
 
+/* The reference keeps two independent families of kd-trees alive at the same time: the sub-map
+ * trees of the rolling grids (rebuilt only on keyframes, RollingGrid.cxx:441) and the trees on the
+ * previous scan's keypoints that ComputeEgoMotion builds every frame (Slam.cxx:845-860).  A target
+ * therefore lives in a slot: */
+#define LSA_TARGET_MAP 0       /* RollingGrid::GetSubMapKdTree() */
+#define LSA_TARGET_PREVIOUS 1  /* kdtreePrevious of Slam::ComputeEgoMotion */
+
 /* Sets the kNN target of one keypoint type from host points (the sub-map the
  * host-side RollingGrid produced, Slam.cxx:1003-1037) and builds the device
  * search grid.  Point order is kept: indices seen by the PCA are these. */
-int lsa_set_target(lsa_ctx* ctx, int type, const lsa_point_t* pts, int m);
+int lsa_set_target(lsa_ctx* ctx, int slot, int type, const lsa_point_t* pts, int m);
 /* Same, from a device-resident keypoint set (ego-motion registers on the
  * previous frame's raw keypoints, Slam.cxx:845-860): no PCIe traffic. */
-int lsa_set_target_from_set(lsa_ctx* ctx, int type, int set);
-int lsa_target_size(const lsa_ctx* ctx, int type);
+int lsa_set_target_from_set(lsa_ctx* ctx, int slot, int type, int set);
+int lsa_target_size(const lsa_ctx* ctx, int slot, int type);
 /* Edge length [m] of the search-grid cells used by the next lsa_set_target* of this type
  * (default 1.0; it is enlarged automatically when the grid would exceed 2^21 cells). */
-int lsa_set_target_cell_size(lsa_ctx* ctx, int type, float cell);
+int lsa_set_target_cell_size(lsa_ctx* ctx, int slot, int type, float cell);
 /* Diagnostics: queries of the last lsa_match that needed the exhaustive fall-back. */
 int lsa_match_slow_queries(lsa_ctx* ctx);
 
@@ -183,7 +190,7 @@ int lsa_set_keypoints(lsa_ctx* ctx, int set, int type, const lsa_point_t* pts, i
  * record (A, P, X, weight).  Records stay on the device for lsa_accumulate.
  * pose = PosePrior, row-major 4x4.  histogram[s] = number of keypoints with
  * MatchStatus s (MatchingResults::RejectionsHistogram). */
-int lsa_match(lsa_ctx* ctx, int type, int query_set, const lsa_match_params_t* params, const double pose[16],
+int lsa_match(lsa_ctx* ctx, int slot, int type, int query_set, const lsa_match_params_t* params, const double pose[16],
               int histogram[LSA_MATCH_NSTATUS]);
 
 /* MatchingResults::Rejections / Weights of the last lsa_match of `type`
@@ -204,6 +211,18 @@ int lsa_download_match(lsa_ctx* ctx, int type, uint8_t* status, double* weights,
  * 6x6 solve); see lidarslam_amd/csrc/host/lsa_lm.cpp. */
 int lsa_accumulate(lsa_ctx* ctx, unsigned type_mask, const double w[6], int want_jacobian, double* cost, double g[6],
                    double H[36], int* n_valid);
+
+/* LocalOptimizer::SetPosePrior + Solve + GetOptimizedPose (LocalOptimizer.cxx:44-48, 74-109) on the
+ * device-resident residual blocks of type_mask: the Ceres trust-region Levenberg-Marquardt loop
+ * (DENSE_QR, max_num_iterations = lm_max_iter, TwoDMode holds Z, rX, rY) with every evaluation on
+ * the GPU.  summary[0] = num_successful_steps (counts iteration 0, as ceres::Solver::Summary does:
+ * == 1 means no step was accepted, Slam.cxx:950), [1] unsuccessful steps, [2] iterations,
+ * [3] evaluations; costs[0] initial, [1] final. */
+int lsa_solve(lsa_ctx* ctx, unsigned type_mask, const double prior[16], int lm_max_iter, int two_d_mode, double optimized[16],
+              int summary[4], double costs[2]);
+/* LocalOptimizer::EstimateRegistrationError (LocalOptimizer.cxx:112-140) at `pose`: covariance
+ * (row-major 6x6, DoF order X,Y,Z,rX,rY,rZ), err[0] position error [m], err[1] orientation error [deg]. */
+int lsa_registration_error(lsa_ctx* ctx, unsigned type_mask, const double pose[16], int two_d_mode, double cov[36], double err[2]);
 
 /* ------------------------------------------------------------------------- */
 /* Seam 4: undistortion / transforms.                                         */
@@ -234,6 +253,11 @@ int lsa_download_transformed(lsa_ctx* ctx, int set, int type, const double pose[
  * (t1); else rigid H0. */
 int lsa_transform_frame(lsa_ctx* ctx, int interpolate, const double H0[16], const double H1[16], double t0, double t1,
                         lsa_point_t* out, int capacity);
+
+/* Device self-test of the arithmetic the bit-exact parity rests on: evaluates fn on the GPU for n
+ * inputs.  fn: 0 lsa_sin(x) 1 lsa_cos(x) 2 lsa_atan2(y, x) 3 (float)sqrt((float)x)
+ * 4 (float)x / (float)y  5 sqrt(x)  6 x / y.  Results as doubles. */
+int lsa_selftest_math(lsa_ctx* ctx, int fn, const double* x, const double* y, int n, double* out);
 
 /* ------------------------------------------------------------------------- */
 /* Per-kernel timing of the last call sequence (HIP events on the context's   */

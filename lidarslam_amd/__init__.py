@@ -36,6 +36,8 @@ from ._native import (  # noqa: F401
 
 __all__ = ["Context", "Slam", "ExtractParams", "MatchParams", "POINT_DTYPE", "lib", "LsaError"]
 
+TARGET_MAP, TARGET_PREVIOUS = 0, 1
+
 DEBUG_NAMES = [
     "sin_angle", "saliency", "depth_gap", "intensity_gap", "edge_keypoint", "plane_keypoint", "blob_keypoint",
     "edge_validity", "plane_validity", "blob_validity",
@@ -48,7 +50,7 @@ ABI_SYMBOLS = [
     "lsa_set_azimuthal_resolution", "lsa_extract_keypoints", "lsa_download_keypoints", "lsa_keypoint_count",
     "lsa_download_debug", "lsa_nb_laser_rings", "lsa_transform_keypoints", "lsa_set_target", "lsa_set_target_from_set",
     "lsa_target_size", "lsa_set_target_cell_size", "lsa_match_slow_queries", "lsa_set_keypoints", "lsa_match",
-    "lsa_download_match", "lsa_accumulate", "lsa_reset_working_keypoints", "lsa_undistort", "lsa_working_time_range",
+    "lsa_download_match", "lsa_accumulate", "lsa_solve", "lsa_registration_error", "lsa_selftest_math", "lsa_reset_working_keypoints", "lsa_undistort", "lsa_working_time_range",
     "lsa_working_bbox", "lsa_download_transformed", "lsa_transform_frame", "lsa_profile_enable", "lsa_profile_reset",
     "lsa_profile_get", "lsa_slam_create", "lsa_slam_destroy", "lsa_slam_last_error", "lsa_slam_set_param",
     "lsa_slam_get_param", "lsa_slam_reset", "lsa_slam_add_frame", "lsa_slam_store_frame", "lsa_slam_add_stored_frame",
@@ -92,15 +94,18 @@ def lib():
     L.lsa_download_debug.argtypes = [vp, i32, vp, i32]
     L.lsa_nb_laser_rings.argtypes = [vp]
     L.lsa_transform_keypoints.argtypes = [vp, i32, i32, vp, f64]
-    L.lsa_set_target.argtypes = [vp, i32, vp, i32]
-    L.lsa_set_target_from_set.argtypes = [vp, i32, i32]
-    L.lsa_target_size.argtypes = [vp, i32]
-    L.lsa_set_target_cell_size.argtypes = [vp, i32, C.c_float]
+    L.lsa_set_target.argtypes = [vp, i32, i32, vp, i32]
+    L.lsa_set_target_from_set.argtypes = [vp, i32, i32, i32]
+    L.lsa_target_size.argtypes = [vp, i32, i32]
+    L.lsa_set_target_cell_size.argtypes = [vp, i32, i32, C.c_float]
     L.lsa_match_slow_queries.argtypes = [vp]
     L.lsa_set_keypoints.argtypes = [vp, i32, i32, vp, i32]
-    L.lsa_match.argtypes = [vp, i32, i32, C.POINTER(MatchParams), vp, vp]
+    L.lsa_match.argtypes = [vp, i32, i32, i32, C.POINTER(MatchParams), vp, vp]
     L.lsa_download_match.argtypes = [vp, i32, vp, vp, vp, i32]
     L.lsa_accumulate.argtypes = [vp, C.c_uint, vp, i32, vp, vp, vp, vp]
+    L.lsa_solve.argtypes = [vp, C.c_uint, vp, i32, i32, vp, vp, vp]
+    L.lsa_registration_error.argtypes = [vp, C.c_uint, vp, i32, vp, vp]
+    L.lsa_selftest_math.argtypes = [vp, i32, vp, vp, i32, vp]
     L.lsa_reset_working_keypoints.argtypes = [vp]
     L.lsa_undistort.argtypes = [vp, vp, vp, f64, f64]
     L.lsa_working_time_range.argtypes = [vp, vp, vp]
@@ -219,20 +224,20 @@ class Context:
         self._check(self.L.lsa_transform_keypoints(self.h, kset, ktype, ptr(pose16(T)), time_offset), "lsa_transform_keypoints")
 
     # ---- matching
-    def set_target(self, ktype, pts, cell=None):
+    def set_target(self, ktype, pts, cell=None, slot=TARGET_MAP):
         pts = np.ascontiguousarray(pts)
         if cell is not None:
-            self.L.lsa_set_target_cell_size(self.h, ktype, cell)
-        self._check(self.L.lsa_set_target(self.h, ktype, ptr(pts) if pts.size else None, pts.size), "lsa_set_target")
+            self.L.lsa_set_target_cell_size(self.h, slot, ktype, cell)
+        self._check(self.L.lsa_set_target(self.h, slot, ktype, ptr(pts) if pts.size else None, pts.size), "lsa_set_target")
 
-    def set_target_from_set(self, ktype, kset, cell=None):
+    def set_target_from_set(self, ktype, kset, cell=None, slot=TARGET_PREVIOUS):
         if cell is not None:
-            self.L.lsa_set_target_cell_size(self.h, ktype, cell)
-        self._check(self.L.lsa_set_target_from_set(self.h, ktype, kset), "lsa_set_target_from_set")
+            self.L.lsa_set_target_cell_size(self.h, slot, ktype, cell)
+        self._check(self.L.lsa_set_target_from_set(self.h, slot, ktype, kset), "lsa_set_target_from_set")
 
-    def match(self, ktype, query_set, params, pose):
+    def match(self, ktype, query_set, params, pose, slot=TARGET_MAP):
         hist = np.zeros(MATCH_NSTATUS, np.int32)
-        self._check(self.L.lsa_match(self.h, ktype, query_set, C.byref(params), ptr(pose16(pose)), ptr(hist)), "lsa_match")
+        self._check(self.L.lsa_match(self.h, slot, ktype, query_set, C.byref(params), ptr(pose16(pose)), ptr(hist)), "lsa_match")
         return hist
 
     def match_results(self, ktype, query_set=None, records=True):
@@ -257,6 +262,27 @@ class Context:
         H = np.zeros((6, 6))
         self._check(self.L.lsa_accumulate(self.h, type_mask, ptr(w), int(jac), C.byref(cost), ptr(g), ptr(H), C.byref(nv)), "lsa_accumulate")
         return cost.value, g, H, nv.value
+
+    def solve(self, type_mask, prior, max_iter=15, two_d=False):
+        """LocalOptimizer::Solve on the device residuals: (pose 4x4, summary[4], costs[2])."""
+        out = np.zeros(16)
+        summ = np.zeros(4, np.int32)
+        costs = np.zeros(2)
+        self._check(self.L.lsa_solve(self.h, type_mask, ptr(pose16(prior)), max_iter, int(two_d), ptr(out), ptr(summ), ptr(costs)), "lsa_solve")
+        return out.reshape(4, 4), summ, costs
+
+    def registration_error(self, type_mask, pose, two_d=False):
+        cov = np.zeros((6, 6))
+        err = np.zeros(2)
+        self._check(self.L.lsa_registration_error(self.h, type_mask, ptr(pose16(pose)), int(two_d), ptr(cov), ptr(err)), "lsa_registration_error")
+        return cov, err
+
+    def selftest_math(self, fn, x, y=None):
+        x = np.ascontiguousarray(x, np.float64)
+        y = np.ascontiguousarray(x if y is None else y, np.float64)
+        out = np.zeros_like(x)
+        self._check(self.L.lsa_selftest_math(self.h, fn, ptr(x), ptr(y), x.size, ptr(out)), "lsa_selftest_math")
+        return out
 
     # ---- undistortion / transforms
     def reset_working_keypoints(self):

@@ -80,12 +80,12 @@ class MatchParams(C.Structure):
     @classmethod
     def ego_motion(cls, **kw):
         """Slam::ComputeEgoMotion's matcher setup (Slam.cxx:877-886, Slam.h:612-628)."""
-        return cls(single_edge_per_ring=1, edge_nb_neighbors=8, edge_min_nb_neighbors=3, **kw)
+        return cls(**{**dict(single_edge_per_ring=1, edge_nb_neighbors=8, edge_min_nb_neighbors=3), **kw})
 
     @classmethod
     def localization(cls, **kw):
         """Slam::Localization's matcher setup (Slam.cxx:1055-1065)."""
-        return cls(single_edge_per_ring=0, edge_nb_neighbors=10, edge_min_nb_neighbors=4, **kw)
+        return cls(**{**dict(single_edge_per_ring=0, edge_nb_neighbors=10, edge_min_nb_neighbors=4), **kw})
 
 
 class KernelStat(C.Structure):

@@ -199,8 +199,12 @@ int LocalOptimizer::Solve(SolveSummary& sum)
       delta_norm += e * e;
     }
     delta_norm = std::sqrt(delta_norm);
+    // Ceres evaluates the cost only here and, if the step is accepted, residuals + Jacobian again at
+    // the same point.  On the device the Jacobian costs nothing extra (the kernel is bound by the
+    // record reads), so it is evaluated speculatively and reused on acceptance: one launch + one
+    // read-back per LM iteration instead of two, same arithmetic.
     Eval cc;
-    rc = evaluate(cand, false, cc);
+    rc = evaluate(cand, true, cc);
     if (rc) return rc;
 
     // parameter / function tolerance terminate WITHOUT taking the candidate step
@@ -213,10 +217,7 @@ int LocalOptimizer::Solve(SolveSummary& sum)
     {
       std::memcpy(x, cand, sizeof(x));
       x_norm = xnorm(x);
-      Eval next;
-      rc = evaluate(x, true, next);
-      if (rc) return rc;
-      cur = next;
+      cur = cc;  // gradient and J^T J at the accepted point were evaluated speculatively above
       ++sum.num_successful_steps;
       const double t = 2.0 * relative_decrease - 1.0;
       radius = std::min(max_radius, radius / std::max(1.0 / 3.0, 1.0 - t * t * t));

@@ -218,7 +218,7 @@ int SlamCore::ComputeEgoMotion()
     return LSA_OK;
 
   // kd-trees on the previous frame's raw keypoints -> device search grids, no PCIe traffic
-  for (int k : {LSA_EDGE, LSA_PLANE}) LSA_TRY(lsa_set_target_from_set(Ctx, k, LSA_SET_RAW_PREVIOUS));
+  for (int k : {LSA_EDGE, LSA_PLANE}) LSA_TRY(lsa_set_target_from_set(Ctx, LSA_TARGET_PREVIOUS, k, LSA_SET_RAW_PREVIOUS));
   TotalMatchedKeypoints = 0;
   lsa_match_params_t mp = EgoMatchParams();
 
@@ -231,7 +231,7 @@ int SlamCore::ComputeEgoMotion()
     for (int k : {LSA_EDGE, LSA_PLANE})
     {
       int hist[LSA_MATCH_NSTATUS];
-      LSA_TRY(lsa_match(Ctx, k, LSA_SET_RAW_CURRENT, &mp, Trelative.m, hist));
+      LSA_TRY(lsa_match(Ctx, LSA_TARGET_PREVIOUS, k, LSA_SET_RAW_CURRENT, &mp, Trelative.m, hist));
       TotalMatchedKeypoints += hist[LSA_MATCH_SUCCESS];
     }
     Stats.ego_icp += ticp.Stop();
@@ -295,8 +295,8 @@ int SlamCore::Localization()
       }
       const auto& sub = LocalMaps[k]->GetSubMap();
       // kNN grid cell ~ twice the map leaf size: ~1 map point per leaf on a surface
-      lsa_set_target_cell_size(Ctx, k, static_cast<float>(std::max(0.5, 2.0 * LocalMaps[k]->GetLeafSize())));
-      LSA_TRY(lsa_set_target(Ctx, k, sub.data(), static_cast<int>(sub.size())));
+      lsa_set_target_cell_size(Ctx, LSA_TARGET_MAP, k, static_cast<float>(std::max(0.5, 2.0 * LocalMaps[k]->GetLeafSize())));
+      LSA_TRY(lsa_set_target(Ctx, LSA_TARGET_MAP, k, sub.data(), static_cast<int>(sub.size())));
     }
     Stats.submap += t.Stop();
   }
@@ -312,7 +312,7 @@ int SlamCore::Localization()
     for (int k = 0; k < 3; ++k)
     {
       int hist[LSA_MATCH_NSTATUS];
-      LSA_TRY(lsa_match(Ctx, k, LSA_SET_WORKING, &mp, Tworld.m, hist));
+      LSA_TRY(lsa_match(Ctx, LSA_TARGET_MAP, k, LSA_SET_WORKING, &mp, Tworld.m, hist));
       TotalMatchedKeypoints += hist[LSA_MATCH_SUCCESS];
     }
     Stats.loc_icp += ticp.Stop();

@@ -127,7 +127,7 @@ struct lsa_ctx
   lsa_point_t* kp[3][3] = {};
   int kp_n[3][3] = {};
 
-  lsa::Target target[3];
+  lsa::Target target[6];  // [slot * 3 + type]: slot 0 = map sub-maps (localization), slot 1 = previous scan (ego-motion)
   lsa::MatchBuf match[3];
 
   double* partials = nullptr;  // [kAccumBlocks][kAccumVals]
@@ -162,7 +162,7 @@ namespace lsa
   } while (0)
 
 int ensure_capacity(lsa_ctx* ctx, int n);
-int ensure_target(lsa_ctx* ctx, int type, int m);
+int ensure_target(lsa_ctx* ctx, int ti, int m);
 int ensure_match(lsa_ctx* ctx, int type, int k);
 int ensure_scratch(lsa_ctx* ctx, size_t bytes);
 

@@ -46,9 +46,9 @@ int ensure_capacity(lsa_ctx* ctx, int n)
   return LSA_OK;
 }
 
-int ensure_target(lsa_ctx* ctx, int type, int m)
+int ensure_target(lsa_ctx* ctx, int ti, int m)
 {
-  Target& t = ctx->target[type];
+  Target& t = ctx->target[ti];
   if (!t.desc)
   {
     for (int l = 0; l < 2; ++l)
@@ -243,11 +243,14 @@ void lsa_ctx_destroy(lsa_ctx* ctx)
   for (int i = 0; i < 4; ++i) fr(ctx->score[i]);
   fr(ctx->valid); fr(ctx->label); fr(ctx->ring_counts); fr(ctx->kp_count_dev);
   for (int s = 0; s < 3; ++s) for (int k = 0; k < 3; ++k) fr(ctx->kp[s][k]);
-  for (int k = 0; k < 3; ++k)
+  for (int k = 0; k < 6; ++k)
   {
     Target& t = ctx->target[k];
     fr(t.pts); fr(t.xyzl); fr(t.desc); fr(t.bbox_bits);
     for (int l = 0; l < 2; ++l) { fr(t.lv[l].sorted); fr(t.lv[l].cell_of); fr(t.lv[l].cell_start); fr(t.lv[l].cell_fill); fr(t.lv[l].block_sums); }
+  }
+  for (int k = 0; k < 3; ++k)
+  {
     fr(ctx->match[k].rec); fr(ctx->match[k].status); fr(ctx->match[k].knn_idx); fr(ctx->match[k].knn_d2); fr(ctx->match[k].knn_cnt);
   }
   fr(ctx->partials); fr(ctx->reduce_out); fr(ctx->hist_dev); fr(ctx->scratch_out); fr(ctx->range_bits);

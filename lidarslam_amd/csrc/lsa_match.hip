@@ -747,9 +747,9 @@ __global__ void k_records_to_aos(const double* __restrict__ rec, const uint8_t* 
   weights[i] = ok ? rec[(size_t)15 * cap + i] : 0.;
 }
 
-int build_grid(lsa_ctx* ctx, int type)
+int build_grid(lsa_ctx* ctx, int ti)
 {
-  Target& t = ctx->target[type];
+  Target& t = ctx->target[ti];
   hipStream_t st = ctx->stream;
   const int m = t.m;
   const int init[8] = {0x7fffffff, 0x7fffffff, 0x7fffffff, (int)0x80000000, (int)0x80000000, (int)0x80000000, 0, 0};
@@ -775,9 +775,9 @@ int build_grid(lsa_ctx* ctx, int type)
 }
 
 template <int KMAX>
-void launch_knn(lsa_ctx* ctx, const lsa_point_t* q, int nq, const Rigid& pose, int k, int type)
+void launch_knn(lsa_ctx* ctx, const lsa_point_t* q, int nq, const Rigid& pose, int k, int type, int ti)
 {
-  Target& t = ctx->target[type];
+  Target& t = ctx->target[ti];
   MatchBuf& mb = ctx->match[type];
   const int threads = nq * kGroup;
   hipLaunchKernelGGL((k_knn<KMAX>), dim3((threads + 255) / 256), dim3(256), 0, ctx->stream, reinterpret_cast<const float4*>(q), nq, pose, k, t.desc,
@@ -786,9 +786,9 @@ void launch_knn(lsa_ctx* ctx, const lsa_point_t* q, int nq, const Rigid& pose, i
 }
 
 template <int KMAX, int TYPE>
-void launch_model(lsa_ctx* ctx, const lsa_point_t* q, int nq, const MatchConst& mc, int type)
+void launch_model(lsa_ctx* ctx, const lsa_point_t* q, int nq, const MatchConst& mc, int type, int ti)
 {
-  Target& t = ctx->target[type];
+  Target& t = ctx->target[ti];
   MatchBuf& mb = ctx->match[type];
   hipLaunchKernelGGL((k_model<KMAX, TYPE>), dim3((nq + kModelBlock - 1) / kModelBlock), dim3(kModelBlock), 0, ctx->stream,
                      reinterpret_cast<const float4*>(q), nq, mc, mb.knn_idx, mb.knn_d2, mb.knn_cnt, t.xyzl, mb.rec, mb.status, mb.cap, ctx->hist_dev);
@@ -798,51 +798,53 @@ void launch_model(lsa_ctx* ctx, const lsa_point_t* q, int nq, const MatchConst& 
 
 extern "C" {
 
-int lsa_set_target(lsa_ctx* ctx, int type, const lsa_point_t* pts, int m)
+int lsa_set_target(lsa_ctx* ctx, int slot, int type, const lsa_point_t* pts, int m)
 {
-  if (!ctx || type < 0 || type > 2 || m < 0 || (!pts && m > 0)) return ctx ? ctx->fail(LSA_E_ARG, "lsa_set_target: bad argument") : LSA_E_ARG;
+  if (!ctx || slot < 0 || slot > 1 || type < 0 || type > 2 || m < 0 || (!pts && m > 0)) return ctx ? ctx->fail(LSA_E_ARG, "lsa_set_target: bad argument") : LSA_E_ARG;
   LSA_HIP(ctx, hipSetDevice(ctx->device));
-  int rc = ensure_target(ctx, type, m);
+  const int ti = slot * 3 + type;
+  int rc = ensure_target(ctx, ti, m);
   if (rc) return rc;
-  Target& t = ctx->target[type];
+  Target& t = ctx->target[ti];
   t.m = m;
   if (m == 0) return LSA_OK;
   {
     ProfScope ps(ctx, "target_upload_h2d", (double)m * 32);
     LSA_HIP(ctx, hipMemcpyAsync(t.pts, pts, (size_t)m * sizeof(lsa_point_t), hipMemcpyHostToDevice, ctx->stream));
   }
-  rc = build_grid(ctx, type);
+  rc = build_grid(ctx, ti);
   if (rc) return rc;
   LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the host buffer may be pageable and go away
   return LSA_OK;
 }
 
-int lsa_set_target_from_set(lsa_ctx* ctx, int type, int set)
+int lsa_set_target_from_set(lsa_ctx* ctx, int slot, int type, int set)
 {
-  if (!ctx || type < 0 || type > 2 || set < 0 || set > 2) return ctx ? ctx->fail(LSA_E_ARG, "lsa_set_target_from_set: bad argument") : LSA_E_ARG;
+  if (!ctx || slot < 0 || slot > 1 || type < 0 || type > 2 || set < 0 || set > 2) return ctx ? ctx->fail(LSA_E_ARG, "lsa_set_target_from_set: bad argument") : LSA_E_ARG;
   LSA_HIP(ctx, hipSetDevice(ctx->device));
   const int m = ctx->kp_n[set][type];
-  int rc = ensure_target(ctx, type, m);
+  const int ti = slot * 3 + type;
+  int rc = ensure_target(ctx, ti, m);
   if (rc) return rc;
-  Target& t = ctx->target[type];
+  Target& t = ctx->target[ti];
   t.m = m;
   if (m == 0) return LSA_OK;
   LSA_HIP(ctx, hipMemcpyAsync(t.pts, ctx->kp[set][type], (size_t)m * sizeof(lsa_point_t), hipMemcpyDeviceToDevice, ctx->stream));
-  return build_grid(ctx, type);
+  return build_grid(ctx, ti);
 }
 
-int lsa_target_size(const lsa_ctx* ctx, int type) { return (ctx && type >= 0 && type <= 2) ? ctx->target[type].m : LSA_E_ARG; }
+int lsa_target_size(const lsa_ctx* ctx, int slot, int type) { return (ctx && slot >= 0 && slot <= 1 && type >= 0 && type <= 2) ? ctx->target[slot * 3 + type].m : LSA_E_ARG; }
 
-int lsa_set_target_cell_size(lsa_ctx* ctx, int type, float cell)
+int lsa_set_target_cell_size(lsa_ctx* ctx, int slot, int type, float cell)
 {
-  if (!ctx || type < 0 || type > 2 || !(cell > 0.f)) return LSA_E_ARG;
-  ctx->target[type].cell_hint = cell;
+  if (!ctx || slot < 0 || slot > 1 || type < 0 || type > 2 || !(cell > 0.f)) return LSA_E_ARG;
+  ctx->target[slot * 3 + type].cell_hint = cell;
   return LSA_OK;
 }
 
-int lsa_match(lsa_ctx* ctx, int type, int query_set, const lsa_match_params_t* p, const double pose[16], int histogram[LSA_MATCH_NSTATUS])
+int lsa_match(lsa_ctx* ctx, int slot, int type, int query_set, const lsa_match_params_t* p, const double pose[16], int histogram[LSA_MATCH_NSTATUS])
 {
-  if (!ctx || !p || !pose || type < 0 || type > 2 || query_set < 0 || query_set > 2)
+  if (!ctx || !p || !pose || slot < 0 || slot > 1 || type < 0 || type > 2 || query_set < 0 || query_set > 2)
     return ctx ? ctx->fail(LSA_E_ARG, "lsa_match: bad argument") : LSA_E_ARG;
   LSA_HIP(ctx, hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
@@ -855,7 +857,8 @@ int lsa_match(lsa_ctx* ctx, int type, int query_set, const lsa_match_params_t* p
   mb.valid = true;
   if (histogram) std::memset(histogram, 0, LSA_MATCH_NSTATUS * sizeof(int));
   if (nq == 0) return LSA_OK;
-  Target& t = ctx->target[type];
+  const int ti = slot * 3 + type;
+  Target& t = ctx->target[ti];
   if (t.m == 0)
   {
     // empty target: MatchingResults::Reset leaves every keypoint UNKOWN and the histogram empty
@@ -899,26 +902,26 @@ int lsa_match(lsa_ctx* ctx, int type, int query_set, const lsa_match_params_t* p
   if (!mc.bad_param)
   {
     ProfScope ps(ctx, type == LSA_EDGE ? "knn_edge" : type == LSA_PLANE ? "knn_plane" : "knn_blob", (double)nq * (32 + mc.k * 16 + mc.k * 8));
-    if (mc.k <= 8) launch_knn<8>(ctx, q, nq, rp, mc.k, type);
-    else launch_knn<16>(ctx, q, nq, rp, mc.k, type);
+    if (mc.k <= 8) launch_knn<8>(ctx, q, nq, rp, mc.k, type, ti);
+    else launch_knn<16>(ctx, q, nq, rp, mc.k, type, ti);
   }
   {
     ProfScope ps(ctx, type == LSA_EDGE ? "model_edge" : type == LSA_PLANE ? "model_plane" : "model_blob",
                  (double)nq * (32 + mc.k * 8 + mc.k * 16 + 136));
     if (type == LSA_EDGE)
     {
-      if (mc.k <= 8) launch_model<8, LSA_EDGE>(ctx, q, nq, mc, type);
-      else launch_model<16, LSA_EDGE>(ctx, q, nq, mc, type);
+      if (mc.k <= 8) launch_model<8, LSA_EDGE>(ctx, q, nq, mc, type, ti);
+      else launch_model<16, LSA_EDGE>(ctx, q, nq, mc, type, ti);
     }
     else if (type == LSA_PLANE)
     {
-      if (mc.k <= 8) launch_model<8, LSA_PLANE>(ctx, q, nq, mc, type);
-      else launch_model<16, LSA_PLANE>(ctx, q, nq, mc, type);
+      if (mc.k <= 8) launch_model<8, LSA_PLANE>(ctx, q, nq, mc, type, ti);
+      else launch_model<16, LSA_PLANE>(ctx, q, nq, mc, type, ti);
     }
     else
     {
-      if (mc.k <= 8) launch_model<8, LSA_BLOB>(ctx, q, nq, mc, type);
-      else launch_model<16, LSA_BLOB>(ctx, q, nq, mc, type);
+      if (mc.k <= 8) launch_model<8, LSA_BLOB>(ctx, q, nq, mc, type, ti);
+      else launch_model<16, LSA_BLOB>(ctx, q, nq, mc, type, ti);
     }
   }
   if (histogram)

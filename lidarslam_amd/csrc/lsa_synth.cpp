@@ -135,6 +135,7 @@ extern "C" int lsa_synth_sensor(int model, int* nrings, int* ncols, double* el_m
 {
   switch (model)
   {
+    case 8: *nrings = 8; *ncols = 400; *el_min_deg = -16.0; *el_max_deg = 12.0; return 0;  // miniature sensor for fixtures
     case 16: *nrings = 16; *ncols = 1800; *el_min_deg = -15.0; *el_max_deg = 15.0; return 0;
     case 64: *nrings = 64; *ncols = 2048; *el_min_deg = -24.8; *el_max_deg = 2.0; return 0;
     case 128: *nrings = 128; *ncols = 2048; *el_min_deg = -25.0; *el_max_deg = 15.0; return 0;

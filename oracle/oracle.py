@@ -53,6 +53,7 @@ def lib():
         L.orc_accumulate.argtypes = [vp, vp, i32, f64, vp, i32, vp, vp, vp, vp]
         L.orc_lm_solve.argtypes = [vp, vp, i32, f64, vp, i32, i32, vp, vp, vp, vp]
         L.orc_covariance.argtypes = [vp, vp, i32, f64, vp, vp, vp]
+        L.orc_math.argtypes = [i32, vp, vp, i32, vp]
         L.orc_undistort.argtypes = [vp, i32, vp, vp, f64, f64]
         L.orc_transform.argtypes = [vp, i32, vp]
         L.orc_slam_create.restype = vp
@@ -174,6 +175,15 @@ def covariance(records, status, sat, pose):
     err = np.zeros(2)
     lib().orc_covariance(ptr(records), ptr(status), status.size, sat, ptr(pose16(pose)), ptr(cov), ptr(err))
     return cov, err
+
+
+def math(fn, x, y=None):
+    """Same function ids as lsa_selftest_math, evaluated on the host."""
+    x = np.ascontiguousarray(x, np.float64)
+    y = np.ascontiguousarray(x if y is None else y, np.float64)
+    out = np.zeros_like(x)
+    lib().orc_math(fn, ptr(x), ptr(y), x.size, ptr(out))
+    return out
 
 
 def undistort(pts, H0, H1, t0, t1):

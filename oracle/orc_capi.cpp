@@ -221,6 +221,26 @@ int orc_covariance(const double* records, const uint8_t* status, int n, double s
   return 0;
 }
 
+// ---- elementary functions (same ids as lsa_selftest_math) ----
+int orc_math(int fn, const double* x, const double* y, int n, double* out)
+{
+  for (int i = 0; i < n; ++i)
+  {
+    switch (fn)
+    {
+      case 0: out[i] = lsa_sin(x[i]); break;
+      case 1: out[i] = lsa_cos(x[i]); break;
+      case 2: out[i] = lsa_atan2(y[i], x[i]); break;
+      case 3: out[i] = (double)std::sqrt((float)x[i]); break;
+      case 4: out[i] = (double)((float)x[i] / (float)y[i]); break;
+      case 5: out[i] = std::sqrt(x[i]); break;
+      case 6: out[i] = x[i] / y[i]; break;
+      default: return -1;
+    }
+  }
+  return 0;
+}
+
 // ---- undistortion ------------------------------------------------------------------
 int orc_undistort(lsa_point_t* pts, int n, const double H0[16], const double H1[16], double t0, double t1)
 {

@@ -35,7 +35,7 @@ print("EXTRACT PARITY", ok)
 pose = np.eye(4); pose[0, 3] = 0.45
 for k, mp in ((0, MatchParams.ego_motion(saturation_distance=5.0)), (1, MatchParams.ego_motion(saturation_distance=5.0))):
     ctx.set_target_from_set(k, L.SET_RAW_PREVIOUS)
-    hist = ctx.match(k, L.SET_RAW_CURRENT, mp, pose)
+    hist = ctx.match(k, L.SET_RAW_CURRENT, mp, pose, slot=L.TARGET_PREVIOUS)
     st, w, rec = ctx.match_results(k, L.SET_RAW_CURRENT)
     cur, tgt = ctx.keypoints(L.SET_RAW_CURRENT, k), ctx.keypoints(L.SET_RAW_PREVIOUS, k)
     so, wo, ro, ho = O.match(cur, tgt, k, mp, pose)
@@ -45,7 +45,7 @@ for k, mp in ((0, MatchParams.ego_motion(saturation_distance=5.0)), (1, MatchPar
     ok &= np.array_equal(st, so) and np.array_equal(rec, ro)
 # localization style (ransac edges)
 for k, mp in ((0, MatchParams.localization(saturation_distance=2.0)),):
-    hist = ctx.match(k, L.SET_RAW_CURRENT, mp, pose)
+    hist = ctx.match(k, L.SET_RAW_CURRENT, mp, pose, slot=L.TARGET_PREVIOUS)
     st, w, rec = ctx.match_results(k, L.SET_RAW_CURRENT)
     cur, tgt = ctx.keypoints(L.SET_RAW_CURRENT, k), ctx.keypoints(L.SET_RAW_PREVIOUS, k)
     so, wo, ro, ho = O.match(cur, tgt, k, mp, pose)
@@ -54,7 +54,7 @@ for k, mp in ((0, MatchParams.localization(saturation_distance=2.0)),):
     ok &= np.array_equal(st, so) and np.array_equal(rec, ro)
 # accumulate: plane records
 mp = MatchParams.ego_motion(saturation_distance=5.0)
-ctx.match(0, L.SET_RAW_CURRENT, mp, pose); ctx.match(1, L.SET_RAW_CURRENT, mp, pose)
+ctx.match(0, L.SET_RAW_CURRENT, mp, pose, slot=L.TARGET_PREVIOUS); ctx.match(1, L.SET_RAW_CURRENT, mp, pose, slot=L.TARGET_PREVIOUS)
 w6 = np.array([0.45, 0.01, -0.02, 0.001, -0.002, 0.003])
 cg, gg, Hg, ng = ctx.accumulate(3, w6)
 tot = None

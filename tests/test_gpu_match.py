@@ -1,0 +1,205 @@
+"""GPU parity, seams 2 and 3: KeypointsMatcher::BuildMatchResiduals (exact kNN + model fit) and the
+LocalOptimizer evaluation / solve through the C ABI against the CPU oracle.
+Bar: match status, weights and residual records bit-exact (integer / decision work and the float and
+double arithmetic behind it); normal equations within 1e-12 relative (the GPU tree reduction sums in
+another order than the reference's sequential loop); solved poses within 1e-9 (north star: 1e-4)."""
+import numpy as np
+import pytest
+
+from conftest import bits, pose_diff
+
+pytestmark = pytest.mark.gpu
+
+
+def perturbed(dx=0.45, yaw=0.01, dz=0.0):
+    T = np.eye(4)
+    c, s = np.cos(yaw), np.sin(yaw)
+    T[:3, :3] = [[c, -s, 0], [s, c, 0], [0, 0, 1]]
+    T[:3, 3] = [dx, 0.02, dz]
+    return T
+
+
+def assert_match_equal(ctx, O, L, k, cur, tgt, mp, pose, cell=None):
+    ctx.set_keypoints(L.SET_WORKING, k, cur)
+    ctx.set_target(k, tgt, cell=cell)
+    hist = ctx.match(k, L.SET_WORKING, mp, pose)
+    st, w, rec = ctx.match_results(k, L.SET_WORKING)
+    so, wo, ro, ho = O.match(cur, tgt, k, mp, pose)
+    assert st.size == so.size == cur.size
+    bad = np.flatnonzero(st != so)
+    assert bad.size == 0, f"status differs at {bad[:8]}: gpu {st[bad[:8]]} oracle {so[bad[:8]]}"
+    assert hist.tolist() == ho.tolist()
+    assert np.array_equal(bits(w), bits(wo)), "weights"
+    assert np.array_equal(bits(rec), bits(ro)), f"records: max abs diff {np.abs(rec - ro).max()}"
+    return st
+
+
+@pytest.fixture(scope="module")
+def kps(O, L):
+    """keypoints of two consecutive scans per sensor model, extracted by the oracle"""
+    out = {}
+    for model in (8, 16, 128):
+        ex = O.Extractor()
+        per = []
+        for f in range(2):
+            pts, _ = L.synth_frame(model, 1000, f)
+            ex.compute(pts)
+            per.append([ex.keypoints(k) for k in range(3)])
+        out[model] = per
+    return out
+
+
+@pytest.mark.parametrize("model", [8, 16, 128])
+def test_ego_motion_matching_bit_exact(gpu_ctx, O, L, kps, model):
+    """per-ring edge neighbourhoods + plane fits, current scan on the previous scan (Slam.cxx:877-911)"""
+    prev, cur = kps[model]
+    mp = L.MatchParams.ego_motion(saturation_distance=5.0)
+    for k in (L.EDGE, L.PLANE):
+        st = assert_match_equal(gpu_ctx, O, L, k, cur[k], prev[k], mp, perturbed())
+        assert (st == 0).sum() > 20
+
+
+@pytest.mark.parametrize("model", [8, 16, 128])
+def test_localization_matching_bit_exact(gpu_ctx, O, L, kps, model):
+    """RANSAC line neighbourhoods, planes and blobs (Slam.cxx:1055-1090)"""
+    prev, cur = kps[model]
+    mp = L.MatchParams.localization(saturation_distance=2.0)
+    for k in (L.EDGE, L.PLANE, L.BLOB):
+        n = 20000 if k == L.BLOB else None  # blobs: every third point, keep the oracle run short
+        assert_match_equal(gpu_ctx, O, L, k, cur[k][:n], prev[k], mp, perturbed(), cell=1.2)
+
+
+@pytest.mark.parametrize("edge_k,plane_k,blob_k", [(2, 3, 4), (5, 4, 6), (9, 7, 9), (12, 8, 12), (16, 16, 16)])
+def test_matching_with_other_neighbour_counts(gpu_ctx, O, L, kps, edge_k, plane_k, blob_k):
+    prev, cur = kps[16]
+    for single in (0, 1):
+        mp = L.MatchParams(single_edge_per_ring=single, edge_nb_neighbors=edge_k, edge_min_nb_neighbors=2, plane_nb_neighbors=plane_k,
+                           blob_nb_neighbors=blob_k, max_neighbors_distance=3.0, edge_max_model_error=0.1, plane_max_model_error=0.1)
+        for k in range(3):
+            assert_match_equal(gpu_ctx, O, L, k, cur[k][:3000], prev[k], mp, perturbed(0.3, -0.02, 0.05))
+
+
+@pytest.mark.parametrize("cell", [0.3, 1.0, 4.0, 50.0])
+def test_knn_is_exact_for_any_grid_resolution(gpu_ctx, O, L, kps, cell):
+    """the search grid is an implementation detail: results must not depend on the cell size"""
+    prev, cur = kps[16]
+    mp = L.MatchParams.localization()
+    assert_match_equal(gpu_ctx, O, L, L.PLANE, cur[1], prev[1], mp, perturbed(), cell=cell)
+    assert_match_equal(gpu_ctx, O, L, L.EDGE, cur[0], prev[0], mp, perturbed(), cell=cell)
+
+
+def test_matching_edge_cases(gpu_ctx, O, L, kps):
+    prev, cur = kps[16]
+    ego = L.MatchParams.ego_motion()
+    # empty target: every keypoint stays UNKOWN, histogram empty (KeypointsMatcher.cxx:53-58)
+    st = assert_match_equal(gpu_ctx, O, L, 1, cur[1], prev[1][:0], ego, np.eye(4))
+    assert np.all(st == 7)
+    # fewer target points than neighbours requested
+    st = assert_match_equal(gpu_ctx, O, L, 1, cur[1], prev[1][:3], ego, np.eye(4))
+    assert np.all(st == 2)
+    st = assert_match_equal(gpu_ctx, O, L, 0, cur[0], prev[0][:1], ego, np.eye(4))
+    # queries far outside the target's bounding box, sparse target (exhaustive fall-back of the search)
+    far = perturbed(400.0, 0.3, 30.0)
+    st = assert_match_equal(gpu_ctx, O, L, 1, cur[1], prev[1], ego, far)
+    assert np.all(st == 3)
+    assert_match_equal(gpu_ctx, O, L, 0, cur[0], prev[0][::40], L.MatchParams.localization(), perturbed())
+    assert_match_equal(gpu_ctx, O, L, 0, cur[0], prev[0][::40], ego, perturbed())
+    # bad parametrisation
+    st = assert_match_equal(gpu_ctx, O, L, 1, cur[1], prev[1], L.MatchParams(plane_nb_neighbors=2), np.eye(4))
+    assert np.all(st == 1)
+    st = assert_match_equal(gpu_ctx, O, L, 2, cur[2][:500], prev[2], L.MatchParams(blob_nb_neighbors=3), np.eye(4))
+    assert np.all(st == 1)
+    # no queries at all
+    gpu_ctx.set_keypoints(L.SET_WORKING, 1, cur[1][:0])
+    assert gpu_ctx.match(1, L.SET_WORKING, ego, np.eye(4)).sum() == 0
+    # duplicated target points: exact distance ties are ordered by index
+    dup = np.concatenate([prev[1], prev[1]])
+    assert_match_equal(gpu_ctx, O, L, 1, cur[1], dup, ego, perturbed())
+    # collinear / coincident neighbourhoods (degenerate covariance)
+    line = prev[1][:200].copy()
+    line["y"], line["z"] = 0, 0
+    line["x"] = np.linspace(-5, 5, 200, dtype=np.float32)
+    assert_match_equal(gpu_ctx, O, L, 1, cur[1][:500], line, ego, np.eye(4))
+    same = np.repeat(prev[1][:1], 50)
+    assert_match_equal(gpu_ctx, O, L, 1, cur[1][:500], same, ego, np.eye(4))
+    assert_match_equal(gpu_ctx, O, L, 0, cur[0][:500], same, L.MatchParams.localization(), np.eye(4))
+
+
+def test_device_resident_target_equals_host_target(gpu_ctx, O, L):
+    """ego-motion registers on the previous scan's keypoints without leaving the device"""
+    ex = O.Extractor()
+    gpu_ctx.azimuthal_resolution = 0.0
+    for f in range(2):
+        pts, _ = L.synth_frame(16, 1000, f)
+        gpu_ctx.upload_frame(pts)
+        gpu_ctx.extract_keypoints()
+        ex.compute(pts)
+    mp = L.MatchParams.ego_motion(saturation_distance=5.0)
+    for k in (0, 1):
+        gpu_ctx.set_target_from_set(k, L.SET_RAW_PREVIOUS)
+        gpu_ctx.match(k, L.SET_RAW_CURRENT, mp, perturbed(), slot=L.TARGET_PREVIOUS)
+        st, w, rec = gpu_ctx.match_results(k, L.SET_RAW_CURRENT)
+        so, wo, ro, _ = O.match(gpu_ctx.keypoints(L.SET_RAW_CURRENT, k), gpu_ctx.keypoints(L.SET_RAW_PREVIOUS, k), k, mp, perturbed())
+        assert np.array_equal(st, so) and np.array_equal(bits(rec), bits(ro))
+
+
+# ---------------------------------------------------------------------------------- seam 3
+def setup_residuals(ctx, O, L, kps, model=16, sat=5.0):
+    prev, cur = kps[model]
+    mp = L.MatchParams.ego_motion(saturation_distance=sat)
+    recs, sts = [], []
+    for k in (0, 1):
+        ctx.set_keypoints(L.SET_WORKING, k, cur[k])
+        ctx.set_target(k, prev[k])
+        ctx.match(k, L.SET_WORKING, mp, perturbed())
+        st, w, rec = ctx.match_results(k, L.SET_WORKING)
+        recs.append(rec)
+        sts.append(st)
+    ctx.set_keypoints(L.SET_WORKING, 2, cur[2][:0])
+    ctx.match(2, L.SET_WORKING, mp, perturbed())
+    return np.concatenate(recs), np.concatenate(sts)
+
+
+@pytest.mark.parametrize("model", [16, 128])
+def test_normal_equations_match_the_oracle(gpu_ctx, O, L, kps, model):
+    rec, st = setup_residuals(gpu_ctx, O, L, kps, model)
+    for w6 in (np.zeros(6), np.array([0.45, 0.01, -0.02, 0.001, -0.002, 0.012]), np.array([3.0, -2.0, 1.0, 0.3, -0.2, 1.5])):
+        cost, g, H, nv = gpu_ctx.accumulate(7, w6)
+        co, go, Ho, no = O.accumulate(rec, st, 5.0, w6)
+        assert nv == no
+        assert abs(cost - co) <= 1e-12 * abs(co)
+        assert np.abs(g - go).max() <= 1e-11 * np.abs(go).max()
+        assert np.abs(H - Ho).max() <= 1e-12 * np.abs(Ho).max()
+        assert np.array_equal(H, H.T)
+        c2, _, _, _ = gpu_ctx.accumulate(7, w6, jac=False)
+        assert c2 == cost  # the cost does not depend on whether the Jacobian is asked for
+
+
+def test_normal_equations_are_reproducible_and_additive(gpu_ctx, O, L, kps):
+    setup_residuals(gpu_ctx, O, L, kps)
+    w6 = np.array([0.4, 0.0, 0.01, 0.0, 0.001, 0.01])
+    a = gpu_ctx.accumulate(3, w6)
+    b = gpu_ctx.accumulate(3, w6)
+    assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])  # fixed-order reduction: bitwise
+    e, p = gpu_ctx.accumulate(1, w6), gpu_ctx.accumulate(2, w6)  # residual blocks of the two types are independent
+    assert abs(e[0] + p[0] - a[0]) <= 1e-12 * a[0] and e[3] + p[3] == a[3]
+    assert np.abs(e[2] + p[2] - a[2]).max() <= 1e-12 * np.abs(a[2]).max()
+
+
+@pytest.mark.parametrize("two_d", [False, True])
+def test_lm_solve_matches_the_oracle(gpu_ctx, O, L, kps, two_d):
+    rec, st = setup_residuals(gpu_ctx, O, L, kps)
+    prior = perturbed(0.3, 0.0)
+    pose, summ, costs = gpu_ctx.solve(7, prior, max_iter=15, two_d=two_d)
+    po, wo, so, co = O.lm_solve(rec, st, 5.0, prior, max_iter=15, two_d=two_d)
+    dp, da = pose_diff(po, pose)
+    assert dp < 1e-9 and da < 1e-7, (dp, da)
+    assert summ[0] == so[0] and summ[2] == so[2]  # accepted steps and iterations; evaluations differ by design
+    assert abs(costs[1] - co[1]) <= 1e-9 * co[1] and costs[1] <= costs[0]
+    # solving again from the optimum: "num_successful_steps == 1", the ICP stop criterion
+    pose2, summ2, _ = gpu_ctx.solve(7, pose, max_iter=15, two_d=two_d)
+    assert summ2[0] == 1
+    cov, err = gpu_ctx.registration_error(7, pose, two_d=two_d)
+    covo, erro = O.covariance(rec, st, 5.0, pose) if not two_d else (None, None)
+    if covo is not None:
+        assert np.abs(cov - covo).max() <= 1e-6 * np.abs(covo).max() and np.allclose(err, erro, rtol=1e-6)

@@ -1,0 +1,226 @@
+"""Self-checks of the CPU oracle that need no reference: portable math vs libm,
+kNN vs brute force, PCA / residual-record identities, LM behaviour, extractor invariants and edge
+cases, recovery of the known synthetic motion."""
+import numpy as np
+import pytest
+
+from conftest import pose_diff
+
+
+# ---------------------------------------------------------------- portable math
+def ulp_err(a, ref):
+    # 1 ulp of the result, but never finer than 1 ulp of 1.0: next to the zeros of sin / cos the
+    # two-constant argument reduction is accurate in absolute, not in relative, terms
+    ref = np.asarray(ref, np.float64)
+    spacing = np.maximum(np.spacing(np.abs(ref)), np.finfo(np.float64).eps)
+    return np.abs(a - ref) / spacing
+
+
+def test_portable_trig_is_within_one_ulp_of_libm(O):
+    rng = np.random.default_rng(0)
+    x = np.concatenate([rng.uniform(-4, 4, 200000), rng.uniform(0, np.pi / 3, 100000), [0.0, 1e-300, np.pi / 4, -np.pi / 4, np.pi, 1e-9]])
+    assert ulp_err(O.math(0, x), np.sin(x)).max() <= 1.0
+    assert ulp_err(O.math(1, x), np.cos(x)).max() <= 1.0
+    y, xx = rng.uniform(-10, 10, 200000), rng.uniform(-10, 10, 200000)
+    assert ulp_err(O.math(2, xx, y), np.arctan2(y, xx)).max() <= 1.0
+    # the quadrant cases the analytic eigen-solver reaches: y >= 0
+    assert O.math(2, np.array([1.0, 0.0, -1.0]), np.array([0.0, 1.0, 0.0])).tolist() == [0.0, np.pi / 2, np.pi]
+
+
+# ---------------------------------------------------------------- kNN
+@pytest.mark.parametrize("k", [1, 5, 8, 10, 16])
+def test_kdtree_equals_brute_force(O, L, k):
+    tgt, _ = L.synth_frame(8, 1000, 0)
+    rng = np.random.default_rng(k)
+    q = np.stack([tgt["x"], tgt["y"], tgt["z"]], 1)[rng.integers(0, tgt.size, 600)].astype(np.float64) + rng.normal(0, 0.3, (600, 3))
+    q = np.concatenate([q, rng.uniform(-300, 300, (50, 3))])  # far outside the cloud too
+    i1, d1, c1 = O.knn(tgt, q, k)
+    i2, d2, c2 = O.knn(tgt, q, k, brute=True)
+    assert np.array_equal(c1, c2) and np.array_equal(i1, i2) and np.array_equal(d1, d2)
+    assert np.all(np.diff(d1, axis=1) >= 0)  # ascending
+
+
+def test_knn_ties_are_broken_by_index(O, L):
+    tgt = np.zeros(6, L.POINT_DTYPE)
+    tgt["x"] = [1, -1, 1, -1, 2, 0]  # four points at the same distance from the origin
+    tgt["w"] = 1
+    idx, d2, cnt = O.knn(tgt, np.zeros((1, 3)), 4)
+    assert idx[0].tolist() == [5, 0, 1, 2] and cnt[0] == 4
+    idx, d2, cnt = O.knn(tgt[:3], np.zeros((1, 3)), 5)  # fewer points than k
+    assert cnt[0] == 3
+
+
+# ---------------------------------------------------------------- matcher records
+def test_match_records_satisfy_model_identities(O, L, golden):
+    pose = golden["match_pose"]
+    st, w, rec, hist = O.match(golden["kp1_1"], golden["kp0_1"], 1, L.MatchParams.ego_motion(), pose)
+    ok = st == 0
+    assert ok.sum() > 50 and hist[0] == ok.sum() and hist.sum() == st.size
+    A = rec[ok, :9].reshape(-1, 3, 3)
+    # plane: A = n n^T is a symmetric rank-1 projector
+    assert np.abs(A - A.transpose(0, 2, 1)).max() == 0
+    assert np.abs(A @ A - A).max() < 1e-12
+    assert np.abs(np.trace(A, axis1=1, axis2=2) - 1).max() < 1e-12
+    assert np.all((w[ok] > 0) & (w[ok] <= 1)) and np.all(w[~ok] == 0) and np.all(rec[~ok] == 0)
+    # X is the untransformed BASE point (KeypointsMatcher.cxx:185, 271)
+    kp = golden["kp1_1"][ok]
+    assert np.array_equal(rec[ok, 12:15], np.stack([kp["x"], kp["y"], kp["z"]], 1).astype(np.float64))
+    st, w, rec, _ = O.match(golden["kp1_0"], golden["kp0_0"], 0, L.MatchParams.ego_motion(), pose)
+    A = rec[st == 0, :9].reshape(-1, 3, 3)
+    # line: A = I - n n^T projector of rank 2
+    assert np.abs(A @ A - A).max() < 1e-12 and np.abs(np.trace(A, axis1=1, axis2=2) - 2).max() < 1e-12
+
+
+def test_match_status_edge_cases(O, L, golden):
+    cur, tgt = golden["kp1_1"], golden["kp0_1"]
+    pose = np.eye(4)
+    st, _, _, hist = O.match(cur, tgt[:0], 1, L.MatchParams.ego_motion(), pose)  # empty target
+    assert np.all(st == 7) and hist.sum() == 0  # UNKOWN, histogram untouched (KeypointsMatcher.cxx:53-58)
+    st, _, _, _ = O.match(cur, tgt[:3], 1, L.MatchParams.ego_motion(), pose)  # fewer points than k
+    assert np.all(st == 2)  # NOT_ENOUGH_NEIGHBORS
+    far = np.eye(4)
+    far[0, 3] = 500.0
+    st, _, _, _ = O.match(cur, tgt, 1, L.MatchParams.ego_motion(), far)
+    assert np.all(st == 3)  # NEIGHBORS_TOO_FAR
+    st, _, _, _ = O.match(cur, tgt, 1, L.MatchParams.ego_motion(plane_nb_neighbors=2), pose)
+    assert np.all(st == 1)  # BAD_MODEL_PARAMETRIZATION
+    st, _, _, _ = O.match(golden["kp1_0"], golden["kp0_0"], 0, L.MatchParams.ego_motion(edge_min_nb_neighbors=1), pose)
+    assert np.all(st == 1)
+
+
+# ---------------------------------------------------------------- LM
+def make_plane_problem(n=400, seed=0):
+    """Residual records of points on three orthogonal planes displaced by a known transform."""
+    rng = np.random.default_rng(seed)
+    rec = np.zeros((n, 16))
+    normals = np.eye(3)[rng.integers(0, 3, n)]
+    P = rng.uniform(-10, 10, (n, 3))
+    w6 = np.array([0.3, -0.2, 0.1, 0.01, -0.02, 0.03])
+    cx, sx, cy, sy, cz, sz = np.cos(w6[3]), np.sin(w6[3]), np.cos(w6[4]), np.sin(w6[4]), np.cos(w6[5]), np.sin(w6[5])
+    R = np.array([[cy * cz, sx * sy * cz - cx * sz, cx * sy * cz + sx * sz], [cy * sz, sx * sy * sz + cx * cz, cx * sy * sz - sx * cz], [-sy, sx * cy, cx * cy]])
+    X = (P - w6[:3]) @ R  # R^T (P - t): the true pose maps X back onto P
+    rec[:, :9] = np.einsum("ni,nj->nij", normals, normals).reshape(n, 9)
+    rec[:, 9:12] = P
+    rec[:, 12:15] = X
+    rec[:, 15] = 1.0
+    T = np.eye(4)
+    T[:3, :3], T[:3, 3] = R, w6[:3]
+    return rec, np.zeros(n, np.uint8), T
+
+
+def test_lm_recovers_a_known_transform(O):
+    rec, st, T = make_plane_problem()
+    pose, w, summ, costs = O.lm_solve(rec, st, 5.0, np.eye(4), max_iter=15)
+    dp, da = pose_diff(T, pose)
+    assert dp < 1e-6 and da < 1e-6
+    assert costs[1] < 1e-12 * max(costs[0], 1) + 1e-14 and summ[0] >= 2
+
+
+def test_lm_reports_one_successful_step_at_the_optimum(O):
+    rec, st, T = make_plane_problem()
+    pose, w, summ, costs = O.lm_solve(rec, st, 5.0, T)
+    assert summ[0] == 1  # "no LM step accepted": the ICP loops stop on this (Slam.cxx:950, 1151)
+    assert pose_diff(T, pose)[0] < 1e-12
+
+
+def test_lm_cost_never_increases_and_respects_max_iter(O):
+    rec, st, T = make_plane_problem(seed=3)
+    prev = None
+    for it in range(0, 6):
+        pose, w, summ, costs = O.lm_solve(rec, st, 5.0, np.eye(4), max_iter=it)
+        assert summ[2] <= it and costs[1] <= costs[0]
+        if prev is not None:
+            assert costs[1] <= prev + 1e-12
+        prev = costs[1]
+
+
+def test_tukey_saturation_and_two_d_mode(O):
+    rec, st, T = make_plane_problem()
+    rec_out = rec.copy()
+    rec_out[:40, 9:12] += 50.0  # gross outliers: beyond the saturation distance they carry no gradient
+    c0, g0, H0, _ = O.accumulate(rec_out[40:], st[40:], 1.0, np.zeros(6))
+    c1, g1, H1, _ = O.accumulate(rec_out, st, 1.0, np.zeros(6))
+    assert np.allclose(g0, g1, rtol=0, atol=1e-9) and np.allclose(H0, H1, rtol=0, atol=1e-9)
+    assert abs((c1 - c0) - 40 * 0.5 / 3.0) < 1e-9  # each saturated block costs rho = a^2/3
+    pose, w, summ, costs = O.lm_solve(rec, st, 5.0, np.eye(4), two_d=True)
+    assert w[2] == 0 and w[3] == 0 and w[4] == 0  # Z, rX, rY held constant
+
+
+def test_covariance_is_the_inverse_information(O):
+    rec, st, T = make_plane_problem()
+    cov, err = O.covariance(rec, st, 5.0, T)
+    c, g, H, _ = O.accumulate(rec, st, 5.0, np.array([0.3, -0.2, 0.1, 0.01, -0.02, 0.03]))
+    assert np.allclose(cov @ H, np.eye(6), atol=1e-6)
+    assert err[0] > 0 and err[1] > 0
+
+
+# ---------------------------------------------------------------- extractor
+def test_extractor_invariants(O, L):
+    pts, _ = L.synth_frame(16, 1000, 0)
+    ex = O.Extractor()
+    counts = ex.compute(pts)
+    lab = [ex.debug(4 + k).astype(bool) for k in range(3)]
+    val = [ex.debug(7 + k).astype(bool) for k in range(3)]
+    assert counts.tolist() == [int(l.sum()) for l in lab]
+    for k in range(3):
+        assert np.all(val[k][lab[k]])  # labelled points get their validity bit back (SSKE.cxx:584)
+    ring = pts["laser_id"]
+    for r in np.unique(ring):
+        sel = np.flatnonzero(ring == r)
+        pl = np.flatnonzero(lab[1][sel])
+        assert np.all(np.diff(pl) > 4)  # plane NMS window +-4
+        bl = np.flatnonzero(lab[2][sel])
+        assert np.all(bl % 3 == 0)
+        assert not lab[0][sel][:4].any() and not lab[0][sel][-4:].any()  # first/last NeighborWidth points are invalid
+    # keypoint clouds are ring-major, index ascending
+    for k in range(3):
+        kp = ex.keypoints(k)
+        assert np.all(np.diff(kp["laser_id"].astype(int)) >= 0)
+    assert 0.003 < ex.azimuthal_resolution < 0.004  # 0.2 deg
+
+
+def test_extractor_edge_cases(O, L):
+    pts, _ = L.synth_frame(8, 1000, 0)
+    ex = O.Extractor()
+    ex.azimuthal_resolution = 0.0157
+    few = pts[pts["laser_id"] == 0][:8]  # a ring with fewer than 2W+1 points: fully invalid
+    assert ex.compute(few).tolist() == [0, 0, 0] and ex.debug(7).sum() == 0
+    only7 = pts[pts["laser_id"] == 7]  # rings 0..6 empty
+    c = ex.compute(only7)
+    assert ex.nb_rings() == 8 and c[2] > 0
+    dup = np.repeat(pts[pts["laser_id"] == 3], 2)  # dual returns hitting the same point: zero-length segments
+    c = ex.compute(dup)
+    assert np.isfinite(ex.debug(0)).all()
+    one = pts[:1]
+    assert ex.compute(one).tolist() == [0, 0, 0]
+
+
+# ---------------------------------------------------------------- pipeline
+def test_oracle_recovers_the_synthetic_motion(O, L):
+    s = O.Slam(EgoMotion=3)
+    prev = None
+    steps = []
+    for f in range(8):
+        pts, stamp = L.synth_frame(16, 1000, f)
+        s.add_frame(pts, stamp, f)
+        T = s.world_transform()
+        if prev is not None and f >= 4:
+            steps.append(pose_diff(prev, T)[0])
+        prev = T
+    # 5 m/s at 10 Hz: every frame moves 0.5 m (the first frames carry the un-undistorted first sweep: transient)
+    assert np.all(np.abs(np.array(steps) - 0.5) < 0.06), steps
+    st = s.stats()
+    assert st[12] > 1000 and st[13] >= 6  # matched keypoints, keyframes
+
+
+def test_frame_checks(O, L):
+    s = O.Slam(EgoMotion=3)
+    pts, stamp = L.synth_frame(8, 1000, 0)
+    s.add_frame(pts, 0, 0)  # stamp 0 equals the post-reset "previous" stamp: dropped (Slam.cxx:727-731)
+    assert s.stats()[0] == 0
+    s.add_frame(pts, stamp, 0)
+    T0 = s.world_transform()
+    s.add_frame(pts, stamp, 1)  # same stamp again: ignored
+    assert np.array_equal(T0, s.world_transform())
+    s.add_frame(pts[:0], stamp + 100000, 2)  # empty frame: ignored
+    assert np.array_equal(T0, s.world_transform())

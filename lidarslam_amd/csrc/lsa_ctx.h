@@ -28,7 +28,7 @@ constexpr int kBucketChunk = 1024;        // points per block of the ring bucket
 constexpr int kCellCap = 1 << 21;         // max cells of the fine kNN search grid
 constexpr int kCellCapCoarse = 1 << 15;   // max cells of the coarse level (cell x 8)
 constexpr int kKnnMax = 16;               // neighbours per query the kNN buffers hold
-constexpr int kAccumBlocks = 120;         // grid of the normal-equation kernel (grid-stride)
+constexpr int kAccumBlocks = 256;         // grid of the normal-equation kernel (grid-stride, <= 256: folded by one block)
 constexpr int kAccumVals = 29;            // cost, g[6], H upper[21], nvalid
 
 struct GridDesc
@@ -72,6 +72,7 @@ struct MatchBuf
   int* knn_idx = nullptr;      // [kKnnMax][cap] neighbour indices, ascending (distance, index)
   float* knn_d2 = nullptr;     // [kKnnMax][cap]
   int* knn_cnt = nullptr;      // [cap]
+  int* slow_list = nullptr;    // [cap] queries deferred to the exhaustive kernel
   int k = 0;                   // number of queries of the last match
   int cap = 0;
   double sat = 1.0;

@@ -87,6 +87,7 @@ int ensure_match(lsa_ctx* ctx, int type, int k)
   LSA_HIP(ctx, dev_alloc(&b.knn_idx, (size_t)cap * kKnnMax));
   LSA_HIP(ctx, dev_alloc(&b.knn_d2, (size_t)cap * kKnnMax));
   LSA_HIP(ctx, dev_alloc(&b.knn_cnt, (size_t)cap));
+  LSA_HIP(ctx, dev_alloc(&b.slow_list, (size_t)cap));
   b.cap = cap;
   return LSA_OK;
 }
@@ -222,6 +223,7 @@ int lsa_ctx_create(int device_id, lsa_ctx** out)
   ok &= hipMalloc((void**)&ctx->kp_count_dev, 4 * sizeof(int)) == hipSuccess;
   ok &= hipMalloc((void**)&ctx->partials, (size_t)kAccumBlocks * kAccumVals * sizeof(double)) == hipSuccess;
   ok &= hipMalloc((void**)&ctx->reduce_out, 64 * sizeof(double)) == hipSuccess;
+  if (ok) ok &= hipMemset(ctx->reduce_out, 0, 64 * sizeof(double)) == hipSuccess;  // [32] holds the arrival ticket of k_accumulate
   ok &= hipMalloc((void**)&ctx->hist_dev, 16 * sizeof(int)) == hipSuccess;
   ok &= hipMalloc((void**)&ctx->range_bits, 16 * sizeof(unsigned long long)) == hipSuccess;
   ok &= hipHostMalloc((void**)&ctx->host_pinned, 256 * sizeof(double), hipHostMallocDefault) == hipSuccess;
@@ -251,7 +253,7 @@ void lsa_ctx_destroy(lsa_ctx* ctx)
   }
   for (int k = 0; k < 3; ++k)
   {
-    fr(ctx->match[k].rec); fr(ctx->match[k].status); fr(ctx->match[k].knn_idx); fr(ctx->match[k].knn_d2); fr(ctx->match[k].knn_cnt);
+    fr(ctx->match[k].rec); fr(ctx->match[k].status); fr(ctx->match[k].knn_idx); fr(ctx->match[k].knn_d2); fr(ctx->match[k].knn_cnt); fr(ctx->match[k].slow_list);
   }
   fr(ctx->partials); fr(ctx->reduce_out); fr(ctx->hist_dev); fr(ctx->scratch_out); fr(ctx->range_bits);
   for (auto& s : ctx->store) fr(s.first);

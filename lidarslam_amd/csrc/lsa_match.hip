@@ -307,7 +307,8 @@ template <int KMAX>
 __global__ __launch_bounds__(256) void k_knn(const float4* __restrict__ queries, int nq, Rigid pose, int k, const GridDesc* __restrict__ desc,
                                              const uint32_t* __restrict__ cs0, const float4* __restrict__ sorted0,
                                              const uint32_t* __restrict__ cs1, const float4* __restrict__ sorted1, int* __restrict__ knn_idx,
-                                             float* __restrict__ knn_d2, int* __restrict__ knn_cnt, int cap, int* __restrict__ slow_counter)
+                                             float* __restrict__ knn_d2, int* __restrict__ knn_cnt, int cap, int* __restrict__ slow_counter,
+                                             int* __restrict__ slow_list)
 {
   const int tid = blockIdx.x * blockDim.x + threadIdx.x;
   const int q = tid / kGroup;
@@ -327,7 +328,7 @@ __global__ __launch_bounds__(256) void k_knn(const float4* __restrict__ queries,
   GridView gv;
   grid_view(gv, desc, cs0, sorted0, qx, qy, qz);
   int level = 0, r = 0;
-  bool done = !active;
+  bool done = !active, deferred = false;
   while (true)
   {
     float bound2 = -1.f;
@@ -363,11 +364,6 @@ __global__ __launch_bounds__(256) void k_knn(const float4* __restrict__ queries,
         }
         covered = (x0 == 0 && y0 == 0 && z0 == 0 && x1 == nx - 1 && y1 == ny - 1 && z1 == nz - 1);
       }
-      else
-      {
-        scan_range(ks, gv.sorted, (uint32_t)lane, (uint32_t)gv.g.npoints, (uint32_t)kGroup, qx, qy, qz);
-        covered = true;
-      }
     }
     // wave-convergent: how many candidates of the whole group lie inside the proven radius
     int c = done ? 0 : ks.count_below(bound2);
@@ -383,7 +379,14 @@ __global__ __launch_bounds__(256) void k_knn(const float4* __restrict__ queries,
         r = 0;
         ks.init(k);
         if (level == 1) grid_view(gv, desc + 1, cs1, sorted1, qx, qy, qz);
-        else if (lane == 0) atomicAdd(slow_counter, 1);
+        else
+        {
+          // fewer than k points within 8 coarse shells: hand the query to k_knn_sparse (a whole block
+          // scans the target) instead of letting 8 lanes stall the wave
+          if (lane == 0) slow_list[atomicAdd(slow_counter, 1)] = q;
+          deferred = true;
+          done = true;
+        }
       }
       else ++r;
     }
@@ -404,7 +407,7 @@ __global__ __launch_bounds__(256) void k_knn(const float4* __restrict__ queries,
       if (s < k) ks.offer(od, oi);
     }
   }
-  if (active && lane == 0)
+  if (active && lane == 0 && !deferred)
   {
     int cnt = 0;
 #pragma unroll
@@ -416,6 +419,68 @@ __global__ __launch_bounds__(256) void k_knn(const float4* __restrict__ queries,
         if (ks.idx[s] != 0x7fffffff) ++cnt;
       }
     knn_cnt[q] = cnt;
+  }
+}
+
+// Exhaustive search for the queries k_knn deferred: one 256-thread block per query scans the whole
+// target with coalesced loads, every thread keeps a private top-k, the lists are merged by a 64-lane
+// shuffle butterfly and then across the 4 waves through LDS.  Same (distance, index) order => same result.
+template <int KMAX>
+__global__ __launch_bounds__(256) void k_knn_sparse(const float4* __restrict__ queries, Rigid pose, int k, const GridDesc* __restrict__ desc,
+                                                    const float4* __restrict__ sorted0, int* __restrict__ knn_idx, float* __restrict__ knn_d2,
+                                                    int* __restrict__ knn_cnt, int cap, const int* __restrict__ slow_counter,
+                                                    const int* __restrict__ slow_list)
+{
+  __shared__ float sd[4][KMAX];
+  __shared__ int si[4][KMAX];
+  const int nslow = *slow_counter;
+  const int m = desc->npoints;
+  for (int e = blockIdx.x; e < nslow; e += gridDim.x)
+  {
+    const int q = slow_list[e];
+    const float4 q4 = queries[2 * (size_t)q];
+    double wx, wy, wz;
+    rigid_apply(pose, (double)q4.x, (double)q4.y, (double)q4.z, wx, wy, wz);
+    const float qx = (float)wx, qy = (float)wy, qz = (float)wz;
+    KnnSet<KMAX> ks;
+    ks.init(k);
+    scan_range(ks, sorted0, (uint32_t)threadIdx.x, (uint32_t)m, 256u, qx, qy, qz);
+#pragma unroll
+    for (int mask = 1; mask < 64; mask <<= 1)
+    {
+      float td[KMAX]; int ti[KMAX];
+#pragma unroll
+      for (int s = 0; s < KMAX; ++s) { td[s] = ks.d2[s]; ti[s] = ks.idx[s]; }
+#pragma unroll
+      for (int s = 0; s < KMAX; ++s)
+      {
+        const float od = __shfl_xor(td[s], mask);
+        const int oi = __shfl_xor(ti[s], mask);
+        if (s < k) ks.offer(od, oi);
+      }
+    }
+    if ((threadIdx.x & 63) == 0)
+    {
+#pragma unroll
+      for (int s = 0; s < KMAX; ++s) { sd[threadIdx.x >> 6][s] = ks.d2[s]; si[threadIdx.x >> 6][s] = ks.idx[s]; }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+      for (int w = 1; w < 4; ++w)
+        for (int s = 0; s < k; ++s) ks.offer(sd[w][s], si[w][s]);
+      int cnt = 0;
+#pragma unroll
+      for (int s = 0; s < KMAX; ++s)
+        if (s < k)
+        {
+          knn_idx[(size_t)s * cap + q] = ks.idx[s];
+          knn_d2[(size_t)s * cap + q] = ks.d2[s];
+          if (ks.idx[s] != 0x7fffffff) ++cnt;
+        }
+      knn_cnt[q] = cnt;
+    }
+    __syncthreads();
   }
 }
 
@@ -655,7 +720,8 @@ __device__ __forceinline__ void mv3(const double M[9], double x, double y, doubl
   oz = (M[6] * x + M[7] * y) + M[8] * z;
 }
 
-__global__ __launch_bounds__(256) void k_accumulate(AccumConst c, double* __restrict__ partials)
+__global__ __launch_bounds__(256) void k_accumulate(AccumConst c, double* __restrict__ partials, unsigned* __restrict__ ticket,
+                                                    double* __restrict__ out)
 {
   double acc[kAccumVals];
 #pragma unroll
@@ -725,6 +791,25 @@ __global__ __launch_bounds__(256) void k_accumulate(AccumConst c, double* __rest
   if (threadIdx.x < kAccumVals)
     partials[(size_t)blockIdx.x * kAccumVals + threadIdx.x] =
       ((wsum[0][threadIdx.x] + wsum[1][threadIdx.x]) + wsum[2][threadIdx.x]) + wsum[3][threadIdx.x];
+  // the block that arrives last folds the per-block partials, in a fixed order, in the same launch
+  __shared__ bool is_last;
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) is_last = (atomicAdd(ticket, 1u) == gridDim.x - 1);
+  __syncthreads();
+  if (!is_last) return;
+  __threadfence();
+#pragma unroll 1
+  for (int v = 0; v < kAccumVals; ++v)
+  {
+    double x = (threadIdx.x < gridDim.x) ? partials[(size_t)threadIdx.x * kAccumVals + v] : 0.;
+    for (int o = 32; o > 0; o >>= 1) x += __shfl_down(x, o);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6][v] = x;
+  }
+  __syncthreads();
+  if (threadIdx.x < kAccumVals)
+    out[threadIdx.x] = ((wsum[0][threadIdx.x] + wsum[1][threadIdx.x]) + wsum[2][threadIdx.x]) + wsum[3][threadIdx.x];
+  if (threadIdx.x == 0) *ticket = 0u;
 }
 
 __global__ void k_accumulate_final(const double* __restrict__ partials, int nblocks, double* __restrict__ out)
@@ -782,7 +867,9 @@ void launch_knn(lsa_ctx* ctx, const lsa_point_t* q, int nq, const Rigid& pose, i
   const int threads = nq * kGroup;
   hipLaunchKernelGGL((k_knn<KMAX>), dim3((threads + 255) / 256), dim3(256), 0, ctx->stream, reinterpret_cast<const float4*>(q), nq, pose, k, t.desc,
                      t.lv[0].cell_start, t.lv[0].sorted, t.lv[1].cell_start, t.lv[1].sorted, mb.knn_idx, mb.knn_d2, mb.knn_cnt, mb.cap,
-                     ctx->hist_dev + LSA_MATCH_NSTATUS);
+                     ctx->hist_dev + LSA_MATCH_NSTATUS, mb.slow_list);
+  hipLaunchKernelGGL((k_knn_sparse<KMAX>), dim3(256), dim3(256), 0, ctx->stream, reinterpret_cast<const float4*>(q), pose, k, t.desc, t.lv[0].sorted,
+                     mb.knn_idx, mb.knn_d2, mb.knn_cnt, mb.cap, ctx->hist_dev + LSA_MATCH_NSTATUS, mb.slow_list);
 }
 
 template <int KMAX, int TYPE>
@@ -993,8 +1080,8 @@ int lsa_accumulate(lsa_ctx* ctx, unsigned type_mask, const double w[6], int want
   hipStream_t st = ctx->stream;
   {
     ProfScope ps(ctx, want_jacobian ? "accumulate_jac" : "accumulate_cost", (double)total * (want_jacobian ? 129 : 129));
-    hipLaunchKernelGGL(k_accumulate, dim3(kAccumBlocks), dim3(256), 0, st, c, ctx->partials);
-    hipLaunchKernelGGL(k_accumulate_final, dim3(1), dim3(64), 0, st, ctx->partials, kAccumBlocks, ctx->reduce_out);
+    hipLaunchKernelGGL(k_accumulate, dim3(kAccumBlocks), dim3(256), 0, st, c, ctx->partials, reinterpret_cast<unsigned*>(ctx->reduce_out + 32),
+                       ctx->reduce_out);
   }
   double* hp = ctx->host_pinned + 64;
   LSA_HIP(ctx, hipMemcpyAsync(hp, ctx->reduce_out, kAccumVals * sizeof(double), hipMemcpyDeviceToHost, st));

@@ -38,6 +38,7 @@ def parse():
     ap.add_argument("--model", type=int, default=128, help="16 VLP-16, 64 HDL-64, 128 VLS-128 (headline)")
     ap.add_argument("--cpu-frames", type=int, default=10, help="frames of the CPU baseline sample (0 disables)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = all host cores available to this process")
+    ap.add_argument("--param", action="append", default=[], help="Slam parameter override NAME=VALUE (reference setter names)")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events in the timed region")
     return ap.parse_args()
 
@@ -67,6 +68,9 @@ def main():
     # ---- inputs: one independent sequence per rank, generated on the host, made resident in HBM
     total = args.warmup + args.steps
     slam = L.Slam(local_rank, EgoMotion=3)  # MOTION_EXTRAPOLATION_AND_REGISTRATION: the default mode skips the ego-motion ICP
+    for kv in args.param:
+        name, value = kv.split("=")
+        slam.set_param(name, float(value))
     seed = sequence_seed(rank)
     stamps, npts = [], 0
     for f in range(total):

@@ -218,7 +218,11 @@ int SlamCore::ComputeEgoMotion()
     return LSA_OK;
 
   // kd-trees on the previous frame's raw keypoints -> device search grids, no PCIe traffic
-  for (int k : {LSA_EDGE, LSA_PLANE}) LSA_TRY(lsa_set_target_from_set(Ctx, LSA_TARGET_PREVIOUS, k, LSA_SET_RAW_PREVIOUS));
+  for (int k : {LSA_EDGE, LSA_PLANE})
+  {
+    lsa_set_target_cell_size(Ctx, LSA_TARGET_PREVIOUS, k, static_cast<float>(KnnCellSizeEgoMotion));
+    LSA_TRY(lsa_set_target_from_set(Ctx, LSA_TARGET_PREVIOUS, k, LSA_SET_RAW_PREVIOUS));
+  }
   TotalMatchedKeypoints = 0;
   lsa_match_params_t mp = EgoMatchParams();
 
@@ -294,8 +298,8 @@ int SlamCore::Localization()
         LocalMaps[k]->BuildSubMap(mn, mx, KeypointCounts[k] / 2);
       }
       const auto& sub = LocalMaps[k]->GetSubMap();
-      // kNN grid cell ~ twice the map leaf size: ~1 map point per leaf on a surface
-      lsa_set_target_cell_size(Ctx, LSA_TARGET_MAP, k, static_cast<float>(std::max(0.5, 2.0 * LocalMaps[k]->GetLeafSize())));
+      // the map holds one point per leaf voxel: a search cell of about one leaf keeps a handful of candidates per cell
+      lsa_set_target_cell_size(Ctx, LSA_TARGET_MAP, k, static_cast<float>(KnnCellScaleMaps * LocalMaps[k]->GetLeafSize()));
       LSA_TRY(lsa_set_target(Ctx, LSA_TARGET_MAP, k, sub.data(), static_cast<int>(sub.size())));
     }
     Stats.submap += t.Stop();
@@ -510,6 +514,8 @@ int SlamCore::GetRegisteredFrame(std::vector<lsa_point_t>& out)
   X("KfDistanceThreshold", KfDistanceThreshold, double)                                                \
   X("KfAngleThreshold", KfAngleThreshold, double)                                                      \
   X("KeepMatchDebug", KeepMatchDebug, bool)                                                            \
+  X("KnnCellSizeEgoMotion", KnnCellSizeEgoMotion, double)                                              \
+  X("KnnCellScaleMaps", KnnCellScaleMaps, double)                                                            \
   X("NeighborWidth", ExtractParams.neighbor_width, int)                                                \
   X("MinDistanceToSensor", ExtractParams.min_distance_to_sensor, float)                                \
   X("MinBeamSurfaceAngle", ExtractParams.min_beam_surface_angle, float)                                \

@@ -96,6 +96,9 @@ public:
   MappingMode MapUpdate = MappingMode::UPDATE;
   Pose BaseToLidarOffset = Pose::Identity();
   lsa_extract_params_t ExtractParams;
+  // edge length of the finest kNN search-grid cells (an implementation knob: results do not depend on it)
+  double KnnCellSizeEgoMotion = 0.25; // [m] previous-scan targets
+  double KnnCellScaleMaps = 1.0;      // x map leaf size, sub-map targets
   bool KeepMatchDebug = false;  // download MatchingResults::Rejections/Weights every frame (Slam::GetDebugArray)
 
   std::shared_ptr<RollingGrid> LocalMaps[3];

@@ -25,8 +25,9 @@ namespace lsa
 constexpr int kMaxRings = 512;            // laser_id < kMaxRings (largest spinning sensors have 128)
 constexpr int kMaxRingPoints = 8192;      // points per ring handled by the in-LDS labelling kernel
 constexpr int kBucketChunk = 1024;        // points per block of the ring bucketing kernels
-constexpr int kCellCap = 1 << 21;         // max cells of the fine kNN search grid
-constexpr int kCellCapCoarse = 1 << 15;   // max cells of the coarse level (cell x 8)
+constexpr int kGridLevels = 3;            // search grid resolutions: cell, 4 x cell, 16 x cell
+constexpr int kCellCap = 1 << 22;         // max cells of the finest kNN search grid
+__host__ __device__ constexpr int grid_level_cells(int level) { return level == 0 ? kCellCap : level == 1 ? (kCellCap >> 6) + 64 : (kCellCap >> 12) + 64; }
 constexpr int kKnnMax = 16;               // neighbours per query the kNN buffers hold
 constexpr int kAccumBlocks = 256;         // grid of the normal-equation kernel (grid-stride, <= 256: folded by one block)
 constexpr int kAccumVals = 29;            // cost, g[6], H upper[21], nvalid
@@ -41,8 +42,9 @@ struct GridDesc
   int npoints;
 };
 
-// One resolution of the search grid.  Level 0 (cell = hint) answers dense neighbourhoods, level 1
-// (cell = 8 x hint) lets sparse ones expand over empty space in a few shells instead of thousands.
+// One resolution of the search grid.  A spinning-LiDAR cloud spans three orders of magnitude in density
+// (centimetres between keypoints next to the sensor, tens of metres at range): level 0 answers the dense
+// neighbourhoods, the coarser levels let sparse ones expand over empty space in a few shells.
 struct GridLevel
 {
   float4* sorted = nullptr;        // cell-sorted x,y,z, index bits
@@ -57,8 +59,8 @@ struct Target
 {
   lsa_point_t* pts = nullptr;   // AoS as given (order kept)
   float4* xyzl = nullptr;       // x,y,z, laser_id bits
-  GridLevel lv[2];
-  GridDesc* desc = nullptr;     // device, [2]
+  GridLevel lv[kGridLevels];
+  GridDesc* desc = nullptr;     // device, [kGridLevels]
   int* bbox_bits = nullptr;     // 6 ordered ints
   int m = 0;
   int cap = 0;

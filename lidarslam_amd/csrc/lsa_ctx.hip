@@ -51,15 +51,15 @@ int ensure_target(lsa_ctx* ctx, int ti, int m)
   Target& t = ctx->target[ti];
   if (!t.desc)
   {
-    for (int l = 0; l < 2; ++l)
+    for (int l = 0; l < kGridLevels; ++l)
     {
       GridLevel& g = t.lv[l];
-      g.max_cells = l == 0 ? kCellCap : kCellCapCoarse;
+      g.max_cells = grid_level_cells(l);
       LSA_HIP(ctx, dev_alloc(&g.cell_start, (size_t)g.max_cells + 1));
       LSA_HIP(ctx, dev_alloc(&g.cell_fill, (size_t)g.max_cells));
       LSA_HIP(ctx, dev_alloc(&g.block_sums, (size_t)g.max_cells / 1024 + 2));
     }
-    LSA_HIP(ctx, dev_alloc(&t.desc, 2));
+    LSA_HIP(ctx, dev_alloc(&t.desc, kGridLevels));
     LSA_HIP(ctx, dev_alloc(&t.bbox_bits, 8));
   }
   if (m <= t.cap) return LSA_OK;
@@ -67,7 +67,7 @@ int ensure_target(lsa_ctx* ctx, int ti, int m)
   LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
   LSA_HIP(ctx, dev_alloc(&t.pts, (size_t)cap));
   LSA_HIP(ctx, dev_alloc(&t.xyzl, (size_t)cap));
-  for (int l = 0; l < 2; ++l)
+  for (int l = 0; l < kGridLevels; ++l)
   {
     LSA_HIP(ctx, dev_alloc(&t.lv[l].sorted, (size_t)cap));
     LSA_HIP(ctx, dev_alloc(&t.lv[l].cell_of, (size_t)cap));
@@ -87,7 +87,7 @@ int ensure_match(lsa_ctx* ctx, int type, int k)
   LSA_HIP(ctx, dev_alloc(&b.knn_idx, (size_t)cap * kKnnMax));
   LSA_HIP(ctx, dev_alloc(&b.knn_d2, (size_t)cap * kKnnMax));
   LSA_HIP(ctx, dev_alloc(&b.knn_cnt, (size_t)cap));
-  LSA_HIP(ctx, dev_alloc(&b.slow_list, (size_t)cap));
+  LSA_HIP(ctx, dev_alloc(&b.slow_list, (size_t)cap * 2));
   b.cap = cap;
   return LSA_OK;
 }
@@ -249,7 +249,7 @@ void lsa_ctx_destroy(lsa_ctx* ctx)
   {
     Target& t = ctx->target[k];
     fr(t.pts); fr(t.xyzl); fr(t.desc); fr(t.bbox_bits);
-    for (int l = 0; l < 2; ++l) { fr(t.lv[l].sorted); fr(t.lv[l].cell_of); fr(t.lv[l].cell_start); fr(t.lv[l].cell_fill); fr(t.lv[l].block_sums); }
+    for (int l = 0; l < kGridLevels; ++l) { fr(t.lv[l].sorted); fr(t.lv[l].cell_of); fr(t.lv[l].cell_start); fr(t.lv[l].cell_fill); fr(t.lv[l].block_sums); }
   }
   for (int k = 0; k < 3; ++k)
   {

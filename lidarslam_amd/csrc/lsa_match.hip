@@ -67,18 +67,18 @@ __global__ __launch_bounds__(256) void k_target_prep(const float4* __restrict__ 
   }
 }
 
-// desc[0]: cell = hint (grown until the grid fits kCellCap); desc[1]: cell x 8 (grown until it fits
-// kCellCapCoarse)
+// desc[0]: cell = hint (grown until the grid fits its cell budget); every further level has cells 4 x
+// larger (grown likewise)
 __global__ void k_grid_setup(const int* __restrict__ bbox, int m, float cell_hint, GridDesc* __restrict__ desc)
 {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   float mn[3], mx[3];
   for (int d = 0; d < 3; ++d) { mn[d] = o2f(bbox[d]); mx[d] = o2f(bbox[3 + d]); }
   float cell = cell_hint;
-  for (int level = 0; level < 2; ++level)
+  for (int level = 0; level < kGridLevels; ++level)
   {
-    const double cap = level == 0 ? (double)kCellCap : (double)kCellCapCoarse;
-    if (level == 1) cell *= 8.0f;
+    const double cap = (double)grid_level_cells(level);
+    if (level > 0) cell *= 4.0f;
     GridDesc g;
     while (true)
     {
@@ -213,8 +213,6 @@ __global__ __launch_bounds__(256) void k_grid_scatter(const float4* __restrict__
 
 // ------------------------------------------------------------------------------------------
 constexpr int kGroup = 8;         // lanes cooperating on one query
-constexpr int kShellCapFine = 6;  // shells searched at level 0 before escalating
-constexpr int kShellCapCoarse = 8;
 
 // private top-k of one lane, ascending (distance, index); empty slots hold (+inf, INT_MAX)
 template <int KMAX> struct KnnSet
@@ -259,16 +257,40 @@ template <int KMAX> struct KnnSet
   }
 };
 
+// Offers the points sorted[b], sorted[b + stride], ... (< e) to the private list.  Four loads are issued
+// before the first one is consumed: the loop is bound by load latency, not by arithmetic.
 template <int KMAX>
 __device__ __forceinline__ void scan_range(KnnSet<KMAX>& ks, const float4* __restrict__ sorted, uint32_t b, uint32_t e, uint32_t stride,
                                            float qx, float qy, float qz)
 {
-  for (uint32_t t = b; t < e; t += stride)
+  if (b >= e) return;
+  const uint32_t last = e - 1;
+  for (uint32_t t = b; t < e; t += 4 * stride)
   {
-    const float4 p = sorted[t];
-    const float dx = qx - p.x, dy = qy - p.y, dz = qz - p.z;
-    const float d = (dx * dx + dy * dy) + dz * dz;
-    ks.offer(d, __float_as_int(p.w));
+    const uint32_t t1 = t + stride, t2 = t + 2 * stride, t3 = t + 3 * stride;
+    const float4 p0 = sorted[t];
+    const float4 p1 = sorted[min(t1, last)];
+    const float4 p2 = sorted[min(t2, last)];
+    const float4 p3 = sorted[min(t3, last)];
+    {
+      const float dx = qx - p0.x, dy = qy - p0.y, dz = qz - p0.z;
+      ks.offer((dx * dx + dy * dy) + dz * dz, __float_as_int(p0.w));
+    }
+    if (t1 < e)
+    {
+      const float dx = qx - p1.x, dy = qy - p1.y, dz = qz - p1.z;
+      ks.offer((dx * dx + dy * dy) + dz * dz, __float_as_int(p1.w));
+    }
+    if (t2 < e)
+    {
+      const float dx = qx - p2.x, dy = qy - p2.y, dz = qz - p2.z;
+      ks.offer((dx * dx + dy * dy) + dz * dz, __float_as_int(p2.w));
+    }
+    if (t3 < e)
+    {
+      const float dx = qx - p3.x, dy = qy - p3.y, dz = qz - p3.z;
+      ks.offer((dx * dx + dy * dy) + dz * dz, __float_as_int(p3.w));
+    }
   }
 }
 
@@ -302,40 +324,63 @@ __device__ __forceinline__ void grid_view(GridView& v, const GridDesc* desc, con
   v.outd2 = o * 0.999f;
 }
 
-// neighbour lists are written SoA: idx[s * cap + q]
-template <int KMAX>
-__global__ __launch_bounds__(256) void k_knn(const float4* __restrict__ queries, int nq, Rigid pose, int k, const GridDesc* __restrict__ desc,
-                                             const uint32_t* __restrict__ cs0, const float4* __restrict__ sorted0,
-                                             const uint32_t* __restrict__ cs1, const float4* __restrict__ sorted1, int* __restrict__ knn_idx,
-                                             float* __restrict__ knn_d2, int* __restrict__ knn_cnt, int cap, int* __restrict__ slow_counter,
-                                             int* __restrict__ slow_list)
+struct GridPtrs
 {
-  const int tid = blockIdx.x * blockDim.x + threadIdx.x;
-  const int q = tid / kGroup;
-  const int lane = tid % kGroup;
-  const bool active = q < nq;
-  float qx = 0.f, qy = 0.f, qz = 0.f;
-  if (active)
+  const uint32_t* cell_start[kGridLevels];
+  const float4* sorted[kGridLevels];
+};
+
+// neighbour lists are written SoA: idx[s * cap + q].  knn_cnt[q] = number of neighbours found, or
+// kKnnFar when the search proved that the k-th neighbour lies beyond far_d2 (plane / blob matches only
+// need to know that: KeypointsMatcher.cxx:217, 303 reject them as NEIGHBORS_TOO_FAR whatever they are).
+constexpr int kKnnFar = -1;
+constexpr int kShellCap = 4;  // shells searched per level before moving to the next, 4 x coarser, level
+
+// The search cascade.  G lanes cooperate on one query; the rows of a shell are dealt to G / W sub-groups
+// of W lanes which scan a row with stride W (W = 1: one lane per row, W = 8: coalesced 128-byte reads).
+//   k_knn<KMAX, 8, 1, 0, 1>    every query, finest level only: short rows, 8 queries per wavefront
+//   k_knn<KMAX, 64, 8, 1, 3>   the few queries whose neighbourhood is sparse at the finest level (a few
+//                              percent): one wavefront each over the coarser levels, whose cells hold
+//                              hundreds of points, so rows are scanned cooperatively and stay balanced
+//   k_knn_sparse               what is left: a whole block scans the target
+// A kernel hands unfinished queries to the next one through a device list (list_out / count_out).
+template <int KMAX, int G, int W, int LEVEL0, int LEVEL1>
+__global__ __launch_bounds__(256) void k_knn(const float4* __restrict__ queries, int nq, const int* __restrict__ list_in,
+                                             const int* __restrict__ count_in, Rigid pose, int k, float far_d2,
+                                             const GridDesc* __restrict__ desc, GridPtrs gp, int* __restrict__ knn_idx,
+                                             float* __restrict__ knn_d2, int* __restrict__ knn_cnt, int cap, int* __restrict__ count_out,
+                                             int* __restrict__ list_out)
+{
+  const int lane = threadIdx.x % G;
+  const int sub = lane / W, sl = lane % W;
+  const int nwork = list_in ? *count_in : nq;
+  const int per_pass = gridDim.x * (256 / G);
+  // the loop bound is the same for every lane of the wavefront, the shuffles below stay convergent
+  for (int base = blockIdx.x * (256 / G); base < nwork; base += per_pass)
   {
-    // KeypointsMatcher: worldPoint = PosePrior * basePoint in double, narrowed to float for the search
-    const float4 q4 = queries[2 * (size_t)q];
-    double wx, wy, wz;
-    rigid_apply(pose, (double)q4.x, (double)q4.y, (double)q4.z, wx, wy, wz);
-    qx = (float)wx; qy = (float)wy; qz = (float)wz;
-  }
-  KnnSet<KMAX> ks;
-  ks.init(k);
-  GridView gv;
-  grid_view(gv, desc, cs0, sorted0, qx, qy, qz);
-  int level = 0, r = 0;
-  bool done = !active, deferred = false;
-  while (true)
-  {
-    float bound2 = -1.f;
-    bool covered = false;
-    if (!done)
+    const int w = base + threadIdx.x / G;
+    const bool active = w < nwork;
+    const int q = active ? (list_in ? list_in[w] : w) : 0;
+    float qx = 0.f, qy = 0.f, qz = 0.f;
+    if (active)
     {
-      if (level < 2)
+      // KeypointsMatcher: worldPoint = PosePrior * basePoint in double, narrowed to float for the search
+      const float4 q4 = queries[2 * (size_t)q];
+      double wx, wy, wz;
+      rigid_apply(pose, (double)q4.x, (double)q4.y, (double)q4.z, wx, wy, wz);
+      qx = (float)wx; qy = (float)wy; qz = (float)wz;
+    }
+    KnnSet<KMAX> ks;
+    ks.init(k);
+    GridView gv;
+    grid_view(gv, desc + LEVEL0, gp.cell_start[LEVEL0], gp.sorted[LEVEL0], qx, qy, qz);
+    int level = LEVEL0, r = 0;
+    bool done = !active, deferred = false, far = false;
+    while (true)
+    {
+      float bound2 = -1.f;
+      bool covered = false;
+      if (!done)
       {
         const int nx = gv.g.dims[0], ny = gv.g.dims[1], nz = gv.g.dims[2];
         const int z0 = max(0, gv.cz - r), z1 = min(nz - 1, gv.cz + r);
@@ -343,18 +388,36 @@ __global__ __launch_bounds__(256) void k_knn(const float4* __restrict__ queries,
         const int x0 = max(0, gv.cx - r), x1 = min(nx - 1, gv.cx + r);
         const int ys = y1 - y0 + 1;
         const int nrows = (z1 - z0 + 1) * ys;
-        for (int ri = lane; ri < nrows; ri += kGroup)
-        {
+        // a row of the shell = one contiguous run of the cell-sorted array (rows on the shell's faces) or
+        // its two end cells (interior rows); the runs of the NEXT row are fetched while this one is scanned
+        auto row_runs = [&](int ri, uint32_t& b0, uint32_t& e0, uint32_t& b1, uint32_t& e1) {
           const int z = z0 + ri / ys, y = y0 + ri % ys;
           const int row = (z * ny + y) * nx;
           const bool shell = (abs(z - gv.cz) == r) || (abs(y - gv.cy) == r);
+          b1 = e1 = 0;
           if (shell)
-            scan_range(ks, gv.sorted, gv.cell_start[row + x0], gv.cell_start[row + x1 + 1], 1u, qx, qy, qz);
+          {
+            b0 = gv.cell_start[row + x0];
+            e0 = gv.cell_start[row + x1 + 1];
+          }
           else
           {
-            if (gv.cx - r >= 0) scan_range(ks, gv.sorted, gv.cell_start[row + gv.cx - r], gv.cell_start[row + gv.cx - r + 1], 1u, qx, qy, qz);
-            if (gv.cx + r < nx) scan_range(ks, gv.sorted, gv.cell_start[row + gv.cx + r], gv.cell_start[row + gv.cx + r + 1], 1u, qx, qy, qz);
+            b0 = e0 = 0;
+            if (gv.cx - r >= 0) { b0 = gv.cell_start[row + gv.cx - r]; e0 = gv.cell_start[row + gv.cx - r + 1]; }
+            if (gv.cx + r < nx) { b1 = gv.cell_start[row + gv.cx + r]; e1 = gv.cell_start[row + gv.cx + r + 1]; }
           }
+        };
+        uint32_t b0 = 0, e0 = 0, b1 = 0, e1 = 0;
+        int ri = sub;
+        if (ri < nrows) row_runs(ri, b0, e0, b1, e1);
+        while (ri < nrows)
+        {
+          const int rn = ri + G / W;
+          uint32_t nb0 = 0, ne0 = 0, nb1 = 0, ne1 = 0;
+          if (rn < nrows) row_runs(rn, nb0, ne0, nb1, ne1);
+          scan_range(ks, gv.sorted, b0 + sl, e0, (uint32_t)W, qx, qy, qz);
+          scan_range(ks, gv.sorted, b1 + sl, e1, (uint32_t)W, qx, qy, qz);
+          ri = rn; b0 = nb0; e0 = ne0; b1 = nb1; e1 = ne1;
         }
         // every point closer than r cells (minus a 0.1 % guard for the float cell assignment) has been seen
         if (r >= 1)
@@ -364,61 +427,65 @@ __global__ __launch_bounds__(256) void k_knn(const float4* __restrict__ queries,
         }
         covered = (x0 == 0 && y0 == 0 && z0 == 0 && x1 == nx - 1 && y1 == ny - 1 && z1 == nz - 1);
       }
-    }
-    // wave-convergent: how many candidates of the whole group lie inside the proven radius
-    int c = done ? 0 : ks.count_below(bound2);
-    c += __shfl_xor(c, 1, kGroup);
-    c += __shfl_xor(c, 2, kGroup);
-    c += __shfl_xor(c, 4, kGroup);
-    if (!done)
-    {
-      if (covered || c >= k) done = true;
-      else if (r >= (level == 0 ? kShellCapFine : kShellCapCoarse))
+      // wave-convergent: how many candidates of the whole group lie inside the proven radius
+      int c = done ? 0 : ks.count_below(bound2);
+#pragma unroll
+      for (int mask = 1; mask < G; mask <<= 1) c += __shfl_xor(c, mask, G);
+      if (!done)
       {
-        ++level;
-        r = 0;
-        ks.init(k);
-        if (level == 1) grid_view(gv, desc + 1, cs1, sorted1, qx, qy, qz);
-        else
+        if (covered || c >= k) done = true;
+        else if (bound2 > far_d2)
         {
-          // fewer than k points within 8 coarse shells: hand the query to k_knn_sparse (a whole block
-          // scans the target) instead of letting 8 lanes stall the wave
-          if (lane == 0) slow_list[atomicAdd(slow_counter, 1)] = q;
-          deferred = true;
+          // fewer than k points inside a radius that already exceeds the rejection distance
+          far = true;
           done = true;
         }
+        else if (r >= kShellCap)
+        {
+          ++level;
+          r = 0;
+          ks.init(k);
+          if (level < LEVEL1) grid_view(gv, desc + level, gp.cell_start[level], gp.sorted[level], qx, qy, qz);
+          else
+          {
+            // not settled inside this kernel's levels: pass the query on
+            if (lane == 0) list_out[atomicAdd(count_out, 1)] = q;
+            deferred = true;
+            done = true;
+          }
+        }
+        else ++r;
       }
-      else ++r;
+      if (__all(done)) break;
     }
-    if (__all(done)) break;
-  }
-  // merge the 8 private lists (disjoint by construction) with a butterfly of shuffles
+    // merge the private lists (disjoint by construction) with a butterfly of shuffles
 #pragma unroll
-  for (int mask = 1; mask < kGroup; mask <<= 1)
-  {
-    float td[KMAX]; int ti[KMAX];
-#pragma unroll
-    for (int s = 0; s < KMAX; ++s) { td[s] = ks.d2[s]; ti[s] = ks.idx[s]; }
-#pragma unroll
-    for (int s = 0; s < KMAX; ++s)
+    for (int mask = 1; mask < G; mask <<= 1)
     {
-      const float od = __shfl_xor(td[s], mask, kGroup);
-      const int oi = __shfl_xor(ti[s], mask, kGroup);
-      if (s < k) ks.offer(od, oi);
-    }
-  }
-  if (active && lane == 0 && !deferred)
-  {
-    int cnt = 0;
+      float td[KMAX]; int ti[KMAX];
 #pragma unroll
-    for (int s = 0; s < KMAX; ++s)
-      if (s < k)
+      for (int s = 0; s < KMAX; ++s)
       {
-        knn_idx[(size_t)s * cap + q] = ks.idx[s];
-        knn_d2[(size_t)s * cap + q] = ks.d2[s];
-        if (ks.idx[s] != 0x7fffffff) ++cnt;
+        td[s] = __shfl_xor(ks.d2[s], mask, G);
+        ti[s] = __shfl_xor(ks.idx[s], mask, G);
       }
-    knn_cnt[q] = cnt;
+#pragma unroll
+      for (int s = 0; s < KMAX; ++s)
+        if (s < k) ks.offer(td[s], ti[s]);
+    }
+    if (active && lane == 0 && !deferred)
+    {
+      int cnt = 0;
+#pragma unroll
+      for (int s = 0; s < KMAX; ++s)
+        if (s < k)
+        {
+          knn_idx[(size_t)s * cap + q] = ks.idx[s];
+          knn_d2[(size_t)s * cap + q] = ks.d2[s];
+          if (ks.idx[s] != 0x7fffffff) ++cnt;
+        }
+      knn_cnt[q] = far ? kKnnFar : cnt;
+    }
   }
 }
 
@@ -450,14 +517,14 @@ __global__ __launch_bounds__(256) void k_knn_sparse(const float4* __restrict__ q
     {
       float td[KMAX]; int ti[KMAX];
 #pragma unroll
-      for (int s = 0; s < KMAX; ++s) { td[s] = ks.d2[s]; ti[s] = ks.idx[s]; }
-#pragma unroll
       for (int s = 0; s < KMAX; ++s)
       {
-        const float od = __shfl_xor(td[s], mask);
-        const int oi = __shfl_xor(ti[s], mask);
-        if (s < k) ks.offer(od, oi);
+        td[s] = __shfl_xor(ks.d2[s], mask);
+        ti[s] = __shfl_xor(ks.idx[s], mask);
       }
+#pragma unroll
+      for (int s = 0; s < KMAX; ++s)
+        if (s < k) ks.offer(td[s], ti[s]);
     }
     if ((threadIdx.x & 63) == 0)
     {
@@ -611,7 +678,9 @@ __global__ __launch_bounds__(kModelBlock) void k_model(const float4* __restrict_
       }
       else
       {
-        if (n < c.k) st = LSA_MATCH_NOT_ENOUGH_NEIGHBORS;
+        // n == kKnnFar: the target holds >= k points but the k-th nearest is beyond MaxNeighborsDistance
+        if (n == kKnnFar) st = LSA_MATCH_NEIGHBORS_TOO_FAR;
+        else if (n < c.k) st = LSA_MATCH_NOT_ENOUGH_NEIGHBORS;
         else
         {
 #pragma unroll
@@ -720,8 +789,7 @@ __device__ __forceinline__ void mv3(const double M[9], double x, double y, doubl
   oz = (M[6] * x + M[7] * y) + M[8] * z;
 }
 
-__global__ __launch_bounds__(256) void k_accumulate(AccumConst c, double* __restrict__ partials, unsigned* __restrict__ ticket,
-                                                    double* __restrict__ out)
+__global__ __launch_bounds__(256) void k_accumulate(AccumConst c, double* __restrict__ partials)
 {
   double acc[kAccumVals];
 #pragma unroll
@@ -780,36 +848,52 @@ __global__ __launch_bounds__(256) void k_accumulate(AccumConst c, double* __rest
   }
   // fixed-order reduction: wavefront shuffles, then the 4 waves through LDS
   __shared__ double wsum[4][kAccumVals];
+  // one shuffle step for all 29 values at a time: 29 independent LDS permutes in flight per step
+  // instead of 29 chains of 6 dependent ones
 #pragma unroll
-  for (int v = 0; v < kAccumVals; ++v)
+  for (int o = 32; o > 0; o >>= 1)
   {
-    double x = acc[v];
-    for (int o = 32; o > 0; o >>= 1) x += __shfl_down(x, o);
-    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6][v] = x;
+    double tmp[kAccumVals];
+#pragma unroll
+    for (int v = 0; v < kAccumVals; ++v) tmp[v] = __shfl_down(acc[v], o);
+#pragma unroll
+    for (int v = 0; v < kAccumVals; ++v) acc[v] += tmp[v];
+  }
+  if ((threadIdx.x & 63) == 0)
+  {
+#pragma unroll
+    for (int v = 0; v < kAccumVals; ++v) wsum[threadIdx.x >> 6][v] = acc[v];
   }
   __syncthreads();
   if (threadIdx.x < kAccumVals)
     partials[(size_t)blockIdx.x * kAccumVals + threadIdx.x] =
       ((wsum[0][threadIdx.x] + wsum[1][threadIdx.x]) + wsum[2][threadIdx.x]) + wsum[3][threadIdx.x];
-  // the block that arrives last folds the per-block partials, in a fixed order, in the same launch
-  __shared__ bool is_last;
-  __threadfence();
-  __syncthreads();
-  if (threadIdx.x == 0) is_last = (atomicAdd(ticket, 1u) == gridDim.x - 1);
-  __syncthreads();
-  if (!is_last) return;
-  __threadfence();
-#pragma unroll 1
-  for (int v = 0; v < kAccumVals; ++v)
+}
+
+// folds the per-block partials in a fixed order (one block: 256 partial rows x 29 values)
+__global__ __launch_bounds__(256) void k_accumulate_fold(const double* __restrict__ partials, int nblocks, double* __restrict__ out)
+{
+  __shared__ double wsum[4][kAccumVals];
+  double px[kAccumVals];
+#pragma unroll
+  for (int v = 0; v < kAccumVals; ++v) px[v] = ((int)threadIdx.x < nblocks) ? partials[(size_t)threadIdx.x * kAccumVals + v] : 0.;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1)
   {
-    double x = (threadIdx.x < gridDim.x) ? partials[(size_t)threadIdx.x * kAccumVals + v] : 0.;
-    for (int o = 32; o > 0; o >>= 1) x += __shfl_down(x, o);
-    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6][v] = x;
+    double tmp[kAccumVals];
+#pragma unroll
+    for (int v = 0; v < kAccumVals; ++v) tmp[v] = __shfl_down(px[v], o);
+#pragma unroll
+    for (int v = 0; v < kAccumVals; ++v) px[v] += tmp[v];
+  }
+  if ((threadIdx.x & 63) == 0)
+  {
+#pragma unroll
+    for (int v = 0; v < kAccumVals; ++v) wsum[threadIdx.x >> 6][v] = px[v];
   }
   __syncthreads();
   if (threadIdx.x < kAccumVals)
     out[threadIdx.x] = ((wsum[0][threadIdx.x] + wsum[1][threadIdx.x]) + wsum[2][threadIdx.x]) + wsum[3][threadIdx.x];
-  if (threadIdx.x == 0) *ticket = 0u;
 }
 
 __global__ void k_accumulate_final(const double* __restrict__ partials, int nblocks, double* __restrict__ out)
@@ -839,11 +923,11 @@ int build_grid(lsa_ctx* ctx, int ti)
   const int m = t.m;
   const int init[8] = {0x7fffffff, 0x7fffffff, 0x7fffffff, (int)0x80000000, (int)0x80000000, (int)0x80000000, 0, 0};
   LSA_HIP(ctx, hipMemcpyAsync(t.bbox_bits, init, sizeof(init), hipMemcpyHostToDevice, st));
-  ProfScope ps(ctx, "target_grid_build", (double)m * (32 + 16 + 2 * (16 + 4 + 4 + 16 + 16)));
+  ProfScope ps(ctx, "target_grid_build", (double)m * (32 + 16 + kGridLevels * (16 + 4 + 4 + 16 + 16)));
   const int gb = (m + 255) / 256;
   hipLaunchKernelGGL(k_target_prep, dim3(gb), dim3(256), 0, st, reinterpret_cast<const float4*>(t.pts), m, t.xyzl, t.bbox_bits);
   hipLaunchKernelGGL(k_grid_setup, dim3(1), dim3(1), 0, st, t.bbox_bits, m, t.cell_hint, t.desc);
-  for (int l = 0; l < 2; ++l)
+  for (int l = 0; l < kGridLevels; ++l)
   {
     GridLevel& g = t.lv[l];
     const GridDesc* d = t.desc + l;
@@ -860,16 +944,23 @@ int build_grid(lsa_ctx* ctx, int ti)
 }
 
 template <int KMAX>
-void launch_knn(lsa_ctx* ctx, const lsa_point_t* q, int nq, const Rigid& pose, int k, int type, int ti)
+void launch_knn(lsa_ctx* ctx, const lsa_point_t* q, int nq, const Rigid& pose, int k, float far_d2, int type, int ti)
 {
   Target& t = ctx->target[ti];
   MatchBuf& mb = ctx->match[type];
-  const int threads = nq * kGroup;
-  hipLaunchKernelGGL((k_knn<KMAX>), dim3((threads + 255) / 256), dim3(256), 0, ctx->stream, reinterpret_cast<const float4*>(q), nq, pose, k, t.desc,
-                     t.lv[0].cell_start, t.lv[0].sorted, t.lv[1].cell_start, t.lv[1].sorted, mb.knn_idx, mb.knn_d2, mb.knn_cnt, mb.cap,
-                     ctx->hist_dev + LSA_MATCH_NSTATUS, mb.slow_list);
-  hipLaunchKernelGGL((k_knn_sparse<KMAX>), dim3(256), dim3(256), 0, ctx->stream, reinterpret_cast<const float4*>(q), pose, k, t.desc, t.lv[0].sorted,
-                     mb.knn_idx, mb.knn_d2, mb.knn_cnt, mb.cap, ctx->hist_dev + LSA_MATCH_NSTATUS, mb.slow_list);
+  GridPtrs gp;
+  for (int l = 0; l < kGridLevels; ++l) { gp.cell_start[l] = t.lv[l].cell_start; gp.sorted[l] = t.lv[l].sorted; }
+  const float4* q4 = reinterpret_cast<const float4*>(q);
+  int* cntA = ctx->hist_dev + LSA_MATCH_NSTATUS;  // queries handed from the fine to the coarse kernel
+  int* cntB = cntA + 1;                           // ... from the coarse kernel to the exhaustive one
+  int* listA = mb.slow_list;
+  int* listB = mb.slow_list + mb.cap;
+  hipLaunchKernelGGL((k_knn<KMAX, 8, 1, 0, 1>), dim3((nq * 8 + 255) / 256), dim3(256), 0, ctx->stream, q4, nq, (const int*)nullptr, (const int*)nullptr,
+                     pose, k, far_d2, t.desc, gp, mb.knn_idx, mb.knn_d2, mb.knn_cnt, mb.cap, cntA, listA);
+  hipLaunchKernelGGL((k_knn<KMAX, 64, 8, 1, kGridLevels>), dim3(512), dim3(256), 0, ctx->stream, q4, nq, (const int*)listA, (const int*)cntA, pose, k,
+                     far_d2, t.desc, gp, mb.knn_idx, mb.knn_d2, mb.knn_cnt, mb.cap, cntB, listB);
+  hipLaunchKernelGGL((k_knn_sparse<KMAX>), dim3(256), dim3(256), 0, ctx->stream, q4, pose, k, t.desc, t.lv[0].sorted, mb.knn_idx, mb.knn_d2,
+                     mb.knn_cnt, mb.cap, (const int*)cntB, (const int*)listB);
 }
 
 template <int KMAX, int TYPE>
@@ -989,8 +1080,13 @@ int lsa_match(lsa_ctx* ctx, int slot, int type, int query_set, const lsa_match_p
   if (!mc.bad_param)
   {
     ProfScope ps(ctx, type == LSA_EDGE ? "knn_edge" : type == LSA_PLANE ? "knn_plane" : "knn_blob", (double)nq * (32 + mc.k * 16 + mc.k * 8));
-    if (mc.k <= 8) launch_knn<8>(ctx, q, nq, rp, mc.k, type, ti);
-    else launch_knn<16>(ctx, q, nq, rp, mc.k, type, ti);
+    // planes and blobs use all k neighbours and reject the match when the k-th is too far: the search may
+    // stop as soon as that is certain (and the target is known to hold at least k points).  Edge matches
+    // filter their neighbours first, so they need the true k nearest whatever the distance.
+    float far_d2 = INFINITY;
+    if (type != LSA_EDGE && t.m >= mc.k) far_d2 = (float)(mc.max_dist2 * 1.0001);
+    if (mc.k <= 8) launch_knn<8>(ctx, q, nq, rp, mc.k, far_d2, type, ti);
+    else launch_knn<16>(ctx, q, nq, rp, mc.k, far_d2, type, ti);
   }
   {
     ProfScope ps(ctx, type == LSA_EDGE ? "model_edge" : type == LSA_PLANE ? "model_plane" : "model_blob",
@@ -1080,8 +1176,8 @@ int lsa_accumulate(lsa_ctx* ctx, unsigned type_mask, const double w[6], int want
   hipStream_t st = ctx->stream;
   {
     ProfScope ps(ctx, want_jacobian ? "accumulate_jac" : "accumulate_cost", (double)total * (want_jacobian ? 129 : 129));
-    hipLaunchKernelGGL(k_accumulate, dim3(kAccumBlocks), dim3(256), 0, st, c, ctx->partials, reinterpret_cast<unsigned*>(ctx->reduce_out + 32),
-                       ctx->reduce_out);
+    hipLaunchKernelGGL(k_accumulate, dim3(kAccumBlocks), dim3(256), 0, st, c, ctx->partials);
+    hipLaunchKernelGGL(k_accumulate_fold, dim3(1), dim3(256), 0, st, ctx->partials, kAccumBlocks, ctx->reduce_out);
   }
   double* hp = ctx->host_pinned + 64;
   LSA_HIP(ctx, hipMemcpyAsync(hp, ctx->reduce_out, kAccumVals * sizeof(double), hipMemcpyDeviceToHost, st));

@@ -1,0 +1,40 @@
+// Minimal caller written against the reference's C++ API (LidarSlam::Slam::AddFrame /
+// GetWorldTransform), linked with liblidarslam_amd.so instead of libLidarSlam.
+//   g++ -std=c++17 -Iinclude -Ilidarslam_amd/include examples/slam_example.cpp \
+//       -Llidarslam_amd -llidarslam_amd -Wl,-rpath,$PWD/lidarslam_amd -o slam_example
+//   ./slam_example [model=16] [frames=5]      prints "frame x y z" of every pose
+#include <cstdio>
+#include <cstdlib>
+#include "LidarSlam/Slam.h"
+
+int main(int argc, char** argv)
+{
+  const int model = argc > 1 ? std::atoi(argv[1]) : 16;
+  const int nframes = argc > 2 ? std::atoi(argv[2]) : 5;
+  try
+  {
+    LidarSlam::Slam slam;
+    slam.SetEgoMotion(LidarSlam::EgoMotionMode::MOTION_EXTRAPOLATION_AND_REGISTRATION);
+    slam.SetNbThreads(4);  // accepted and ignored
+    for (int f = 0; f < nframes; ++f)
+    {
+      LidarSlam::Slam::PointCloud::Ptr pc(new LidarSlam::Slam::PointCloud);
+      pc->points.resize(1 << 19);
+      std::uint64_t stamp = 0;
+      const int n = lsa_synth_frame(model, 1000, f, reinterpret_cast<lsa_point_t*>(pc->points.data()), (int)pc->points.size(), &stamp);
+      if (n < 0) return 2;
+      pc->points.resize(n);
+      pc->header.stamp = stamp;
+      pc->header.seq = f;
+      slam.AddFrame(pc);
+      const LidarSlam::Transform T = slam.GetWorldTransform();
+      std::printf("%d %.12f %.12f %.12f %d\n", f, T.x(), T.y(), T.z(), (int)slam.GetKeypoints(LidarSlam::PLANE)->size());
+    }
+  }
+  catch (const std::exception& e)
+  {
+    std::fprintf(stderr, "%s\n", e.what());
+    return 1;
+  }
+  return 0;
+}

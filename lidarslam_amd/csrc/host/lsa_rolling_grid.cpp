@@ -155,9 +155,16 @@ void RollingGrid::Add(const PointCloud& pointcloud, bool fixed, double currentTi
   float origin[3];
   this->GridOrigin(origin);
 
-  std::unordered_map<int, std::unordered_map<int, bool>> seen;
+  // The reference tracks "first time this leaf voxel is touched by this call" in a map of maps
+  // (`seen`, RollingGrid.cxx:183) and reaches the voxel through Voxels[idxOut][idxIn] four times per
+  // point; here the voxel remembers the serial of the last Add that touched it and is looked up once.
+  // Insertions happen at the same moments (outer voxel on first use, then the leaf), so the iteration
+  // order of both maps -- and with it the order of the sub-map points -- is unchanged.
+  const unsigned int serial = ++AddSerial;
   std::unordered_map<int, std::unordered_map<int, Voxel>> meanPts;
   bool updated = false;
+  int lastOut = -1;
+  SamplingVG* outer = nullptr;
   for (const lsa_point_t& point : pointcloud)
   {
     const float p[3] = {point.x, point.y, point.z};
@@ -168,17 +175,23 @@ void RollingGrid::Add(const PointCloud& pointcloud, bool fixed, double currentTi
     for (int i = 0; i < 3; ++i) centerIn[i] = static_cast<float>(vo[i]) * res + origin[i];
     int vi[3];
     ToVoxel(p, centerIn, LeafSize, vi);
-    const unsigned int idxOut = this->To1d(vo);
-    const unsigned int idxIn = this->To1d(vi);
-    if (!Voxels.count(idxOut) || !Voxels[idxOut].count(idxIn))
+    const int idxOut = this->To1d(vo);
+    const int idxIn = this->To1d(vi);
+    if (idxOut != lastOut || !outer)
     {
-      Voxels[idxOut][idxIn].point = point;
+      outer = &Voxels[idxOut];  // inserts the outer voxel when it is new, exactly as Voxels[idxOut][idxIn] would
+      lastOut = idxOut;
+    }
+    auto ins = outer->emplace(idxIn, Voxel());
+    Voxel& voxel = ins.first->second;
+    if (ins.second)
+    {
+      voxel.point = point;
       ++NbPoints;
       updated = true;
     }
     else
     {
-      Voxel& voxel = Voxels[idxOut][idxIn];
       if (voxel.point.label == 1) continue;  // fixed map point
       switch (Sampling)
       {
@@ -224,20 +237,19 @@ void RollingGrid::Add(const PointCloud& pointcloud, bool fixed, double currentTi
       for (auto& mo : meanPts)
         for (auto& mi : mo.second)
         {
-          Voxel& voxel = Voxels[mo.first][mi.first];
-          const float k = static_cast<float>(voxel.count), k1 = static_cast<float>(voxel.count + 1);
-          voxel.point.x = (voxel.point.x * k + mi.second.point.x) / k1;
-          voxel.point.y = (voxel.point.y * k + mi.second.point.y) / k1;
-          voxel.point.z = (voxel.point.z * k + mi.second.point.z) / k1;
+          Voxel& vx = Voxels[mo.first][mi.first];
+          const float k = static_cast<float>(vx.count), k1 = static_cast<float>(vx.count + 1);
+          vx.point.x = (vx.point.x * k + mi.second.point.x) / k1;
+          vx.point.y = (vx.point.y * k + mi.second.point.y) / k1;
+          vx.point.z = (vx.point.z * k + mi.second.point.z) / k1;
         }
     }
-    Voxel& voxel = Voxels[idxOut][idxIn];
     voxel.point.time = currentTime;
     voxel.point.label = fixed ? 1 : 0;
-    if (!seen.count(idxOut) || !seen[idxOut].count(idxIn))
+    if (voxel.seen != serial)
     {
       ++voxel.count;
-      seen[idxOut][idxIn] = true;
+      voxel.seen = serial;
     }
   }
   if (updated) SubMapValid = false;  // KdTree.Reset() in the reference

@@ -26,6 +26,7 @@ public:
   {
     lsa_point_t point{};
     unsigned int count = 0;
+    unsigned int seen = 0;  // serial of the last Add() that touched this voxel (replaces the reference's `seen` maps)
   };
   using SamplingVG = std::unordered_map<int, Voxel>;
   using RollingVG = std::unordered_map<int, SamplingVG>;
@@ -69,6 +70,7 @@ private:
   RollingVG Voxels;
   float VoxelGridPosition[3] = {0.f, 0.f, 0.f};
   unsigned int NbPoints = 0;
+  unsigned int AddSerial = 0;
   PointCloud SubMap;
   bool SubMapValid = false;
   unsigned int MinFramesPerVoxel = 0;

@@ -220,7 +220,7 @@ int SlamCore::ComputeEgoMotion()
   // kd-trees on the previous frame's raw keypoints -> device search grids, no PCIe traffic
   for (int k : {LSA_EDGE, LSA_PLANE})
   {
-    lsa_set_target_cell_size(Ctx, LSA_TARGET_PREVIOUS, k, static_cast<float>(KnnCellSizeEgoMotion));
+    lsa_set_target_cell_size(Ctx, LSA_TARGET_PREVIOUS, k, static_cast<float>(k == LSA_EDGE ? KnnCellSizeEgoMotionEdges : KnnCellSizeEgoMotion));
     LSA_TRY(lsa_set_target_from_set(Ctx, LSA_TARGET_PREVIOUS, k, LSA_SET_RAW_PREVIOUS));
   }
   TotalMatchedKeypoints = 0;
@@ -299,7 +299,7 @@ int SlamCore::Localization()
       }
       const auto& sub = LocalMaps[k]->GetSubMap();
       // the map holds one point per leaf voxel: a search cell of about one leaf keeps a handful of candidates per cell
-      lsa_set_target_cell_size(Ctx, LSA_TARGET_MAP, k, static_cast<float>(KnnCellScaleMaps * LocalMaps[k]->GetLeafSize()));
+      lsa_set_target_cell_size(Ctx, LSA_TARGET_MAP, k, static_cast<float>((k == LSA_EDGE ? KnnCellScaleMapsEdges : KnnCellScaleMaps) * LocalMaps[k]->GetLeafSize()));
       LSA_TRY(lsa_set_target(Ctx, LSA_TARGET_MAP, k, sub.data(), static_cast<int>(sub.size())));
     }
     Stats.submap += t.Stop();
@@ -515,7 +515,9 @@ int SlamCore::GetRegisteredFrame(std::vector<lsa_point_t>& out)
   X("KfAngleThreshold", KfAngleThreshold, double)                                                      \
   X("KeepMatchDebug", KeepMatchDebug, bool)                                                            \
   X("KnnCellSizeEgoMotion", KnnCellSizeEgoMotion, double)                                              \
-  X("KnnCellScaleMaps", KnnCellScaleMaps, double)                                                            \
+  X("KnnCellScaleMaps", KnnCellScaleMaps, double)                                                      \
+  X("KnnCellSizeEgoMotionEdges", KnnCellSizeEgoMotionEdges, double)                                    \
+  X("KnnCellScaleMapsEdges", KnnCellScaleMapsEdges, double)                                                            \
   X("NeighborWidth", ExtractParams.neighbor_width, int)                                                \
   X("MinDistanceToSensor", ExtractParams.min_distance_to_sensor, float)                                \
   X("MinBeamSurfaceAngle", ExtractParams.min_beam_surface_angle, float)                                \

@@ -97,8 +97,10 @@ public:
   Pose BaseToLidarOffset = Pose::Identity();
   lsa_extract_params_t ExtractParams;
   // edge length of the finest kNN search-grid cells (an implementation knob: results do not depend on it)
-  double KnnCellSizeEgoMotion = 0.25; // [m] previous-scan targets
-  double KnnCellScaleMaps = 1.0;      // x map leaf size, sub-map targets
+  double KnnCellSizeEgoMotion = 0.25;      // [m] previous-scan plane targets (dense)
+  double KnnCellSizeEgoMotionEdges = 0.5;  // [m] previous-scan edge targets (sparse)
+  double KnnCellScaleMaps = 1.0;           // x map leaf size, plane / blob sub-maps
+  double KnnCellScaleMapsEdges = 2.5;      // x map leaf size, edge sub-maps
   bool KeepMatchDebug = false;  // download MatchingResults::Rejections/Weights every frame (Slam::GetDebugArray)
 
   std::shared_ptr<RollingGrid> LocalMaps[3];

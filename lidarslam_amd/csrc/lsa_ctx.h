@@ -136,6 +136,8 @@ struct lsa_ctx
   double* partials = nullptr;  // [kAccumBlocks][kAccumVals]
   double* reduce_out = nullptr;
   double* host_pinned = nullptr;  // >= 64 doubles, pinned
+  double* mailbox = nullptr;      // coherent host memory the fold kernel writes directly: [0..28] values, [32] sequence flag
+  unsigned long long mailbox_seq = 0;
   int* hist_dev = nullptr;        // [8] + slow-query counter
   void* scratch_out = nullptr;    // device staging for transformed downloads
   size_t scratch_cap = 0;

@@ -227,6 +227,10 @@ int lsa_ctx_create(int device_id, lsa_ctx** out)
   ok &= hipMalloc((void**)&ctx->hist_dev, 16 * sizeof(int)) == hipSuccess;
   ok &= hipMalloc((void**)&ctx->range_bits, 16 * sizeof(unsigned long long)) == hipSuccess;
   ok &= hipHostMalloc((void**)&ctx->host_pinned, 256 * sizeof(double), hipHostMallocDefault) == hipSuccess;
+  if (hipHostMalloc((void**)&ctx->mailbox, 64 * sizeof(double), hipHostMallocCoherent | hipHostMallocMapped) == hipSuccess)
+    std::memset(ctx->mailbox, 0, 64 * sizeof(double));
+  else
+    ctx->mailbox = nullptr;  // optional: lsa_accumulate falls back to a copy + synchronise
   if (!ok) { lsa_ctx_destroy(ctx); return LSA_E_HIP; }
   *out = ctx;
   return LSA_OK;
@@ -258,6 +262,7 @@ void lsa_ctx_destroy(lsa_ctx* ctx)
   fr(ctx->partials); fr(ctx->reduce_out); fr(ctx->hist_dev); fr(ctx->scratch_out); fr(ctx->range_bits);
   for (auto& s : ctx->store) fr(s.first);
   if (ctx->host_pinned) (void)hipHostFree(ctx->host_pinned);
+  if (ctx->mailbox) (void)hipHostFree(ctx->mailbox);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }

@@ -21,6 +21,7 @@
 // kNN order: ascending (float squared distance, target index); the distance is evaluated exactly like
 // nanoflann's L2_Simple_Adaptor: ((dx*dx)+dy*dy)+dz*dz with d = query - point.
 #include <cfloat>
+#include <chrono>
 #include <cmath>
 #include "lsa_ctx.h"
 #include "lsa_device_math.h"
@@ -212,7 +213,6 @@ __global__ __launch_bounds__(256) void k_grid_scatter(const float4* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------
-constexpr int kGroup = 8;         // lanes cooperating on one query
 
 // private top-k of one lane, ascending (distance, index); empty slots hold (+inf, INT_MAX)
 template <int KMAX> struct KnnSet
@@ -374,8 +374,9 @@ __global__ __launch_bounds__(256) void k_knn(const float4* __restrict__ queries,
     ks.init(k);
     GridView gv;
     grid_view(gv, desc + LEVEL0, gp.cell_start[LEVEL0], gp.sorted[LEVEL0], qx, qy, qz);
-    int level = LEVEL0, r = 0;
-    bool done = !active, deferred = false, far = false;
+    // the first round takes shells 0 and 1 together (the 3x3x3 block around the query): one round trip less
+    int level = LEVEL0, r = 1;
+    bool done = !active, deferred = false, far = false, first = true;
     while (true)
     {
       float bound2 = -1.f;
@@ -393,7 +394,7 @@ __global__ __launch_bounds__(256) void k_knn(const float4* __restrict__ queries,
         auto row_runs = [&](int ri, uint32_t& b0, uint32_t& e0, uint32_t& b1, uint32_t& e1) {
           const int z = z0 + ri / ys, y = y0 + ri % ys;
           const int row = (z * ny + y) * nx;
-          const bool shell = (abs(z - gv.cz) == r) || (abs(y - gv.cy) == r);
+          const bool shell = first || (abs(z - gv.cz) == r) || (abs(y - gv.cy) == r);
           b1 = e1 = 0;
           if (shell)
           {
@@ -443,7 +444,8 @@ __global__ __launch_bounds__(256) void k_knn(const float4* __restrict__ queries,
         else if (r >= kShellCap)
         {
           ++level;
-          r = 0;
+          r = 1;
+          first = true;
           ks.init(k);
           if (level < LEVEL1) grid_view(gv, desc + level, gp.cell_start[level], gp.sorted[level], qx, qy, qz);
           else
@@ -454,7 +456,7 @@ __global__ __launch_bounds__(256) void k_knn(const float4* __restrict__ queries,
             done = true;
           }
         }
-        else ++r;
+        else { ++r; first = false; }
       }
       if (__all(done)) break;
     }
@@ -871,7 +873,8 @@ __global__ __launch_bounds__(256) void k_accumulate(AccumConst c, double* __rest
 }
 
 // folds the per-block partials in a fixed order (one block: 256 partial rows x 29 values)
-__global__ __launch_bounds__(256) void k_accumulate_fold(const double* __restrict__ partials, int nblocks, double* __restrict__ out)
+__global__ __launch_bounds__(256) void k_accumulate_fold(const double* __restrict__ partials, int nblocks, double* __restrict__ out,
+                                                         double* __restrict__ mailbox, unsigned long long seq)
 {
   __shared__ double wsum[4][kAccumVals];
   double px[kAccumVals];
@@ -893,7 +896,20 @@ __global__ __launch_bounds__(256) void k_accumulate_fold(const double* __restric
   }
   __syncthreads();
   if (threadIdx.x < kAccumVals)
-    out[threadIdx.x] = ((wsum[0][threadIdx.x] + wsum[1][threadIdx.x]) + wsum[2][threadIdx.x]) + wsum[3][threadIdx.x];
+  {
+    const double r = ((wsum[0][threadIdx.x] + wsum[1][threadIdx.x]) + wsum[2][threadIdx.x]) + wsum[3][threadIdx.x];
+    out[threadIdx.x] = r;
+    // zero-copy hand-over: the 29 doubles land in coherent host memory, then the sequence number that
+    // the host is polling -- no D2H copy, no stream synchronisation on the LM critical path
+    if (mailbox) __hip_atomic_store(&mailbox[threadIdx.x], r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  if (mailbox)
+  {
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0)
+      __hip_atomic_store(reinterpret_cast<unsigned long long*>(mailbox + 32), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 }
 
 __global__ void k_accumulate_final(const double* __restrict__ partials, int nblocks, double* __restrict__ out)
@@ -1085,7 +1101,8 @@ int lsa_match(lsa_ctx* ctx, int slot, int type, int query_set, const lsa_match_p
     // filter their neighbours first, so they need the true k nearest whatever the distance.
     float far_d2 = INFINITY;
     if (type != LSA_EDGE && t.m >= mc.k) far_d2 = (float)(mc.max_dist2 * 1.0001);
-    if (mc.k <= 8) launch_knn<8>(ctx, q, nq, rp, mc.k, far_d2, type, ti);
+    if (mc.k <= 5) launch_knn<5>(ctx, q, nq, rp, mc.k, far_d2, type, ti);  // planes: 5 neighbours, fewer registers, more waves in flight
+    else if (mc.k <= 8) launch_knn<8>(ctx, q, nq, rp, mc.k, far_d2, type, ti);
     else launch_knn<16>(ctx, q, nq, rp, mc.k, far_d2, type, ti);
   }
   {
@@ -1177,11 +1194,34 @@ int lsa_accumulate(lsa_ctx* ctx, unsigned type_mask, const double w[6], int want
   {
     ProfScope ps(ctx, want_jacobian ? "accumulate_jac" : "accumulate_cost", (double)total * (want_jacobian ? 129 : 129));
     hipLaunchKernelGGL(k_accumulate, dim3(kAccumBlocks), dim3(256), 0, st, c, ctx->partials);
-    hipLaunchKernelGGL(k_accumulate_fold, dim3(1), dim3(256), 0, st, ctx->partials, kAccumBlocks, ctx->reduce_out);
+    hipLaunchKernelGGL(k_accumulate_fold, dim3(1), dim3(256), 0, st, ctx->partials, kAccumBlocks, ctx->reduce_out, ctx->mailbox, ++ctx->mailbox_seq);
   }
   double* hp = ctx->host_pinned + 64;
-  LSA_HIP(ctx, hipMemcpyAsync(hp, ctx->reduce_out, kAccumVals * sizeof(double), hipMemcpyDeviceToHost, st));
-  LSA_HIP(ctx, hipStreamSynchronize(st));
+  bool got = false;
+  if (ctx->mailbox)
+  {
+    // poll the mailbox (bounded: fall back to a synchronous copy if the flag does not arrive)
+    volatile unsigned long long* flag = reinterpret_cast<volatile unsigned long long*>(ctx->mailbox + 32);
+    const auto t0 = std::chrono::steady_clock::now();
+    unsigned spins = 0;
+    while (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != ctx->mailbox_seq)
+    {
+      if ((++spins & 0x3ff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) break;
+#if defined(__x86_64__)
+      __builtin_ia32_pause();
+#endif
+    }
+    if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == ctx->mailbox_seq)
+    {
+      for (int v = 0; v < kAccumVals; ++v) hp[v] = ctx->mailbox[v];
+      got = true;
+    }
+  }
+  if (!got)
+  {
+    LSA_HIP(ctx, hipMemcpyAsync(hp, ctx->reduce_out, kAccumVals * sizeof(double), hipMemcpyDeviceToHost, st));
+    LSA_HIP(ctx, hipStreamSynchronize(st));
+  }
   *cost = hp[0];
   if (n_valid) *n_valid = (int)hp[28];
   if (g) for (int a = 0; a < 6; ++a) g[a] = hp[1 + a];

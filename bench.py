@@ -163,7 +163,7 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": ach / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": pmc_traffic(dom["name"], args.model),
                 "avg_launch_us": 1e3 * dom["total_ms"] / max(dom["launches"], 1),
                 "algorithmic_bytes_per_launch": dom["bytes"] / max(dom["launches"], 1),
             }
@@ -182,6 +182,29 @@ def main():
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
+
+
+# profiling scope -> device kernel, for looking a scope up in the committed PMC table
+SCOPE_KERNEL = {"knn_fine_edge": "k_knn<5, 8, 1, 0, 1>", "knn_fine_plane": "k_knn<8, 8, 1, 0, 1>", "knn_fine_blob": "k_knn<16, 8, 1, 0, 1>",
+                "knn_coarse_edge": "k_knn<5, 64, 8, 1, 3>", "accumulate": "k_accumulate", "label": "k_label"}
+
+
+def pmc_traffic(scope, model):
+    """HBM bytes per launch of the roofline kernel from the newest committed rocprofv3 --pmc table
+    (profiles/rNN_vls128_pmc_traffic.json, made by scripts/round_measure.sh + collect_profiles.py from
+    separate FETCH_SIZE and WRITE_SIZE passes of this same command).  The counters cannot be read from
+    inside the process, so this is the figure of the profiled run, or None when no table matches."""
+    import glob
+
+    if model != 128 or scope not in SCOPE_KERNEL:
+        return None
+    tabs = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_vls128_pmc_traffic.json")))
+    if not tabs:
+        return None
+    row = json.load(open(tabs[-1])).get(SCOPE_KERNEL[scope])
+    # raw counters (KiB): the gfx950 x2 FETCH correction is for 16 B/lane streaming reads; the kNN reads are
+    # gathers, so the raw figure is reported (DESIGN.md gives the corrected upper bound beside it)
+    return None if row is None else (row["fetch_kib"] + row["write_kib"]) * 1024.0
 
 
 def cpu_baseline(args, seed):

@@ -971,12 +971,22 @@ void launch_knn(lsa_ctx* ctx, const lsa_point_t* q, int nq, const Rigid& pose, i
   int* cntB = cntA + 1;                           // ... from the coarse kernel to the exhaustive one
   int* listA = mb.slow_list;
   int* listB = mb.slow_list + mb.cap;
-  hipLaunchKernelGGL((k_knn<KMAX, 8, 1, 0, 1>), dim3((nq * 8 + 255) / 256), dim3(256), 0, ctx->stream, q4, nq, (const int*)nullptr, (const int*)nullptr,
-                     pose, k, far_d2, t.desc, gp, mb.knn_idx, mb.knn_d2, mb.knn_cnt, mb.cap, cntA, listA);
-  hipLaunchKernelGGL((k_knn<KMAX, 64, 8, 1, kGridLevels>), dim3(512), dim3(256), 0, ctx->stream, q4, nq, (const int*)listA, (const int*)cntA, pose, k,
-                     far_d2, t.desc, gp, mb.knn_idx, mb.knn_d2, mb.knn_cnt, mb.cap, cntB, listB);
-  hipLaunchKernelGGL((k_knn_sparse<KMAX>), dim3(256), dim3(256), 0, ctx->stream, q4, pose, k, t.desc, t.lv[0].sorted, mb.knn_idx, mb.knn_d2,
-                     mb.knn_cnt, mb.cap, (const int*)cntB, (const int*)listB);
+  const char* nf = type == LSA_EDGE ? "knn_fine_edge" : type == LSA_PLANE ? "knn_fine_plane" : "knn_fine_blob";
+  const char* nc = type == LSA_EDGE ? "knn_coarse_edge" : type == LSA_PLANE ? "knn_coarse_plane" : "knn_coarse_blob";
+  {
+    // algorithmic bytes: query point in, k candidate points examined at least, k (index, distance) pairs out
+    ProfScope ps(ctx, nf, (double)nq * (32 + k * 16 + k * 8));
+    hipLaunchKernelGGL((k_knn<KMAX, 8, 1, 0, 1>), dim3((nq * 8 + 255) / 256), dim3(256), 0, ctx->stream, q4, nq, (const int*)nullptr,
+                       (const int*)nullptr, pose, k, far_d2, t.desc, gp, mb.knn_idx, mb.knn_d2, mb.knn_cnt, mb.cap, cntA, listA);
+  }
+  {
+    // the deferred share is only known on the device: no bytes are credited to these two stages
+    ProfScope ps(ctx, nc, 0.);
+    hipLaunchKernelGGL((k_knn<KMAX, 64, 8, 1, kGridLevels>), dim3(512), dim3(256), 0, ctx->stream, q4, nq, (const int*)listA, (const int*)cntA, pose, k,
+                       far_d2, t.desc, gp, mb.knn_idx, mb.knn_d2, mb.knn_cnt, mb.cap, cntB, listB);
+    hipLaunchKernelGGL((k_knn_sparse<KMAX>), dim3(256), dim3(256), 0, ctx->stream, q4, pose, k, t.desc, t.lv[0].sorted, mb.knn_idx, mb.knn_d2,
+                       mb.knn_cnt, mb.cap, (const int*)cntB, (const int*)listB);
+  }
 }
 
 template <int KMAX, int TYPE>
@@ -1095,7 +1105,6 @@ int lsa_match(lsa_ctx* ctx, int slot, int type, int query_set, const lsa_match_p
   const lsa_point_t* q = ctx->kp[query_set][type];
   if (!mc.bad_param)
   {
-    ProfScope ps(ctx, type == LSA_EDGE ? "knn_edge" : type == LSA_PLANE ? "knn_plane" : "knn_blob", (double)nq * (32 + mc.k * 16 + mc.k * 8));
     // planes and blobs use all k neighbours and reject the match when the k-th is too far: the search may
     // stop as soon as that is certain (and the target is known to hold at least k points).  Edge matches
     // filter their neighbours first, so they need the true k nearest whatever the distance.

@@ -1,0 +1,19 @@
+#!/bin/bash
+# End-of-round measurement on one MI355X box: bench lines for the three sensor configs, CPU baseline
+# sweeps, rocprofv3 kernel-trace summary and the two PMC passes (FETCH_SIZE / WRITE_SIZE separately).
+set -o pipefail
+mkdir -p gpurun_out/r01
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+python bench.py --steps 40 --warmup 8 > gpurun_out/r01/bench_vls128.json 2> gpurun_out/r01/bench_vls128.err; echo "bench128 rc=$?"
+python bench.py --steps 40 --warmup 8 --model 64 --cpu-frames 8 > gpurun_out/r01/bench_hdl64.json 2>/dev/null; echo "bench64 rc=$?"
+python bench.py --steps 40 --warmup 8 --model 16 --cpu-frames 20 > gpurun_out/r01/bench_vlp16.json 2>/dev/null; echo "bench16 rc=$?"
+python scripts/cpu_baseline_sweep.py 16 20 > gpurun_out/r01/cpu_sweep_vlp16.log 2>&1; echo "cpu16 rc=$?"
+python scripts/cpu_baseline_sweep.py 64 8 > gpurun_out/r01/cpu_sweep_hdl64.log 2>&1; echo "cpu64 rc=$?"
+python scripts/cpu_baseline_sweep.py 128 6 > gpurun_out/r01/cpu_sweep_vls128.log 2>&1; echo "cpu128 rc=$?"
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r01/trace -- python3 bench.py --steps 40 --warmup 8 --cpu-frames 0 > gpurun_out/r01/trace_run.log 2>&1; echo "trace rc=$?"
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/r01/pmc_fetch -- python3 bench.py --steps 10 --warmup 4 --cpu-frames 0 --no-profile > gpurun_out/r01/pmc_fetch_run.log 2>&1; echo "pmc fetch rc=$?"
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/r01/pmc_write -- python3 bench.py --steps 10 --warmup 4 --cpu-frames 0 --no-profile > gpurun_out/r01/pmc_write_run.log 2>&1; echo "pmc write rc=$?"
+find gpurun_out/r01 -name "*.csv" | head -20
+# keep the merged-back payload small: drop the per-dispatch kernel traces of the pmc runs except counter files
+find gpurun_out/r01/pmc_fetch gpurun_out/r01/pmc_write -name "*kernel_trace.csv" -delete
+ls -la gpurun_out/r01 gpurun_out/r01/*/* | head -40

@@ -153,6 +153,8 @@ def main():
             k: 1e3 * stats_acc[i] / n
             for i, k in enumerate(["total", "extract", "ego_icp", "ego_lm", "loc_icp", "loc_lm", "undistort", "submap", "maps"])
         }
+        out["stage_ms_per_frame"]["maps_wait"] = 1e3 * stats_acc[14] / n
+        out["stage_ms_per_frame"]["maps_async"] = 1e3 * stats_acc[15] / n
         if kernels:
             dom = max(kernels, key=lambda k: k["total_ms"])
             ach = dom["bytes"] / (dom["total_ms"] * 1e-3) / 1e9 if dom["total_ms"] > 0 else 0.0

@@ -193,6 +193,15 @@ int lsa_set_keypoints(lsa_ctx* ctx, int set, int type, const lsa_point_t* pts, i
 int lsa_match(lsa_ctx* ctx, int slot, int type, int query_set, const lsa_match_params_t* params, const double pose[16],
               int histogram[LSA_MATCH_NSTATUS]);
 
+/* One ICP iteration's matching step (the `for (auto k : KeypointTypes)` loops of
+ * Slam.cxx:895-912 and 1074-1091): every type in type_mask (bit k = type k) is
+ * matched as by lsa_match, the types running concurrently on the device.
+ * histograms: NULL, or [3][LSA_MATCH_NSTATUS] (rows of types outside the mask
+ * are zero).  With NULL the call only enqueues work and returns without waiting
+ * for the device; lsa_accumulate's n_valid then reports the number of matches. */
+int lsa_match_types(lsa_ctx* ctx, int slot, unsigned type_mask, int query_set, const lsa_match_params_t* params, const double pose[16],
+                    int* histograms);
+
 /* MatchingResults::Rejections / Weights of the last lsa_match of `type`
  * (exported by Slam::GetDebugArray, Slam.cxx:635-657).  records (optional,
  * may be NULL) receives 16 doubles per keypoint: A[9] row-major, P[3], X[3],
@@ -305,7 +314,8 @@ int lsa_slam_get_match_status(lsa_slam* s, int localization, int type, uint8_t* 
 /* Slam::GetDebugInformation-like counters and stage timings [s]:
  * out[0] total, [1] extract, [2] ego_icp, [3] ego_lm, [4] loc_icp, [5] loc_lm,
  * [6] undistort, [7] submap, [8] maps, [9] ego_iters, [10] loc_iters,
- * [11] lm_evals, [12] total matched, [13] keyframe counter. */
+ * [11] lm_evals, [12] total matched, [13] keyframe counter, [14] wait for the
+ * previous keyframe's asynchronous map insertion, [15] duration of that insertion. */
 int lsa_slam_get_stats(const lsa_slam* s, double out[16]);
 lsa_ctx* lsa_slam_context(lsa_slam* s);
 

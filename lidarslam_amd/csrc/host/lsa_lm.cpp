@@ -132,6 +132,13 @@ int LocalOptimizer::Solve(SolveSummary& sum)
   Eval cur;
   int rc = evaluate(x, true, cur);
   if (rc) return rc;
+  sum.num_matches = cur.nValid;
+  if (static_cast<unsigned>(cur.nValid) < MinMatches)
+  {
+    sum.skipped = true;
+    sum.message = "not enough matches";
+    return LSA_OK;
+  }
   sum.initial_cost = sum.final_cost = cur.cost;
   sum.num_successful_steps = 1;  // iteration 0 is reported as a successful step by Ceres
 

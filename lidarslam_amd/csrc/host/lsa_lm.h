@@ -24,6 +24,8 @@ struct SolveSummary
   int num_iterations = 0;
   int num_evaluations = 0;
   double initial_cost = 0., final_cost = 0.;
+  int num_matches = 0;      // residual blocks (successful matches) the problem was built from
+  bool skipped = false;     // fewer than SetMinMatches(): nothing was optimised, the prior is returned
   const char* message = "";
 };
 
@@ -46,6 +48,9 @@ public:
   void SetPosePrior(const Pose& prior) { ToXYZRPY(prior, PoseArray); }
   // residual blocks = the device records of the last lsa_match of every type in the mask
   void UseDeviceResiduals(unsigned typeMask) { TypeMask = typeMask; }
+  // Slam.cxx:919-923 / 1098-1107 skip the optimisation when too few keypoints matched.  The count comes
+  // back with the first evaluation, so the caller does not have to read the match histograms first.
+  void SetMinMatches(unsigned n) { MinMatches = n; }
   int Solve(SolveSummary& summary);
   Pose GetOptimizedPose() const { return FromXYZRPY(PoseArray); }
   int EstimateRegistrationError(RegistrationError& err);
@@ -55,6 +60,7 @@ private:
   unsigned TypeMask = 7;
   bool TwoDMode = false;
   unsigned LMMaxIter = 15;
+  unsigned MinMatches = 0;
   double PoseArray[6] = {0, 0, 0, 0, 0, 0};
 };
 

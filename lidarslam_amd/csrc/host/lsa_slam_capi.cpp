@@ -120,7 +120,7 @@ int lsa_slam_get_stats(const lsa_slam* s, double out[16])
   const lsa::host::FrameStats& t = s->core.Stats;
   const double v[16] = {t.total, t.extract, t.ego_icp, t.ego_lm, t.loc_icp, t.loc_lm, t.undistort, t.submap, t.maps,
                         (double)t.ego_iters, (double)t.loc_iters, (double)t.lm_evals, (double)s->core.TotalMatchedKeypoints,
-                        (double)s->core.KfCounter, (double)s->core.KeypointCounts[0], (double)s->core.KeypointCounts[1]};
+                        (double)s->core.KfCounter, t.maps_wait, t.maps_async};
   std::memcpy(out, v, sizeof(v));
   return LSA_OK;
 }

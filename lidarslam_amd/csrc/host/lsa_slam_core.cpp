@@ -1,5 +1,6 @@
 // lsa_slam_core.cpp -- see lsa_slam_core.h.
 #include "lsa_slam_core.h"
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstring>
@@ -17,6 +18,47 @@ struct Tick
 };
 inline double StampToSec(uint64_t us) { return us * 1e-6; }  // Utils::PclStampToSec
 }  // namespace
+
+HostWorker::HostWorker() : T([this] { Run(); }) {}
+HostWorker::~HostWorker()
+{
+  {
+    std::lock_guard<std::mutex> l(M);
+    Quit = true;
+  }
+  Cv.notify_all();
+  T.join();
+}
+void HostWorker::Submit(std::function<void()> job)
+{
+  {
+    std::lock_guard<std::mutex> l(M);
+    Jobs.push_back(std::move(job));
+  }
+  Cv.notify_one();
+}
+void HostWorker::Wait()
+{
+  std::unique_lock<std::mutex> l(M);
+  Idle.wait(l, [this] { return Jobs.empty() && !Busy; });
+}
+void HostWorker::Run()
+{
+  std::unique_lock<std::mutex> l(M);
+  while (true)
+  {
+    Cv.wait(l, [this] { return Quit || !Jobs.empty(); });
+    if (Jobs.empty()) return;  // Quit with nothing left to do
+    std::function<void()> job = std::move(Jobs.front());
+    Jobs.pop_front();
+    Busy = true;
+    l.unlock();
+    job();
+    l.lock();
+    Busy = false;
+    if (Jobs.empty()) Idle.notify_all();
+  }
+}
 
 #define LSA_TRY(call)                          \
   do                                           \
@@ -54,6 +96,7 @@ SlamCore::SlamCore(int device)
 
 SlamCore::~SlamCore()
 {
+  WaitMaps();
   if (Ctx) lsa_ctx_destroy(Ctx);
 }
 
@@ -66,6 +109,7 @@ int SlamCore::Fail(int rc, const char* where)
 // Slam::Reset (Slam.cxx:164-210)
 void SlamCore::Reset(bool resetLog)
 {
+  WaitMaps();
   for (int k = 0; k < 3; ++k) LocalMaps[k]->Reset();
   KfLastPose = Pose::Identity();
   KfCounter = 0;
@@ -231,28 +275,26 @@ int SlamCore::ComputeEgoMotion()
     Tick ticp;
     const double iterRatio = icpIter / static_cast<double>(EgoMotionICPMaxIter - 1);
     mp.saturation_distance = (1 - iterRatio) * EgoMotionInitSaturationDistance + iterRatio * EgoMotionFinalSaturationDistance;
-    TotalMatchedKeypoints = 0;
-    for (int k : {LSA_EDGE, LSA_PLANE})
-    {
-      int hist[LSA_MATCH_NSTATUS];
-      LSA_TRY(lsa_match(Ctx, LSA_TARGET_PREVIOUS, k, LSA_SET_RAW_CURRENT, &mp, Trelative.m, hist));
-      TotalMatchedKeypoints += hist[LSA_MATCH_SUCCESS];
-    }
+    // both keypoint types are matched concurrently and nothing is read back: the number of matches
+    // arrives with the optimizer's first evaluation
+    LSA_TRY(lsa_match_types(Ctx, LSA_TARGET_PREVIOUS, (1u << LSA_EDGE) | (1u << LSA_PLANE), LSA_SET_RAW_CURRENT, &mp, Trelative.m, nullptr));
     Stats.ego_icp += ticp.Stop();
     Stats.ego_iters++;
-    if (TotalMatchedKeypoints < MinNbMatchedKeypoints) break;  // "Not enough keypoints, EgoMotion skipped for this frame."
 
     Tick tlm;
     LocalOptimizer optimizer(Ctx);
     optimizer.SetTwoDMode(TwoDMode);
     optimizer.SetPosePrior(Trelative);
     optimizer.SetLMMaxIter(EgoMotionLMMaxIter);
+    optimizer.SetMinMatches(MinNbMatchedKeypoints);
     optimizer.UseDeviceResiduals((1u << LSA_EDGE) | (1u << LSA_PLANE));
     SolveSummary summary;
     LSA_TRY(optimizer.Solve(summary));
-    Trelative = optimizer.GetOptimizedPose();
+    TotalMatchedKeypoints = summary.num_matches;
     Stats.ego_lm += tlm.Stop();
     Stats.lm_evals += summary.num_evaluations;
+    if (summary.skipped) break;  // "Not enough keypoints, EgoMotion skipped for this frame."
+    Trelative = optimizer.GetOptimizedPose();
     if (summary.num_successful_steps == 1) break;
   }
   if (KeepMatchDebug)
@@ -285,18 +327,36 @@ int SlamCore::Localization()
 
   {
     Tick t;
+    WaitMaps();  // the previous keyframe's insertion, normally long finished
+    Stats.maps_wait = t.Stop();
+    Stats.maps_async = std::max(MapJobSeconds[0], std::max(MapJobSeconds[1], MapJobSeconds[2]));
+    // sub-map extraction: bounding boxes from the device, then the three maps side by side on their workers
+    bool rebuild[3] = {false, false, false};
     for (int k = 0; k < 3; ++k)
     {
       if (!(UseKeypoints[k] && !LocalMaps[k]->IsSubMapValid())) continue;
+      rebuild[k] = true;
+      RollingGrid* map = LocalMaps[k].get();
       if (MapUpdate == MappingMode::NONE)
-        LocalMaps[k]->BuildSubMap();
+        MapWorker[k].Submit([map] { map->BuildSubMap(); });
       else
       {
-        if (LocalMaps[k]->IsTimeThreshold()) LocalMaps[k]->ClearOldPoints(CurrentTime);
         float mn[3], mx[3];
         LSA_TRY(lsa_working_bbox(Ctx, k, Tworld.m, mn, mx));
-        LocalMaps[k]->BuildSubMap(mn, mx, KeypointCounts[k] / 2);
+        const bool clear = map->IsTimeThreshold();
+        const double now = CurrentTime;
+        const int minPts = KeypointCounts[k] / 2;
+        MapWorker[k].Submit([map, clear, now, minPts, mn0 = mn[0], mn1 = mn[1], mn2 = mn[2], mx0 = mx[0], mx1 = mx[1], mx2 = mx[2]] {
+          if (clear) map->ClearOldPoints(now);
+          const float lo[3] = {mn0, mn1, mn2}, hi[3] = {mx0, mx1, mx2};
+          map->BuildSubMap(lo, hi, minPts);
+        });
       }
+    }
+    for (int k = 0; k < 3; ++k)
+    {
+      if (!rebuild[k]) continue;
+      MapWorker[k].Wait();
       const auto& sub = LocalMaps[k]->GetSubMap();
       // the map holds one point per leaf voxel: a search cell of about one leaf keeps a handful of candidates per cell
       lsa_set_target_cell_size(Ctx, LSA_TARGET_MAP, k, static_cast<float>((k == LSA_EDGE ? KnnCellScaleMapsEdges : KnnCellScaleMaps) * LocalMaps[k]->GetLeafSize()));
@@ -312,33 +372,33 @@ int SlamCore::Localization()
     Tick ticp;
     const double iterRatio = icpIter / static_cast<double>(LocalizationICPMaxIter - 1);
     mp.saturation_distance = (1 - iterRatio) * LocalizationInitSaturationDistance + iterRatio * LocalizationFinalSaturationDistance;
-    TotalMatchedKeypoints = 0;
+    unsigned mask = 0;
     for (int k = 0; k < 3; ++k)
-    {
-      int hist[LSA_MATCH_NSTATUS];
-      LSA_TRY(lsa_match(Ctx, LSA_TARGET_MAP, k, LSA_SET_WORKING, &mp, Tworld.m, hist));
-      TotalMatchedKeypoints += hist[LSA_MATCH_SUCCESS];
-    }
+      if (UseKeypoints[k]) mask |= 1u << k;
+    LSA_TRY(lsa_match_types(Ctx, LSA_TARGET_MAP, mask, LSA_SET_WORKING, &mp, Tworld.m, nullptr));
     Stats.loc_icp += ticp.Stop();
     Stats.loc_iters++;
-    if (TotalMatchedKeypoints < MinNbMatchedKeypoints)
-    {
-      // reset state to previous one to avoid instability (Slam.cxx:1098-1107)
-      Trelative = Pose::Identity();
-      Tworld = PreviousTworld;
-      if (Undistortion) Motion.SetTransforms(Pose::Identity(), Pose::Identity());
-      LastError = "Not enough keypoints matched, Localization skipped for this frame.";
-      break;
-    }
 
     Tick tlm;
     LocalOptimizer optimizer(Ctx);
     optimizer.SetTwoDMode(TwoDMode);
     optimizer.SetPosePrior(Tworld);
     optimizer.SetLMMaxIter(LocalizationLMMaxIter);
+    optimizer.SetMinMatches(MinNbMatchedKeypoints);
     optimizer.UseDeviceResiduals(7u);
     SolveSummary summary;
     LSA_TRY(optimizer.Solve(summary));
+    TotalMatchedKeypoints = summary.num_matches;
+    if (summary.skipped)
+    {
+      // reset state to previous one to avoid instability (Slam.cxx:1098-1107)
+      Trelative = Pose::Identity();
+      Tworld = PreviousTworld;
+      if (Undistortion) Motion.SetTransforms(Pose::Identity(), Pose::Identity());
+      LastError = "Not enough keypoints matched, Localization skipped for this frame.";
+      Stats.loc_lm += tlm.Stop();
+      break;
+    }
     Stats.lm_evals += summary.num_evaluations;
     Tworld = optimizer.GetOptimizedPose();
     Trelative = Inverse(PreviousTworld) * Tworld;
@@ -372,6 +432,7 @@ int SlamCore::UpdateMapsUsingTworld()
   const double trans = std::sqrt((motion(0, 3) * motion(0, 3) + motion(1, 3) * motion(1, 3)) + motion(2, 3) * motion(2, 3));
   const double rot = RotationAngle(motion);
   constexpr double MIN_KF_NB = 10.;
+  WaitMaps();
   const double thresholdCoef = std::min(KfCounter / MIN_KF_NB, 1.);
   unsigned nbMapKpts = 0;
   for (int k = 0; k < 3; ++k) nbMapKpts += LocalMaps[k]->Size();
@@ -380,13 +441,22 @@ int SlamCore::UpdateMapsUsingTworld()
   if (!isNewKeyFrame) return LSA_OK;
   KfCounter++;
   KfLastPose = Tworld;
+  for (double& v : MapJobSeconds) v = 0.;
   for (int k = 0; k < 3; ++k)
   {
     if (!UseKeypoints[k]) continue;
     const int n = lsa_keypoint_count(Ctx, LSA_SET_WORKING, k);
-    Scratch.resize(std::max(n, 0));
-    if (n > 0) LSA_TRY(lsa_download_transformed(Ctx, LSA_SET_WORKING, k, Tworld.m, Scratch.data(), n));
-    LocalMaps[k]->Add(Scratch, false, CurrentTime);
+    MapInbox[k].resize(std::max(n, 0));
+    if (n > 0) LSA_TRY(lsa_download_transformed(Ctx, LSA_SET_WORKING, k, Tworld.m, MapInbox[k].data(), n));
+    RollingGrid* map = LocalMaps[k].get();
+    const std::vector<lsa_point_t>* cloud = &MapInbox[k];
+    const double time = CurrentTime;
+    double* spent = &MapJobSeconds[k];
+    MapWorker[k].Submit([map, cloud, time, spent] {
+      Tick t;
+      map->Add(*cloud, false, time);
+      *spent += t.Stop();
+    });
   }
   return LSA_OK;
 }
@@ -530,6 +600,7 @@ int SlamCore::GetRegisteredFrame(std::vector<lsa_point_t>& out)
 
 int SlamCore::SetParam(const std::string& name, double v)
 {
+  WaitMaps();
 #define X(NAME, MEMBER, TYPE) if (name == NAME) { MEMBER = static_cast<TYPE>(v); return LSA_OK; }
   LSA_PARAMS(X)
 #undef X

@@ -8,9 +8,13 @@
 // keypoint runs on the device through lidarslam_amd.h.
 #pragma once
 #include <array>
+#include <condition_variable>
 #include <deque>
+#include <functional>
 #include <memory>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 #include "../../../include/lidarslam_amd.h"
 #include "lsa_hostmath.h"
@@ -36,12 +40,36 @@ struct FrameStats
 {
   double total = 0, extract = 0, ego_icp = 0, ego_lm = 0, loc_icp = 0, loc_lm = 0, undistort = 0, submap = 0, maps = 0;
   int ego_iters = 0, loc_iters = 0, lm_evals = 0;
+  double maps_wait = 0;   // time this frame waited for the previous keyframe's map insertion
+  double maps_async = 0;  // duration of that insertion on the worker thread
 };
 
 struct MatchDebug
 {
   std::vector<uint8_t> status;
   std::vector<double> weights;
+};
+
+// One persistent host thread that runs jobs in submission order.  Each map has one: the keyframe's
+// insertion (RollingGrid::Add, hash-map bound) is handed to it at the end of AddFrame and overlaps the next
+// frame's keypoint extraction and ego-motion ICP on the device, and the sub-maps of the three keypoint
+// types are extracted side by side.  Wait() is called before anything else reads a map.
+// Same operations in the same order on the same containers: results do not depend on the overlap.
+class HostWorker
+{
+public:
+  HostWorker();
+  ~HostWorker();
+  void Submit(std::function<void()> job);
+  void Wait();
+
+private:
+  void Run();
+  std::mutex M;
+  std::condition_variable Cv, Idle;
+  std::deque<std::function<void()>> Jobs;
+  bool Busy = false, Quit = false;
+  std::thread T;
 };
 
 class SlamCore
@@ -70,6 +98,8 @@ public:
 
   int SetParam(const std::string& name, double v);
   int GetParam(const std::string& name, double* v) const;
+  // LocalMaps[k] after every pending insertion has landed (Slam::GetMap reads through this)
+  RollingGrid& Map(int k) { WaitMaps(); return *LocalMaps[k]; }
 
   // ---- parameters (names = the reference's members) ----
   bool UseKeypoints[3] = {true, true, false};
@@ -138,6 +168,11 @@ private:
   Pose KfLastPose;
   MatchDebug EgoDebug[3], LocDebug[3];
   std::vector<lsa_point_t> Scratch;
+  // keyframe keypoints in world coordinates on their way into the maps (owned by the worker until WaitMaps)
+  std::vector<lsa_point_t> MapInbox[3];
+  double MapJobSeconds[3] = {0., 0., 0.};  // written by the workers, read after WaitMaps
+  HostWorker MapWorker[3];                  // one per map: the three rolling grids are independent
+  void WaitMaps() { for (auto& w : MapWorker) w.Wait(); }
 };
 
 }  // namespace host

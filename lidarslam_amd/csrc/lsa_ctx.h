@@ -65,6 +65,7 @@ struct Target
   int m = 0;
   int cap = 0;
   float cell_hint = 1.0f;
+  bool dirty = false;           // points changed, search grid not rebuilt yet
 };
 
 struct MatchBuf
@@ -138,7 +139,12 @@ struct lsa_ctx
   double* host_pinned = nullptr;  // >= 64 doubles, pinned
   double* mailbox = nullptr;      // coherent host memory the fold kernel writes directly: [0..28] values, [32] sequence flag
   unsigned long long mailbox_seq = 0;
-  int* hist_dev = nullptr;        // [8] + slow-query counter
+  int* hist_dev = nullptr;        // per match type 16 ints: [8] rejection histogram + 2 hand-over counters of the kNN cascade
+  int last_match_type = 0;
+  // lsa_match_types: the keypoint types of one ICP iteration are matched concurrently, the first on
+  // `stream`, the others on these, forked and joined with events (no host synchronisation)
+  hipStream_t side_stream[2] = {nullptr, nullptr};
+  hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
   void* scratch_out = nullptr;    // device staging for transformed downloads
   size_t scratch_cap = 0;
   unsigned long long* range_bits = nullptr;  // time range / bbox reductions
@@ -177,7 +183,8 @@ struct ProfScope
   lsa_ctx* ctx;
   int stat = -1;
   hipEvent_t a = nullptr, b = nullptr;
-  ProfScope(lsa_ctx* c, const char* name, double bytes);
+  hipStream_t st = nullptr;
+  ProfScope(lsa_ctx* c, const char* name, double bytes, hipStream_t stream = nullptr);
   ~ProfScope();
 };
 void profile_collect(lsa_ctx* ctx);

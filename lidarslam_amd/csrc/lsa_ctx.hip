@@ -61,6 +61,9 @@ int ensure_target(lsa_ctx* ctx, int ti, int m)
     }
     LSA_HIP(ctx, dev_alloc(&t.desc, kGridLevels));
     LSA_HIP(ctx, dev_alloc(&t.bbox_bits, 8));
+    // armed once here, re-armed by k_grid_setup after every build
+    const int init[8] = {0x7fffffff, 0x7fffffff, 0x7fffffff, (int)0x80000000, (int)0x80000000, (int)0x80000000, 0, 0};
+    LSA_HIP(ctx, hipMemcpy(t.bbox_bits, init, sizeof(init), hipMemcpyHostToDevice));
   }
   if (m <= t.cap) return LSA_OK;
   int cap = std::max(m + m / 4, 4096);
@@ -103,7 +106,7 @@ int ensure_scratch(lsa_ctx* ctx, size_t bytes)
   return LSA_OK;
 }
 
-ProfScope::ProfScope(lsa_ctx* c, const char* name, double bytes) : ctx(c)
+ProfScope::ProfScope(lsa_ctx* c, const char* name, double bytes, hipStream_t stream) : ctx(c), st(stream ? stream : c->stream)
 {
   if (!ctx->profiling) return;
   for (size_t i = 0; i < ctx->stats.size(); ++i)
@@ -123,12 +126,12 @@ ProfScope::ProfScope(lsa_ctx* c, const char* name, double bytes) : ctx(c)
   };
   a = get();
   b = get();
-  (void)hipEventRecord(a, ctx->stream);
+  (void)hipEventRecord(a, st);
 }
 ProfScope::~ProfScope()
 {
   if (stat < 0) return;
-  (void)hipEventRecord(b, ctx->stream);
+  (void)hipEventRecord(b, st);
   ctx->pending.push_back({stat, a, b});
 }
 void profile_collect(lsa_ctx* ctx)
@@ -216,6 +219,12 @@ int lsa_ctx_create(int device_id, lsa_ctx** out)
   ctx->device = device_id;
   if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return LSA_E_HIP; }
   bool ok = true;
+  for (int i = 0; i < 2; ++i)
+  {
+    ok &= hipStreamCreateWithFlags(&ctx->side_stream[i], hipStreamNonBlocking) == hipSuccess;
+    ok &= hipEventCreateWithFlags(&ctx->ev_join[i], hipEventDisableTiming) == hipSuccess;
+  }
+  ok &= hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) == hipSuccess;
   ok &= hipMalloc((void**)&ctx->ring_start, (kMaxRings + 1) * sizeof(int)) == hipSuccess;
   ok &= hipMalloc((void**)&ctx->ring_len, kMaxRings * sizeof(int)) == hipSuccess;
   ok &= hipMalloc((void**)&ctx->ring_meta, 8 * sizeof(int)) == hipSuccess;
@@ -224,7 +233,7 @@ int lsa_ctx_create(int device_id, lsa_ctx** out)
   ok &= hipMalloc((void**)&ctx->partials, (size_t)kAccumBlocks * kAccumVals * sizeof(double)) == hipSuccess;
   ok &= hipMalloc((void**)&ctx->reduce_out, 64 * sizeof(double)) == hipSuccess;
   if (ok) ok &= hipMemset(ctx->reduce_out, 0, 64 * sizeof(double)) == hipSuccess;  // [32] holds the arrival ticket of k_accumulate
-  ok &= hipMalloc((void**)&ctx->hist_dev, 16 * sizeof(int)) == hipSuccess;
+  ok &= hipMalloc((void**)&ctx->hist_dev, 3 * 16 * sizeof(int)) == hipSuccess;
   ok &= hipMalloc((void**)&ctx->range_bits, 16 * sizeof(unsigned long long)) == hipSuccess;
   ok &= hipHostMalloc((void**)&ctx->host_pinned, 256 * sizeof(double), hipHostMallocDefault) == hipSuccess;
   if (hipHostMalloc((void**)&ctx->mailbox, 64 * sizeof(double), hipHostMallocCoherent | hipHostMallocMapped) == hipSuccess)
@@ -241,6 +250,8 @@ void lsa_ctx_destroy(lsa_ctx* ctx)
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  for (int i = 0; i < 2; ++i)
+    if (ctx->side_stream[i]) (void)hipStreamSynchronize(ctx->side_stream[i]);
   profile_collect(ctx);
   for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
   auto fr = [](void* p) { if (p) (void)hipFree(p); };
@@ -263,6 +274,12 @@ void lsa_ctx_destroy(lsa_ctx* ctx)
   for (auto& s : ctx->store) fr(s.first);
   if (ctx->host_pinned) (void)hipHostFree(ctx->host_pinned);
   if (ctx->mailbox) (void)hipHostFree(ctx->mailbox);
+  for (int i = 0; i < 2; ++i)
+  {
+    if (ctx->ev_join[i]) (void)hipEventDestroy(ctx->ev_join[i]);
+    if (ctx->side_stream[i]) (void)hipStreamDestroy(ctx->side_stream[i]);
+  }
+  if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }

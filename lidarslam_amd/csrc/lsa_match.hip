@@ -39,15 +39,38 @@ __device__ __forceinline__ int f2o(float f)
 __device__ __forceinline__ float o2f(int i) { return __int_as_float(i >= 0 ? i : i ^ 0x7fffffff); }
 
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_target_prep(const float4* __restrict__ pts, int m, float4* __restrict__ xyzl, int* __restrict__ bbox)
+// Search-grid construction.  Every target that changed since the last match (the two previous-scan targets
+// of the ego-motion step, the two or three sub-maps after a keyframe) is built by ONE sequence of eight
+// launches: blockIdx.y selects the target (point passes) or the (target, level) pair (cell passes).
+constexpr int kBatchTargets = 6;
+struct GridBatch
 {
+  int ntargets;
+  int m[kBatchTargets];
+  float cell_hint[kBatchTargets];
+  const float4* pts[kBatchTargets];  // AoS points, two float4 per point
+  float4* xyzl[kBatchTargets];
+  int* bbox[kBatchTargets];
+  GridDesc* desc[kBatchTargets];     // [kGridLevels] each
+  uint32_t* cell_of[kBatchTargets][kGridLevels];
+  uint32_t* cell_start[kBatchTargets][kGridLevels];
+  uint32_t* cell_fill[kBatchTargets][kGridLevels];
+  uint32_t* block_sums[kBatchTargets][kGridLevels];
+  float4* sorted[kBatchTargets][kGridLevels];
+};
+
+__global__ __launch_bounds__(256) void k_target_prep(GridBatch gb)
+{
+  const int t = blockIdx.y;
+  const int m = gb.m[t];
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (blockIdx.x * blockDim.x >= m) return;
   float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
   if (i < m)
   {
-    const float4 a = pts[2 * (size_t)i];
-    const float4 b = pts[2 * (size_t)i + 1];
-    xyzl[i] = make_float4(a.x, a.y, a.z, __uint_as_float(__float_as_uint(b.w) & 0xffffu));
+    const float4 a = gb.pts[t][2 * (size_t)i];
+    const float4 b = gb.pts[t][2 * (size_t)i + 1];
+    gb.xyzl[t][i] = make_float4(a.x, a.y, a.z, __uint_as_float(__float_as_uint(b.w) & 0xffffu));
     mn[0] = mx[0] = a.x; mn[1] = mx[1] = a.y; mn[2] = mx[2] = a.z;
   }
   for (int d = 0; d < 3; ++d)
@@ -62,20 +85,23 @@ __global__ __launch_bounds__(256) void k_target_prep(const float4* __restrict__ 
   {
     for (int d = 0; d < 3; ++d)
     {
-      atomicMin(&bbox[d], f2o(mn[d]));
-      atomicMax(&bbox[3 + d], f2o(mx[d]));
+      atomicMin(&gb.bbox[t][d], f2o(mn[d]));
+      atomicMax(&gb.bbox[t][3 + d], f2o(mx[d]));
     }
   }
 }
 
 // desc[0]: cell = hint (grown until the grid fits its cell budget); every further level has cells 4 x
-// larger (grown likewise)
-__global__ void k_grid_setup(const int* __restrict__ bbox, int m, float cell_hint, GridDesc* __restrict__ desc)
+// larger (grown likewise).  One thread per target; the bounding box is re-armed for the next build.
+__global__ void k_grid_setup(GridBatch gb)
 {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const int t = blockIdx.x;
+  if (threadIdx.x != 0) return;
+  int* bbox = gb.bbox[t];
   float mn[3], mx[3];
   for (int d = 0; d < 3; ++d) { mn[d] = o2f(bbox[d]); mx[d] = o2f(bbox[3 + d]); }
-  float cell = cell_hint;
+  for (int d = 0; d < 3; ++d) { bbox[d] = 0x7fffffff; bbox[3 + d] = (int)0x80000000; }
+  float cell = gb.cell_hint[t];
   for (int level = 0; level < kGridLevels; ++level)
   {
     const double cap = (double)grid_level_cells(level);
@@ -96,8 +122,8 @@ __global__ void k_grid_setup(const int* __restrict__ bbox, int m, float cell_hin
     g.cell = cell;
     g.inv_cell = 1.0f / cell;
     g.ncells = g.dims[0] * g.dims[1] * g.dims[2];
-    g.npoints = m;
-    desc[level] = g;
+    g.npoints = gb.m[t];
+    gb.desc[t][level] = g;
   }
 }
 
@@ -107,44 +133,60 @@ __device__ __forceinline__ int cell_coord(float v, float o, float inv, int n)
   return min(max(c, 0), n - 1);
 }
 
-__global__ __launch_bounds__(256) void k_grid_zero(const GridDesc* __restrict__ desc, uint32_t* __restrict__ cell_start, uint32_t* __restrict__ cell_fill)
+__global__ __launch_bounds__(256) void k_grid_zero(GridBatch gb)
 {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const int nc = desc->ncells;
-  if (i <= nc) cell_start[i] = 0;
-  if (i < nc) cell_fill[i] = 0;
+  const int t = blockIdx.y / kGridLevels, l = blockIdx.y % kGridLevels;
+  const int nc = gb.desc[t][l].ncells;
+  const int i0 = blockIdx.x * 1024 + threadIdx.x;
+  if (blockIdx.x * 1024 > nc) return;
+  uint32_t* cs = gb.cell_start[t][l];
+  uint32_t* cf = gb.cell_fill[t][l];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+  {
+    const int i = i0 + q * 256;
+    if (i <= nc) cs[i] = 0;
+    if (i < nc) cf[i] = 0;
+  }
 }
 
-__global__ __launch_bounds__(256) void k_grid_count(const float4* __restrict__ xyzl, int m, const GridDesc* __restrict__ desc,
-                                                    uint32_t* __restrict__ cell_of, uint32_t* __restrict__ cell_start)
+// one read of the point, its cell at every level
+__global__ __launch_bounds__(256) void k_grid_count(GridBatch gb)
 {
+  const int t = blockIdx.y;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= m) return;
-  const GridDesc g = *desc;
-  const float4 p = xyzl[i];
-  const int cx = cell_coord(p.x, g.origin[0], g.inv_cell, g.dims[0]);
-  const int cy = cell_coord(p.y, g.origin[1], g.inv_cell, g.dims[1]);
-  const int cz = cell_coord(p.z, g.origin[2], g.inv_cell, g.dims[2]);
-  const uint32_t cid = (uint32_t)((cz * g.dims[1] + cy) * g.dims[0] + cx);
-  cell_of[i] = cid;
-  atomicAdd(&cell_start[cid], 1u);
+  if (i >= gb.m[t]) return;
+  const float4 p = gb.xyzl[t][i];
+#pragma unroll
+  for (int l = 0; l < kGridLevels; ++l)
+  {
+    const GridDesc g = gb.desc[t][l];
+    const int cx = cell_coord(p.x, g.origin[0], g.inv_cell, g.dims[0]);
+    const int cy = cell_coord(p.y, g.origin[1], g.inv_cell, g.dims[1]);
+    const int cz = cell_coord(p.z, g.origin[2], g.inv_cell, g.dims[2]);
+    const uint32_t cid = (uint32_t)((cz * g.dims[1] + cy) * g.dims[0] + cx);
+    gb.cell_of[t][l][i] = cid;
+    atomicAdd(&gb.cell_start[t][l][cid], 1u);
+  }
 }
 
 // exclusive scan of cell_start[0 .. ncells] in three passes (1024 elements per block)
-__global__ __launch_bounds__(256) void k_scan_block(const GridDesc* __restrict__ desc, uint32_t* __restrict__ data, uint32_t* __restrict__ sums)
+__global__ __launch_bounds__(256) void k_scan_block(GridBatch gb)
 {
   __shared__ uint32_t s[256];
-  const int total = desc->ncells + 1;
+  const int t = blockIdx.y / kGridLevels, l = blockIdx.y % kGridLevels;
+  const int total = gb.desc[t][l].ncells + 1;
   const int base = blockIdx.x * 1024;
   if (base >= total) return;
-  uint32_t v[4], t = 0;
+  uint32_t* data = gb.cell_start[t][l];
+  uint32_t v[4], tsum = 0;
   for (int q = 0; q < 4; ++q)
   {
     const int i = base + threadIdx.x * 4 + q;
     v[q] = (i < total) ? data[i] : 0;
-    t += v[q];
+    tsum += v[q];
   }
-  s[threadIdx.x] = t;
+  s[threadIdx.x] = tsum;
   __syncthreads();
   for (int o = 1; o < 256; o <<= 1)
   {
@@ -153,24 +195,26 @@ __global__ __launch_bounds__(256) void k_scan_block(const GridDesc* __restrict__
     s[threadIdx.x] += a;
     __syncthreads();
   }
-  uint32_t run = s[threadIdx.x] - t;
+  uint32_t run = s[threadIdx.x] - tsum;
   for (int q = 0; q < 4; ++q)
   {
     const int i = base + threadIdx.x * 4 + q;
     if (i < total) data[i] = run;
     run += v[q];
   }
-  if (threadIdx.x == 255) sums[blockIdx.x] = s[255];
+  if (threadIdx.x == 255) gb.block_sums[t][l][blockIdx.x] = s[255];
 }
-__global__ __launch_bounds__(1024) void k_scan_sums(const GridDesc* __restrict__ desc, uint32_t* __restrict__ sums)
+__global__ __launch_bounds__(1024) void k_scan_sums(GridBatch gb)
 {
   __shared__ uint32_t s[1024];
-  const int nb = (desc->ncells + 1 + 1023) / 1024;
+  const int t = blockIdx.x / kGridLevels, l = blockIdx.x % kGridLevels;
+  uint32_t* sums = gb.block_sums[t][l];
+  const int nb = (gb.desc[t][l].ncells + 1 + 1023) / 1024;
   const int per = (nb + 1023) / 1024;
   const int b = min(nb, (int)threadIdx.x * per), e = min(nb, b + per);
-  uint32_t t = 0;
-  for (int i = b; i < e; ++i) t += sums[i];
-  s[threadIdx.x] = t;
+  uint32_t tsum = 0;
+  for (int i = b; i < e; ++i) tsum += sums[i];
+  s[threadIdx.x] = tsum;
   __syncthreads();
   for (int o = 1; o < 1024; o <<= 1)
   {
@@ -179,7 +223,7 @@ __global__ __launch_bounds__(1024) void k_scan_sums(const GridDesc* __restrict__
     s[threadIdx.x] += a;
     __syncthreads();
   }
-  uint32_t run = s[threadIdx.x] - t;
+  uint32_t run = s[threadIdx.x] - tsum;
   for (int i = b; i < e; ++i)
   {
     uint32_t v = sums[i];
@@ -187,12 +231,14 @@ __global__ __launch_bounds__(1024) void k_scan_sums(const GridDesc* __restrict__
     run += v;
   }
 }
-__global__ __launch_bounds__(256) void k_scan_add(const GridDesc* __restrict__ desc, uint32_t* __restrict__ data, const uint32_t* __restrict__ sums)
+__global__ __launch_bounds__(256) void k_scan_add(GridBatch gb)
 {
-  const int total = desc->ncells + 1;
+  const int t = blockIdx.y / kGridLevels, l = blockIdx.y % kGridLevels;
+  const int total = gb.desc[t][l].ncells + 1;
   const int base = blockIdx.x * 1024;
   if (base >= total) return;
-  const uint32_t add = sums[blockIdx.x];
+  uint32_t* data = gb.cell_start[t][l];
+  const uint32_t add = gb.block_sums[t][l][blockIdx.x];
   for (int q = 0; q < 4; ++q)
   {
     const int i = base + threadIdx.x * 4 + q;
@@ -200,16 +246,20 @@ __global__ __launch_bounds__(256) void k_scan_add(const GridDesc* __restrict__ d
   }
 }
 
-__global__ __launch_bounds__(256) void k_grid_scatter(const float4* __restrict__ xyzl, int m, const uint32_t* __restrict__ cell_of,
-                                                      const uint32_t* __restrict__ cell_start, uint32_t* __restrict__ cell_fill,
-                                                      float4* __restrict__ sorted)
+__global__ __launch_bounds__(256) void k_grid_scatter(GridBatch gb)
 {
+  const int t = blockIdx.y;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= m) return;
-  const uint32_t cid = cell_of[i];
-  const uint32_t pos = cell_start[cid] + atomicAdd(&cell_fill[cid], 1u);
-  const float4 p = xyzl[i];
-  sorted[pos] = make_float4(p.x, p.y, p.z, __int_as_float(i));
+  if (i >= gb.m[t]) return;
+  const float4 p = gb.xyzl[t][i];
+  const float4 rec = make_float4(p.x, p.y, p.z, __int_as_float(i));
+#pragma unroll
+  for (int l = 0; l < kGridLevels; ++l)
+  {
+    const uint32_t cid = gb.cell_of[t][l][i];
+    const uint32_t pos = gb.cell_start[t][l][cid] + atomicAdd(&gb.cell_fill[t][l][cid], 1u);
+    gb.sorted[t][l][pos] = rec;
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -932,42 +982,63 @@ __global__ void k_records_to_aos(const double* __restrict__ rec, const uint8_t* 
   weights[i] = ok ? rec[(size_t)15 * cap + i] : 0.;
 }
 
-int build_grid(lsa_ctx* ctx, int ti)
+// builds the search grids of every target marked dirty, all in one sequence of launches
+int flush_grids(lsa_ctx* ctx)
 {
-  Target& t = ctx->target[ti];
-  hipStream_t st = ctx->stream;
-  const int m = t.m;
-  const int init[8] = {0x7fffffff, 0x7fffffff, 0x7fffffff, (int)0x80000000, (int)0x80000000, (int)0x80000000, 0, 0};
-  LSA_HIP(ctx, hipMemcpyAsync(t.bbox_bits, init, sizeof(init), hipMemcpyHostToDevice, st));
-  ProfScope ps(ctx, "target_grid_build", (double)m * (32 + 16 + kGridLevels * (16 + 4 + 4 + 16 + 16)));
-  const int gb = (m + 255) / 256;
-  hipLaunchKernelGGL(k_target_prep, dim3(gb), dim3(256), 0, st, reinterpret_cast<const float4*>(t.pts), m, t.xyzl, t.bbox_bits);
-  hipLaunchKernelGGL(k_grid_setup, dim3(1), dim3(1), 0, st, t.bbox_bits, m, t.cell_hint, t.desc);
-  for (int l = 0; l < kGridLevels; ++l)
+  GridBatch gb;
+  int nt = 0, max_m = 0, max_cells = 0;
+  double bytes = 0;
+  for (int ti = 0; ti < 6; ++ti)
   {
-    GridLevel& g = t.lv[l];
-    const GridDesc* d = t.desc + l;
-    const int cb = (g.max_cells + 1 + 255) / 256;
-    hipLaunchKernelGGL(k_grid_zero, dim3(cb), dim3(256), 0, st, d, g.cell_start, g.cell_fill);
-    hipLaunchKernelGGL(k_grid_count, dim3(gb), dim3(256), 0, st, t.xyzl, m, d, g.cell_of, g.cell_start);
-    const int sb = (g.max_cells + 1 + 1023) / 1024;
-    hipLaunchKernelGGL(k_scan_block, dim3(sb), dim3(256), 0, st, d, g.cell_start, g.block_sums);
-    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, st, d, g.block_sums);
-    hipLaunchKernelGGL(k_scan_add, dim3(sb), dim3(256), 0, st, d, g.cell_start, g.block_sums);
-    hipLaunchKernelGGL(k_grid_scatter, dim3(gb), dim3(256), 0, st, t.xyzl, m, g.cell_of, g.cell_start, g.cell_fill, g.sorted);
+    Target& t = ctx->target[ti];
+    if (!t.dirty) continue;
+    t.dirty = false;
+    if (t.m == 0) continue;
+    gb.m[nt] = t.m;
+    gb.cell_hint[nt] = t.cell_hint;
+    gb.pts[nt] = reinterpret_cast<const float4*>(t.pts);
+    gb.xyzl[nt] = t.xyzl;
+    gb.bbox[nt] = t.bbox_bits;
+    gb.desc[nt] = t.desc;
+    for (int l = 0; l < kGridLevels; ++l)
+    {
+      gb.cell_of[nt][l] = t.lv[l].cell_of;
+      gb.cell_start[nt][l] = t.lv[l].cell_start;
+      gb.cell_fill[nt][l] = t.lv[l].cell_fill;
+      gb.block_sums[nt][l] = t.lv[l].block_sums;
+      gb.sorted[nt][l] = t.lv[l].sorted;
+      max_cells = std::max(max_cells, t.lv[l].max_cells);
+    }
+    max_m = std::max(max_m, t.m);
+    bytes += (double)t.m * (32 + 16 + kGridLevels * (16 + 4 + 4 + 16 + 16));
+    ++nt;
   }
+  if (nt == 0) return LSA_OK;
+  gb.ntargets = nt;
+  hipStream_t st = ctx->stream;
+  ProfScope ps(ctx, "target_grid_build", bytes);
+  const int pb = (max_m + 255) / 256;
+  const int cb = (max_cells + 1 + 1023) / 1024;  // the cell passes return at once beyond a grid's own cell count
+  hipLaunchKernelGGL(k_target_prep, dim3(pb, nt), dim3(256), 0, st, gb);
+  hipLaunchKernelGGL(k_grid_setup, dim3(nt), dim3(64), 0, st, gb);
+  hipLaunchKernelGGL(k_grid_zero, dim3(cb, nt * kGridLevels), dim3(256), 0, st, gb);
+  hipLaunchKernelGGL(k_grid_count, dim3(pb, nt), dim3(256), 0, st, gb);
+  hipLaunchKernelGGL(k_scan_block, dim3(cb, nt * kGridLevels), dim3(256), 0, st, gb);
+  hipLaunchKernelGGL(k_scan_sums, dim3(nt * kGridLevels), dim3(1024), 0, st, gb);
+  hipLaunchKernelGGL(k_scan_add, dim3(cb, nt * kGridLevels), dim3(256), 0, st, gb);
+  hipLaunchKernelGGL(k_grid_scatter, dim3(pb, nt), dim3(256), 0, st, gb);
   return LSA_OK;
 }
 
 template <int KMAX>
-void launch_knn(lsa_ctx* ctx, const lsa_point_t* q, int nq, const Rigid& pose, int k, float far_d2, int type, int ti)
+void launch_knn(lsa_ctx* ctx, const lsa_point_t* q, int nq, const Rigid& pose, int k, float far_d2, int type, int ti, hipStream_t st, int* hist)
 {
   Target& t = ctx->target[ti];
   MatchBuf& mb = ctx->match[type];
   GridPtrs gp;
   for (int l = 0; l < kGridLevels; ++l) { gp.cell_start[l] = t.lv[l].cell_start; gp.sorted[l] = t.lv[l].sorted; }
   const float4* q4 = reinterpret_cast<const float4*>(q);
-  int* cntA = ctx->hist_dev + LSA_MATCH_NSTATUS;  // queries handed from the fine to the coarse kernel
+  int* cntA = hist + LSA_MATCH_NSTATUS;  // queries handed from the fine to the coarse kernel
   int* cntB = cntA + 1;                           // ... from the coarse kernel to the exhaustive one
   int* listA = mb.slow_list;
   int* listB = mb.slow_list + mb.cap;
@@ -975,27 +1046,27 @@ void launch_knn(lsa_ctx* ctx, const lsa_point_t* q, int nq, const Rigid& pose, i
   const char* nc = type == LSA_EDGE ? "knn_coarse_edge" : type == LSA_PLANE ? "knn_coarse_plane" : "knn_coarse_blob";
   {
     // algorithmic bytes: query point in, k candidate points examined at least, k (index, distance) pairs out
-    ProfScope ps(ctx, nf, (double)nq * (32 + k * 16 + k * 8));
-    hipLaunchKernelGGL((k_knn<KMAX, 8, 1, 0, 1>), dim3((nq * 8 + 255) / 256), dim3(256), 0, ctx->stream, q4, nq, (const int*)nullptr,
+    ProfScope ps(ctx, nf, (double)nq * (32 + k * 16 + k * 8), st);
+    hipLaunchKernelGGL((k_knn<KMAX, 8, 1, 0, 1>), dim3((nq * 8 + 255) / 256), dim3(256), 0, st, q4, nq, (const int*)nullptr,
                        (const int*)nullptr, pose, k, far_d2, t.desc, gp, mb.knn_idx, mb.knn_d2, mb.knn_cnt, mb.cap, cntA, listA);
   }
   {
     // the deferred share is only known on the device: no bytes are credited to these two stages
-    ProfScope ps(ctx, nc, 0.);
-    hipLaunchKernelGGL((k_knn<KMAX, 64, 8, 1, kGridLevels>), dim3(512), dim3(256), 0, ctx->stream, q4, nq, (const int*)listA, (const int*)cntA, pose, k,
+    ProfScope ps(ctx, nc, 0., st);
+    hipLaunchKernelGGL((k_knn<KMAX, 64, 8, 1, kGridLevels>), dim3(512), dim3(256), 0, st, q4, nq, (const int*)listA, (const int*)cntA, pose, k,
                        far_d2, t.desc, gp, mb.knn_idx, mb.knn_d2, mb.knn_cnt, mb.cap, cntB, listB);
-    hipLaunchKernelGGL((k_knn_sparse<KMAX>), dim3(256), dim3(256), 0, ctx->stream, q4, pose, k, t.desc, t.lv[0].sorted, mb.knn_idx, mb.knn_d2,
+    hipLaunchKernelGGL((k_knn_sparse<KMAX>), dim3(256), dim3(256), 0, st, q4, pose, k, t.desc, t.lv[0].sorted, mb.knn_idx, mb.knn_d2,
                        mb.knn_cnt, mb.cap, (const int*)cntB, (const int*)listB);
   }
 }
 
 template <int KMAX, int TYPE>
-void launch_model(lsa_ctx* ctx, const lsa_point_t* q, int nq, const MatchConst& mc, int type, int ti)
+void launch_model(lsa_ctx* ctx, const lsa_point_t* q, int nq, const MatchConst& mc, int type, int ti, hipStream_t st, int* hist)
 {
   Target& t = ctx->target[ti];
   MatchBuf& mb = ctx->match[type];
-  hipLaunchKernelGGL((k_model<KMAX, TYPE>), dim3((nq + kModelBlock - 1) / kModelBlock), dim3(kModelBlock), 0, ctx->stream,
-                     reinterpret_cast<const float4*>(q), nq, mc, mb.knn_idx, mb.knn_d2, mb.knn_cnt, t.xyzl, mb.rec, mb.status, mb.cap, ctx->hist_dev);
+  hipLaunchKernelGGL((k_model<KMAX, TYPE>), dim3((nq + kModelBlock - 1) / kModelBlock), dim3(kModelBlock), 0, st,
+                     reinterpret_cast<const float4*>(q), nq, mc, mb.knn_idx, mb.knn_d2, mb.knn_cnt, t.xyzl, mb.rec, mb.status, mb.cap, hist);
 }
 
 }  // namespace
@@ -1016,8 +1087,7 @@ int lsa_set_target(lsa_ctx* ctx, int slot, int type, const lsa_point_t* pts, int
     ProfScope ps(ctx, "target_upload_h2d", (double)m * 32);
     LSA_HIP(ctx, hipMemcpyAsync(t.pts, pts, (size_t)m * sizeof(lsa_point_t), hipMemcpyHostToDevice, ctx->stream));
   }
-  rc = build_grid(ctx, ti);
-  if (rc) return rc;
+  t.dirty = true;  // the search grid is built with the other pending targets at the next match
   LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the host buffer may be pageable and go away
   return LSA_OK;
 }
@@ -1034,7 +1104,8 @@ int lsa_set_target_from_set(lsa_ctx* ctx, int slot, int type, int set)
   t.m = m;
   if (m == 0) return LSA_OK;
   LSA_HIP(ctx, hipMemcpyAsync(t.pts, ctx->kp[set][type], (size_t)m * sizeof(lsa_point_t), hipMemcpyDeviceToDevice, ctx->stream));
-  return build_grid(ctx, ti);
+  t.dirty = true;
+  return LSA_OK;
 }
 
 int lsa_target_size(const lsa_ctx* ctx, int slot, int type) { return (ctx && slot >= 0 && slot <= 1 && type >= 0 && type <= 2) ? ctx->target[slot * 3 + type].m : LSA_E_ARG; }
@@ -1046,20 +1117,18 @@ int lsa_set_target_cell_size(lsa_ctx* ctx, int slot, int type, float cell)
   return LSA_OK;
 }
 
-int lsa_match(lsa_ctx* ctx, int slot, int type, int query_set, const lsa_match_params_t* p, const double pose[16], int histogram[LSA_MATCH_NSTATUS])
+// Enqueues the match of one keypoint type on `st` (no host synchronisation); the rejection histogram
+// lands in the type's block of hist_dev.
+static int match_enqueue(lsa_ctx* ctx, int slot, int type, int query_set, const lsa_match_params_t* p, const double pose[16], hipStream_t st)
 {
-  if (!ctx || !p || !pose || slot < 0 || slot > 1 || type < 0 || type > 2 || query_set < 0 || query_set > 2)
-    return ctx ? ctx->fail(LSA_E_ARG, "lsa_match: bad argument") : LSA_E_ARG;
-  LSA_HIP(ctx, hipSetDevice(ctx->device));
-  hipStream_t st = ctx->stream;
   const int nq = ctx->kp_n[query_set][type];
   MatchBuf& mb = ctx->match[type];
-  int rc = ensure_match(ctx, type, nq);
-  if (rc) return rc;
+  int* hist = ctx->hist_dev + type * 16;
   mb.k = nq;
   mb.sat = p->saturation_distance;
   mb.valid = true;
-  if (histogram) std::memset(histogram, 0, LSA_MATCH_NSTATUS * sizeof(int));
+  ctx->last_match_type = type;
+  LSA_HIP(ctx, hipMemsetAsync(hist, 0, 16 * sizeof(int), st));
   if (nq == 0) return LSA_OK;
   const int ti = slot * 3 + type;
   Target& t = ctx->target[ti];
@@ -1099,9 +1168,7 @@ int lsa_match(lsa_ctx* ctx, int slot, int type, int query_set, const lsa_match_p
     mc.max_model_err = 0.;
     if (p->blob_nb_neighbors < 4) mc.bad_param = 1;
   }
-  if (mc.k > 16) return ctx->fail(LSA_E_ARG, "lsa_match: more than 16 neighbours requested");
   if (mc.k < 1) mc.k = 1;
-  LSA_HIP(ctx, hipMemsetAsync(ctx->hist_dev, 0, 16 * sizeof(int), st));
   const lsa_point_t* q = ctx->kp[query_set][type];
   if (!mc.bad_param)
   {
@@ -1110,35 +1177,89 @@ int lsa_match(lsa_ctx* ctx, int slot, int type, int query_set, const lsa_match_p
     // filter their neighbours first, so they need the true k nearest whatever the distance.
     float far_d2 = INFINITY;
     if (type != LSA_EDGE && t.m >= mc.k) far_d2 = (float)(mc.max_dist2 * 1.0001);
-    if (mc.k <= 5) launch_knn<5>(ctx, q, nq, rp, mc.k, far_d2, type, ti);  // planes: 5 neighbours, fewer registers, more waves in flight
-    else if (mc.k <= 8) launch_knn<8>(ctx, q, nq, rp, mc.k, far_d2, type, ti);
-    else launch_knn<16>(ctx, q, nq, rp, mc.k, far_d2, type, ti);
+    if (mc.k <= 5) launch_knn<5>(ctx, q, nq, rp, mc.k, far_d2, type, ti, st, hist);  // planes: 5 neighbours, fewer registers, more waves in flight
+    else if (mc.k <= 8) launch_knn<8>(ctx, q, nq, rp, mc.k, far_d2, type, ti, st, hist);
+    else launch_knn<16>(ctx, q, nq, rp, mc.k, far_d2, type, ti, st, hist);
   }
   {
     ProfScope ps(ctx, type == LSA_EDGE ? "model_edge" : type == LSA_PLANE ? "model_plane" : "model_blob",
-                 (double)nq * (32 + mc.k * 8 + mc.k * 16 + 136));
+                 (double)nq * (32 + mc.k * 8 + mc.k * 16 + 136), st);
     if (type == LSA_EDGE)
     {
-      if (mc.k <= 8) launch_model<8, LSA_EDGE>(ctx, q, nq, mc, type, ti);
-      else launch_model<16, LSA_EDGE>(ctx, q, nq, mc, type, ti);
+      if (mc.k <= 8) launch_model<8, LSA_EDGE>(ctx, q, nq, mc, type, ti, st, hist);
+      else launch_model<16, LSA_EDGE>(ctx, q, nq, mc, type, ti, st, hist);
     }
     else if (type == LSA_PLANE)
     {
-      if (mc.k <= 8) launch_model<8, LSA_PLANE>(ctx, q, nq, mc, type, ti);
-      else launch_model<16, LSA_PLANE>(ctx, q, nq, mc, type, ti);
+      if (mc.k <= 8) launch_model<8, LSA_PLANE>(ctx, q, nq, mc, type, ti, st, hist);
+      else launch_model<16, LSA_PLANE>(ctx, q, nq, mc, type, ti, st, hist);
     }
     else
     {
-      if (mc.k <= 8) launch_model<8, LSA_BLOB>(ctx, q, nq, mc, type, ti);
-      else launch_model<16, LSA_BLOB>(ctx, q, nq, mc, type, ti);
+      if (mc.k <= 8) launch_model<8, LSA_BLOB>(ctx, q, nq, mc, type, ti, st, hist);
+      else launch_model<16, LSA_BLOB>(ctx, q, nq, mc, type, ti, st, hist);
     }
   }
-  if (histogram)
+  return LSA_OK;
+}
+
+static int match_check(lsa_ctx* ctx, int type, const lsa_match_params_t* p)
+{
+  const int k = type == LSA_EDGE ? p->edge_nb_neighbors : type == LSA_PLANE ? p->plane_nb_neighbors : p->blob_nb_neighbors;
+  if (k > kKnnMax) return ctx->fail(LSA_E_ARG, "lsa_match: more than 16 neighbours requested");
+  return LSA_OK;
+}
+
+int lsa_match(lsa_ctx* ctx, int slot, int type, int query_set, const lsa_match_params_t* p, const double pose[16], int histogram[LSA_MATCH_NSTATUS])
+{
+  if (!ctx || !p || !pose || slot < 0 || slot > 1 || type < 0 || type > 2 || query_set < 0 || query_set > 2)
+    return ctx ? ctx->fail(LSA_E_ARG, "lsa_match: bad argument") : LSA_E_ARG;
+  int hist3[3 * LSA_MATCH_NSTATUS];
+  const int rc = lsa_match_types(ctx, slot, 1u << type, query_set, p, pose, histogram ? hist3 : nullptr);
+  if (rc == LSA_OK && histogram) std::memcpy(histogram, hist3 + type * LSA_MATCH_NSTATUS, LSA_MATCH_NSTATUS * sizeof(int));
+  return rc;
+}
+
+int lsa_match_types(lsa_ctx* ctx, int slot, unsigned type_mask, int query_set, const lsa_match_params_t* p, const double pose[16], int* histograms)
+{
+  if (!ctx || !p || !pose || slot < 0 || slot > 1 || (type_mask & ~7u) || query_set < 0 || query_set > 2)
+    return ctx ? ctx->fail(LSA_E_ARG, "lsa_match_types: bad argument") : LSA_E_ARG;
+  LSA_HIP(ctx, hipSetDevice(ctx->device));
+  if (histograms) std::memset(histograms, 0, 3 * LSA_MATCH_NSTATUS * sizeof(int));
+  int types[3], nt = 0;
+  for (int k = 0; k < 3; ++k)
+    if ((type_mask >> k) & 1u)
+    {
+      int rc = match_check(ctx, k, p);
+      if (rc) return rc;
+      rc = ensure_match(ctx, k, ctx->kp_n[query_set][k]);  // may reallocate (and synchronise) before anything is forked
+      if (rc) return rc;
+      types[nt++] = k;
+    }
+  if (nt == 0) return LSA_OK;
+  {
+    const int rc = flush_grids(ctx);
+    if (rc) return rc;
+  }
+  // fork: the first type stays on the context stream, the others run beside it.  A single type's kernels
+  // leave most of the 256 CUs idle (a few thousand queries, latency bound), so the types overlap almost fully.
+  if (nt > 1) LSA_HIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
+  for (int i = 0; i < nt; ++i)
+  {
+    hipStream_t st = i == 0 ? ctx->stream : ctx->side_stream[i - 1];
+    if (i > 0) LSA_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_fork, 0));
+    const int rc = match_enqueue(ctx, slot, types[i], query_set, p, pose, st);
+    if (rc) return rc;
+    if (i > 0) LSA_HIP(ctx, hipEventRecord(ctx->ev_join[i - 1], st));
+  }
+  for (int i = 1; i < nt; ++i) LSA_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join[i - 1], 0));
+  if (histograms)
   {
     int* hp = reinterpret_cast<int*>(ctx->host_pinned) + 32;
-    LSA_HIP(ctx, hipMemcpyAsync(hp, ctx->hist_dev, 16 * sizeof(int), hipMemcpyDeviceToHost, st));
-    LSA_HIP(ctx, hipStreamSynchronize(st));
-    for (int s = 0; s < LSA_MATCH_NSTATUS; ++s) histogram[s] = hp[s];
+    LSA_HIP(ctx, hipMemcpyAsync(hp, ctx->hist_dev, 3 * 16 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < nt; ++i)
+      for (int s = 0; s < LSA_MATCH_NSTATUS; ++s) histograms[types[i] * LSA_MATCH_NSTATUS + s] = hp[types[i] * 16 + s];
   }
   return LSA_OK;
 }
@@ -1167,7 +1288,8 @@ int lsa_match_slow_queries(lsa_ctx* ctx)
 {
   if (!ctx) return LSA_E_ARG;
   int v = 0;
-  if (hipMemcpy(&v, ctx->hist_dev + LSA_MATCH_NSTATUS, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return LSA_E_HIP;
+  if (hipStreamSynchronize(ctx->stream) != hipSuccess) return LSA_E_HIP;
+  if (hipMemcpy(&v, ctx->hist_dev + ctx->last_match_type * 16 + LSA_MATCH_NSTATUS, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return LSA_E_HIP;
   return v;
 }
 

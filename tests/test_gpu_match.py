@@ -203,3 +203,32 @@ def test_lm_solve_matches_the_oracle(gpu_ctx, O, L, kps, two_d):
     covo, erro = O.covariance(rec, st, 5.0, pose) if not two_d else (None, None)
     if covo is not None:
         assert np.abs(cov - covo).max() <= 1e-6 * np.abs(covo).max() and np.allclose(err, erro, rtol=1e-6)
+
+
+@pytest.mark.parametrize("model", [16, 128])
+def test_concurrent_types_equal_sequential_calls(gpu_ctx, O, L, kps, model):
+    """lsa_match_types (one ICP iteration's matching step, types side by side on the device) leaves the
+    records, status and histograms of three lsa_match calls; the asynchronous form (no histogram) reports
+    the number of matches through lsa_accumulate."""
+    prev, cur = kps[model]
+    mp = L.MatchParams.localization(saturation_distance=2.0)
+    pose = perturbed()
+    for k in (L.EDGE, L.PLANE, L.BLOB):
+        n = 20000 if k == L.BLOB else None
+        gpu_ctx.set_keypoints(L.SET_WORKING, k, cur[k][:n])
+        gpu_ctx.set_target(k, prev[k], cell=1.2)
+    seq = {}
+    for k in (L.EDGE, L.PLANE, L.BLOB):
+        hist = gpu_ctx.match(k, L.SET_WORKING, mp, pose)
+        seq[k] = (hist,) + gpu_ctx.match_results(k, L.SET_WORKING)
+    ref_acc = gpu_ctx.accumulate(7, np.zeros(6))
+    hists = gpu_ctx.match_types(7, L.SET_WORKING, mp, pose)
+    for k in (L.EDGE, L.PLANE, L.BLOB):
+        st, w, rec = gpu_ctx.match_results(k, L.SET_WORKING)
+        assert hists[k].tolist() == seq[k][0].tolist()
+        assert np.array_equal(st, seq[k][1]) and np.array_equal(bits(w), bits(seq[k][2])) and np.array_equal(bits(rec), bits(seq[k][3]))
+    # a subset of the types, asynchronously: the other type's records stay, the count comes with the evaluation
+    assert gpu_ctx.match_types((1 << L.EDGE) | (1 << L.PLANE), L.SET_WORKING, mp, pose, histograms=False) is None
+    acc = gpu_ctx.accumulate(7, np.zeros(6))
+    assert acc[3] == ref_acc[3] == sum(int(seq[k][0][0]) for k in seq)
+    assert acc[0] == ref_acc[0] and np.array_equal(acc[2], ref_acc[2])

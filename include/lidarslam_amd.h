@@ -178,7 +178,10 @@ int lsa_target_size(const lsa_ctx* ctx, int slot, int type);
 /* Edge length [m] of the search-grid cells used by the next lsa_set_target* of this type
  * (default 1.0; it is enlarged automatically when the grid would exceed 2^21 cells). */
 int lsa_set_target_cell_size(lsa_ctx* ctx, int slot, int type, float cell);
-/* Diagnostics: queries of the last lsa_match that needed the exhaustive fall-back. */
+/* Tuning only (results do not depend on it): lanes of a wavefront that cooperate on one query of `type`
+ * in the first kNN kernel: 8, 16 or 32 (sparse targets such as edges: more lanes). */
+int lsa_set_knn_lanes(lsa_ctx* ctx, int type, int lanes);
+/* Diagnostics: queries of the last lsa_match that the first kNN kernel handed to the second stage. */
 int lsa_match_slow_queries(lsa_ctx* ctx);
 
 /* Replaces a device keypoint set by host points (used by tests and by callers

@@ -49,7 +49,7 @@ ABI_SYMBOLS = [
     "lsa_frame_store_put", "lsa_frame_store_use", "lsa_frame_size", "lsa_get_azimuthal_resolution",
     "lsa_set_azimuthal_resolution", "lsa_extract_keypoints", "lsa_download_keypoints", "lsa_keypoint_count",
     "lsa_download_debug", "lsa_nb_laser_rings", "lsa_transform_keypoints", "lsa_set_target", "lsa_set_target_from_set",
-    "lsa_target_size", "lsa_set_target_cell_size", "lsa_match_slow_queries", "lsa_set_keypoints", "lsa_match", "lsa_match_types",
+    "lsa_target_size", "lsa_set_target_cell_size", "lsa_set_knn_lanes", "lsa_match_slow_queries", "lsa_set_keypoints", "lsa_match", "lsa_match_types",
     "lsa_download_match", "lsa_accumulate", "lsa_solve", "lsa_registration_error", "lsa_selftest_math", "lsa_reset_working_keypoints", "lsa_undistort", "lsa_working_time_range",
     "lsa_working_bbox", "lsa_download_transformed", "lsa_transform_frame", "lsa_profile_enable", "lsa_profile_reset",
     "lsa_profile_get", "lsa_slam_create", "lsa_slam_destroy", "lsa_slam_last_error", "lsa_slam_set_param",
@@ -101,6 +101,7 @@ def lib():
     L.lsa_match_slow_queries.argtypes = [vp]
     L.lsa_set_keypoints.argtypes = [vp, i32, i32, vp, i32]
     L.lsa_match.argtypes = [vp, i32, i32, i32, C.POINTER(MatchParams), vp, vp]
+    L.lsa_set_knn_lanes.argtypes = [vp, i32, i32]
     L.lsa_match_types.argtypes = [vp, i32, C.c_uint, i32, C.POINTER(MatchParams), vp, vp]
     L.lsa_download_match.argtypes = [vp, i32, vp, vp, vp, i32]
     L.lsa_accumulate.argtypes = [vp, C.c_uint, vp, i32, vp, vp, vp, vp]

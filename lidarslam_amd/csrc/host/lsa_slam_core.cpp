@@ -166,6 +166,9 @@ int SlamCore::ProcessCurrentFrame(uint64_t stampUs)
   CurrentStamp = stampUs;
   CurrentTime = StampToSec(stampUs);
   HaveFrame = true;
+  lsa_set_knn_lanes(Ctx, LSA_EDGE, KnnLanesEdges);
+  lsa_set_knn_lanes(Ctx, LSA_PLANE, KnnLanesPlanes);
+  lsa_set_knn_lanes(Ctx, LSA_BLOB, KnnLanesBlobs);
   {
     Tick t;
     int rc = ExtractKeypoints();
@@ -587,7 +590,10 @@ int SlamCore::GetRegisteredFrame(std::vector<lsa_point_t>& out)
   X("KnnCellSizeEgoMotion", KnnCellSizeEgoMotion, double)                                              \
   X("KnnCellScaleMaps", KnnCellScaleMaps, double)                                                      \
   X("KnnCellSizeEgoMotionEdges", KnnCellSizeEgoMotionEdges, double)                                    \
-  X("KnnCellScaleMapsEdges", KnnCellScaleMapsEdges, double)                                                            \
+  X("KnnCellScaleMapsEdges", KnnCellScaleMapsEdges, double)                                            \
+  X("KnnLanesEdges", KnnLanesEdges, int)                                                               \
+  X("KnnLanesPlanes", KnnLanesPlanes, int)                                                             \
+  X("KnnLanesBlobs", KnnLanesBlobs, int)                                                               \
   X("NeighborWidth", ExtractParams.neighbor_width, int)                                                \
   X("MinDistanceToSensor", ExtractParams.min_distance_to_sensor, float)                                \
   X("MinBeamSurfaceAngle", ExtractParams.min_beam_surface_angle, float)                                \

@@ -131,6 +131,8 @@ public:
   double KnnCellSizeEgoMotionEdges = 0.5;  // [m] previous-scan edge targets (sparse)
   double KnnCellScaleMaps = 1.0;           // x map leaf size, plane / blob sub-maps
   double KnnCellScaleMapsEdges = 2.5;      // x map leaf size, edge sub-maps
+  // lanes per query in the first kNN kernel (sparse edge targets: more lanes, fewer queries per wavefront)
+  int KnnLanesEdges = 16, KnnLanesPlanes = 8, KnnLanesBlobs = 8;
   bool KeepMatchDebug = false;  // download MatchingResults::Rejections/Weights every frame (Slam::GetDebugArray)
 
   std::shared_ptr<RollingGrid> LocalMaps[3];

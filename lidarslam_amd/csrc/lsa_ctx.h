@@ -29,7 +29,9 @@ constexpr int kGridLevels = 3;            // search grid resolutions: cell, 4 x 
 constexpr int kCellCap = 1 << 22;         // max cells of the finest kNN search grid
 __host__ __device__ constexpr int grid_level_cells(int level) { return level == 0 ? kCellCap : level == 1 ? (kCellCap >> 6) + 64 : (kCellCap >> 12) + 64; }
 constexpr int kKnnMax = 16;               // neighbours per query the kNN buffers hold
-constexpr int kAccumBlocks = 256;         // grid of the normal-equation kernel (grid-stride, <= 256: folded by one block)
+constexpr int kAccumBlocks = 128;         // grid of the normal-equation kernel (grid-stride); the host folds the blocks' partial sums
+constexpr int kMailboxStride = 32;        // doubles per block in the mailbox: [0..28] partial sums, [31] sequence flag
+constexpr int kMailboxFlag = 31;
 constexpr int kAccumVals = 29;            // cost, g[6], H upper[21], nvalid
 
 struct GridDesc
@@ -137,10 +139,12 @@ struct lsa_ctx
   double* partials = nullptr;  // [kAccumBlocks][kAccumVals]
   double* reduce_out = nullptr;
   double* host_pinned = nullptr;  // >= 64 doubles, pinned
-  double* mailbox = nullptr;      // coherent host memory the fold kernel writes directly: [0..28] values, [32] sequence flag
+  double* mailbox = nullptr;      // coherent host memory k_accumulate's blocks write directly: [kAccumBlocks][kMailboxStride]
   unsigned long long mailbox_seq = 0;
   int* hist_dev = nullptr;        // per match type 16 ints: [8] rejection histogram + 2 hand-over counters of the kNN cascade
   int last_match_type = 0;
+  // lanes cooperating on one query in the first kNN kernel, per keypoint type (8, 16 or 32)
+  int knn_lanes[3] = {16, 8, 8};
   // lsa_match_types: the keypoint types of one ICP iteration are matched concurrently, the first on
   // `stream`, the others on these, forked and joined with events (no host synchronisation)
   hipStream_t side_stream[2] = {nullptr, nullptr};

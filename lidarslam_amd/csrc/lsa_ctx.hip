@@ -236,8 +236,8 @@ int lsa_ctx_create(int device_id, lsa_ctx** out)
   ok &= hipMalloc((void**)&ctx->hist_dev, 3 * 16 * sizeof(int)) == hipSuccess;
   ok &= hipMalloc((void**)&ctx->range_bits, 16 * sizeof(unsigned long long)) == hipSuccess;
   ok &= hipHostMalloc((void**)&ctx->host_pinned, 256 * sizeof(double), hipHostMallocDefault) == hipSuccess;
-  if (hipHostMalloc((void**)&ctx->mailbox, 64 * sizeof(double), hipHostMallocCoherent | hipHostMallocMapped) == hipSuccess)
-    std::memset(ctx->mailbox, 0, 64 * sizeof(double));
+  if (hipHostMalloc((void**)&ctx->mailbox, (size_t)kAccumBlocks * kMailboxStride * sizeof(double), hipHostMallocCoherent | hipHostMallocMapped) == hipSuccess)
+    std::memset(ctx->mailbox, 0, (size_t)kAccumBlocks * kMailboxStride * sizeof(double));
   else
     ctx->mailbox = nullptr;  // optional: lsa_accumulate falls back to a copy + synchronise
   if (!ok) { lsa_ctx_destroy(ctx); return LSA_E_HIP; }

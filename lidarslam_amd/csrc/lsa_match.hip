@@ -2,15 +2,16 @@
 // the residual blocks on the GPU.
 //
 //   target grid     replaces KDTreePCLAdaptor::Reset (nanoflann kd-tree build,
-//                   slam_lib/include/LidarSlam/KDTreePCLAdaptor.h:57-65) by a two-level dense uniform
-//                   grid: bbox reduce -> per level { cell count -> exclusive scan -> cell-sorted float4 copy }
-//   k_knn<KMAX>     EXACT k-nearest neighbours (KDTreePCLAdaptor::KnnSearch, :79-105), 8 lanes per
-//                   query: Chebyshev shells of grid cells are expanded until the k-th distance is
-//                   provably inside the searched radius; the rows of a shell (contiguous runs of the
-//                   cell-sorted array) are dealt to the 8 lanes, each keeps a private top-k in registers,
-//                   the stop test is a 3-step shuffle sum of "how many of my entries are inside the
-//                   bound", the private lists are merged by shuffles at the end.  Sparse neighbourhoods
-//                   escalate to the coarse level (cell x 8) and, at last, to a cooperative exhaustive scan.
+//                   slam_lib/include/LidarSlam/KDTreePCLAdaptor.h:57-65) by a three-level dense uniform
+//                   grid, all pending targets in one launch sequence: bbox reduce -> cell count (wave-
+//                   aggregated atomics on the coarse levels) -> exclusive scan -> cell-sorted float4 copies
+//   k_knn_first /   EXACT k-nearest neighbours (KDTreePCLAdaptor::KnnSearch, :79-105).  G lanes per query
+//   k_knn_second    search the 3x3x3, then the 5x5x5 block of cells around it; a block's rows are contiguous
+//                   runs of the cell-sorted array, flattened by a group prefix sum and dealt evenly to the
+//                   lanes; the k best are picked by k rounds of group-minimum (DPP), identical instructions in
+//                   every lane.  A round settles the query when k picks lie inside the radius the block
+//                   proves; the few percent left go, through a device list, to the second kernel (one
+//                   wavefront each, coarser levels, finally the whole target).
 //   k_model<..>     one thread per keypoint (slam_lib/src/KeypointsMatcher.cxx:106-346): neighbourhood
 //                   filter (per-ring :349-405 / RANSAC line :408-480, candidates staged in LDS), PCA in
 //                   double, validity tests, residual record (A, P, X, weight)
@@ -81,13 +82,15 @@ __global__ __launch_bounds__(256) void k_target_prep(GridBatch gb)
       mx[d] = fmaxf(mx[d], __shfl_down(mx[d], o));
     }
   }
+  __shared__ float smn[4][3], smx[4][3];
   if ((threadIdx.x & 63) == 0)
+    for (int d = 0; d < 3; ++d) { smn[threadIdx.x >> 6][d] = mn[d]; smx[threadIdx.x >> 6][d] = mx[d]; }
+  __syncthreads();
+  if (threadIdx.x < 3)
   {
-    for (int d = 0; d < 3; ++d)
-    {
-      atomicMin(&gb.bbox[t][d], f2o(mn[d]));
-      atomicMax(&gb.bbox[t][3 + d], f2o(mx[d]));
-    }
+    const int d = threadIdx.x;
+    atomicMin(&gb.bbox[t][d], f2o(fminf(fminf(smn[0][d], smn[1][d]), fminf(smn[2][d], smn[3][d]))));
+    atomicMax(&gb.bbox[t][3 + d], f2o(fmaxf(fmaxf(smx[0][d], smx[1][d]), fmaxf(smx[2][d], smx[3][d]))));
   }
 }
 
@@ -150,13 +153,47 @@ __global__ __launch_bounds__(256) void k_grid_zero(GridBatch gb)
   }
 }
 
+// Lanes of a wavefront that fall into the same cell are served by ONE atomic: the lowest of them adds the
+// group's size, every member learns its rank inside the group.  Keypoints arrive in scan order, so
+// neighbouring lanes share the cells of the coarse levels, whose few counters plain atomics would hammer
+// from every wave (measured: 72 us per pass on a 33k-point scan, against 10 us).
+struct CellGroup
+{
+  int leader;  // lane that issues the atomic for this lane's cell
+  int rank;    // position of this lane among the lanes of its cell
+  int count;   // lanes of the wavefront in this cell
+};
+__device__ __forceinline__ CellGroup group_by_cell(bool active, uint32_t cid)
+{
+  CellGroup g{-1, 0, 0};
+  const int lane = threadIdx.x & 63;
+  const unsigned long long below = (1ull << lane) - 1ull;
+  unsigned long long remaining = __ballot(active);
+  while (remaining)
+  {
+    const int first = __ffsll((long long)remaining) - 1;
+    const uint32_t c = __shfl(cid, first);
+    const unsigned long long same = __ballot(active && cid == c);
+    if (active && cid == c)
+    {
+      g.leader = first;
+      g.rank = __popcll(same & below);
+      g.count = __popcll(same);
+    }
+    remaining &= ~same;
+  }
+  return g;
+}
+
 // one read of the point, its cell at every level
 __global__ __launch_bounds__(256) void k_grid_count(GridBatch gb)
 {
   const int t = blockIdx.y;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= gb.m[t]) return;
-  const float4 p = gb.xyzl[t][i];
+  if (blockIdx.x * blockDim.x >= gb.m[t]) return;
+  const bool active = i < gb.m[t];
+  const float4 p = active ? gb.xyzl[t][i] : make_float4(0.f, 0.f, 0.f, 0.f);
+  const int lane = threadIdx.x & 63;
 #pragma unroll
   for (int l = 0; l < kGridLevels; ++l)
   {
@@ -165,8 +202,16 @@ __global__ __launch_bounds__(256) void k_grid_count(GridBatch gb)
     const int cy = cell_coord(p.y, g.origin[1], g.inv_cell, g.dims[1]);
     const int cz = cell_coord(p.z, g.origin[2], g.inv_cell, g.dims[2]);
     const uint32_t cid = (uint32_t)((cz * g.dims[1] + cy) * g.dims[0] + cx);
-    gb.cell_of[t][l][i] = cid;
-    atomicAdd(&gb.cell_start[t][l][cid], 1u);
+    if (active) gb.cell_of[t][l][i] = cid;
+    if (l == 0)
+    {
+      if (active) atomicAdd(&gb.cell_start[t][l][cid], 1u);
+    }
+    else
+    {
+      const CellGroup cg = group_by_cell(active, cid);
+      if (active && lane == cg.leader) atomicAdd(&gb.cell_start[t][l][cid], (uint32_t)cg.count);
+    }
   }
 }
 
@@ -250,99 +295,30 @@ __global__ __launch_bounds__(256) void k_grid_scatter(GridBatch gb)
 {
   const int t = blockIdx.y;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= gb.m[t]) return;
-  const float4 p = gb.xyzl[t][i];
+  if (blockIdx.x * blockDim.x >= gb.m[t]) return;
+  const bool active = i < gb.m[t];
+  const int lane = threadIdx.x & 63;
+  const float4 p = active ? gb.xyzl[t][i] : make_float4(0.f, 0.f, 0.f, 0.f);
   const float4 rec = make_float4(p.x, p.y, p.z, __int_as_float(i));
 #pragma unroll
   for (int l = 0; l < kGridLevels; ++l)
   {
-    const uint32_t cid = gb.cell_of[t][l][i];
-    const uint32_t pos = gb.cell_start[t][l][cid] + atomicAdd(&gb.cell_fill[t][l][cid], 1u);
-    gb.sorted[t][l][pos] = rec;
+    const uint32_t cid = active ? gb.cell_of[t][l][i] : 0u;
+    uint32_t slot;
+    if (l == 0)
+      slot = active ? atomicAdd(&gb.cell_fill[t][l][cid], 1u) : 0u;
+    else
+    {
+      const CellGroup cg = group_by_cell(active, cid);
+      uint32_t base = 0;
+      if (active && lane == cg.leader) base = atomicAdd(&gb.cell_fill[t][l][cid], (uint32_t)cg.count);
+      slot = __shfl(base, max(cg.leader, 0)) + (uint32_t)cg.rank;
+    }
+    if (active) gb.sorted[t][l][gb.cell_start[t][l][cid] + slot] = rec;
   }
 }
 
 // ------------------------------------------------------------------------------------------
-
-// private top-k of one lane, ascending (distance, index); empty slots hold (+inf, INT_MAX)
-template <int KMAX> struct KnnSet
-{
-  float d2[KMAX];
-  int idx[KMAX];
-  float worst_d;
-  int worst_i;
-  int k;
-  __device__ __forceinline__ void init(int kk)
-  {
-#pragma unroll
-    for (int s = 0; s < KMAX; ++s) { d2[s] = INFINITY; idx[s] = 0x7fffffff; }
-    worst_d = INFINITY; worst_i = 0x7fffffff; k = kk;
-  }
-  __device__ __forceinline__ void offer(float d, int i)
-  {
-    if (!(d < worst_d || (d == worst_d && i < worst_i))) return;
-    float cd = d; int ci = i;
-#pragma unroll
-    for (int s = 0; s < KMAX; ++s)
-    {
-      if (s < k)
-      {
-        const bool lt = cd < d2[s] || (cd == d2[s] && ci < idx[s]);
-        if (lt)
-        {
-          const float td = d2[s]; const int ti = idx[s];
-          d2[s] = cd; idx[s] = ci; cd = td; ci = ti;
-        }
-        if (s == k - 1) { worst_d = d2[s]; worst_i = idx[s]; }
-      }
-    }
-  }
-  __device__ __forceinline__ int count_below(float bound2) const
-  {
-    int c = 0;
-#pragma unroll
-    for (int s = 0; s < KMAX; ++s)
-      if (s < k && d2[s] < bound2) ++c;
-    return c;
-  }
-};
-
-// Offers the points sorted[b], sorted[b + stride], ... (< e) to the private list.  Four loads are issued
-// before the first one is consumed: the loop is bound by load latency, not by arithmetic.
-template <int KMAX>
-__device__ __forceinline__ void scan_range(KnnSet<KMAX>& ks, const float4* __restrict__ sorted, uint32_t b, uint32_t e, uint32_t stride,
-                                           float qx, float qy, float qz)
-{
-  if (b >= e) return;
-  const uint32_t last = e - 1;
-  for (uint32_t t = b; t < e; t += 4 * stride)
-  {
-    const uint32_t t1 = t + stride, t2 = t + 2 * stride, t3 = t + 3 * stride;
-    const float4 p0 = sorted[t];
-    const float4 p1 = sorted[min(t1, last)];
-    const float4 p2 = sorted[min(t2, last)];
-    const float4 p3 = sorted[min(t3, last)];
-    {
-      const float dx = qx - p0.x, dy = qy - p0.y, dz = qz - p0.z;
-      ks.offer((dx * dx + dy * dy) + dz * dz, __float_as_int(p0.w));
-    }
-    if (t1 < e)
-    {
-      const float dx = qx - p1.x, dy = qy - p1.y, dz = qz - p1.z;
-      ks.offer((dx * dx + dy * dy) + dz * dz, __float_as_int(p1.w));
-    }
-    if (t2 < e)
-    {
-      const float dx = qx - p2.x, dy = qy - p2.y, dz = qz - p2.z;
-      ks.offer((dx * dx + dy * dy) + dz * dz, __float_as_int(p2.w));
-    }
-    if (t3 < e)
-    {
-      const float dx = qx - p3.x, dy = qy - p3.y, dz = qz - p3.z;
-      ks.offer((dx * dx + dy * dy) + dz * dz, __float_as_int(p3.w));
-    }
-  }
-}
 
 struct GridView
 {
@@ -384,222 +360,332 @@ struct GridPtrs
 // kKnnFar when the search proved that the k-th neighbour lies beyond far_d2 (plane / blob matches only
 // need to know that: KeypointsMatcher.cxx:217, 303 reject them as NEIGHBORS_TOO_FAR whatever they are).
 constexpr int kKnnFar = -1;
-constexpr int kShellCap = 4;  // shells searched per level before moving to the next, 4 x coarser, level
+// ------------------------------------------------------------------------------------------
+// Selection-based search (k_knn_first / k_knn_second).  G lanes cooperate on one query.  The rows of the
+// block of cells being searched are contiguous runs of the cell-sorted array; their bounds are fetched by
+// as many lanes at once, flattened with a group prefix sum, and the candidates are dealt to the lanes evenly,
+// U per lane and batch, all loads in flight together.  The k best of (previous best + batch) are then PICKED:
+// k rounds of "group minimum by (distance, index), owner retires it".  Every lane executes the same
+// instructions whatever its candidates are -- no per-lane sorted lists, no divergent insertion, no merge
+// tree -- and the result sits in registers that are uniform across the group.
 
-// The search cascade.  G lanes cooperate on one query; the rows of a shell are dealt to G / W sub-groups
-// of W lanes which scan a row with stride W (W = 1: one lane per row, W = 8: coalesced 128-byte reads).
-//   k_knn<KMAX, 8, 1, 0, 1>    every query, finest level only: short rows, 8 queries per wavefront
-//   k_knn<KMAX, 64, 8, 1, 3>   the few queries whose neighbourhood is sparse at the finest level (a few
-//                              percent): one wavefront each over the coarser levels, whose cells hold
-//                              hundreds of points, so rows are scanned cooperatively and stay balanced
-//   k_knn_sparse               what is left: a whole block scans the target
-// A kernel hands unfinished queries to the next one through a device list (list_out / count_out).
-template <int KMAX, int G, int W, int LEVEL0, int LEVEL1>
-__global__ __launch_bounds__(256) void k_knn(const float4* __restrict__ queries, int nq, const int* __restrict__ list_in,
-                                             const int* __restrict__ count_in, Rigid pose, int k, float far_d2,
-                                             const GridDesc* __restrict__ desc, GridPtrs gp, int* __restrict__ knn_idx,
-                                             float* __restrict__ knn_d2, int* __restrict__ knn_cnt, int cap, int* __restrict__ count_out,
-                                             int* __restrict__ list_out)
+// minimum of (d, i) over the G lanes of a group, total order (distance, index); result in every lane
+template <int G>
+__device__ __forceinline__ void group_min(float& d, int& i)
 {
-  const int lane = threadIdx.x % G;
-  const int sub = lane / W, sl = lane % W;
-  const int nwork = list_in ? *count_in : nq;
-  const int per_pass = gridDim.x * (256 / G);
-  // the loop bound is the same for every lane of the wavefront, the shuffles below stay convergent
-  for (int base = blockIdx.x * (256 / G); base < nwork; base += per_pass)
+  auto take = [&](float od, int oi) {
+    const bool lt = od < d || (od == d && oi < i);
+    d = lt ? od : d;
+    i = lt ? oi : i;
+  };
+  // inside a row of 16 lanes the exchange is a DPP operand modifier (no LDS round trip):
+  // quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror
+  if (G >= 2) take(__int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(d), 0xB1, 0xF, 0xF, true)), __builtin_amdgcn_update_dpp(0, i, 0xB1, 0xF, 0xF, true));
+  if (G >= 4) take(__int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(d), 0x4E, 0xF, 0xF, true)), __builtin_amdgcn_update_dpp(0, i, 0x4E, 0xF, 0xF, true));
+  if (G >= 8) take(__int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(d), 0x141, 0xF, 0xF, true)), __builtin_amdgcn_update_dpp(0, i, 0x141, 0xF, 0xF, true));
+  if (G >= 16) take(__int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(d), 0x140, 0xF, 0xF, true)), __builtin_amdgcn_update_dpp(0, i, 0x140, 0xF, 0xF, true));
+  if (G >= 32) take(__shfl_xor(d, 16), __shfl_xor(i, 16));
+  if (G >= 64) take(__shfl_xor(d, 32), __shfl_xor(i, 32));
+}
+
+template <int KMAX, int G, int U>
+struct GroupSelect
+{
+  static constexpr int C = (KMAX + G - 1) / G;  // carry slots per lane: the previous best, dealt over the group
+  float cd[U + C];
+  int ci[U + C];
+  float best_d[KMAX];  // ascending (distance, index), uniform across the group; (+inf, INT_MAX) = empty
+  int best_i[KMAX];
+  __device__ __forceinline__ void reset()
   {
-    const int w = base + threadIdx.x / G;
-    const bool active = w < nwork;
-    const int q = active ? (list_in ? list_in[w] : w) : 0;
-    float qx = 0.f, qy = 0.f, qz = 0.f;
-    if (active)
+#pragma unroll
+    for (int s = 0; s < KMAX; ++s) { best_d[s] = INFINITY; best_i[s] = 0x7fffffff; }
+#pragma unroll
+    for (int u = 0; u < U + C; ++u) { cd[u] = INFINITY; ci[u] = 0x7fffffff; }
+  }
+  // best <- the k smallest of (carry slots + the U fresh candidates of every lane)
+  __device__ __forceinline__ void select(int k, int gl)
+  {
+    // nothing in this batch beats the current k-th best of any group of the wavefront: keep the list
+    bool improves = false;
+    float kth_d = INFINITY; int kth_i = 0x7fffffff;
+#pragma unroll
+    for (int s = 0; s < KMAX; ++s)
+      if (s == k - 1) { kth_d = best_d[s]; kth_i = best_i[s]; }
+#pragma unroll
+    for (int u = 0; u < U; ++u) improves |= cd[u] < kth_d || (cd[u] == kth_d && ci[u] < kth_i);
+    if (!__any(improves)) return;
+#pragma unroll
+    for (int s = 0; s < KMAX; ++s)
     {
-      // KeypointsMatcher: worldPoint = PosePrior * basePoint in double, narrowed to float for the search
-      const float4 q4 = queries[2 * (size_t)q];
-      double wx, wy, wz;
-      rigid_apply(pose, (double)q4.x, (double)q4.y, (double)q4.z, wx, wy, wz);
-      qx = (float)wx; qy = (float)wy; qz = (float)wz;
-    }
-    KnnSet<KMAX> ks;
-    ks.init(k);
-    GridView gv;
-    grid_view(gv, desc + LEVEL0, gp.cell_start[LEVEL0], gp.sorted[LEVEL0], qx, qy, qz);
-    // the first round takes shells 0 and 1 together (the 3x3x3 block around the query): one round trip less
-    int level = LEVEL0, r = 1;
-    bool done = !active, deferred = false, far = false, first = true;
-    while (true)
-    {
-      float bound2 = -1.f;
-      bool covered = false;
-      if (!done)
+      if (s < k)
       {
-        const int nx = gv.g.dims[0], ny = gv.g.dims[1], nz = gv.g.dims[2];
-        const int z0 = max(0, gv.cz - r), z1 = min(nz - 1, gv.cz + r);
-        const int y0 = max(0, gv.cy - r), y1 = min(ny - 1, gv.cy + r);
-        const int x0 = max(0, gv.cx - r), x1 = min(nx - 1, gv.cx + r);
-        const int ys = y1 - y0 + 1;
-        const int nrows = (z1 - z0 + 1) * ys;
-        // a row of the shell = one contiguous run of the cell-sorted array (rows on the shell's faces) or
-        // its two end cells (interior rows); the runs of the NEXT row are fetched while this one is scanned
-        auto row_runs = [&](int ri, uint32_t& b0, uint32_t& e0, uint32_t& b1, uint32_t& e1) {
-          const int z = z0 + ri / ys, y = y0 + ri % ys;
-          const int row = (z * ny + y) * nx;
-          const bool shell = first || (abs(z - gv.cz) == r) || (abs(y - gv.cy) == r);
-          b1 = e1 = 0;
-          if (shell)
-          {
-            b0 = gv.cell_start[row + x0];
-            e0 = gv.cell_start[row + x1 + 1];
-          }
-          else
-          {
-            b0 = e0 = 0;
-            if (gv.cx - r >= 0) { b0 = gv.cell_start[row + gv.cx - r]; e0 = gv.cell_start[row + gv.cx - r + 1]; }
-            if (gv.cx + r < nx) { b1 = gv.cell_start[row + gv.cx + r]; e1 = gv.cell_start[row + gv.cx + r + 1]; }
-          }
-        };
-        uint32_t b0 = 0, e0 = 0, b1 = 0, e1 = 0;
-        int ri = sub;
-        if (ri < nrows) row_runs(ri, b0, e0, b1, e1);
-        while (ri < nrows)
-        {
-          const int rn = ri + G / W;
-          uint32_t nb0 = 0, ne0 = 0, nb1 = 0, ne1 = 0;
-          if (rn < nrows) row_runs(rn, nb0, ne0, nb1, ne1);
-          scan_range(ks, gv.sorted, b0 + sl, e0, (uint32_t)W, qx, qy, qz);
-          scan_range(ks, gv.sorted, b1 + sl, e1, (uint32_t)W, qx, qy, qz);
-          ri = rn; b0 = nb0; e0 = ne0; b1 = nb1; e1 = ne1;
-        }
-        // every point closer than r cells (minus a 0.1 % guard for the float cell assignment) has been seen
-        if (r >= 1)
-        {
-          const float br = ((float)r - 0.001f) * gv.g.cell;
-          bound2 = gv.outd2 + br * br;
-        }
-        covered = (x0 == 0 && y0 == 0 && z0 == 0 && x1 == nx - 1 && y1 == ny - 1 && z1 == nz - 1);
-      }
-      // wave-convergent: how many candidates of the whole group lie inside the proven radius
-      int c = done ? 0 : ks.count_below(bound2);
+        float md = cd[0]; int mi = ci[0];
 #pragma unroll
-      for (int mask = 1; mask < G; mask <<= 1) c += __shfl_xor(c, mask, G);
-      if (!done)
-      {
-        if (covered || c >= k) done = true;
-        else if (bound2 > far_d2)
+        for (int u = 1; u < U + C; ++u)
         {
-          // fewer than k points inside a radius that already exceeds the rejection distance
-          far = true;
-          done = true;
+          const bool lt = cd[u] < md || (cd[u] == md && ci[u] < mi);
+          md = lt ? cd[u] : md;
+          mi = lt ? ci[u] : mi;
         }
-        else if (r >= kShellCap)
-        {
-          ++level;
-          r = 1;
-          first = true;
-          ks.init(k);
-          if (level < LEVEL1) grid_view(gv, desc + level, gp.cell_start[level], gp.sorted[level], qx, qy, qz);
-          else
-          {
-            // not settled inside this kernel's levels: pass the query on
-            if (lane == 0) list_out[atomicAdd(count_out, 1)] = q;
-            deferred = true;
-            done = true;
-          }
-        }
-        else { ++r; first = false; }
+        group_min<G>(md, mi);
+        best_d[s] = md; best_i[s] = mi;
+        // the owner retires it (indices are unique among real candidates; empty slots all look alike, harmless)
+#pragma unroll
+        for (int u = 0; u < U + C; ++u)
+          if (ci[u] == mi) { cd[u] = INFINITY; ci[u] = 0x7fffffff; }
       }
-      if (__all(done)) break;
     }
-    // merge the private lists (disjoint by construction) with a butterfly of shuffles
+    // the new best becomes the carry of the next batch: entry s lives in slot s / G of lane s % G
 #pragma unroll
-    for (int mask = 1; mask < G; mask <<= 1)
+    for (int c = 0; c < C; ++c) { cd[U + c] = INFINITY; ci[U + c] = 0x7fffffff; }
+#pragma unroll
+    for (int s = 0; s < KMAX; ++s)
+      if (s < k && gl == s % G) { cd[U + s / G] = best_d[s]; ci[U + s / G] = best_i[s]; }
+  }
+  __device__ __forceinline__ int count_below(float bound2, int k) const
+  {
+    int c = 0;
+#pragma unroll
+    for (int s = 0; s < KMAX; ++s)
+      if (s < k && best_d[s] < bound2) ++c;
+    return c;
+  }
+};
+
+// the rows of one block of cells, dealt E per lane and flattened: candidate c of [0, total) is an offset into
+// the cell-sorted array
+template <int G, int E>
+struct BlockRuns
+{
+  uint32_t b[E], len[E];
+  uint32_t excl, total;
+  bool covered;
+  // every lane of the wavefront calls this (shuffles); groups with live == false get an empty block
+  __device__ __forceinline__ void build(const GridView& gv, int r, int gl, bool live)
+  {
+    const int nx = gv.g.dims[0], ny = gv.g.dims[1], nz = gv.g.dims[2];
+    const int z0 = max(0, gv.cz - r), z1 = min(nz - 1, gv.cz + r);
+    const int y0 = max(0, gv.cy - r), y1 = min(ny - 1, gv.cy + r);
+    const int x0 = max(0, gv.cx - r), x1 = min(nx - 1, gv.cx + r);
+    const int ys = y1 - y0 + 1;
+    const int nrows = live ? (z1 - z0 + 1) * ys : 0;
+    covered = (x0 == 0 && y0 == 0 && z0 == 0 && x1 == nx - 1 && y1 == ny - 1 && z1 == nz - 1);
+    uint32_t mine = 0;
+#pragma unroll
+    for (int e = 0; e < E; ++e)
     {
-      float td[KMAX]; int ti[KMAX];
-#pragma unroll
-      for (int s = 0; s < KMAX; ++s)
+      const int ri = gl * E + e;
+      b[e] = 0; len[e] = 0;
+      if (ri < nrows)
       {
-        td[s] = __shfl_xor(ks.d2[s], mask, G);
-        ti[s] = __shfl_xor(ks.idx[s], mask, G);
+        const int row = ((z0 + ri / ys) * ny + (y0 + ri % ys)) * nx;
+        b[e] = gv.cell_start[row + x0];
+        len[e] = gv.cell_start[row + x1 + 1] - b[e];
       }
-#pragma unroll
-      for (int s = 0; s < KMAX; ++s)
-        if (s < k) ks.offer(td[s], ti[s]);
+      mine += len[e];
     }
-    if (active && lane == 0 && !deferred)
+    uint32_t inc = mine;
+#pragma unroll
+    for (int o = 1; o < G; o <<= 1)
     {
-      int cnt = 0;
-#pragma unroll
-      for (int s = 0; s < KMAX; ++s)
-        if (s < k)
-        {
-          knn_idx[(size_t)s * cap + q] = ks.idx[s];
-          knn_d2[(size_t)s * cap + q] = ks.d2[s];
-          if (ks.idx[s] != 0x7fffffff) ++cnt;
-        }
-      knn_cnt[q] = far ? kKnnFar : cnt;
+      const uint32_t t = __shfl_up(inc, o, G);
+      if (gl >= o) inc += t;
     }
+    excl = inc - mine;  // non-decreasing over the lanes of the group
+    total = __shfl(inc, G - 1, G);
+  }
+  // the whole target as one run (exhaustive stage)
+  __device__ __forceinline__ void whole(uint32_t m, int gl)
+  {
+#pragma unroll
+    for (int e = 0; e < E; ++e) { b[e] = 0; len[e] = 0; }
+    if (gl == 0) len[0] = m;
+    excl = gl == 0 ? 0u : m;
+    total = m;
+    covered = true;
+  }
+  __device__ __forceinline__ uint32_t locate(uint32_t c) const
+  {
+    // the last lane L of the group with excl[L] <= c owns candidate c (then c < excl[L + 1]: it has a non-empty row)
+    int L = 0;
+#pragma unroll
+    for (int step = G / 2; step > 0; step >>= 1)
+    {
+      const uint32_t ex = __shfl(excl, L + step, G);
+      if (ex <= c) L += step;
+    }
+    uint32_t off = c - __shfl(excl, L, G);
+    uint32_t addr = 0;
+    bool found = false;
+#pragma unroll
+    for (int e = 0; e < E; ++e)
+    {
+      const uint32_t bb = __shfl(b[e], L, G), ll = __shfl(len[e], L, G);
+      if (!found && off < ll) { addr = bb + off; found = true; }
+      if (!found) off -= ll;
+    }
+    return addr;
+  }
+};
+
+// one search round: the k best of the block's candidates end up in sel.best (uniform across the group)
+template <int KMAX, int G, int U, int E>
+__device__ __forceinline__ void search_block(GroupSelect<KMAX, G, U>& sel, const BlockRuns<G, E>& runs, const float4* __restrict__ sorted, int k, int gl,
+                                             float qx, float qy, float qz)
+{
+  sel.reset();
+  for (uint32_t base = 0; __any(base < runs.total); base += G * U)
+  {
+    float4 p[U];
+    bool ok[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+    {
+      const uint32_t c = base + u * G + gl;
+      ok[u] = c < runs.total;
+      const uint32_t addr = runs.locate(c);
+      p[u] = sorted[ok[u] ? addr : 0];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+    {
+      const float dx = qx - p[u].x, dy = qy - p[u].y, dz = qz - p[u].z;
+      sel.cd[u] = ok[u] ? (dx * dx + dy * dy) + dz * dz : INFINITY;
+      sel.ci[u] = ok[u] ? __float_as_int(p[u].w) : 0x7fffffff;
+    }
+    sel.select(k, gl);
   }
 }
 
-// Exhaustive search for the queries k_knn deferred: one 256-thread block per query scans the whole
-// target with coalesced loads, every thread keeps a private top-k, the lists are merged by a 64-lane
-// shuffle butterfly and then across the 4 waves through LDS.  Same (distance, index) order => same result.
-template <int KMAX>
-__global__ __launch_bounds__(256) void k_knn_sparse(const float4* __restrict__ queries, Rigid pose, int k, const GridDesc* __restrict__ desc,
-                                                    const float4* __restrict__ sorted0, int* __restrict__ knn_idx, float* __restrict__ knn_d2,
-                                                    int* __restrict__ knn_cnt, int cap, const int* __restrict__ slow_counter,
-                                                    const int* __restrict__ slow_list)
+// First stage: every query, G lanes each, the 3x3x3 and then the 5x5x5 block of the finest grid (each round
+// searches its whole block afresh: no bookkeeping of what the previous round saw).  Queries that are not
+// settled inside 2 cells go to the second stage through the device list.
+template <int KMAX, int G>
+__global__ __launch_bounds__(256) void k_knn_first(const float4* __restrict__ queries, int nq, Rigid pose, int k, float far_d2,
+                                                   const GridDesc* __restrict__ desc, GridPtrs gp, int* __restrict__ knn_idx,
+                                                   float* __restrict__ knn_d2, int* __restrict__ knn_cnt, int cap, int* __restrict__ count_out,
+                                                   int* __restrict__ list_out)
 {
-  __shared__ float sd[4][KMAX];
-  __shared__ int si[4][KMAX];
-  const int nslow = *slow_counter;
-  const int m = desc->npoints;
-  for (int e = blockIdx.x; e < nslow; e += gridDim.x)
+  constexpr int U = 4, E = (25 + G - 1) / G;
+  const int gl = threadIdx.x % G;
+  const int q = (int)(((size_t)blockIdx.x * 256 + threadIdx.x) / G);
+  const bool active = q < nq;
+  float qx = 0.f, qy = 0.f, qz = 0.f;
+  if (active)
   {
-    const int q = slow_list[e];
+    // KeypointsMatcher: worldPoint = PosePrior * basePoint in double, narrowed to float for the search
+    const float4 q4 = queries[2 * (size_t)q];
+    double wx, wy, wz;
+    rigid_apply(pose, (double)q4.x, (double)q4.y, (double)q4.z, wx, wy, wz);
+    qx = (float)wx; qy = (float)wy; qz = (float)wz;
+  }
+  GridView gv;
+  grid_view(gv, desc, gp.cell_start[0], gp.sorted[0], qx, qy, qz);
+  GroupSelect<KMAX, G, U> sel;
+  sel.reset();
+  bool done = !active, far = false, deferred = false;
+  for (int r = 1; r <= 2; ++r)
+  {
+    if (__all(done)) break;
+    BlockRuns<G, E> runs;
+    runs.build(gv, r, gl, !done);
+    // groups that are done keep their result: their block is empty, `cur` is scratch for them
+    GroupSelect<KMAX, G, U> cur;
+    search_block<KMAX, G, U, E>(cur, runs, gv.sorted, k, gl, qx, qy, qz);
+    if (!done)
+    {
+      sel = cur;
+      // every point closer than r cells (minus a 0.1 % guard for the float cell assignment) has been seen
+      const float br = ((float)r - 0.001f) * gv.g.cell;
+      const float bound2 = gv.outd2 + br * br;
+      if (runs.covered || sel.count_below(bound2, k) >= k) done = true;
+      else if (bound2 > far_d2) { far = true; done = true; }
+      else if (r == 2)
+      {
+        if (gl == 0) list_out[atomicAdd(count_out, 1)] = q;
+        deferred = true;
+        done = true;
+      }
+    }
+  }
+  if (active && gl == 0 && !deferred)
+  {
+    int cnt = 0;
+#pragma unroll
+    for (int s = 0; s < KMAX; ++s)
+      if (s < k)
+      {
+        knn_idx[(size_t)s * cap + q] = sel.best_i[s];
+        knn_d2[(size_t)s * cap + q] = sel.best_d[s];
+        if (sel.best_i[s] != 0x7fffffff) ++cnt;
+      }
+    knn_cnt[q] = far ? kKnnFar : cnt;
+  }
+}
+
+// Second and last stage: one wavefront per query the first stage handed over (a few percent: the isolated
+// keypoints).  Coarser levels, two rounds each (3x3x3, then 5x5x5 cells), finally the whole target as one
+// run, so every query leaves this kernel answered.  Same (distance, index) order everywhere => the result
+// does not depend on the route taken.
+template <int KMAX>
+__global__ __launch_bounds__(256) void k_knn_second(const float4* __restrict__ queries, const int* __restrict__ list_in, const int* __restrict__ count_in,
+                                                    Rigid pose, int k, float far_d2, const GridDesc* __restrict__ desc, GridPtrs gp,
+                                                    int* __restrict__ knn_idx, float* __restrict__ knn_d2, int* __restrict__ knn_cnt, int cap,
+                                                    int* __restrict__ exhaustive_count)
+{
+  constexpr int G = 64, U = 8, E = 1;
+  constexpr int kStages = 2 * (kGridLevels - 1);  // (level 1, r = 1), (level 1, r = 2), (level 2, r = 1), (level 2, r = 2), then the whole target
+  const int gl = threadIdx.x & 63;
+  const int nwork = *count_in;
+  const int nwaves = gridDim.x * 4;
+  for (int w = blockIdx.x * 4 + (threadIdx.x >> 6); w < nwork; w += nwaves)
+  {
+    const int q = list_in[w];
     const float4 q4 = queries[2 * (size_t)q];
     double wx, wy, wz;
     rigid_apply(pose, (double)q4.x, (double)q4.y, (double)q4.z, wx, wy, wz);
     const float qx = (float)wx, qy = (float)wy, qz = (float)wz;
-    KnnSet<KMAX> ks;
-    ks.init(k);
-    scan_range(ks, sorted0, (uint32_t)threadIdx.x, (uint32_t)m, 256u, qx, qy, qz);
-#pragma unroll
-    for (int mask = 1; mask < 64; mask <<= 1)
+    GroupSelect<KMAX, G, U> sel;
+    bool done = false, far = false;
+    for (int stage = 0; stage <= kStages && !done; ++stage)
     {
-      float td[KMAX]; int ti[KMAX];
-#pragma unroll
-      for (int s = 0; s < KMAX; ++s)
+      BlockRuns<G, E> runs;
+      const float4* src;
+      float bound2 = 0.f;
+      if (stage < kStages)
       {
-        td[s] = __shfl_xor(ks.d2[s], mask);
-        ti[s] = __shfl_xor(ks.idx[s], mask);
+        const int level = 1 + stage / 2, r = 1 + stage % 2;
+        GridView gv;
+        grid_view(gv, desc + level, gp.cell_start[level], gp.sorted[level], qx, qy, qz);
+        runs.build(gv, r, gl, true);
+        src = gv.sorted;
+        const float br = ((float)r - 0.001f) * gv.g.cell;
+        bound2 = gv.outd2 + br * br;
       }
-#pragma unroll
-      for (int s = 0; s < KMAX; ++s)
-        if (s < k) ks.offer(td[s], ti[s]);
+      else
+      {
+        runs.whole((uint32_t)desc->npoints, gl);
+        src = gp.sorted[0];
+        if (gl == 0) atomicAdd(exhaustive_count, 1);
+      }
+      search_block<KMAX, G, U, E>(sel, runs, src, k, gl, qx, qy, qz);
+      if (runs.covered || sel.count_below(bound2, k) >= k) done = true;
+      else if (bound2 > far_d2) { far = true; done = true; }  // fewer than k points inside a radius beyond the rejection distance
     }
-    if ((threadIdx.x & 63) == 0)
+    if (gl == 0)
     {
-#pragma unroll
-      for (int s = 0; s < KMAX; ++s) { sd[threadIdx.x >> 6][s] = ks.d2[s]; si[threadIdx.x >> 6][s] = ks.idx[s]; }
-    }
-    __syncthreads();
-    if (threadIdx.x == 0)
-    {
-      for (int w = 1; w < 4; ++w)
-        for (int s = 0; s < k; ++s) ks.offer(sd[w][s], si[w][s]);
       int cnt = 0;
 #pragma unroll
       for (int s = 0; s < KMAX; ++s)
         if (s < k)
         {
-          knn_idx[(size_t)s * cap + q] = ks.idx[s];
-          knn_d2[(size_t)s * cap + q] = ks.d2[s];
-          if (ks.idx[s] != 0x7fffffff) ++cnt;
+          knn_idx[(size_t)s * cap + q] = sel.best_i[s];
+          knn_d2[(size_t)s * cap + q] = sel.best_d[s];
+          if (sel.best_i[s] != 0x7fffffff) ++cnt;
         }
-      knn_cnt[q] = cnt;
+      knn_cnt[q] = far ? kKnnFar : cnt;
     }
-    __syncthreads();
   }
 }
 
@@ -841,7 +927,7 @@ __device__ __forceinline__ void mv3(const double M[9], double x, double y, doubl
   oz = (M[6] * x + M[7] * y) + M[8] * z;
 }
 
-__global__ __launch_bounds__(256) void k_accumulate(AccumConst c, double* __restrict__ partials)
+__global__ __launch_bounds__(256) void k_accumulate(AccumConst c, double* __restrict__ partials, double* __restrict__ mailbox, unsigned long long seq)
 {
   double acc[kAccumVals];
 #pragma unroll
@@ -918,50 +1004,25 @@ __global__ __launch_bounds__(256) void k_accumulate(AccumConst c, double* __rest
   }
   __syncthreads();
   if (threadIdx.x < kAccumVals)
-    partials[(size_t)blockIdx.x * kAccumVals + threadIdx.x] =
-      ((wsum[0][threadIdx.x] + wsum[1][threadIdx.x]) + wsum[2][threadIdx.x]) + wsum[3][threadIdx.x];
-}
-
-// folds the per-block partials in a fixed order (one block: 256 partial rows x 29 values)
-__global__ __launch_bounds__(256) void k_accumulate_fold(const double* __restrict__ partials, int nblocks, double* __restrict__ out,
-                                                         double* __restrict__ mailbox, unsigned long long seq)
-{
-  __shared__ double wsum[4][kAccumVals];
-  double px[kAccumVals];
-#pragma unroll
-  for (int v = 0; v < kAccumVals; ++v) px[v] = ((int)threadIdx.x < nblocks) ? partials[(size_t)threadIdx.x * kAccumVals + v] : 0.;
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1)
-  {
-    double tmp[kAccumVals];
-#pragma unroll
-    for (int v = 0; v < kAccumVals; ++v) tmp[v] = __shfl_down(px[v], o);
-#pragma unroll
-    for (int v = 0; v < kAccumVals; ++v) px[v] += tmp[v];
-  }
-  if ((threadIdx.x & 63) == 0)
-  {
-#pragma unroll
-    for (int v = 0; v < kAccumVals; ++v) wsum[threadIdx.x >> 6][v] = px[v];
-  }
-  __syncthreads();
-  if (threadIdx.x < kAccumVals)
   {
     const double r = ((wsum[0][threadIdx.x] + wsum[1][threadIdx.x]) + wsum[2][threadIdx.x]) + wsum[3][threadIdx.x];
-    out[threadIdx.x] = r;
-    // zero-copy hand-over: the 29 doubles land in coherent host memory, then the sequence number that
-    // the host is polling -- no D2H copy, no stream synchronisation on the LM critical path
-    if (mailbox) __hip_atomic_store(&mailbox[threadIdx.x], r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    partials[(size_t)blockIdx.x * kAccumVals + threadIdx.x] = r;
+    // zero-copy hand-over: the block's 29 partial sums land in coherent host memory, then the sequence
+    // number the host is polling.  The host folds the blocks in index order (as k_accumulate_final does):
+    // no second kernel, no D2H copy, no stream synchronisation on the LM critical path.
+    if (mailbox) __hip_atomic_store(&mailbox[(size_t)blockIdx.x * kMailboxStride + threadIdx.x], r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
   if (mailbox)
   {
     __threadfence_system();
     __syncthreads();
     if (threadIdx.x == 0)
-      __hip_atomic_store(reinterpret_cast<unsigned long long*>(mailbox + 32), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(reinterpret_cast<unsigned long long*>(mailbox + (size_t)blockIdx.x * kMailboxStride + kMailboxFlag), seq, __ATOMIC_RELEASE,
+                         __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 
+// folds the per-block partials in block order (the path without a mailbox; same order as the host fold)
 __global__ void k_accumulate_final(const double* __restrict__ partials, int nblocks, double* __restrict__ out)
 {
   const int v = threadIdx.x;
@@ -1038,25 +1099,28 @@ void launch_knn(lsa_ctx* ctx, const lsa_point_t* q, int nq, const Rigid& pose, i
   GridPtrs gp;
   for (int l = 0; l < kGridLevels; ++l) { gp.cell_start[l] = t.lv[l].cell_start; gp.sorted[l] = t.lv[l].sorted; }
   const float4* q4 = reinterpret_cast<const float4*>(q);
-  int* cntA = hist + LSA_MATCH_NSTATUS;  // queries handed from the fine to the coarse kernel
-  int* cntB = cntA + 1;                           // ... from the coarse kernel to the exhaustive one
+  int* cntA = hist + LSA_MATCH_NSTATUS;  // queries handed from the first to the second stage
+  int* cntB = cntA + 1;                  // queries that needed the exhaustive scan (diagnostics)
   int* listA = mb.slow_list;
-  int* listB = mb.slow_list + mb.cap;
   const char* nf = type == LSA_EDGE ? "knn_fine_edge" : type == LSA_PLANE ? "knn_fine_plane" : "knn_fine_blob";
   const char* nc = type == LSA_EDGE ? "knn_coarse_edge" : type == LSA_PLANE ? "knn_coarse_plane" : "knn_coarse_blob";
   {
     // algorithmic bytes: query point in, k candidate points examined at least, k (index, distance) pairs out
     ProfScope ps(ctx, nf, (double)nq * (32 + k * 16 + k * 8), st);
-    hipLaunchKernelGGL((k_knn<KMAX, 8, 1, 0, 1>), dim3((nq * 8 + 255) / 256), dim3(256), 0, st, q4, nq, (const int*)nullptr,
-                       (const int*)nullptr, pose, k, far_d2, t.desc, gp, mb.knn_idx, mb.knn_d2, mb.knn_cnt, mb.cap, cntA, listA);
+    const int lanes = ctx->knn_lanes[type];
+#define LSA_FIRST(G)                                                                                                                     \
+  hipLaunchKernelGGL((k_knn_first<KMAX, G>), dim3((int)(((size_t)nq * G + 255) / 256)), dim3(256), 0, st, q4, nq, pose, k, far_d2, t.desc, gp, \
+                     mb.knn_idx, mb.knn_d2, mb.knn_cnt, mb.cap, cntA, listA)
+    if (lanes >= 32) LSA_FIRST(32);
+    else if (lanes >= 16) LSA_FIRST(16);
+    else LSA_FIRST(8);
+#undef LSA_FIRST
   }
   {
-    // the deferred share is only known on the device: no bytes are credited to these two stages
+    // the deferred share is only known on the device: no bytes are credited to this stage
     ProfScope ps(ctx, nc, 0., st);
-    hipLaunchKernelGGL((k_knn<KMAX, 64, 8, 1, kGridLevels>), dim3(512), dim3(256), 0, st, q4, nq, (const int*)listA, (const int*)cntA, pose, k,
-                       far_d2, t.desc, gp, mb.knn_idx, mb.knn_d2, mb.knn_cnt, mb.cap, cntB, listB);
-    hipLaunchKernelGGL((k_knn_sparse<KMAX>), dim3(256), dim3(256), 0, st, q4, pose, k, t.desc, t.lv[0].sorted, mb.knn_idx, mb.knn_d2,
-                       mb.knn_cnt, mb.cap, (const int*)cntB, (const int*)listB);
+    hipLaunchKernelGGL((k_knn_second<KMAX>), dim3(1024), dim3(256), 0, st, q4, (const int*)listA, (const int*)cntA, pose, k, far_d2, t.desc, gp,
+                       mb.knn_idx, mb.knn_d2, mb.knn_cnt, mb.cap, cntB);
   }
 }
 
@@ -1105,6 +1169,13 @@ int lsa_set_target_from_set(lsa_ctx* ctx, int slot, int type, int set)
   if (m == 0) return LSA_OK;
   LSA_HIP(ctx, hipMemcpyAsync(t.pts, ctx->kp[set][type], (size_t)m * sizeof(lsa_point_t), hipMemcpyDeviceToDevice, ctx->stream));
   t.dirty = true;
+  return LSA_OK;
+}
+
+int lsa_set_knn_lanes(lsa_ctx* ctx, int type, int lanes)
+{
+  if (!ctx || type < 0 || type > 2 || lanes < 1) return LSA_E_ARG;
+  ctx->knn_lanes[type] = lanes;
   return LSA_OK;
 }
 
@@ -1324,32 +1395,41 @@ int lsa_accumulate(lsa_ctx* ctx, unsigned type_mask, const double w[6], int want
   hipStream_t st = ctx->stream;
   {
     ProfScope ps(ctx, want_jacobian ? "accumulate_jac" : "accumulate_cost", (double)total * (want_jacobian ? 129 : 129));
-    hipLaunchKernelGGL(k_accumulate, dim3(kAccumBlocks), dim3(256), 0, st, c, ctx->partials);
-    hipLaunchKernelGGL(k_accumulate_fold, dim3(1), dim3(256), 0, st, ctx->partials, kAccumBlocks, ctx->reduce_out, ctx->mailbox, ++ctx->mailbox_seq);
+    hipLaunchKernelGGL(k_accumulate, dim3(kAccumBlocks), dim3(256), 0, st, c, ctx->partials, ctx->mailbox, ++ctx->mailbox_seq);
   }
   double* hp = ctx->host_pinned + 64;
   bool got = false;
   if (ctx->mailbox)
   {
-    // poll the mailbox (bounded: fall back to a synchronous copy if the flag does not arrive)
-    volatile unsigned long long* flag = reinterpret_cast<volatile unsigned long long*>(ctx->mailbox + 32);
+    // poll the blocks' flags (bounded: fall back to a device fold + synchronous copy if one does not arrive)
     const auto t0 = std::chrono::steady_clock::now();
     unsigned spins = 0;
-    while (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != ctx->mailbox_seq)
+    bool timeout = false;
+    for (int b = 0; b < kAccumBlocks && !timeout; ++b)
     {
-      if ((++spins & 0x3ff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) break;
+      volatile unsigned long long* flag = reinterpret_cast<volatile unsigned long long*>(ctx->mailbox + (size_t)b * kMailboxStride + kMailboxFlag);
+      while (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != ctx->mailbox_seq)
+      {
+        if ((++spins & 0x3ff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) { timeout = true; break; }
 #if defined(__x86_64__)
-      __builtin_ia32_pause();
+        __builtin_ia32_pause();
 #endif
+      }
     }
-    if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == ctx->mailbox_seq)
+    if (!timeout)
     {
-      for (int v = 0; v < kAccumVals; ++v) hp[v] = ctx->mailbox[v];
+      for (int v = 0; v < kAccumVals; ++v) hp[v] = 0.;
+      for (int b = 0; b < kAccumBlocks; ++b)
+      {
+        const double* row = ctx->mailbox + (size_t)b * kMailboxStride;
+        for (int v = 0; v < kAccumVals; ++v) hp[v] += row[v];
+      }
       got = true;
     }
   }
   if (!got)
   {
+    hipLaunchKernelGGL(k_accumulate_final, dim3(1), dim3(64), 0, st, ctx->partials, kAccumBlocks, ctx->reduce_out);
     LSA_HIP(ctx, hipMemcpyAsync(hp, ctx->reduce_out, kAccumVals * sizeof(double), hipMemcpyDeviceToHost, st));
     LSA_HIP(ctx, hipStreamSynchronize(st));
   }

@@ -19,6 +19,8 @@ using namespace lsa;
 namespace
 {
 
+constexpr int kLabelThreads = 512;  // one block per ring
+
 struct ExtractConst
 {
   int W;
@@ -66,51 +68,109 @@ __global__ __launch_bounds__(256) void k_ring_hist(const float4* __restrict__ fr
   for (int r = threadIdx.x; r < kMaxRings; r += blockDim.x) block_hist[(size_t)blockIdx.x * kMaxRings + r] = h[r];
 }
 
-__global__ __launch_bounds__(kMaxRings) void k_ring_scan(uint32_t* __restrict__ block_hist, int nblocks, int* __restrict__ ring_start,
-                                                         int* __restrict__ ring_len, int* __restrict__ ring_meta)
+// One wavefront per ring: exclusive scan of the ring's column of the per-chunk histograms (where the ring's
+// points of chunk b start inside the ring), the ring's length; ring 0 also publishes NbLaserRings.
+__global__ __launch_bounds__(64) void k_ring_scan(uint32_t* __restrict__ block_hist, int nblocks, int* __restrict__ ring_len, int* __restrict__ ring_meta)
 {
-  __shared__ int s[kMaxRings];
-  const int r = threadIdx.x;
-  uint32_t sum = 0;
-  for (int b = 0; b < nblocks; ++b)
+  const int r = blockIdx.x, lane = threadIdx.x;
+  const int per = (nblocks + 63) / 64;
+  const int b0 = min(nblocks, lane * per), b1 = min(nblocks, b0 + per);
+  uint32_t mine = 0;
+  for (int b = b0; b < b1; ++b) mine += block_hist[(size_t)b * kMaxRings + r];
+  uint32_t inc = mine;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1)
   {
-    uint32_t v = block_hist[(size_t)b * kMaxRings + r];
-    block_hist[(size_t)b * kMaxRings + r] = sum;
-    sum += v;
+    const uint32_t t = __shfl_up(inc, o);
+    if (lane >= o) inc += t;
   }
-  ring_len[r] = (int)sum;
-  s[r] = (int)sum;
-  __syncthreads();
-  for (int o = 1; o < kMaxRings; o <<= 1)
+  uint32_t run = inc - mine;
+  for (int b = b0; b < b1; ++b)
   {
-    int v = (r >= o) ? s[r - o] : 0;
-    __syncthreads();
-    s[r] += v;
-    __syncthreads();
+    const uint32_t v = block_hist[(size_t)b * kMaxRings + r];
+    block_hist[(size_t)b * kMaxRings + r] = run;
+    run += v;
   }
-  ring_start[r] = s[r] - (int)sum;
-  if (r == kMaxRings - 1) ring_start[kMaxRings] = s[r];
-  if (r == 0) ring_meta[0] = ring_meta[1] + 1;  // NbLaserRings = max laser_id + 1 (SSKE.cxx:153-164)
+  if (lane == 63) ring_len[r] = (int)inc;
+  if (r == 0 && lane == 0) ring_meta[0] = ring_meta[1] + 1;  // NbLaserRings = max laser id + 1 (SSKE.cxx:153-164)
 }
 
+// lanes of the wavefront holding the same key (9-bit ring id): 9 ballots
+__device__ __forceinline__ unsigned long long same_ring_lanes(unsigned id, bool active)
+{
+  unsigned long long m = __ballot(active);
+#pragma unroll
+  for (int bit = 0; bit < 9; ++bit)
+  {
+    const unsigned long long bal = __ballot(active && ((id >> bit) & 1u));
+    m &= ((id >> bit) & 1u) ? bal : ~bal;
+  }
+  return m;
+}
+
+// Stable scatter of one chunk of the scan into ring-major order.  Wave 0 ranks the chunk 64 points at a time,
+// in arrival order: a point's slot is ring_start + (points of its ring in earlier chunks) + (in earlier
+// batches of this chunk, a running count in LDS) + (in lower lanes of its batch, a popcount).  Then the whole
+// block moves the points.  Every block derives ring_start from ring_len itself (a 512-entry scan in LDS);
+// block 0 publishes it for the later kernels.
 __global__ __launch_bounds__(256) void k_ring_scatter(const float4* __restrict__ frame, int n, const uint32_t* __restrict__ block_hist,
-                                                      const int* __restrict__ ring_start, const int* __restrict__ ring_meta,
+                                                      const int* __restrict__ ring_len, int* __restrict__ ring_start,
                                                       float4* __restrict__ xyzi, uint32_t* __restrict__ orig, uint16_t* __restrict__ ring_of,
                                                       uint8_t* __restrict__ valid)
 {
   __shared__ uint16_t ids[kBucketChunk];
   __shared__ uint32_t dest[kBucketChunk];
+  __shared__ uint32_t slot[kMaxRings];  // next free slot of every ring for this chunk
+  __shared__ int scan[kMaxRings];
   const int base = blockIdx.x * kBucketChunk;
   const int cnt = min(kBucketChunk, n - base);
   for (int i = threadIdx.x; i < cnt; i += blockDim.x) ids[i] = (uint16_t)laser_of(frame[2 * (size_t)(base + i) + 1]);
+  for (int r = threadIdx.x; r < kMaxRings; r += blockDim.x) scan[r] = ring_len[r];
   __syncthreads();
-  const int nrings = ring_meta[0];
-  // one thread owns one ring of the chunk and walks it in arrival order: stable by construction
-  for (int r = threadIdx.x; r < nrings; r += blockDim.x)
+  // inclusive scan of the 512 ring lengths, two per thread
   {
-    uint32_t d = (uint32_t)ring_start[r] + block_hist[(size_t)blockIdx.x * kMaxRings + r];
-    for (int i = 0; i < cnt; ++i)
-      if (ids[i] == r) dest[i] = d++;
+    const int t = threadIdx.x;
+    const int a0 = scan[2 * t], a1 = scan[2 * t + 1];
+    __shared__ int pair[256];
+    pair[t] = a0 + a1;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1)
+    {
+      const int v = (t >= o) ? pair[t - o] : 0;
+      __syncthreads();
+      pair[t] += v;
+      __syncthreads();
+    }
+    const int before = pair[t] - (a0 + a1);
+    const uint32_t s0 = (uint32_t)before, s1 = (uint32_t)(before + a0);
+    slot[2 * t] = s0 + block_hist[(size_t)blockIdx.x * kMaxRings + 2 * t];
+    slot[2 * t + 1] = s1 + block_hist[(size_t)blockIdx.x * kMaxRings + 2 * t + 1];
+    if (blockIdx.x == 0)
+    {
+      ring_start[2 * t] = (int)s0;
+      ring_start[2 * t + 1] = (int)s1;
+      if (t == 255) ring_start[kMaxRings] = pair[t];
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 64)
+  {
+    const int lane = threadIdx.x;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    for (int b = 0; b < cnt; b += 64)
+    {
+      const int i = b + lane;
+      const unsigned id = i < cnt ? ids[i] : 0u;
+      const bool active = i < cnt && id < (unsigned)kMaxRings;
+      const unsigned long long same = same_ring_lanes(id, active);
+      if (active)
+      {
+        const uint32_t s = slot[id];
+        dest[i] = s + (uint32_t)__popcll(same & below);
+        // the last lane of the ring in this batch advances the ring's slot for the next batch
+        if ((same >> lane) == 1ull) slot[id] = s + (uint32_t)__popcll(same);
+      }
+    }
   }
   __syncthreads();
   for (int i = threadIdx.x; i < cnt; i += blockDim.x)
@@ -348,43 +408,43 @@ __global__ __launch_bounds__(128) void k_curvature(const float4* __restrict__ xy
 // Greedy non-maximum selection as a fixed point.  st: 0 = out, 1 = undecided candidate, 2 = selected.
 // prio(k) > prio(j):  EDGE  score desc, index asc   (Utils::SortIdx(v, false) + stable tie-break)
 //                     PLANE score asc,  index desc  (the same sorted array walked backwards)
+// Every thread owns a contiguous chunk of the ring and sweeps it forwards, then backwards, updating the states
+// IN PLACE: a decision is only ever taken on final facts (a selected neighbour; no undecided neighbour of
+// higher priority), so reading a neighbour's old or new state both give correct, merely earlier or later,
+// decisions -- and a sweep carries a decision across the whole chunk instead of one window per round.
 template <bool PLANE>
-__device__ uint8_t* nms_fixed_point(const float* sc, uint8_t* st, uint8_t* st2, int np, int hw)
+__device__ void nms_fixed_point(const float* sc, volatile uint8_t* st, int np, int hw)
 {
+  const int per = (np + blockDim.x - 1) / blockDim.x;
+  const int j0 = min(np, (int)threadIdx.x * per), j1 = min(np, j0 + per);
+  auto visit = [&](int j) -> int {
+    if (st[j] != 1) return 0;
+    const float v = sc[j];
+    const int b = max(0, j - hw), e = min(np - 1, j + hw);
+    bool selNear = false, higher = false;
+    for (int k = b; k <= e; ++k)
+    {
+      if (k == j) continue;
+      const uint8_t sk = st[k];
+      if (sk == 2) selNear = true;
+      else if (sk == 1)
+      {
+        const float vk = sc[k];
+        const bool hk = PLANE ? (vk < v || (vk == v && k > j)) : (vk > v || (vk == v && k < j));
+        if (hk) higher = true;
+      }
+    }
+    if (selNear) { st[j] = 0; return 0; }
+    if (!higher) { st[j] = 2; return 0; }
+    return 1;
+  };
   while (true)
   {
     int undecided = 0;
-    for (int j = threadIdx.x; j < np; j += blockDim.x)
-    {
-      uint8_t s = st[j];
-      if (s == 1)
-      {
-        const float v = sc[j];
-        const int b = max(0, j - hw), e = min(np - 1, j + hw);
-        bool selNear = false, higher = false;
-        for (int k = b; k <= e; ++k)
-        {
-          if (k == j) continue;
-          const uint8_t sk = st[k];
-          if (sk == 2) selNear = true;
-          else if (sk == 1)
-          {
-            const float vk = sc[k];
-            const bool hk = PLANE ? (vk < v || (vk == v && k > j)) : (vk > v || (vk == v && k < j));
-            if (hk) higher = true;
-          }
-        }
-        if (selNear) s = 0;
-        else if (!higher) s = 2;
-        else undecided = 1;
-      }
-      st2[j] = s;
-    }
-    const int any = __syncthreads_or(undecided);
-    uint8_t* t = st; st = st2; st2 = t;
-    if (!any) break;
+    for (int j = j0; j < j1; ++j) visit(j);
+    for (int j = j1 - 1; j >= j0; --j) undecided |= visit(j);
+    if (!__syncthreads_or(undecided)) break;
   }
-  return st;  // final state (the buffers were swapped once per round)
 }
 
 // after a selection round: label the winners, clear the validity bit `vbit` within +-hw of them
@@ -403,7 +463,7 @@ __device__ void nms_apply(const uint8_t* st, uint8_t* flags, int np, int hw, uin
   __syncthreads();
 }
 
-__global__ __launch_bounds__(256) void k_label(const float* __restrict__ g_angle, const float* __restrict__ g_gap,
+__global__ __launch_bounds__(kLabelThreads) void k_label(const float* __restrict__ g_angle, const float* __restrict__ g_gap,
                                                const float* __restrict__ g_sal, const float* __restrict__ g_int,
                                                const int* __restrict__ ring_start, const int* __restrict__ ring_len,
                                                int* __restrict__ ring_meta, ExtractConst c, uint8_t* __restrict__ valid,
@@ -411,7 +471,6 @@ __global__ __launch_bounds__(256) void k_label(const float* __restrict__ g_angle
 {
   __shared__ float sc[kMaxRingPoints];
   __shared__ uint8_t stA[kMaxRingPoints];
-  __shared__ uint8_t stB[kMaxRingPoints];
   __shared__ uint8_t flags[kMaxRingPoints];  // bits 0-2 validity E/P/B, bits 3-5 label E/P/B
   __shared__ int cnt[3];
   const int r = blockIdx.x;
@@ -448,7 +507,8 @@ __global__ __launch_bounds__(256) void k_label(const float* __restrict__ g_angle
       stA[j] = ((v >= thr) && (flags[j] & 1)) ? 1 : 0;  // NaN never qualifies
     }
     __syncthreads();
-    nms_apply(nms_fixed_point<false>(sc, stA, stB, np, hw), flags, np, hw, 1, 8);
+    nms_fixed_point<false>(sc, stA, np, hw);
+    nms_apply(stA, flags, np, hw, 1, 8);
   }
 
   // --- planes: ascending sin angle, skip < 1e-6, stop above the threshold, +-4 window (SSKE.cxx:536-563)
@@ -462,7 +522,8 @@ __global__ __launch_bounds__(256) void k_label(const float* __restrict__ g_angle
       stA[j] = cand ? 1 : 0;
     }
     __syncthreads();
-    nms_apply(nms_fixed_point<true>(sc, stA, stB, np, hw), flags, np, hw, 2, 16);
+    nms_fixed_point<true>(sc, stA, np, hw);
+    nms_apply(stA, flags, np, hw, 2, 16);
   }
 
   // --- blobs (SSKE.cxx:568-572) + validity bit set back for labelled points (:584) + counts
@@ -623,8 +684,8 @@ int lsa_extract_keypoints(lsa_ctx* ctx, const lsa_extract_params_t* params, int 
   {
     ProfScope ps(ctx, "ring_bucket", (double)n * (4 + 32 + 16 + 4 + 2 + 1));
     hipLaunchKernelGGL(k_ring_hist, dim3(nblocks), dim3(256), 0, st, frame4, n, ctx->block_hist, ctx->ring_meta);
-    hipLaunchKernelGGL(k_ring_scan, dim3(1), dim3(kMaxRings), 0, st, ctx->block_hist, nblocks, ctx->ring_start, ctx->ring_len, ctx->ring_meta);
-    hipLaunchKernelGGL(k_ring_scatter, dim3(nblocks), dim3(256), 0, st, frame4, n, ctx->block_hist, ctx->ring_start, ctx->ring_meta,
+    hipLaunchKernelGGL(k_ring_scan, dim3(kMaxRings), dim3(64), 0, st, ctx->block_hist, nblocks, ctx->ring_len, ctx->ring_meta);
+    hipLaunchKernelGGL(k_ring_scatter, dim3(nblocks), dim3(256), 0, st, frame4, n, ctx->block_hist, ctx->ring_len, ctx->ring_start,
                        ctx->xyzi, ctx->orig, ctx->ring_of, ctx->valid);
   }
   {
@@ -643,7 +704,7 @@ int lsa_extract_keypoints(lsa_ctx* ctx, const lsa_extract_params_t* params, int 
   }
   {
     ProfScope ps(ctx, "label_nms", (double)n * (16 + 1 + 1 + 1));
-    hipLaunchKernelGGL(k_label, dim3(kMaxRings), dim3(256), 0, st, ctx->score[0], ctx->score[1], ctx->score[2], ctx->score[3], ctx->ring_start,
+    hipLaunchKernelGGL(k_label, dim3(kMaxRings), dim3(kLabelThreads), 0, st, ctx->score[0], ctx->score[1], ctx->score[2], ctx->score[3], ctx->ring_start,
                        ctx->ring_len, ctx->ring_meta, c, ctx->valid, ctx->label, ctx->ring_counts);
   }
   {

@@ -461,8 +461,10 @@ struct BlockRuns
   uint32_t b[E], len[E];
   uint32_t excl, total;
   bool covered;
-  // every lane of the wavefront calls this (shuffles); groups with live == false get an empty block
-  __device__ __forceinline__ void build(const GridView& gv, int r, int gl, bool live)
+  // every lane of the wavefront calls these (shuffles); groups with live == false get an empty block.
+  // fetch() only issues the loads of the row bounds, finish() consumes them: several blocks can be fetched
+  // before the first is finished, their loads overlap.
+  __device__ __forceinline__ void fetch(const GridView& gv, int r, int gl, bool live)
   {
     const int nx = gv.g.dims[0], ny = gv.g.dims[1], nz = gv.g.dims[2];
     const int z0 = max(0, gv.cz - r), z1 = min(nz - 1, gv.cz + r);
@@ -471,7 +473,6 @@ struct BlockRuns
     const int ys = y1 - y0 + 1;
     const int nrows = live ? (z1 - z0 + 1) * ys : 0;
     covered = (x0 == 0 && y0 == 0 && z0 == 0 && x1 == nx - 1 && y1 == ny - 1 && z1 == nz - 1);
-    uint32_t mine = 0;
 #pragma unroll
     for (int e = 0; e < E; ++e)
     {
@@ -481,8 +482,17 @@ struct BlockRuns
       {
         const int row = ((z0 + ri / ys) * ny + (y0 + ri % ys)) * nx;
         b[e] = gv.cell_start[row + x0];
-        len[e] = gv.cell_start[row + x1 + 1] - b[e];
+        len[e] = gv.cell_start[row + x1 + 1];  // end of the run until finish()
       }
+    }
+  }
+  __device__ __forceinline__ void finish(int gl)
+  {
+    uint32_t mine = 0;
+#pragma unroll
+    for (int e = 0; e < E; ++e)
+    {
+      len[e] -= b[e];
       mine += len[e];
     }
     uint32_t inc = mine;
@@ -494,6 +504,11 @@ struct BlockRuns
     }
     excl = inc - mine;  // non-decreasing over the lanes of the group
     total = __shfl(inc, G - 1, G);
+  }
+  __device__ __forceinline__ void build(const GridView& gv, int r, int gl, bool live)
+  {
+    fetch(gv, r, gl, live);
+    finish(gl);
   }
   // the whole target as one run (exhaustive stage)
   __device__ __forceinline__ void whole(uint32_t m, int gl)
@@ -635,7 +650,7 @@ __global__ __launch_bounds__(256) void k_knn_second(const float4* __restrict__ q
                                                     int* __restrict__ exhaustive_count)
 {
   constexpr int G = 64, U = 8, E = 1;
-  constexpr int kStages = 2 * (kGridLevels - 1);  // (level 1, r = 1), (level 1, r = 2), (level 2, r = 1), (level 2, r = 2), then the whole target
+  constexpr int kStages = 2 * (kGridLevels - 1);  // blocks (level 1, r = 1), (level 1, r = 2), (level 2, r = 1), (level 2, r = 2); then the whole target
   const int gl = threadIdx.x & 63;
   const int nwork = *count_in;
   const int nwaves = gridDim.x * 4;
@@ -647,31 +662,43 @@ __global__ __launch_bounds__(256) void k_knn_second(const float4* __restrict__ q
     rigid_apply(pose, (double)q4.x, (double)q4.y, (double)q4.z, wx, wy, wz);
     const float qx = (float)wx, qy = (float)wy, qz = (float)wz;
     GroupSelect<KMAX, G, U> sel;
+    sel.reset();
     bool done = false, far = false;
-    for (int stage = 0; stage <= kStages && !done; ++stage)
+    // the row bounds of all four blocks in one memory round trip; a block holding fewer than k points cannot
+    // settle the query and is not scanned at all
+    BlockRuns<G, E> runs[kStages];
+    float bound2[kStages];
+#pragma unroll
+    for (int stage = 0; stage < kStages; ++stage)
     {
-      BlockRuns<G, E> runs;
-      const float4* src;
-      float bound2 = 0.f;
-      if (stage < kStages)
+      const int level = 1 + stage / 2, r = 1 + stage % 2;
+      GridView gv;
+      grid_view(gv, desc + level, gp.cell_start[level], gp.sorted[level], qx, qy, qz);
+      runs[stage].fetch(gv, r, gl, true);
+      // every point closer than r cells (minus a 0.1 % guard for the float cell assignment) is in the block
+      const float br = ((float)r - 0.001f) * gv.g.cell;
+      bound2[stage] = gv.outd2 + br * br;
+    }
+#pragma unroll
+    for (int stage = 0; stage < kStages; ++stage) runs[stage].finish(gl);
+#pragma unroll
+    for (int stage = 0; stage < kStages; ++stage)
+    {
+      if (done) continue;
+      if (runs[stage].covered || runs[stage].total >= (uint32_t)k)
       {
-        const int level = 1 + stage / 2, r = 1 + stage % 2;
-        GridView gv;
-        grid_view(gv, desc + level, gp.cell_start[level], gp.sorted[level], qx, qy, qz);
-        runs.build(gv, r, gl, true);
-        src = gv.sorted;
-        const float br = ((float)r - 0.001f) * gv.g.cell;
-        bound2 = gv.outd2 + br * br;
+        search_block<KMAX, G, U, E>(sel, runs[stage], gp.sorted[1 + stage / 2], k, gl, qx, qy, qz);
+        if (runs[stage].covered || sel.count_below(bound2[stage], k) >= k) done = true;
       }
-      else
-      {
-        runs.whole((uint32_t)desc->npoints, gl);
-        src = gp.sorted[0];
-        if (gl == 0) atomicAdd(exhaustive_count, 1);
-      }
-      search_block<KMAX, G, U, E>(sel, runs, src, k, gl, qx, qy, qz);
-      if (runs.covered || sel.count_below(bound2, k) >= k) done = true;
-      else if (bound2 > far_d2) { far = true; done = true; }  // fewer than k points inside a radius beyond the rejection distance
+      // fewer than k points inside a radius beyond the rejection distance
+      if (!done && bound2[stage] > far_d2) { far = true; done = true; }
+    }
+    if (!done)
+    {
+      BlockRuns<G, E> all;
+      all.whole((uint32_t)desc->npoints, gl);
+      if (gl == 0) atomicAdd(exhaustive_count, 1);
+      search_block<KMAX, G, U, E>(sel, all, gp.sorted[0], k, gl, qx, qy, qz);
     }
     if (gl == 0)
     {
@@ -1010,7 +1037,8 @@ __global__ __launch_bounds__(256) void k_accumulate(AccumConst c, double* __rest
     // zero-copy hand-over: the block's 29 partial sums land in coherent host memory, then the sequence
     // number the host is polling.  The host folds the blocks in index order (as k_accumulate_final does):
     // no second kernel, no D2H copy, no stream synchronisation on the LM critical path.
-    if (mailbox) __hip_atomic_store(&mailbox[(size_t)blockIdx.x * kMailboxStride + threadIdx.x], r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    // (plain stores: the 29 lanes' 8 bytes leave as a few wide writes, per-lane atomics would each be a bus transaction)
+    if (mailbox) mailbox[(size_t)blockIdx.x * kMailboxStride + threadIdx.x] = r;
   }
   if (mailbox)
   {

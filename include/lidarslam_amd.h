@@ -255,6 +255,9 @@ int lsa_undistort(lsa_ctx* ctx, const double H0[16], const double H1[16], double
  * (Slam.cxx:1026-1029). */
 int lsa_working_time_range(lsa_ctx* ctx, double* tmin, double* tmax);
 int lsa_working_bbox(lsa_ctx* ctx, int type, const double pose[16], float mn[3], float mx[3]);
+/* The same for the three keypoint types in one pass and one synchronisation:
+ * mn / mx = [type][xyz]. */
+int lsa_working_bboxes(lsa_ctx* ctx, const double pose[16], float mn[9], float mx[9]);
 
 /* Slam::TransformPointCloud (Slam.cxx:1491-1509) on a device keypoint set:
  * writes pose * set to `out` on the host. */

@@ -9,7 +9,8 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG, "liblidarslam_amd.so")
+# LSA_LIB: another build of the same ABI, for A/B timing on one box (scripts/ab.sh)
+LIB_PATH = os.environ.get("LSA_LIB") or os.path.join(PKG, "liblidarslam_amd.so")
 SYNTH_LIB_PATH = os.path.join(PKG, "libslamsynth.so")
 
 # 32-byte LidarPoint (slam_lib/include/LidarSlam/LidarPoint.h:31-64)

@@ -335,21 +335,28 @@ int SlamCore::Localization()
     Stats.maps_async = std::max(MapJobSeconds[0], std::max(MapJobSeconds[1], MapJobSeconds[2]));
     // sub-map extraction: bounding boxes from the device, then the three maps side by side on their workers
     bool rebuild[3] = {false, false, false};
+    bool any = false;
     for (int k = 0; k < 3; ++k)
     {
-      if (!(UseKeypoints[k] && !LocalMaps[k]->IsSubMapValid())) continue;
-      rebuild[k] = true;
+      rebuild[k] = UseKeypoints[k] && !LocalMaps[k]->IsSubMapValid();
+      any = any || rebuild[k];
+    }
+    float mn[9], mx[9];
+    if (any && MapUpdate != MappingMode::NONE) LSA_TRY(lsa_working_bboxes(Ctx, Tworld.m, mn, mx));  // all types, one pass
+    for (int k = 0; k < 3; ++k)
+    {
+      if (!rebuild[k]) continue;
       RollingGrid* map = LocalMaps[k].get();
       if (MapUpdate == MappingMode::NONE)
         MapWorker[k].Submit([map] { map->BuildSubMap(); });
       else
       {
-        float mn[3], mx[3];
-        LSA_TRY(lsa_working_bbox(Ctx, k, Tworld.m, mn, mx));
         const bool clear = map->IsTimeThreshold();
         const double now = CurrentTime;
         const int minPts = KeypointCounts[k] / 2;
-        MapWorker[k].Submit([map, clear, now, minPts, mn0 = mn[0], mn1 = mn[1], mn2 = mn[2], mx0 = mx[0], mx1 = mx[1], mx2 = mx[2]] {
+        const float* lo3 = mn + 3 * k;
+        const float* hi3 = mx + 3 * k;
+        MapWorker[k].Submit([map, clear, now, minPts, mn0 = lo3[0], mn1 = lo3[1], mn2 = lo3[2], mx0 = hi3[0], mx1 = hi3[1], mx2 = hi3[2]] {
           if (clear) map->ClearOldPoints(now);
           const float lo[3] = {mn0, mn1, mn2}, hi[3] = {mx0, mx1, mx2};
           map->BuildSubMap(lo, hi, minPts);

@@ -132,6 +132,9 @@ struct lsa_ctx
   // keypoint sets [set][type]
   lsa_point_t* kp[3][3] = {};
   int kp_n[3][3] = {};
+  // [min, max] of the points' time field per set, kept while it is known (lsa_working_time_range)
+  double kp_time[3][2] = {};
+  bool kp_time_valid[3] = {false, false, false};
 
   lsa::Target target[6];  // [slot * 3 + type]: slot 0 = map sub-maps (localization), slot 1 = previous scan (ego-motion)
   lsa::MatchBuf match[3];
@@ -180,6 +183,8 @@ int ensure_capacity(lsa_ctx* ctx, int n);
 int ensure_target(lsa_ctx* ctx, int ti, int m);
 int ensure_match(lsa_ctx* ctx, int type, int k);
 int ensure_scratch(lsa_ctx* ctx, size_t bytes);
+int enqueue_time_range(lsa_ctx* ctx, int set, const int* counts_dev);
+void finish_time_range(lsa_ctx* ctx, int set, const unsigned long long bits[2]);
 
 // RAII helper: times the enclosed launches with HIP events on the ctx stream when profiling
 struct ProfScope

@@ -675,6 +675,10 @@ int lsa_extract_keypoints(lsa_ctx* ctx, const lsa_extract_params_t* params, int 
     ctx->kp_n[LSA_SET_RAW_PREVIOUS][k] = ctx->kp_n[LSA_SET_RAW_CURRENT][k];
     ctx->kp_n[LSA_SET_RAW_CURRENT][k] = 0;
   }
+  ctx->kp_time_valid[LSA_SET_RAW_PREVIOUS] = ctx->kp_time_valid[LSA_SET_RAW_CURRENT];
+  ctx->kp_time[LSA_SET_RAW_PREVIOUS][0] = ctx->kp_time[LSA_SET_RAW_CURRENT][0];
+  ctx->kp_time[LSA_SET_RAW_PREVIOUS][1] = ctx->kp_time[LSA_SET_RAW_CURRENT][1];
+  ctx->kp_time_valid[LSA_SET_RAW_CURRENT] = false;
 
   const int nblocks = (n + kBucketChunk - 1) / kBucketChunk;
   const float4* frame4 = reinterpret_cast<const float4*>(ctx->frame);
@@ -714,9 +718,14 @@ int lsa_extract_keypoints(lsa_ctx* ctx, const lsa_extract_params_t* params, int 
                        reinterpret_cast<float4*>(ctx->kp[LSA_SET_RAW_CURRENT][1]), reinterpret_cast<float4*>(ctx->kp[LSA_SET_RAW_CURRENT][2]),
                        ctx->kp_count_dev);
   }
+  // the keypoints' time range (Slam::InitUndistortion needs it later) rides on this synchronisation
+  rc = enqueue_time_range(ctx, LSA_SET_RAW_CURRENT, ctx->kp_count_dev);
+  if (rc) return rc;
   int* hp = reinterpret_cast<int*>(ctx->host_pinned);
+  unsigned long long* hpt = reinterpret_cast<unsigned long long*>(ctx->host_pinned + 128);
   LSA_HIP(ctx, hipMemcpyAsync(hp, ctx->kp_count_dev, 3 * sizeof(int), hipMemcpyDeviceToHost, st));
   LSA_HIP(ctx, hipMemcpyAsync(hp + 4, ctx->ring_meta, 3 * sizeof(int), hipMemcpyDeviceToHost, st));
+  LSA_HIP(ctx, hipMemcpyAsync(hpt, ctx->range_bits, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
   LSA_HIP(ctx, hipStreamSynchronize(st));
   if (hp[6] & 1) return ctx->fail(LSA_E_CAPACITY, "lsa_extract_keypoints: laser_id >= 512 is not supported");
   if (hp[6] & 2) return ctx->fail(LSA_E_CAPACITY, "lsa_extract_keypoints: more than 8192 points on one laser ring");
@@ -726,6 +735,7 @@ int lsa_extract_keypoints(lsa_ctx* ctx, const lsa_extract_params_t* params, int 
     counts[k] = hp[k];
     ctx->kp_n[LSA_SET_RAW_CURRENT][k] = hp[k];
   }
+  finish_time_range(ctx, LSA_SET_RAW_CURRENT, hpt);
   return LSA_OK;
 }
 
@@ -757,6 +767,7 @@ int lsa_set_keypoints(lsa_ctx* ctx, int set, int type, const lsa_point_t* pts, i
     LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));  // pts may be pageable and reused by the caller
   }
   ctx->kp_n[set][type] = k;
+  ctx->kp_time_valid[set] = false;
   return LSA_OK;
 }
 
@@ -782,6 +793,7 @@ int lsa_transform_keypoints(lsa_ctx* ctx, int set, int type, const double T[16],
 {
   if (!ctx || !T || set < 0 || set > 2 || type < 0 || type > 2) return ctx ? ctx->fail(LSA_E_ARG, "lsa_transform_keypoints: bad argument") : LSA_E_ARG;
   const int n = ctx->kp_n[set][type];
+  if (time_offset != 0.) ctx->kp_time_valid[set] = false;
   if (n <= 0) return LSA_OK;
   Rigid R;
   row_major_to_rt(T, R.R, R.t);

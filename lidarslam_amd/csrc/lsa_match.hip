@@ -550,24 +550,31 @@ __device__ __forceinline__ void search_block(GroupSelect<KMAX, G, U>& sel, const
                                              float qx, float qy, float qz)
 {
   sel.reset();
-  for (uint32_t base = 0; __any(base < runs.total); base += G * U)
-  {
-    float4 p[U];
-    bool ok[U];
+  // software pipeline: the loads of batch i + 1 are in flight while batch i is being picked from
+  float4 nxt[U];
+  auto issue = [&](uint32_t base) {
 #pragma unroll
     for (int u = 0; u < U; ++u)
     {
       const uint32_t c = base + u * G + gl;
-      ok[u] = c < runs.total;
       const uint32_t addr = runs.locate(c);
-      p[u] = sorted[ok[u] ? addr : 0];
+      nxt[u] = sorted[c < runs.total ? addr : 0];
     }
+  };
+  if (__any(0u < runs.total)) issue(0);
+  for (uint32_t base = 0; __any(base < runs.total); base += G * U)
+  {
+    float4 p[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) p[u] = nxt[u];
+    if (__any(base + G * U < runs.total)) issue(base + G * U);
 #pragma unroll
     for (int u = 0; u < U; ++u)
     {
+      const bool ok = base + u * G + gl < runs.total;
       const float dx = qx - p[u].x, dy = qy - p[u].y, dz = qz - p[u].z;
-      sel.cd[u] = ok[u] ? (dx * dx + dy * dy) + dz * dz : INFINITY;
-      sel.ci[u] = ok[u] ? __float_as_int(p[u].w) : 0x7fffffff;
+      sel.cd[u] = ok ? (dx * dx + dy * dy) + dz * dz : INFINITY;
+      sel.ci[u] = ok ? __float_as_int(p[u].w) : 0x7fffffff;
     }
     sel.select(k, gl);
   }
@@ -618,7 +625,17 @@ __global__ __launch_bounds__(256) void k_knn_first(const float4* __restrict__ qu
       else if (bound2 > far_d2) { far = true; done = true; }
       else if (r == 2)
       {
-        if (gl == 0) list_out[atomicAdd(count_out, 1)] = q;
+        // handed to the second stage together with an upper bound of the k-th distance: the k-th best seen
+        // so far (+inf when the 5x5x5 block holds fewer than k points)
+        if (gl == 0)
+        {
+          list_out[atomicAdd(count_out, 1)] = q;
+          float ub = INFINITY;
+#pragma unroll
+          for (int s = 0; s < KMAX; ++s)
+            if (s == k - 1) ub = sel.best_d[s];
+          knn_d2[q] = ub;
+        }
         deferred = true;
         done = true;
       }
@@ -640,7 +657,7 @@ __global__ __launch_bounds__(256) void k_knn_first(const float4* __restrict__ qu
 }
 
 // Second and last stage: one wavefront per query the first stage handed over (a few percent: the isolated
-// keypoints).  Coarser levels, two rounds each (3x3x3, then 5x5x5 cells), finally the whole target as one
+// keypoints).  Coarser levels, blocks of 3^3, 5^3, 7^3 cells each, finally the whole target as one
 // run, so every query leaves this kernel answered.  Same (distance, index) order everywhere => the result
 // does not depend on the route taken.
 template <int KMAX>
@@ -650,7 +667,7 @@ __global__ __launch_bounds__(256) void k_knn_second(const float4* __restrict__ q
                                                     int* __restrict__ exhaustive_count)
 {
   constexpr int G = 64, U = 8, E = 1;
-  constexpr int kStages = 2 * (kGridLevels - 1);  // blocks (level 1, r = 1), (level 1, r = 2), (level 2, r = 1), (level 2, r = 2); then the whole target
+  constexpr int kStages = 3 * (kGridLevels - 1);  // blocks (level 1, r = 1 .. 3), (level 2, r = 1 .. 3); then the whole target
   const int gl = threadIdx.x & 63;
   const int nwork = *count_in;
   const int nwaves = gridDim.x * 4;
@@ -664,14 +681,14 @@ __global__ __launch_bounds__(256) void k_knn_second(const float4* __restrict__ q
     GroupSelect<KMAX, G, U> sel;
     sel.reset();
     bool done = false, far = false;
-    // the row bounds of all four blocks in one memory round trip; a block holding fewer than k points cannot
+    // the row bounds of all the blocks in one memory round trip; a block holding fewer than k points cannot
     // settle the query and is not scanned at all
     BlockRuns<G, E> runs[kStages];
     float bound2[kStages];
 #pragma unroll
     for (int stage = 0; stage < kStages; ++stage)
     {
-      const int level = 1 + stage / 2, r = 1 + stage % 2;
+      const int level = 1 + stage / 3, r = 1 + stage % 3;
       GridView gv;
       grid_view(gv, desc + level, gp.cell_start[level], gp.sorted[level], qx, qy, qz);
       runs[stage].fetch(gv, r, gl, true);
@@ -681,17 +698,29 @@ __global__ __launch_bounds__(256) void k_knn_second(const float4* __restrict__ q
     }
 #pragma unroll
     for (int stage = 0; stage < kStages; ++stage) runs[stage].finish(gl);
+    // upper bound of the k-th distance (+inf: none yet), from the first stage and then from every scan that
+    // did not settle the query: the first block whose proven radius exceeds it settles the query for certain,
+    // smaller ones are not tried
+    float ub = knn_d2[q];
 #pragma unroll
     for (int stage = 0; stage < kStages; ++stage)
     {
       if (done) continue;
-      if (runs[stage].covered || runs[stage].total >= (uint32_t)k)
+      const bool few = runs[stage].total < (uint32_t)k;  // cannot hold k neighbours
+      if (runs[stage].covered || (!few && (ub == INFINITY || bound2[stage] > ub || stage == kStages - 1)))
       {
-        search_block<KMAX, G, U, E>(sel, runs[stage], gp.sorted[1 + stage / 2], k, gl, qx, qy, qz);
+        search_block<KMAX, G, U, E>(sel, runs[stage], gp.sorted[1 + stage / 3], k, gl, qx, qy, qz);
         if (runs[stage].covered || sel.count_below(bound2[stage], k) >= k) done = true;
+        else if (bound2[stage] > far_d2) { far = true; done = true; }
+        else
+        {
+#pragma unroll
+          for (int s = 0; s < KMAX; ++s)
+            if (s == k - 1) ub = sel.best_d[s];
+        }
       }
       // fewer than k points inside a radius beyond the rejection distance
-      if (!done && bound2[stage] > far_d2) { far = true; done = true; }
+      else if (few && bound2[stage] > far_d2) { far = true; done = true; }
     }
     if (!done)
     {

@@ -123,6 +123,79 @@ __global__ __launch_bounds__(256) void k_bbox(const float4* __restrict__ pts, in
     }
 }
 
+// the three keypoint sets at once: blockIdx.y = type, counts read from the device (they may not be on the
+// host yet), one set of atomics per block.  bits: [0..1] time range, [2 + 6 * type ..] bounding boxes.
+struct KpSets
+{
+  const float4* pts[3];
+  int n[3];              // used when counts == nullptr
+};
+__global__ void k_range_init(unsigned long long* __restrict__ bits)
+{
+  unsigned* b32 = reinterpret_cast<unsigned*>(bits + 2);
+  if (threadIdx.x == 0) { bits[0] = ~0ull; bits[1] = 0ull; }
+  if (threadIdx.x < 18) b32[threadIdx.x] = (threadIdx.x % 6) < 3 ? ~0u : 0u;
+}
+__global__ __launch_bounds__(256) void k_time_range3(KpSets sets, const int* __restrict__ counts, unsigned long long* __restrict__ bits)
+{
+  __shared__ unsigned long long slo[4], shi[4];
+  const int t = blockIdx.y;
+  const int n = counts ? counts[t] : sets.n[t];
+  if ((int)(blockIdx.x * blockDim.x) >= n) return;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned long long lo = ~0ull, hi = 0ull;
+  if (i < n) lo = hi = d2o(point_time(sets.pts[t][2 * (size_t)i + 1]));
+  for (int s = 32; s > 0; s >>= 1)
+  {
+    const unsigned long long l2 = __shfl_down(lo, s), h2 = __shfl_down(hi, s);
+    lo = l2 < lo ? l2 : lo;
+    hi = h2 > hi ? h2 : hi;
+  }
+  if ((threadIdx.x & 63) == 0) { slo[threadIdx.x >> 6] = lo; shi[threadIdx.x >> 6] = hi; }
+  __syncthreads();
+  if (threadIdx.x == 0)
+  {
+    for (int w = 1; w < 4; ++w) { lo = slo[w] < lo ? slo[w] : lo; hi = shi[w] > hi ? shi[w] : hi; }
+    atomicMin(&bits[0], lo);
+    atomicMax(&bits[1], hi);
+  }
+}
+__global__ __launch_bounds__(256) void k_bbox3(KpSets sets, Rigid T, unsigned* __restrict__ bits)
+{
+  __shared__ unsigned slo[4][3], shi[4][3];
+  const int t = blockIdx.y;
+  const int n = sets.n[t];
+  if ((int)(blockIdx.x * blockDim.x) >= n) return;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned lo[3] = {~0u, ~0u, ~0u}, hi[3] = {0u, 0u, 0u};
+  if (i < n)
+  {
+    const float4 a = sets.pts[t][2 * (size_t)i];
+    double ox, oy, oz;
+    rigid_apply(T, (double)a.x, (double)a.y, (double)a.z, ox, oy, oz);
+    const float v[3] = {(float)ox, (float)oy, (float)oz};
+    for (int d = 0; d < 3; ++d) lo[d] = hi[d] = f2ou(v[d]);
+  }
+  for (int d = 0; d < 3; ++d)
+    for (int s = 32; s > 0; s >>= 1)
+    {
+      const unsigned l2 = __shfl_down(lo[d], s), h2 = __shfl_down(hi[d], s);
+      lo[d] = l2 < lo[d] ? l2 : lo[d];
+      hi[d] = h2 > hi[d] ? h2 : hi[d];
+    }
+  if ((threadIdx.x & 63) == 0)
+    for (int d = 0; d < 3; ++d) { slo[threadIdx.x >> 6][d] = lo[d]; shi[threadIdx.x >> 6][d] = hi[d]; }
+  __syncthreads();
+  if (threadIdx.x < 3)
+  {
+    const int d = threadIdx.x;
+    unsigned l = slo[0][d], h = shi[0][d];
+    for (int w = 1; w < 4; ++w) { l = slo[w][d] < l ? slo[w][d] : l; h = shi[w][d] > h ? shi[w][d] : h; }
+    atomicMin(&bits[6 * t + d], l);
+    atomicMax(&bits[6 * t + 3 + d], h);
+  }
+}
+
 // host-side quaternion helpers (Eigen::Quaternion(Matrix3d), slam_lib/include/LidarSlam/MotionModel.h:64-76)
 void quat_from_matrix(const double R[9], double q[4])
 {
@@ -197,6 +270,35 @@ InterpConst make_interp(const double H0[16], const double H1[16], double t0, dou
 
 }  // namespace
 
+namespace lsa
+{
+// time range of a keypoint set into range_bits[0..1]; counts_dev: device counts (extraction, host counts not known yet) or nullptr
+int enqueue_time_range(lsa_ctx* ctx, int set, const int* counts_dev)
+{
+  KpSets sets;
+  int nmax = 0;
+  for (int k = 0; k < 3; ++k)
+  {
+    sets.pts[k] = reinterpret_cast<const float4*>(ctx->kp[set][k]);
+    sets.n[k] = ctx->kp_n[set][k];
+    nmax = std::max(nmax, sets.n[k]);
+  }
+  if (counts_dev) nmax = ctx->frame_n;  // upper bound of every count
+  hipLaunchKernelGGL(k_range_init, dim3(1), dim3(64), 0, ctx->stream, ctx->range_bits);
+  if (nmax > 0)
+    hipLaunchKernelGGL(k_time_range3, dim3((nmax + 255) / 256, 3), dim3(256), 0, ctx->stream, sets, counts_dev, ctx->range_bits);
+  return LSA_OK;
+}
+void finish_time_range(lsa_ctx* ctx, int set, const unsigned long long bits[2])
+{
+  const int total = ctx->kp_n[set][0] + ctx->kp_n[set][1] + ctx->kp_n[set][2];
+  // empty set: the reference's min/max loop leaves its initial values (Slam.cxx:1291-1300)
+  ctx->kp_time[set][0] = total == 0 ? std::numeric_limits<double>::max() : o2d_host(bits[0]);
+  ctx->kp_time[set][1] = total == 0 ? std::numeric_limits<double>::lowest() : o2d_host(bits[1]);
+  ctx->kp_time_valid[set] = true;
+}
+}  // namespace lsa
+
 extern "C" {
 
 int lsa_reset_working_keypoints(lsa_ctx* ctx)
@@ -211,6 +313,9 @@ int lsa_reset_working_keypoints(lsa_ctx* ctx)
       LSA_HIP(ctx, hipMemcpyAsync(ctx->kp[LSA_SET_WORKING][k], ctx->kp[LSA_SET_RAW_CURRENT][k], (size_t)n * sizeof(lsa_point_t),
                                   hipMemcpyDeviceToDevice, ctx->stream));
   }
+  ctx->kp_time_valid[LSA_SET_WORKING] = ctx->kp_time_valid[LSA_SET_RAW_CURRENT];
+  ctx->kp_time[LSA_SET_WORKING][0] = ctx->kp_time[LSA_SET_RAW_CURRENT][0];
+  ctx->kp_time[LSA_SET_WORKING][1] = ctx->kp_time[LSA_SET_RAW_CURRENT][1];
   return LSA_OK;
 }
 
@@ -233,48 +338,55 @@ int lsa_working_time_range(lsa_ctx* ctx, double* tmin, double* tmax)
 {
   if (!ctx || !tmin || !tmax) return ctx ? ctx->fail(LSA_E_ARG, "lsa_working_time_range: bad argument") : LSA_E_ARG;
   LSA_HIP(ctx, hipSetDevice(ctx->device));
-  const unsigned long long init[2] = {~0ull, 0ull};
-  LSA_HIP(ctx, hipMemcpyAsync(ctx->range_bits, init, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
-  int total = 0;
-  for (int k = 0; k < 3; ++k)
+  if (!ctx->kp_time_valid[LSA_SET_WORKING])
   {
-    const int n = ctx->kp_n[LSA_SET_WORKING][k];
-    if (n <= 0) continue;
-    total += n;
-    hipLaunchKernelGGL(k_time_range, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, reinterpret_cast<const float4*>(ctx->kp[LSA_SET_WORKING][k]), n,
-                       ctx->range_bits);
+    // (the usual case costs nothing: lsa_extract_keypoints reduced the range of the raw keypoints and
+    // lsa_reset_working_keypoints carried it over)
+    int rc = lsa::enqueue_time_range(ctx, LSA_SET_WORKING, nullptr);
+    if (rc) return rc;
+    unsigned long long* hp = reinterpret_cast<unsigned long long*>(ctx->host_pinned + 128);
+    LSA_HIP(ctx, hipMemcpyAsync(hp, ctx->range_bits, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+    LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    lsa::finish_time_range(ctx, LSA_SET_WORKING, hp);
   }
-  unsigned long long* hp = reinterpret_cast<unsigned long long*>(ctx->host_pinned + 128);
-  LSA_HIP(ctx, hipMemcpyAsync(hp, ctx->range_bits, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
-  LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  if (total == 0)
-  {
-    *tmin = std::numeric_limits<double>::max();
-    *tmax = std::numeric_limits<double>::lowest();
-    return LSA_OK;
-  }
-  *tmin = o2d_host(hp[0]);
-  *tmax = o2d_host(hp[1]);
+  *tmin = ctx->kp_time[LSA_SET_WORKING][0];
+  *tmax = ctx->kp_time[LSA_SET_WORKING][1];
   return LSA_OK;
 }
-
+int lsa_working_bboxes(lsa_ctx* ctx, const double pose[16], float mn[9], float mx[9])
+{
+  if (!ctx || !pose || !mn || !mx) return ctx ? ctx->fail(LSA_E_ARG, "lsa_working_bboxes: bad argument") : LSA_E_ARG;
+  LSA_HIP(ctx, hipSetDevice(ctx->device));
+  KpSets sets;
+  int nmax = 0;
+  for (int k = 0; k < 3; ++k)
+  {
+    sets.pts[k] = reinterpret_cast<const float4*>(ctx->kp[LSA_SET_WORKING][k]);
+    sets.n[k] = ctx->kp_n[LSA_SET_WORKING][k];
+    nmax = std::max(nmax, sets.n[k]);
+    for (int d = 0; d < 3; ++d) { mn[3 * k + d] = FLT_MAX; mx[3 * k + d] = -FLT_MAX; }
+  }
+  if (nmax <= 0) return LSA_OK;
+  Rigid T;
+  row_major_to_rt(pose, T.R, T.t);
+  unsigned* bits = reinterpret_cast<unsigned*>(ctx->range_bits + 2);
+  hipLaunchKernelGGL(k_range_init, dim3(1), dim3(64), 0, ctx->stream, ctx->range_bits);
+  hipLaunchKernelGGL(k_bbox3, dim3((nmax + 255) / 256, 3), dim3(256), 0, ctx->stream, sets, T, bits);
+  unsigned* hp = reinterpret_cast<unsigned*>(ctx->host_pinned + 136);
+  LSA_HIP(ctx, hipMemcpyAsync(hp, bits, 18 * sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
+  LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  for (int k = 0; k < 3; ++k)
+    if (sets.n[k] > 0)
+      for (int d = 0; d < 3; ++d) { mn[3 * k + d] = ou2f_host(hp[6 * k + d]); mx[3 * k + d] = ou2f_host(hp[6 * k + 3 + d]); }
+  return LSA_OK;
+}
 int lsa_working_bbox(lsa_ctx* ctx, int type, const double pose[16], float mn[3], float mx[3])
 {
   if (!ctx || !pose || type < 0 || type > 2) return ctx ? ctx->fail(LSA_E_ARG, "lsa_working_bbox: bad argument") : LSA_E_ARG;
-  LSA_HIP(ctx, hipSetDevice(ctx->device));
-  const int n = ctx->kp_n[LSA_SET_WORKING][type];
-  for (int d = 0; d < 3; ++d) { mn[d] = FLT_MAX; mx[d] = -FLT_MAX; }
-  if (n <= 0) return LSA_OK;
-  unsigned* bits = reinterpret_cast<unsigned*>(ctx->range_bits + 4);
-  const unsigned init[6] = {~0u, ~0u, ~0u, 0u, 0u, 0u};
-  LSA_HIP(ctx, hipMemcpyAsync(bits, init, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
-  Rigid T;
-  row_major_to_rt(pose, T.R, T.t);
-  hipLaunchKernelGGL(k_bbox, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, reinterpret_cast<const float4*>(ctx->kp[LSA_SET_WORKING][type]), n, T, bits);
-  unsigned* hp = reinterpret_cast<unsigned*>(ctx->host_pinned + 136);
-  LSA_HIP(ctx, hipMemcpyAsync(hp, bits, 6 * sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
-  LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  for (int d = 0; d < 3; ++d) { mn[d] = ou2f_host(hp[d]); mx[d] = ou2f_host(hp[3 + d]); }
+  float lo[9], hi[9];
+  const int rc = lsa_working_bboxes(ctx, pose, lo, hi);
+  if (rc) return rc;
+  for (int d = 0; d < 3; ++d) { mn[d] = lo[3 * type + d]; mx[d] = hi[3 * type + d]; }
   return LSA_OK;
 }
 

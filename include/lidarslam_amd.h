@@ -258,6 +258,10 @@ int lsa_working_bbox(lsa_ctx* ctx, int type, const double pose[16], float mn[3],
 /* The same for the three keypoint types in one pass and one synchronisation:
  * mn / mx = [type][xyz]. */
 int lsa_working_bboxes(lsa_ctx* ctx, const double pose[16], float mn[9], float mx[9]);
+/* The same on any keypoint set, split in two: _begin only enqueues the reduction and its read-back, _end
+ * waits for exactly that work.  Whatever the caller enqueues in between overlaps it. */
+int lsa_keypoint_bboxes_begin(lsa_ctx* ctx, int set, const double pose[16]);
+int lsa_keypoint_bboxes_end(lsa_ctx* ctx, float mn[9], float mx[9]);
 
 /* Slam::TransformPointCloud (Slam.cxx:1491-1509) on a device keypoint set:
  * writes pose * set to `out` on the host. */
@@ -285,6 +289,9 @@ typedef struct lsa_kernel_stat_t
   double bytes;   /* algorithmic bytes summed over the launches */
 } lsa_kernel_stat_t;
 int lsa_profile_enable(lsa_ctx* ctx, int on);
+/* Events cost a few microseconds per scope on a path that is launch bound: time only the scope `scope`,
+ * and only one launch in `every` of it (all launches are counted; total_ms is scaled to all of them). */
+int lsa_profile_select(lsa_ctx* ctx, const char* scope, int every);
 int lsa_profile_reset(lsa_ctx* ctx);
 int lsa_profile_get(lsa_ctx* ctx, lsa_kernel_stat_t* out, int capacity);
 

@@ -276,14 +276,13 @@ void RollingGrid::BuildSubMap()
 {
   SubMap = this->Get();
   SubMapValid = true;
+  SubMapBoxed = false;
 }
 
-// RollingGrid.cxx:363-442
-void RollingGrid::BuildSubMap(const float minPoint[3], const float maxPoint[3], int minNbPoints)
+void RollingGrid::VoxelRange(const float minPoint[3], const float maxPoint[3], int lo[3], int hi[3]) const
 {
   float origin[3];
   this->GridOrigin(origin);
-  int lo[3], hi[3];
   ToVoxel(minPoint, origin, VoxelResolution, lo);
   ToVoxel(maxPoint, origin, VoxelResolution, hi);
   for (int i = 0; i < 3; ++i)
@@ -291,6 +290,26 @@ void RollingGrid::BuildSubMap(const float minPoint[3], const float maxPoint[3], 
     lo[i] = std::max(lo[i], 0);
     hi[i] = std::min(hi[i], GridSize - 1);
   }
+}
+
+bool RollingGrid::SubMapBuiltFor(const float minPoint[3], const float maxPoint[3], int minNbPoints) const
+{
+  if (!SubMapValid || !SubMapBoxed || minNbPoints != SubMapMinNbPoints) return false;
+  int lo[3], hi[3];
+  this->VoxelRange(minPoint, maxPoint, lo, hi);
+  for (int i = 0; i < 3; ++i)
+    if (lo[i] != SubMapLo[i] || hi[i] != SubMapHi[i]) return false;
+  return true;
+}
+
+// RollingGrid.cxx:363-442
+void RollingGrid::BuildSubMap(const float minPoint[3], const float maxPoint[3], int minNbPoints)
+{
+  int lo[3], hi[3];
+  this->VoxelRange(minPoint, maxPoint, lo, hi);
+  for (int i = 0; i < 3; ++i) { SubMapLo[i] = lo[i]; SubMapHi[i] = hi[i]; }
+  SubMapMinNbPoints = minNbPoints;
+  SubMapBoxed = true;
   auto intersects = [&](int id) {
     int v[3];
     this->To3d(id, v);

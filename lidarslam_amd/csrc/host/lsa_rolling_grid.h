@@ -58,6 +58,10 @@ public:
   // sub-map cloud, the device search grid is built by lsa_set_target.
   void BuildSubMap();
   void BuildSubMap(const float minPoint[3], const float maxPoint[3], int minNbPoints = -1);
+  // Would BuildSubMap(minPoint, maxPoint, minNbPoints) return the sub-map that is there?  The sub-map is a
+  // function of the map, of the range of outer voxels the box touches and of minNbPoints; this compares the
+  // last two with what the current sub-map was built for (the caller knows the map has not changed since).
+  bool SubMapBuiltFor(const float minPoint[3], const float maxPoint[3], int minNbPoints) const;
   // IsSubMapKdTreeValid(): false after every map modification until the next BuildSubMap
   bool IsSubMapValid() const { return this->SubMapValid && !this->SubMap.empty(); }
   const PointCloud& GetSubMap() const { return this->SubMap; }
@@ -73,6 +77,9 @@ private:
   unsigned int AddSerial = 0;
   PointCloud SubMap;
   bool SubMapValid = false;
+  bool SubMapBoxed = false;  // built by the bounding-box overload
+  int SubMapLo[3] = {0, 0, 0}, SubMapHi[3] = {0, 0, 0}, SubMapMinNbPoints = 0;
+  void VoxelRange(const float minPoint[3], const float maxPoint[3], int lo[3], int hi[3]) const;
   unsigned int MinFramesPerVoxel = 0;
   SamplingMode Sampling = SamplingMode::MAX_INTENSITY;
   double DecayingThreshold = -1;

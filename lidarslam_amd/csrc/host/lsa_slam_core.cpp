@@ -121,7 +121,8 @@ void SlamCore::Reset(bool resetLog)
   if (Ctx)
     for (int s = 0; s < 3; ++s)
       for (int k = 0; k < 3; ++k) lsa_set_keypoints(Ctx, s, k, nullptr, 0);
-  for (int k = 0; k < 3; ++k) { EgoDebug[k] = MatchDebug(); LocDebug[k] = MatchDebug(); KeypointCounts[k] = 0; }
+  for (int k = 0; k < 3; ++k) { EgoDebug[k] = MatchDebug(); LocDebug[k] = MatchDebug(); KeypointCounts[k] = 0; SpecBuilt[k] = false; }
+  SpecPending = false;
   if (resetLog)
   {
     NbrFrameProcessed = 0;
@@ -261,6 +262,10 @@ int SlamCore::ComputeEgoMotion()
       Trelative = Inverse(Tworld) * next;
     }
   }
+  {
+    const int rc = BeginSubMapSpeculation(Tworld * Trelative);
+    if (rc < 0) return rc;
+  }
   if (!(EgoMotion == EgoMotionMode::REGISTRATION || EgoMotion == EgoMotionMode::MOTION_EXTRAPOLATION_AND_REGISTRATION))
     return LSA_OK;
 
@@ -294,6 +299,12 @@ int SlamCore::ComputeEgoMotion()
     SolveSummary summary;
     LSA_TRY(optimizer.Solve(summary));
     TotalMatchedKeypoints = summary.num_matches;
+    if (SpecPending)
+    {
+      // the predicted bounding boxes have long arrived: the map workers extract the sub-maps from here on
+      const int rc = FinishSubMapSpeculation();
+      if (rc < 0) return rc;
+    }
     Stats.ego_lm += tlm.Stop();
     Stats.lm_evals += summary.num_evaluations;
     if (summary.skipped) break;  // "Not enough keypoints, EgoMotion skipped for this frame."
@@ -330,30 +341,43 @@ int SlamCore::Localization()
 
   {
     Tick t;
-    WaitMaps();  // the previous keyframe's insertion, normally long finished
+    if (SpecPending)
+    {
+      const int rc = FinishSubMapSpeculation();
+      if (rc < 0) return rc;
+    }
+    WaitMaps();  // the previous keyframe's insertion and the sub-maps extracted ahead of time
     Stats.maps_wait = t.Stop();
     Stats.maps_async = std::max(MapJobSeconds[0], std::max(MapJobSeconds[1], MapJobSeconds[2]));
-    // sub-map extraction: bounding boxes from the device, then the three maps side by side on their workers
-    bool rebuild[3] = {false, false, false};
+    // which sub-maps are new (extracted ahead of time for the predicted pose) or stale (the map changed)
+    bool fresh[3], rebuild[3] = {false, false, false};
     bool any = false;
     for (int k = 0; k < 3; ++k)
     {
-      rebuild[k] = UseKeypoints[k] && !LocalMaps[k]->IsSubMapValid();
-      any = any || rebuild[k];
+      fresh[k] = UseKeypoints[k] && SpecBuilt[k];
+      rebuild[k] = UseKeypoints[k] && !fresh[k] && !LocalMaps[k]->IsSubMapValid();
+      any = any || fresh[k] || rebuild[k];
+      SpecBuilt[k] = false;
     }
     float mn[9], mx[9];
     if (any && MapUpdate != MappingMode::NONE) LSA_TRY(lsa_working_bboxes(Ctx, Tworld.m, mn, mx));  // all types, one pass
     for (int k = 0; k < 3; ++k)
     {
-      if (!rebuild[k]) continue;
+      if (!fresh[k] && !rebuild[k]) continue;
       RollingGrid* map = LocalMaps[k].get();
+      const int minPts = KeypointCounts[k] / 2;
+      if (fresh[k])
+      {
+        // the box under the actual pose touches the same voxels as the predicted one: the sub-map stands
+        if (map->SubMapBuiltFor(mn + 3 * k, mx + 3 * k, minPts)) { Stats.submap_spec_hits++; SubMapSpecHitsTotal++; rebuild[k] = true; continue; }
+        rebuild[k] = true;
+      }
       if (MapUpdate == MappingMode::NONE)
         MapWorker[k].Submit([map] { map->BuildSubMap(); });
       else
       {
         const bool clear = map->IsTimeThreshold();
         const double now = CurrentTime;
-        const int minPts = KeypointCounts[k] / 2;
         const float* lo3 = mn + 3 * k;
         const float* hi3 = mx + 3 * k;
         MapWorker[k].Submit([map, clear, now, minPts, mn0 = lo3[0], mn1 = lo3[1], mn2 = lo3[2], mx0 = hi3[0], mx1 = hi3[1], mx2 = hi3[2]] {
@@ -432,6 +456,42 @@ int SlamCore::Localization()
       LocDebug[k].weights.assign(n, 0.);
       if (n > 0) LSA_TRY(lsa_download_match(Ctx, k, LocDebug[k].status.data(), LocDebug[k].weights.data(), nullptr, n));
     }
+  return LSA_OK;
+}
+
+int SlamCore::BeginSubMapSpeculation(const Pose& predicted)
+{
+  SpecPending = false;
+  if (MapUpdate == MappingMode::NONE) return LSA_OK;
+  LSA_TRY(lsa_keypoint_bboxes_begin(Ctx, LSA_SET_RAW_CURRENT, predicted.m));
+  SpecPending = true;
+  return LSA_OK;
+}
+
+int SlamCore::FinishSubMapSpeculation()
+{
+  SpecPending = false;
+  float mn[9], mx[9];
+  LSA_TRY(lsa_keypoint_bboxes_end(Ctx, mn, mx));
+  for (int k = 0; k < 3; ++k)
+  {
+    if (!UseKeypoints[k] || KeypointCounts[k] <= 0) continue;
+    RollingGrid* map = LocalMaps[k].get();
+    const bool clear = map->IsTimeThreshold();
+    const double now = CurrentTime;
+    const int minPts = KeypointCounts[k] / 2;
+    bool* built = &SpecBuilt[k];
+    const float* lo3 = mn + 3 * k;
+    const float* hi3 = mx + 3 * k;
+    // queued behind the previous keyframe's insertion on the same worker: it sees the final map
+    MapWorker[k].Submit([map, clear, now, minPts, built, mn0 = lo3[0], mn1 = lo3[1], mn2 = lo3[2], mx0 = hi3[0], mx1 = hi3[1], mx2 = hi3[2]] {
+      if (map->IsSubMapValid()) return;  // the map did not change: Slam.cxx:1013 keeps the kd-tree
+      if (clear) map->ClearOldPoints(now);
+      const float lo[3] = {mn0, mn1, mn2}, hi[3] = {mx0, mx1, mx2};
+      map->BuildSubMap(lo, hi, minPts);
+      *built = true;
+    });
+  }
   return LSA_OK;
 }
 
@@ -652,6 +712,7 @@ int SlamCore::GetParam(const std::string& name, double* v) const
   if (name == "VoxelGridResolution") { *v = LocalMaps[0]->GetVoxelResolution(); return LSA_OK; }
   if (name == "NbrFrameProcessed") { *v = NbrFrameProcessed; return LSA_OK; }
   if (name == "TotalMatchedKeypoints") { *v = TotalMatchedKeypoints; return LSA_OK; }
+  if (name == "SubMapSpeculationHits") { *v = SubMapSpecHitsTotal; return LSA_OK; }
   return LSA_E_ARG;
 }
 

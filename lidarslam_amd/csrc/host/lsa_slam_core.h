@@ -40,6 +40,7 @@ struct FrameStats
 {
   double total = 0, extract = 0, ego_icp = 0, ego_lm = 0, loc_icp = 0, loc_lm = 0, undistort = 0, submap = 0, maps = 0;
   int ego_iters = 0, loc_iters = 0, lm_evals = 0;
+  int submap_spec_hits = 0;  // sub-maps extracted ahead of time that Localization() could keep
   double maps_wait = 0;   // time this frame waited for the previous keyframe's map insertion
   double maps_async = 0;  // duration of that insertion on the worker thread
 };
@@ -142,6 +143,7 @@ public:
   RegistrationError LocalizationUncertainty;
   unsigned TotalMatchedKeypoints = 0;
   unsigned NbrFrameProcessed = 0;
+  unsigned SubMapSpecHitsTotal = 0;
   int KfCounter = 0;
   FrameStats Stats;
   std::deque<StampedPose> LogTrajectory;
@@ -172,6 +174,15 @@ private:
   std::vector<lsa_point_t> Scratch;
   // keyframe keypoints in world coordinates on their way into the maps (owned by the worker until WaitMaps)
   std::vector<lsa_point_t> MapInbox[3];
+  // Sub-maps are extracted ahead of time: as soon as the keypoints exist, their bounding box under the
+  // PREDICTED pose is reduced on the device (asynchronously) and the map workers extract the sub-maps for it
+  // while the ego-motion ICP runs.  Localization() checks the box under the actual pose: the sub-map only
+  // depends on the range of 10 m voxels the box touches, which a pose refinement rarely changes; if it did,
+  // the sub-map is extracted again.  Same result either way.
+  int BeginSubMapSpeculation(const Pose& predicted);
+  int FinishSubMapSpeculation();
+  bool SpecPending = false;
+  bool SpecBuilt[3] = {false, false, false};  // written by the workers, read after WaitMaps
   double MapJobSeconds[3] = {0., 0., 0.};  // written by the workers, read after WaitMaps
   HostWorker MapWorker[3];                  // one per map: the three rolling grids are independent
   void WaitMaps() { for (auto& w : MapWorker) w.Wait(); }

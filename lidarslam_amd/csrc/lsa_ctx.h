@@ -88,7 +88,8 @@ struct KernelStat
 {
   std::string name;
   uint32_t launches = 0;
-  double total_ms = 0;
+  uint32_t timed = 0;     // launches that carried events
+  double total_ms = 0;    // of the timed launches
   double bytes = 0;
 };
 
@@ -154,10 +155,15 @@ struct lsa_ctx
   hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
   void* scratch_out = nullptr;    // device staging for transformed downloads
   size_t scratch_cap = 0;
-  unsigned long long* range_bits = nullptr;  // time range / bbox reductions
+  unsigned long long* range_bits = nullptr;  // [0..1] time range, [16..24] bounding boxes (ordered bits)
+  hipEvent_t ev_bbox = nullptr;
+  bool bbox_pending = false;
+  int bbox_n[3] = {0, 0, 0};
 
   // profiling
   bool profiling = false;
+  std::string prof_only;   // when not empty: only the scope of this name is timed ...
+  int prof_every = 1;      // ... and only one launch in prof_every of it (the others are counted)
   std::vector<lsa::KernelStat> stats;
   std::vector<lsa::PendingEvent> pending;
   std::vector<hipEvent_t> event_pool;

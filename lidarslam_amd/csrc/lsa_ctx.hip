@@ -111,13 +111,18 @@ ProfScope::ProfScope(lsa_ctx* c, const char* name, double bytes, hipStream_t str
   if (!ctx->profiling) return;
   for (size_t i = 0; i < ctx->stats.size(); ++i)
     if (ctx->stats[i].name == name) { stat = (int)i; break; }
+  if (!ctx->prof_only.empty() && ctx->prof_only != name) return;
   if (stat < 0)
   {
-    ctx->stats.push_back({name, 0, 0, 0});
+    KernelStat ks;
+    ks.name = name;
+    ctx->stats.push_back(ks);
     stat = (int)ctx->stats.size() - 1;
   }
   ctx->stats[stat].launches++;
   ctx->stats[stat].bytes += bytes;
+  if (ctx->prof_every > 1 && (ctx->stats[stat].launches % ctx->prof_every) != 1) { stat = -1; return; }
+  ctx->stats[stat].timed++;
   auto get = [&]() {
     hipEvent_t e;
     if (!ctx->event_pool.empty()) { e = ctx->event_pool.back(); ctx->event_pool.pop_back(); }
@@ -225,6 +230,7 @@ int lsa_ctx_create(int device_id, lsa_ctx** out)
     ok &= hipEventCreateWithFlags(&ctx->ev_join[i], hipEventDisableTiming) == hipSuccess;
   }
   ok &= hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) == hipSuccess;
+  ok &= hipEventCreateWithFlags(&ctx->ev_bbox, hipEventDisableTiming) == hipSuccess;
   ok &= hipMalloc((void**)&ctx->ring_start, (kMaxRings + 1) * sizeof(int)) == hipSuccess;
   ok &= hipMalloc((void**)&ctx->ring_len, kMaxRings * sizeof(int)) == hipSuccess;
   ok &= hipMalloc((void**)&ctx->ring_meta, 8 * sizeof(int)) == hipSuccess;
@@ -234,7 +240,7 @@ int lsa_ctx_create(int device_id, lsa_ctx** out)
   ok &= hipMalloc((void**)&ctx->reduce_out, 64 * sizeof(double)) == hipSuccess;
   if (ok) ok &= hipMemset(ctx->reduce_out, 0, 64 * sizeof(double)) == hipSuccess;  // [32] holds the arrival ticket of k_accumulate
   ok &= hipMalloc((void**)&ctx->hist_dev, 3 * 16 * sizeof(int)) == hipSuccess;
-  ok &= hipMalloc((void**)&ctx->range_bits, 16 * sizeof(unsigned long long)) == hipSuccess;
+  ok &= hipMalloc((void**)&ctx->range_bits, 32 * sizeof(unsigned long long)) == hipSuccess;
   ok &= hipHostMalloc((void**)&ctx->host_pinned, 256 * sizeof(double), hipHostMallocDefault) == hipSuccess;
   if (hipHostMalloc((void**)&ctx->mailbox, (size_t)kAccumBlocks * kMailboxStride * sizeof(double), hipHostMallocCoherent | hipHostMallocMapped) == hipSuccess)
     std::memset(ctx->mailbox, 0, (size_t)kAccumBlocks * kMailboxStride * sizeof(double));
@@ -280,6 +286,7 @@ void lsa_ctx_destroy(lsa_ctx* ctx)
     if (ctx->side_stream[i]) (void)hipStreamDestroy(ctx->side_stream[i]);
   }
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+  if (ctx->ev_bbox) (void)hipEventDestroy(ctx->ev_bbox);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -340,6 +347,16 @@ int lsa_profile_enable(lsa_ctx* ctx, int on)
 {
   if (!ctx) return LSA_E_ARG;
   ctx->profiling = on != 0;
+  ctx->prof_only.clear();
+  ctx->prof_every = 1;
+  return LSA_OK;
+}
+int lsa_profile_select(lsa_ctx* ctx, const char* scope, int every)
+{
+  if (!ctx || !scope || every < 1) return LSA_E_ARG;
+  ctx->profiling = true;
+  ctx->prof_only = scope;
+  ctx->prof_every = every;
   return LSA_OK;
 }
 int lsa_profile_reset(lsa_ctx* ctx)
@@ -360,7 +377,8 @@ int lsa_profile_get(lsa_ctx* ctx, lsa_kernel_stat_t* out, int capacity)
     std::memset(&out[i], 0, sizeof(out[i]));
     std::strncpy(out[i].name, ctx->stats[i].name.c_str(), sizeof(out[i].name) - 1);
     out[i].launches = ctx->stats[i].launches;
-    out[i].total_ms = ctx->stats[i].total_ms;
+    // sampled scopes: the timed launches' mean stands for all launches
+    out[i].total_ms = ctx->stats[i].timed > 0 ? ctx->stats[i].total_ms * ((double)ctx->stats[i].launches / ctx->stats[i].timed) : 0.;
     out[i].bytes = ctx->stats[i].bytes;
   }
   return n;

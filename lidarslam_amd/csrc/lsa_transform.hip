@@ -132,8 +132,10 @@ struct KpSets
 };
 __global__ void k_range_init(unsigned long long* __restrict__ bits)
 {
-  unsigned* b32 = reinterpret_cast<unsigned*>(bits + 2);
   if (threadIdx.x == 0) { bits[0] = ~0ull; bits[1] = 0ull; }
+}
+__global__ void k_bbox_init(unsigned* __restrict__ b32)
+{
   if (threadIdx.x < 18) b32[threadIdx.x] = (threadIdx.x % 6) < 3 ? ~0u : 0u;
 }
 __global__ __launch_bounds__(256) void k_time_range3(KpSets sets, const int* __restrict__ counts, unsigned long long* __restrict__ bits)
@@ -353,32 +355,48 @@ int lsa_working_time_range(lsa_ctx* ctx, double* tmin, double* tmax)
   *tmax = ctx->kp_time[LSA_SET_WORKING][1];
   return LSA_OK;
 }
-int lsa_working_bboxes(lsa_ctx* ctx, const double pose[16], float mn[9], float mx[9])
+int lsa_keypoint_bboxes_begin(lsa_ctx* ctx, int set, const double pose[16])
 {
-  if (!ctx || !pose || !mn || !mx) return ctx ? ctx->fail(LSA_E_ARG, "lsa_working_bboxes: bad argument") : LSA_E_ARG;
+  if (!ctx || !pose || set < 0 || set > 2) return ctx ? ctx->fail(LSA_E_ARG, "lsa_keypoint_bboxes_begin: bad argument") : LSA_E_ARG;
   LSA_HIP(ctx, hipSetDevice(ctx->device));
   KpSets sets;
   int nmax = 0;
   for (int k = 0; k < 3; ++k)
   {
-    sets.pts[k] = reinterpret_cast<const float4*>(ctx->kp[LSA_SET_WORKING][k]);
-    sets.n[k] = ctx->kp_n[LSA_SET_WORKING][k];
+    sets.pts[k] = reinterpret_cast<const float4*>(ctx->kp[set][k]);
+    sets.n[k] = ctx->bbox_n[k] = ctx->kp_n[set][k];
     nmax = std::max(nmax, sets.n[k]);
-    for (int d = 0; d < 3; ++d) { mn[3 * k + d] = FLT_MAX; mx[3 * k + d] = -FLT_MAX; }
   }
+  ctx->bbox_pending = true;
   if (nmax <= 0) return LSA_OK;
   Rigid T;
   row_major_to_rt(pose, T.R, T.t);
-  unsigned* bits = reinterpret_cast<unsigned*>(ctx->range_bits + 2);
-  hipLaunchKernelGGL(k_range_init, dim3(1), dim3(64), 0, ctx->stream, ctx->range_bits);
+  unsigned* bits = reinterpret_cast<unsigned*>(ctx->range_bits + 16);
+  hipLaunchKernelGGL(k_bbox_init, dim3(1), dim3(64), 0, ctx->stream, bits);
   hipLaunchKernelGGL(k_bbox3, dim3((nmax + 255) / 256, 3), dim3(256), 0, ctx->stream, sets, T, bits);
-  unsigned* hp = reinterpret_cast<unsigned*>(ctx->host_pinned + 136);
-  LSA_HIP(ctx, hipMemcpyAsync(hp, bits, 18 * sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
-  LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  LSA_HIP(ctx, hipMemcpyAsync(ctx->host_pinned + 160, bits, 18 * sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
+  LSA_HIP(ctx, hipEventRecord(ctx->ev_bbox, ctx->stream));
+  return LSA_OK;
+}
+int lsa_keypoint_bboxes_end(lsa_ctx* ctx, float mn[9], float mx[9])
+{
+  if (!ctx || !mn || !mx) return ctx ? ctx->fail(LSA_E_ARG, "lsa_keypoint_bboxes_end: bad argument") : LSA_E_ARG;
+  if (!ctx->bbox_pending) return ctx->fail(LSA_E_STATE, "lsa_keypoint_bboxes_end: no lsa_keypoint_bboxes_begin before");
+  ctx->bbox_pending = false;
+  for (int i = 0; i < 9; ++i) { mn[i] = FLT_MAX; mx[i] = -FLT_MAX; }
+  if (ctx->bbox_n[0] <= 0 && ctx->bbox_n[1] <= 0 && ctx->bbox_n[2] <= 0) return LSA_OK;
+  LSA_HIP(ctx, hipEventSynchronize(ctx->ev_bbox));
+  const unsigned* hp = reinterpret_cast<const unsigned*>(ctx->host_pinned + 160);
   for (int k = 0; k < 3; ++k)
-    if (sets.n[k] > 0)
+    if (ctx->bbox_n[k] > 0)
       for (int d = 0; d < 3; ++d) { mn[3 * k + d] = ou2f_host(hp[6 * k + d]); mx[3 * k + d] = ou2f_host(hp[6 * k + 3 + d]); }
   return LSA_OK;
+}
+int lsa_working_bboxes(lsa_ctx* ctx, const double pose[16], float mn[9], float mx[9])
+{
+  if (!ctx || !pose || !mn || !mx) return ctx ? ctx->fail(LSA_E_ARG, "lsa_working_bboxes: bad argument") : LSA_E_ARG;
+  const int rc = lsa_keypoint_bboxes_begin(ctx, LSA_SET_WORKING, pose);
+  return rc ? rc : lsa_keypoint_bboxes_end(ctx, mn, mx);
 }
 int lsa_working_bbox(lsa_ctx* ctx, int type, const double pose[16], float mn[3], float mx[3])
 {

@@ -173,6 +173,12 @@ int lsa_transform_keypoints(lsa_ctx* ctx, int set, int type, const double T[16],
 int lsa_set_target(lsa_ctx* ctx, int slot, int type, const lsa_point_t* pts, int m);
 /* Same, from a device-resident keypoint set (ego-motion registers on the
  * previous frame's raw keypoints, Slam.cxx:845-860): no PCIe traffic. */
+/* lsa_set_target without the wait: the caller fills a pinned host buffer owned by the context
+ * (lsa_target_staging returns it, grown to `capacity` points; it may be called and filled from another host
+ * thread, e.g. the one that extracts the sub-map) and lsa_set_target_staged enqueues the copy of its first m
+ * points.  The buffer must stay untouched until the next match of that target has been waited for. */
+lsa_point_t* lsa_target_staging(lsa_ctx* ctx, int slot, int type, int capacity);
+int lsa_set_target_staged(lsa_ctx* ctx, int slot, int type, int m);
 int lsa_set_target_from_set(lsa_ctx* ctx, int slot, int type, int set);
 int lsa_target_size(const lsa_ctx* ctx, int slot, int type);
 /* Edge length [m] of the search-grid cells used by the next lsa_set_target* of this type
@@ -266,6 +272,12 @@ int lsa_keypoint_bboxes_end(lsa_ctx* ctx, float mn[9], float mx[9]);
 /* Slam::TransformPointCloud (Slam.cxx:1491-1509) on a device keypoint set:
  * writes pose * set to `out` on the host. */
 int lsa_download_transformed(lsa_ctx* ctx, int set, int type, const double pose[16], lsa_point_t* out, int capacity);
+/* The same for the three types of a set at once and without waiting: the device writes the transformed
+ * points straight into pinned host buffers owned by the context.  lsa_staged_transformed waits for that
+ * work only (it may be called from another host thread, e.g. the one that inserts the points into a map)
+ * and returns the buffer of one type; it stays valid until the next lsa_stage_transformed. */
+int lsa_stage_transformed(lsa_ctx* ctx, int set, const double pose[16]);
+int lsa_staged_transformed(lsa_ctx* ctx, int type, const lsa_point_t** pts, int* n);
 
 /* Slam::AggregateFrames(frames, true) (Slam.cxx:1512-1578): the whole current
  * frame to WORLD.  interpolate != 0: per-point pose between H0 (t0) and H1

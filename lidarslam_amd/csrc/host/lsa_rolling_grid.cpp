@@ -17,15 +17,16 @@ inline void ToVoxel(const float p[3], const float origin[3], double resolution, 
   const float r = static_cast<float>(resolution);
   for (int i = 0; i < 3; ++i) out[i] = static_cast<int>(std::round((p[i] - origin[i]) / r));
 }
-inline void BoundingBox(const RollingGrid::PointCloud& c, float mn[3], float mx[3])
+inline void BoundingBox(const lsa_point_t* pts, size_t count, float mn[3], float mx[3])
 {
   for (int i = 0; i < 3; ++i)
   {
     mn[i] = std::numeric_limits<float>::max();
     mx[i] = -std::numeric_limits<float>::max();
   }
-  for (const lsa_point_t& p : c)
+  for (size_t i = 0; i < count; ++i)
   {
+    const lsa_point_t& p = pts[i];
     mn[0] = std::min(mn[0], p.x); mx[0] = std::max(mx[0], p.x);
     mn[1] = std::min(mn[1], p.y); mx[1] = std::max(mx[1], p.y);
     mn[2] = std::min(mn[2], p.z); mx[2] = std::max(mx[2], p.z);
@@ -141,13 +142,13 @@ void RollingGrid::Roll(const float minPoint[3], const float maxPoint[3])
 }
 
 // RollingGrid.cxx:160-318
-void RollingGrid::Add(const PointCloud& pointcloud, bool fixed, double currentTime, bool roll)
+void RollingGrid::Add(const lsa_point_t* points, size_t count, bool fixed, double currentTime, bool roll)
 {
-  if (pointcloud.empty()) return;
+  if (count == 0) return;
   if (roll)
   {
     float mn[3], mx[3];
-    BoundingBox(pointcloud, mn, mx);
+    BoundingBox(points, count, mn, mx);
     this->Roll(mn, mx);
   }
   const float res = static_cast<float>(VoxelResolution);
@@ -165,8 +166,9 @@ void RollingGrid::Add(const PointCloud& pointcloud, bool fixed, double currentTi
   bool updated = false;
   int lastOut = -1;
   SamplingVG* outer = nullptr;
-  for (const lsa_point_t& point : pointcloud)
+  for (size_t pi = 0; pi < count; ++pi)
   {
+    const lsa_point_t& point = points[pi];
     const float p[3] = {point.x, point.y, point.z};
     int vo[3];
     ToVoxel(p, origin, VoxelResolution, vo);

@@ -7,6 +7,7 @@
 // std::unordered_map<int, std::unordered_map<int, Voxel>> so that libstdc++'s iteration order --
 // which decides the order of the sub-map points and with it the PCA summation order -- is kept.
 #pragma once
+#include <cstddef>
 #include <unordered_map>
 #include <vector>
 #include "../../../include/lidarslam_amd.h"
@@ -52,7 +53,11 @@ public:
   PointCloud Get(bool clean = false) const;
   unsigned int Size() const { return this->NbPoints; }
   void Roll(const float minPoint[3], const float maxPoint[3]);
-  void Add(const PointCloud& pointcloud, bool fixed = false, double currentTime = -1., bool roll = true);
+  void Add(const PointCloud& pointcloud, bool fixed = false, double currentTime = -1., bool roll = true)
+  {
+    this->Add(pointcloud.data(), pointcloud.size(), fixed, currentTime, roll);
+  }
+  void Add(const lsa_point_t* points, std::size_t count, bool fixed = false, double currentTime = -1., bool roll = true);
 
   // The reference builds a nanoflann kd-tree here; the MI355X path only materialises the
   // sub-map cloud, the device search grid is built by lsa_set_target.

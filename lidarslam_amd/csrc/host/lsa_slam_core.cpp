@@ -60,6 +60,14 @@ void HostWorker::Run()
   }
 }
 
+// worker side: the sub-map goes into the pinned staging buffer of its device target
+static void StageSubMap(lsa_ctx* ctx, int type, const RollingGrid& map)
+{
+  const auto& sub = map.GetSubMap();
+  lsa_point_t* dst = lsa_target_staging(ctx, LSA_TARGET_MAP, type, static_cast<int>(sub.size()));
+  if (dst && !sub.empty()) std::memcpy(dst, sub.data(), sub.size() * sizeof(lsa_point_t));
+}
+
 #define LSA_TRY(call)                          \
   do                                           \
   {                                            \
@@ -372,18 +380,20 @@ int SlamCore::Localization()
         if (map->SubMapBuiltFor(mn + 3 * k, mx + 3 * k, minPts)) { Stats.submap_spec_hits++; SubMapSpecHitsTotal++; rebuild[k] = true; continue; }
         rebuild[k] = true;
       }
+      lsa_ctx* ctx = Ctx;
       if (MapUpdate == MappingMode::NONE)
-        MapWorker[k].Submit([map] { map->BuildSubMap(); });
+        MapWorker[k].Submit([map, ctx, k] { map->BuildSubMap(); StageSubMap(ctx, k, *map); });
       else
       {
         const bool clear = map->IsTimeThreshold();
         const double now = CurrentTime;
         const float* lo3 = mn + 3 * k;
         const float* hi3 = mx + 3 * k;
-        MapWorker[k].Submit([map, clear, now, minPts, mn0 = lo3[0], mn1 = lo3[1], mn2 = lo3[2], mx0 = hi3[0], mx1 = hi3[1], mx2 = hi3[2]] {
+        MapWorker[k].Submit([map, ctx, k, clear, now, minPts, mn0 = lo3[0], mn1 = lo3[1], mn2 = lo3[2], mx0 = hi3[0], mx1 = hi3[1], mx2 = hi3[2]] {
           if (clear) map->ClearOldPoints(now);
           const float lo[3] = {mn0, mn1, mn2}, hi[3] = {mx0, mx1, mx2};
           map->BuildSubMap(lo, hi, minPts);
+          StageSubMap(ctx, k, *map);
         });
       }
     }
@@ -394,7 +404,8 @@ int SlamCore::Localization()
       const auto& sub = LocalMaps[k]->GetSubMap();
       // the map holds one point per leaf voxel: a search cell of about one leaf keeps a handful of candidates per cell
       lsa_set_target_cell_size(Ctx, LSA_TARGET_MAP, k, static_cast<float>((k == LSA_EDGE ? KnnCellScaleMapsEdges : KnnCellScaleMaps) * LocalMaps[k]->GetLeafSize()));
-      LSA_TRY(lsa_set_target(Ctx, LSA_TARGET_MAP, k, sub.data(), static_cast<int>(sub.size())));
+      // the worker left the sub-map in the target's pinned staging buffer: the copy is only enqueued
+      LSA_TRY(lsa_set_target_staged(Ctx, LSA_TARGET_MAP, k, static_cast<int>(sub.size())));
     }
     Stats.submap += t.Stop();
   }
@@ -481,14 +492,16 @@ int SlamCore::FinishSubMapSpeculation()
     const double now = CurrentTime;
     const int minPts = KeypointCounts[k] / 2;
     bool* built = &SpecBuilt[k];
+    lsa_ctx* ctx = Ctx;
     const float* lo3 = mn + 3 * k;
     const float* hi3 = mx + 3 * k;
     // queued behind the previous keyframe's insertion on the same worker: it sees the final map
-    MapWorker[k].Submit([map, clear, now, minPts, built, mn0 = lo3[0], mn1 = lo3[1], mn2 = lo3[2], mx0 = hi3[0], mx1 = hi3[1], mx2 = hi3[2]] {
+    MapWorker[k].Submit([map, ctx, k, clear, now, minPts, built, mn0 = lo3[0], mn1 = lo3[1], mn2 = lo3[2], mx0 = hi3[0], mx1 = hi3[1], mx2 = hi3[2]] {
       if (map->IsSubMapValid()) return;  // the map did not change: Slam.cxx:1013 keeps the kd-tree
       if (clear) map->ClearOldPoints(now);
       const float lo[3] = {mn0, mn1, mn2}, hi[3] = {mx0, mx1, mx2};
       map->BuildSubMap(lo, hi, minPts);
+      StageSubMap(ctx, k, *map);
       *built = true;
     });
   }
@@ -512,19 +525,22 @@ int SlamCore::UpdateMapsUsingTworld()
   KfCounter++;
   KfLastPose = Tworld;
   for (double& v : MapJobSeconds) v = 0.;
+  // the device writes the world keypoints into pinned host memory; the map workers wait for exactly that and
+  // insert them while this thread goes on with the next frame
+  LSA_TRY(lsa_stage_transformed(Ctx, LSA_SET_WORKING, Tworld.m));
   for (int k = 0; k < 3; ++k)
   {
     if (!UseKeypoints[k]) continue;
-    const int n = lsa_keypoint_count(Ctx, LSA_SET_WORKING, k);
-    MapInbox[k].resize(std::max(n, 0));
-    if (n > 0) LSA_TRY(lsa_download_transformed(Ctx, LSA_SET_WORKING, k, Tworld.m, MapInbox[k].data(), n));
     RollingGrid* map = LocalMaps[k].get();
-    const std::vector<lsa_point_t>* cloud = &MapInbox[k];
+    lsa_ctx* ctx = Ctx;
     const double time = CurrentTime;
     double* spent = &MapJobSeconds[k];
-    MapWorker[k].Submit([map, cloud, time, spent] {
+    MapWorker[k].Submit([map, ctx, k, time, spent] {
+      const lsa_point_t* pts = nullptr;
+      int n = 0;
+      if (lsa_staged_transformed(ctx, k, &pts, &n) != LSA_OK) return;
       Tick t;
-      map->Add(*cloud, false, time);
+      map->Add(pts, static_cast<size_t>(std::max(n, 0)), false, time);
       *spent += t.Stop();
     });
   }

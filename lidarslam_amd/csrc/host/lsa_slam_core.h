@@ -172,8 +172,6 @@ private:
   Pose KfLastPose;
   MatchDebug EgoDebug[3], LocDebug[3];
   std::vector<lsa_point_t> Scratch;
-  // keyframe keypoints in world coordinates on their way into the maps (owned by the worker until WaitMaps)
-  std::vector<lsa_point_t> MapInbox[3];
   // Sub-maps are extracted ahead of time: as soon as the keypoints exist, their bounding box under the
   // PREDICTED pose is reduced on the device (asynchronously) and the map workers extract the sub-maps for it
   // while the ego-motion ICP runs.  Localization() checks the box under the actual pose: the sub-map only

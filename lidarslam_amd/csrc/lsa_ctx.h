@@ -137,6 +137,9 @@ struct lsa_ctx
   double kp_time[3][2] = {};
   bool kp_time_valid[3] = {false, false, false};
 
+  // lsa_target_staging: pinned host buffers a target's points are written into before lsa_set_target_staged
+  lsa_point_t* tstage[6] = {};
+  int tstage_cap[6] = {};
   lsa::Target target[6];  // [slot * 3 + type]: slot 0 = map sub-maps (localization), slot 1 = previous scan (ego-motion)
   lsa::MatchBuf match[3];
 
@@ -157,6 +160,11 @@ struct lsa_ctx
   size_t scratch_cap = 0;
   unsigned long long* range_bits = nullptr;  // [0..1] time range, [16..24] bounding boxes (ordered bits)
   hipEvent_t ev_bbox = nullptr;
+  // lsa_stage_transformed: pinned host buffers the device writes the transformed keypoints into directly
+  lsa_point_t* stage[3] = {nullptr, nullptr, nullptr};
+  int stage_cap[3] = {0, 0, 0}, stage_n[3] = {0, 0, 0};
+  hipEvent_t ev_stage = nullptr;
+  bool stage_pending = false;
   bool bbox_pending = false;
   int bbox_n[3] = {0, 0, 0};
 

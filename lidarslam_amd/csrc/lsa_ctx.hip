@@ -231,6 +231,7 @@ int lsa_ctx_create(int device_id, lsa_ctx** out)
   }
   ok &= hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) == hipSuccess;
   ok &= hipEventCreateWithFlags(&ctx->ev_bbox, hipEventDisableTiming) == hipSuccess;
+  ok &= hipEventCreateWithFlags(&ctx->ev_stage, hipEventDisableTiming) == hipSuccess;
   ok &= hipMalloc((void**)&ctx->ring_start, (kMaxRings + 1) * sizeof(int)) == hipSuccess;
   ok &= hipMalloc((void**)&ctx->ring_len, kMaxRings * sizeof(int)) == hipSuccess;
   ok &= hipMalloc((void**)&ctx->ring_meta, 8 * sizeof(int)) == hipSuccess;
@@ -287,6 +288,11 @@ void lsa_ctx_destroy(lsa_ctx* ctx)
   }
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
   if (ctx->ev_bbox) (void)hipEventDestroy(ctx->ev_bbox);
+  if (ctx->ev_stage) (void)hipEventDestroy(ctx->ev_stage);
+  for (int k = 0; k < 3; ++k)
+    if (ctx->stage[k]) (void)hipHostFree(ctx->stage[k]);
+  for (int k = 0; k < 6; ++k)
+    if (ctx->tstage[k]) (void)hipHostFree(ctx->tstage[k]);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }

@@ -1213,6 +1213,42 @@ int lsa_set_target(lsa_ctx* ctx, int slot, int type, const lsa_point_t* pts, int
   return LSA_OK;
 }
 
+lsa_point_t* lsa_target_staging(lsa_ctx* ctx, int slot, int type, int capacity)
+{
+  if (!ctx || slot < 0 || slot > 1 || type < 0 || type > 2 || capacity < 0) return nullptr;
+  const int ti = slot * 3 + type;
+  if (capacity > ctx->tstage_cap[ti])
+  {
+    if (hipSetDevice(ctx->device) != hipSuccess) return nullptr;
+    if (ctx->tstage[ti]) (void)hipHostFree(ctx->tstage[ti]);  // waits for a copy still reading it
+    ctx->tstage[ti] = nullptr;
+    ctx->tstage_cap[ti] = 0;
+    const int cap = std::max(capacity + capacity / 4, 4096);
+    if (hipHostMalloc((void**)&ctx->tstage[ti], (size_t)cap * sizeof(lsa_point_t), hipHostMallocDefault) != hipSuccess) return nullptr;
+    ctx->tstage_cap[ti] = cap;
+  }
+  return ctx->tstage[ti];
+}
+
+int lsa_set_target_staged(lsa_ctx* ctx, int slot, int type, int m)
+{
+  if (!ctx || slot < 0 || slot > 1 || type < 0 || type > 2 || m < 0) return ctx ? ctx->fail(LSA_E_ARG, "lsa_set_target_staged: bad argument") : LSA_E_ARG;
+  const int ti = slot * 3 + type;
+  if (m > ctx->tstage_cap[ti]) return ctx->fail(LSA_E_STATE, "lsa_set_target_staged: more points than the staging buffer holds");
+  LSA_HIP(ctx, hipSetDevice(ctx->device));
+  int rc = ensure_target(ctx, ti, m);
+  if (rc) return rc;
+  Target& t = ctx->target[ti];
+  t.m = m;
+  if (m == 0) return LSA_OK;
+  {
+    ProfScope ps(ctx, "target_upload_h2d", (double)m * 32);
+    LSA_HIP(ctx, hipMemcpyAsync(t.pts, ctx->tstage[ti], (size_t)m * sizeof(lsa_point_t), hipMemcpyHostToDevice, ctx->stream));
+  }
+  t.dirty = true;  // the search grid is built with the other pending targets at the next match
+  return LSA_OK;
+}
+
 int lsa_set_target_from_set(lsa_ctx* ctx, int slot, int type, int set)
 {
   if (!ctx || slot < 0 || slot > 1 || type < 0 || type > 2 || set < 0 || set > 2) return ctx ? ctx->fail(LSA_E_ARG, "lsa_set_target_from_set: bad argument") : LSA_E_ARG;

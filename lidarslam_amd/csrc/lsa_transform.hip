@@ -47,6 +47,27 @@ __global__ __launch_bounds__(256) void k_transform_out(const float4* __restrict_
   out[2 * (size_t)i + 1] = b;
 }
 
+// the three keypoint types of a set in one launch, written straight into pinned host memory (blockIdx.y = type)
+struct StageOut
+{
+  const float4* in[3];
+  float4* out[3];
+  int n[3];
+};
+__global__ __launch_bounds__(256) void k_transform_stage(StageOut s, Rigid T)
+{
+  const int t = blockIdx.y;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= s.n[t]) return;
+  float4 a = s.in[t][2 * (size_t)i];
+  const float4 b = s.in[t][2 * (size_t)i + 1];
+  double ox, oy, oz;
+  rigid_apply(T, (double)a.x, (double)a.y, (double)a.z, ox, oy, oz);
+  a.x = (float)ox; a.y = (float)oy; a.z = (float)oz;
+  s.out[t][2 * (size_t)i] = a;
+  s.out[t][2 * (size_t)i + 1] = b;
+}
+
 // monotone encoding of doubles for 64-bit atomicMin/Max
 __device__ __forceinline__ unsigned long long d2o(double d)
 {
@@ -405,6 +426,51 @@ int lsa_working_bbox(lsa_ctx* ctx, int type, const double pose[16], float mn[3],
   const int rc = lsa_working_bboxes(ctx, pose, lo, hi);
   if (rc) return rc;
   for (int d = 0; d < 3; ++d) { mn[d] = lo[3 * type + d]; mx[d] = hi[3 * type + d]; }
+  return LSA_OK;
+}
+
+int lsa_stage_transformed(lsa_ctx* ctx, int set, const double pose[16])
+{
+  if (!ctx || !pose || set < 0 || set > 2) return ctx ? ctx->fail(LSA_E_ARG, "lsa_stage_transformed: bad argument") : LSA_E_ARG;
+  LSA_HIP(ctx, hipSetDevice(ctx->device));
+  StageOut so;
+  int nmax = 0;
+  for (int k = 0; k < 3; ++k)
+  {
+    const int n = ctx->kp_n[set][k];
+    if (n > ctx->stage_cap[k])
+    {
+      LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      if (ctx->stage[k]) (void)hipHostFree(ctx->stage[k]);
+      ctx->stage[k] = nullptr;
+      const int cap = std::max(n + n / 4, 4096);
+      LSA_HIP(ctx, hipHostMalloc((void**)&ctx->stage[k], (size_t)cap * sizeof(lsa_point_t), hipHostMallocDefault));
+      ctx->stage_cap[k] = cap;
+    }
+    so.in[k] = reinterpret_cast<const float4*>(ctx->kp[set][k]);
+    so.out[k] = reinterpret_cast<float4*>(ctx->stage[k]);
+    so.n[k] = ctx->stage_n[k] = n;
+    nmax = std::max(nmax, n);
+  }
+  if (nmax > 0)
+  {
+    Rigid T;
+    row_major_to_rt(pose, T.R, T.t);
+    ProfScope ps(ctx, "transform_keypoints_out", (double)(so.n[0] + so.n[1] + so.n[2]) * 64);
+    hipLaunchKernelGGL(k_transform_stage, dim3((nmax + 255) / 256, 3), dim3(256), 0, ctx->stream, so, T);
+  }
+  LSA_HIP(ctx, hipEventRecord(ctx->ev_stage, ctx->stream));
+  ctx->stage_pending = true;
+  return LSA_OK;
+}
+int lsa_staged_transformed(lsa_ctx* ctx, int type, const lsa_point_t** pts, int* n)
+{
+  if (!ctx || type < 0 || type > 2 || !pts || !n) return LSA_E_ARG;
+  if (!ctx->stage_pending) return LSA_E_STATE;
+  // may be called from another host thread than the one that staged
+  if (hipSetDevice(ctx->device) != hipSuccess || hipEventSynchronize(ctx->ev_stage) != hipSuccess) return LSA_E_HIP;
+  *pts = ctx->stage[type];
+  *n = ctx->stage_n[type];
   return LSA_OK;
 }
 

@@ -187,8 +187,13 @@ int lsa_set_target_cell_size(lsa_ctx* ctx, int slot, int type, float cell);
 /* Tuning only (results do not depend on it): lanes of a wavefront that cooperate on one query of `type`
  * in the first kNN kernel: 8, 16 or 32 (sparse targets such as edges: more lanes). */
 int lsa_set_knn_lanes(lsa_ctx* ctx, int type, int lanes);
+/* ... and the number of rounds of that kernel (2: blocks of 3^3 and 5^3 cells; 3: also 7^3) before a query is
+ * handed to the second kernel. */
+int lsa_set_knn_rounds(lsa_ctx* ctx, int type, int rounds);
 /* Diagnostics: queries of the last lsa_match that the first kNN kernel handed to the second stage. */
 int lsa_match_slow_queries(lsa_ctx* ctx);
+/* ... and those of them that ended up scanning the whole target. */
+int lsa_match_exhaustive_queries(lsa_ctx* ctx);
 
 /* Replaces a device keypoint set by host points (used by tests and by callers
  * that aggregate several LiDAR devices on the host). */

@@ -178,6 +178,9 @@ int SlamCore::ProcessCurrentFrame(uint64_t stampUs)
   lsa_set_knn_lanes(Ctx, LSA_EDGE, KnnLanesEdges);
   lsa_set_knn_lanes(Ctx, LSA_PLANE, KnnLanesPlanes);
   lsa_set_knn_lanes(Ctx, LSA_BLOB, KnnLanesBlobs);
+  lsa_set_knn_rounds(Ctx, LSA_EDGE, KnnRoundsEdges);
+  lsa_set_knn_rounds(Ctx, LSA_PLANE, KnnRoundsPlanes);
+  lsa_set_knn_rounds(Ctx, LSA_BLOB, KnnRoundsBlobs);
   {
     Tick t;
     int rc = ExtractKeypoints();
@@ -677,6 +680,9 @@ int SlamCore::GetRegisteredFrame(std::vector<lsa_point_t>& out)
   X("KnnLanesEdges", KnnLanesEdges, int)                                                               \
   X("KnnLanesPlanes", KnnLanesPlanes, int)                                                             \
   X("KnnLanesBlobs", KnnLanesBlobs, int)                                                               \
+  X("KnnRoundsEdges", KnnRoundsEdges, int)                                                             \
+  X("KnnRoundsPlanes", KnnRoundsPlanes, int)                                                           \
+  X("KnnRoundsBlobs", KnnRoundsBlobs, int)                                                             \
   X("NeighborWidth", ExtractParams.neighbor_width, int)                                                \
   X("MinDistanceToSensor", ExtractParams.min_distance_to_sensor, float)                                \
   X("MinBeamSurfaceAngle", ExtractParams.min_beam_surface_angle, float)                                \

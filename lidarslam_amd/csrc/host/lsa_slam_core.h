@@ -134,6 +134,7 @@ public:
   double KnnCellScaleMapsEdges = 2.5;      // x map leaf size, edge sub-maps
   // lanes per query in the first kNN kernel (sparse edge targets: more lanes, fewer queries per wavefront)
   int KnnLanesEdges = 16, KnnLanesPlanes = 8, KnnLanesBlobs = 8;
+  int KnnRoundsEdges = 2, KnnRoundsPlanes = 2, KnnRoundsBlobs = 2;  // rounds of the first kNN kernel (2 or 3)
   bool KeepMatchDebug = false;  // download MatchingResults::Rejections/Weights every frame (Slam::GetDebugArray)
 
   std::shared_ptr<RollingGrid> LocalMaps[3];

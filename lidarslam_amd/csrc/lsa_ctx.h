@@ -77,7 +77,8 @@ struct MatchBuf
   int* knn_idx = nullptr;      // [kKnnMax][cap] neighbour indices, ascending (distance, index)
   float* knn_d2 = nullptr;     // [kKnnMax][cap]
   int* knn_cnt = nullptr;      // [cap]
-  int* slow_list = nullptr;    // [cap] queries deferred to the exhaustive kernel
+  int* slow_list = nullptr;    // [cap] queries handed to the second kNN kernel ...
+  float4* slow_pts = nullptr;  // [cap] ... in target coordinates, w = upper bound of the k-th squared distance
   int k = 0;                   // number of queries of the last match
   int cap = 0;
   double sat = 1.0;
@@ -152,6 +153,7 @@ struct lsa_ctx
   int last_match_type = 0;
   // lanes cooperating on one query in the first kNN kernel, per keypoint type (8, 16 or 32)
   int knn_lanes[3] = {16, 8, 8};
+  int knn_rounds[3] = {2, 2, 2};  // blocks of 3^3 .. (2 rounds + 1)^3 cells the first kernel tries
   // lsa_match_types: the keypoint types of one ICP iteration are matched concurrently, the first on
   // `stream`, the others on these, forked and joined with events (no host synchronisation)
   hipStream_t side_stream[2] = {nullptr, nullptr};

@@ -91,6 +91,7 @@ int ensure_match(lsa_ctx* ctx, int type, int k)
   LSA_HIP(ctx, dev_alloc(&b.knn_d2, (size_t)cap * kKnnMax));
   LSA_HIP(ctx, dev_alloc(&b.knn_cnt, (size_t)cap));
   LSA_HIP(ctx, dev_alloc(&b.slow_list, (size_t)cap * 2));
+  LSA_HIP(ctx, dev_alloc(&b.slow_pts, (size_t)cap));
   b.cap = cap;
   return LSA_OK;
 }
@@ -275,7 +276,7 @@ void lsa_ctx_destroy(lsa_ctx* ctx)
   }
   for (int k = 0; k < 3; ++k)
   {
-    fr(ctx->match[k].rec); fr(ctx->match[k].status); fr(ctx->match[k].knn_idx); fr(ctx->match[k].knn_d2); fr(ctx->match[k].knn_cnt); fr(ctx->match[k].slow_list);
+    fr(ctx->match[k].rec); fr(ctx->match[k].status); fr(ctx->match[k].knn_idx); fr(ctx->match[k].knn_d2); fr(ctx->match[k].knn_cnt); fr(ctx->match[k].slow_list); fr(ctx->match[k].slow_pts);
   }
   fr(ctx->partials); fr(ctx->reduce_out); fr(ctx->hist_dev); fr(ctx->scratch_out); fr(ctx->range_bits);
   for (auto& s : ctx->store) fr(s.first);

@@ -531,6 +531,7 @@ struct BlockRuns
       if (ex <= c) L += step;
     }
     uint32_t off = c - __shfl(excl, L, G);
+    if constexpr (E == 1) return __shfl(b[0], L, G) + off;  // the lane's only row holds it
     uint32_t addr = 0;
     bool found = false;
 #pragma unroll
@@ -580,16 +581,16 @@ __device__ __forceinline__ void search_block(GroupSelect<KMAX, G, U>& sel, const
   }
 }
 
-// First stage: every query, G lanes each, the 3x3x3 and then the 5x5x5 block of the finest grid (each round
-// searches its whole block afresh: no bookkeeping of what the previous round saw).  Queries that are not
-// settled inside 2 cells go to the second stage through the device list.
-template <int KMAX, int G>
+// First stage: every query, G lanes each, the 3x3x3, then the 5x5x5 (and with RMAX = 3 the 7x7x7) block of the
+// finest grid (each round searches its whole block afresh: no bookkeeping of what the previous round saw).
+// Queries that are not settled inside RMAX cells go to the second stage through the device list.
+template <int KMAX, int G, int RMAX>
 __global__ __launch_bounds__(256) void k_knn_first(const float4* __restrict__ queries, int nq, Rigid pose, int k, float far_d2,
                                                    const GridDesc* __restrict__ desc, GridPtrs gp, int* __restrict__ knn_idx,
                                                    float* __restrict__ knn_d2, int* __restrict__ knn_cnt, int cap, int* __restrict__ count_out,
-                                                   int* __restrict__ list_out)
+                                                   int* __restrict__ list_out, float4* __restrict__ list_pts)
 {
-  constexpr int U = 4, E = (25 + G - 1) / G;
+  constexpr int U = 4, E = ((2 * RMAX + 1) * (2 * RMAX + 1) + G - 1) / G;
   const int gl = threadIdx.x % G;
   const int q = (int)(((size_t)blockIdx.x * 256 + threadIdx.x) / G);
   const bool active = q < nq;
@@ -607,12 +608,17 @@ __global__ __launch_bounds__(256) void k_knn_first(const float4* __restrict__ qu
   GroupSelect<KMAX, G, U> sel;
   sel.reset();
   bool done = !active, far = false, deferred = false;
-  for (int r = 1; r <= 2; ++r)
+  // the row bounds of every round's block in one memory round trip (a later round costs one trip less)
+  BlockRuns<G, E> all_runs[RMAX];
+#pragma unroll
+  for (int r = 1; r <= RMAX; ++r) all_runs[r - 1].fetch(gv, r, gl, active);
+#pragma unroll
+  for (int r = 1; r <= RMAX; ++r)
   {
     if (__all(done)) break;
-    BlockRuns<G, E> runs;
-    runs.build(gv, r, gl, !done);
-    // groups that are done keep their result: their block is empty, `cur` is scratch for them
+    BlockRuns<G, E>& runs = all_runs[r - 1];
+    runs.finish(gl);
+    if (done) runs.total = 0;  // groups that are done keep their result: an empty block, `cur` is scratch for them
     GroupSelect<KMAX, G, U> cur;
     search_block<KMAX, G, U, E>(cur, runs, gv.sorted, k, gl, qx, qy, qz);
     if (!done)
@@ -623,18 +629,19 @@ __global__ __launch_bounds__(256) void k_knn_first(const float4* __restrict__ qu
       const float bound2 = gv.outd2 + br * br;
       if (runs.covered || sel.count_below(bound2, k) >= k) done = true;
       else if (bound2 > far_d2) { far = true; done = true; }
-      else if (r == 2)
+      else if (r == RMAX)
       {
-        // handed to the second stage together with an upper bound of the k-th distance: the k-th best seen
-        // so far (+inf when the 5x5x5 block holds fewer than k points)
+        // handed to the second stage: the query in target coordinates, and an upper bound of the k-th distance
+        // (the k-th best seen so far; +inf when the block holds fewer than k points)
         if (gl == 0)
         {
-          list_out[atomicAdd(count_out, 1)] = q;
           float ub = INFINITY;
 #pragma unroll
           for (int s = 0; s < KMAX; ++s)
             if (s == k - 1) ub = sel.best_d[s];
-          knn_d2[q] = ub;
+          const int slot = atomicAdd(count_out, 1);
+          list_out[slot] = q;
+          list_pts[slot] = make_float4(qx, qy, qz, ub);
         }
         deferred = true;
         done = true;
@@ -661,57 +668,87 @@ __global__ __launch_bounds__(256) void k_knn_first(const float4* __restrict__ qu
 // run, so every query leaves this kernel answered.  Same (distance, index) order everywhere => the result
 // does not depend on the route taken.
 template <int KMAX>
-__global__ __launch_bounds__(256) void k_knn_second(const float4* __restrict__ queries, const int* __restrict__ list_in, const int* __restrict__ count_in,
-                                                    Rigid pose, int k, float far_d2, const GridDesc* __restrict__ desc, GridPtrs gp,
+__global__ __launch_bounds__(256) void k_knn_second(const int* __restrict__ list_in, const float4* __restrict__ list_pts, const int* __restrict__ count_in,
+                                                    int list_cap, int k, float far_d2, const GridDesc* __restrict__ desc, GridPtrs gp,
                                                     int* __restrict__ knn_idx, float* __restrict__ knn_d2, int* __restrict__ knn_cnt, int cap,
                                                     int* __restrict__ exhaustive_count)
 {
   constexpr int G = 64, U = 8, E = 1;
   constexpr int kStages = 3 * (kGridLevels - 1);  // blocks (level 1, r = 1 .. 3), (level 2, r = 1 .. 3); then the whole target
+  __shared__ uint32_t s_b[4][kStages][64], s_excl[4][kStages][64], s_total[4][kStages];
+  __shared__ float s_bound[4][kStages];
+  __shared__ int s_cov[4][kStages];
+  const int wv = threadIdx.x >> 6;
   const int gl = threadIdx.x & 63;
-  const int nwork = *count_in;
   const int nwaves = gridDim.x * 4;
-  for (int w = blockIdx.x * 4 + (threadIdx.x >> 6); w < nwork; w += nwaves)
+  // the list entry is loaded together with the count (its slot exists whatever the count is): one round trip
+  int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+  int q = list_in[min(w, list_cap - 1)];
+  float4 qp = list_pts[min(w, list_cap - 1)];
+  const int nwork = *count_in;
+  for (; w < nwork; w += nwaves, q = list_in[min(w, list_cap - 1)], qp = list_pts[min(w, list_cap - 1)])
   {
-    const int q = list_in[w];
-    const float4 q4 = queries[2 * (size_t)q];
-    double wx, wy, wz;
-    rigid_apply(pose, (double)q4.x, (double)q4.y, (double)q4.z, wx, wy, wz);
-    const float qx = (float)wx, qy = (float)wy, qz = (float)wz;
+    const float qx = qp.x, qy = qp.y, qz = qp.z;
     GroupSelect<KMAX, G, U> sel;
     sel.reset();
     bool done = false, far = false;
-    // the row bounds of all the blocks in one memory round trip; a block holding fewer than k points cannot
-    // settle the query and is not scanned at all
-    BlockRuns<G, E> runs[kStages];
-    float bound2[kStages];
-#pragma unroll
-    for (int stage = 0; stage < kStages; ++stage)
+    // The row bounds of all the blocks are fetched in one memory round trip (unrolled: the loads overlap) and
+    // parked in LDS, so that the loop over the blocks below is a real loop around ONE instance of the search
+    // code: unrolled six times that code was 100 KB, more than the instruction cache, and every launch paid for
+    // fetching it.  Each lane reads back what it wrote itself: no synchronisation.
     {
-      const int level = 1 + stage / 3, r = 1 + stage % 3;
-      GridView gv;
-      grid_view(gv, desc + level, gp.cell_start[level], gp.sorted[level], qx, qy, qz);
-      runs[stage].fetch(gv, r, gl, true);
-      // every point closer than r cells (minus a 0.1 % guard for the float cell assignment) is in the block
-      const float br = ((float)r - 0.001f) * gv.g.cell;
-      bound2[stage] = gv.outd2 + br * br;
-    }
+      BlockRuns<G, E> runs[kStages];
 #pragma unroll
-    for (int stage = 0; stage < kStages; ++stage) runs[stage].finish(gl);
+      for (int stage = 0; stage < kStages; ++stage)
+      {
+        const int level = 1 + stage / 3, r = 1 + stage % 3;
+        GridView gv;
+        grid_view(gv, desc + level, gp.cell_start[level], gp.sorted[level], qx, qy, qz);
+        runs[stage].fetch(gv, r, gl, true);
+        // every point closer than r cells (minus a 0.1 % guard for the float cell assignment) is in the block
+        const float br = ((float)r - 0.001f) * gv.g.cell;
+        if (gl == 0) s_bound[wv][stage] = gv.outd2 + br * br;
+      }
+#pragma unroll
+      for (int stage = 0; stage < kStages; ++stage)
+      {
+        runs[stage].finish(gl);
+        s_b[wv][stage][gl] = runs[stage].b[0];
+        s_excl[wv][stage][gl] = runs[stage].excl;
+        if (gl == 0) { s_total[wv][stage] = runs[stage].total; s_cov[wv][stage] = runs[stage].covered ? 1 : 0; }
+      }
+    }
     // upper bound of the k-th distance (+inf: none yet), from the first stage and then from every scan that
     // did not settle the query: the first block whose proven radius exceeds it settles the query for certain,
-    // smaller ones are not tried
-    float ub = knn_d2[q];
-#pragma unroll
-    for (int stage = 0; stage < kStages; ++stage)
+    // smaller ones are not tried.  The last "block" is the whole target.
+    float ub = qp.w;
+#pragma unroll 1
+    for (int stage = 0; stage <= kStages && !done; ++stage)
     {
-      if (done) continue;
-      const bool few = runs[stage].total < (uint32_t)k;  // cannot hold k neighbours
-      if (runs[stage].covered || (!few && (ub == INFINITY || bound2[stage] > ub || stage == kStages - 1)))
+      BlockRuns<G, E> runs;
+      float bound2 = INFINITY;
+      if (stage < kStages)
       {
-        search_block<KMAX, G, U, E>(sel, runs[stage], gp.sorted[1 + stage / 3], k, gl, qx, qy, qz);
-        if (runs[stage].covered || sel.count_below(bound2[stage], k) >= k) done = true;
-        else if (bound2[stage] > far_d2) { far = true; done = true; }
+        runs.b[0] = s_b[wv][stage][gl];
+        runs.excl = s_excl[wv][stage][gl];
+        runs.len[0] = 0;  // not used by locate()
+        runs.total = s_total[wv][stage];
+        runs.covered = s_cov[wv][stage] != 0;
+        bound2 = s_bound[wv][stage];
+      }
+      else
+      {
+        runs.whole((uint32_t)desc->npoints, gl);
+        if (gl == 0) atomicAdd(exhaustive_count, 1);
+      }
+      const bool few = runs.total < (uint32_t)k;  // cannot hold k neighbours
+      if (runs.covered || (!few && (ub == INFINITY || bound2 > ub || stage == kStages - 1)))
+      {
+        const int level = stage < kStages ? 1 + stage / 3 : 0;
+        const float4* src = level == 0 ? gp.sorted[0] : level == 1 ? gp.sorted[1] : gp.sorted[2];
+        search_block<KMAX, G, U, E>(sel, runs, src, k, gl, qx, qy, qz);
+        if (runs.covered || sel.count_below(bound2, k) >= k) done = true;
+        else if (bound2 > far_d2) { far = true; done = true; }
         else
         {
 #pragma unroll
@@ -720,14 +757,7 @@ __global__ __launch_bounds__(256) void k_knn_second(const float4* __restrict__ q
         }
       }
       // fewer than k points inside a radius beyond the rejection distance
-      else if (few && bound2[stage] > far_d2) { far = true; done = true; }
-    }
-    if (!done)
-    {
-      BlockRuns<G, E> all;
-      all.whole((uint32_t)desc->npoints, gl);
-      if (gl == 0) atomicAdd(exhaustive_count, 1);
-      search_block<KMAX, G, U, E>(sel, all, gp.sorted[0], k, gl, qx, qy, qz);
+      else if (few && bound2 > far_d2) { far = true; done = true; }
     }
     if (gl == 0)
     {
@@ -1165,19 +1195,20 @@ void launch_knn(lsa_ctx* ctx, const lsa_point_t* q, int nq, const Rigid& pose, i
     // algorithmic bytes: query point in, k candidate points examined at least, k (index, distance) pairs out
     ProfScope ps(ctx, nf, (double)nq * (32 + k * 16 + k * 8), st);
     const int lanes = ctx->knn_lanes[type];
-#define LSA_FIRST(G)                                                                                                                     \
-  hipLaunchKernelGGL((k_knn_first<KMAX, G>), dim3((int)(((size_t)nq * G + 255) / 256)), dim3(256), 0, st, q4, nq, pose, k, far_d2, t.desc, gp, \
-                     mb.knn_idx, mb.knn_d2, mb.knn_cnt, mb.cap, cntA, listA)
-    if (lanes >= 32) LSA_FIRST(32);
-    else if (lanes >= 16) LSA_FIRST(16);
-    else LSA_FIRST(8);
+    const int rounds = ctx->knn_rounds[type];
+#define LSA_FIRST(G, R)                                                                                                                     \
+  hipLaunchKernelGGL((k_knn_first<KMAX, G, R>), dim3((int)(((size_t)nq * G + 255) / 256)), dim3(256), 0, st, q4, nq, pose, k, far_d2, t.desc, gp, \
+                     mb.knn_idx, mb.knn_d2, mb.knn_cnt, mb.cap, cntA, listA, mb.slow_pts)
+    if (lanes >= 32) { if (rounds >= 3) LSA_FIRST(32, 3); else LSA_FIRST(32, 2); }
+    else if (lanes >= 16) { if (rounds >= 3) LSA_FIRST(16, 3); else LSA_FIRST(16, 2); }
+    else { if (rounds >= 3) LSA_FIRST(8, 3); else LSA_FIRST(8, 2); }
 #undef LSA_FIRST
   }
   {
     // the deferred share is only known on the device: no bytes are credited to this stage
     ProfScope ps(ctx, nc, 0., st);
-    hipLaunchKernelGGL((k_knn_second<KMAX>), dim3(1024), dim3(256), 0, st, q4, (const int*)listA, (const int*)cntA, pose, k, far_d2, t.desc, gp,
-                       mb.knn_idx, mb.knn_d2, mb.knn_cnt, mb.cap, cntB);
+    hipLaunchKernelGGL((k_knn_second<KMAX>), dim3(1024), dim3(256), 0, st, (const int*)listA, (const float4*)mb.slow_pts, (const int*)cntA, mb.cap, k,
+                       far_d2, t.desc, gp, mb.knn_idx, mb.knn_d2, mb.knn_cnt, mb.cap, cntB);
   }
 }
 
@@ -1262,6 +1293,13 @@ int lsa_set_target_from_set(lsa_ctx* ctx, int slot, int type, int set)
   if (m == 0) return LSA_OK;
   LSA_HIP(ctx, hipMemcpyAsync(t.pts, ctx->kp[set][type], (size_t)m * sizeof(lsa_point_t), hipMemcpyDeviceToDevice, ctx->stream));
   t.dirty = true;
+  return LSA_OK;
+}
+
+int lsa_set_knn_rounds(lsa_ctx* ctx, int type, int rounds)
+{
+  if (!ctx || type < 0 || type > 2 || rounds < 2 || rounds > 3) return LSA_E_ARG;
+  ctx->knn_rounds[type] = rounds;
   return LSA_OK;
 }
 
@@ -1454,6 +1492,15 @@ int lsa_match_slow_queries(lsa_ctx* ctx)
   int v = 0;
   if (hipStreamSynchronize(ctx->stream) != hipSuccess) return LSA_E_HIP;
   if (hipMemcpy(&v, ctx->hist_dev + ctx->last_match_type * 16 + LSA_MATCH_NSTATUS, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return LSA_E_HIP;
+  return v;
+}
+
+int lsa_match_exhaustive_queries(lsa_ctx* ctx)
+{
+  if (!ctx) return LSA_E_ARG;
+  int v = 0;
+  if (hipStreamSynchronize(ctx->stream) != hipSuccess) return LSA_E_HIP;
+  if (hipMemcpy(&v, ctx->hist_dev + ctx->last_match_type * 16 + LSA_MATCH_NSTATUS + 1, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return LSA_E_HIP;
   return v;
 }
 

@@ -30,8 +30,7 @@ constexpr int kCellCap = 1 << 22;         // max cells of the finest kNN search 
 __host__ __device__ constexpr int grid_level_cells(int level) { return level == 0 ? kCellCap : level == 1 ? (kCellCap >> 6) + 64 : (kCellCap >> 12) + 64; }
 constexpr int kKnnMax = 16;               // neighbours per query the kNN buffers hold
 constexpr int kAccumBlocks = 64;          // grid of the normal-equation kernel (grid-stride); the host folds the blocks' partial sums
-constexpr int kMailboxStride = 32;        // doubles per block in the mailbox: [0..28] partial sums, [31] sequence flag
-constexpr int kMailboxFlag = 31;
+constexpr int kMailboxStride = 40;        // doubles per block in the mailbox: ten 32-byte pieces of 3 partial sums + the sequence tag
 constexpr int kAccumVals = 29;            // cost, g[6], H upper[21], nvalid
 
 struct GridDesc

@@ -1013,6 +1013,21 @@ __device__ __forceinline__ void mv3(const double M[9], double x, double y, doubl
   oz = (M[6] * x + M[7] * y) + M[8] * z;
 }
 
+// value of lane (i + o) of the same row of 16 lanes, 0 where that lane does not exist (o = 1, 2, 4, 8)
+__device__ __forceinline__ double dpp_row_shl(double x, int o)
+{
+  const long long b = __double_as_longlong(x);
+  int lo = (int)(b & 0xffffffffll), hi = (int)(b >> 32);
+  switch (o)
+  {
+    case 8: lo = __builtin_amdgcn_update_dpp(0, lo, 0x108, 0xF, 0xF, true); hi = __builtin_amdgcn_update_dpp(0, hi, 0x108, 0xF, 0xF, true); break;
+    case 4: lo = __builtin_amdgcn_update_dpp(0, lo, 0x104, 0xF, 0xF, true); hi = __builtin_amdgcn_update_dpp(0, hi, 0x104, 0xF, 0xF, true); break;
+    case 2: lo = __builtin_amdgcn_update_dpp(0, lo, 0x102, 0xF, 0xF, true); hi = __builtin_amdgcn_update_dpp(0, hi, 0x102, 0xF, 0xF, true); break;
+    default: lo = __builtin_amdgcn_update_dpp(0, lo, 0x101, 0xF, 0xF, true); hi = __builtin_amdgcn_update_dpp(0, hi, 0x101, 0xF, 0xF, true); break;
+  }
+  return __longlong_as_double(((long long)hi << 32) | (long long)(unsigned)lo);
+}
+
 __global__ __launch_bounds__(256) void k_accumulate(AccumConst c, double* __restrict__ partials, double* __restrict__ mailbox, unsigned long long seq)
 {
   double acc[kAccumVals];
@@ -1075,7 +1090,7 @@ __global__ __launch_bounds__(256) void k_accumulate(AccumConst c, double* __rest
   // one shuffle step for all 29 values at a time: 29 independent LDS permutes in flight per step
   // instead of 29 chains of 6 dependent ones
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1)
+  for (int o = 32; o >= 16; o >>= 1)
   {
     double tmp[kAccumVals];
 #pragma unroll
@@ -1083,29 +1098,36 @@ __global__ __launch_bounds__(256) void k_accumulate(AccumConst c, double* __rest
 #pragma unroll
     for (int v = 0; v < kAccumVals; ++v) acc[v] += tmp[v];
   }
+  // inside a row of 16 lanes the partner's value comes through a DPP operand (row_shr), not through LDS;
+  // lanes the shift leaves without a partner read 0 -- only lane 0's sum is kept
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1)
+  {
+#pragma unroll
+    for (int v = 0; v < kAccumVals; ++v) acc[v] += dpp_row_shl(acc[v], o);
+  }
   if ((threadIdx.x & 63) == 0)
   {
 #pragma unroll
     for (int v = 0; v < kAccumVals; ++v) wsum[threadIdx.x >> 6][v] = acc[v];
   }
   __syncthreads();
-  if (threadIdx.x < kAccumVals)
+  // Zero-copy hand-over: the block's 29 partial sums land in coherent host memory as ten aligned 32-byte
+  // pieces of 3 values + the evaluation's sequence number in the piece's last word.  One store instruction
+  // writes them all; 32 bytes is the smallest unit a write is ever split into, so a piece's tag never arrives
+  // without its values: the host polls the tags -- no fence, no flag, no second kernel, no D2H copy, no stream
+  // synchronisation on the LM critical path -- and folds the blocks in index order (as k_accumulate_final does).
+  if (threadIdx.x < kMailboxStride)
   {
-    const double r = ((wsum[0][threadIdx.x] + wsum[1][threadIdx.x]) + wsum[2][threadIdx.x]) + wsum[3][threadIdx.x];
-    partials[(size_t)blockIdx.x * kAccumVals + threadIdx.x] = r;
-    // zero-copy hand-over: the block's 29 partial sums land in coherent host memory, then the sequence
-    // number the host is polling.  The host folds the blocks in index order (as k_accumulate_final does):
-    // no second kernel, no D2H copy, no stream synchronisation on the LM critical path.
-    // (plain stores: the 29 lanes' 8 bytes leave as a few wide writes, per-lane atomics would each be a bus transaction)
+    const int chunk = threadIdx.x >> 2, slot = threadIdx.x & 3, v = chunk * 3 + slot;
+    double r = 0.;
+    if (slot < 3 && v < kAccumVals)
+    {
+      r = ((wsum[0][v] + wsum[1][v]) + wsum[2][v]) + wsum[3][v];
+      partials[(size_t)blockIdx.x * kAccumVals + v] = r;
+    }
+    if (slot == 3) r = __longlong_as_double((long long)seq);
     if (mailbox) mailbox[(size_t)blockIdx.x * kMailboxStride + threadIdx.x] = r;
-  }
-  if (mailbox)
-  {
-    __threadfence_system();
-    __syncthreads();
-    if (threadIdx.x == 0)
-      __hip_atomic_store(reinterpret_cast<unsigned long long*>(mailbox + (size_t)blockIdx.x * kMailboxStride + kMailboxFlag), seq, __ATOMIC_RELEASE,
-                         __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 
@@ -1541,28 +1563,30 @@ int lsa_accumulate(lsa_ctx* ctx, unsigned type_mask, const double w[6], int want
   bool got = false;
   if (ctx->mailbox)
   {
-    // poll the blocks' flags (bounded: fall back to a device fold + synchronous copy if one does not arrive)
+    // poll the pieces' tags (bounded: fall back to a device fold + synchronous copy if one does not arrive)
     const auto t0 = std::chrono::steady_clock::now();
     unsigned spins = 0;
     bool timeout = false;
+    const unsigned long long want = ctx->mailbox_seq;
     for (int b = 0; b < kAccumBlocks && !timeout; ++b)
-    {
-      volatile unsigned long long* flag = reinterpret_cast<volatile unsigned long long*>(ctx->mailbox + (size_t)b * kMailboxStride + kMailboxFlag);
-      while (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != ctx->mailbox_seq)
+      for (int c = 0; c < kMailboxStride / 4 && !timeout; ++c)
       {
-        if ((++spins & 0x3ff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) { timeout = true; break; }
+        volatile unsigned long long* tag = reinterpret_cast<volatile unsigned long long*>(ctx->mailbox + (size_t)b * kMailboxStride + c * 4 + 3);
+        while (__atomic_load_n(tag, __ATOMIC_ACQUIRE) != want)
+        {
+          if ((++spins & 0x3ff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) { timeout = true; break; }
 #if defined(__x86_64__)
-        __builtin_ia32_pause();
+          __builtin_ia32_pause();
 #endif
+        }
       }
-    }
     if (!timeout)
     {
       for (int v = 0; v < kAccumVals; ++v) hp[v] = 0.;
       for (int b = 0; b < kAccumBlocks; ++b)
       {
-        const double* row = ctx->mailbox + (size_t)b * kMailboxStride;
-        for (int v = 0; v < kAccumVals; ++v) hp[v] += row[v];
+        const volatile double* row = ctx->mailbox + (size_t)b * kMailboxStride;
+        for (int v = 0; v < kAccumVals; ++v) hp[v] += row[(v / 3) * 4 + (v % 3)];
       }
       got = true;
     }

@@ -22,6 +22,7 @@
 // kNN order: ascending (float squared distance, target index); the distance is evaluated exactly like
 // nanoflann's L2_Simple_Adaptor: ((dx*dx)+dy*dy)+dz*dz with d = query - point.
 #include <cfloat>
+#include <type_traits>
 #include <chrono>
 #include <cmath>
 #include "lsa_ctx.h"
@@ -458,6 +459,7 @@ struct GroupSelect
 template <int G, int E>
 struct BlockRuns
 {
+  static constexpr int kE = E;
   uint32_t b[E], len[E];
   uint32_t excl, total;
   bool covered;
@@ -473,6 +475,7 @@ struct BlockRuns
     const int ys = y1 - y0 + 1;
     const int nrows = live ? (z1 - z0 + 1) * ys : 0;
     covered = (x0 == 0 && y0 == 0 && z0 == 0 && x1 == nx - 1 && y1 == ny - 1 && z1 == nz - 1);
+    const int inv_ys = (1 << 16) / ys + 1;  // ri / ys == (ri * inv_ys) >> 16 for ys <= 9, ri < 128: no integer division in the loop
 #pragma unroll
     for (int e = 0; e < E; ++e)
     {
@@ -480,7 +483,8 @@ struct BlockRuns
       b[e] = 0; len[e] = 0;
       if (ri < nrows)
       {
-        const int row = ((z0 + ri / ys) * ny + (y0 + ri % ys)) * nx;
+        const int zi = (ri * inv_ys) >> 16;
+        const int row = ((z0 + zi) * ny + (y0 + ri - zi * ys)) * nx;
         b[e] = gv.cell_start[row + x0];
         len[e] = gv.cell_start[row + x1 + 1];  // end of the run until finish()
       }
@@ -590,7 +594,7 @@ __global__ __launch_bounds__(256) void k_knn_first(const float4* __restrict__ qu
                                                    float* __restrict__ knn_d2, int* __restrict__ knn_cnt, int cap, int* __restrict__ count_out,
                                                    int* __restrict__ list_out, float4* __restrict__ list_pts)
 {
-  constexpr int U = 4, E = ((2 * RMAX + 1) * (2 * RMAX + 1) + G - 1) / G;
+  constexpr int U = 4;
   const int gl = threadIdx.x % G;
   const int q = (int)(((size_t)blockIdx.x * 256 + threadIdx.x) / G);
   const bool active = q < nq;
@@ -608,46 +612,50 @@ __global__ __launch_bounds__(256) void k_knn_first(const float4* __restrict__ qu
   GroupSelect<KMAX, G, U> sel;
   sel.reset();
   bool done = !active, far = false, deferred = false;
-  // the row bounds of every round's block in one memory round trip (a later round costs one trip less)
-  BlockRuns<G, E> all_runs[RMAX];
-#pragma unroll
-  for (int r = 1; r <= RMAX; ++r) all_runs[r - 1].fetch(gv, r, gl, active);
-#pragma unroll
-  for (int r = 1; r <= RMAX; ++r)
-  {
-    if (__all(done)) break;
-    BlockRuns<G, E>& runs = all_runs[r - 1];
+  // the row bounds of every round's block in one memory round trip (a later round costs one trip less); each
+  // block has its own number of rows per lane, so that locating a candidate in the 3x3x3 block costs no more
+  // shuffles than its 9 rows need
+  constexpr int E1 = (9 + G - 1) / G, E2 = (25 + G - 1) / G, E3 = (49 + G - 1) / G;
+  BlockRuns<G, E1> runs1;
+  BlockRuns<G, E2> runs2;
+  BlockRuns<G, (RMAX >= 3 ? E3 : 1)> runs3;
+  runs1.fetch(gv, 1, gl, active);
+  runs2.fetch(gv, 2, gl, active);
+  if (RMAX >= 3) runs3.fetch(gv, 3, gl, active);
+  auto round = [&](auto& runs, int r) {
+    if (__all(done)) return;
     runs.finish(gl);
     if (done) runs.total = 0;  // groups that are done keep their result: an empty block, `cur` is scratch for them
     GroupSelect<KMAX, G, U> cur;
-    search_block<KMAX, G, U, E>(cur, runs, gv.sorted, k, gl, qx, qy, qz);
-    if (!done)
+    search_block<KMAX, G, U, std::remove_reference_t<decltype(runs)>::kE>(cur, runs, gv.sorted, k, gl, qx, qy, qz);
+    if (done) return;
+    sel = cur;
+    // every point closer than r cells (minus a 0.1 % guard for the float cell assignment) has been seen
+    const float br = ((float)r - 0.001f) * gv.g.cell;
+    const float bound2 = gv.outd2 + br * br;
+    if (runs.covered || sel.count_below(bound2, k) >= k) done = true;
+    else if (bound2 > far_d2) { far = true; done = true; }
+    else if (r == RMAX)
     {
-      sel = cur;
-      // every point closer than r cells (minus a 0.1 % guard for the float cell assignment) has been seen
-      const float br = ((float)r - 0.001f) * gv.g.cell;
-      const float bound2 = gv.outd2 + br * br;
-      if (runs.covered || sel.count_below(bound2, k) >= k) done = true;
-      else if (bound2 > far_d2) { far = true; done = true; }
-      else if (r == RMAX)
+      // handed to the second stage: the query in target coordinates, and an upper bound of the k-th distance
+      // (the k-th best seen so far; +inf when the block holds fewer than k points)
+      if (gl == 0)
       {
-        // handed to the second stage: the query in target coordinates, and an upper bound of the k-th distance
-        // (the k-th best seen so far; +inf when the block holds fewer than k points)
-        if (gl == 0)
-        {
-          float ub = INFINITY;
+        float ub = INFINITY;
 #pragma unroll
-          for (int s = 0; s < KMAX; ++s)
-            if (s == k - 1) ub = sel.best_d[s];
-          const int slot = atomicAdd(count_out, 1);
-          list_out[slot] = q;
-          list_pts[slot] = make_float4(qx, qy, qz, ub);
-        }
-        deferred = true;
-        done = true;
+        for (int s = 0; s < KMAX; ++s)
+          if (s == k - 1) ub = sel.best_d[s];
+        const int slot = atomicAdd(count_out, 1);
+        list_out[slot] = q;
+        list_pts[slot] = make_float4(qx, qy, qz, ub);
       }
+      deferred = true;
+      done = true;
     }
-  }
+  };
+  round(runs1, 1);
+  round(runs2, 2);
+  if (RMAX >= 3) round(runs3, 3);
   if (active && gl == 0 && !deferred)
   {
     int cnt = 0;
@@ -675,10 +683,6 @@ __global__ __launch_bounds__(256) void k_knn_second(const int* __restrict__ list
 {
   constexpr int G = 64, U = 8, E = 1;
   constexpr int kStages = 3 * (kGridLevels - 1);  // blocks (level 1, r = 1 .. 3), (level 2, r = 1 .. 3); then the whole target
-  __shared__ uint32_t s_b[4][kStages][64], s_excl[4][kStages][64], s_total[4][kStages];
-  __shared__ float s_bound[4][kStages];
-  __shared__ int s_cov[4][kStages];
-  const int wv = threadIdx.x >> 6;
   const int gl = threadIdx.x & 63;
   const int nwaves = gridDim.x * 4;
   // the list entry is loaded together with the count (its slot exists whatever the count is): one round trip
@@ -692,49 +696,41 @@ __global__ __launch_bounds__(256) void k_knn_second(const int* __restrict__ list
     GroupSelect<KMAX, G, U> sel;
     sel.reset();
     bool done = false, far = false;
-    // The row bounds of all the blocks are fetched in one memory round trip (unrolled: the loads overlap) and
-    // parked in LDS, so that the loop over the blocks below is a real loop around ONE instance of the search
-    // code: unrolled six times that code was 100 KB, more than the instruction cache, and every launch paid for
-    // fetching it.  Each lane reads back what it wrote itself: no synchronisation.
-    {
-      BlockRuns<G, E> runs[kStages];
-#pragma unroll
-      for (int stage = 0; stage < kStages; ++stage)
-      {
-        const int level = 1 + stage / 3, r = 1 + stage % 3;
-        GridView gv;
-        grid_view(gv, desc + level, gp.cell_start[level], gp.sorted[level], qx, qy, qz);
-        runs[stage].fetch(gv, r, gl, true);
-        // every point closer than r cells (minus a 0.1 % guard for the float cell assignment) is in the block
-        const float br = ((float)r - 0.001f) * gv.g.cell;
-        if (gl == 0) s_bound[wv][stage] = gv.outd2 + br * br;
-      }
-#pragma unroll
-      for (int stage = 0; stage < kStages; ++stage)
-      {
-        runs[stage].finish(gl);
-        s_b[wv][stage][gl] = runs[stage].b[0];
-        s_excl[wv][stage][gl] = runs[stage].excl;
-        if (gl == 0) { s_total[wv][stage] = runs[stage].total; s_cov[wv][stage] = runs[stage].covered ? 1 : 0; }
-      }
-    }
-    // upper bound of the k-th distance (+inf: none yet), from the first stage and then from every scan that
-    // did not settle the query: the first block whose proven radius exceeds it settles the query for certain,
-    // smaller ones are not tried.  The last "block" is the whole target.
+    GridView gv1, gv2;
+    grid_view(gv1, desc + 1, gp.cell_start[1], gp.sorted[1], qx, qy, qz);
+    grid_view(gv2, desc + 2, gp.cell_start[2], gp.sorted[2], qx, qy, qz);
+    // every point closer than r cells (minus a 0.1 % guard for the float cell assignment) is in block (level, r)
+    auto proven = [&](int stage) {
+      const GridView& gv = stage < 3 ? gv1 : gv2;
+      const float br = ((float)(1 + stage % 3) - 0.001f) * gv.g.cell;
+      return gv.outd2 + br * br;
+    };
+    // Upper bound of the k-th distance (+inf: none yet), from the first stage and then from every scan that did
+    // not settle the query: the first block whose proven radius exceeds it settles the query for certain, so the
+    // search starts there -- one fetch of row bounds, one scan.  Without a bound the blocks are tried in order;
+    // one that holds fewer than k points is not scanned.  The last "block" is the whole target.
     float ub = qp.w;
+    int stage = 0;
+    if (ub != INFINITY)
+      while (stage < kStages - 1 && !(proven(stage) > ub)) ++stage;
 #pragma unroll 1
-    for (int stage = 0; stage <= kStages && !done; ++stage)
+    for (; stage <= kStages && !done; ++stage)
     {
       BlockRuns<G, E> runs;
       float bound2 = INFINITY;
+      const float4* src = gp.sorted[0];
       if (stage < kStages)
       {
-        runs.b[0] = s_b[wv][stage][gl];
-        runs.excl = s_excl[wv][stage][gl];
-        runs.len[0] = 0;  // not used by locate()
-        runs.total = s_total[wv][stage];
-        runs.covered = s_cov[wv][stage] != 0;
-        bound2 = s_bound[wv][stage];
+        const bool l1 = stage < 3;
+        GridView gv;
+        gv.g = l1 ? gv1.g : gv2.g;
+        gv.cell_start = l1 ? gv1.cell_start : gv2.cell_start;
+        gv.sorted = l1 ? gv1.sorted : gv2.sorted;
+        gv.cx = l1 ? gv1.cx : gv2.cx; gv.cy = l1 ? gv1.cy : gv2.cy; gv.cz = l1 ? gv1.cz : gv2.cz;
+        gv.outd2 = l1 ? gv1.outd2 : gv2.outd2;
+        runs.build(gv, 1 + stage % 3, gl, true);
+        bound2 = proven(stage);
+        src = gv.sorted;
       }
       else
       {
@@ -744,8 +740,6 @@ __global__ __launch_bounds__(256) void k_knn_second(const int* __restrict__ list
       const bool few = runs.total < (uint32_t)k;  // cannot hold k neighbours
       if (runs.covered || (!few && (ub == INFINITY || bound2 > ub || stage == kStages - 1)))
       {
-        const int level = stage < kStages ? 1 + stage / 3 : 0;
-        const float4* src = level == 0 ? gp.sorted[0] : level == 1 ? gp.sorted[1] : gp.sorted[2];
         search_block<KMAX, G, U, E>(sel, runs, src, k, gl, qx, qy, qz);
         if (runs.covered || sel.count_below(bound2, k) >= k) done = true;
         else if (bound2 > far_d2) { far = true; done = true; }
@@ -1229,7 +1223,7 @@ void launch_knn(lsa_ctx* ctx, const lsa_point_t* q, int nq, const Rigid& pose, i
   {
     // the deferred share is only known on the device: no bytes are credited to this stage
     ProfScope ps(ctx, nc, 0., st);
-    hipLaunchKernelGGL((k_knn_second<KMAX>), dim3(1024), dim3(256), 0, st, (const int*)listA, (const float4*)mb.slow_pts, (const int*)cntA, mb.cap, k,
+    hipLaunchKernelGGL((k_knn_second<KMAX>), dim3(512), dim3(256), 0, st, (const int*)listA, (const float4*)mb.slow_pts, (const int*)cntA, mb.cap, k,
                        far_d2, t.desc, gp, mb.knn_idx, mb.knn_d2, mb.knn_cnt, mb.cap, cntB);
   }
 }

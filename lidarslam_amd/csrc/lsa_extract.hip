@@ -19,7 +19,7 @@ using namespace lsa;
 namespace
 {
 
-constexpr int kLabelThreads = 512;  // one block per ring
+constexpr int kLabelThreads = 1024;  // one block per ring
 
 struct ExtractConst
 {

@@ -211,10 +211,13 @@ def main():
 # profiling scope -> device kernel, for looking a scope up in the committed PMC table
 SCOPE_KERNEL = {
     "accumulate_jac": ["k_accumulate"], "accumulate_cost": ["k_accumulate"],
-    "knn_fine_edge": ["k_knn_first<8, 16>", "k_knn_first<16, 16>"], "knn_fine_plane": ["k_knn_first<5, 8>"],
+    "knn_fine_edge": ["k_knn_first<8, 16, 2>", "k_knn_first<16, 16, 2>"], "knn_fine_plane": ["k_knn_first<5, 8, 2>"],
     "knn_coarse_edge": ["k_knn_second<8>", "k_knn_second<16>"], "knn_coarse_plane": ["k_knn_second<5>"],
     "label_nms": ["k_label"], "curvature": ["k_curvature<4>"],
 }
+
+
+STREAMING_SCOPES = {"accumulate_jac", "accumulate_cost", "curvature", "label_nms"}
 
 
 def pmc_traffic(scope, model):
@@ -234,10 +237,12 @@ def pmc_traffic(scope, model):
     calls = sum(r["calls"] for r in rows)
     if not rows or calls == 0:
         return None
-    # raw counters (KiB), launch-weighted over the kernel instances behind the scope.  The gfx950 x2 FETCH
-    # correction is for 16 B/lane streaming reads; these kernels gather, so the raw figure is reported
-    # (DESIGN.md gives the corrected upper bound beside it)
-    return sum((r["fetch_kib"] + r["write_kib"]) * 1024.0 * r["calls"] for r in rows) / calls
+    # launch-weighted over the kernel instances behind the scope.  gfx950 FETCH_SIZE reports half the bytes of
+    # wide coalesced streaming reads (MI355X_MICROARCH.md, HBM): doubled for the kernels that stream their input
+    # (the normal-equation and per-point kernels; 2 x FETCH then lands within 10 % of the algorithmic bytes), raw for
+    # the gather kernels (kNN), whose access width the guide calls uncalibrated.
+    fetch_scale = 2.0 if scope in STREAMING_SCOPES else 1.0
+    return sum((fetch_scale * r["fetch_kib"] + r["write_kib"]) * 1024.0 * r["calls"] for r in rows) / calls
 
 
 def cpu_baseline(args, seed):

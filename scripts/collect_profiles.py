@@ -14,7 +14,7 @@ if f and w:
                          capture_output=True, text=True, check=True).stdout
     open(os.path.join(dst, f"{rnd}_vls128_pmc_traffic.txt"), "w").write(out)
 lines = []
-for m in ("vls128", "hdl64", "vlp16"):
+for m in ("vls128", "hdl64", "vlp16", "vls128_noevents"):
     p = os.path.join(src, f"bench_{m}.json")
     if os.path.exists(p):
         for l in open(p):
@@ -24,4 +24,5 @@ for m in ("vls128", "hdl64", "vlp16"):
 open(os.path.join(dst, f"{rnd}_bench_lines.jsonl"), "w").write("\n".join(lines) + "\n")
 for l in lines:
     d = json.loads(l)
-    print(d["config"]["workload"], d["value"], d["unit"], "roofline", d["roofline"]["kernel"] if "kernel" in d["roofline"] else "", d["roofline"]["frac"])
+    r = d.get("roofline", {})
+    print(d["config"]["workload"].split(",")[0], round(d["value"], 1), d["unit"], "| roofline", r.get("kernel", "-"), r.get("frac", "-"))

@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = all host cores available to this process")
     ap.add_argument("--param", action="append", default=[], help="Slam parameter override NAME=VALUE (reference setter names)")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events at all")
+    ap.add_argument("--host-frames", action="store_true", help="hand every scan over from a host buffer (PCIe inclusive; never the headline value)")
     ap.add_argument("--profile-all", action="store_true", help="time every scope in the timed region too (costs ~10 %% of the frame rate)")
     return ap.parse_args()
 
@@ -73,10 +74,13 @@ def main():
         name, value = kv.split("=")
         slam.set_param(name, float(value))
     seed = sequence_seed(rank)
-    stamps, npts = [], 0
+    stamps, npts, host_frames = [], 0, []
     for f in range(total):
         pts, stamp = L.synth_frame(args.model, seed, f)
-        slam.store_frame(f, pts)
+        if args.host_frames:
+            host_frames.append(pts)
+        else:
+            slam.store_frame(f, pts)
         stamps.append(stamp)
         npts += pts.size
     ctx = slam.context()
@@ -85,7 +89,10 @@ def main():
     exchange = PoseExchange(world, device="cuda")
 
     def step(f):
-        slam.add_stored_frame(f, stamps[f], f)
+        if args.host_frames:
+            slam.add_frame(host_frames[f], stamps[f], f)
+        else:
+            slam.add_stored_frame(f, stamps[f], f)
         return exchange.post(slam.world_transform(), stamps[f] * 1e-6) if distributed else None
 
     # Warm-up frames carry HIP events around every scope: that gives the per-kernel table and names the dominant
@@ -159,7 +166,7 @@ def main():
                 "points_per_frame": npts // total,
                 "sequences": world,
                 "parallelism": f"1 sequence per GPU x {world}, RCCL all-gather of poses",
-                "frames_resident_in_hbm": True,
+                "frames_resident_in_hbm": not args.host_frames,
             },
         }
         n = args.steps

@@ -216,6 +216,15 @@ int lsa_match(lsa_ctx* ctx, int slot, int type, int query_set, const lsa_match_p
 int lsa_match_types(lsa_ctx* ctx, int slot, unsigned type_mask, int query_set, const lsa_match_params_t* params, const double pose[16],
                     int* histograms);
 
+/* Confidence::LCPEstimator (slam_lib/src/ConfidenceEstimators.cxx:27-65) as Slam::EstimateOverlap calls it
+ * (Slam.cxx:1370-1388): every (1 / sampling_ratio)-th point of the current frame is registered into the
+ * world (H0, or the H0 -> H1 interpolation of lsa_transform_frame when interpolate != 0), its nearest
+ * neighbour is searched in the map-slot target of every type in type_mask that holds points, and the best
+ * Gaussian score exp(-d^2 / (2 (leaf / 3)^2)) is averaged.  *overlap = -1 when nothing can be estimated.
+ * The reference sums in float under an OpenMP reduction, i.e. in no defined order; agreement is to rounding. */
+int lsa_overlap(lsa_ctx* ctx, unsigned type_mask, int interpolate, const double H0[16], const double H1[16], double t0, double t1, float sampling_ratio,
+                const double leaf_size[3], float* overlap);
+
 /* MatchingResults::Rejections / Weights of the last lsa_match of `type`
  * (exported by Slam::GetDebugArray, Slam.cxx:635-657).  records (optional,
  * may be NULL) receives 16 doubles per keypoint: A[9] row-major, P[3], X[3],

@@ -50,7 +50,7 @@ ABI_SYMBOLS = [
     "lsa_set_azimuthal_resolution", "lsa_extract_keypoints", "lsa_download_keypoints", "lsa_keypoint_count",
     "lsa_download_debug", "lsa_nb_laser_rings", "lsa_transform_keypoints", "lsa_set_target", "lsa_set_target_from_set", "lsa_target_staging", "lsa_set_target_staged",
     "lsa_target_size", "lsa_set_target_cell_size", "lsa_set_knn_lanes", "lsa_set_knn_rounds", "lsa_match_slow_queries", "lsa_match_exhaustive_queries", "lsa_set_keypoints", "lsa_match", "lsa_match_types",
-    "lsa_download_match", "lsa_accumulate", "lsa_solve", "lsa_registration_error", "lsa_selftest_math", "lsa_reset_working_keypoints", "lsa_undistort", "lsa_working_time_range",
+    "lsa_download_match", "lsa_overlap", "lsa_accumulate", "lsa_solve", "lsa_registration_error", "lsa_selftest_math", "lsa_reset_working_keypoints", "lsa_undistort", "lsa_working_time_range",
     "lsa_working_bbox", "lsa_working_bboxes", "lsa_keypoint_bboxes_begin", "lsa_keypoint_bboxes_end", "lsa_download_transformed", "lsa_stage_transformed", "lsa_staged_transformed", "lsa_transform_frame", "lsa_profile_enable", "lsa_profile_select", "lsa_profile_reset",
     "lsa_profile_get", "lsa_slam_create", "lsa_slam_destroy", "lsa_slam_last_error", "lsa_slam_set_param",
     "lsa_slam_get_param", "lsa_slam_reset", "lsa_slam_add_frame", "lsa_slam_store_frame", "lsa_slam_add_stored_frame",
@@ -102,6 +102,7 @@ def lib():
     L.lsa_set_keypoints.argtypes = [vp, i32, i32, vp, i32]
     L.lsa_match.argtypes = [vp, i32, i32, i32, C.POINTER(MatchParams), vp, vp]
     L.lsa_set_knn_lanes.argtypes = [vp, i32, i32]
+    L.lsa_overlap.argtypes = [vp, C.c_uint, i32, vp, vp, C.c_double, C.c_double, C.c_float, vp, vp]
     L.lsa_match_types.argtypes = [vp, i32, C.c_uint, i32, C.POINTER(MatchParams), vp, vp]
     L.lsa_download_match.argtypes = [vp, i32, vp, vp, vp, i32]
     L.lsa_accumulate.argtypes = [vp, C.c_uint, vp, i32, vp, vp, vp, vp]
@@ -249,6 +250,14 @@ class Context:
         self._check(self.L.lsa_match_types(self.h, slot, type_mask, query_set, C.byref(params), ptr(pose16(pose)),
                                            ptr(hist) if histograms else None), "lsa_match_types")
         return hist
+
+    def overlap(self, type_mask, ratio, leaves, H0, H1=None, t0=0.0, t1=0.0):
+        """lsa_overlap: LCP overlap estimate of the current frame against the map-slot targets."""
+        out = C.c_float(-1.0)
+        lf = (C.c_double * 3)(*[float(x) for x in leaves])
+        self._check(self.L.lsa_overlap(self.h, type_mask, int(H1 is not None), ptr(pose16(H0)), ptr(pose16(H1)) if H1 is not None else None,
+                                       C.c_double(t0), C.c_double(t1), C.c_float(ratio), lf, C.byref(out)), "lsa_overlap")
+        return float(out.value)
 
     def match_results(self, ktype, query_set=None, records=True):
         n = self.L.lsa_keypoint_count(self.h, SET_WORKING if query_set is None else query_set, ktype)

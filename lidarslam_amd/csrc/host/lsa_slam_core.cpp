@@ -191,6 +191,12 @@ int SlamCore::ProcessCurrentFrame(uint64_t stampUs)
   if (rc < 0) return rc;
   rc = Localization();
   if (rc < 0) return rc;
+  // confidence estimators: before the maps update, which invalidates the sub-maps (Slam.cxx:269-280)
+  if (OverlapSamplingRatio > 0)
+  {
+    rc = EstimateOverlap();
+    if (rc < 0) return rc;
+  }
   if (MapUpdate == MappingMode::ADD_KPTS_TO_FIXED_MAP || MapUpdate == MappingMode::UPDATE)
   {
     Tick t;
@@ -511,6 +517,30 @@ int SlamCore::FinishSubMapSpeculation()
   return LSA_OK;
 }
 
+// Slam::EstimateOverlap (Slam.cxx:1370-1388): Confidence::LCPEstimator on the registered frame
+int SlamCore::EstimateOverlap()
+{
+  unsigned mask = 0;
+  double leaf[3];
+  for (int k = 0; k < 3; ++k)
+  {
+    leaf[k] = LocalMaps[k]->GetLeafSize();
+    if (UseKeypoints[k] && LocalMaps[k]->IsSubMapValid()) mask |= 1u << k;
+  }
+  if (Undistortion)
+  {
+    const Pose H0 = (Tworld * Motion.GetH0()) * BaseToLidarOffset;
+    const Pose H1 = (Tworld * Motion.GetH1()) * BaseToLidarOffset;
+    LSA_TRY(lsa_overlap(Ctx, mask, 1, H0.m, H1.m, Motion.Time0, Motion.Time1, OverlapSamplingRatio, leaf, &OverlapEstimation));
+  }
+  else
+  {
+    const Pose tf = Tworld * BaseToLidarOffset;
+    LSA_TRY(lsa_overlap(Ctx, mask, 0, tf.m, nullptr, 0., 0., OverlapSamplingRatio, leaf, &OverlapEstimation));
+  }
+  return LSA_OK;
+}
+
 // Slam::UpdateMapsUsingTworld (Slam.cxx:1178-1222)
 int SlamCore::UpdateMapsUsingTworld()
 {
@@ -704,6 +734,13 @@ int SlamCore::SetParam(const std::string& name, double v)
   if (name == "EgoMotion") { EgoMotion = static_cast<EgoMotionMode>(static_cast<int>(v)); return LSA_OK; }
   if (name == "Undistortion") { Undistortion = static_cast<UndistortionMode>(static_cast<int>(v)); return LSA_OK; }
   if (name == "MapUpdate") { MapUpdate = static_cast<MappingMode>(static_cast<int>(v)); return LSA_OK; }
+  if (name == "OverlapSamplingRatio")
+  {
+    // Slam::SetOverlapSamplingRatio (Slam.cxx:1359-1367)
+    OverlapSamplingRatio = std::min(std::max(static_cast<float>(v), 0.f), 1.f);
+    if (OverlapSamplingRatio == 0.f) OverlapEstimation = -1.f;
+    return LSA_OK;
+  }
   if (name == "AzimuthalResolution") { if (Ctx) lsa_set_azimuthal_resolution(Ctx, static_cast<float>(v)); return LSA_OK; }
   if (name == "VoxelGridLeafSizeEdges") { LocalMaps[LSA_EDGE]->SetLeafSize(v); return LSA_OK; }
   if (name == "VoxelGridLeafSizePlanes") { LocalMaps[LSA_PLANE]->SetLeafSize(v); return LSA_OK; }
@@ -734,6 +771,8 @@ int SlamCore::GetParam(const std::string& name, double* v) const
   if (name == "VoxelGridResolution") { *v = LocalMaps[0]->GetVoxelResolution(); return LSA_OK; }
   if (name == "NbrFrameProcessed") { *v = NbrFrameProcessed; return LSA_OK; }
   if (name == "TotalMatchedKeypoints") { *v = TotalMatchedKeypoints; return LSA_OK; }
+  if (name == "OverlapSamplingRatio") { *v = OverlapSamplingRatio; return LSA_OK; }
+  if (name == "OverlapEstimation") { *v = OverlapEstimation; return LSA_OK; }
   if (name == "SubMapSpeculationHits") { *v = SubMapSpecHitsTotal; return LSA_OK; }
   return LSA_E_ARG;
 }

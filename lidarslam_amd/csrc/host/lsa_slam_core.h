@@ -125,6 +125,10 @@ public:
   unsigned MinNbMatchedKeypoints = 20;
   double KfDistanceThreshold = 0.5, KfAngleThreshold = 5.;
   MappingMode MapUpdate = MappingMode::UPDATE;
+  // Confidence estimator: share of the frame's points with a map point nearby (Slam::SetOverlapSamplingRatio,
+  // GetOverlapEstimation; 0 = off, the library default; the ROS configuration uses 0.33)
+  float OverlapSamplingRatio = 0.f;
+  float OverlapEstimation = -1.f;
   Pose BaseToLidarOffset = Pose::Identity();
   lsa_extract_params_t ExtractParams;
   // edge length of the finest kNN search-grid cells (an implementation knob: results do not depend on it)
@@ -156,6 +160,7 @@ private:
   int ComputeEgoMotion();
   int Localization();
   int UpdateMapsUsingTworld();
+  int EstimateOverlap();
   void LogCurrentFrameState(double time);
   Pose InterpolateScanPose(double time) const;
   int InitUndistortion();

@@ -30,6 +30,11 @@
 
 using namespace lsa;
 
+namespace lsa
+{
+InterpConst make_interp_const(const double H0[16], const double H1[16], double t0, double t1);  // lsa_transform.hip
+}
+
 namespace
 {
 
@@ -1146,6 +1151,53 @@ __global__ void k_records_to_aos(const double* __restrict__ rec, const uint8_t* 
   weights[i] = ok ? rec[(size_t)15 * cap + i] : 0.;
 }
 
+// ---- Confidence::LCPEstimator (slam_lib/src/ConfidenceEstimators.cxx:27-65, Slam::EstimateOverlap Slam.cxx:1370-1388) ----
+__device__ __forceinline__ double point_time(const float4& b) { return __hiloint2double(__float_as_int(b.y), __float_as_int(b.x)); }
+// sampled points of the frame, registered into the world (undistorted when asked), as kNN queries
+__global__ __launch_bounds__(256) void k_overlap_queries(const float4* __restrict__ frame, int nb, float ratio, int interpolate, InterpConst c, Rigid R,
+                                                         float4* __restrict__ out)
+{
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= nb) return;
+  const size_t src = (size_t)((float)n / ratio);  // cloud->at(n / subsamplingRatio)
+  float4 a = frame[2 * src];
+  const float4 b = frame[2 * src + 1];
+  Rigid T = R;
+  if (interpolate) interp_eval(c, point_time(b), T);
+  double ox, oy, oz;
+  rigid_apply(T, (double)a.x, (double)a.y, (double)a.z, ox, oy, oz);
+  a.x = (float)ox; a.y = (float)oy; a.z = (float)oz;
+  out[2 * (size_t)n] = a;
+  out[2 * (size_t)n + 1] = b;
+}
+// best Gaussian score over the maps per point, summed: block partials in a fixed order
+struct OverlapConst
+{
+  const float* d2[3];   // nearest squared distance per sampled point (slot 0 of the kNN output), nullptr = map not used
+  float inv2sq[3];      // 1 / (2 (leaf / 3)^2)
+};
+__global__ __launch_bounds__(256) void k_overlap_score(OverlapConst c, int nb, float* __restrict__ partials)
+{
+  __shared__ float ws[4];
+  float acc = 0.f;
+  for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < nb; n += gridDim.x * blockDim.x)
+  {
+    float best = 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+      if (c.d2[k])
+      {
+        const float p = expf(-c.d2[k][n] * c.inv2sq[k]);
+        best = p > best ? p : best;
+      }
+    acc += best;
+  }
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
+  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) partials[blockIdx.x] = ((ws[0] + ws[1]) + ws[2]) + ws[3];
+}
+
 // builds the search grids of every target marked dirty, all in one sequence of launches
 int flush_grids(lsa_ctx* ctx)
 {
@@ -1479,6 +1531,72 @@ int lsa_match_types(lsa_ctx* ctx, int slot, unsigned type_mask, int query_set, c
     for (int i = 0; i < nt; ++i)
       for (int s = 0; s < LSA_MATCH_NSTATUS; ++s) histograms[types[i] * LSA_MATCH_NSTATUS + s] = hp[types[i] * 16 + s];
   }
+  return LSA_OK;
+}
+
+int lsa_overlap(lsa_ctx* ctx, unsigned type_mask, int interpolate, const double H0[16], const double H1[16], double t0, double t1, float sampling_ratio,
+                const double leaf_size[3], float* overlap)
+{
+  if (!ctx || !H0 || (interpolate && !H1) || !leaf_size || !overlap || (type_mask & ~7u))
+    return ctx ? ctx->fail(LSA_E_ARG, "lsa_overlap: bad argument") : LSA_E_ARG;
+  if (!ctx->frame || ctx->frame_n <= 0) return ctx->fail(LSA_E_STATE, "lsa_overlap: no frame");
+  LSA_HIP(ctx, hipSetDevice(ctx->device));
+  *overlap = -1.f;
+  const int nb = (int)(ctx->frame_n * sampling_ratio);  // size_t * float -> float -> int (ConfidenceEstimators.cxx:33)
+  unsigned used = 0;
+  for (int k = 0; k < 3; ++k)
+    if (((type_mask >> k) & 1u) && ctx->target[LSA_TARGET_MAP * 3 + k].m > 0) used |= 1u << k;
+  if (nb <= 0 || used == 0) return LSA_OK;
+  if (nb > ctx->frame_n) return ctx->fail(LSA_E_ARG, "lsa_overlap: sampling ratio above 1");
+  int rc = ensure_scratch(ctx, (size_t)nb * sizeof(lsa_point_t) + 1024 * sizeof(float));
+  if (rc) return rc;
+  for (int k = 0; k < 3; ++k)
+    if ((used >> k) & 1u)
+    {
+      MatchBuf& mb = ctx->match[k];
+      const int cap0 = mb.cap;
+      rc = ensure_match(ctx, k, nb);
+      if (rc) return rc;
+      if (mb.cap != cap0) mb.valid = false;  // the records moved with the buffers
+    }
+  rc = flush_grids(ctx);
+  if (rc) return rc;
+  hipStream_t st = ctx->stream;
+  float4* q4 = reinterpret_cast<float4*>(ctx->scratch_out);
+  float* partials = reinterpret_cast<float*>(reinterpret_cast<char*>(ctx->scratch_out) + (size_t)nb * sizeof(lsa_point_t));
+  Rigid T;
+  row_major_to_rt(H0, T.R, T.t);
+  InterpConst ic{};
+  if (interpolate) ic = make_interp_const(H0, H1, t0, t1);
+  Rigid ident;
+  for (int i = 0; i < 9; ++i) ident.R[i] = (i % 4 == 0) ? 1. : 0.;
+  ident.t[0] = ident.t[1] = ident.t[2] = 0.;
+  OverlapConst oc;
+  {
+    ProfScope ps(ctx, "overlap_lcp", (double)nb * (32 + 3 * (32 + 24) + 12));
+    hipLaunchKernelGGL(k_overlap_queries, dim3((nb + 255) / 256), dim3(256), 0, st, reinterpret_cast<const float4*>(ctx->frame), nb, sampling_ratio,
+                       interpolate, ic, T, q4);
+    for (int k = 0; k < 3; ++k)
+    {
+      oc.d2[k] = nullptr;
+      oc.inv2sq[k] = 0.f;
+      if (!((used >> k) & 1u)) continue;
+      int* hist = ctx->hist_dev + k * 16;
+      LSA_HIP(ctx, hipMemsetAsync(hist, 0, 16 * sizeof(int), st));
+      // nearest neighbour = the k = 1 case of the exact search (identity pose: the queries are world points already)
+      launch_knn<5>(ctx, reinterpret_cast<const lsa_point_t*>(q4), nb, ident, 1, INFINITY, k, LSA_TARGET_MAP * 3 + k, st, hist);
+      oc.d2[k] = ctx->match[k].knn_d2;
+      const float sq = (float)std::pow(leaf_size[k] / 3.f, 2);  // std::pow(GetLeafSize() / 3.f, 2) (:55)
+      oc.inv2sq[k] = 1.f / (2.f * sq);
+    }
+    hipLaunchKernelGGL(k_overlap_score, dim3(256), dim3(256), 0, st, oc, nb, partials);
+  }
+  float* hp = reinterpret_cast<float*>(ctx->host_pinned + 192);
+  LSA_HIP(ctx, hipMemcpyAsync(hp, partials, 256 * sizeof(float), hipMemcpyDeviceToHost, st));
+  LSA_HIP(ctx, hipStreamSynchronize(st));
+  float lcp = 0.f;
+  for (int b = 0; b < 256; ++b) lcp += hp[b];
+  *overlap = lcp / nb;
   return LSA_OK;
 }
 

@@ -295,6 +295,8 @@ InterpConst make_interp(const double H0[16], const double H1[16], double t0, dou
 
 namespace lsa
 {
+InterpConst make_interp_const(const double H0[16], const double H1[16], double t0, double t1) { return make_interp(H0, H1, t0, t1); }
+
 // time range of a keypoint set into range_bits[0..1]; counts_dev: device counts (extraction, host counts not known yet) or nullptr
 int enqueue_time_range(lsa_ctx* ctx, int set, const int* counts_dev)
 {

@@ -189,6 +189,10 @@ public:
   }
   unsigned int GetNbrFrameProcessed() const { return static_cast<unsigned int>(this->GetParam("NbrFrameProcessed")); }
   int GetTotalMatchedKeypoints() const { return static_cast<int>(this->GetParam("TotalMatchedKeypoints")); }
+  // Confidence estimator (Slam.h: GetOverlapSamplingRatio / SetOverlapSamplingRatio / GetOverlapEstimation)
+  float GetOverlapSamplingRatio() const { return static_cast<float>(this->GetParam("OverlapSamplingRatio")); }
+  void SetOverlapSamplingRatio(float ratio) { this->SetParam("OverlapSamplingRatio", ratio); }
+  float GetOverlapEstimation() const { return static_cast<float>(this->GetParam("OverlapEstimation")); }
   double GetLatency() const
   {
     double s[16];

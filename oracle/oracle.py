@@ -198,6 +198,19 @@ def transform(pts, T):
     return out
 
 
+def lcp(cloud, ratio, targets, leaves):
+    """Confidence::LCPEstimator on a registered cloud; targets / leaves: per keypoint type (None = map not used)."""
+    cloud = np.ascontiguousarray(cloud)
+    tg = [np.ascontiguousarray(t) if t is not None else None for t in targets]
+    arr = (C.c_void_p * 3)(*[t.ctypes.data if t is not None and t.size else None for t in tg])
+    m = (C.c_int * 3)(*[int(t.size) if t is not None else 0 for t in tg])
+    lf = (C.c_double * 3)(*[float(x) for x in leaves])
+    f = lib().orc_lcp
+    f.restype = C.c_float
+    f.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
+    return float(f(ptr(cloud), cloud.size, ratio, arr, m, lf))
+
+
 class Slam:
     """Mirror of the product's lidarslam_amd.Slam for the oracle."""
 
@@ -205,6 +218,12 @@ class Slam:
         self.h = lib().orc_slam_create()
         for k, v in params.items():
             self.set_param(k, v)
+
+    def overlap(self):
+        f = lib().orc_slam_get_overlap
+        f.restype = C.c_float
+        f.argtypes = [C.c_void_p]
+        return float(f(self.h))
 
     def __del__(self):
         if getattr(self, "h", None):

@@ -259,6 +259,48 @@ int orc_transform(lsa_point_t* pts, int n, const double T[16])
   return 0;
 }
 
+// Confidence::LCPEstimator (slam_lib/src/ConfidenceEstimators.cxx:27-65) on an already registered cloud:
+// every (1 / ratio)-th point, 1-NN into each non-empty target, best Gaussian score with sigma = leaf / 3,
+// mean over the sampled points.  The reference sums in float under an OpenMP reduction (order not defined);
+// here sequentially.  Returns -1 like the reference when nothing can be estimated.
+float orc_lcp(const lsa_point_t* cloud, int n, float ratio, const lsa_point_t* const tgt[3], const int m[3], const double leaf[3])
+{
+  const int nbPoints = (int)(n * ratio);  // size_t * float -> float -> int (:33)
+  bool any = false;
+  KDTree tree[3];
+  std::vector<Point> clouds[3];
+  for (int k = 0; k < 3; ++k)
+    if (tgt[k] && m[k] > 0)
+    {
+      clouds[k].assign((const Point*)tgt[k], (const Point*)tgt[k] + m[k]);
+      tree[k].Reset(&clouds[k]);
+      any = true;
+    }
+  if (nbPoints == 0 || !any) return -1.f;
+  const Point* c = (const Point*)cloud;
+  float lcp = 0.f;
+  for (int i = 0; i < nbPoints; ++i)
+  {
+    const Point& point = c[(size_t)(i / ratio)];  // cloud->at(n / subsamplingRatio) (:43)
+    float bestProba = 0.f;
+    for (int k = 0; k < 3; ++k)
+    {
+      if (clouds[k].empty()) continue;
+      int nnIndex[2];
+      float nnSqDist[2];
+      const float q[3] = {point.x, point.y, point.z};
+      if (tree[k].KnnSearch(q, 1, nnIndex, nnSqDist))
+      {
+        const float sqLCPThreshold = (float)std::pow(leaf[k] / 3.f, 2);                 // (:55)
+        const float currentProba = std::exp(-nnSqDist[0] / (2.f * sqLCPThreshold));     // float exp (:56)
+        if (currentProba > bestProba) bestProba = currentProba;
+      }
+    }
+    lcp += bestProba;
+  }
+  return lcp / nbPoints;
+}
+
 // ---- full pipeline ---------------------------------------------------------------------
 void* orc_slam_create() { return new SlamHandle; }
 void orc_slam_destroy(void* h) { delete (SlamHandle*)h; }
@@ -301,6 +343,7 @@ int orc_slam_set_param(void* h, const char* name, double v)
   P("KfDistanceThreshold", s.KfDistanceThreshold = v)
   P("KfAngleThreshold", s.KfAngleThreshold = v)
   P("MapUpdate", s.MapUpdate = (MappingMode)(int)v)
+  P("OverlapSamplingRatio", s.OverlapSamplingRatio = std::min(std::max((float)v, 0.f), 1.f); if (s.OverlapSamplingRatio == 0.f) s.OverlapEstimation = -1.f)
   P("VoxelGridLeafSizeEdges", s.LocalMaps[EDGE]->SetLeafSize(v))
   P("VoxelGridLeafSizePlanes", s.LocalMaps[PLANE]->SetLeafSize(v))
   P("VoxelGridLeafSizeBlobs", s.LocalMaps[BLOB]->SetLeafSize(v))
@@ -337,6 +380,7 @@ int orc_slam_get_world_transform(void* h, double T[16], double* time)
   if (time) *time = s.LogTrajectory.empty() ? 0. : s.LogTrajectory.back().time;
   return 0;
 }
+float orc_slam_get_overlap(void* h) { return ((SlamHandle*)h)->s.OverlapEstimation; }
 int orc_slam_get_covariance(void* h, double cov[36])
 {
   std::memcpy(cov, ((SlamHandle*)h)->s.GetTransformCovariance(), 36 * sizeof(double));

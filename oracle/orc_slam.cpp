@@ -79,6 +79,8 @@ void Slam::AddFrame(const std::vector<Point>& frame, uint64_t stampUs, unsigned)
   { Tick t; ExtractKeypoints(); Times.extract = t.Stop(); }
   ComputeEgoMotion();
   Localization();
+  // confidence estimators: before the maps update, which resets the kd-trees (Slam.cxx:269-280)
+  if (OverlapSamplingRatio > 0) EstimateOverlap();
   if (MapUpdate == MappingMode::ADD_KPTS_TO_FIXED_MAP || MapUpdate == MappingMode::UPDATE)
   {
     Tick t;
@@ -382,6 +384,39 @@ void Slam::RefineUndistortion()
       transform_point(p, interp(p.time));
     }
   }
+}
+
+// Slam::EstimateOverlap (Slam.cxx:1370-1388) + Confidence::LCPEstimator (ConfidenceEstimators.cxx:27-65)
+void Slam::EstimateOverlap()
+{
+  const std::vector<Point> cloud = GetRegisteredFrame();
+  const float ratio = OverlapSamplingRatio;
+  const int nbPoints = (int)(cloud.size() * ratio);
+  bool any = false;
+  for (int k = 0; k < 3; ++k) any = any || (UseKeypoints[k] && LocalMaps[k]->IsSubMapKdTreeValid());
+  if (nbPoints == 0 || !any) { OverlapEstimation = -1.f; return; }
+  float lcp = 0.f;
+  // the reference reduces with OpenMP (summation order not defined); sequential here
+  for (int n = 0; n < nbPoints; ++n)
+  {
+    const Point& point = cloud[(size_t)(n / ratio)];
+    float bestProba = 0.f;
+    for (int k = 0; k < 3; ++k)
+    {
+      if (!(UseKeypoints[k] && LocalMaps[k]->IsSubMapKdTreeValid())) continue;
+      int nnIndex[2];
+      float nnSqDist[2];
+      const float q[3] = {point.x, point.y, point.z};
+      if (LocalMaps[k]->GetSubMapKdTree().KnnSearch(q, 1, nnIndex, nnSqDist))
+      {
+        const float sqLCPThreshold = (float)std::pow(LocalMaps[k]->GetLeafSize() / 3.f, 2);
+        const float currentProba = std::exp(-nnSqDist[0] / (2.f * sqLCPThreshold));
+        if (currentProba > bestProba) bestProba = currentProba;
+      }
+    }
+    lcp += bestProba;
+  }
+  OverlapEstimation = lcp / nbPoints;
 }
 
 // Slam.cxx:660-667 + 1512-1578 with worldCoordinates == true

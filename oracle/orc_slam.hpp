@@ -86,7 +86,12 @@ public:
 
   std::vector<Point> GetRegisteredFrame();
 
+  // Confidence estimator (Slam.h OverlapSamplingRatio / GetOverlapEstimation; Slam.cxx:1359-1388)
+  float OverlapSamplingRatio = 0.f;
+  float OverlapEstimation = -1.f;
+
 private:
+  void EstimateOverlap();
   bool CheckFrame(const std::vector<Point>& frame, uint64_t stampUs);
   void ExtractKeypoints();
   void ComputeEgoMotion();

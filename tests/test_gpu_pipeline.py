@@ -221,3 +221,44 @@ def test_stored_frames_equal_uploaded_frames(L):
         assert np.array_equal(a.world_transform(), b.world_transform())
     a.close()
     b.close()
+
+
+# ---------------------------------------------------------------------------------------- SURVEY.md 8f-3
+def test_overlap_estimator_follows_the_oracle(gpu_ctx, O, L, scan):
+    """Confidence::LCPEstimator (ConfidenceEstimators.cxx:27-65): nearest map point of every third frame point,
+    best Gaussian score, mean.  The reference sums in float in no defined order: agreement to rounding."""
+    ex = O.Extractor()
+    ex.compute(scan)
+    maps = [ex.keypoints(k) for k in range(3)]  # stand-ins for the three sub-maps
+    gpu_ctx.upload_frame(scan)
+    leaves = (0.3, 0.6, 0.3)
+    H0, H1 = se3(0.05, 0.01, 0.0, 0.0, 0.001, 0.002), se3(0.3, 0.02, 0.0, 0.0, 0.002, 0.01)
+    for k in range(3):
+        gpu_ctx.set_target(k, maps[k], cell=1.0)
+    # rigid and interpolated registration, all maps and a subset
+    for mask, h1 in ((7, None), (3, H1), (2, H1)):
+        tg = [maps[k] if (mask >> k) & 1 else None for k in range(3)]
+        reg = O.transform(scan, H0) if h1 is None else O.undistort(scan, H0, h1, -0.1, 0.0)
+        want = O.lcp(reg, 0.33, tg, leaves)
+        got = gpu_ctx.overlap(mask, 0.33, leaves, H0, h1, -0.1, 0.0)
+        assert 0.0 < want <= 1.0 and abs(got - want) <= 2e-5 * want, (mask, got, want)
+    # nothing to estimate: no map, or no sampled point
+    for k in range(3):
+        gpu_ctx.set_target(k, maps[k][:0])
+    assert gpu_ctx.overlap(7, 0.33, leaves, H0) == -1.0 == O.lcp(O.transform(scan, H0), 0.33, [None] * 3, leaves)
+    gpu_ctx.set_target(1, maps[1])
+    assert gpu_ctx.overlap(7, 1e-9, leaves, H0) == -1.0
+
+
+def test_pipeline_overlap_estimation(L, O):
+    """Slam::EstimateOverlap (Slam.cxx:1370-1388) inside AddFrame, with the ROS configuration's sampling ratio"""
+    sg, so = L.Slam(0, EgoMotion=3, OverlapSamplingRatio=0.33), O.Slam(EgoMotion=3, OverlapSamplingRatio=0.33)
+    seen = []
+    for f in range(5):
+        pts, stamp = L.synth_frame(16, 1000, f)
+        sg.add_frame(pts, stamp, f)
+        so.add_frame(pts, stamp, f)
+        got, want = sg.get_param("OverlapEstimation"), so.overlap()
+        assert (want == -1.0 and got == -1.0) or abs(got - want) <= 2e-5 * abs(want), (f, got, want)
+        seen.append(want)
+    assert seen[0] == -1.0 and all(0.3 < v <= 1.0 for v in seen[1:])  # no map before the first frame, then mostly overlapping

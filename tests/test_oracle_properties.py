@@ -224,3 +224,22 @@ def test_frame_checks(O, L):
     assert np.array_equal(T0, s.world_transform())
     s.add_frame(pts[:0], stamp + 100000, 2)  # empty frame: ignored
     assert np.array_equal(T0, s.world_transform())
+
+
+def test_lcp_estimator_properties(O, L):
+    """Confidence::LCPEstimator (ConfidenceEstimators.cxx:27-65): 1 for a cloud lying on its map, ~0 far away,
+    the best map wins, -1 when there is nothing to estimate."""
+    pts, _ = L.synth_frame(8, 1000, 0)
+    cloud = pts[:3000]
+    far = cloud.copy()
+    far["z"] += 500.0
+    leaves = (0.3, 0.6, 0.3)
+    assert O.lcp(cloud, 0.5, [cloud, None, None], leaves) == 1.0
+    assert O.lcp(cloud, 0.5, [far, None, None], leaves) < 1e-6
+    assert O.lcp(cloud, 0.5, [far, cloud, None], leaves) == 1.0  # best probability over the maps
+    shifted = cloud.copy()
+    shifted["z"] += 0.1  # one sigma of the 0.3 m leaf: exp(-0.5) at most, less where another point is nearer
+    v = O.lcp(shifted, 1.0, [cloud, None, None], leaves)
+    assert np.exp(-0.5) - 1e-6 <= v < 1.0
+    assert O.lcp(cloud, 0.5, [None, None, None], leaves) == -1.0
+    assert O.lcp(cloud[:1], 0.5, [cloud, None, None], leaves) == -1.0  # int(1 * 0.5) == 0 sampled points

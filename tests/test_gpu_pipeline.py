@@ -142,6 +142,27 @@ def test_pipeline_modes(L, O, params):
     sg.close()
 
 
+@pytest.mark.parametrize(
+    "params",
+    [
+        dict(),                                                             # every frame a keyframe after the ramp-up
+        dict(KfDistanceThreshold=1.2),                                      # sub-maps reused between keyframes
+        dict(VoxelGridDecayingThreshold=0.45, VoxelGridMinFramesPerVoxel=2),  # ClearOldPoints + filtered sub-maps
+        dict(VoxelGridSamplingMode=1), dict(VoxelGridSamplingMode=3), dict(VoxelGridSamplingMode=4),  # LAST, CENTER_POINT, CENTROID
+        dict(MapUpdate=0),                                                  # no map: localization has nothing to match
+    ],
+)
+def test_map_maintenance_beside_the_device_work(L, O, params):
+    """30 frames: the keyframe insertions run on worker threads beside the next frame, the sub-maps are extracted
+    ahead of time under the predicted pose -- the trajectory must not know (same maps, same sub-map order)."""
+    sg, so, poses, _ = run_both(L, O, 8, 30, check_keypoints=False, **params)
+    if params.get("MapUpdate", 2) != 0:
+        assert sg.get_param("SubMapSpeculationHits") > 0
+    step = np.linalg.norm(poses[-1][:3, 3] - poses[10][:3, 3])
+    assert step > 5.0 or params.get("MapUpdate", 2) == 0  # it moved: 5 m/s for 2 s
+    sg.close()
+
+
 def test_pipeline_matches_golden_poses(L, golden):
     s = L.Slam(0, EgoMotion=3)
     for f in range(4):

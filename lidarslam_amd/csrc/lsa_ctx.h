@@ -31,6 +31,7 @@ __host__ __device__ constexpr int grid_level_cells(int level) { return level == 
 constexpr int kKnnMax = 16;               // neighbours per query the kNN buffers hold
 constexpr int kAccumBlocks = 64;          // grid of the normal-equation kernel (grid-stride); the host folds the blocks' partial sums
 constexpr int kMailboxStride = 40;        // doubles per block in the mailbox: ten 32-byte pieces of 3 partial sums + the sequence tag
+constexpr int kHistRing = 32;
 constexpr int kAccumVals = 29;            // cost, g[6], H upper[21], nvalid
 
 struct GridDesc
@@ -148,7 +149,10 @@ struct lsa_ctx
   double* host_pinned = nullptr;  // >= 64 doubles, pinned
   double* mailbox = nullptr;      // coherent host memory k_accumulate's blocks write directly: [kAccumBlocks][kMailboxStride]
   unsigned long long mailbox_seq = 0;
-  int* hist_dev = nullptr;        // per match type 16 ints: [8] rejection histogram + 2 hand-over counters of the kNN cascade
+  // per match type a ring of kHistRing blocks of 16 ints ([8] rejection histogram + 2 hand-over counters of the kNN
+  // cascade): every match takes the next block, the ring is zeroed once per turn instead of one memset per match
+  int* hist_dev = nullptr;
+  int hist_pos[3] = {0, 0, 0};    // block of the last match per type
   int last_match_type = 0;
   // lanes cooperating on one query in the first kNN kernel, per keypoint type (8, 16 or 32)
   int knn_lanes[3] = {16, 8, 8};

@@ -90,7 +90,7 @@ int ensure_match(lsa_ctx* ctx, int type, int k)
   LSA_HIP(ctx, dev_alloc(&b.knn_idx, (size_t)cap * kKnnMax));
   LSA_HIP(ctx, dev_alloc(&b.knn_d2, (size_t)cap * kKnnMax));
   LSA_HIP(ctx, dev_alloc(&b.knn_cnt, (size_t)cap));
-  LSA_HIP(ctx, dev_alloc(&b.slow_list, (size_t)cap * 2));
+  LSA_HIP(ctx, dev_alloc(&b.slow_list, (size_t)cap));
   LSA_HIP(ctx, dev_alloc(&b.slow_pts, (size_t)cap));
   b.cap = cap;
   return LSA_OK;
@@ -241,7 +241,8 @@ int lsa_ctx_create(int device_id, lsa_ctx** out)
   ok &= hipMalloc((void**)&ctx->partials, (size_t)kAccumBlocks * kAccumVals * sizeof(double)) == hipSuccess;
   ok &= hipMalloc((void**)&ctx->reduce_out, 64 * sizeof(double)) == hipSuccess;
   if (ok) ok &= hipMemset(ctx->reduce_out, 0, 64 * sizeof(double)) == hipSuccess;  // [32] holds the arrival ticket of k_accumulate
-  ok &= hipMalloc((void**)&ctx->hist_dev, 3 * 16 * sizeof(int)) == hipSuccess;
+  ok &= hipMalloc((void**)&ctx->hist_dev, 3 * kHistRing * 16 * sizeof(int)) == hipSuccess;
+  if (ok) ok &= hipMemset(ctx->hist_dev, 0, 3 * kHistRing * 16 * sizeof(int)) == hipSuccess;
   ok &= hipMalloc((void**)&ctx->range_bits, 32 * sizeof(unsigned long long)) == hipSuccess;
   ok &= hipHostMalloc((void**)&ctx->host_pinned, 512 * sizeof(double), hipHostMallocDefault) == hipSuccess;
   if (hipHostMalloc((void**)&ctx->mailbox, (size_t)kAccumBlocks * kMailboxStride * sizeof(double), hipHostMallocCoherent | hipHostMallocMapped) == hipSuccess)

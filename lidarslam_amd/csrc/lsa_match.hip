@@ -1393,12 +1393,18 @@ static int match_enqueue(lsa_ctx* ctx, int slot, int type, int query_set, const 
 {
   const int nq = ctx->kp_n[query_set][type];
   MatchBuf& mb = ctx->match[type];
-  int* hist = ctx->hist_dev + type * 16;
+  // next block of the type's ring; a turn of the ring ends with one memset of it (everything that used it has
+  // finished: the streams were joined and the host has read the results of those matches since)
+  if (++ctx->hist_pos[type] >= kHistRing)
+  {
+    ctx->hist_pos[type] = 0;
+    LSA_HIP(ctx, hipMemsetAsync(ctx->hist_dev + (size_t)type * kHistRing * 16, 0, kHistRing * 16 * sizeof(int), st));
+  }
+  int* hist = ctx->hist_dev + ((size_t)type * kHistRing + ctx->hist_pos[type]) * 16;
   mb.k = nq;
   mb.sat = p->saturation_distance;
   mb.valid = true;
   ctx->last_match_type = type;
-  LSA_HIP(ctx, hipMemsetAsync(hist, 0, 16 * sizeof(int), st));
   if (nq == 0) return LSA_OK;
   const int ti = slot * 3 + type;
   Target& t = ctx->target[ti];
@@ -1526,7 +1532,9 @@ int lsa_match_types(lsa_ctx* ctx, int slot, unsigned type_mask, int query_set, c
   if (histograms)
   {
     int* hp = reinterpret_cast<int*>(ctx->host_pinned) + 32;
-    LSA_HIP(ctx, hipMemcpyAsync(hp, ctx->hist_dev, 3 * 16 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    for (int i = 0; i < nt; ++i)
+      LSA_HIP(ctx, hipMemcpyAsync(hp + types[i] * 16, ctx->hist_dev + ((size_t)types[i] * kHistRing + ctx->hist_pos[types[i]]) * 16, 16 * sizeof(int),
+                                  hipMemcpyDeviceToHost, ctx->stream));
     LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
     for (int i = 0; i < nt; ++i)
       for (int s = 0; s < LSA_MATCH_NSTATUS; ++s) histograms[types[i] * LSA_MATCH_NSTATUS + s] = hp[types[i] * 16 + s];
@@ -1581,8 +1589,12 @@ int lsa_overlap(lsa_ctx* ctx, unsigned type_mask, int interpolate, const double 
       oc.d2[k] = nullptr;
       oc.inv2sq[k] = 0.f;
       if (!((used >> k) & 1u)) continue;
-      int* hist = ctx->hist_dev + k * 16;
-      LSA_HIP(ctx, hipMemsetAsync(hist, 0, 16 * sizeof(int), st));
+      if (++ctx->hist_pos[k] >= kHistRing)
+      {
+        ctx->hist_pos[k] = 0;
+        LSA_HIP(ctx, hipMemsetAsync(ctx->hist_dev + (size_t)k * kHistRing * 16, 0, kHistRing * 16 * sizeof(int), st));
+      }
+      int* hist = ctx->hist_dev + ((size_t)k * kHistRing + ctx->hist_pos[k]) * 16;
       // nearest neighbour = the k = 1 case of the exact search (identity pose: the queries are world points already)
       launch_knn<5>(ctx, reinterpret_cast<const lsa_point_t*>(q4), nb, ident, 1, INFINITY, k, LSA_TARGET_MAP * 3 + k, st, hist);
       oc.d2[k] = ctx->match[k].knn_d2;
@@ -1625,7 +1637,7 @@ int lsa_match_slow_queries(lsa_ctx* ctx)
   if (!ctx) return LSA_E_ARG;
   int v = 0;
   if (hipStreamSynchronize(ctx->stream) != hipSuccess) return LSA_E_HIP;
-  if (hipMemcpy(&v, ctx->hist_dev + ctx->last_match_type * 16 + LSA_MATCH_NSTATUS, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return LSA_E_HIP;
+  if (hipMemcpy(&v, ctx->hist_dev + ((size_t)ctx->last_match_type * kHistRing + ctx->hist_pos[ctx->last_match_type]) * 16 + LSA_MATCH_NSTATUS, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return LSA_E_HIP;
   return v;
 }
 
@@ -1634,7 +1646,7 @@ int lsa_match_exhaustive_queries(lsa_ctx* ctx)
   if (!ctx) return LSA_E_ARG;
   int v = 0;
   if (hipStreamSynchronize(ctx->stream) != hipSuccess) return LSA_E_HIP;
-  if (hipMemcpy(&v, ctx->hist_dev + ctx->last_match_type * 16 + LSA_MATCH_NSTATUS + 1, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return LSA_E_HIP;
+  if (hipMemcpy(&v, ctx->hist_dev + ((size_t)ctx->last_match_type * kHistRing + ctx->hist_pos[ctx->last_match_type]) * 16 + LSA_MATCH_NSTATUS + 1, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return LSA_E_HIP;
   return v;
 }
 

@@ -16,10 +16,17 @@ namespace
 
 __device__ __forceinline__ double point_time(const float4& b) { return __hiloint2double(__float_as_int(b.y), __float_as_int(b.x)); }
 
-__global__ __launch_bounds__(256) void k_undistort(float4* __restrict__ pts, int n, InterpConst c)
+// in place, the three keypoint types in one launch (blockIdx.y = type)
+struct KpSetsRW
 {
+  float4* pts[3];
+  int n[3];
+};
+__global__ __launch_bounds__(256) void k_undistort(KpSetsRW s, InterpConst c)
+{
+  float4* __restrict__ pts = s.pts[blockIdx.y];
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+  if (i >= s.n[blockIdx.y]) return;
   float4 a = pts[2 * (size_t)i];
   const float4 b = pts[2 * (size_t)i + 1];
   Rigid T;
@@ -66,6 +73,15 @@ __global__ __launch_bounds__(256) void k_transform_stage(StageOut s, Rigid T)
   a.x = (float)ox; a.y = (float)oy; a.z = (float)oz;
   s.out[t][2 * (size_t)i] = a;
   s.out[t][2 * (size_t)i + 1] = b;
+}
+
+__global__ __launch_bounds__(256) void k_copy_sets(StageOut s)
+{
+  const int t = blockIdx.y;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= s.n[t]) return;
+  s.out[t][2 * (size_t)i] = s.in[t][2 * (size_t)i];
+  s.out[t][2 * (size_t)i + 1] = s.in[t][2 * (size_t)i + 1];
 }
 
 // monotone encoding of doubles for 64-bit atomicMin/Max
@@ -330,14 +346,18 @@ int lsa_reset_working_keypoints(lsa_ctx* ctx)
 {
   if (!ctx) return LSA_E_ARG;
   LSA_HIP(ctx, hipSetDevice(ctx->device));
+  StageOut so;
+  int nmax = 0;
   for (int k = 0; k < 3; ++k)
   {
     const int n = ctx->kp_n[LSA_SET_RAW_CURRENT][k];
     ctx->kp_n[LSA_SET_WORKING][k] = n;
-    if (n > 0)
-      LSA_HIP(ctx, hipMemcpyAsync(ctx->kp[LSA_SET_WORKING][k], ctx->kp[LSA_SET_RAW_CURRENT][k], (size_t)n * sizeof(lsa_point_t),
-                                  hipMemcpyDeviceToDevice, ctx->stream));
+    so.in[k] = reinterpret_cast<const float4*>(ctx->kp[LSA_SET_RAW_CURRENT][k]);
+    so.out[k] = reinterpret_cast<float4*>(ctx->kp[LSA_SET_WORKING][k]);
+    so.n[k] = n;
+    nmax = std::max(nmax, n);
   }
+  if (nmax > 0) hipLaunchKernelGGL(k_copy_sets, dim3((nmax + 255) / 256, 3), dim3(256), 0, ctx->stream, so);  // one launch instead of three copies
   ctx->kp_time_valid[LSA_SET_WORKING] = ctx->kp_time_valid[LSA_SET_RAW_CURRENT];
   ctx->kp_time[LSA_SET_WORKING][0] = ctx->kp_time[LSA_SET_RAW_CURRENT][0];
   ctx->kp_time[LSA_SET_WORKING][1] = ctx->kp_time[LSA_SET_RAW_CURRENT][1];
@@ -349,13 +369,18 @@ int lsa_undistort(lsa_ctx* ctx, const double H0[16], const double H1[16], double
   if (!ctx || !H0 || !H1) return ctx ? ctx->fail(LSA_E_ARG, "lsa_undistort: bad argument") : LSA_E_ARG;
   LSA_HIP(ctx, hipSetDevice(ctx->device));
   const InterpConst c = make_interp(H0, H1, t0, t1);
+  KpSetsRW sets;
+  int nmax = 0, total = 0;
   for (int k = 0; k < 3; ++k)
   {
-    const int n = ctx->kp_n[LSA_SET_WORKING][k];
-    if (n <= 0) continue;
-    ProfScope ps(ctx, "undistort", (double)n * 48);
-    hipLaunchKernelGGL(k_undistort, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, reinterpret_cast<float4*>(ctx->kp[LSA_SET_WORKING][k]), n, c);
+    sets.pts[k] = reinterpret_cast<float4*>(ctx->kp[LSA_SET_WORKING][k]);
+    sets.n[k] = ctx->kp_n[LSA_SET_WORKING][k];
+    nmax = std::max(nmax, sets.n[k]);
+    total += std::max(sets.n[k], 0);
   }
+  if (nmax <= 0) return LSA_OK;
+  ProfScope ps(ctx, "undistort", (double)total * 48);
+  hipLaunchKernelGGL(k_undistort, dim3((nmax + 255) / 256, 3), dim3(256), 0, ctx->stream, sets, c);
   return LSA_OK;
 }
 

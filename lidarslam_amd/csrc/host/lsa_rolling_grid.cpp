@@ -274,9 +274,28 @@ void RollingGrid::ClearOldPoints(double currentTime)
 }
 
 // RollingGrid.cxx:354-360
+void RollingGrid::BeginSubMap(std::size_t capacity)
+{
+  SubMapCount = 0;
+  if (SubMapStorage) SubMapPtr = SubMapStorage(capacity);
+  else
+  {
+    SubMapOwn.resize(capacity);
+    SubMapPtr = SubMapOwn.data();
+  }
+  if (!SubMapPtr && capacity > 0)
+  {
+    // the provider failed: fall back to own storage (the caller notices through SubMapData())
+    SubMapOwn.resize(capacity);
+    SubMapPtr = SubMapOwn.data();
+  }
+}
+
 void RollingGrid::BuildSubMap()
 {
-  SubMap = this->Get();
+  this->BeginSubMap(NbPoints);
+  for (const auto& out : Voxels)
+    for (const auto& in : out.second) SubMapPtr[SubMapCount++] = in.second.point;
   SubMapValid = true;
   SubMapBoxed = false;
 }
@@ -317,26 +336,25 @@ void RollingGrid::BuildSubMap(const float minPoint[3], const float maxPoint[3], 
     this->To3d(id, v);
     return lo[0] <= v[0] && v[0] <= hi[0] && lo[1] <= v[1] && v[1] <= hi[1] && lo[2] <= v[2] && v[2] <= hi[2];
   };
-  SubMap.clear();
-  SubMap.reserve(NbPoints);
+  this->BeginSubMap(NbPoints);
   if (minNbPoints < 0 || MinFramesPerVoxel <= 1)
   {
     for (const auto& out : Voxels)
       if (intersects(out.first))
-        for (const auto& in : out.second) SubMap.push_back(in.second.point);
+        for (const auto& in : out.second) SubMapPtr[SubMapCount++] = in.second.point;
   }
   else
   {
     for (const auto& out : Voxels)
       if (intersects(out.first))
         for (const auto& in : out.second)
-          if (in.second.count >= MinFramesPerVoxel || in.second.point.label == 1) SubMap.push_back(in.second.point);
-    if (static_cast<int>(SubMap.size()) < minNbPoints)
+          if (in.second.count >= MinFramesPerVoxel || in.second.point.label == 1) SubMapPtr[SubMapCount++] = in.second.point;
+    if (static_cast<int>(SubMapCount) < minNbPoints)
     {
       for (const auto& out : Voxels)
         if (intersects(out.first))
           for (const auto& in : out.second)
-            if (in.second.count < MinFramesPerVoxel && in.second.point.label != 1) SubMap.push_back(in.second.point);
+            if (in.second.count < MinFramesPerVoxel && in.second.point.label != 1) SubMapPtr[SubMapCount++] = in.second.point;
     }
   }
   SubMapValid = true;

@@ -8,6 +8,7 @@
 // which decides the order of the sub-map points and with it the PCA summation order -- is kept.
 #pragma once
 #include <cstddef>
+#include <functional>
 #include <unordered_map>
 #include <vector>
 #include "../../../include/lidarslam_amd.h"
@@ -68,8 +69,13 @@ public:
   // last two with what the current sub-map was built for (the caller knows the map has not changed since).
   bool SubMapBuiltFor(const float minPoint[3], const float maxPoint[3], int minNbPoints) const;
   // IsSubMapKdTreeValid(): false after every map modification until the next BuildSubMap
-  bool IsSubMapValid() const { return this->SubMapValid && !this->SubMap.empty(); }
-  const PointCloud& GetSubMap() const { return this->SubMap; }
+  bool IsSubMapValid() const { return this->SubMapValid && this->SubMapCount > 0; }
+  const lsa_point_t* SubMapData() const { return this->SubMapPtr; }
+  std::size_t SubMapSize() const { return this->SubMapCount; }
+  // Where BuildSubMap writes: by default a vector of its own; with a provider (called with the number of points
+  // it has to hold, returns the buffer) straight into the caller's memory -- the pinned staging buffer of the
+  // device target, so that the sub-map is extracted once and never copied on the host.
+  void SetSubMapStorage(std::function<lsa_point_t*(std::size_t)> provider) { this->SubMapStorage = std::move(provider); }
   void ClearOldPoints(double currentTime);
 
 private:
@@ -80,7 +86,11 @@ private:
   float VoxelGridPosition[3] = {0.f, 0.f, 0.f};
   unsigned int NbPoints = 0;
   unsigned int AddSerial = 0;
-  PointCloud SubMap;
+  PointCloud SubMapOwn;
+  std::function<lsa_point_t*(std::size_t)> SubMapStorage;
+  lsa_point_t* SubMapPtr = nullptr;
+  std::size_t SubMapCount = 0;
+  void BeginSubMap(std::size_t capacity);
   bool SubMapValid = false;
   bool SubMapBoxed = false;  // built by the bounding-box overload
   int SubMapLo[3] = {0, 0, 0}, SubMapHi[3] = {0, 0, 0}, SubMapMinNbPoints = 0;

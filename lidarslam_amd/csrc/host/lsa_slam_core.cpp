@@ -60,14 +60,6 @@ void HostWorker::Run()
   }
 }
 
-// worker side: the sub-map goes into the pinned staging buffer of its device target
-static void StageSubMap(lsa_ctx* ctx, int type, const RollingGrid& map)
-{
-  const auto& sub = map.GetSubMap();
-  lsa_point_t* dst = lsa_target_staging(ctx, LSA_TARGET_MAP, type, static_cast<int>(sub.size()));
-  if (dst && !sub.empty()) std::memcpy(dst, sub.data(), sub.size() * sizeof(lsa_point_t));
-}
-
 #define LSA_TRY(call)                          \
   do                                           \
   {                                            \
@@ -99,6 +91,12 @@ SlamCore::SlamCore(int device)
     Ctx = nullptr;
     LastError = rc == LSA_E_NO_DEVICE ? "no usable HIP device (there is no CPU fallback)" : "lsa_ctx_create failed";
   }
+  else
+    for (int k = 0; k < 3; ++k)
+    {
+      lsa_ctx* ctx = Ctx;
+      LocalMaps[k]->SetSubMapStorage([ctx, k](std::size_t n) { return lsa_target_staging(ctx, LSA_TARGET_MAP, k, static_cast<int>(n)); });
+    }
   Reset();
 }
 
@@ -389,20 +387,18 @@ int SlamCore::Localization()
         if (map->SubMapBuiltFor(mn + 3 * k, mx + 3 * k, minPts)) { Stats.submap_spec_hits++; SubMapSpecHitsTotal++; rebuild[k] = true; continue; }
         rebuild[k] = true;
       }
-      lsa_ctx* ctx = Ctx;
       if (MapUpdate == MappingMode::NONE)
-        MapWorker[k].Submit([map, ctx, k] { map->BuildSubMap(); StageSubMap(ctx, k, *map); });
+        MapWorker[k].Submit([map] { map->BuildSubMap(); });
       else
       {
         const bool clear = map->IsTimeThreshold();
         const double now = CurrentTime;
         const float* lo3 = mn + 3 * k;
         const float* hi3 = mx + 3 * k;
-        MapWorker[k].Submit([map, ctx, k, clear, now, minPts, mn0 = lo3[0], mn1 = lo3[1], mn2 = lo3[2], mx0 = hi3[0], mx1 = hi3[1], mx2 = hi3[2]] {
+        MapWorker[k].Submit([map, clear, now, minPts, mn0 = lo3[0], mn1 = lo3[1], mn2 = lo3[2], mx0 = hi3[0], mx1 = hi3[1], mx2 = hi3[2]] {
           if (clear) map->ClearOldPoints(now);
           const float lo[3] = {mn0, mn1, mn2}, hi[3] = {mx0, mx1, mx2};
           map->BuildSubMap(lo, hi, minPts);
-          StageSubMap(ctx, k, *map);
         });
       }
     }
@@ -410,11 +406,10 @@ int SlamCore::Localization()
     {
       if (!rebuild[k]) continue;
       MapWorker[k].Wait();
-      const auto& sub = LocalMaps[k]->GetSubMap();
       // the map holds one point per leaf voxel: a search cell of about one leaf keeps a handful of candidates per cell
       lsa_set_target_cell_size(Ctx, LSA_TARGET_MAP, k, static_cast<float>((k == LSA_EDGE ? KnnCellScaleMapsEdges : KnnCellScaleMaps) * LocalMaps[k]->GetLeafSize()));
-      // the worker left the sub-map in the target's pinned staging buffer: the copy is only enqueued
-      LSA_TRY(lsa_set_target_staged(Ctx, LSA_TARGET_MAP, k, static_cast<int>(sub.size())));
+      // the worker extracted the sub-map straight into the target's pinned staging buffer: the copy is only enqueued
+      LSA_TRY(lsa_set_target_staged(Ctx, LSA_TARGET_MAP, k, static_cast<int>(LocalMaps[k]->SubMapSize())));
     }
     Stats.submap += t.Stop();
   }
@@ -501,16 +496,14 @@ int SlamCore::FinishSubMapSpeculation()
     const double now = CurrentTime;
     const int minPts = KeypointCounts[k] / 2;
     bool* built = &SpecBuilt[k];
-    lsa_ctx* ctx = Ctx;
     const float* lo3 = mn + 3 * k;
     const float* hi3 = mx + 3 * k;
     // queued behind the previous keyframe's insertion on the same worker: it sees the final map
-    MapWorker[k].Submit([map, ctx, k, clear, now, minPts, built, mn0 = lo3[0], mn1 = lo3[1], mn2 = lo3[2], mx0 = hi3[0], mx1 = hi3[1], mx2 = hi3[2]] {
+    MapWorker[k].Submit([map, clear, now, minPts, built, mn0 = lo3[0], mn1 = lo3[1], mn2 = lo3[2], mx0 = hi3[0], mx1 = hi3[1], mx2 = hi3[2]] {
       if (map->IsSubMapValid()) return;  // the map did not change: Slam.cxx:1013 keeps the kd-tree
       if (clear) map->ClearOldPoints(now);
       const float lo[3] = {mn0, mn1, mn2}, hi[3] = {mx0, mx1, mx2};
       map->BuildSubMap(lo, hi, minPts);
-      StageSubMap(ctx, k, *map);
       *built = true;
     });
   }

@@ -12,10 +12,20 @@ namespace host
 namespace
 {
 // Utils::PositionToVoxel (RollingGrid.h:39-42): round((p - origin) / resolution)
+// static_cast<int>(std::round(x)) without the libm call: truncate, then step away from zero when the
+// remainder reaches one half (x - float(t) is exact for |x| < 2^24, far above any voxel index)
+inline int RoundToInt(float x)
+{
+  int t = static_cast<int>(x);
+  const float d = x - static_cast<float>(t);
+  if (d >= 0.5f) ++t;
+  else if (d <= -0.5f) --t;
+  return t;
+}
 inline void ToVoxel(const float p[3], const float origin[3], double resolution, int out[3])
 {
   const float r = static_cast<float>(resolution);
-  for (int i = 0; i < 3; ++i) out[i] = static_cast<int>(std::round((p[i] - origin[i]) / r));
+  for (int i = 0; i < 3; ++i) out[i] = RoundToInt((p[i] - origin[i]) / r);
 }
 inline void BoundingBox(const lsa_point_t* pts, size_t count, float mn[3], float mx[3])
 {
@@ -184,7 +194,7 @@ void RollingGrid::Add(const lsa_point_t* points, size_t count, bool fixed, doubl
       outer = &Voxels[idxOut];  // inserts the outer voxel when it is new, exactly as Voxels[idxOut][idxIn] would
       lastOut = idxOut;
     }
-    auto ins = outer->emplace(idxIn, Voxel());
+    auto ins = outer->try_emplace(idxIn);  // no node is built (and thrown away) when the voxel exists
     Voxel& voxel = ins.first->second;
     if (ins.second)
     {

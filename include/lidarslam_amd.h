@@ -137,6 +137,9 @@ void lsa_set_azimuthal_resolution(lsa_ctx* ctx, float rad);
  * keypoints of type k; keypoints stay on the device, ordered ring-major /
  * index-ascending as SSKE.cxx:575-589 pushes them. */
 int lsa_extract_keypoints(lsa_ctx* ctx, const lsa_extract_params_t* params, int counts[3]);
+/* Keypoint types lsa_extract_keypoints keeps (bit k = type k; Slam::UseKeypoints, Slam.h:406): the others
+ * come out empty, exactly as Slam::ExtractKeypoints drops them (Slam.cxx:789-793).  Default: all three. */
+int lsa_set_keypoint_types(lsa_ctx* ctx, unsigned type_mask);
 
 /* Copies a device keypoint set to the host.  Returns the number of points
  * written (<= capacity) or a negative error. */

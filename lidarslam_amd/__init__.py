@@ -47,7 +47,7 @@ DEBUG_NAMES = [
 ABI_SYMBOLS = [
     "lsa_device_count", "lsa_ctx_create", "lsa_ctx_destroy", "lsa_last_error", "lsa_sync", "lsa_upload_frame",
     "lsa_frame_store_put", "lsa_frame_store_use", "lsa_frame_size", "lsa_get_azimuthal_resolution",
-    "lsa_set_azimuthal_resolution", "lsa_extract_keypoints", "lsa_download_keypoints", "lsa_keypoint_count",
+    "lsa_set_azimuthal_resolution", "lsa_extract_keypoints", "lsa_set_keypoint_types", "lsa_download_keypoints", "lsa_keypoint_count",
     "lsa_download_debug", "lsa_nb_laser_rings", "lsa_transform_keypoints", "lsa_set_target", "lsa_set_target_from_set", "lsa_target_staging", "lsa_set_target_staged",
     "lsa_target_size", "lsa_set_target_cell_size", "lsa_set_knn_lanes", "lsa_set_knn_rounds", "lsa_match_slow_queries", "lsa_match_exhaustive_queries", "lsa_set_keypoints", "lsa_match", "lsa_match_types",
     "lsa_download_match", "lsa_overlap", "lsa_accumulate", "lsa_solve", "lsa_registration_error", "lsa_selftest_math", "lsa_reset_working_keypoints", "lsa_undistort", "lsa_working_time_range",

@@ -211,16 +211,12 @@ int SlamCore::ProcessCurrentFrame(uint64_t stampUs)
 int SlamCore::ExtractKeypoints()
 {
   int counts[3];
-  LSA_TRY(lsa_extract_keypoints(Ctx, &ExtractParams, counts));  // also: PreviousRawKeypoints = CurrentRawKeypoints
+  unsigned mask = 0;
   for (int k = 0; k < 3; ++k)
-  {
-    if (!UseKeypoints[k])
-    {
-      LSA_TRY(lsa_set_keypoints(Ctx, LSA_SET_RAW_CURRENT, k, nullptr, 0));
-      counts[k] = 0;
-    }
-    KeypointCounts[k] = counts[k];
-  }
+    if (UseKeypoints[k]) mask |= 1u << k;
+  lsa_set_keypoint_types(Ctx, mask);  // unused types come out empty (Slam.cxx:789-793)
+  LSA_TRY(lsa_extract_keypoints(Ctx, &ExtractParams, counts));  // also: PreviousRawKeypoints = CurrentRawKeypoints
+  for (int k = 0; k < 3; ++k) KeypointCounts[k] = counts[k];
   // AggregateFrames(keypoints, false): LIDAR -> BASE (Slam.cxx:1551-1573); skipped when identity
   if (!IsApprox(BaseToLidarOffset, Pose::Identity()))
     for (int k = 0; k < 3; ++k)

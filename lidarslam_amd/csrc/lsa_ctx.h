@@ -124,12 +124,15 @@ struct lsa_ctx
   uint32_t* block_hist = nullptr;  // [nblocks][kMaxRings]
   int* ring_start = nullptr;       // [kMaxRings + 1]
   int* ring_len = nullptr;         // [kMaxRings]
-  int* ring_meta = nullptr;        // [0] nrings, [1] max laser id, [2] error flags
+  // one 64-byte block read back per extraction: [0..3] keypoint counts, [4..11] ring_meta, [12..15] time range bits
+  int* extract_out = nullptr;
+  int* ring_meta = nullptr;        // = extract_out + 4: [0] nrings, [1] max laser id, [2] error flags
   float* score[4] = {nullptr, nullptr, nullptr, nullptr};  // angle, depth_gap, saliency, intensity_gap
   uint8_t* valid = nullptr;
   uint8_t* label = nullptr;
   int* ring_counts = nullptr;  // [kMaxRings][3]
-  int* kp_count_dev = nullptr; // [3]
+  int* kp_count_dev = nullptr; // = extract_out: [3]
+  unsigned kp_type_mask = 7;   // keypoint types the extraction keeps (Slam::UseKeypoints)
 
   // keypoint sets [set][type]
   lsa_point_t* kp[3][3] = {};

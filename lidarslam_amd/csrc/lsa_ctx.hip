@@ -235,9 +235,9 @@ int lsa_ctx_create(int device_id, lsa_ctx** out)
   ok &= hipEventCreateWithFlags(&ctx->ev_stage, hipEventDisableTiming) == hipSuccess;
   ok &= hipMalloc((void**)&ctx->ring_start, (kMaxRings + 1) * sizeof(int)) == hipSuccess;
   ok &= hipMalloc((void**)&ctx->ring_len, kMaxRings * sizeof(int)) == hipSuccess;
-  ok &= hipMalloc((void**)&ctx->ring_meta, 8 * sizeof(int)) == hipSuccess;
+  ok &= hipMalloc((void**)&ctx->extract_out, 16 * sizeof(int)) == hipSuccess;
+  if (ok) { ctx->kp_count_dev = ctx->extract_out; ctx->ring_meta = ctx->extract_out + 4; }
   ok &= hipMalloc((void**)&ctx->ring_counts, kMaxRings * 3 * sizeof(int)) == hipSuccess;
-  ok &= hipMalloc((void**)&ctx->kp_count_dev, 4 * sizeof(int)) == hipSuccess;
   ok &= hipMalloc((void**)&ctx->partials, (size_t)kAccumBlocks * kAccumVals * sizeof(double)) == hipSuccess;
   ok &= hipMalloc((void**)&ctx->reduce_out, 64 * sizeof(double)) == hipSuccess;
   if (ok) ok &= hipMemset(ctx->reduce_out, 0, 64 * sizeof(double)) == hipSuccess;  // [32] holds the arrival ticket of k_accumulate
@@ -265,9 +265,9 @@ void lsa_ctx_destroy(lsa_ctx* ctx)
   for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
   auto fr = [](void* p) { if (p) (void)hipFree(p); };
   fr(ctx->frame_own); fr(ctx->xyzi); fr(ctx->orig); fr(ctx->ring_of); fr(ctx->block_hist);
-  fr(ctx->ring_start); fr(ctx->ring_len); fr(ctx->ring_meta);
+  fr(ctx->ring_start); fr(ctx->ring_len); fr(ctx->extract_out);
   for (int i = 0; i < 4; ++i) fr(ctx->score[i]);
-  fr(ctx->valid); fr(ctx->label); fr(ctx->ring_counts); fr(ctx->kp_count_dev);
+  fr(ctx->valid); fr(ctx->label); fr(ctx->ring_counts);
   for (int s = 0; s < 3; ++s) for (int k = 0; k < 3; ++k) fr(ctx->kp[s][k]);
   for (int k = 0; k < 6; ++k)
   {

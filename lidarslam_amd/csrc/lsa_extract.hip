@@ -39,6 +39,23 @@ struct ExtractConst
 __device__ __forceinline__ unsigned laser_of(const float4& second) { return __float_as_uint(second.w) & 0xffffu; }
 
 // --------------------------------------------------------------------------------------------
+// arms the read-back block of one extraction: counts 0, ring_meta 0 with max laser id -1, empty time range
+__global__ void k_extract_init(int* __restrict__ out)
+{
+  const int i = threadIdx.x;
+  if (i >= 16) return;
+  int v = 0;
+  if (i == 5) v = -1;                      // ring_meta[1]: max laser id
+  if (i == 12 || i == 13) v = -1;          // time range lo = ~0ull
+  out[i] = v;
+}
+// monotone encoding of doubles for 64-bit atomicMin/Max (as in lsa_transform.hip)
+__device__ __forceinline__ unsigned long long time_bits(const float4& b)
+{
+  const unsigned long long u = (unsigned long long)__double_as_longlong(__hiloint2double(__float_as_int(b.y), __float_as_int(b.x)));
+  return (u & 0x8000000000000000ull) ? ~u : (u | 0x8000000000000000ull);
+}
+
 __global__ __launch_bounds__(256) void k_ring_hist(const float4* __restrict__ frame, int n, uint32_t* __restrict__ block_hist,
                                                    int* __restrict__ ring_meta)
 {
@@ -554,10 +571,12 @@ __global__ __launch_bounds__(256) void k_compact(const float4* __restrict__ fram
                                                  const uint8_t* __restrict__ label, const int* __restrict__ ring_start,
                                                  const int* __restrict__ ring_len, const int* __restrict__ ring_meta,
                                                  const int* __restrict__ ring_counts, float4* __restrict__ out_e,
-                                                 float4* __restrict__ out_p, float4* __restrict__ out_b, int* __restrict__ kp_count)
+                                                 float4* __restrict__ out_p, float4* __restrict__ out_b, int* __restrict__ kp_count,
+                                                 unsigned type_mask, unsigned long long* __restrict__ time_range)
 {
   __shared__ int base[3];
   __shared__ unsigned long long part[256];
+  __shared__ unsigned long long tlo[4], thi[4];
   const int r = blockIdx.x;
   const int nr = ring_meta[0];
   if (r >= nr) return;
@@ -566,7 +585,8 @@ __global__ __launch_bounds__(256) void k_compact(const float4* __restrict__ fram
     int s = 0;
     for (int q = 0; q < r; ++q) s += ring_counts[q * 3 + threadIdx.x];
     base[threadIdx.x] = s;
-    if (r == nr - 1) kp_count[threadIdx.x] = s + ring_counts[r * 3 + threadIdx.x];
+    // a type the caller does not use (Slam::UseKeypoints) is dropped here: count 0, nothing written
+    if (r == nr - 1) kp_count[threadIdx.x] = ((type_mask >> threadIdx.x) & 1u) ? s + ring_counts[r * 3 + threadIdx.x] : 0;
   }
   const int s0 = ring_start[r];
   const int np = ring_len[r];
@@ -575,7 +595,7 @@ __global__ __launch_bounds__(256) void k_compact(const float4* __restrict__ fram
   unsigned long long mine = 0;
   for (int j = jb; j < je; ++j)
   {
-    const uint8_t l = label[s0 + j];
+    const uint8_t l = label[s0 + j] & type_mask;
     mine += (unsigned long long)(l & 1) | ((unsigned long long)((l >> 1) & 1) << 21) | ((unsigned long long)((l >> 2) & 1) << 42);
   }
   part[threadIdx.x] = mine;
@@ -591,15 +611,33 @@ __global__ __launch_bounds__(256) void k_compact(const float4* __restrict__ fram
   int pe = base[0] + (int)(excl & 0x1fffff);
   int pp = base[1] + (int)((excl >> 21) & 0x1fffff);
   int pb = base[2] + (int)((excl >> 42) & 0x1fffff);
+  // the keypoints' time range (Slam::InitUndistortion, Slam.cxx:1291-1300) is reduced on the way
+  unsigned long long lo = ~0ull, hi = 0ull;
   for (int j = jb; j < je; ++j)
   {
-    const uint8_t l = label[s0 + j];
+    const uint8_t l = label[s0 + j] & type_mask;
     if (!l) continue;
     const size_t o = orig[s0 + j];
     const float4 a = frame[2 * o], b = frame[2 * o + 1];
     if (l & 1) { out_e[2 * (size_t)pe] = a; out_e[2 * (size_t)pe + 1] = b; ++pe; }
     if (l & 2) { out_p[2 * (size_t)pp] = a; out_p[2 * (size_t)pp + 1] = b; ++pp; }
     if (l & 4) { out_b[2 * (size_t)pb] = a; out_b[2 * (size_t)pb + 1] = b; ++pb; }
+    const unsigned long long tb = time_bits(b);
+    lo = tb < lo ? tb : lo;
+    hi = tb > hi ? tb : hi;
+  }
+  for (int s = 32; s > 0; s >>= 1)
+  {
+    const unsigned long long l2 = __shfl_down(lo, s), h2 = __shfl_down(hi, s);
+    lo = l2 < lo ? l2 : lo;
+    hi = h2 > hi ? h2 : hi;
+  }
+  if ((threadIdx.x & 63) == 0) { tlo[threadIdx.x >> 6] = lo; thi[threadIdx.x >> 6] = hi; }
+  __syncthreads();
+  if (threadIdx.x == 0)
+  {
+    for (int w = 1; w < 4; ++w) { lo = tlo[w] < lo ? tlo[w] : lo; hi = thi[w] > hi ? thi[w] : hi; }
+    if (hi >= lo) { atomicMin(&time_range[0], lo); atomicMax(&time_range[1], hi); }
   }
 }
 
@@ -682,9 +720,7 @@ int lsa_extract_keypoints(lsa_ctx* ctx, const lsa_extract_params_t* params, int 
 
   const int nblocks = (n + kBucketChunk - 1) / kBucketChunk;
   const float4* frame4 = reinterpret_cast<const float4*>(ctx->frame);
-  LSA_HIP(ctx, hipMemsetAsync(ctx->ring_meta, 0, 8 * sizeof(int), st));
-  LSA_HIP(ctx, hipMemsetAsync(ctx->ring_meta + 1, 0xff, sizeof(int), st));  // max laser id = -1
-  LSA_HIP(ctx, hipMemsetAsync(ctx->kp_count_dev, 0, 4 * sizeof(int), st));
+  hipLaunchKernelGGL(k_extract_init, dim3(1), dim3(64), 0, st, ctx->extract_out);
   {
     ProfScope ps(ctx, "ring_bucket", (double)n * (4 + 32 + 16 + 4 + 2 + 1));
     hipLaunchKernelGGL(k_ring_hist, dim3(nblocks), dim3(256), 0, st, frame4, n, ctx->block_hist, ctx->ring_meta);
@@ -716,17 +752,14 @@ int lsa_extract_keypoints(lsa_ctx* ctx, const lsa_extract_params_t* params, int 
     hipLaunchKernelGGL(k_compact, dim3(kMaxRings), dim3(256), 0, st, frame4, ctx->orig, ctx->label, ctx->ring_start, ctx->ring_len,
                        ctx->ring_meta, ctx->ring_counts, reinterpret_cast<float4*>(ctx->kp[LSA_SET_RAW_CURRENT][0]),
                        reinterpret_cast<float4*>(ctx->kp[LSA_SET_RAW_CURRENT][1]), reinterpret_cast<float4*>(ctx->kp[LSA_SET_RAW_CURRENT][2]),
-                       ctx->kp_count_dev);
+                       ctx->kp_count_dev, ctx->kp_type_mask, reinterpret_cast<unsigned long long*>(ctx->extract_out + 12));
   }
-  // the keypoints' time range (Slam::InitUndistortion needs it later) rides on this synchronisation
-  rc = enqueue_time_range(ctx, LSA_SET_RAW_CURRENT, ctx->kp_count_dev);
-  if (rc) return rc;
+  // counts, ring_meta and the keypoints' time range (Slam::InitUndistortion needs it later) in one 64-byte read-back
   int* hp = reinterpret_cast<int*>(ctx->host_pinned);
-  unsigned long long* hpt = reinterpret_cast<unsigned long long*>(ctx->host_pinned + 128);
-  LSA_HIP(ctx, hipMemcpyAsync(hp, ctx->kp_count_dev, 3 * sizeof(int), hipMemcpyDeviceToHost, st));
-  LSA_HIP(ctx, hipMemcpyAsync(hp + 4, ctx->ring_meta, 3 * sizeof(int), hipMemcpyDeviceToHost, st));
-  LSA_HIP(ctx, hipMemcpyAsync(hpt, ctx->range_bits, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+  LSA_HIP(ctx, hipMemcpyAsync(hp, ctx->extract_out, 16 * sizeof(int), hipMemcpyDeviceToHost, st));
   LSA_HIP(ctx, hipStreamSynchronize(st));
+  unsigned long long hpt[2];
+  std::memcpy(hpt, hp + 12, sizeof(hpt));
   if (hp[6] & 1) return ctx->fail(LSA_E_CAPACITY, "lsa_extract_keypoints: laser_id >= 512 is not supported");
   if (hp[6] & 2) return ctx->fail(LSA_E_CAPACITY, "lsa_extract_keypoints: more than 8192 points on one laser ring");
   ctx->nb_rings_seen = std::max(ctx->nb_rings_seen, hp[4]);
@@ -753,6 +786,13 @@ int lsa_download_keypoints(lsa_ctx* ctx, int set, int type, lsa_point_t* out, in
   LSA_HIP(ctx, hipMemcpyAsync(out, ctx->kp[set][type], (size_t)n * sizeof(lsa_point_t), hipMemcpyDeviceToHost, ctx->stream));
   LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return n;
+}
+
+int lsa_set_keypoint_types(lsa_ctx* ctx, unsigned type_mask)
+{
+  if (!ctx || (type_mask & ~7u)) return LSA_E_ARG;
+  ctx->kp_type_mask = type_mask;
+  return LSA_OK;
 }
 
 int lsa_set_keypoints(lsa_ctx* ctx, int set, int type, const lsa_point_t* pts, int k)

@@ -141,3 +141,32 @@ def test_device_arithmetic_is_bit_identical_to_the_host(gpu_ctx, O):
             xs, ys = np.clip(np.abs(xs), 1e-15, 1e15) * np.sign(xs + 1e-300), np.clip(np.abs(ys), 1e-15, 1e15)
         a, b = gpu_ctx.selftest_math(fn, xs, ys), O.math(fn, xs, ys)
         assert np.array_equal(bits(a), bits(b)), f"fn {fn}: {np.count_nonzero(bits(a) != bits(b))} results differ"
+
+
+def test_unused_keypoint_types_come_out_empty(O, L):
+    """Slam::ExtractKeypoints drops the types the caller does not use (Slam.cxx:789-793); the time range that rides
+    on the extraction (Slam::InitUndistortion, Slam.cxx:1291-1300) then only covers the types that are kept."""
+    pts, _ = L.synth_frame(16, 1000, 2)
+    ex = O.Extractor()
+    ex.compute(pts)
+    want = [ex.keypoints(k) for k in range(3)]
+    lib = L.lib()
+    gpu_ctx = L.Context(0)  # a context of its own: the azimuthal resolution is estimated on the first frame it sees
+    try:
+        for mask in (3, 5, 2, 0, 7):
+            assert lib.lsa_set_keypoint_types(gpu_ctx.h, mask) == 0
+            gpu_ctx.upload_frame(pts)
+            counts = gpu_ctx.extract_keypoints()
+            kept = [want[k] if (mask >> k) & 1 else want[k][:0] for k in range(3)]
+            assert counts.tolist() == [a.size for a in kept]
+            for k in range(3):
+                assert gpu_ctx.keypoints(L.SET_RAW_CURRENT, k).tobytes() == kept[k].tobytes()
+            gpu_ctx.reset_working_keypoints()
+            t0, t1 = gpu_ctx.working_time_range()
+            times = np.concatenate([a["time"] for a in kept])
+            if times.size:
+                assert (t0, t1) == (times.min(), times.max())
+            else:
+                assert t0 > t1  # the reference's untouched initial values
+    finally:
+        gpu_ctx.close()

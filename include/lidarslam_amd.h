@@ -121,6 +121,23 @@ int lsa_sync(lsa_ctx* ctx);
  * (SSKE.cxx:593-637) and then frozen in the context (SSKE.cxx:169-170). */
 int lsa_upload_frame(lsa_ctx* ctx, const lsa_point_t* pts, int n);
 
+/* The sensor driver's record layout (a sensor_msgs/PointCloud2 of velodyne_pcl::PointXYZIRT, or any record
+ * with float x, y, z, intensity, time and a uint16 ring): byte offsets inside a record of point_step bytes. */
+typedef struct lsa_wire_layout_t
+{
+  int32_t point_step;
+  int32_t off_x, off_y, off_z, off_intensity, off_ring, off_time;
+} lsa_wire_layout_t;
+
+/* lsa_upload_frame for the driver's records, converted on the device as VelodyneToLidarNode::Callback does on
+ * the host (ros_wrapping/lidar_conversions/src/VelodyneToLidarNode.cxx:52-112): laser_id = mapping[ring] (or
+ * ring when mapping_len == 0), device_id, time = the record's time offset.  When the time field is not usable
+ * (last - first <= 1e-8, :74) the time is built from the azimuth advancement exactly as the node does
+ * (SpinningFrameAdvancementEstimator, lidar_conversions/src/Utilities.h:62-114, rpm and timestamp_first_packet
+ * as its parameters); that sequential path, and the first frame, are converted on the host. */
+int lsa_upload_wire_frame(lsa_ctx* ctx, const void* records, int n, const lsa_wire_layout_t* layout, const uint16_t* laser_id_mapping,
+                          int mapping_len, int device_id, double rpm, int timestamp_first_packet);
+
 /* Frame store: keeps scans resident in HBM so that a replay (bench.py) can
  * time the path without the PCIe copy.  Slots are created on demand. */
 int lsa_frame_store_put(lsa_ctx* ctx, int slot, const lsa_point_t* pts, int n);

@@ -45,7 +45,7 @@ DEBUG_NAMES = [
 
 # every symbol include/lidarslam_amd.h declares (tests/test_abi.py checks the .so exports them all)
 ABI_SYMBOLS = [
-    "lsa_device_count", "lsa_ctx_create", "lsa_ctx_destroy", "lsa_last_error", "lsa_sync", "lsa_upload_frame",
+    "lsa_device_count", "lsa_ctx_create", "lsa_ctx_destroy", "lsa_last_error", "lsa_sync", "lsa_upload_frame", "lsa_upload_wire_frame",
     "lsa_frame_store_put", "lsa_frame_store_use", "lsa_frame_size", "lsa_get_azimuthal_resolution",
     "lsa_set_azimuthal_resolution", "lsa_extract_keypoints", "lsa_set_keypoint_types", "lsa_download_keypoints", "lsa_keypoint_count",
     "lsa_download_debug", "lsa_nb_laser_rings", "lsa_transform_keypoints", "lsa_set_target", "lsa_set_target_from_set", "lsa_target_staging", "lsa_set_target_staged",
@@ -103,6 +103,7 @@ def lib():
     L.lsa_match.argtypes = [vp, i32, i32, i32, C.POINTER(MatchParams), vp, vp]
     L.lsa_set_knn_lanes.argtypes = [vp, i32, i32]
     L.lsa_overlap.argtypes = [vp, C.c_uint, i32, vp, vp, C.c_double, C.c_double, C.c_float, vp, vp]
+    L.lsa_upload_wire_frame.argtypes = [vp, vp, i32, vp, vp, i32, i32, C.c_double, i32]
     L.lsa_match_types.argtypes = [vp, i32, C.c_uint, i32, C.POINTER(MatchParams), vp, vp]
     L.lsa_download_match.argtypes = [vp, i32, vp, vp, vp, i32]
     L.lsa_accumulate.argtypes = [vp, C.c_uint, vp, i32, vp, vp, vp, vp]
@@ -197,6 +198,17 @@ class Context:
     @azimuthal_resolution.setter
     def azimuthal_resolution(self, v):
         self.L.lsa_set_azimuthal_resolution(self.h, v)
+
+    def upload_wire_frame(self, records, layout, mapping=None, device_id=0, rpm=600.0, timestamp_first_packet=False):
+        """lsa_upload_wire_frame: records = contiguous structured / byte array of n driver records;
+        layout = (point_step, off_x, off_y, off_z, off_intensity, off_ring, off_time)."""
+        rec = np.ascontiguousarray(records)
+        lay = (C.c_int32 * 7)(*[int(v) for v in layout])
+        n = rec.nbytes // int(layout[0])
+        mp = np.ascontiguousarray(mapping, np.uint16) if mapping is not None else None
+        self._check(self.L.lsa_upload_wire_frame(self.h, rec.ctypes.data_as(C.c_void_p), n, lay, ptr(mp) if mp is not None else None,
+                                                 0 if mp is None else mp.size, device_id, C.c_double(rpm), int(timestamp_first_packet)),
+                    "lsa_upload_wire_frame")
 
     def extract_keypoints(self, params=None):
         params = params or ExtractParams()

@@ -308,6 +308,122 @@ int lsa_sync(lsa_ctx* ctx)
   return LSA_OK;
 }
 
+// ---- the driver's wire format straight to the device --------------------------------------
+namespace
+{
+struct WireMap
+{
+  lsa_wire_layout_t lay;
+  int mapping_len;
+  int device_id;
+  uint16_t mapping[kMaxRings];
+};
+// one LidarPoint per wire record (VelodyneToLidarNode.cxx:81-96): coordinates, intensity, mapped ring, device,
+// time offset widened to double
+__global__ __launch_bounds__(256) void k_wire_to_points(const unsigned char* __restrict__ raw, int n, WireMap m, float4* __restrict__ out)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const unsigned char* r = raw + (size_t)i * m.lay.point_step;
+  auto f32 = [&](int off) { float v; memcpy(&v, r + off, sizeof(v)); return v; };
+  uint16_t ring;
+  memcpy(&ring, r + m.lay.off_ring, sizeof(ring));
+  const unsigned id = m.mapping_len > 0 ? (ring < m.mapping_len ? m.mapping[ring] : 0xffffu) : ring;
+  const double t = (double)f32(m.lay.off_time);
+  const long long tb = __double_as_longlong(t);
+  float4 a = make_float4(f32(m.lay.off_x), f32(m.lay.off_y), f32(m.lay.off_z), 1.f);
+  float4 b;
+  b.x = __int_as_float((int)(tb & 0xffffffffll));
+  b.y = __int_as_float((int)(tb >> 32));
+  b.z = f32(m.lay.off_intensity);
+  b.w = __uint_as_float(id | ((unsigned)(m.device_id & 0xff) << 16));  // laser_id u16, device_id u8, label u8 = 0
+  out[2 * (size_t)i] = a;
+  out[2 * (size_t)i + 1] = b;
+}
+// lidar_conversions::Utils::SpinningFrameAdvancementEstimator (ros_wrapping/lidar_conversions/src/Utilities.h:62-114)
+struct FrameAdvancementEstimator
+{
+  double init = 0.;
+  bool first = true;
+  std::vector<double> prev = std::vector<double>(65536, 0.);  // std::map<int, double>: a missing ring reads 0
+  double operator()(float x, float y, unsigned laser_id)
+  {
+    const double adv = (M_PI - std::atan2(y, x)) / (2 * M_PI);
+    if (first) { init = adv; first = false; }
+    auto wrapMax = [](double v, double max) { return std::fmod(max + std::fmod(v, max), max); };
+    double frameAdv = wrapMax(adv - init, 1.);
+    if (frameAdv < prev[laser_id]) frameAdv += 1.;
+    prev[laser_id] = frameAdv;
+    return frameAdv;
+  }
+};
+}  // namespace
+
+int lsa_upload_wire_frame(lsa_ctx* ctx, const void* data, int n, const lsa_wire_layout_t* lay, const uint16_t* laser_id_mapping, int mapping_len,
+                          int device_id, double rpm, int timestamp_first_packet)
+{
+  if (!ctx || !data || !lay || n <= 0 || lay->point_step <= 0 || mapping_len < 0 || (mapping_len > 0 && !laser_id_mapping))
+    return ctx ? ctx->fail(LSA_E_ARG, "lsa_upload_wire_frame: empty frame or bad layout") : LSA_E_ARG;
+  if (mapping_len > kMaxRings) return ctx->fail(LSA_E_CAPACITY, "lsa_upload_wire_frame: more than 512 entries in the laser id mapping");
+  const int offs[6] = {lay->off_x, lay->off_y, lay->off_z, lay->off_intensity, lay->off_time, lay->off_ring};
+  for (int i = 0; i < 6; ++i)
+    if (offs[i] < 0 || offs[i] + (i == 5 ? 2 : 4) > lay->point_step) return ctx->fail(LSA_E_ARG, "lsa_upload_wire_frame: field outside the record");
+  LSA_HIP(ctx, hipSetDevice(ctx->device));
+  const unsigned char* raw = static_cast<const unsigned char*>(data);
+  auto f32 = [&](int i, int off) { float v; std::memcpy(&v, raw + (size_t)i * lay->point_step + off, sizeof(v)); return v; };
+  // "If first and last points have same timestamps, this is not normal" (VelodyneToLidarNode.cxx:74)
+  const bool isTimeValid = f32(n - 1, lay->off_time) - f32(0, lay->off_time) > 1e-8;
+  if (!isTimeValid || ctx->az_res <= 0.f)
+  {
+    // host conversion: the time has to be built from the azimuth advancement, ring by ring in arrival order
+    // (libm atan2 / fmod, as the driver node does), or this is the first frame, whose azimuthal resolution is
+    // estimated on the host from the converted points anyway
+    std::vector<lsa_point_t> pts(n);
+    FrameAdvancementEstimator est;
+    for (int i = 0; i < n; ++i)
+    {
+      lsa_point_t& p = pts[i];
+      uint16_t ring;
+      std::memcpy(&ring, raw + (size_t)i * lay->point_step + lay->off_ring, sizeof(ring));
+      p.x = f32(i, lay->off_x); p.y = f32(i, lay->off_y); p.z = f32(i, lay->off_z); p.w = 1.f;
+      p.intensity = f32(i, lay->off_intensity);
+      p.laser_id = mapping_len > 0 ? (ring < mapping_len ? laser_id_mapping[ring] : (uint16_t)0xffff) : ring;
+      p.device_id = (uint8_t)device_id;
+      p.label = 0;
+      if (isTimeValid) p.time = f32(i, lay->off_time);
+      else
+      {
+        const double adv = est(p.x, p.y, p.laser_id);
+        p.time = (timestamp_first_packet ? adv : adv - 1) / rpm * 60.;
+      }
+    }
+    const int rc = lsa_upload_frame(ctx, pts.data(), n);
+    if (rc) return rc;
+    LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));  // pts goes away
+    return LSA_OK;
+  }
+  int rc = ensure_capacity(ctx, n);
+  if (rc) return rc;
+  const size_t bytes = (size_t)n * lay->point_step;
+  rc = ensure_scratch(ctx, bytes);
+  if (rc) return rc;
+  WireMap m;
+  m.lay = *lay;
+  m.mapping_len = mapping_len;
+  m.device_id = device_id;
+  if (mapping_len > 0) std::memcpy(m.mapping, laser_id_mapping, (size_t)mapping_len * sizeof(uint16_t));
+  LSA_HIP(ctx, hipMemcpyAsync(ctx->scratch_out, data, bytes, hipMemcpyHostToDevice, ctx->stream));
+  {
+    ProfScope ps(ctx, "wire_to_points", (double)n * (lay->point_step + 32));
+    hipLaunchKernelGGL(k_wire_to_points, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, static_cast<const unsigned char*>(ctx->scratch_out), n, m,
+                       reinterpret_cast<float4*>(ctx->frame_own));
+  }
+  LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the caller's buffer may be pageable and go away
+  ctx->frame = ctx->frame_own;
+  ctx->frame_n = n;
+  return LSA_OK;
+}
+
 int lsa_upload_frame(lsa_ctx* ctx, const lsa_point_t* pts, int n)
 {
   if (!ctx || !pts || n <= 0) return ctx ? ctx->fail(LSA_E_ARG, "lsa_upload_frame: empty frame") : LSA_E_ARG;

@@ -198,6 +198,21 @@ def transform(pts, T):
     return out
 
 
+def velodyne_to_lidar(records, layout, mapping=None, device_id=0, rpm=600.0, timestamp_first_packet=False):
+    """VelodyneToLidarNode::Callback on driver records; returns (LidarPoint array, time field was usable)."""
+    rec = np.ascontiguousarray(records)
+    n = rec.nbytes // int(layout[0])
+    out = np.zeros(n, POINT_DTYPE)
+    lay = (C.c_int32 * 7)(*[int(v) for v in layout])
+    mp = np.ascontiguousarray(mapping, np.uint16) if mapping is not None else None
+    f = lib().orc_velodyne_to_lidar
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_int, C.c_void_p]
+    rc = f(rec.ctypes.data_as(C.c_void_p), n, lay, ptr(mp) if mp is not None else None, 0 if mp is None else mp.size, device_id, rpm,
+           int(timestamp_first_packet), ptr(out))
+    return out, rc == 1
+
+
 def lcp(cloud, ratio, targets, leaves):
     """Confidence::LCPEstimator on a registered cloud; targets / leaves: per keypoint type (None = map not used)."""
     cloud = np.ascontiguousarray(cloud)

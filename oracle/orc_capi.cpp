@@ -5,6 +5,7 @@
 // include/lidarslam_amd.h so that a test passes the very same bytes to the HIP
 // path and to the oracle.
 #include <cstring>
+#include <map>
 #include <string>
 #include <vector>
 #include "../include/lidarslam_amd.h"
@@ -299,6 +300,48 @@ float orc_lcp(const lsa_point_t* cloud, int n, float ratio, const lsa_point_t* c
     lcp += bestProba;
   }
   return lcp / nbPoints;
+}
+
+// VelodyneToLidarNode::Callback (ros_wrapping/lidar_conversions/src/VelodyneToLidarNode.cxx:52-112) with
+// Utils::SpinningFrameAdvancementEstimator (ros_wrapping/lidar_conversions/src/Utilities.h:62-114): driver
+// records (float x, y, z, intensity, time; uint16 ring at the given byte offsets) -> LidarPoint.
+// layout = {point_step, off_x, off_y, off_z, off_intensity, off_ring, off_time}.  Returns 1 when the time
+// field was usable, 0 when the time was built from the azimuth advancement, -1 for an empty cloud.
+int orc_velodyne_to_lidar(const void* records, int n, const int32_t layout[7], const uint16_t* mapping, int mapping_len, int device_id, double rpm,
+                          int timestamp_first_packet, lsa_point_t* out)
+{
+  if (n <= 0) return -1;  // "Input Velodyne pointcloud is empty : frame ignored." (:56-60)
+  const unsigned char* raw = (const unsigned char*)records;
+  const int step = layout[0];
+  auto f32 = [&](int i, int off) { float v; std::memcpy(&v, raw + (size_t)i * step + off, 4); return v; };
+  const bool isTimeValid = f32(n - 1, layout[6]) - f32(0, layout[6]) > 1e-8;  // (:74)
+  double initAdvancement = 0.;
+  std::map<int, double> previousAdvancementPerRing;
+  for (int i = 0; i < n; ++i)
+  {
+    lsa_point_t p;
+    std::memset(&p, 0, sizeof(p));
+    uint16_t ring;
+    std::memcpy(&ring, raw + (size_t)i * step + layout[5], 2);
+    p.x = f32(i, layout[1]); p.y = f32(i, layout[2]); p.z = f32(i, layout[3]); p.w = 1.f;
+    p.intensity = f32(i, layout[4]);
+    p.laser_id = mapping_len > 0 ? mapping[ring] : ring;  // (:90)
+    p.device_id = (uint8_t)device_id;
+    if (isTimeValid) p.time = f32(i, layout[6]);  // (:95-96)
+    else
+    {
+      // SpinningFrameAdvancementEstimator::operator() (Utilities.h:88-108)
+      double pointAdvancement = (M_PI - std::atan2(p.y, p.x)) / (2 * M_PI);
+      if (previousAdvancementPerRing.empty()) initAdvancement = pointAdvancement;
+      auto wrapMax = [](double x, double max) { return std::fmod(max + std::fmod(x, max), max); };
+      double frameAdvancement = wrapMax(pointAdvancement - initAdvancement, 1.);
+      if (frameAdvancement < previousAdvancementPerRing[p.laser_id]) frameAdvancement += 1.;
+      previousAdvancementPerRing[p.laser_id] = frameAdvancement;
+      p.time = (timestamp_first_packet ? frameAdvancement : frameAdvancement - 1) / rpm * 60.;  // (:106)
+    }
+    out[i] = p;
+  }
+  return isTimeValid ? 1 : 0;
 }
 
 // ---- full pipeline ---------------------------------------------------------------------

@@ -283,3 +283,57 @@ def test_pipeline_overlap_estimation(L, O):
         assert (want == -1.0 and got == -1.0) or abs(got - want) <= 2e-5 * abs(want), (f, got, want)
         seen.append(want)
     assert seen[0] == -1.0 and all(0.3 < v <= 1.0 for v in seen[1:])  # no map before the first frame, then mostly overlapping
+
+
+# ---------------------------------------------------------------------------------------- SURVEY.md 8f-4
+VELODYNE = np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("pad", "<f4"), ("intensity", "<f4"), ("ring", "<u2"), ("pad2", "<u2"),
+                     ("time", "<f4"), ("pad3", "<f4")])  # velodyne_pcl::PointXYZIRT, 32 bytes
+VELODYNE_LAYOUT = (32, 0, 4, 8, 16, 20, 24)
+
+
+def wire_records(pts, with_time=True):
+    rec = np.zeros(pts.size, VELODYNE)
+    for f in ("x", "y", "z", "intensity"):
+        rec[f] = pts[f]
+    rec["ring"] = pts["laser_id"]
+    if with_time:
+        rec["time"] = pts["time"].astype(np.float32)
+    return rec
+
+
+def same_points(a, b):
+    """field by field (the identity transform used to read the frame back turns -0.0 into +0.0)"""
+    return a.size == b.size and all(np.array_equal(a[f], b[f]) for f in a.dtype.names)
+
+
+def test_wire_format_upload_follows_the_driver_node(O, L):
+    """VelodyneToLidarNode::Callback (lidar_conversions/src/VelodyneToLidarNode.cxx:52-112) on the device: the frame the
+    context holds after lsa_upload_wire_frame is the LidarPoint cloud the node would publish, value for value"""
+    ctx = L.Context(0)
+    eye = np.eye(4)
+    mapping = np.arange(16, dtype=np.uint16)[::-1].copy()  # a custom laser id mapping: rings reversed
+    try:
+        for f, (mp, dev) in enumerate(((None, 0), (None, 3), (mapping, 1))):  # frame 0 goes through the host (resolution estimate)
+            pts, _ = L.synth_frame(16, 1000, f)
+            rec = wire_records(pts)
+            want, valid = O.velodyne_to_lidar(rec, VELODYNE_LAYOUT, mp, dev)
+            assert valid
+            ctx.upload_wire_frame(rec, VELODYNE_LAYOUT, mp, dev)
+            assert same_points(ctx.transform_frame(eye), want)
+        # keypoints from the wire frame == keypoints from the converted cloud
+        counts = ctx.extract_keypoints()
+        ctx2 = L.Context(0)
+        ctx2.azimuthal_resolution = ctx.azimuthal_resolution
+        ctx2.upload_frame(want)
+        assert counts.tolist() == ctx2.extract_keypoints().tolist()
+        ctx2.close()
+        # no usable time field: built from the azimuth advancement, first or last packet stamp
+        pts, _ = L.synth_frame(16, 1000, 5)
+        rec = wire_records(pts, with_time=False)
+        for first in (False, True):
+            want, valid = O.velodyne_to_lidar(rec, VELODYNE_LAYOUT, None, 0, 600.0, first)
+            assert not valid and np.ptp(want["time"]) > 0.05
+            ctx.upload_wire_frame(rec, VELODYNE_LAYOUT, None, 0, 600.0, first)
+            assert same_points(ctx.transform_frame(eye), want)
+    finally:
+        ctx.close()

@@ -243,3 +243,31 @@ def test_lcp_estimator_properties(O, L):
     assert np.exp(-0.5) - 1e-6 <= v < 1.0
     assert O.lcp(cloud, 0.5, [None, None, None], leaves) == -1.0
     assert O.lcp(cloud[:1], 0.5, [cloud, None, None], leaves) == -1.0  # int(1 * 0.5) == 0 sampled points
+
+
+def test_velodyne_conversion_properties(O, L):
+    """VelodyneToLidarNode::Callback + SpinningFrameAdvancementEstimator: fields carried over, ring mapping, and
+    a time built from the azimuth that grows monotonically inside every ring over about one revolution."""
+    vel = np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("pad", "<f4"), ("intensity", "<f4"), ("ring", "<u2"), ("pad2", "<u2"),
+                    ("time", "<f4"), ("pad3", "<f4")])
+    layout = (32, 0, 4, 8, 16, 20, 24)
+    pts, _ = L.synth_frame(8, 1000, 1)
+    rec = np.zeros(pts.size, vel)
+    for f in ("x", "y", "z", "intensity"):
+        rec[f] = pts[f]
+    rec["ring"] = pts["laser_id"]
+    rec["time"] = pts["time"].astype(np.float32)
+    out, valid = O.velodyne_to_lidar(rec, layout, None, 2)
+    assert valid and np.array_equal(out["x"], pts["x"]) and np.array_equal(out["laser_id"], pts["laser_id"])
+    assert np.array_equal(out["time"], rec["time"].astype(np.float64)) and (out["device_id"] == 2).all() and (out["w"] == 1).all()
+    mapping = np.arange(8, dtype=np.uint16)[::-1].copy()
+    out2, _ = O.velodyne_to_lidar(rec, layout, mapping, 0)
+    assert np.array_equal(out2["laser_id"], mapping[pts["laser_id"]])
+    rec["time"] = 0
+    for first, lo, hi in ((True, 0.0, 0.1), (False, -0.1, 0.0)):
+        out3, valid = O.velodyne_to_lidar(rec, layout, None, 0, 600.0, first)
+        assert not valid
+        assert out3["time"][0] == lo and out3["time"].min() >= lo - 1e-12 and out3["time"].max() <= hi + 0.01
+        for r in range(8):
+            t = out3["time"][out3["laser_id"] == r]
+            assert (np.diff(t) >= 0).all()  # the estimator's whole point: no wrap inside a ring

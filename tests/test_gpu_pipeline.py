@@ -163,6 +163,20 @@ def test_map_maintenance_beside_the_device_work(L, O, params):
     sg.close()
 
 
+def test_long_sequence_stays_on_the_oracle(L, O):
+    """120 VLP-16 frames (12 s, 60 m): no drift between the two implementations, overlap estimate included"""
+    sg, so = L.Slam(0, EgoMotion=3, OverlapSamplingRatio=0.25), O.Slam(EgoMotion=3, NbThreads=8, OverlapSamplingRatio=0.25)
+    for f in range(120):
+        pts, stamp = L.synth_frame(16, 1000, f)
+        sg.add_frame(pts, stamp, f)
+        so.add_frame(pts, stamp, f)
+        dp, da = pose_diff(so.world_transform(), sg.world_transform())
+        assert dp < 1e-9 and da < 1e-6, (f, dp, da)
+    assert abs(sg.get_param("OverlapEstimation") - so.overlap()) < 1e-4
+    assert 55.0 < sg.world_transform()[0, 3] < 65.0  # 5 m/s for 12 s
+    sg.close()
+
+
 def test_pipeline_matches_golden_poses(L, golden):
     s = L.Slam(0, EgoMotion=3)
     for f in range(4):

@@ -375,86 +375,97 @@ constexpr int kKnnFar = -1;
 // instructions whatever its candidates are -- no per-lane sorted lists, no divergent insertion, no merge
 // tree -- and the result sits in registers that are uniform across the group.
 
-// minimum of (d, i) over the G lanes of a group, total order (distance, index); result in every lane
+// A candidate is ONE 64-bit key: the squared distance's bits above, the target index below.  Distances are
+// sums of squares (never negative, never NaN for finite points), so unsigned order of the key IS the search's
+// total order (distance, then index) and every comparison of the selection is a single instruction.
+typedef unsigned long long knn_key;
+constexpr knn_key kKeyEmpty = ((knn_key)0x7f800000u << 32) | 0x7fffffffu;  // (+inf, INT_MAX)
+__device__ __forceinline__ knn_key make_key(float d2, int idx) { return ((knn_key)__float_as_uint(d2) << 32) | (unsigned)idx; }
+__device__ __forceinline__ float key_d2(knn_key k) { return __uint_as_float((unsigned)(k >> 32)); }
+__device__ __forceinline__ int key_idx(knn_key k) { return (int)(unsigned)(k & 0xffffffffu); }
+
+// minimum of the key over the G lanes of a group; result in every lane
 template <int G>
-__device__ __forceinline__ void group_min(float& d, int& i)
+__device__ __forceinline__ void group_min(knn_key& m)
 {
-  auto take = [&](float od, int oi) {
-    const bool lt = od < d || (od == d && oi < i);
-    d = lt ? od : d;
-    i = lt ? oi : i;
+  auto dpp = [&](auto ctrl) {
+    constexpr int c = decltype(ctrl)::value;
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(m & 0xffffffffu), c, 0xF, 0xF, true);
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(m >> 32), c, 0xF, 0xF, true);
+    const knn_key o = ((knn_key)hi << 32) | lo;
+    m = o < m ? o : m;
   };
   // inside a row of 16 lanes the exchange is a DPP operand modifier (no LDS round trip):
   // quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror
-  if (G >= 2) take(__int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(d), 0xB1, 0xF, 0xF, true)), __builtin_amdgcn_update_dpp(0, i, 0xB1, 0xF, 0xF, true));
-  if (G >= 4) take(__int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(d), 0x4E, 0xF, 0xF, true)), __builtin_amdgcn_update_dpp(0, i, 0x4E, 0xF, 0xF, true));
-  if (G >= 8) take(__int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(d), 0x141, 0xF, 0xF, true)), __builtin_amdgcn_update_dpp(0, i, 0x141, 0xF, 0xF, true));
-  if (G >= 16) take(__int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(d), 0x140, 0xF, 0xF, true)), __builtin_amdgcn_update_dpp(0, i, 0x140, 0xF, 0xF, true));
-  if (G >= 32) take(__shfl_xor(d, 16), __shfl_xor(i, 16));
-  if (G >= 64) take(__shfl_xor(d, 32), __shfl_xor(i, 32));
+  if (G >= 2) dpp(std::integral_constant<int, 0xB1>());
+  if (G >= 4) dpp(std::integral_constant<int, 0x4E>());
+  if (G >= 8) dpp(std::integral_constant<int, 0x141>());
+  if (G >= 16) dpp(std::integral_constant<int, 0x140>());
+  if (G >= 32) { const knn_key o = __shfl_xor(m, 16); m = o < m ? o : m; }
+  if (G >= 64) { const knn_key o = __shfl_xor(m, 32); m = o < m ? o : m; }
 }
 
 template <int KMAX, int G, int U>
 struct GroupSelect
 {
   static constexpr int C = (KMAX + G - 1) / G;  // carry slots per lane: the previous best, dealt over the group
-  float cd[U + C];
-  int ci[U + C];
-  float best_d[KMAX];  // ascending (distance, index), uniform across the group; (+inf, INT_MAX) = empty
-  int best_i[KMAX];
+  knn_key key[U + C];   // [0, U) fresh candidates of the batch, [U, U + C) carry
+  knn_key best[KMAX];   // ascending, uniform across the group; kKeyEmpty = none
   __device__ __forceinline__ void reset()
   {
 #pragma unroll
-    for (int s = 0; s < KMAX; ++s) { best_d[s] = INFINITY; best_i[s] = 0x7fffffff; }
+    for (int s = 0; s < KMAX; ++s) best[s] = kKeyEmpty;
 #pragma unroll
-    for (int u = 0; u < U + C; ++u) { cd[u] = INFINITY; ci[u] = 0x7fffffff; }
+    for (int u = 0; u < U + C; ++u) key[u] = kKeyEmpty;
   }
-  // best <- the k smallest of (carry slots + the U fresh candidates of every lane)
-  __device__ __forceinline__ void select(int k, int gl)
+  // best <- the k smallest of (carry slots + the fresh candidates of every lane); nfresh: fresh slots any group
+  // of the wavefront uses in this batch (wave-uniform; the others hold nothing and are not looked at)
+  __device__ __forceinline__ void select(int k, int gl, int nfresh)
   {
     // nothing in this batch beats the current k-th best of any group of the wavefront: keep the list
-    bool improves = false;
-    float kth_d = INFINITY; int kth_i = 0x7fffffff;
+    knn_key kth = kKeyEmpty;
 #pragma unroll
     for (int s = 0; s < KMAX; ++s)
-      if (s == k - 1) { kth_d = best_d[s]; kth_i = best_i[s]; }
+      if (s == k - 1) kth = best[s];
+    bool improves = false;
 #pragma unroll
-    for (int u = 0; u < U; ++u) improves |= cd[u] < kth_d || (cd[u] == kth_d && ci[u] < kth_i);
+    for (int u = 0; u < U; ++u) improves |= key[u] < kth;
     if (!__any(improves)) return;
 #pragma unroll
     for (int s = 0; s < KMAX; ++s)
     {
       if (s < k)
       {
-        float md = cd[0]; int mi = ci[0];
+        knn_key m = key[U];
 #pragma unroll
-        for (int u = 1; u < U + C; ++u)
-        {
-          const bool lt = cd[u] < md || (cd[u] == md && ci[u] < mi);
-          md = lt ? cd[u] : md;
-          mi = lt ? ci[u] : mi;
-        }
-        group_min<G>(md, mi);
-        best_d[s] = md; best_i[s] = mi;
-        // the owner retires it (indices are unique among real candidates; empty slots all look alike, harmless)
+        for (int c = 1; c < C; ++c) m = key[U + c] < m ? key[U + c] : m;
 #pragma unroll
-        for (int u = 0; u < U + C; ++u)
-          if (ci[u] == mi) { cd[u] = INFINITY; ci[u] = 0x7fffffff; }
+        for (int u = 0; u < U; ++u)
+          if (u < nfresh) m = key[u] < m ? key[u] : m;
+        group_min<G>(m);
+        best[s] = m;
+        // the owner retires it (keys of real candidates are unique; empty slots all look alike, harmless)
+#pragma unroll
+        for (int c = 0; c < C; ++c)
+          if (key[U + c] == m) key[U + c] = kKeyEmpty;
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+          if (u < nfresh && key[u] == m) key[u] = kKeyEmpty;
       }
     }
     // the new best becomes the carry of the next batch: entry s lives in slot s / G of lane s % G
 #pragma unroll
-    for (int c = 0; c < C; ++c) { cd[U + c] = INFINITY; ci[U + c] = 0x7fffffff; }
+    for (int c = 0; c < C; ++c) key[U + c] = kKeyEmpty;
 #pragma unroll
     for (int s = 0; s < KMAX; ++s)
-      if (s < k && gl == s % G) { cd[U + s / G] = best_d[s]; ci[U + s / G] = best_i[s]; }
+      if (s < k && gl == s % G) key[U + s / G] = best[s];
   }
   __device__ __forceinline__ int count_below(float bound2, int k) const
   {
     int c = 0;
 #pragma unroll
     for (int s = 0; s < KMAX; ++s)
-      if (s < k && best_d[s] < bound2) ++c;
+      if (s < k && key_d2(best[s]) < bound2) ++c;
     return c;
   }
 };
@@ -578,15 +589,16 @@ __device__ __forceinline__ void search_block(GroupSelect<KMAX, G, U>& sel, const
 #pragma unroll
     for (int u = 0; u < U; ++u) p[u] = nxt[u];
     if (__any(base + G * U < runs.total)) issue(base + G * U);
+    int nfresh = 0;
 #pragma unroll
     for (int u = 0; u < U; ++u)
     {
       const bool ok = base + u * G + gl < runs.total;
+      if (__any(ok)) nfresh = u + 1;
       const float dx = qx - p[u].x, dy = qy - p[u].y, dz = qz - p[u].z;
-      sel.cd[u] = ok ? (dx * dx + dy * dy) + dz * dz : INFINITY;
-      sel.ci[u] = ok ? __float_as_int(p[u].w) : 0x7fffffff;
+      sel.key[u] = ok ? make_key((dx * dx + dy * dy) + dz * dz, __float_as_int(p[u].w)) : kKeyEmpty;
     }
-    sel.select(k, gl);
+    sel.select(k, gl, nfresh);
   }
 }
 
@@ -649,7 +661,7 @@ __global__ __launch_bounds__(256) void k_knn_first(const float4* __restrict__ qu
         float ub = INFINITY;
 #pragma unroll
         for (int s = 0; s < KMAX; ++s)
-          if (s == k - 1) ub = sel.best_d[s];
+          if (s == k - 1) ub = key_d2(sel.best[s]);
         const int slot = atomicAdd(count_out, 1);
         list_out[slot] = q;
         list_pts[slot] = make_float4(qx, qy, qz, ub);
@@ -668,9 +680,9 @@ __global__ __launch_bounds__(256) void k_knn_first(const float4* __restrict__ qu
     for (int s = 0; s < KMAX; ++s)
       if (s < k)
       {
-        knn_idx[(size_t)s * cap + q] = sel.best_i[s];
-        knn_d2[(size_t)s * cap + q] = sel.best_d[s];
-        if (sel.best_i[s] != 0x7fffffff) ++cnt;
+        knn_idx[(size_t)s * cap + q] = key_idx(sel.best[s]);
+        knn_d2[(size_t)s * cap + q] = key_d2(sel.best[s]);
+        if (sel.best[s] != kKeyEmpty) ++cnt;
       }
     knn_cnt[q] = far ? kKnnFar : cnt;
   }
@@ -752,7 +764,7 @@ __global__ __launch_bounds__(256) void k_knn_second(const int* __restrict__ list
         {
 #pragma unroll
           for (int s = 0; s < KMAX; ++s)
-            if (s == k - 1) ub = sel.best_d[s];
+            if (s == k - 1) ub = key_d2(sel.best[s]);
         }
       }
       // fewer than k points inside a radius beyond the rejection distance
@@ -765,9 +777,9 @@ __global__ __launch_bounds__(256) void k_knn_second(const int* __restrict__ list
       for (int s = 0; s < KMAX; ++s)
         if (s < k)
         {
-          knn_idx[(size_t)s * cap + q] = sel.best_i[s];
-          knn_d2[(size_t)s * cap + q] = sel.best_d[s];
-          if (sel.best_i[s] != 0x7fffffff) ++cnt;
+          knn_idx[(size_t)s * cap + q] = key_idx(sel.best[s]);
+          knn_d2[(size_t)s * cap + q] = key_d2(sel.best[s]);
+          if (sel.best[s] != kKeyEmpty) ++cnt;
         }
       knn_cnt[q] = far ? kKnnFar : cnt;
     }

@@ -577,6 +577,8 @@ __device__ __forceinline__ void search_block(GroupSelect<KMAX, G, U>& sel, const
 #pragma unroll
     for (int u = 0; u < U; ++u)
     {
+      // a slot no group of the wavefront has a candidate for costs nothing (most blocks fill one or two slots)
+      if (!__any(base + u * G + gl < runs.total)) break;
       const uint32_t c = base + u * G + gl;
       const uint32_t addr = runs.locate(c);
       nxt[u] = sorted[c < runs.total ? addr : 0];

@@ -401,8 +401,24 @@ __device__ __forceinline__ void group_min(knn_key& m)
   if (G >= 4) dpp(std::integral_constant<int, 0x4E>());
   if (G >= 8) dpp(std::integral_constant<int, 0x141>());
   if (G >= 16) dpp(std::integral_constant<int, 0x140>());
-  if (G >= 32) { const knn_key o = __shfl_xor(m, 16); m = o < m ? o : m; }
-  if (G >= 64) { const knn_key o = __shfl_xor(m, 32); m = o < m ? o : m; }
+  // across rows: gfx950's v_permlane16_swap / v_permlane32_swap exchange whole rows between two registers in one
+  // VALU pass.  With the same value in both operands, the two results hold (row 0, row 0, row 2, row 2) and
+  // (row 1, row 1, row 3, row 3) -- resp. the lower and the upper half twice -- and their minimum is the exchange
+  // of the butterfly, without an LDS round trip.
+  if (G >= 32)
+  {
+    const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)(m & 0xffffffffu), (unsigned)(m & 0xffffffffu), false, false);
+    const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)(m >> 32), (unsigned)(m >> 32), false, false);
+    const knn_key a = ((knn_key)hi[0] << 32) | lo[0], b = ((knn_key)hi[1] << 32) | lo[1];
+    m = b < a ? b : a;
+  }
+  if (G >= 64)
+  {
+    const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)(m & 0xffffffffu), (unsigned)(m & 0xffffffffu), false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)(m >> 32), (unsigned)(m >> 32), false, false);
+    const knn_key a = ((knn_key)hi[0] << 32) | lo[0], b = ((knn_key)hi[1] << 32) | lo[1];
+    m = b < a ? b : a;
+  }
 }
 
 template <int KMAX, int G, int U>

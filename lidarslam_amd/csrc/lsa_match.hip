@@ -1042,6 +1042,20 @@ __device__ __forceinline__ void mv3(const double M[9], double x, double y, doubl
   oz = (M[6] * x + M[7] * y) + M[8] * z;
 }
 
+// x of this lane's half (rows) + x of the partner half (rows): first operand + second operand, as lane i < W gets
+// from a shuffle-down by W
+template <int W>
+__device__ __forceinline__ double swap_add(double x)
+{
+  const long long b = __double_as_longlong(x);
+  const unsigned xl = (unsigned)(b & 0xffffffffll), xh = (unsigned)((unsigned long long)b >> 32);
+  const auto lo = W == 32 ? __builtin_amdgcn_permlane32_swap(xl, xl, false, false) : __builtin_amdgcn_permlane16_swap(xl, xl, false, false);
+  const auto hi = W == 32 ? __builtin_amdgcn_permlane32_swap(xh, xh, false, false) : __builtin_amdgcn_permlane16_swap(xh, xh, false, false);
+  const double a = __longlong_as_double((long long)(((unsigned long long)hi[0] << 32) | lo[0]));  // lower half / even rows, everywhere
+  const double c = __longlong_as_double((long long)(((unsigned long long)hi[1] << 32) | lo[1]));  // upper half / odd rows, everywhere
+  return a + c;
+}
+
 // value of lane (i + o) of the same row of 16 lanes, 0 where that lane does not exist (o = 1, 2, 4, 8)
 __device__ __forceinline__ double dpp_row_shl(double x, int o)
 {
@@ -1118,15 +1132,13 @@ __global__ __launch_bounds__(256) void k_accumulate(AccumConst c, double* __rest
   __shared__ double wsum[4][kAccumVals];
   // one shuffle step for all 29 values at a time: 29 independent LDS permutes in flight per step
   // instead of 29 chains of 6 dependent ones
+  // across the four rows of 16 lanes: v_permlane32_swap / v_permlane16_swap (gfx950) hand every lane its partner's
+  // value in one VALU pass -- lower half + upper half, then row 0 + row 1 -- the same pairs, in the same order,
+  // as a shuffle-down by 32 and by 16 gives lane 0
 #pragma unroll
-  for (int o = 32; o >= 16; o >>= 1)
-  {
-    double tmp[kAccumVals];
+  for (int v = 0; v < kAccumVals; ++v) acc[v] = swap_add<32>(acc[v]);
 #pragma unroll
-    for (int v = 0; v < kAccumVals; ++v) tmp[v] = __shfl_down(acc[v], o);
-#pragma unroll
-    for (int v = 0; v < kAccumVals; ++v) acc[v] += tmp[v];
-  }
+  for (int v = 0; v < kAccumVals; ++v) acc[v] = swap_add<16>(acc[v]);
   // inside a row of 16 lanes the partner's value comes through a DPP operand (row_shr), not through LDS;
   // lanes the shift leaves without a partner read 0 -- only lane 0's sum is kept
 #pragma unroll

@@ -36,7 +36,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--model", type=int, default=128, help="16 VLP-16, 64 HDL-64, 128 VLS-128 (headline)")
-    ap.add_argument("--cpu-frames", type=int, default=10, help="frames of the CPU baseline sample (0 disables)")
+    ap.add_argument("--cpu-frames", type=int, default=160, help="frames of the CPU baseline sample (0 disables); 160 VLS-128 frames are about 10 s of CPU work")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = all host cores available to this process")
     ap.add_argument("--param", action="append", default=[], help="Slam parameter override NAME=VALUE (reference setter names)")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events at all")

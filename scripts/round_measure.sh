@@ -7,8 +7,8 @@ set -o pipefail
 mkdir -p gpurun_out/$R
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 python bench.py --steps 60 --warmup 10 > gpurun_out/$R/bench_vls128.json 2> gpurun_out/$R/bench_vls128.err; echo "bench128 rc=$?"
-python bench.py --steps 60 --warmup 10 --model 64 --cpu-frames 8 > gpurun_out/$R/bench_hdl64.json 2>/dev/null; echo "bench64 rc=$?"
-python bench.py --steps 60 --warmup 10 --model 16 --cpu-frames 20 > gpurun_out/$R/bench_vlp16.json 2>/dev/null; echo "bench16 rc=$?"
+python bench.py --steps 60 --warmup 10 --model 64 > gpurun_out/$R/bench_hdl64.json 2>/dev/null; echo "bench64 rc=$?"
+python bench.py --steps 60 --warmup 10 --model 16 > gpurun_out/$R/bench_vlp16.json 2>/dev/null; echo "bench16 rc=$?"
 python bench.py --steps 60 --warmup 10 --cpu-frames 0 --no-profile > gpurun_out/$R/bench_vls128_noevents.json 2>/dev/null; echo "bench128 (no events) rc=$?"
 python scripts/cpu_baseline_sweep.py 16 20 > gpurun_out/$R/cpu_sweep_vlp16.log 2>&1; echo "cpu16 rc=$?"
 python scripts/cpu_baseline_sweep.py 64 8 > gpurun_out/$R/cpu_sweep_hdl64.log 2>&1; echo "cpu64 rc=$?"

@@ -201,6 +201,8 @@ lsa_point_t* lsa_target_staging(lsa_ctx* ctx, int slot, int type, int capacity);
 int lsa_set_target_staged(lsa_ctx* ctx, int slot, int type, int m);
 int lsa_set_target_from_set(lsa_ctx* ctx, int slot, int type, int set);
 int lsa_target_size(const lsa_ctx* ctx, int slot, int type);
+/* The target's points as they were given (Slam::GetTargetSubMap, Slam.h:168): returns the number written. */
+int lsa_download_target(lsa_ctx* ctx, int slot, int type, lsa_point_t* out, int capacity);
 /* Edge length [m] of the search-grid cells used by the next lsa_set_target* of this type
  * (default 1.0; it is enlarged automatically when the grid would exceed 2^21 cells). */
 int lsa_set_target_cell_size(lsa_ctx* ctx, int slot, int type, float cell);

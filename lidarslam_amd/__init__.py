@@ -49,7 +49,7 @@ ABI_SYMBOLS = [
     "lsa_frame_store_put", "lsa_frame_store_use", "lsa_frame_size", "lsa_get_azimuthal_resolution",
     "lsa_set_azimuthal_resolution", "lsa_extract_keypoints", "lsa_set_keypoint_types", "lsa_download_keypoints", "lsa_keypoint_count",
     "lsa_download_debug", "lsa_nb_laser_rings", "lsa_transform_keypoints", "lsa_set_target", "lsa_set_target_from_set", "lsa_target_staging", "lsa_set_target_staged",
-    "lsa_target_size", "lsa_set_target_cell_size", "lsa_set_knn_lanes", "lsa_set_knn_rounds", "lsa_match_slow_queries", "lsa_match_exhaustive_queries", "lsa_set_keypoints", "lsa_match", "lsa_match_types",
+    "lsa_target_size", "lsa_download_target", "lsa_set_target_cell_size", "lsa_set_knn_lanes", "lsa_set_knn_rounds", "lsa_match_slow_queries", "lsa_match_exhaustive_queries", "lsa_set_keypoints", "lsa_match", "lsa_match_types",
     "lsa_download_match", "lsa_overlap", "lsa_accumulate", "lsa_solve", "lsa_registration_error", "lsa_selftest_math", "lsa_reset_working_keypoints", "lsa_undistort", "lsa_working_time_range",
     "lsa_working_bbox", "lsa_working_bboxes", "lsa_keypoint_bboxes_begin", "lsa_keypoint_bboxes_end", "lsa_download_transformed", "lsa_stage_transformed", "lsa_staged_transformed", "lsa_transform_frame", "lsa_profile_enable", "lsa_profile_select", "lsa_profile_reset",
     "lsa_profile_get", "lsa_slam_create", "lsa_slam_destroy", "lsa_slam_last_error", "lsa_slam_set_param",
@@ -250,6 +250,13 @@ class Context:
         if cell is not None:
             self.L.lsa_set_target_cell_size(self.h, slot, ktype, cell)
         self._check(self.L.lsa_set_target_from_set(self.h, slot, ktype, kset), "lsa_set_target_from_set")
+
+    def target(self, ktype, slot=TARGET_MAP):
+        n = self.L.lsa_target_size(self.h, slot, ktype)
+        out = np.zeros(max(n, 0), POINT_DTYPE)
+        if n > 0:
+            self._check(self.L.lsa_download_target(self.h, slot, ktype, ptr(out), n), "lsa_download_target")
+        return out
 
     def match(self, ktype, query_set, params, pose, slot=TARGET_MAP):
         hist = np.zeros(MATCH_NSTATUS, np.int32)

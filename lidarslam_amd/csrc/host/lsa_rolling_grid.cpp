@@ -14,8 +14,12 @@ namespace
 // Utils::PositionToVoxel (RollingGrid.h:39-42): round((p - origin) / resolution)
 // static_cast<int>(std::round(x)) without the libm call: truncate, then step away from zero when the
 // remainder reaches one half (x - float(t) is exact for |x| < 2^24, far above any voxel index)
+// Out-of-range values saturate (the reference's cast is undefined there): the bounding box of an empty
+// keypoint set, (+FLT_MAX, -FLT_MAX), then selects no voxel, as it does in the reference in practice.
 inline int RoundToInt(float x)
 {
+  if (!(x > -1.0e9f)) return -1000000000;
+  if (!(x < 1.0e9f)) return 1000000000;
   int t = static_cast<int>(x);
   const float d = x - static_cast<float>(t);
   if (d >= 0.5f) ++t;

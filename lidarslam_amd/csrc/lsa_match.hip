@@ -1420,6 +1420,18 @@ int lsa_set_knn_lanes(lsa_ctx* ctx, int type, int lanes)
   return LSA_OK;
 }
 
+int lsa_download_target(lsa_ctx* ctx, int slot, int type, lsa_point_t* out, int capacity)
+{
+  if (!ctx || slot < 0 || slot > 1 || type < 0 || type > 2 || !out) return ctx ? ctx->fail(LSA_E_ARG, "lsa_download_target: bad argument") : LSA_E_ARG;
+  const Target& t = ctx->target[slot * 3 + type];
+  const int n = std::min(capacity, t.m);
+  if (n <= 0) return 0;
+  LSA_HIP(ctx, hipSetDevice(ctx->device));
+  LSA_HIP(ctx, hipMemcpyAsync(out, t.pts, (size_t)n * sizeof(lsa_point_t), hipMemcpyDeviceToHost, ctx->stream));
+  LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return n;
+}
+
 int lsa_target_size(const lsa_ctx* ctx, int slot, int type) { return (ctx && slot >= 0 && slot <= 1 && type >= 0 && type <= 2) ? ctx->target[slot * 3 + type].m : LSA_E_ARG; }
 
 int lsa_set_target_cell_size(lsa_ctx* ctx, int slot, int type, float cell)

@@ -213,7 +213,9 @@ __global__ __launch_bounds__(256) void k_bbox3(KpSets sets, Rigid T, unsigned* _
     double ox, oy, oz;
     rigid_apply(T, (double)a.x, (double)a.y, (double)a.z, ox, oy, oz);
     const float v[3] = {(float)ox, (float)oy, (float)oz};
-    for (int d = 0; d < 3; ++d) lo[d] = hi[d] = f2ou(v[d]);
+    // a NaN coordinate takes no part, as in a min / max loop written with comparisons
+    for (int d = 0; d < 3; ++d)
+      if (v[d] == v[d]) lo[d] = hi[d] = f2ou(v[d]);
   }
   for (int d = 0; d < 3; ++d)
     for (int s = 32; s > 0; s >>= 1)

@@ -14,7 +14,13 @@ namespace
 inline void PositionToVoxel(const float p[3], const float origin[3], double resolution, int out[3])
 {
   const float r = (float)resolution;
-  for (int i = 0; i < 3; ++i) out[i] = (int)std::round((p[i] - origin[i]) / r);
+  for (int i = 0; i < 3; ++i)
+  {
+    // the reference casts whatever it gets; out of range (the +-FLT_MAX box of an empty cloud) that is
+    // undefined in C++ and INT_MIN on x86-64, which is stated here explicitly
+    const float v = std::round((p[i] - origin[i]) / r);
+    out[i] = (v >= -2147483648.f && v < 2147483648.f) ? (int)v : std::numeric_limits<int>::min();
+  }
 }
 inline void MinMax3D(const std::vector<Point>& c, float mn[3], float mx[3])
 {

@@ -380,6 +380,36 @@ int lsa_slam_get_match_status(lsa_slam* s, int localization, int type, uint8_t* 
 int lsa_slam_get_stats(const lsa_slam* s, double out[16]);
 lsa_ctx* lsa_slam_context(lsa_slam* s);
 
+
+/* ---- the rolling voxel map (host) ---------------------------
+ * LidarSlam::RollingGrid -- slam_lib/include/LidarSlam/RollingGrid.h:63-212,
+ * slam_lib/src/RollingGrid.cxx.  Map maintenance runs on host threads beside the
+ * device work (once per keyframe); the handle below is the class the pipeline
+ * uses, exposed so that a maintainer can swap it in on its own and so that the
+ * tests can compare it with the oracle call by call (no GPU involved).
+ * Parameter names: "GridSize", "VoxelResolution", "LeafSize",
+ * "MinFramesPerVoxel", "Sampling" (0 FIRST .. 4 CENTROID), "DecayingThreshold". */
+typedef struct lsa_rolling_grid lsa_rolling_grid;
+lsa_rolling_grid* lsa_rolling_grid_create(void);
+void lsa_rolling_grid_destroy(lsa_rolling_grid* g);
+int lsa_rolling_grid_set(lsa_rolling_grid* g, const char* name, double value);
+/* RollingGrid::Reset (position may be NULL), ::Clear, ::Size */
+void lsa_rolling_grid_reset(lsa_rolling_grid* g, const float position[3]);
+void lsa_rolling_grid_clear(lsa_rolling_grid* g);
+int lsa_rolling_grid_size(const lsa_rolling_grid* g);
+/* RollingGrid::Roll, ::Add (RollingGrid.cxx:117-318), ::ClearOldPoints */
+void lsa_rolling_grid_roll(lsa_rolling_grid* g, const float min_point[3], const float max_point[3]);
+int lsa_rolling_grid_add(lsa_rolling_grid* g, const lsa_point_t* pts, int n, int fixed, double current_time, int roll);
+void lsa_rolling_grid_clear_old_points(lsa_rolling_grid* g, double current_time);
+/* RollingGrid::Get(clean): returns the number of points written */
+int lsa_rolling_grid_get(const lsa_rolling_grid* g, int clean, lsa_point_t* out, int capacity);
+/* RollingGrid::BuildSubMapKdTree: whole map when min_point is NULL, else the
+ * bounding-box overload (RollingGrid.cxx:363-442).  Returns the sub-map size. */
+int lsa_rolling_grid_build_submap(lsa_rolling_grid* g, const float min_point[3], const float max_point[3], int min_nb_points);
+/* IsSubMapKdTreeValid / GetSubMap */
+int lsa_rolling_grid_submap_valid(const lsa_rolling_grid* g);
+int lsa_rolling_grid_submap(const lsa_rolling_grid* g, lsa_point_t* out, int capacity);
+
 /* ------------------------------------------------------------------------- */
 /* Synthetic spinning-LiDAR sequences; host only, no GPU.      */
 /* model: 16 (VLP-16, 16x1800), 64 (HDL-64, 64x2048), 128 (VLS-128, 128x2048) */

@@ -57,6 +57,9 @@ ABI_SYMBOLS = [
     "lsa_slam_get_world_transform", "lsa_slam_get_covariance", "lsa_slam_get_keypoints", "lsa_slam_get_registered_frame",
     "lsa_slam_get_match_status", "lsa_slam_get_stats", "lsa_slam_context", "lsa_synth_sensor", "lsa_synth_frame",
     "lsa_synth_pose",
+    "lsa_rolling_grid_create", "lsa_rolling_grid_destroy", "lsa_rolling_grid_set", "lsa_rolling_grid_reset", "lsa_rolling_grid_clear",
+    "lsa_rolling_grid_size", "lsa_rolling_grid_roll", "lsa_rolling_grid_add", "lsa_rolling_grid_clear_old_points", "lsa_rolling_grid_get",
+    "lsa_rolling_grid_build_submap", "lsa_rolling_grid_submap_valid", "lsa_rolling_grid_submap",
 ]
 
 
@@ -138,6 +141,25 @@ def lib():
     L.lsa_slam_get_stats.argtypes = [vp, vp]
     L.lsa_slam_context.restype = vp
     L.lsa_slam_context.argtypes = [vp]
+    L.lsa_rolling_grid_create.restype = vp
+    L.lsa_rolling_grid_create.argtypes = []
+    L.lsa_rolling_grid_destroy.argtypes = [vp]
+    L.lsa_rolling_grid_destroy.restype = None
+    L.lsa_rolling_grid_set.argtypes = [vp, C.c_char_p, f64]
+    L.lsa_rolling_grid_reset.argtypes = [vp, vp]
+    L.lsa_rolling_grid_reset.restype = None
+    L.lsa_rolling_grid_clear.argtypes = [vp]
+    L.lsa_rolling_grid_clear.restype = None
+    L.lsa_rolling_grid_size.argtypes = [vp]
+    L.lsa_rolling_grid_roll.argtypes = [vp, vp, vp]
+    L.lsa_rolling_grid_roll.restype = None
+    L.lsa_rolling_grid_add.argtypes = [vp, vp, i32, i32, f64, i32]
+    L.lsa_rolling_grid_clear_old_points.argtypes = [vp, f64]
+    L.lsa_rolling_grid_clear_old_points.restype = None
+    L.lsa_rolling_grid_get.argtypes = [vp, i32, vp, i32]
+    L.lsa_rolling_grid_build_submap.argtypes = [vp, vp, vp, i32]
+    L.lsa_rolling_grid_submap_valid.argtypes = [vp]
+    L.lsa_rolling_grid_submap.argtypes = [vp, vp, i32]
     _lib = L
     return L
 
@@ -463,3 +485,65 @@ class Slam:
 
     def context(self):
         return Context(handle=C.c_void_p(self.L.lsa_slam_context(self.h)))
+
+
+class RollingGrid:
+    """LidarSlam::RollingGrid (RollingGrid.h:63-212) as the pipeline uses it: host code, no device involved."""
+
+    def __init__(self, **params):
+        self.L = lib()
+        self.h = C.c_void_p(self.L.lsa_rolling_grid_create())
+        if not self.h:
+            raise LsaError("lsa_rolling_grid_create failed")
+        for k, v in params.items():
+            self.set(k, v)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.lsa_rolling_grid_destroy(self.h)
+            self.h = None
+
+    def set(self, name, value):
+        if self.L.lsa_rolling_grid_set(self.h, name.encode(), float(value)) != 0:
+            raise LsaError(f"lsa_rolling_grid_set({name}, {value}) refused")
+
+    def reset(self, position=None):
+        pos = None if position is None else np.ascontiguousarray(position, np.float32)
+        self.L.lsa_rolling_grid_reset(self.h, None if pos is None else ptr(pos))
+
+    def clear(self):
+        self.L.lsa_rolling_grid_clear(self.h)
+
+    def size(self):
+        return self.L.lsa_rolling_grid_size(self.h)
+
+    def roll(self, mn, mx):
+        mn, mx = np.ascontiguousarray(mn, np.float32), np.ascontiguousarray(mx, np.float32)
+        self.L.lsa_rolling_grid_roll(self.h, ptr(mn), ptr(mx))
+
+    def add(self, pts, fixed=False, time=-1.0, roll=True):
+        pts = np.ascontiguousarray(pts, POINT_DTYPE)
+        if self.L.lsa_rolling_grid_add(self.h, ptr(pts) if pts.size else None, pts.size, int(fixed), float(time), int(roll)) != 0:
+            raise LsaError("lsa_rolling_grid_add failed")
+
+    def clear_old_points(self, time):
+        self.L.lsa_rolling_grid_clear_old_points(self.h, float(time))
+
+    def get(self, clean=False):
+        out = np.zeros(max(self.size(), 1), POINT_DTYPE)
+        n = self.L.lsa_rolling_grid_get(self.h, int(clean), ptr(out), out.size)
+        return out[:n].copy()
+
+    def build_submap(self, mn=None, mx=None, min_nb_points=-1):
+        if mn is None:
+            return self.L.lsa_rolling_grid_build_submap(self.h, None, None, -1)
+        mn, mx = np.ascontiguousarray(mn, np.float32), np.ascontiguousarray(mx, np.float32)
+        return self.L.lsa_rolling_grid_build_submap(self.h, ptr(mn), ptr(mx), int(min_nb_points))
+
+    def submap_valid(self):
+        return bool(self.L.lsa_rolling_grid_submap_valid(self.h))
+
+    def submap(self):
+        out = np.zeros(max(self.size(), 1), POINT_DTYPE)
+        n = self.L.lsa_rolling_grid_submap(self.h, ptr(out), out.size)
+        return out[:n].copy()

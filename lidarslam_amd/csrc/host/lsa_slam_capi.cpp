@@ -127,4 +127,67 @@ int lsa_slam_get_stats(const lsa_slam* s, double out[16])
 
 lsa_ctx* lsa_slam_context(lsa_slam* s) { return s ? s->core.Context() : nullptr; }
 
+// ---- LidarSlam::RollingGrid on its own (include/lidarslam_amd.h, "the rolling voxel map") ----
+struct lsa_rolling_grid
+{
+  lsa::host::RollingGrid grid;
+};
+
+lsa_rolling_grid* lsa_rolling_grid_create(void) { return new (std::nothrow) lsa_rolling_grid; }
+void lsa_rolling_grid_destroy(lsa_rolling_grid* g) { delete g; }
+int lsa_rolling_grid_set(lsa_rolling_grid* g, const char* name, double value)
+{
+  if (!g || !name) return LSA_E_ARG;
+  const std::string n(name);
+  if (n == "GridSize") g->grid.SetGridSize(static_cast<int>(value));
+  else if (n == "VoxelResolution") g->grid.SetVoxelResolution(value);
+  else if (n == "LeafSize") g->grid.SetLeafSize(value);
+  else if (n == "MinFramesPerVoxel") g->grid.SetMinFramesPerVoxel(static_cast<unsigned int>(value));
+  else if (n == "Sampling")
+  {
+    if (value < 0 || value > 4) return LSA_E_ARG;
+    g->grid.SetSampling(static_cast<lsa::host::SamplingMode>(static_cast<int>(value)));
+  }
+  else if (n == "DecayingThreshold") g->grid.SetDecayingThreshold(value);
+  else return LSA_E_ARG;
+  return LSA_OK;
+}
+void lsa_rolling_grid_reset(lsa_rolling_grid* g, const float position[3]) { if (g) g->grid.Reset(position); }
+void lsa_rolling_grid_clear(lsa_rolling_grid* g) { if (g) g->grid.Clear(); }
+int lsa_rolling_grid_size(const lsa_rolling_grid* g) { return g ? static_cast<int>(g->grid.Size()) : LSA_E_ARG; }
+void lsa_rolling_grid_roll(lsa_rolling_grid* g, const float min_point[3], const float max_point[3])
+{
+  if (g && min_point && max_point) g->grid.Roll(min_point, max_point);
+}
+int lsa_rolling_grid_add(lsa_rolling_grid* g, const lsa_point_t* pts, int n, int fixed, double current_time, int roll)
+{
+  if (!g || n < 0 || (n > 0 && !pts)) return LSA_E_ARG;
+  g->grid.Add(pts, static_cast<std::size_t>(n), fixed != 0, current_time, roll != 0);
+  return LSA_OK;
+}
+void lsa_rolling_grid_clear_old_points(lsa_rolling_grid* g, double current_time) { if (g) g->grid.ClearOldPoints(current_time); }
+int lsa_rolling_grid_get(const lsa_rolling_grid* g, int clean, lsa_point_t* out, int capacity)
+{
+  if (!g || capacity < 0 || (capacity > 0 && !out)) return LSA_E_ARG;
+  const lsa::host::RollingGrid::PointCloud pc = g->grid.Get(clean != 0);
+  const int n = std::min<int>(capacity, static_cast<int>(pc.size()));
+  if (n > 0) std::memcpy(out, pc.data(), static_cast<std::size_t>(n) * sizeof(lsa_point_t));
+  return n;
+}
+int lsa_rolling_grid_build_submap(lsa_rolling_grid* g, const float min_point[3], const float max_point[3], int min_nb_points)
+{
+  if (!g || ((min_point == nullptr) != (max_point == nullptr))) return LSA_E_ARG;
+  if (min_point) g->grid.BuildSubMap(min_point, max_point, min_nb_points);
+  else g->grid.BuildSubMap();
+  return static_cast<int>(g->grid.SubMapSize());
+}
+int lsa_rolling_grid_submap_valid(const lsa_rolling_grid* g) { return g && g->grid.IsSubMapValid() ? 1 : 0; }
+int lsa_rolling_grid_submap(const lsa_rolling_grid* g, lsa_point_t* out, int capacity)
+{
+  if (!g || capacity < 0 || (capacity > 0 && !out)) return LSA_E_ARG;
+  const int n = std::min<int>(capacity, static_cast<int>(g->grid.SubMapSize()));
+  if (n > 0) std::memcpy(out, g->grid.SubMapData(), static_cast<std::size_t>(n) * sizeof(lsa_point_t));
+  return n;
+}
+
 }  // extern "C"

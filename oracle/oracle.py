@@ -68,6 +68,25 @@ def lib():
         L.orc_slam_get_match_status.argtypes = [vp, i32, i32, vp, vp, i32]
         L.orc_slam_get_stats.argtypes = [vp, vp]
         L.orc_slam_get_submap.argtypes = [vp, i32, vp, i32]
+        L.orc_grid_create.restype = vp
+        L.orc_grid_destroy.argtypes = [vp]
+        L.orc_grid_destroy.restype = None
+        L.orc_grid_set.argtypes = [vp, C.c_char_p, f64]
+        L.orc_grid_reset.argtypes = [vp, vp]
+        L.orc_grid_reset.restype = None
+        L.orc_grid_clear.argtypes = [vp]
+        L.orc_grid_clear.restype = None
+        L.orc_grid_size.argtypes = [vp]
+        L.orc_grid_roll.argtypes = [vp, vp, vp]
+        L.orc_grid_roll.restype = None
+        L.orc_grid_add.argtypes = [vp, vp, i32, i32, f64, i32]
+        L.orc_grid_add.restype = None
+        L.orc_grid_clear_old_points.argtypes = [vp, f64]
+        L.orc_grid_clear_old_points.restype = None
+        L.orc_grid_get.argtypes = [vp, i32, vp, i32]
+        L.orc_grid_build_submap.argtypes = [vp, vp, vp, i32]
+        L.orc_grid_submap_valid.argtypes = [vp]
+        L.orc_grid_submap.argtypes = [vp, vp, i32]
         _lib = L
     return _lib
 
@@ -293,4 +312,61 @@ class Slam:
     def submap(self, k, cap=4000000):
         out = np.zeros(cap, POINT_DTYPE)
         n = lib().orc_slam_get_submap(self.h, k, ptr(out), cap)
+        return out[:n].copy()
+
+
+class RollingGrid:
+    """orc::RollingGrid on its own (RollingGrid.cxx restated), same methods as lidarslam_amd.RollingGrid."""
+
+    def __init__(self, **params):
+        self.h = C.c_void_p(lib().orc_grid_create())
+        for k, v in params.items():
+            self.set(k, v)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_grid_destroy(self.h)
+            self.h = None
+
+    def set(self, name, value):
+        assert lib().orc_grid_set(self.h, name.encode(), float(value)) == 0, name
+
+    def reset(self, position=None):
+        pos = None if position is None else np.ascontiguousarray(position, np.float32)
+        lib().orc_grid_reset(self.h, None if pos is None else ptr(pos))
+
+    def clear(self):
+        lib().orc_grid_clear(self.h)
+
+    def size(self):
+        return lib().orc_grid_size(self.h)
+
+    def roll(self, mn, mx):
+        mn, mx = np.ascontiguousarray(mn, np.float32), np.ascontiguousarray(mx, np.float32)
+        lib().orc_grid_roll(self.h, ptr(mn), ptr(mx))
+
+    def add(self, pts, fixed=False, time=-1.0, roll=True):
+        pts = np.ascontiguousarray(pts, POINT_DTYPE)
+        lib().orc_grid_add(self.h, ptr(pts) if pts.size else None, pts.size, int(fixed), float(time), int(roll))
+
+    def clear_old_points(self, time):
+        lib().orc_grid_clear_old_points(self.h, float(time))
+
+    def get(self, clean=False):
+        out = np.zeros(max(self.size(), 1), POINT_DTYPE)
+        n = lib().orc_grid_get(self.h, int(clean), ptr(out), out.size)
+        return out[:n].copy()
+
+    def build_submap(self, mn=None, mx=None, min_nb_points=-1):
+        if mn is None:
+            return lib().orc_grid_build_submap(self.h, None, None, -1)
+        mn, mx = np.ascontiguousarray(mn, np.float32), np.ascontiguousarray(mx, np.float32)
+        return lib().orc_grid_build_submap(self.h, ptr(mn), ptr(mx), int(min_nb_points))
+
+    def submap_valid(self):
+        return bool(lib().orc_grid_submap_valid(self.h))
+
+    def submap(self):
+        out = np.zeros(max(self.size(), 1), POINT_DTYPE)
+        n = lib().orc_grid_submap(self.h, ptr(out), out.size)
         return out[:n].copy()

@@ -480,4 +480,54 @@ int orc_slam_get_submap(void* h, int type, lsa_point_t* out, int capacity)
   return n;
 }
 
+// ---- RollingGrid on its own (tests/test_rolling_grid.py) ----
+void* orc_grid_create() { return new RollingGrid; }
+void orc_grid_destroy(void* g) { delete (RollingGrid*)g; }
+int orc_grid_set(void* h, const char* name, double v)
+{
+  RollingGrid& g = *(RollingGrid*)h;
+  const std::string n(name);
+  if (n == "GridSize") g.SetGridSize((int)v);
+  else if (n == "VoxelResolution") g.SetVoxelResolution(v);
+  else if (n == "LeafSize") g.SetLeafSize(v);
+  else if (n == "MinFramesPerVoxel") g.SetMinFramesPerVoxel((unsigned)v);
+  else if (n == "Sampling") g.SetSampling((SamplingMode)(int)v);
+  else if (n == "DecayingThreshold") g.SetDecayingThreshold(v);
+  else return -1;
+  return 0;
+}
+void orc_grid_reset(void* g, const float* position) { ((RollingGrid*)g)->Reset(position); }
+void orc_grid_clear(void* g) { ((RollingGrid*)g)->Clear(); }
+int orc_grid_size(void* g) { return (int)((RollingGrid*)g)->Size(); }
+void orc_grid_roll(void* g, const float* mn, const float* mx) { ((RollingGrid*)g)->Roll(mn, mx); }
+void orc_grid_add(void* g, const lsa_point_t* pts, int n, int fixed, double time, int roll)
+{
+  std::vector<Point> pc(n);
+  if (n > 0) std::memcpy(pc.data(), pts, (size_t)n * sizeof(Point));
+  ((RollingGrid*)g)->Add(pc, fixed != 0, time, roll != 0);
+}
+void orc_grid_clear_old_points(void* g, double time) { ((RollingGrid*)g)->ClearOldPoints(time); }
+int orc_grid_get(void* g, int clean, lsa_point_t* out, int capacity)
+{
+  const std::vector<Point> pc = ((RollingGrid*)g)->Get(clean != 0);
+  const int n = std::min<int>(capacity, pc.size());
+  if (n > 0) std::memcpy(out, pc.data(), (size_t)n * sizeof(Point));
+  return n;
+}
+int orc_grid_build_submap(void* h, const float* mn, const float* mx, int minNbPoints)
+{
+  RollingGrid& g = *(RollingGrid*)h;
+  if (mn) g.BuildSubMapKdTree(mn, mx, minNbPoints);
+  else g.BuildSubMapKdTree();
+  return (int)g.GetSubMap().size();
+}
+int orc_grid_submap_valid(void* g) { return ((RollingGrid*)g)->IsSubMapKdTreeValid() ? 1 : 0; }
+int orc_grid_submap(void* g, lsa_point_t* out, int capacity)
+{
+  const std::vector<Point>& m = ((RollingGrid*)g)->GetSubMap();
+  const int n = std::min<int>(capacity, m.size());
+  if (n > 0) std::memcpy(out, m.data(), (size_t)n * sizeof(Point));
+  return n;
+}
+
 }  // extern "C"

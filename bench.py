@@ -20,6 +20,7 @@ import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -41,6 +42,8 @@ def parse():
     ap.add_argument("--param", action="append", default=[], help="Slam parameter override NAME=VALUE (reference setter names)")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events at all")
     ap.add_argument("--host-frames", action="store_true", help="hand every scan over from a host buffer (PCIe inclusive; never the headline value)")
+    ap.add_argument("--sequences-per-gpu", type=int, default=1, help="independent sequences replayed side by side on every GPU (the headline is 1: BASELINE.json shards 1 per GPU)")
+    ap.add_argument("--batch-sequences", type=int, default=4, help="N=1 only: extra leg with this many sequences side by side on the GPU, reported as batch_replay (0 disables)")
     ap.add_argument("--profile-all", action="store_true", help="time every scope in the timed region too (costs ~10 %% of the frame rate)")
     return ap.parse_args()
 
@@ -85,15 +88,59 @@ def main():
         npts += pts.size
     ctx = slam.context()
 
+    # further sequences of this rank (--sequences-per-gpu): a Slam, a context and a host thread each, free-running
+    # beside the first one between the same start and end barriers; their latest poses travel with the first one's
+    per_gpu = max(args.sequences_per_gpu, 1)
+    latest = np.zeros((per_gpu, 17))
+    latest_lock = threading.Lock()
+    others, gate = [], threading.Barrier(per_gpu)
+    for s in range(1, per_gpu):
+        o = L.Slam(local_rank, EgoMotion=3)
+        for kv in args.param:
+            name, value = kv.split("=")
+            o.set_param(name, float(value))
+        st = []
+        for f in range(total):
+            pts, stamp = L.synth_frame(args.model, sequence_seed(rank * per_gpu + s), f)
+            o.store_frame(f, pts)
+            st.append(stamp)
+            npts += pts.size
+        others.append((o, st))
+
+    def publish(s, o, stamp):
+        with latest_lock:
+            latest[s, :16] = np.asarray(o.world_transform()).reshape(16)
+            latest[s, 16] = stamp * 1e-6
+
+    def follow(s, o, st):
+        try:
+            for f in range(total):
+                if f == args.warmup:
+                    gate.wait()
+                o.add_stored_frame(f, st[f], f)
+                publish(s, o, st[f])
+            o.context().sync()
+        except BaseException:
+            gate.abort()  # the first sequence then stops with BrokenBarrierError instead of waiting for ever
+            raise
+        gate.wait()
+
+    followers = [threading.Thread(target=follow, args=(s + 1, o, st), daemon=True) for s, (o, st) in enumerate(others)]
+
     # RCCL pose broadcast of the north star: every rank ends up with every sequence's pose table
-    exchange = PoseExchange(world, device="cuda")
+    exchange = PoseExchange(world, device="cuda", per_rank=per_gpu)
 
     def step(f):
         if args.host_frames:
             slam.add_frame(host_frames[f], stamps[f], f)
         else:
             slam.add_stored_frame(f, stamps[f], f)
-        return exchange.post(slam.world_transform(), stamps[f] * 1e-6) if distributed else None
+        if not distributed:
+            return None
+        publish(0, slam, stamps[f])
+        with latest_lock:
+            rows = latest.copy()
+        return exchange.post_rows(rows)
 
     # Warm-up frames carry HIP events around every scope: that gives the per-kernel table and names the dominant
     # kernel.  Events cost a few microseconds each on a launch-bound path, so the timed region only keeps them on
@@ -102,6 +149,8 @@ def main():
     if not args.no_profile:
         ctx.profile(True)
         ctx.profile_reset()
+    for t in followers:
+        t.start()
     for f in range(args.warmup):
         h = step(f)
         if h is not None:
@@ -123,6 +172,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     ctx.sync()
+    gate.wait()  # the other sequences of this rank have finished their warm-up frames too
     t0 = time.perf_counter()
     pending = None
     for f in range(args.warmup, total):
@@ -134,10 +184,15 @@ def main():
     if pending is not None:
         pending.wait()
     ctx.sync()
+    gate.wait()  # ... and their timed frames
     torch.cuda.synchronize()
     if distributed:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    for t in followers:
+        t.join()
+    for o, _ in others:
+        o.close()
     if distributed:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -149,7 +204,7 @@ def main():
     if rank == 0:
         out = {
             "metric": "LiDAR frames/sec (AddFrame end-to-end), VLS-128 scan" if args.model == 128 else f"LiDAR frames/sec (AddFrame end-to-end), model {args.model}",
-            "value": world * args.steps / elapsed,
+            "value": world * per_gpu * args.steps / elapsed,
             "unit": "frames/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -163,9 +218,9 @@ def main():
             "config": {
                 "workload": {128: "VLS-128", 64: "HDL-64", 16: "VLP-16"}.get(args.model, str(args.model))
                 + " synthetic spinning scan, street canyon, 5 m/s, EgoMotion=MOTION_EXTRAPOLATION_AND_REGISTRATION, Undistortion=REFINED, library defaults",
-                "points_per_frame": npts // total,
-                "sequences": world,
-                "parallelism": f"1 sequence per GPU x {world}, RCCL all-gather of poses",
+                "points_per_frame": npts // (total * per_gpu),
+                "sequences": world * per_gpu,
+                "parallelism": f"{per_gpu} sequence{'s' if per_gpu > 1 else ''} per GPU x {world}, RCCL all-gather of poses",
                 "frames_resident_in_hbm": not args.host_frames,
             },
         }
@@ -208,11 +263,30 @@ def main():
             }
         if world == 1 and args.cpu_frames > 0:
             out["cpu_baseline"] = cpu_baseline(args, seed)
-        print(json.dumps(out), flush=True)
     slam.close()
+    if rank == 0:
+        if world == 1 and per_gpu == 1 and args.batch_sequences > 1 and not args.host_frames:
+            out["batch_replay"] = batch_replay(args, local_rank)
+        print(json.dumps(out), flush=True)
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def batch_replay(args, device):
+    """Not the headline: the same GPU replaying several independent sequences side by side (seeds 1000, 1001, ...),
+    same frames per sequence as the timed region above, aggregate frames/s between a common start and the last end."""
+    from lidarslam_amd.replay import ConcurrentReplay, sequence_seed
+
+    n = args.batch_sequences
+    rep = ConcurrentReplay(device, args.model, [sequence_seed(s) for s in range(n)], args.warmup + args.steps, EgoMotion=3)
+    for kv in args.param:
+        name, value = kv.split("=")
+        for s in rep.slams:
+            s.set_param(name, float(value))
+    fps = rep.run(args.warmup)
+    rep.close()
+    return {"sequences_on_one_gpu": n, "value": fps, "unit": "frames/s", "per_sequence": fps / n, "steps": args.steps, "warmup": args.warmup}
 
 
 # profiling scope -> device kernel, for looking a scope up in the committed PMC table

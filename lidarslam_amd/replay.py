@@ -20,15 +20,16 @@ def sequence_seed(rank, base=1000):
 class PoseExchange:
     """All-gathers the latest pose of every sequence.  `device` is 'cuda' (RCCL) or 'cpu' (gloo)."""
 
-    def __init__(self, world, device="cuda"):
+    def __init__(self, world, device="cuda", per_rank=1):
         import torch
 
         self.torch = torch
         self.world = world
         self.device = device
-        self.mine = torch.zeros(POSE_WORDS, dtype=torch.float64, device=device)
-        self.table = torch.zeros(POSE_WORDS * world, dtype=torch.float64, device=device)
-        self.host = torch.zeros(POSE_WORDS, dtype=torch.float64)
+        self.per_rank = per_rank  # sequences replayed side by side on one GPU: their poses travel together
+        self.mine = torch.zeros(POSE_WORDS * per_rank, dtype=torch.float64, device=device)
+        self.table = torch.zeros(POSE_WORDS * per_rank * world, dtype=torch.float64, device=device)
+        self.host = torch.zeros(POSE_WORDS * per_rank, dtype=torch.float64)
         self.side = None
         if device == "cuda":
             self.host = self.host.pin_memory()
@@ -36,14 +37,20 @@ class PoseExchange:
 
     def post(self, pose4x4, stamp_s):
         """Starts the exchange of this rank's pose; returns a work handle (None when world == 1)."""
+        row = np.empty(POSE_WORDS)
+        row[:16] = np.ascontiguousarray(pose4x4, np.float64).reshape(16)
+        row[16] = stamp_s
+        return self.post_rows(row)
+
+    def post_rows(self, rows):
+        """Same for the (per_rank, 17) latest pose rows of all the sequences this rank replays."""
+        rows = self.torch.from_numpy(np.ascontiguousarray(rows, np.float64).reshape(POSE_WORDS * self.per_rank))
         if self.world == 1:
-            self.table[:16] = self.torch.from_numpy(np.ascontiguousarray(pose4x4, np.float64).reshape(16))
-            self.table[16] = stamp_s
+            self.table.copy_(rows)
             return None
         import torch.distributed as dist
 
-        self.host[:16] = self.torch.from_numpy(np.ascontiguousarray(pose4x4, np.float64).reshape(16))
-        self.host[16] = stamp_s
+        self.host.copy_(rows)
         if self.side is not None:
             with self.torch.cuda.stream(self.side):
                 self.mine.copy_(self.host, non_blocking=True)
@@ -52,6 +59,77 @@ class PoseExchange:
         return dist.all_gather_into_tensor(self.table, self.mine, async_op=True)
 
     def poses(self):
-        """(world, 4, 4) poses and (world,) stamps of the last completed exchange."""
-        t = self.table.detach().cpu().numpy().reshape(self.world, POSE_WORDS)
-        return t[:, :16].reshape(self.world, 4, 4).copy(), t[:, 16].copy()
+        """(sequences, 4, 4) poses and (sequences,) stamps of the last completed exchange, rank-major."""
+        n = self.world * self.per_rank
+        t = self.table.detach().cpu().numpy().reshape(n, POSE_WORDS)
+        return t[:, :16].reshape(n, 4, 4).copy(), t[:, 16].copy()
+
+
+class ConcurrentReplay:
+    """Replays several independent sequences side by side on ONE device: a Slam, a context and a host thread
+    each.  One sequence is a chain of small dependent kernels and host hand-overs that leaves most of the chip
+    idle; independent sequences fill it.  Every thread drives its own handle, the library keeps no
+    state outside of the handles, and the results are those of a lone run bit for bit (tests/test_gpu_pipeline.py)."""
+
+    def __init__(self, device, model, seeds, frames, **params):
+        import lidarslam_amd as L
+
+        self.frames = frames
+        self.slams, self.stamps = [], []
+        for seed in seeds:
+            slam = L.Slam(device, **params)
+            st = []
+            for f in range(frames):
+                pts, stamp = L.synth_frame(model, seed, f)
+                slam.store_frame(f, pts)
+                st.append(stamp)
+            self.slams.append(slam)
+            self.stamps.append(st)
+        self.poses = np.zeros((len(seeds), frames, 4, 4))
+
+    def run(self, warmup):
+        """Untimed frames [0, warmup), then the rest timed from a common start to the last sequence's end.
+        Returns the aggregate frames/s."""
+        import threading
+        import time
+
+        if not 0 <= warmup < self.frames:
+            raise ValueError("warmup must leave at least one timed frame")
+        n = len(self.slams)
+        gate = threading.Barrier(n + 1)
+        errors = []
+
+        def worker(s):
+            try:
+                for f in range(self.frames):
+                    if f == warmup:
+                        gate.wait()
+                    self.slams[s].add_stored_frame(f, self.stamps[s][f], f)
+                    self.poses[s, f] = self.slams[s].world_transform()
+                self.slams[s].context().sync()
+            except Exception as e:  # a failed sequence must not leave the others waiting
+                errors.append(e)
+                gate.abort()
+                return
+            gate.wait()
+
+        threads = [threading.Thread(target=worker, args=(s,)) for s in range(n)]
+        for t in threads:
+            t.start()
+        try:
+            gate.wait()
+            t0 = time.perf_counter()
+            gate.wait()
+            dt = time.perf_counter() - t0
+        except threading.BrokenBarrierError:
+            dt = float("nan")
+        for t in threads:
+            t.join()
+        if errors:
+            raise errors[0]
+        return n * (self.frames - warmup) / dt
+
+    def close(self):
+        for s in self.slams:
+            s.close()
+        self.slams = []

@@ -375,3 +375,28 @@ def test_wire_format_upload_follows_the_driver_node(O, L):
             assert same_points(ctx.transform_frame(eye), want)
     finally:
         ctx.close()
+
+
+@pytest.mark.gpu
+def test_sequences_side_by_side_on_one_gpu_reproduce_lone_runs():
+    """Batch replay with several sequences per GPU (replay.ConcurrentReplay, bench.py --sequences-per-gpu): every
+    sequence has its own handle and host thread, and nothing is shared between handles -- the poses of each one
+    are those of a lone run, bit for bit, whatever the interleaving on the device."""
+    from lidarslam_amd.replay import ConcurrentReplay
+
+    frames = 10
+    lone = []
+    for seed in (1000, 1001, 1002):
+        rep = ConcurrentReplay(0, 16, [seed], frames, EgoMotion=3)
+        rep.run(2)
+        lone.append(rep.poses[0].copy())
+        rep.close()
+    rep = ConcurrentReplay(0, 16, [1000, 1001, 1002, 1000], frames, EgoMotion=3)
+    fps = rep.run(2)
+    assert fps > 0
+    for s, ref in enumerate([lone[0], lone[1], lone[2], lone[0]]):
+        assert np.array_equal(rep.poses[s], ref), s
+    assert not np.array_equal(lone[0][-1], lone[1][-1])
+    rep.close()
+    with pytest.raises(ValueError):
+        ConcurrentReplay(0, 16, [1000], 2, EgoMotion=3).run(2)

@@ -62,6 +62,39 @@ def test_two_rank_pose_exchange(tmp_path):
     assert np.allclose(r0["stamps"], 0.3)
 
 
+def _worker_two_per_rank(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+
+    from lidarslam_amd.replay import POSE_WORDS, PoseExchange
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ex = PoseExchange(world, device="cpu", per_rank=2)
+    rows = np.zeros((2, POSE_WORDS))
+    for s in range(2):
+        T = np.eye(4)
+        T[0, 3] = 10 * rank + s
+        rows[s, :16], rows[s, 16] = T.reshape(16), 0.1 * (2 * rank + s)
+    ex.post_rows(rows).wait()
+    poses, stamps = ex.poses()
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), poses=poses, stamps=stamps)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_with_two_sequences_each(tmp_path):
+    """--sequences-per-gpu 2: the table is rank-major, (world x per_rank) rows"""
+    import torch.multiprocessing as mp
+
+    mp.spawn(_worker_two_per_rank, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    assert np.array_equal(r0["poses"], r1["poses"]) and np.array_equal(r0["stamps"], r1["stamps"])
+    assert r0["poses"].shape == (4, 4, 4)
+    assert r0["poses"][:, 0, 3].tolist() == [0.0, 1.0, 10.0, 11.0]
+    assert np.allclose(r0["stamps"], [0.0, 0.1, 0.2, 0.3])
+
+
 def test_sequence_sharding_is_by_rank():
     sys.path.insert(0, ROOT)
     from lidarslam_amd.replay import sequence_seed

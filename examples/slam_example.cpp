@@ -16,6 +16,10 @@ int main(int argc, char** argv)
     LidarSlam::Slam slam;
     slam.SetEgoMotion(LidarSlam::EgoMotionMode::MOTION_EXTRAPOLATION_AND_REGISTRATION);
     slam.SetNbThreads(4);  // accepted and ignored
+    slam.SetLoggingTimeout(-1.);  // keep the whole trajectory
+    slam.SetTimeWindowDuration(0.25f);
+    slam.SetVelocityLimits({{2.f, 1000.f}});  // the synthetic sensor drives at 5 m/s: not compliant
+    LidarSlam::Slam::PointCloud::Ptr last;
     for (int f = 0; f < nframes; ++f)
     {
       LidarSlam::Slam::PointCloud::Ptr pc(new LidarSlam::Slam::PointCloud);
@@ -29,7 +33,24 @@ int main(int argc, char** argv)
       slam.AddFrame(pc);
       const LidarSlam::Transform T = slam.GetWorldTransform();
       std::printf("%d %.12f %.12f %.12f %d\n", f, T.x(), T.y(), T.z(), (int)slam.GetKeypoints(LidarSlam::PLANE)->size());
+      last = pc;
     }
+    // the rest of the result getters (Slam.h:141-189) and the stand-alone extractor (SSKE.h:38-88)
+    const auto traj = slam.GetTrajectory();
+    std::printf("# trajectory %d %d %.12f\n", (int)traj.size(), (int)slam.GetCovariances().size(), traj.empty() ? 0. : traj.back().x());
+    std::printf("# maps %d %d\n", (int)slam.GetMap(LidarSlam::EDGE)->size(), (int)slam.GetMap(LidarSlam::PLANE)->size());
+    std::printf("# submaps %d %d\n", (int)slam.GetTargetSubMap(LidarSlam::EDGE)->size(), (int)slam.GetTargetSubMap(LidarSlam::PLANE)->size());
+    const auto info = slam.GetDebugInformation();
+    std::printf("# used %d %d %d %d\n", (int)info.at("EgoMotion: edges used"), (int)info.at("EgoMotion: planes used"),
+                (int)info.at("Localization: edges used"), (int)info.at("Localization: planes used"));
+    std::printf("# comply %d\n", slam.GetComplyMotionLimits() ? 1 : 0);
+    const LidarSlam::Transform ahead = slam.GetLatencyCompensatedWorldTransform();
+    std::printf("# ahead %.12f %.12f\n", ahead.x(), slam.GetLatency());
+    LidarSlam::SpinningSensorKeypointExtractor ke;
+    ke.ComputeKeyPoints(last);
+    const auto dbg = ke.GetDebugArray();
+    std::printf("# extractor %d %d %d %d %d\n", (int)ke.GetKeypoints(LidarSlam::EDGE)->size(), (int)ke.GetKeypoints(LidarSlam::PLANE)->size(),
+                ke.GetNbLaserRings(), (int)dbg.at("sin_angle").size(), (int)dbg.size());
   }
   catch (const std::exception& e)
   {

@@ -212,6 +212,14 @@ int lsa_set_knn_lanes(lsa_ctx* ctx, int type, int lanes);
 /* ... and the number of rounds of that kernel (2: blocks of 3^3 and 5^3 cells; 3: also 7^3) before a query is
  * handed to the second kernel. */
 int lsa_set_knn_rounds(lsa_ctx* ctx, int type, int rounds);
+
+/* MatchingResults::NbMatches() and the rejection histogram of an earlier match
+ * (KeypointsMatcher.h:100-122) without reading anything back on the frame's
+ * critical path: lsa_match_serial names the last match enqueued for a type, and
+ * lsa_match_histogram reads that match's histogram later (it waits for the stream).
+ * The device keeps the last 16 matches of every type. */
+long long lsa_match_serial(const lsa_ctx* ctx, int type);
+int lsa_match_histogram(lsa_ctx* ctx, int type, long long serial, int histogram[LSA_MATCH_NSTATUS]);
 /* Diagnostics: queries of the last lsa_match that the first kNN kernel handed to the second stage. */
 int lsa_match_slow_queries(lsa_ctx* ctx);
 /* ... and those of them that ended up scanning the whole target. */
@@ -378,6 +386,28 @@ int lsa_slam_get_match_status(lsa_slam* s, int localization, int type, uint8_t* 
  * [11] lm_evals, [12] total matched, [13] keyframe counter, [14] wait for the
  * previous keyframe's asynchronous map insertion, [15] duration of that insertion. */
 int lsa_slam_get_stats(const lsa_slam* s, double out[16]);
+
+/* The remaining result getters of Slam.h:141-189.
+ * - GetLatencyCompensatedWorldTransform (Slam.cxx:555-590): the last pose extrapolated by the duration of the last
+ *   AddFrame (parameter "Latency").
+ * - SetWorldTransformFromGuess (Slam.cxx:490-501).
+ * - GetTrajectory / GetCovariances (Slam.cxx:593-605): rows of 17 doubles (row-major 4x4 + time [s]) and of 36;
+ *   either pointer may be NULL; returns the number of logged poses (parameter "LoggingTimeout": 0 keeps two).
+ * - GetDebugInformation (Slam.cxx:610-633): [0..1] ego-motion edges / planes used, [2..4] localization edges /
+ *   planes / blobs used, [5] position error, [6] orientation error, [7] overlap, [8] comply motion limits,
+ *   [9] latency [s].
+ * - GetMap(k, clean) / GetTargetSubMap(k) (Slam.cxx:670-688): return the full size, write at most capacity points. */
+int lsa_slam_get_latency_compensated_world_transform(const lsa_slam* s, double T[16], double* time);
+/* Slam::SetBaseToLidarOffset / GetBaseToLidarOffset (Slam.h:249-250, Slam.cxx:1540-1575): rigid transform from the
+ * sensor to the BASE frame, applied to the keypoints after the extraction.  One LiDAR device per Slam in this
+ * round: device_id must be 0. */
+int lsa_slam_set_base_to_lidar_offset(lsa_slam* s, const double T[16], int device_id);
+int lsa_slam_get_base_to_lidar_offset(const lsa_slam* s, double T[16], int device_id);
+int lsa_slam_set_world_transform_from_guess(lsa_slam* s, const double T[16]);
+int lsa_slam_get_trajectory(const lsa_slam* s, double* poses, double* covariances, int capacity);
+int lsa_slam_get_debug_information(lsa_slam* s, double out[10]);
+int lsa_slam_get_map(lsa_slam* s, int type, int clean, lsa_point_t* out, int capacity);
+int lsa_slam_get_target_submap(lsa_slam* s, int type, lsa_point_t* out, int capacity);
 lsa_ctx* lsa_slam_context(lsa_slam* s);
 
 

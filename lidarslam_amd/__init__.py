@@ -38,6 +38,12 @@ __all__ = ["Context", "Slam", "ExtractParams", "MatchParams", "POINT_DTYPE", "li
 
 TARGET_MAP, TARGET_PREVIOUS = 0, 1
 
+DEBUG_INFORMATION_NAMES = [
+    "EgoMotion: edges used", "EgoMotion: planes used", "Localization: edges used", "Localization: planes used",
+    "Localization: blobs used", "Localization: position error", "Localization: orientation error",
+    "Confidence: overlap", "Confidence: comply motion limits", "latency",
+]
+
 DEBUG_NAMES = [
     "sin_angle", "saliency", "depth_gap", "intensity_gap", "edge_keypoint", "plane_keypoint", "blob_keypoint",
     "edge_validity", "plane_validity", "blob_validity",
@@ -55,7 +61,9 @@ ABI_SYMBOLS = [
     "lsa_profile_get", "lsa_slam_create", "lsa_slam_destroy", "lsa_slam_last_error", "lsa_slam_set_param",
     "lsa_slam_get_param", "lsa_slam_reset", "lsa_slam_add_frame", "lsa_slam_store_frame", "lsa_slam_add_stored_frame",
     "lsa_slam_get_world_transform", "lsa_slam_get_covariance", "lsa_slam_get_keypoints", "lsa_slam_get_registered_frame",
-    "lsa_slam_get_match_status", "lsa_slam_get_stats", "lsa_slam_context", "lsa_synth_sensor", "lsa_synth_frame",
+    "lsa_slam_get_match_status", "lsa_slam_get_stats", "lsa_slam_context", "lsa_slam_get_latency_compensated_world_transform",
+    "lsa_slam_set_world_transform_from_guess", "lsa_slam_get_trajectory", "lsa_slam_get_debug_information", "lsa_slam_get_map",
+    "lsa_slam_get_target_submap", "lsa_slam_set_base_to_lidar_offset", "lsa_slam_get_base_to_lidar_offset", "lsa_match_serial", "lsa_match_histogram", "lsa_synth_sensor", "lsa_synth_frame",
     "lsa_synth_pose",
     "lsa_rolling_grid_create", "lsa_rolling_grid_destroy", "lsa_rolling_grid_set", "lsa_rolling_grid_reset", "lsa_rolling_grid_clear",
     "lsa_rolling_grid_size", "lsa_rolling_grid_roll", "lsa_rolling_grid_add", "lsa_rolling_grid_clear_old_points", "lsa_rolling_grid_get",
@@ -141,6 +149,17 @@ def lib():
     L.lsa_slam_get_stats.argtypes = [vp, vp]
     L.lsa_slam_context.restype = vp
     L.lsa_slam_context.argtypes = [vp]
+    L.lsa_slam_get_latency_compensated_world_transform.argtypes = [vp, vp, vp]
+    L.lsa_slam_set_world_transform_from_guess.argtypes = [vp, vp]
+    L.lsa_slam_get_trajectory.argtypes = [vp, vp, vp, i32]
+    L.lsa_slam_set_base_to_lidar_offset.argtypes = [vp, vp, i32]
+    L.lsa_slam_get_base_to_lidar_offset.argtypes = [vp, vp, i32]
+    L.lsa_slam_get_debug_information.argtypes = [vp, vp]
+    L.lsa_slam_get_map.argtypes = [vp, i32, i32, vp, i32]
+    L.lsa_slam_get_target_submap.argtypes = [vp, i32, vp, i32]
+    L.lsa_match_serial.restype = C.c_longlong
+    L.lsa_match_serial.argtypes = [vp, i32]
+    L.lsa_match_histogram.argtypes = [vp, i32, C.c_longlong, vp]
     L.lsa_rolling_grid_create.restype = vp
     L.lsa_rolling_grid_create.argtypes = []
     L.lsa_rolling_grid_destroy.argtypes = [vp]
@@ -459,6 +478,52 @@ class Slam:
         c = np.zeros((6, 6))
         self.L.lsa_slam_get_covariance(self.h, ptr(c))
         return c
+
+    def latency_compensated_world_transform(self):
+        T = np.zeros(16)
+        t = C.c_double()
+        self._check(self.L.lsa_slam_get_latency_compensated_world_transform(self.h, ptr(T), C.byref(t)), "latency compensated transform")
+        return T.reshape(4, 4)
+
+    def set_world_transform_from_guess(self, T):
+        T = np.ascontiguousarray(T, np.float64).reshape(16)
+        self._check(self.L.lsa_slam_set_world_transform_from_guess(self.h, ptr(T)), "lsa_slam_set_world_transform_from_guess")
+
+    def set_base_to_lidar_offset(self, T, device_id=0):
+        T = np.ascontiguousarray(T, np.float64).reshape(16)
+        self._check(self.L.lsa_slam_set_base_to_lidar_offset(self.h, ptr(T), device_id), "lsa_slam_set_base_to_lidar_offset")
+
+    def base_to_lidar_offset(self, device_id=0):
+        T = np.zeros(16)
+        self._check(self.L.lsa_slam_get_base_to_lidar_offset(self.h, ptr(T), device_id), "lsa_slam_get_base_to_lidar_offset")
+        return T.reshape(4, 4)
+
+    def trajectory(self):
+        """Slam::GetTrajectory / GetCovariances: (n, 4, 4) poses, (n,) times [s], (n, 6, 6) covariances"""
+        n = self._check(self.L.lsa_slam_get_trajectory(self.h, None, None, 0), "lsa_slam_get_trajectory")
+        rows, cov = np.zeros((max(n, 1), 17)), np.zeros((max(n, 1), 36))
+        self.L.lsa_slam_get_trajectory(self.h, ptr(rows), ptr(cov), n)
+        return rows[:n, :16].reshape(n, 4, 4).copy(), rows[:n, 16].copy(), cov[:n].reshape(n, 6, 6).copy()
+
+    def debug_information(self):
+        """Slam::GetDebugInformation with the reference's keys (+ "latency")"""
+        o = np.zeros(10)
+        self._check(self.L.lsa_slam_get_debug_information(self.h, ptr(o)), "lsa_slam_get_debug_information")
+        return dict(zip(DEBUG_INFORMATION_NAMES, o.tolist()))
+
+    def map(self, ktype, clean=False):
+        """Slam::GetMap(k, clean)"""
+        n = self._check(self.L.lsa_slam_get_map(self.h, ktype, int(clean), None, 0), "lsa_slam_get_map")
+        out = np.zeros(max(n, 1), POINT_DTYPE)
+        n = self.L.lsa_slam_get_map(self.h, ktype, int(clean), ptr(out), out.size)
+        return out[:n].copy()
+
+    def target_submap(self, ktype):
+        """Slam::GetTargetSubMap(k)"""
+        n = self._check(self.L.lsa_slam_get_target_submap(self.h, ktype, None, 0), "lsa_slam_get_target_submap")
+        out = np.zeros(max(n, 1), POINT_DTYPE)
+        n = self.L.lsa_slam_get_target_submap(self.h, ktype, ptr(out), out.size)
+        return out[:n].copy()
 
     def keypoints(self, ktype, which=0, cap=400000):
         """which: 0 undistorted BASE, 1 WORLD, 2 raw BASE."""

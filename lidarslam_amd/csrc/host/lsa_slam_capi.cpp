@@ -125,6 +125,85 @@ int lsa_slam_get_stats(const lsa_slam* s, double out[16])
   return LSA_OK;
 }
 
+// ---- the remaining result getters of Slam.h:141-189 ----
+int lsa_slam_get_latency_compensated_world_transform(const lsa_slam* s, double T[16], double* time)
+{
+  if (!s || !T) return LSA_E_ARG;
+  const lsa::host::Pose p = s->core.GetLatencyCompensatedWorldTransform(time);
+  std::memcpy(T, p.m, sizeof(p.m));
+  return LSA_OK;
+}
+
+int lsa_slam_set_base_to_lidar_offset(lsa_slam* s, const double T[16], int device_id)
+{
+  if (!s || !T || device_id != 0) return LSA_E_ARG;
+  std::memcpy(s->core.BaseToLidarOffset.m, T, 16 * sizeof(double));
+  return LSA_OK;
+}
+
+int lsa_slam_get_base_to_lidar_offset(const lsa_slam* s, double T[16], int device_id)
+{
+  if (!s || !T || device_id != 0) return LSA_E_ARG;
+  std::memcpy(T, s->core.BaseToLidarOffset.m, 16 * sizeof(double));
+  return LSA_OK;
+}
+
+int lsa_slam_set_world_transform_from_guess(lsa_slam* s, const double T[16])
+{
+  if (!s || !T) return LSA_E_ARG;
+  lsa::host::Pose p;
+  std::memcpy(p.m, T, sizeof(p.m));
+  return s->core.SetWorldTransformFromGuess(p);
+}
+
+int lsa_slam_get_trajectory(const lsa_slam* s, double* poses, double* covariances, int capacity)
+{
+  if (!s || capacity < 0) return LSA_E_ARG;
+  const auto& traj = s->core.LogTrajectory;
+  const auto& covs = s->core.LogCovariances;
+  const int n = static_cast<int>(traj.size());
+  for (int i = 0; i < std::min(n, capacity); ++i)
+  {
+    if (poses)
+    {
+      std::memcpy(poses + 17 * i, traj[i].pose.m, 16 * sizeof(double));
+      poses[17 * i + 16] = traj[i].time;
+    }
+    if (covariances)
+    {
+      // the covariances are logged only while LoggingTimeout != 0, newest last like the poses
+      const long j = static_cast<long>(covs.size()) - n + i;
+      if (j >= 0) std::memcpy(covariances + 36 * i, covs[j].data(), 36 * sizeof(double));
+      else std::memset(covariances + 36 * i, 0, 36 * sizeof(double));
+    }
+  }
+  return n;
+}
+
+int lsa_slam_get_debug_information(lsa_slam* s, double out[10])
+{
+  if (!s || !out) return LSA_E_ARG;
+  return s->core.GetDebugInformation(out);
+}
+
+int lsa_slam_get_map(lsa_slam* s, int type, int clean, lsa_point_t* out, int capacity)
+{
+  if (!s || type < 0 || type > 2 || capacity < 0 || (capacity > 0 && !out)) return LSA_E_ARG;
+  const lsa::host::RollingGrid::PointCloud pc = s->core.Map(type).Get(clean != 0);
+  const int n = static_cast<int>(pc.size());
+  if (std::min(n, capacity) > 0) std::memcpy(out, pc.data(), static_cast<size_t>(std::min(n, capacity)) * sizeof(lsa_point_t));
+  return n;
+}
+
+int lsa_slam_get_target_submap(lsa_slam* s, int type, lsa_point_t* out, int capacity)
+{
+  if (!s || type < 0 || type > 2 || capacity < 0 || (capacity > 0 && !out)) return LSA_E_ARG;
+  const lsa::host::RollingGrid& map = s->core.Map(type);
+  const int n = static_cast<int>(map.SubMapSize());
+  if (std::min(n, capacity) > 0) std::memcpy(out, map.SubMapData(), static_cast<size_t>(std::min(n, capacity)) * sizeof(lsa_point_t));
+  return n;
+}
+
 lsa_ctx* lsa_slam_context(lsa_slam* s) { return s ? s->core.Context() : nullptr; }
 
 // ---- LidarSlam::RollingGrid on its own (include/lidarslam_amd.h, "the rolling voxel map") ----

@@ -129,10 +129,11 @@ void SlamCore::Reset(bool resetLog)
       for (int k = 0; k < 3; ++k) lsa_set_keypoints(Ctx, s, k, nullptr, 0);
   for (int k = 0; k < 3; ++k) { EgoDebug[k] = MatchDebug(); LocDebug[k] = MatchDebug(); KeypointCounts[k] = 0; SpecBuilt[k] = false; }
   SpecPending = false;
+  for (int k = 0; k < 3; ++k) EgoMatchSerial[k] = LocMatchSerial[k] = 0;
   if (resetLog)
   {
     NbrFrameProcessed = 0;
-    LogTrajectory.clear();
+    LogTrajectory.clear();  // LogCovariances is left alone, as in the reference (Slam.cxx:200-209)
   }
 }
 
@@ -140,6 +141,61 @@ Pose SlamCore::GetWorldTransform(double* time) const
 {
   if (time) *time = LogTrajectory.empty() ? 0. : LogTrajectory.back().time;
   return LogTrajectory.empty() ? Pose::Identity() : LogTrajectory.back().pose;
+}
+
+// Slam::GetLatencyCompensatedWorldTransform (Slam.cxx:555-590)
+Pose SlamCore::GetLatencyCompensatedWorldTransform(double* time) const
+{
+  const size_t n = LogTrajectory.size();
+  if (time) *time = n ? LogTrajectory.back().time : 0.;
+  if (n == 0) return Pose::Identity();
+  if (n == 1) return LogTrajectory.back().pose;
+  const StampedPose& previous = LogTrajectory[n - 2];
+  const StampedPose& current = LogTrajectory[n - 1];
+  // timestamps undefined or too close / extrapolation too far: the current pose
+  if (std::abs(current.time - previous.time) < 1e-6) return current.pose;
+  if (std::abs(Latency / (current.time - previous.time)) > MaxExtrapolationRatio) return current.pose;
+  return LinearInterpolation(previous.pose, current.pose, current.time + Latency, previous.time, current.time);
+}
+
+// Slam::SetWorldTransformFromGuess (Slam.cxx:490-501)
+int SlamCore::SetWorldTransformFromGuess(const Pose& guess)
+{
+  if (!Ctx) return LSA_E_NO_DEVICE;
+  Tworld = guess;
+  // the ego-motion extrapolation then gives identity, and without current keypoints the next frame skips the
+  // ego-motion registration
+  PreviousTworld = Tworld;
+  for (int k = 0; k < 3; ++k) LSA_TRY(lsa_set_keypoints(Ctx, LSA_SET_RAW_CURRENT, k, nullptr, 0));
+  return LSA_OK;
+}
+
+// Slam::GetDebugInformation (Slam.cxx:610-633)
+int SlamCore::GetDebugInformation(double out[10])
+{
+  if (!Ctx) return LSA_E_NO_DEVICE;
+  for (int i = 0; i < 10; ++i) out[i] = 0.;
+  int hist[LSA_MATCH_NSTATUS];
+  for (int k = 0; k < 3; ++k)
+  {
+    // MatchingResults::NbMatches() = RejectionsHistogram[SUCCESS] of the last iteration's match
+    if (k < 2 && EgoMatchSerial[k] > 0)
+    {
+      LSA_TRY(lsa_match_histogram(Ctx, k, EgoMatchSerial[k], hist));
+      out[k] = hist[LSA_MATCH_SUCCESS];
+    }
+    if (LocMatchSerial[k] > 0)
+    {
+      LSA_TRY(lsa_match_histogram(Ctx, k, LocMatchSerial[k], hist));
+      out[2 + k] = hist[LSA_MATCH_SUCCESS];
+    }
+  }
+  out[5] = LocalizationUncertainty.PositionError;
+  out[6] = LocalizationUncertainty.OrientationError;
+  out[7] = OverlapEstimation;
+  out[8] = ComplyMotionLimits ? 1. : 0.;
+  out[9] = Latency;
+  return LSA_OK;
 }
 
 // Slam::AddFrames (Slam.cxx:230-344) + CheckFrames (:709-743)
@@ -152,7 +208,7 @@ int SlamCore::AddFrame(const lsa_point_t* pts, int n, uint64_t stampUs, uint32_t
   if (stampUs == CurrentStamp) { LastError = "SLAM frames have the same timestamp as previous ones : frames ignored."; return LSA_OK; }
   LSA_TRY(lsa_upload_frame(Ctx, pts, n));
   int rc = ProcessCurrentFrame(stampUs);
-  Stats.total = total.Stop();
+  Latency = Stats.total = total.Stop();
   return rc;
 }
 
@@ -164,7 +220,7 @@ int SlamCore::AddStoredFrame(int slot, uint64_t stampUs, uint32_t)
   if (stampUs == CurrentStamp) { LastError = "SLAM frames have the same timestamp as previous ones : frames ignored."; return LSA_OK; }
   LSA_TRY(lsa_frame_store_use(Ctx, slot));
   int rc = ProcessCurrentFrame(stampUs);
-  Stats.total = total.Stop();
+  Latency = Stats.total = total.Stop();
   return rc;
 }
 
@@ -195,6 +251,7 @@ int SlamCore::ProcessCurrentFrame(uint64_t stampUs)
     rc = EstimateOverlap();
     if (rc < 0) return rc;
   }
+  if (TimeWindowDuration > 0) CheckMotionLimits();
   if (MapUpdate == MappingMode::ADD_KPTS_TO_FIXED_MAP || MapUpdate == MappingMode::UPDATE)
   {
     Tick t;
@@ -297,6 +354,7 @@ int SlamCore::ComputeEgoMotion()
     // both keypoint types are matched concurrently and nothing is read back: the number of matches
     // arrives with the optimizer's first evaluation
     LSA_TRY(lsa_match_types(Ctx, LSA_TARGET_PREVIOUS, (1u << LSA_EDGE) | (1u << LSA_PLANE), LSA_SET_RAW_CURRENT, &mp, Trelative.m, nullptr));
+    for (int k : {LSA_EDGE, LSA_PLANE}) EgoMatchSerial[k] = lsa_match_serial(Ctx, k);
     Stats.ego_icp += ticp.Stop();
     Stats.ego_iters++;
 
@@ -421,6 +479,8 @@ int SlamCore::Localization()
     for (int k = 0; k < 3; ++k)
       if (UseKeypoints[k]) mask |= 1u << k;
     LSA_TRY(lsa_match_types(Ctx, LSA_TARGET_MAP, mask, LSA_SET_WORKING, &mp, Tworld.m, nullptr));
+    for (int k = 0; k < 3; ++k)
+      if ((mask >> k) & 1u) LocMatchSerial[k] = lsa_match_serial(Ctx, k);
     Stats.loc_icp += ticp.Stop();
     Stats.loc_iters++;
 
@@ -569,11 +629,69 @@ int SlamCore::UpdateMapsUsingTworld()
   return LSA_OK;
 }
 
-// Slam::LogCurrentFrameState with LoggingTimeout == 0 (Slam.cxx:1257-1263)
+// Slam::LogCurrentFrameState (Slam.cxx:1225-1264); the keypoints log feeds the pose-graph optimisation, which is
+// out of scope, so only the poses and their covariances are kept
 void SlamCore::LogCurrentFrameState(double time)
 {
   LogTrajectory.push_back({Tworld, time});
-  while (LogTrajectory.size() > 2) LogTrajectory.pop_front();
+  if (LoggingTimeout != 0.)
+  {
+    LogCovariances.push_back(LocalizationUncertainty.Covariance);
+    if (LoggingTimeout > 0)
+      while (time - LogTrajectory.front().time > LoggingTimeout && LogTrajectory.size() > 2)
+      {
+        LogTrajectory.pop_front();
+        LogCovariances.pop_front();
+      }
+  }
+  else
+    while (LogTrajectory.size() > 2) LogTrajectory.pop_front();
+}
+
+// Slam::CheckMotionLimits (Slam.cxx:1391-1484)
+void SlamCore::CheckMotionLimits()
+{
+  const int nPoses = static_cast<int>(LogTrajectory.size());
+  if (nPoses == 0) return;
+  const double currentTimeStamp = StampToSec(CurrentStamp);
+  double deltaTime = currentTimeStamp - LogTrajectory.back().time;
+  double nextDeltaTime = std::numeric_limits<float>::max();
+  int startIndex = nPoses - 1;  // the window ends on the current pose and starts at this logged one
+  if (deltaTime < TimeWindowDuration)
+  {
+    // an interval [deltaTime, nextDeltaTime] containing TimeWindowDuration
+    while (startIndex >= 0)
+    {
+      deltaTime = nextDeltaTime;
+      nextDeltaTime = currentTimeStamp - LogTrajectory[startIndex].time;
+      if (nextDeltaTime >= TimeWindowDuration) break;
+      --startIndex;
+    }
+    if (startIndex < 0) startIndex = 0;  // not enough logged poses: the oldest one
+    else if (std::abs(deltaTime - TimeWindowDuration) < std::abs(nextDeltaTime - TimeWindowDuration)) ++startIndex;
+    deltaTime = currentTimeStamp - LogTrajectory[startIndex].time;
+  }
+  ComplyMotionLimits = true;
+  const Pose window = Inverse(LogTrajectory[startIndex].pose) * Tworld;
+  float angle = static_cast<float>(RotationAngle(window));  // [0, 2 pi]
+  if (angle > M_PI) angle = static_cast<float>(2 * M_PI - angle);
+  angle = static_cast<float>(angle / M_PI * 180.);  // Utils::Rad2Deg (Utilities.h:150-153)
+  const float distance = static_cast<float>(std::sqrt(window.m[3] * window.m[3] + window.m[7] * window.m[7] + window.m[11] * window.m[11]));
+  const float velocity[2] = {static_cast<float>(distance / deltaTime), static_cast<float>(angle / deltaTime)};
+  if (NbrFrameProcessed >= 2)
+  {
+    bool comply = true;
+    for (int i = 0; i < 2; ++i)
+    {
+      // Eigen::Array2f / double: the scalar is converted to the array's type first
+      const float acceleration = (velocity[i] - PreviousVelocity[i]) / static_cast<float>(deltaTime);
+      comply = comply && velocity[i] < VelocityLimits[i] && std::abs(acceleration) < AccelerationLimits[i];
+    }
+    ComplyMotionLimits = comply;
+  }
+  PreviousVelocity[0] = velocity[0];
+  PreviousVelocity[1] = velocity[1];
+  if (!ComplyMotionLimits) LastError = "The pose does not comply with the motion limitations. Lidar SLAM may have failed.";
 }
 
 // Slam::InterpolateScanPose (Slam.cxx:1271-1285)
@@ -730,6 +848,12 @@ int SlamCore::SetParam(const std::string& name, double v)
     if (OverlapSamplingRatio == 0.f) OverlapEstimation = -1.f;
     return LSA_OK;
   }
+  if (name == "LoggingTimeout") { LoggingTimeout = v; return LSA_OK; }
+  if (name == "TimeWindowDuration") { TimeWindowDuration = static_cast<float>(v); return LSA_OK; }
+  if (name == "VelocityLimitLinear") { VelocityLimits[0] = static_cast<float>(v); return LSA_OK; }
+  if (name == "VelocityLimitAngular") { VelocityLimits[1] = static_cast<float>(v); return LSA_OK; }
+  if (name == "AccelerationLimitLinear") { AccelerationLimits[0] = static_cast<float>(v); return LSA_OK; }
+  if (name == "AccelerationLimitAngular") { AccelerationLimits[1] = static_cast<float>(v); return LSA_OK; }
   if (name == "AzimuthalResolution") { if (Ctx) lsa_set_azimuthal_resolution(Ctx, static_cast<float>(v)); return LSA_OK; }
   if (name == "VoxelGridLeafSizeEdges") { LocalMaps[LSA_EDGE]->SetLeafSize(v); return LSA_OK; }
   if (name == "VoxelGridLeafSizePlanes") { LocalMaps[LSA_PLANE]->SetLeafSize(v); return LSA_OK; }
@@ -763,6 +887,14 @@ int SlamCore::GetParam(const std::string& name, double* v) const
   if (name == "OverlapSamplingRatio") { *v = OverlapSamplingRatio; return LSA_OK; }
   if (name == "OverlapEstimation") { *v = OverlapEstimation; return LSA_OK; }
   if (name == "SubMapSpeculationHits") { *v = SubMapSpecHitsTotal; return LSA_OK; }
+  if (name == "LoggingTimeout") { *v = LoggingTimeout; return LSA_OK; }
+  if (name == "TimeWindowDuration") { *v = TimeWindowDuration; return LSA_OK; }
+  if (name == "VelocityLimitLinear") { *v = VelocityLimits[0]; return LSA_OK; }
+  if (name == "VelocityLimitAngular") { *v = VelocityLimits[1]; return LSA_OK; }
+  if (name == "AccelerationLimitLinear") { *v = AccelerationLimits[0]; return LSA_OK; }
+  if (name == "AccelerationLimitAngular") { *v = AccelerationLimits[1]; return LSA_OK; }
+  if (name == "ComplyMotionLimits") { *v = ComplyMotionLimits ? 1. : 0.; return LSA_OK; }
+  if (name == "Latency") { *v = Latency; return LSA_OK; }
   return LSA_E_ARG;
 }
 

@@ -10,6 +10,7 @@
 #include <array>
 #include <condition_variable>
 #include <deque>
+#include <limits>
 #include <functional>
 #include <memory>
 #include <mutex>
@@ -91,6 +92,13 @@ public:
   int AddStoredFrame(int slot, uint64_t stampUs, uint32_t seq);
 
   Pose GetWorldTransform(double* time = nullptr) const;
+  // Slam::GetLatencyCompensatedWorldTransform (Slam.cxx:555-590): the last pose extrapolated by Latency
+  Pose GetLatencyCompensatedWorldTransform(double* time = nullptr) const;
+  // Slam::SetWorldTransformFromGuess (Slam.cxx:490-501)
+  int SetWorldTransformFromGuess(const Pose& guess);
+  // Slam::GetDebugInformation (Slam.cxx:610-633): matches used by the last ego-motion / localization iteration per
+  // type, registration errors, overlap, motion-limit compliance.  Reads five 32-byte histograms back on demand.
+  int GetDebugInformation(double out[10]);
   const std::array<double, 36>& GetTransformCovariance() const { return LocalizationUncertainty.Covariance; }
   int GetKeypoints(int type, bool world, std::vector<lsa_point_t>& out);
   int GetRawKeypoints(int type, std::vector<lsa_point_t>& out);
@@ -129,6 +137,15 @@ public:
   // GetOverlapEstimation; 0 = off, the library default; the ROS configuration uses 0.33)
   float OverlapSamplingRatio = 0.f;
   float OverlapEstimation = -1.f;
+  // Confidence estimator: velocity / acceleration over a time window against limits (Slam::CheckMotionLimits,
+  // Slam.cxx:1391-1484; linear [m/s, m/s2] and angular [deg/s, deg/s2]); TimeWindowDuration = 0 turns it off
+  float VelocityLimits[2] = {std::numeric_limits<float>::max(), std::numeric_limits<float>::max()};
+  float AccelerationLimits[2] = {std::numeric_limits<float>::max(), std::numeric_limits<float>::max()};
+  float TimeWindowDuration = 0.f;
+  bool ComplyMotionLimits = true;
+  // Slam::LoggingTimeout (Slam.h:425-438): 0 keeps the last two poses, > 0 the poses of that many seconds, < 0 all
+  double LoggingTimeout = 0.;
+  double Latency = 0.;  // duration of the last AddFrame [s] (Slam::GetLatency)
   Pose BaseToLidarOffset = Pose::Identity();
   lsa_extract_params_t ExtractParams;
   // edge length of the finest kNN search-grid cells (an implementation knob: results do not depend on it)
@@ -152,6 +169,7 @@ public:
   int KfCounter = 0;
   FrameStats Stats;
   std::deque<StampedPose> LogTrajectory;
+  std::deque<std::array<double, 36>> LogCovariances;
   int KeypointCounts[3] = {0, 0, 0};
 
 private:
@@ -161,6 +179,9 @@ private:
   int Localization();
   int UpdateMapsUsingTworld();
   int EstimateOverlap();
+  void CheckMotionLimits();
+  float PreviousVelocity[2] = {0.f, 0.f};
+  long long EgoMatchSerial[3] = {0, 0, 0}, LocMatchSerial[3] = {0, 0, 0};  // lsa_match_serial after the last iteration
   void LogCurrentFrameState(double time);
   Pose InterpolateScanPose(double time) const;
   int InitUndistortion();

@@ -156,6 +156,7 @@ struct lsa_ctx
   // cascade): every match takes the next block, the ring is zeroed once per turn instead of one memset per match
   int* hist_dev = nullptr;
   int hist_pos[3] = {0, 0, 0};    // block of the last match per type
+  long long hist_serial[3] = {0, 0, 0};  // matches enqueued so far per type (names a block for lsa_match_histogram)
   int last_match_type = 0;
   // lanes cooperating on one query in the first kNN kernel, per keypoint type (8, 16 or 32)
   int knn_lanes[3] = {16, 8, 8};

@@ -1441,20 +1441,33 @@ int lsa_set_target_cell_size(lsa_ctx* ctx, int slot, int type, float cell)
   return LSA_OK;
 }
 
+// Next block of the type's histogram ring.  The ring is cleared one half at a time, when the position enters the
+// half: everything that used those blocks finished long ago (the streams were joined and the host has read the
+// results of those matches since), and the blocks of the last kHistRing / 2 matches stay readable
+// (lsa_match_histogram).
+static int next_histogram(lsa_ctx* ctx, int type, hipStream_t st, int** hist)
+{
+  constexpr int half = kHistRing / 2;
+  ++ctx->hist_serial[type];
+  if (++ctx->hist_pos[type] >= kHistRing) ctx->hist_pos[type] = 0;
+  const int pos = ctx->hist_pos[type];
+  if (pos % half == 0)
+    LSA_HIP(ctx, hipMemsetAsync(ctx->hist_dev + ((size_t)type * kHistRing + pos) * 16, 0, (size_t)half * 16 * sizeof(int), st));
+  *hist = ctx->hist_dev + ((size_t)type * kHistRing + pos) * 16;
+  return LSA_OK;
+}
+
 // Enqueues the match of one keypoint type on `st` (no host synchronisation); the rejection histogram
 // lands in the type's block of hist_dev.
 static int match_enqueue(lsa_ctx* ctx, int slot, int type, int query_set, const lsa_match_params_t* p, const double pose[16], hipStream_t st)
 {
   const int nq = ctx->kp_n[query_set][type];
   MatchBuf& mb = ctx->match[type];
-  // next block of the type's ring; a turn of the ring ends with one memset of it (everything that used it has
-  // finished: the streams were joined and the host has read the results of those matches since)
-  if (++ctx->hist_pos[type] >= kHistRing)
+  int* hist = nullptr;
   {
-    ctx->hist_pos[type] = 0;
-    LSA_HIP(ctx, hipMemsetAsync(ctx->hist_dev + (size_t)type * kHistRing * 16, 0, kHistRing * 16 * sizeof(int), st));
+    const int rc = next_histogram(ctx, type, st, &hist);
+    if (rc) return rc;
   }
-  int* hist = ctx->hist_dev + ((size_t)type * kHistRing + ctx->hist_pos[type]) * 16;
   mb.k = nq;
   mb.sat = p->saturation_distance;
   mb.valid = true;
@@ -1643,12 +1656,11 @@ int lsa_overlap(lsa_ctx* ctx, unsigned type_mask, int interpolate, const double 
       oc.d2[k] = nullptr;
       oc.inv2sq[k] = 0.f;
       if (!((used >> k) & 1u)) continue;
-      if (++ctx->hist_pos[k] >= kHistRing)
+      int* hist = nullptr;
       {
-        ctx->hist_pos[k] = 0;
-        LSA_HIP(ctx, hipMemsetAsync(ctx->hist_dev + (size_t)k * kHistRing * 16, 0, kHistRing * 16 * sizeof(int), st));
+        const int rc = next_histogram(ctx, k, st, &hist);
+        if (rc) return rc;
       }
-      int* hist = ctx->hist_dev + ((size_t)k * kHistRing + ctx->hist_pos[k]) * 16;
       // nearest neighbour = the k = 1 case of the exact search (identity pose: the queries are world points already)
       launch_knn<5>(ctx, reinterpret_cast<const lsa_point_t*>(q4), nb, ident, 1, INFINITY, k, LSA_TARGET_MAP * 3 + k, st, hist);
       oc.d2[k] = ctx->match[k].knn_d2;
@@ -1684,6 +1696,24 @@ int lsa_download_match(lsa_ctx* ctx, int type, uint8_t* status, double* weights,
   LSA_HIP(ctx, hipMemcpyAsync(status, mb.status, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
   LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return n;
+}
+
+long long lsa_match_serial(const lsa_ctx* ctx, int type)
+{
+  if (!ctx || type < 0 || type > 2) return LSA_E_ARG;
+  return ctx->hist_serial[type];
+}
+
+int lsa_match_histogram(lsa_ctx* ctx, int type, long long serial, int histogram[LSA_MATCH_NSTATUS])
+{
+  if (!ctx || type < 0 || type > 2 || !histogram) return ctx ? ctx->fail(LSA_E_ARG, "lsa_match_histogram: bad argument") : LSA_E_ARG;
+  const long long back = ctx->hist_serial[type] - serial;
+  if (serial <= 0 || back < 0 || back >= kHistRing / 2) return ctx->fail(LSA_E_STATE, "lsa_match_histogram: that match is not (or no longer) in the ring");
+  const int pos = (int)(((long long)ctx->hist_pos[type] - back) % kHistRing + kHistRing) % kHistRing;
+  LSA_HIP(ctx, hipSetDevice(ctx->device));
+  LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  LSA_HIP(ctx, hipMemcpy(histogram, ctx->hist_dev + ((size_t)type * kHistRing + pos) * 16, LSA_MATCH_NSTATUS * sizeof(int), hipMemcpyDeviceToHost));
+  return LSA_OK;
 }
 
 int lsa_match_slow_queries(lsa_ctx* ctx)

@@ -13,8 +13,9 @@
 // present Transform::GetIsometry() is offered as well.
 //
 // Not mirrored (outside the hot path): pose-graph optimisation, GPS calibration, wheel
-// odometry / IMU constraints, PCD map IO, keypoint logging, overlap / motion-limit estimators.
+// odometry / IMU constraints, PCD map IO, keypoint logging, several LiDAR devices per Slam.
 #pragma once
+#include <algorithm>
 #include <array>
 #include <cstdint>
 #include <cstring>
@@ -26,84 +27,12 @@
 #include <vector>
 #include "lidarslam_amd.h"
 
-#if defined(__has_include)
-#if __has_include(<pcl/point_cloud.h>)
-#include <pcl/point_cloud.h>
-#define LSA_HAVE_PCL 1
-#endif
-#if __has_include(<Eigen/Geometry>)
-#include <Eigen/Geometry>
-#define LSA_HAVE_EIGEN 1
-#endif
-#endif
-
-#ifndef LSA_HAVE_PCL
-namespace pcl
-{
-struct PCLHeader
-{
-  std::uint32_t seq = 0;
-  std::uint64_t stamp = 0;  // microseconds
-  std::string frame_id;
-};
-template <typename PointT> class PointCloud
-{
-public:
-  using Ptr = std::shared_ptr<PointCloud<PointT>>;
-  using ConstPtr = std::shared_ptr<const PointCloud<PointT>>;
-  using PointType = PointT;
-  PCLHeader header;
-  std::vector<PointT> points;
-  bool is_dense = true;
-  std::size_t size() const { return points.size(); }
-  bool empty() const { return points.empty(); }
-  void reserve(std::size_t n) { points.reserve(n); }
-  void clear() { points.clear(); }
-  void push_back(const PointT& p) { points.push_back(p); }
-  PointT& operator[](std::size_t i) { return points[i]; }
-  const PointT& operator[](std::size_t i) const { return points[i]; }
-  PointT& at(std::size_t i) { return points.at(i); }
-  const PointT& at(std::size_t i) const { return points.at(i); }
-  PointT& front() { return points.front(); }
-  const PointT& front() const { return points.front(); }
-  PointT& back() { return points.back(); }
-  const PointT& back() const { return points.back(); }
-  typename std::vector<PointT>::iterator begin() { return points.begin(); }
-  typename std::vector<PointT>::iterator end() { return points.end(); }
-  typename std::vector<PointT>::const_iterator begin() const { return points.begin(); }
-  typename std::vector<PointT>::const_iterator end() const { return points.end(); }
-};
-}  // namespace pcl
-#endif
+#include "Enums.h"
+#include "LidarPoint.h"
+#include "SpinningSensorKeypointExtractor.h"
 
 namespace LidarSlam
 {
-
-// slam_lib/include/LidarSlam/LidarPoint.h:31-64 -- byte-compatible with lsa_point_t
-struct LidarPoint
-{
-  union
-  {
-    float data[4];
-    struct { float x, y, z; };
-  };
-  double time = 0.;
-  float intensity = 0.f;
-  std::uint16_t laser_id = 0;
-  std::uint8_t device_id = 0;
-  std::uint8_t label = 0;
-  LidarPoint() : data{0.f, 0.f, 0.f, 1.f} {}
-};
-static_assert(sizeof(LidarPoint) == sizeof(lsa_point_t), "LidarPoint must stay 32 bytes");
-
-// slam_lib/include/LidarSlam/Enums.h
-enum Keypoint { EDGE = 0, PLANE = 1, BLOB = 2, nKeypointTypes };
-static const std::vector<Keypoint> KeypointTypes = {EDGE, PLANE, BLOB};
-static const std::map<Keypoint, std::string> KeypointTypeNames = {{EDGE, "edge"}, {PLANE, "plane"}, {BLOB, "blob"}};
-enum UndistortionMode { NONE = 0, ONCE = 1, REFINED = 2 };
-enum class EgoMotionMode { NONE = 0, MOTION_EXTRAPOLATION = 1, REGISTRATION = 2, MOTION_EXTRAPOLATION_AND_REGISTRATION = 3 };
-enum class MappingMode { NONE = 0, ADD_KPTS_TO_FIXED_MAP = 1, UPDATE = 2 };
-enum class SamplingMode { FIRST = 0, LAST = 1, MAX_INTENSITY = 2, CENTER_POINT = 3, CENTROID = 4 };
 
 // slam_lib/include/LidarSlam/Transform.h:28-79
 struct Transform
@@ -171,11 +100,61 @@ public:
     t.frameid = this->WorldFrameId;
     return t;
   }
+  // the last pose extrapolated by the duration of the last AddFrame (Slam.cxx:555-590)
+  Transform GetLatencyCompensatedWorldTransform() const
+  {
+    Transform t;
+    lsa_slam_get_latency_compensated_world_transform(this->Handle, t.matrix.data(), &t.time);
+    t.frameid = this->WorldFrameId;
+    return t;
+  }
   std::array<double, 36> GetTransformCovariance() const
   {
     std::array<double, 36> c{};
     lsa_slam_get_covariance(this->Handle, c.data());
     return c;
+  }
+  // Slam.h:150-151; the log holds two poses unless SetLoggingTimeout was given something else than 0
+  std::vector<Transform> GetTrajectory() const
+  {
+    const int n = lsa_slam_get_trajectory(this->Handle, nullptr, nullptr, 0);
+    std::vector<double> rows(static_cast<std::size_t>(n > 0 ? n : 0) * 17);
+    if (n > 0) lsa_slam_get_trajectory(this->Handle, rows.data(), nullptr, n);
+    std::vector<Transform> poses(n > 0 ? n : 0);
+    for (int i = 0; i < n; ++i)
+    {
+      std::memcpy(poses[i].matrix.data(), rows.data() + 17 * i, 16 * sizeof(double));
+      poses[i].time = rows[17 * i + 16];
+      poses[i].frameid = this->WorldFrameId;
+    }
+    return poses;
+  }
+  std::vector<std::array<double, 36>> GetCovariances() const
+  {
+    const int n = lsa_slam_get_trajectory(this->Handle, nullptr, nullptr, 0);
+    std::vector<std::array<double, 36>> covs(n > 0 ? n : 0);
+    if (n > 0) lsa_slam_get_trajectory(this->Handle, nullptr, covs[0].data(), n);
+    return covs;
+  }
+  // Slam.h:155-158
+  PointCloud::Ptr GetMap(Keypoint k, bool clean = false)
+  {
+    return this->Fetch([&](lsa_point_t* out, int cap) { return std::min(cap, lsa_slam_get_map(this->Handle, k, clean ? 1 : 0, out, cap)); }, this->WorldFrameId);
+  }
+  PointCloud::Ptr GetTargetSubMap(Keypoint k)
+  {
+    return this->Fetch([&](lsa_point_t* out, int cap) { return std::min(cap, lsa_slam_get_target_submap(this->Handle, k, out, cap)); }, this->WorldFrameId);
+  }
+  // Slam.h:189
+  void SetWorldTransformFromGuess(const Transform& poseGuess) { lsa_slam_set_world_transform_from_guess(this->Handle, poseGuess.matrix.data()); }
+  // Slam.h:176 (same keys)
+  std::unordered_map<std::string, double> GetDebugInformation() const
+  {
+    double v[10] = {};
+    lsa_slam_get_debug_information(this->Handle, v);
+    return {{"EgoMotion: edges used", v[0]}, {"EgoMotion: planes used", v[1]}, {"Localization: edges used", v[2]},
+            {"Localization: planes used", v[3]}, {"Localization: blobs used", v[4]}, {"Localization: position error", v[5]},
+            {"Localization: orientation error", v[6]}, {"Confidence: overlap", v[7]}, {"Confidence: comply motion limits", v[8]}};
   }
   // worldCoordinates = false: BASE (undistorted), true: WORLD (Slam.cxx:690-702)
   PointCloud::Ptr GetKeypoints(Keypoint k, bool worldCoordinates = false)
@@ -193,12 +172,7 @@ public:
   float GetOverlapSamplingRatio() const { return static_cast<float>(this->GetParam("OverlapSamplingRatio")); }
   void SetOverlapSamplingRatio(float ratio) { this->SetParam("OverlapSamplingRatio", ratio); }
   float GetOverlapEstimation() const { return static_cast<float>(this->GetParam("OverlapEstimation")); }
-  double GetLatency() const
-  {
-    double s[16];
-    lsa_slam_get_stats(this->Handle, s);
-    return s[0];
-  }
+  double GetLatency() const { return this->GetParam("Latency"); }
   // Slam::GetDebugArray (Slam.cxx:635-657); needs SetKeepMatchDebug(true)
   std::unordered_map<std::string, std::vector<double>> GetDebugArray() const
   {
@@ -229,6 +203,35 @@ public:
   LSA_SLAM_ENUM_PARAM(Undistortion, UndistortionMode)
   LSA_SLAM_ENUM_PARAM(MapUpdate, MappingMode)
   LSA_SLAM_PARAM(KeepMatchDebug, bool)
+  LSA_SLAM_PARAM(LoggingTimeout, double)
+  // Slam.h:249-250 (row-major 4x4; one LiDAR device per Slam: deviceId must be 0)
+  void SetBaseToLidarOffset(const std::array<double, 16>& transform, std::uint8_t deviceId = 0)
+  {
+    if (lsa_slam_set_base_to_lidar_offset(this->Handle, transform.data(), deviceId) != LSA_OK)
+      throw std::invalid_argument("LidarSlam::Slam: one LiDAR device (id 0) per Slam in this build");
+  }
+  std::array<double, 16> GetBaseToLidarOffset(std::uint8_t deviceId = 0) const
+  {
+    std::array<double, 16> t{{1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1}};
+    lsa_slam_get_base_to_lidar_offset(this->Handle, t.data(), deviceId);
+    return t;
+  }
+#ifdef LSA_HAVE_EIGEN
+  void SetBaseToLidarOffset(const Eigen::Isometry3d& transform, std::uint8_t deviceId = 0)
+  {
+    std::array<double, 16> t{};
+    for (int r = 0; r < 4; ++r)
+      for (int c = 0; c < 4; ++c) t[r * 4 + c] = transform.matrix()(r, c);
+    this->SetBaseToLidarOffset(t, deviceId);
+  }
+#endif
+  // confidence estimator on the motion (Slam.h:385-394): {linear, angular} limits
+  void SetVelocityLimits(const std::array<float, 2>& l) { this->SetParam("VelocityLimitLinear", l[0]); this->SetParam("VelocityLimitAngular", l[1]); }
+  std::array<float, 2> GetVelocityLimits() const { return {{static_cast<float>(this->GetParam("VelocityLimitLinear")), static_cast<float>(this->GetParam("VelocityLimitAngular"))}}; }
+  void SetAccelerationLimits(const std::array<float, 2>& l) { this->SetParam("AccelerationLimitLinear", l[0]); this->SetParam("AccelerationLimitAngular", l[1]); }
+  std::array<float, 2> GetAccelerationLimits() const { return {{static_cast<float>(this->GetParam("AccelerationLimitLinear")), static_cast<float>(this->GetParam("AccelerationLimitAngular"))}}; }
+  LSA_SLAM_PARAM(TimeWindowDuration, float)
+  bool GetComplyMotionLimits() const { return this->GetParam("ComplyMotionLimits") != 0.; }
   void SetBaseFrameId(const std::string& s) { this->BaseFrameId = s; }
   std::string GetBaseFrameId() const { return this->BaseFrameId; }
   void SetWorldFrameId(const std::string& s) { this->WorldFrameId = s; }

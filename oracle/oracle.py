@@ -68,6 +68,12 @@ def lib():
         L.orc_slam_get_match_status.argtypes = [vp, i32, i32, vp, vp, i32]
         L.orc_slam_get_stats.argtypes = [vp, vp]
         L.orc_slam_get_submap.argtypes = [vp, i32, vp, i32]
+        L.orc_slam_get_latency_compensated_world_transform.argtypes = [vp, vp]
+        L.orc_slam_set_world_transform_from_guess.argtypes = [vp, vp]
+        L.orc_slam_set_base_to_lidar_offset.argtypes = [vp, vp]
+        L.orc_slam_get_trajectory.argtypes = [vp, vp, vp, i32]
+        L.orc_slam_get_debug_information.argtypes = [vp, vp]
+        L.orc_slam_get_map.argtypes = [vp, i32, i32, vp, i32]
         L.orc_grid_create.restype = vp
         L.orc_grid_destroy.argtypes = [vp]
         L.orc_grid_destroy.restype = None
@@ -90,6 +96,12 @@ def lib():
         _lib = L
     return _lib
 
+
+DEBUG_INFORMATION_NAMES = [
+    "EgoMotion: edges used", "EgoMotion: planes used", "Localization: edges used", "Localization: planes used",
+    "Localization: blobs used", "Localization: position error", "Localization: orientation error",
+    "Confidence: overlap", "Confidence: comply motion limits", "latency",
+]
 
 DEBUG_NAMES = [
     "sin_angle", "saliency", "depth_gap", "intensity_gap", "edge_keypoint", "plane_keypoint", "blob_keypoint",
@@ -313,6 +325,36 @@ class Slam:
         out = np.zeros(cap, POINT_DTYPE)
         n = lib().orc_slam_get_submap(self.h, k, ptr(out), cap)
         return out[:n].copy()
+
+    def map(self, k, clean=False, cap=4000000):
+        out = np.zeros(cap, POINT_DTYPE)
+        n = lib().orc_slam_get_map(self.h, k, int(clean), ptr(out), cap)
+        return out[:n].copy()
+
+    def latency_compensated_world_transform(self):
+        T = np.zeros(16)
+        lib().orc_slam_get_latency_compensated_world_transform(self.h, ptr(T))
+        return T.reshape(4, 4)
+
+    def set_world_transform_from_guess(self, T):
+        T = np.ascontiguousarray(T, np.float64).reshape(16)
+        lib().orc_slam_set_world_transform_from_guess(self.h, ptr(T))
+
+    def set_base_to_lidar_offset(self, T):
+        T = np.ascontiguousarray(T, np.float64).reshape(16)
+        lib().orc_slam_set_base_to_lidar_offset(self.h, ptr(T))
+
+    def trajectory(self, cap=100000):
+        """(n, 4, 4) poses, (n,) times, (n, 6, 6) covariances"""
+        n = lib().orc_slam_get_trajectory(self.h, None, None, 0)
+        rows, cov = np.zeros((max(n, 1), 17)), np.zeros((max(n, 1), 36))
+        lib().orc_slam_get_trajectory(self.h, ptr(rows), ptr(cov), n)
+        return rows[:n, :16].reshape(n, 4, 4).copy(), rows[:n, 16].copy(), cov[:n].reshape(n, 6, 6).copy()
+
+    def debug_information(self):
+        o = np.zeros(10)
+        lib().orc_slam_get_debug_information(self.h, ptr(o))
+        return dict(zip(DEBUG_INFORMATION_NAMES, o.tolist()))
 
 
 class RollingGrid:

@@ -387,6 +387,13 @@ int orc_slam_set_param(void* h, const char* name, double v)
   P("KfAngleThreshold", s.KfAngleThreshold = v)
   P("MapUpdate", s.MapUpdate = (MappingMode)(int)v)
   P("OverlapSamplingRatio", s.OverlapSamplingRatio = std::min(std::max((float)v, 0.f), 1.f); if (s.OverlapSamplingRatio == 0.f) s.OverlapEstimation = -1.f)
+  P("LoggingTimeout", s.LoggingTimeout = v)
+  P("TimeWindowDuration", s.TimeWindowDuration = (float)v)
+  P("VelocityLimitLinear", s.VelocityLimits[0] = (float)v)
+  P("VelocityLimitAngular", s.VelocityLimits[1] = (float)v)
+  P("AccelerationLimitLinear", s.AccelerationLimits[0] = (float)v)
+  P("AccelerationLimitAngular", s.AccelerationLimits[1] = (float)v)
+  P("Latency", s.Latency = v)
   P("VoxelGridLeafSizeEdges", s.LocalMaps[EDGE]->SetLeafSize(v))
   P("VoxelGridLeafSizePlanes", s.LocalMaps[PLANE]->SetLeafSize(v))
   P("VoxelGridLeafSizeBlobs", s.LocalMaps[BLOB]->SetLeafSize(v))
@@ -471,6 +478,52 @@ int orc_slam_get_stats(void* h, double out[16])
                   0, 0};
   std::memcpy(out, v, sizeof(v));
   return 0;
+}
+int orc_slam_get_latency_compensated_world_transform(void* h, double T[16])
+{
+  IsoToRowMajor(((SlamHandle*)h)->s.GetLatencyCompensatedWorldTransform(), T);
+  return 0;
+}
+int orc_slam_set_base_to_lidar_offset(void* h, const double T[16])
+{
+  ((SlamHandle*)h)->s.BaseToLidarOffset = IsoFromRowMajor(T);
+  return 0;
+}
+int orc_slam_set_world_transform_from_guess(void* h, const double T[16])
+{
+  ((SlamHandle*)h)->s.SetWorldTransformFromGuess(IsoFromRowMajor(T));
+  return 0;
+}
+int orc_slam_get_trajectory(void* h, double* poses, double* covariances, int capacity)
+{
+  Slam& s = ((SlamHandle*)h)->s;
+  const int n = (int)s.LogTrajectory.size();
+  for (int i = 0; i < std::min(n, capacity); ++i)
+  {
+    if (poses)
+    {
+      IsoToRowMajor(s.LogTrajectory[i].pose, poses + 17 * i);
+      poses[17 * i + 16] = s.LogTrajectory[i].time;
+    }
+    if (covariances)
+    {
+      const long j = (long)s.LogCovariances.size() - n + i;
+      for (int c = 0; c < 36; ++c) covariances[36 * i + c] = j >= 0 ? s.LogCovariances[j][c] : 0.;
+    }
+  }
+  return n;
+}
+int orc_slam_get_debug_information(void* h, double out[10])
+{
+  ((SlamHandle*)h)->s.GetDebugInformation(out);
+  return 0;
+}
+int orc_slam_get_map(void* h, int type, int clean, lsa_point_t* out, int capacity)
+{
+  const std::vector<Point> m = ((SlamHandle*)h)->s.LocalMaps[type]->Get(clean != 0);
+  const int n = (int)m.size();
+  if (std::min(n, capacity) > 0) std::memcpy(out, m.data(), (size_t)std::min(n, capacity) * sizeof(Point));
+  return n;
 }
 int orc_slam_get_submap(void* h, int type, lsa_point_t* out, int capacity)
 {

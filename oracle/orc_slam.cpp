@@ -81,6 +81,7 @@ void Slam::AddFrame(const std::vector<Point>& frame, uint64_t stampUs, unsigned)
   Localization();
   // confidence estimators: before the maps update, which resets the kd-trees (Slam.cxx:269-280)
   if (OverlapSamplingRatio > 0) EstimateOverlap();
+  if (TimeWindowDuration > 0) CheckMotionLimits();
   if (MapUpdate == MappingMode::ADD_KPTS_TO_FIXED_MAP || MapUpdate == MappingMode::UPDATE)
   {
     Tick t;
@@ -324,11 +325,113 @@ void Slam::UpdateMapsUsingTworld()
       LocalMaps[k]->Add(CurrentWorldKeypoints[k], false, CurrentTime);
 }
 
-// Slam.cxx:1225-1264 with LoggingTimeout == 0 (default): keep the last two poses
+// Slam.cxx:1225-1264 (poses and covariances; the keypoints log belongs to the pose-graph optimisation)
 void Slam::LogCurrentFrameState(double time)
 {
-  LogTrajectory.push_back({Tworld, time});
-  while (LogTrajectory.size() > 2) LogTrajectory.pop_front();
+  if (LoggingTimeout != 0.)
+  {
+    LogTrajectory.push_back({Tworld, time});
+    std::array<double, 36> c;
+    for (int i = 0; i < 36; ++i) c[i] = LocalizationUncertainty.Covariance[i];
+    LogCovariances.push_back(c);
+    if (LoggingTimeout > 0)
+      while (time - LogTrajectory.front().time > LoggingTimeout && LogTrajectory.size() > 2)
+      {
+        LogTrajectory.pop_front();
+        LogCovariances.pop_front();
+      }
+  }
+  else
+  {
+    LogTrajectory.push_back({Tworld, time});
+    while (LogTrajectory.size() > 2) LogTrajectory.pop_front();
+  }
+}
+
+// Slam.cxx:555-590
+Iso Slam::GetLatencyCompensatedWorldTransform() const
+{
+  const size_t n = LogTrajectory.size();
+  if (n == 0) return iso_identity();
+  if (n == 1) return LogTrajectory.back().pose;
+  const StampedPose& previous = LogTrajectory[n - 2];
+  const StampedPose& current = LogTrajectory[n - 1];
+  if (std::abs(current.time - previous.time) < 1e-6) return current.pose;
+  if (std::abs(Latency / (current.time - previous.time)) > MaxExtrapolationRatio) return current.pose;
+  return linear_interpolation(previous.pose, current.pose, current.time + Latency, previous.time, current.time);
+}
+
+// Slam.cxx:490-501
+void Slam::SetWorldTransformFromGuess(const Iso& guess)
+{
+  Tworld = guess;
+  PreviousTworld = Tworld;
+  for (int k = 0; k < 3; ++k) CurrentRawKeypoints[k].clear();
+}
+
+// Slam.cxx:610-633; order: ego edges, ego planes, loc edges, planes, blobs, position error, orientation error,
+// overlap, comply motion limits, latency
+void Slam::GetDebugInformation(double out[10]) const
+{
+  for (int k = 0; k < 2; ++k) out[k] = EgoMotionMatchingResults[k].NbMatches();
+  for (int k = 0; k < 3; ++k) out[2 + k] = LocalizationMatchingResults[k].NbMatches();
+  out[5] = LocalizationUncertainty.PositionError;
+  out[6] = LocalizationUncertainty.OrientationError;
+  out[7] = OverlapEstimation;
+  out[8] = ComplyMotionLimits ? 1. : 0.;
+  out[9] = Latency;
+}
+
+// Slam.cxx:1391-1484
+void Slam::CheckMotionLimits()
+{
+  int nPoses = (int)LogTrajectory.size();
+  if (nPoses == 0)
+    return;
+  double currentTimeStamp = StampToSec(CurrentStamp);
+  double deltaTime = currentTimeStamp - LogTrajectory.back().time;
+  double nextDeltaTime = FLT_MAX;
+  int startIndex = nPoses - 1;
+  if (deltaTime < TimeWindowDuration)
+  {
+    while (startIndex >= 0)
+    {
+      deltaTime = nextDeltaTime;
+      nextDeltaTime = currentTimeStamp - LogTrajectory[startIndex].time;
+      if (nextDeltaTime >= TimeWindowDuration)
+        break;
+      --startIndex;
+    }
+    if (startIndex < 0)
+      startIndex = 0;
+    else if (std::abs(deltaTime - TimeWindowDuration) < std::abs(nextDeltaTime - TimeWindowDuration))
+      ++startIndex;
+    deltaTime = currentTimeStamp - LogTrajectory[startIndex].time;
+  }
+  ComplyMotionLimits = true;
+  Iso TWindow = iso_mul(iso_inverse(LogTrajectory[startIndex].pose), Tworld);
+  // Eigen::AngleAxisd(R).angle(): 2 atan2(|q.vec|, |q.w|)
+  Quat q = quat_from_matrix(TWindow.R);
+  double qn = std::sqrt((q.x * q.x + q.y * q.y) + q.z * q.z);
+  float angle = (float)((qn != 0.) ? 2. * std::atan2(qn, std::abs(q.w)) : 0.);
+  if (angle > M_PI)
+    angle = (float)(2 * M_PI - angle);
+  angle = (float)(angle / M_PI * 180.);  // Utils::Rad2Deg (Utilities.h:150-153)
+  float distance = (float)std::sqrt((TWindow.t[0] * TWindow.t[0] + TWindow.t[1] * TWindow.t[1]) + TWindow.t[2] * TWindow.t[2]);
+  float velocity[2] = {(float)(distance / deltaTime), (float)(angle / deltaTime)};
+  if (NbrFrameProcessed >= 2)
+  {
+    bool comply = true;
+    for (int i = 0; i < 2; ++i)
+    {
+      // Eigen::Array2f / double: the scalar is converted to the array's type first
+      float acceleration = (velocity[i] - PreviousVelocity[i]) / (float)deltaTime;
+      comply = comply && velocity[i] < VelocityLimits[i] && std::abs(acceleration) < AccelerationLimits[i];
+    }
+    ComplyMotionLimits = comply;
+  }
+  PreviousVelocity[0] = velocity[0];
+  PreviousVelocity[1] = velocity[1];
 }
 
 // Slam.cxx:1271-1285

@@ -8,6 +8,8 @@
 // One LiDAR device per call (AddFrame); sensor constraints, pose graph, PCD IO,
 // overlap estimator and motion limits are outside the hot path.
 #pragma once
+#include <array>
+#include <cfloat>
 #include <deque>
 #include <map>
 #include <memory>
@@ -42,6 +44,9 @@ public:
   void AddFrame(const std::vector<Point>& frame, uint64_t stampUs, unsigned seq = 0);
 
   Iso GetWorldTransform() const { return LogTrajectory.empty() ? iso_identity() : LogTrajectory.back().pose; }
+  Iso GetLatencyCompensatedWorldTransform() const;          // Slam.cxx:555-590
+  void SetWorldTransformFromGuess(const Iso& guess);          // Slam.cxx:490-501
+  void GetDebugInformation(double out[10]) const;             // Slam.cxx:610-633
   const double* GetTransformCovariance() const { return LocalizationUncertainty.Covariance; }
 
   // parameters (Slam.h:403-694)
@@ -89,8 +94,17 @@ public:
   // Confidence estimator (Slam.h OverlapSamplingRatio / GetOverlapEstimation; Slam.cxx:1359-1388)
   float OverlapSamplingRatio = 0.f;
   float OverlapEstimation = -1.f;
+  // Slam.h:663-694, Slam.cxx:1391-1484
+  float VelocityLimits[2] = {FLT_MAX, FLT_MAX}, AccelerationLimits[2] = {FLT_MAX, FLT_MAX};
+  float TimeWindowDuration = 0.f;
+  bool ComplyMotionLimits = true;
+  float PreviousVelocity[2] = {0.f, 0.f};
+  double LoggingTimeout = 0.;  // Slam.h:425-438
+  double Latency = 0.;         // the tests set it: the reference measures it
+  std::deque<std::array<double, 36>> LogCovariances;
 
 private:
+  void CheckMotionLimits();
   void EstimateOverlap();
   bool CheckFrame(const std::vector<Point>& frame, uint64_t stampUs);
   void ExtractKeypoints();

@@ -30,12 +30,35 @@ def test_cpp_caller_compiles_links_and_refuses_to_run_without_a_gpu(tmp_path, L)
 def test_cpp_caller_matches_the_python_front_end(tmp_path, L):
     exe = build_example(tmp_path)
     r = subprocess.run([exe, "8", "4"], capture_output=True, text=True, check=True)
-    rows = np.array([[float(v) for v in line.split()] for line in r.stdout.strip().splitlines()])
-    s = L.Slam(0, EgoMotion=3)
+    lines = r.stdout.strip().splitlines()
+    rows = np.array([[float(v) for v in line.split()] for line in lines if not line.startswith("#")])
+    extra = {line.split()[1]: [float(v) for v in line.split()[2:]] for line in lines if line.startswith("#")}
+    s = L.Slam(0, EgoMotion=3, LoggingTimeout=-1, TimeWindowDuration=0.25, VelocityLimitLinear=2.0, VelocityLimitAngular=1000.0)
     for f in range(4):
         pts, stamp = L.synth_frame(8, 1000, f)
         s.add_frame(pts, stamp, f)
         T = s.world_transform()
         assert np.allclose(rows[f, 1:4], T[:3, 3], atol=1e-11, rtol=0)
         assert int(rows[f, 4]) == s.keypoints(1).size
+    # the other getters of the C++ mirror against the same calls through the Python front-end
+    poses, times, covs = s.trajectory()
+    assert extra["trajectory"][:2] == [4, 4] and poses.shape[0] == 4
+    assert abs(extra["trajectory"][2] - poses[-1, 0, 3]) < 1e-11
+    assert extra["maps"] == [s.map(L.EDGE).size, s.map(L.PLANE).size]
+    assert extra["submaps"] == [s.target_submap(L.EDGE).size, s.target_submap(L.PLANE).size]
+    info = s.debug_information()
+    assert extra["used"] == [info["EgoMotion: edges used"], info["EgoMotion: planes used"], info["Localization: edges used"], info["Localization: planes used"]]
+    assert min(extra["used"]) > 20
+    assert extra["comply"] == [0.0] == [info["Confidence: comply motion limits"]]
+    # the latency differs from run to run: the extrapolation lies ahead of the last pose by (speed x latency)
+    ahead, latency = extra["ahead"]
+    speed = (poses[-1, 0, 3] - poses[-2, 0, 3]) / (times[-1] - times[-2])
+    assert 0 < latency < 0.1 and abs(ahead - (poses[-1, 0, 3] + speed * latency)) < 1e-6
+    # the stand-alone extractor on the last frame
+    pts, _ = L.synth_frame(8, 1000, 3)
+    c = L.Context(0)
+    c.upload_frame(pts)
+    counts = c.extract_keypoints()
+    assert extra["extractor"] == [counts[0], counts[1], c.nb_laser_rings(), pts.size, 10]
+    c.close()
     s.close()

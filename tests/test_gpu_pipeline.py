@@ -400,3 +400,60 @@ def test_sequences_side_by_side_on_one_gpu_reproduce_lone_runs():
     rep.close()
     with pytest.raises(ValueError):
         ConcurrentReplay(0, 16, [1000], 2, EgoMotion=3).run(2)
+
+
+def _yaw_offset(deg, t):
+    T = np.eye(4)
+    a = np.deg2rad(deg)
+    T[:2, :2] = [[np.cos(a), -np.sin(a)], [np.sin(a), np.cos(a)]]
+    T[:3, 3] = t
+    return T
+
+
+@pytest.mark.gpu
+def test_result_getters_and_confidence_estimators_follow_the_oracle(L, O):
+    """Slam.h:141-189 and :385-394 -- trajectory / covariance log with a timeout, latency-compensated pose, maps and
+    target sub-maps, GetDebugInformation (matches used per type without reading anything back on the frame's critical
+    path), motion limits, a BASE <- LIDAR offset and a pose guess in the middle of the sequence."""
+    params = dict(EgoMotion=3, LoggingTimeout=0.45, TimeWindowDuration=0.25, VelocityLimitLinear=5.05, VelocityLimitAngular=400.0,
+                  AccelerationLimitLinear=3.0, AccelerationLimitAngular=1e4, OverlapSamplingRatio=0.25)
+    sg, so = L.Slam(0, **params), O.Slam(**params)
+    offset = _yaw_offset(10.0, [0.5, -0.1, 1.0])
+    sg.set_base_to_lidar_offset(offset), so.set_base_to_lidar_offset(offset)
+    assert np.array_equal(sg.base_to_lidar_offset(), offset)
+    with pytest.raises(L.LsaError):
+        sg.set_base_to_lidar_offset(offset, device_id=1)
+    comply = []
+    for f in range(14):
+        pts, stamp = L.synth_frame(8, 1000, f)
+        if f == 8:
+            # a pose imposed from outside: the ego-motion is skipped for this frame on both sides
+            guess = sg.world_transform() @ _yaw_offset(1.0, [0.3, 0.05, 0.0])
+            sg.set_world_transform_from_guess(guess), so.set_world_transform_from_guess(guess)
+        sg.add_frame(pts, stamp, f), so.add_frame(pts, stamp, f)
+        Tg, To = sg.world_transform(), so.world_transform()
+        assert np.abs(Tg - To).max() < 1e-9, f
+        ig, io = sg.debug_information(), so.debug_information()
+        for key in L.DEBUG_INFORMATION_NAMES[:5]:
+            assert ig[key] == io[key], (f, key)
+        for key in L.DEBUG_INFORMATION_NAMES[5:8]:
+            assert abs(ig[key] - io[key]) <= 1e-6 * max(1.0, abs(io[key])), (f, key, ig[key], io[key])
+        assert ig["Confidence: comply motion limits"] == io["Confidence: comply motion limits"], f
+        comply.append(ig["Confidence: comply motion limits"])
+        if f >= 2:
+            assert ig["Localization: planes used"] > 20 and ig["Localization: edges used"] > 20
+        # trajectory and covariance log: poses of the last 0.45 s (at least two)
+        pg, tg, cg = sg.trajectory()
+        po, to, co = so.trajectory()
+        assert pg.shape == po.shape and np.array_equal(tg, to) and np.abs(pg - po).max() < 1e-9
+        assert np.allclose(cg, co, rtol=1e-5, atol=1e-12)
+        assert pg.shape[0] == min(f + 1, 5)
+        # latency compensation: the reference measures the latency, the oracle is told the device path's
+        so.set_param("Latency", sg.get_param("Latency"))
+        assert np.abs(sg.latency_compensated_world_transform() - so.latency_compensated_world_transform()).max() < 1e-9
+        for k in (L.EDGE, L.PLANE):
+            assert sg.map(k).size == so.map(k).size and sg.map(k, clean=True).size == so.map(k, clean=True).size
+            assert sg.target_submap(k).size == so.submap(k).size
+    # 5 m/s against a 5.05 m/s limit: compliant while cruising, not across the imposed jump
+    assert comply[7] == 1.0 and 0.0 in comply[8:11]
+    sg.close()

@@ -271,3 +271,33 @@ def test_velodyne_conversion_properties(O, L):
         for r in range(8):
             t = out3["time"][out3["laser_id"] == r]
             assert (np.diff(t) >= 0).all()  # the estimator's whole point: no wrap inside a ring
+
+
+def test_oracle_pose_log_motion_limits_and_latency_compensation(O, L):
+    """Slam.cxx:555-605, 1225-1264, 1391-1484 restated: log lengths for the three LoggingTimeout regimes, the motion
+    limits around the synthetic sensor's 5 m/s, and the constant-velocity extrapolation by the latency."""
+    runs = {}
+    for timeout in (0.0, 0.35, -1.0):
+        s = O.Slam(EgoMotion=3, LoggingTimeout=timeout, TimeWindowDuration=0.25, VelocityLimitLinear=4.0 if timeout < 0 else 6.0, VelocityLimitAngular=1e3)
+        comply = []
+        for f in range(8):
+            pts, stamp = L.synth_frame(8, 1000, f)
+            s.add_frame(pts, stamp, f)
+            comply.append(s.debug_information()["Confidence: comply motion limits"])
+        runs[timeout] = (s, comply)
+    poses0, times0, cov0 = runs[0.0][0].trajectory()
+    assert poses0.shape[0] == 2 and np.all(cov0 == 0)  # logging off: two poses for the extrapolation, no covariances
+    poses1, times1, cov1 = runs[0.35][0].trajectory()
+    assert poses1.shape[0] == 4 and np.allclose(times1[-1] - times1[0], 0.3) and np.any(cov1[-1] != 0)
+    poses2, times2, _ = runs[-1.0][0].trajectory()
+    assert poses2.shape[0] == 8 and np.array_equal(poses2[-2:], poses0)
+    assert runs[0.0][1][2:] == [1.0] * 6      # 5 m/s under a 6 m/s limit
+    assert runs[-1.0][1][2:] == [0.0] * 6     # ... and over a 4 m/s limit
+    s = runs[-1.0][0]
+    assert np.allclose(s.latency_compensated_world_transform(), poses2[-1], atol=1e-14, rtol=0)  # latency 0 (through a quaternion)
+    s.set_param("Latency", 0.05)
+    ahead = s.latency_compensated_world_transform()
+    v = (poses2[-1][:3, 3] - poses2[-2][:3, 3]) / (times2[-1] - times2[-2])
+    assert np.allclose(ahead[:3, 3], poses2[-1][:3, 3] + 0.05 * v, atol=1e-12)
+    s.set_param("Latency", 1.0)  # more than MaxExtrapolationRatio x the frame period: no extrapolation
+    assert np.array_equal(s.latency_compensated_world_transform(), poses2[-1])

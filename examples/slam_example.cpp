@@ -5,6 +5,7 @@
 //   ./slam_example [model=16] [frames=5]      prints "frame x y z" of every pose
 #include <cstdio>
 #include <cstdlib>
+#include <memory>
 #include "LidarSlam/Slam.h"
 
 int main(int argc, char** argv)
@@ -46,6 +47,21 @@ int main(int argc, char** argv)
     std::printf("# comply %d\n", slam.GetComplyMotionLimits() ? 1 : 0);
     const LidarSlam::Transform ahead = slam.GetLatencyCompensatedWorldTransform();
     std::printf("# ahead %.12f %.12f\n", ahead.x(), slam.GetLatency());
+    // two LiDAR devices on one platform: the same scan handed over twice, the copy as device 1 with an extractor
+    // and an offset of its own (Slam::AddFrames, SetKeyPointsExtractor, SetBaseToLidarOffset)
+    {
+      LidarSlam::Slam rig;
+      auto second = std::make_shared<LidarSlam::SpinningSensorKeypointExtractor>();
+      second->SetEdgeIntensityGapThreshold(40.f);
+      rig.SetKeyPointsExtractor(second, 1);
+      rig.SetBaseToLidarOffset({{1, 0, 0, 0.5, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1}}, 1);
+      LidarSlam::Slam::PointCloud::Ptr copy(new LidarSlam::Slam::PointCloud(*last));
+      for (auto& p : copy->points) p.device_id = 1;
+      copy->header.stamp = last->header.stamp + 1000;
+      rig.AddFrames({last, copy});
+      std::printf("# rig %d %d %d\n", (int)rig.GetKeypoints(LidarSlam::EDGE)->size(), (int)rig.GetKeypoints(LidarSlam::PLANE)->size(),
+                  (int)rig.GetRegisteredFrame()->size());
+    }
     LidarSlam::SpinningSensorKeypointExtractor ke;
     ke.ComputeKeyPoints(last);
     const auto dbg = ke.GetDebugArray();

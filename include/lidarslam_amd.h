@@ -154,6 +154,12 @@ void lsa_set_azimuthal_resolution(lsa_ctx* ctx, float rad);
  * keypoints of type k; keypoints stay on the device, ordered ring-major /
  * index-ascending as SSKE.cxx:575-589 pushes them. */
 int lsa_extract_keypoints(lsa_ctx* ctx, const lsa_extract_params_t* params, int counts[3]);
+/* A further frame of the same Slam::AddFrames call (another LiDAR device, Slam.cxx:753-801): the frame in the context
+ * is extracted with `params` (and the azimuthal resolution set for that device) and its keypoints are appended to
+ * the RAW_CURRENT sets instead of replacing them -- AggregateFrames(keypoints, false) (Slam.cxx:1512-1578):
+ * time += time_offset, then the rigid transform sensor -> BASE (NULL = identity, coordinates untouched).
+ * counts[] = keypoints of this frame per type. */
+int lsa_extract_keypoints_more(lsa_ctx* ctx, const lsa_extract_params_t* params, const double base_to_lidar[16], double time_offset, int counts[3]);
 /* Keypoint types lsa_extract_keypoints keeps (bit k = type k; Slam::UseKeypoints, Slam.h:406): the others
  * come out empty, exactly as Slam::ExtractKeypoints drops them (Slam.cxx:789-793).  Default: all three. */
 int lsa_set_keypoint_types(lsa_ctx* ctx, unsigned type_mask);
@@ -328,6 +334,10 @@ int lsa_staged_transformed(lsa_ctx* ctx, int type, const lsa_point_t** pts, int*
  * (t1); else rigid H0. */
 int lsa_transform_frame(lsa_ctx* ctx, int interpolate, const double H0[16], const double H1[16], double t0, double t1,
                         lsa_point_t* out, int capacity);
+/* Same for a further frame of a multi-device AddFrames call: every point's time is shifted by time_offset first
+ * (frame stamp - first frame's stamp, Slam.cxx:1536-1549) and stored shifted. */
+int lsa_transform_frame_at(lsa_ctx* ctx, int interpolate, const double H0[16], const double H1[16], double t0, double t1, double time_offset,
+                           lsa_point_t* out, int capacity);
 
 /* Device self-test of the arithmetic the bit-exact parity rests on: evaluates fn on the GPU for n
  * inputs.  fn: 0 lsa_sin(x) 1 lsa_cos(x) 2 lsa_atan2(y, x) 3 (float)sqrt((float)x)
@@ -398,9 +408,19 @@ int lsa_slam_get_stats(const lsa_slam* s, double out[16]);
  *   [9] latency [s].
  * - GetMap(k, clean) / GetTargetSubMap(k) (Slam.cxx:670-688): return the full size, write at most capacity points. */
 int lsa_slam_get_latency_compensated_world_transform(const lsa_slam* s, double T[16], double* time);
-/* Slam::SetBaseToLidarOffset / GetBaseToLidarOffset (Slam.h:249-250, Slam.cxx:1540-1575): rigid transform from the
- * sensor to the BASE frame, applied to the keypoints after the extraction.  One LiDAR device per Slam in this
- * round: device_id must be 0. */
+/* Several LiDAR devices on one platform (Slam.h:133-138, 239-250; Slam.cxx:753-801, 1512-1578).
+ * - lsa_slam_add_frames = Slam::AddFrames: one frame per device (at most 16), each with its own stamp; the device is
+ *   the device_id of the frame's first point; the pose is dated by the first frame's stamp.  Every frame is extracted
+ *   with its device's extractor and the keypoints are merged in frame order, moved to BASE by the device's offset and
+ *   shifted in time by (its stamp - the first stamp).  A frame of a device without an extractor uses the default one
+ *   when no other device has one, and is ignored otherwise, as in the reference.
+ * - lsa_slam_set_extractor_param = SetKeyPointsExtractor(extractor, deviceId) + the extractor's setter `name`
+ *   ("NeighborWidth" ... "EdgeIntensityGapThreshold", "AzimuthalResolution"); device 0 always has an extractor.
+ * - lsa_slam_set_base_to_lidar_offset / get = SetBaseToLidarOffset / GetBaseToLidarOffset(deviceId): rigid transform
+ *   from the sensor to BASE (identity for a device nobody configured), device_id in [0, 255]. */
+int lsa_slam_add_frames(lsa_slam* s, const lsa_point_t* const* pts, const int* n, const uint64_t* stamp_us, const uint32_t* seq, int nframes);
+int lsa_slam_set_extractor_param(lsa_slam* s, int device_id, const char* name, double value);
+int lsa_slam_get_extractor_param(const lsa_slam* s, int device_id, const char* name, double* value);
 int lsa_slam_set_base_to_lidar_offset(lsa_slam* s, const double T[16], int device_id);
 int lsa_slam_get_base_to_lidar_offset(const lsa_slam* s, double T[16], int device_id);
 int lsa_slam_set_world_transform_from_guess(lsa_slam* s, const double T[16]);

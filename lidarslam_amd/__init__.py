@@ -53,7 +53,7 @@ DEBUG_NAMES = [
 ABI_SYMBOLS = [
     "lsa_device_count", "lsa_ctx_create", "lsa_ctx_destroy", "lsa_last_error", "lsa_sync", "lsa_upload_frame", "lsa_upload_wire_frame",
     "lsa_frame_store_put", "lsa_frame_store_use", "lsa_frame_size", "lsa_get_azimuthal_resolution",
-    "lsa_set_azimuthal_resolution", "lsa_extract_keypoints", "lsa_set_keypoint_types", "lsa_download_keypoints", "lsa_keypoint_count",
+    "lsa_set_azimuthal_resolution", "lsa_extract_keypoints", "lsa_extract_keypoints_more", "lsa_transform_frame_at", "lsa_set_keypoint_types", "lsa_download_keypoints", "lsa_keypoint_count",
     "lsa_download_debug", "lsa_nb_laser_rings", "lsa_transform_keypoints", "lsa_set_target", "lsa_set_target_from_set", "lsa_target_staging", "lsa_set_target_staged",
     "lsa_target_size", "lsa_download_target", "lsa_set_target_cell_size", "lsa_set_knn_lanes", "lsa_set_knn_rounds", "lsa_match_slow_queries", "lsa_match_exhaustive_queries", "lsa_set_keypoints", "lsa_match", "lsa_match_types",
     "lsa_download_match", "lsa_overlap", "lsa_accumulate", "lsa_solve", "lsa_registration_error", "lsa_selftest_math", "lsa_reset_working_keypoints", "lsa_undistort", "lsa_working_time_range",
@@ -63,7 +63,7 @@ ABI_SYMBOLS = [
     "lsa_slam_get_world_transform", "lsa_slam_get_covariance", "lsa_slam_get_keypoints", "lsa_slam_get_registered_frame",
     "lsa_slam_get_match_status", "lsa_slam_get_stats", "lsa_slam_context", "lsa_slam_get_latency_compensated_world_transform",
     "lsa_slam_set_world_transform_from_guess", "lsa_slam_get_trajectory", "lsa_slam_get_debug_information", "lsa_slam_get_map",
-    "lsa_slam_get_target_submap", "lsa_slam_set_base_to_lidar_offset", "lsa_slam_get_base_to_lidar_offset", "lsa_match_serial", "lsa_match_histogram", "lsa_synth_sensor", "lsa_synth_frame",
+    "lsa_slam_get_target_submap", "lsa_slam_set_base_to_lidar_offset", "lsa_slam_get_base_to_lidar_offset", "lsa_slam_add_frames", "lsa_slam_set_extractor_param", "lsa_slam_get_extractor_param", "lsa_match_serial", "lsa_match_histogram", "lsa_synth_sensor", "lsa_synth_frame",
     "lsa_synth_pose",
     "lsa_rolling_grid_create", "lsa_rolling_grid_destroy", "lsa_rolling_grid_set", "lsa_rolling_grid_reset", "lsa_rolling_grid_clear",
     "lsa_rolling_grid_size", "lsa_rolling_grid_roll", "lsa_rolling_grid_add", "lsa_rolling_grid_clear_old_points", "lsa_rolling_grid_get",
@@ -152,6 +152,9 @@ def lib():
     L.lsa_slam_get_latency_compensated_world_transform.argtypes = [vp, vp, vp]
     L.lsa_slam_set_world_transform_from_guess.argtypes = [vp, vp]
     L.lsa_slam_get_trajectory.argtypes = [vp, vp, vp, i32]
+    L.lsa_slam_add_frames.argtypes = [vp, vp, vp, vp, vp, i32]
+    L.lsa_slam_set_extractor_param.argtypes = [vp, i32, C.c_char_p, f64]
+    L.lsa_slam_get_extractor_param.argtypes = [vp, i32, C.c_char_p, vp]
     L.lsa_slam_set_base_to_lidar_offset.argtypes = [vp, vp, i32]
     L.lsa_slam_get_base_to_lidar_offset.argtypes = [vp, vp, i32]
     L.lsa_slam_get_debug_information.argtypes = [vp, vp]
@@ -488,6 +491,24 @@ class Slam:
     def set_world_transform_from_guess(self, T):
         T = np.ascontiguousarray(T, np.float64).reshape(16)
         self._check(self.L.lsa_slam_set_world_transform_from_guess(self.h, ptr(T)), "lsa_slam_set_world_transform_from_guess")
+
+    def add_frames(self, frames, stamps_us, seq=0):
+        """Slam::AddFrames: one frame per LiDAR device, each with its own stamp"""
+        frames = [np.ascontiguousarray(f, POINT_DTYPE) for f in frames]
+        ptrs = (C.c_void_p * len(frames))(*[f.ctypes.data if f.size else None for f in frames])
+        sizes = np.array([f.size for f in frames], np.int32)
+        stamps = np.array(stamps_us, np.uint64)
+        seqs = np.full(len(frames), seq, np.uint32)
+        self._n = max(self._n, int(sizes.sum()))
+        return self._check(self.L.lsa_slam_add_frames(self.h, ptrs, ptr(sizes), ptr(stamps), ptr(seqs), len(frames)), "lsa_slam_add_frames")
+
+    def set_extractor_param(self, device_id, name, value):
+        self._check(self.L.lsa_slam_set_extractor_param(self.h, device_id, name.encode(), float(value)), "lsa_slam_set_extractor_param")
+
+    def extractor_param(self, device_id, name):
+        v = C.c_double()
+        self._check(self.L.lsa_slam_get_extractor_param(self.h, device_id, name.encode(), C.byref(v)), "lsa_slam_get_extractor_param")
+        return v.value
 
     def set_base_to_lidar_offset(self, T, device_id=0):
         T = np.ascontiguousarray(T, np.float64).reshape(16)

@@ -136,16 +136,38 @@ int lsa_slam_get_latency_compensated_world_transform(const lsa_slam* s, double T
 
 int lsa_slam_set_base_to_lidar_offset(lsa_slam* s, const double T[16], int device_id)
 {
-  if (!s || !T || device_id != 0) return LSA_E_ARG;
-  std::memcpy(s->core.BaseToLidarOffset.m, T, 16 * sizeof(double));
-  return LSA_OK;
+  if (!s || !T) return LSA_E_ARG;
+  lsa::host::Pose p;
+  std::memcpy(p.m, T, sizeof(p.m));
+  return s->core.SetBaseToLidarOffset(device_id, p);
 }
 
 int lsa_slam_get_base_to_lidar_offset(const lsa_slam* s, double T[16], int device_id)
 {
-  if (!s || !T || device_id != 0) return LSA_E_ARG;
-  std::memcpy(T, s->core.BaseToLidarOffset.m, 16 * sizeof(double));
+  if (!s || !T || device_id < 0 || device_id > 255) return LSA_E_ARG;
+  const lsa::host::Pose p = s->core.GetBaseToLidarOffset(device_id);
+  std::memcpy(T, p.m, sizeof(p.m));
   return LSA_OK;
+}
+
+int lsa_slam_set_extractor_param(lsa_slam* s, int device_id, const char* name, double value)
+{
+  if (!s || !name) return LSA_E_ARG;
+  return s->core.SetExtractorParam(device_id, name, value);
+}
+
+int lsa_slam_get_extractor_param(const lsa_slam* s, int device_id, const char* name, double* value)
+{
+  if (!s || !name) return LSA_E_ARG;
+  return s->core.GetExtractorParam(device_id, name, value);
+}
+
+int lsa_slam_add_frames(lsa_slam* s, const lsa_point_t* const* pts, const int* n, const uint64_t* stamp_us, const uint32_t* seq, int nframes)
+{
+  if (!s || !pts || !n || !stamp_us || nframes <= 0 || nframes > 16) return LSA_E_ARG;
+  lsa::host::SlamCore::InputFrame frames[16];
+  for (int i = 0; i < nframes; ++i) frames[i] = {pts[i], n[i], stamp_us[i], seq ? seq[i] : 0u};
+  return s->core.AddFrames(frames, nframes);
 }
 
 int lsa_slam_set_world_transform_from_guess(lsa_slam* s, const double T[16])

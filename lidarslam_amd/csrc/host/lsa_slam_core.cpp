@@ -106,6 +106,18 @@ SlamCore::~SlamCore()
   if (Ctx) lsa_ctx_destroy(Ctx);
 }
 
+namespace
+{
+// Slam::AddFrames with several frames keeps them in the last slots of the context's frame store
+constexpr int kMaxDeviceFrames = 16;
+constexpr int kFirstDeviceFrameSlot = 65536 - kMaxDeviceFrames - 1;
+
+lsa_extract_params_t DefaultExtractParams()
+{
+  return lsa_extract_params_t{4, 1.5f, 10.f, 0.5f, 0.86f, 0.20f, 0.15f, 1.5f, 50.f};  // SSKE.h:125-148
+}
+}  // namespace
+
 int SlamCore::Fail(int rc, const char* where)
 {
   LastError = std::string(where) + ": " + (Ctx ? lsa_last_error(Ctx) : "no context");
@@ -129,6 +141,7 @@ void SlamCore::Reset(bool resetLog)
       for (int k = 0; k < 3; ++k) lsa_set_keypoints(Ctx, s, k, nullptr, 0);
   for (int k = 0; k < 3; ++k) { EgoDebug[k] = MatchDebug(); LocDebug[k] = MatchDebug(); KeypointCounts[k] = 0; SpecBuilt[k] = false; }
   SpecPending = false;
+  CurrentFrames.clear();
   for (int k = 0; k < 3; ++k) EgoMatchSerial[k] = LocMatchSerial[k] = 0;
   if (resetLog)
   {
@@ -206,6 +219,13 @@ int SlamCore::AddFrame(const lsa_point_t* pts, int n, uint64_t stampUs, uint32_t
   Stats = FrameStats();
   if (!pts || n <= 0) { LastError = "SLAM input only contains empty pointclouds : exiting."; return LSA_OK; }
   if (stampUs == CurrentStamp) { LastError = "SLAM frames have the same timestamp as previous ones : frames ignored."; return LSA_OK; }
+  if (pts[0].device_id != 0 && (!OtherExtractors.empty() || !OtherBaseToLidarOffsets.empty()))
+  {
+    // a frame of another device that has an extractor or an offset of its own
+    const InputFrame f{pts, n, stampUs, 0};
+    return AddFrames(&f, 1);
+  }
+  CurrentFrames.clear();
   LSA_TRY(lsa_upload_frame(Ctx, pts, n));
   int rc = ProcessCurrentFrame(stampUs);
   Latency = Stats.total = total.Stop();
@@ -218,10 +238,106 @@ int SlamCore::AddStoredFrame(int slot, uint64_t stampUs, uint32_t)
   Tick total;
   Stats = FrameStats();
   if (stampUs == CurrentStamp) { LastError = "SLAM frames have the same timestamp as previous ones : frames ignored."; return LSA_OK; }
+  CurrentFrames.clear();
   LSA_TRY(lsa_frame_store_use(Ctx, slot));
   int rc = ProcessCurrentFrame(stampUs);
   Latency = Stats.total = total.Stop();
   return rc;
+}
+
+// Slam::AddFrames with several frames, one per LiDAR device (Slam.cxx:230-344; CheckFrames :709-743)
+int SlamCore::AddFrames(const InputFrame* frames, int nframes)
+{
+  if (!Ctx) return LSA_E_NO_DEVICE;
+  if (!frames || nframes <= 0 || nframes > kMaxDeviceFrames) { LastError = "AddFrames: between 1 and 16 frames"; return LSA_E_ARG; }
+  // one frame of the default device with nothing configured per device: the plain path (no device-resident copy)
+  const bool perDevice = !OtherExtractors.empty() || !OtherBaseToLidarOffsets.empty();
+  if (nframes == 1 && (!frames[0].pts || frames[0].n <= 0 || frames[0].pts[0].device_id == 0 || !perDevice))
+    return AddFrame(frames[0].pts, frames[0].n, frames[0].stampUs, frames[0].seq);
+  Tick total;
+  Stats = FrameStats();
+  bool allEmpty = true;
+  for (int i = 0; i < nframes; ++i)
+    if (frames[i].pts && frames[i].n > 0) allEmpty = false;
+  if (allEmpty) { LastError = "SLAM input only contains empty pointclouds : exiting."; return LSA_OK; }
+  if (frames[0].stampUs == CurrentStamp) { LastError = "SLAM frames have the same timestamp as previous ones : frames ignored."; return LSA_OK; }
+  // the frames become device-resident: the extraction, the registered frame and the overlap estimator read them
+  CurrentFrames.clear();
+  Device0AzimuthalResolution = lsa_get_azimuthal_resolution(Ctx);
+  for (int i = 0; i < nframes; ++i)
+  {
+    if (!frames[i].pts || frames[i].n <= 0) continue;  // "SLAM input frame i is an empty pointcloud : frame ignored."
+    const int device = frames[i].pts[0].device_id;
+    // the azimuthal resolution is estimated from a device's first frame while it is handed over
+    float* az = device == 0 ? &Device0AzimuthalResolution : (OtherExtractors.count(device) ? &OtherExtractors[device].azimuthalResolution : nullptr);
+    if (!az && OtherExtractors.empty()) az = &Device0AzimuthalResolution;  // the default extractor stands in (Slam.cxx:766-772)
+    lsa_set_azimuthal_resolution(Ctx, az ? *az : 1.f);
+    const int slot = kFirstDeviceFrameSlot + i;
+    LSA_TRY(lsa_frame_store_put(Ctx, slot, frames[i].pts, frames[i].n));
+    if (az) *az = lsa_get_azimuthal_resolution(Ctx);
+    CurrentFrames.push_back({slot, frames[i].n, device, StampToSec(frames[i].stampUs) - StampToSec(frames[0].stampUs)});
+  }
+  lsa_set_azimuthal_resolution(Ctx, Device0AzimuthalResolution);
+  int rc = ProcessCurrentFrame(frames[0].stampUs);
+  Latency = Stats.total = total.Stop();
+  return rc;
+}
+
+int SlamCore::SetExtractorParam(int deviceId, const std::string& name, double v)
+{
+  if (deviceId < 0 || deviceId > 255) return LSA_E_ARG;
+  if (deviceId == 0) return SetParam(name, v);
+  const bool known = OtherExtractors.count(deviceId) != 0;
+  DeviceExtractor e = known ? OtherExtractors[deviceId] : DeviceExtractor{DefaultExtractParams(), 0.f};
+  lsa_extract_params_t& p = e.params;
+  if (name == "NeighborWidth") p.neighbor_width = static_cast<int>(v);
+  else if (name == "MinDistanceToSensor") p.min_distance_to_sensor = static_cast<float>(v);
+  else if (name == "MinBeamSurfaceAngle") p.min_beam_surface_angle = static_cast<float>(v);
+  else if (name == "PlaneSinAngleThreshold") p.plane_sin_angle_threshold = static_cast<float>(v);
+  else if (name == "EdgeSinAngleThreshold") p.edge_sin_angle_threshold = static_cast<float>(v);
+  else if (name == "EdgeDepthGapThreshold") p.edge_depth_gap_threshold = static_cast<float>(v);
+  else if (name == "EdgeSaliencyThreshold") p.edge_saliency_threshold = static_cast<float>(v);
+  else if (name == "EdgeIntensityGapThreshold") p.edge_intensity_gap_threshold = static_cast<float>(v);
+  else if (name == "AzimuthalResolution") e.azimuthalResolution = static_cast<float>(v);
+  else { LastError = "unknown extractor parameter " + name; return LSA_E_ARG; }
+  OtherExtractors[deviceId] = e;
+  return LSA_OK;
+}
+
+int SlamCore::GetExtractorParam(int deviceId, const std::string& name, double* v) const
+{
+  if (!v) return LSA_E_ARG;
+  if (deviceId == 0) return GetParam(name, v);
+  const auto it = OtherExtractors.find(deviceId);
+  if (it == OtherExtractors.end()) return LSA_E_ARG;
+  const lsa_extract_params_t& p = it->second.params;
+  if (name == "NeighborWidth") *v = p.neighbor_width;
+  else if (name == "MinDistanceToSensor") *v = p.min_distance_to_sensor;
+  else if (name == "MinBeamSurfaceAngle") *v = p.min_beam_surface_angle;
+  else if (name == "PlaneSinAngleThreshold") *v = p.plane_sin_angle_threshold;
+  else if (name == "EdgeSinAngleThreshold") *v = p.edge_sin_angle_threshold;
+  else if (name == "EdgeDepthGapThreshold") *v = p.edge_depth_gap_threshold;
+  else if (name == "EdgeSaliencyThreshold") *v = p.edge_saliency_threshold;
+  else if (name == "EdgeIntensityGapThreshold") *v = p.edge_intensity_gap_threshold;
+  else if (name == "AzimuthalResolution") *v = it->second.azimuthalResolution;
+  else return LSA_E_ARG;
+  return LSA_OK;
+}
+
+int SlamCore::SetBaseToLidarOffset(int deviceId, const Pose& offset)
+{
+  if (deviceId < 0 || deviceId > 255) return LSA_E_ARG;
+  if (deviceId == 0) BaseToLidarOffset = offset;
+  else OtherBaseToLidarOffsets[deviceId] = offset;
+  return LSA_OK;
+}
+
+// Slam::GetBaseToLidarOffset (Slam.cxx): identity for a device nobody configured
+Pose SlamCore::GetBaseToLidarOffset(int deviceId) const
+{
+  if (deviceId == 0) return BaseToLidarOffset;
+  const auto it = OtherBaseToLidarOffsets.find(deviceId);
+  return it == OtherBaseToLidarOffsets.end() ? Pose::Identity() : it->second;
 }
 
 int SlamCore::ProcessCurrentFrame(uint64_t stampUs)
@@ -272,12 +388,56 @@ int SlamCore::ExtractKeypoints()
   for (int k = 0; k < 3; ++k)
     if (UseKeypoints[k]) mask |= 1u << k;
   lsa_set_keypoint_types(Ctx, mask);  // unused types come out empty (Slam.cxx:789-793)
+  if (!CurrentFrames.empty()) return ExtractFrames();
   LSA_TRY(lsa_extract_keypoints(Ctx, &ExtractParams, counts));  // also: PreviousRawKeypoints = CurrentRawKeypoints
   for (int k = 0; k < 3; ++k) KeypointCounts[k] = counts[k];
   // AggregateFrames(keypoints, false): LIDAR -> BASE (Slam.cxx:1551-1573); skipped when identity
   if (!IsApprox(BaseToLidarOffset, Pose::Identity()))
     for (int k = 0; k < 3; ++k)
       if (counts[k] > 0) LSA_TRY(lsa_transform_keypoints(Ctx, LSA_SET_RAW_CURRENT, k, BaseToLidarOffset.m, 0.));
+  return LSA_OK;
+}
+
+// Slam::ExtractKeypoints with several device frames (Slam.cxx:753-801) + AggregateFrames(keypoints, false) (:1512-1578)
+int SlamCore::ExtractFrames()
+{
+  for (int k = 0; k < 3; ++k) KeypointCounts[k] = 0;
+  bool first = true;
+  for (const HeldFrame& f : CurrentFrames)
+  {
+    // the extractor of the frame's device; with a single extractor configured, that one stands in (Slam.cxx:762-779)
+    const lsa_extract_params_t* params = nullptr;
+    float* az = nullptr;
+    if (f.device == 0) { params = &ExtractParams; az = &Device0AzimuthalResolution; }
+    else if (OtherExtractors.count(f.device)) { params = &OtherExtractors[f.device].params; az = &OtherExtractors[f.device].azimuthalResolution; }
+    else if (OtherExtractors.empty()) { params = &ExtractParams; az = &Device0AzimuthalResolution; }
+    else
+    {
+      LastError = "Input frame comes from LiDAR device " + std::to_string(f.device) + " but no keypoints extractor has been set for this device : ignoring frame.";
+      continue;
+    }
+    LSA_TRY(lsa_frame_store_use(Ctx, f.slot));
+    lsa_set_azimuthal_resolution(Ctx, *az);
+    // the offset is looked up by the device the points say they come from (Slam.cxx:1540)
+    const Pose offset = GetBaseToLidarOffset(f.device);
+    const bool identity = IsApprox(offset, Pose::Identity());
+    int counts[3] = {0, 0, 0};
+    if (first)
+    {
+      LSA_TRY(lsa_extract_keypoints(Ctx, params, counts));  // also: PreviousRawKeypoints = CurrentRawKeypoints
+      if (!identity || f.timeOffset != 0.)
+        for (int k = 0; k < 3; ++k)
+          if (counts[k] > 0) LSA_TRY(lsa_transform_keypoints(Ctx, LSA_SET_RAW_CURRENT, k, offset.m, f.timeOffset));
+    }
+    else
+      LSA_TRY(lsa_extract_keypoints_more(Ctx, params, identity ? nullptr : offset.m, f.timeOffset, counts));
+    first = false;
+    for (int k = 0; k < 3; ++k) KeypointCounts[k] += counts[k];
+  }
+  lsa_set_azimuthal_resolution(Ctx, Device0AzimuthalResolution);
+  if (first)
+    // no frame had an extractor: the current keypoints are empty (the previous ones are not consulted then)
+    for (int k = 0; k < 3; ++k) LSA_TRY(lsa_set_keypoints(Ctx, LSA_SET_RAW_CURRENT, k, nullptr, 0));
   return LSA_OK;
 }
 
@@ -576,6 +736,18 @@ int SlamCore::EstimateOverlap()
     leaf[k] = LocalMaps[k]->GetLeafSize();
     if (UseKeypoints[k] && LocalMaps[k]->IsSubMapValid()) mask |= 1u << k;
   }
+  if (!CurrentFrames.empty())
+  {
+    // several device frames: the estimator samples the aggregated registered cloud (Slam.cxx:1373); it is built
+    // once (GetRegisteredFrame) and handed back as one frame of world points
+    LSA_TRY(GetRegisteredFrame(Scratch));
+    if (Scratch.empty()) { OverlapEstimation = -1.f; return LSA_OK; }
+    LSA_TRY(lsa_frame_store_put(Ctx, kFirstDeviceFrameSlot + kMaxDeviceFrames, Scratch.data(), static_cast<int>(Scratch.size())));
+    LSA_TRY(lsa_frame_store_use(Ctx, kFirstDeviceFrameSlot + kMaxDeviceFrames));
+    const Pose identity = Pose::Identity();
+    LSA_TRY(lsa_overlap(Ctx, mask, 0, identity.m, nullptr, 0., 0., OverlapSamplingRatio, leaf, &OverlapEstimation));
+    return LSA_OK;
+  }
   if (Undistortion)
   {
     const Pose H0 = (Tworld * Motion.GetH0()) * BaseToLidarOffset;
@@ -758,6 +930,32 @@ int SlamCore::GetRegisteredFrame(std::vector<lsa_point_t>& out)
   if (!Ctx) return LSA_E_NO_DEVICE;
   out.clear();
   if (!HaveFrame) return 0;
+  if (!CurrentFrames.empty())
+  {
+    // AggregateFrames(CurrentFrames, true): every device frame with its own offset and time shift (Slam.cxx:1512-1578)
+    size_t total = 0;
+    for (const HeldFrame& f : CurrentFrames) total += static_cast<size_t>(f.n);
+    out.resize(total);
+    size_t at = 0;
+    for (const HeldFrame& f : CurrentFrames)
+    {
+      LSA_TRY(lsa_frame_store_use(Ctx, f.slot));
+      const Pose offset = GetBaseToLidarOffset(f.device);
+      if (Undistortion)
+      {
+        const Pose H0 = (Tworld * Motion.GetH0()) * offset;
+        const Pose H1 = (Tworld * Motion.GetH1()) * offset;
+        LSA_TRY(lsa_transform_frame_at(Ctx, 1, H0.m, H1.m, Motion.Time0, Motion.Time1, f.timeOffset, out.data() + at, f.n));
+      }
+      else
+      {
+        const Pose tf = Tworld * offset;
+        LSA_TRY(lsa_transform_frame_at(Ctx, 0, tf.m, nullptr, 0., 0., f.timeOffset, out.data() + at, f.n));
+      }
+      at += static_cast<size_t>(f.n);
+    }
+    return static_cast<int>(total);
+  }
   const int n = lsa_frame_size(Ctx);
   if (n <= 0) return 0;
   out.resize(n);

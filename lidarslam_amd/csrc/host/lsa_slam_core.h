@@ -11,6 +11,7 @@
 #include <condition_variable>
 #include <deque>
 #include <limits>
+#include <map>
 #include <functional>
 #include <memory>
 #include <mutex>
@@ -90,6 +91,21 @@ public:
   // Slam::AddFrame on a host scan / on a scan resident in the frame store
   int AddFrame(const lsa_point_t* pts, int n, uint64_t stampUs, uint32_t seq);
   int AddStoredFrame(int slot, uint64_t stampUs, uint32_t seq);
+  // Slam::AddFrames with one frame per LiDAR device (Slam.cxx:230-344, 753-801)
+  struct InputFrame
+  {
+    const lsa_point_t* pts;
+    int n;
+    uint64_t stampUs;
+    uint32_t seq;
+  };
+  int AddFrames(const InputFrame* frames, int nframes);
+  // Slam::SetKeyPointsExtractor(extractor, deviceId) / SetBaseToLidarOffset(transform, deviceId) (Slam.h:239-250):
+  // device 0 always has an extractor (ExtractParams); the others get one with their first parameter
+  int SetExtractorParam(int deviceId, const std::string& name, double v);
+  int GetExtractorParam(int deviceId, const std::string& name, double* v) const;
+  int SetBaseToLidarOffset(int deviceId, const Pose& offset);
+  Pose GetBaseToLidarOffset(int deviceId) const;
 
   Pose GetWorldTransform(double* time = nullptr) const;
   // Slam::GetLatencyCompensatedWorldTransform (Slam.cxx:555-590): the last pose extrapolated by Latency
@@ -146,8 +162,15 @@ public:
   // Slam::LoggingTimeout (Slam.h:425-438): 0 keeps the last two poses, > 0 the poses of that many seconds, < 0 all
   double LoggingTimeout = 0.;
   double Latency = 0.;  // duration of the last AddFrame [s] (Slam::GetLatency)
-  Pose BaseToLidarOffset = Pose::Identity();
-  lsa_extract_params_t ExtractParams;
+  Pose BaseToLidarOffset = Pose::Identity();  // device 0
+  lsa_extract_params_t ExtractParams;         // device 0
+  struct DeviceExtractor
+  {
+    lsa_extract_params_t params;
+    float azimuthalResolution = 0.f;  // estimated from that device's first frame
+  };
+  std::map<int, DeviceExtractor> OtherExtractors;  // devices != 0
+  std::map<int, Pose> OtherBaseToLidarOffsets;
   // edge length of the finest kNN search-grid cells (an implementation knob: results do not depend on it)
   double KnnCellSizeEgoMotion = 0.25;      // [m] previous-scan plane targets (dense)
   double KnnCellSizeEgoMotionEdges = 0.5;  // [m] previous-scan edge targets (sparse)
@@ -190,6 +213,18 @@ private:
   lsa_match_params_t EgoMatchParams() const;
   lsa_match_params_t LocMatchParams() const;
 
+  // the frames of the current AddFrames call when there are several (device-resident, in the last slots of the
+  // context's frame store); empty for the single-frame calls, whose frame is the context's current one
+  struct HeldFrame
+  {
+    int slot;
+    int n;
+    int device;
+    double timeOffset;  // stamp - first frame's stamp [s]
+  };
+  std::vector<HeldFrame> CurrentFrames;
+  float Device0AzimuthalResolution = 0.f;  // parked here while another device's frame is extracted
+  int ExtractFrames();
   lsa_ctx* Ctx = nullptr;
   std::string LastError;
   uint64_t CurrentStamp = 0;

@@ -114,6 +114,7 @@ struct lsa_ctx
   int frame_n = 0;
   int cap_n = 0;  // capacity of all N-sized buffers
   std::vector<std::pair<lsa_point_t*, int>> store;
+  std::vector<int> store_cap;  // points each slot's buffer holds
   float az_res = 0.f;
   int nb_rings_seen = 0;
 

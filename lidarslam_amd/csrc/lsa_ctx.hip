@@ -33,7 +33,19 @@ int ensure_capacity(lsa_ctx* ctx, int n)
         LSA_HIP(ctx, hipMemcpy(ctx->kp[s][k], old_kp[s][k], (size_t)ctx->kp_n[s][k] * sizeof(lsa_point_t), hipMemcpyDeviceToDevice));
       if (old_kp[s][k]) (void)hipFree(old_kp[s][k]);
     }
-  LSA_HIP(ctx, dev_alloc(&ctx->frame_own, (size_t)cap));
+  {
+    // an uploaded frame must survive too (a further device frame may need more room for the merged keypoints)
+    lsa_point_t* old_frame = ctx->frame_own;
+    const bool current = old_frame && ctx->frame == old_frame && ctx->frame_n > 0;
+    ctx->frame_own = nullptr;
+    LSA_HIP(ctx, dev_alloc(&ctx->frame_own, (size_t)cap));
+    if (current)
+    {
+      LSA_HIP(ctx, hipMemcpy(ctx->frame_own, old_frame, (size_t)ctx->frame_n * sizeof(lsa_point_t), hipMemcpyDeviceToDevice));
+      ctx->frame = ctx->frame_own;
+    }
+    if (old_frame) (void)hipFree(old_frame);
+  }
   LSA_HIP(ctx, dev_alloc(&ctx->xyzi, (size_t)cap));
   LSA_HIP(ctx, dev_alloc(&ctx->orig, (size_t)cap));
   LSA_HIP(ctx, dev_alloc(&ctx->ring_of, (size_t)cap));
@@ -443,12 +455,21 @@ int lsa_frame_store_put(lsa_ctx* ctx, int slot, const lsa_point_t* pts, int n)
   LSA_HIP(ctx, hipSetDevice(ctx->device));
   int rc = ensure_capacity(ctx, n);
   if (rc) return rc;
-  if ((int)ctx->store.size() <= slot) ctx->store.resize(slot + 1, {nullptr, 0});
-  if (ctx->store[slot].first) { (void)hipFree(ctx->store[slot].first); ctx->store[slot] = {nullptr, 0}; }
-  lsa_point_t* d = nullptr;
-  LSA_HIP(ctx, hipMalloc((void**)&d, (size_t)n * sizeof(lsa_point_t)));
-  LSA_HIP(ctx, hipMemcpy(d, pts, (size_t)n * sizeof(lsa_point_t), hipMemcpyHostToDevice));
+  if ((int)ctx->store.size() <= slot) { ctx->store.resize(slot + 1, {nullptr, 0}); ctx->store_cap.resize(slot + 1, 0); }
+  lsa_point_t* d = ctx->store[slot].first;
+  if (!d || ctx->store_cap[slot] < n)
+  {
+    // the frame in use may be this very slot: nothing may still read it
+    LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (d) { if (ctx->frame == d) { ctx->frame = nullptr; ctx->frame_n = 0; } (void)hipFree(d); ctx->store[slot] = {nullptr, 0}; ctx->store_cap[slot] = 0; }
+    d = nullptr;
+    LSA_HIP(ctx, hipMalloc((void**)&d, (size_t)n * sizeof(lsa_point_t)));
+    ctx->store_cap[slot] = n;
+  }
+  LSA_HIP(ctx, hipMemcpyAsync(d, pts, (size_t)n * sizeof(lsa_point_t), hipMemcpyHostToDevice, ctx->stream));
+  LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));  // pts may be pageable and reused by the caller
   ctx->store[slot] = {d, n};
+  if (ctx->frame == d) ctx->frame_n = n;
   maybe_estimate_resolution(ctx, pts, n);
   return LSA_OK;
 }

@@ -649,15 +649,18 @@ __global__ void k_debug_gather(const uint32_t* __restrict__ orig, int n, int id,
   out[orig[j]] = (id < 4) ? src[j] : (float)((bits[j] >> bit) & 1);
 }
 
-__global__ void k_transform_points(float4* __restrict__ pts, int n, Rigid T, double time_offset)
+__global__ void k_transform_points(float4* __restrict__ pts, int n, Rigid T, double time_offset, int rigid)
 {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   float4 a = pts[2 * (size_t)i];
   float4 b = pts[2 * (size_t)i + 1];
-  double ox, oy, oz;
-  rigid_apply(T, (double)a.x, (double)a.y, (double)a.z, ox, oy, oz);
-  a.x = (float)ox; a.y = (float)oy; a.z = (float)oz;
+  if (rigid)  // AggregateFrames leaves the coordinates alone when the transform is the identity (Slam.cxx:1557-1562)
+  {
+    double ox, oy, oz;
+    rigid_apply(T, (double)a.x, (double)a.y, (double)a.z, ox, oy, oz);
+    a.x = (float)ox; a.y = (float)oy; a.z = (float)oz;
+  }
   double t = __hiloint2double(__float_as_int(b.y), __float_as_int(b.x)) + time_offset;
   b.x = __int_as_float(__double2loint(t));
   b.y = __int_as_float(__double2hiint(t));
@@ -693,7 +696,10 @@ ExtractConst make_const(const lsa_extract_params_t* p, float az_res)
 
 extern "C" {
 
-int lsa_extract_keypoints(lsa_ctx* ctx, const lsa_extract_params_t* params, int counts[3])
+// One device frame through the extraction kernels.  append == false: Slam::ExtractKeypoints' first frame (the
+// current keypoints become the previous ones, Slam.cxx:751); append == true: a further frame of the same
+// AddFrames call, whose keypoints go behind those already there (AggregateFrames, Slam.cxx:1512-1578).
+static int extract_frame(lsa_ctx* ctx, const lsa_extract_params_t* params, int counts[3], bool append, const double* base_to_lidar, double time_offset)
 {
   if (!ctx || !params || !counts) return ctx ? ctx->fail(LSA_E_ARG, "lsa_extract_keypoints: null argument") : LSA_E_ARG;
   if (!ctx->frame || ctx->frame_n <= 0) return ctx->fail(LSA_E_STATE, "lsa_extract_keypoints: no frame uploaded");
@@ -701,21 +707,28 @@ int lsa_extract_keypoints(lsa_ctx* ctx, const lsa_extract_params_t* params, int 
     return ctx->fail(LSA_E_ARG, "lsa_extract_keypoints: NeighborWidth must be in [1, 8]");
   LSA_HIP(ctx, hipSetDevice(ctx->device));
   const int n = ctx->frame_n;
-  int rc = ensure_capacity(ctx, n);
+  int base[3] = {0, 0, 0};
+  if (append)
+    for (int k = 0; k < 3; ++k) base[k] = ctx->kp_n[LSA_SET_RAW_CURRENT][k];
+  // a type's keypoints of this frame are at most its points: room for them behind what is there
+  int rc = ensure_capacity(ctx, n + std::max(base[0], std::max(base[1], base[2])));
   if (rc) return rc;
   hipStream_t st = ctx->stream;
   const ExtractConst c = make_const(params, ctx->az_res);
 
-  // Slam::ExtractKeypoints: current keypoints become the previous ones (Slam.cxx:751)
-  for (int k = 0; k < 3; ++k)
+  if (!append)
   {
-    std::swap(ctx->kp[LSA_SET_RAW_CURRENT][k], ctx->kp[LSA_SET_RAW_PREVIOUS][k]);
-    ctx->kp_n[LSA_SET_RAW_PREVIOUS][k] = ctx->kp_n[LSA_SET_RAW_CURRENT][k];
-    ctx->kp_n[LSA_SET_RAW_CURRENT][k] = 0;
+    // Slam::ExtractKeypoints: current keypoints become the previous ones (Slam.cxx:751)
+    for (int k = 0; k < 3; ++k)
+    {
+      std::swap(ctx->kp[LSA_SET_RAW_CURRENT][k], ctx->kp[LSA_SET_RAW_PREVIOUS][k]);
+      ctx->kp_n[LSA_SET_RAW_PREVIOUS][k] = ctx->kp_n[LSA_SET_RAW_CURRENT][k];
+      ctx->kp_n[LSA_SET_RAW_CURRENT][k] = 0;
+    }
+    ctx->kp_time_valid[LSA_SET_RAW_PREVIOUS] = ctx->kp_time_valid[LSA_SET_RAW_CURRENT];
+    ctx->kp_time[LSA_SET_RAW_PREVIOUS][0] = ctx->kp_time[LSA_SET_RAW_CURRENT][0];
+    ctx->kp_time[LSA_SET_RAW_PREVIOUS][1] = ctx->kp_time[LSA_SET_RAW_CURRENT][1];
   }
-  ctx->kp_time_valid[LSA_SET_RAW_PREVIOUS] = ctx->kp_time_valid[LSA_SET_RAW_CURRENT];
-  ctx->kp_time[LSA_SET_RAW_PREVIOUS][0] = ctx->kp_time[LSA_SET_RAW_CURRENT][0];
-  ctx->kp_time[LSA_SET_RAW_PREVIOUS][1] = ctx->kp_time[LSA_SET_RAW_CURRENT][1];
   ctx->kp_time_valid[LSA_SET_RAW_CURRENT] = false;
 
   const int nblocks = (n + kBucketChunk - 1) / kBucketChunk;
@@ -750,8 +763,8 @@ int lsa_extract_keypoints(lsa_ctx* ctx, const lsa_extract_params_t* params, int 
   {
     ProfScope ps(ctx, "compact", (double)n * (1 + 4));
     hipLaunchKernelGGL(k_compact, dim3(kMaxRings), dim3(256), 0, st, frame4, ctx->orig, ctx->label, ctx->ring_start, ctx->ring_len,
-                       ctx->ring_meta, ctx->ring_counts, reinterpret_cast<float4*>(ctx->kp[LSA_SET_RAW_CURRENT][0]),
-                       reinterpret_cast<float4*>(ctx->kp[LSA_SET_RAW_CURRENT][1]), reinterpret_cast<float4*>(ctx->kp[LSA_SET_RAW_CURRENT][2]),
+                       ctx->ring_meta, ctx->ring_counts, reinterpret_cast<float4*>(ctx->kp[LSA_SET_RAW_CURRENT][0] + base[0]),
+                       reinterpret_cast<float4*>(ctx->kp[LSA_SET_RAW_CURRENT][1] + base[1]), reinterpret_cast<float4*>(ctx->kp[LSA_SET_RAW_CURRENT][2] + base[2]),
                        ctx->kp_count_dev, ctx->kp_type_mask, reinterpret_cast<unsigned long long*>(ctx->extract_out + 12));
   }
   // counts, ring_meta and the keypoints' time range (Slam::InitUndistortion needs it later) in one 64-byte read-back
@@ -766,10 +779,33 @@ int lsa_extract_keypoints(lsa_ctx* ctx, const lsa_extract_params_t* params, int 
   for (int k = 0; k < 3; ++k)
   {
     counts[k] = hp[k];
-    ctx->kp_n[LSA_SET_RAW_CURRENT][k] = hp[k];
+    ctx->kp_n[LSA_SET_RAW_CURRENT][k] = base[k] + hp[k];
   }
-  finish_time_range(ctx, LSA_SET_RAW_CURRENT, hpt);
+  if (!append && !base_to_lidar && time_offset == 0.)
+  {
+    finish_time_range(ctx, LSA_SET_RAW_CURRENT, hpt);
+    return LSA_OK;
+  }
+  // AggregateFrames(keypoints, false) on the points just written: time offset to the first frame's stamp and the
+  // sensor's pose in BASE (Slam.cxx:1536-1575); the set's time range is reduced again when it is asked for
+  Rigid R;
+  const double identity[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  row_major_to_rt(base_to_lidar ? base_to_lidar : identity, R.R, R.t);
+  for (int k = 0; k < 3; ++k)
+    if (hp[k] > 0 && (base_to_lidar || time_offset != 0.))
+      hipLaunchKernelGGL(k_transform_points, dim3((hp[k] + 255) / 256), dim3(256), 0, st,
+                         reinterpret_cast<float4*>(ctx->kp[LSA_SET_RAW_CURRENT][k] + base[k]), hp[k], R, time_offset, base_to_lidar ? 1 : 0);
   return LSA_OK;
+}
+
+int lsa_extract_keypoints(lsa_ctx* ctx, const lsa_extract_params_t* params, int counts[3])
+{
+  return extract_frame(ctx, params, counts, false, nullptr, 0.);
+}
+
+int lsa_extract_keypoints_more(lsa_ctx* ctx, const lsa_extract_params_t* params, const double base_to_lidar[16], double time_offset, int counts[3])
+{
+  return extract_frame(ctx, params, counts, true, base_to_lidar, time_offset);
 }
 
 int lsa_keypoint_count(const lsa_ctx* ctx, int set, int type)
@@ -839,7 +875,7 @@ int lsa_transform_keypoints(lsa_ctx* ctx, int set, int type, const double T[16],
   row_major_to_rt(T, R.R, R.t);
   ProfScope ps(ctx, "transform_keypoints", (double)n * 64);
   hipLaunchKernelGGL(k_transform_points, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, reinterpret_cast<float4*>(ctx->kp[set][type]), n, R,
-                     time_offset);
+                     time_offset, 1);
   return LSA_OK;
 }
 

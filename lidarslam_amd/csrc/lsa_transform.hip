@@ -39,12 +39,19 @@ __global__ __launch_bounds__(256) void k_undistort(KpSetsRW s, InterpConst c)
 
 // out = T(point) for a whole set; interpolate != 0 -> per-point pose
 __global__ __launch_bounds__(256) void k_transform_out(const float4* __restrict__ in, int n, int interpolate, InterpConst c, Rigid R,
-                                                       float4* __restrict__ out)
+                                                       double time_offset, float4* __restrict__ out)
 {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   float4 a = in[2 * (size_t)i];
-  const float4 b = in[2 * (size_t)i + 1];
+  float4 b = in[2 * (size_t)i + 1];
+  if (time_offset != 0.)
+  {
+    // point.time += timeOffset, before the pose is evaluated at it (Slam.cxx:1547-1549)
+    const double t = point_time(b) + time_offset;
+    b.x = __int_as_float(__double2loint(t));
+    b.y = __int_as_float(__double2hiint(t));
+  }
   Rigid T = R;
   if (interpolate) interp_eval(c, point_time(b), T);
   double ox, oy, oz;
@@ -517,7 +524,7 @@ int lsa_download_transformed(lsa_ctx* ctx, int set, int type, const double pose[
   {
     ProfScope ps(ctx, "transform_keypoints_out", (double)n * 64);
     hipLaunchKernelGGL(k_transform_out, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, reinterpret_cast<const float4*>(ctx->kp[set][type]), n, 0, dummy,
-                       T, reinterpret_cast<float4*>(ctx->scratch_out));
+                       T, 0., reinterpret_cast<float4*>(ctx->scratch_out));
   }
   LSA_HIP(ctx, hipMemcpyAsync(out, ctx->scratch_out, (size_t)n * sizeof(lsa_point_t), hipMemcpyDeviceToHost, ctx->stream));
   LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -526,6 +533,12 @@ int lsa_download_transformed(lsa_ctx* ctx, int set, int type, const double pose[
 
 int lsa_transform_frame(lsa_ctx* ctx, int interpolate, const double H0[16], const double H1[16], double t0, double t1, lsa_point_t* out,
                         int capacity)
+{
+  return lsa_transform_frame_at(ctx, interpolate, H0, H1, t0, t1, 0., out, capacity);
+}
+
+int lsa_transform_frame_at(lsa_ctx* ctx, int interpolate, const double H0[16], const double H1[16], double t0, double t1, double time_offset,
+                           lsa_point_t* out, int capacity)
 {
   if (!ctx || !H0 || (interpolate && !H1) || !out) return ctx ? ctx->fail(LSA_E_ARG, "lsa_transform_frame: bad argument") : LSA_E_ARG;
   if (!ctx->frame || ctx->frame_n <= 0) return ctx->fail(LSA_E_STATE, "lsa_transform_frame: no frame");
@@ -541,7 +554,7 @@ int lsa_transform_frame(lsa_ctx* ctx, int interpolate, const double H0[16], cons
   {
     ProfScope ps(ctx, "transform_frame", (double)n * 64);
     hipLaunchKernelGGL(k_transform_out, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, reinterpret_cast<const float4*>(ctx->frame), n, interpolate, c, T,
-                       reinterpret_cast<float4*>(ctx->scratch_out));
+                       time_offset, reinterpret_cast<float4*>(ctx->scratch_out));
   }
   LSA_HIP(ctx, hipMemcpyAsync(out, ctx->scratch_out, (size_t)n * sizeof(lsa_point_t), hipMemcpyDeviceToHost, ctx->stream));
   LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -13,7 +13,7 @@
 // present Transform::GetIsometry() is offered as well.
 //
 // Not mirrored (outside the hot path): pose-graph optimisation, GPS calibration, wheel
-// odometry / IMU constraints, PCD map IO, keypoint logging, several LiDAR devices per Slam.
+// odometry / IMU constraints, PCD map IO, keypoint logging.
 #pragma once
 #include <algorithm>
 #include <array>
@@ -83,14 +83,24 @@ public:
 
   // ---- main use (Slam.h:111-146)
   void AddFrame(const PointCloud::Ptr& pc) { this->AddFrames({pc}); }
+  // one frame per LiDAR device (at most 16): extracted with the device's extractor, merged in BASE (Slam.cxx:753-801)
   void AddFrames(const std::vector<PointCloud::Ptr>& frames)
   {
-    // one LiDAR device per call in this round (the reference aggregates several, Slam.cxx:753-801)
-    if (frames.empty() || !frames[0]) return;
-    const PointCloud& pc = *frames[0];
-    this->CurrentStamp = pc.header.stamp;
-    const int rc = lsa_slam_add_frame(this->Handle, reinterpret_cast<const lsa_point_t*>(pc.points.data()), static_cast<int>(pc.size()),
-                                      pc.header.stamp, pc.header.seq);
+    if (frames.empty() || !frames[0] || frames.size() > 16) return;
+    const lsa_point_t* pts[16];
+    int n[16];
+    std::uint64_t stamps[16];
+    std::uint32_t seqs[16];
+    for (std::size_t i = 0; i < frames.size(); ++i)
+    {
+      const bool some = frames[i] && !frames[i]->empty();
+      pts[i] = some ? reinterpret_cast<const lsa_point_t*>(frames[i]->points.data()) : nullptr;
+      n[i] = some ? static_cast<int>(frames[i]->size()) : 0;
+      stamps[i] = frames[i] ? frames[i]->header.stamp : frames[0]->header.stamp;
+      seqs[i] = frames[i] ? frames[i]->header.seq : 0;
+    }
+    this->CurrentStamp = frames[0]->header.stamp;
+    const int rc = lsa_slam_add_frames(this->Handle, pts, n, stamps, seqs, static_cast<int>(frames.size()));
     if (rc < 0) this->LastError = lsa_slam_last_error(this->Handle);  // like the reference: report, keep the previous pose
   }
   Transform GetWorldTransform() const
@@ -204,11 +214,36 @@ public:
   LSA_SLAM_ENUM_PARAM(MapUpdate, MappingMode)
   LSA_SLAM_PARAM(KeepMatchDebug, bool)
   LSA_SLAM_PARAM(LoggingTimeout, double)
-  // Slam.h:249-250 (row-major 4x4; one LiDAR device per Slam: deviceId must be 0)
+  // Slam.h:239-245: the extraction runs inside the library, so what is taken from the extractor object is its
+  // parameters (and its azimuthal resolution when it has one); the object is kept for GetKeyPointsExtractor
+  using KeypointExtractorPtr = std::shared_ptr<SpinningSensorKeypointExtractor>;
+  void SetKeyPointsExtractor(KeypointExtractorPtr extractor, std::uint8_t deviceId = 0)
+  {
+    if (!extractor) return;
+    const std::pair<const char*, double> values[] = {
+      {"NeighborWidth", extractor->GetNeighborWidth()}, {"MinDistanceToSensor", extractor->GetMinDistanceToSensor()},
+      {"MinBeamSurfaceAngle", extractor->GetMinBeamSurfaceAngle()}, {"PlaneSinAngleThreshold", extractor->GetPlaneSinAngleThreshold()},
+      {"EdgeSinAngleThreshold", extractor->GetEdgeSinAngleThreshold()}, {"EdgeDepthGapThreshold", extractor->GetEdgeDepthGapThreshold()},
+      {"EdgeSaliencyThreshold", extractor->GetEdgeSaliencyThreshold()}, {"EdgeIntensityGapThreshold", extractor->GetEdgeIntensityGapThreshold()}};
+    for (const auto& v : values) lsa_slam_set_extractor_param(this->Handle, deviceId, v.first, v.second);
+    if (extractor->GetAzimuthalResolution() > 0.f)
+      lsa_slam_set_extractor_param(this->Handle, deviceId, "AzimuthalResolution", extractor->GetAzimuthalResolution());
+    this->KeyPointsExtractors[deviceId] = extractor;
+  }
+  KeypointExtractorPtr GetKeyPointsExtractor(std::uint8_t deviceId = 0) const
+  {
+    const auto it = this->KeyPointsExtractors.find(deviceId);
+    return it != this->KeyPointsExtractors.end() ? it->second : KeypointExtractorPtr();
+  }
+  std::map<std::uint8_t, KeypointExtractorPtr> GetKeyPointsExtractors() const { return this->KeyPointsExtractors; }
+  void SetKeyPointsExtractors(const std::map<std::uint8_t, KeypointExtractorPtr>& extractors)
+  {
+    for (const auto& kv : extractors) this->SetKeyPointsExtractor(kv.second, kv.first);
+  }
+  // Slam.h:249-250 (row-major 4x4)
   void SetBaseToLidarOffset(const std::array<double, 16>& transform, std::uint8_t deviceId = 0)
   {
-    if (lsa_slam_set_base_to_lidar_offset(this->Handle, transform.data(), deviceId) != LSA_OK)
-      throw std::invalid_argument("LidarSlam::Slam: one LiDAR device (id 0) per Slam in this build");
+    lsa_slam_set_base_to_lidar_offset(this->Handle, transform.data(), deviceId);
   }
   std::array<double, 16> GetBaseToLidarOffset(std::uint8_t deviceId = 0) const
   {
@@ -320,6 +355,7 @@ private:
   }
 
   lsa_slam* Handle = nullptr;
+  std::map<std::uint8_t, KeypointExtractorPtr> KeyPointsExtractors;
   std::uint64_t CurrentStamp = 0;
   std::string WorldFrameId = "world", BaseFrameId = "base", LastError;
   int Verbosity = 0;

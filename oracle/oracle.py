@@ -70,7 +70,9 @@ def lib():
         L.orc_slam_get_submap.argtypes = [vp, i32, vp, i32]
         L.orc_slam_get_latency_compensated_world_transform.argtypes = [vp, vp]
         L.orc_slam_set_world_transform_from_guess.argtypes = [vp, vp]
-        L.orc_slam_set_base_to_lidar_offset.argtypes = [vp, vp]
+        L.orc_slam_set_base_to_lidar_offset.argtypes = [vp, vp, i32]
+        L.orc_slam_set_extractor_param.argtypes = [vp, i32, C.c_char_p, f64]
+        L.orc_slam_add_frames.argtypes = [vp, vp, vp, vp, i32]
         L.orc_slam_get_trajectory.argtypes = [vp, vp, vp, i32]
         L.orc_slam_get_debug_information.argtypes = [vp, vp]
         L.orc_slam_get_map.argtypes = [vp, i32, i32, vp, i32]
@@ -340,9 +342,20 @@ class Slam:
         T = np.ascontiguousarray(T, np.float64).reshape(16)
         lib().orc_slam_set_world_transform_from_guess(self.h, ptr(T))
 
-    def set_base_to_lidar_offset(self, T):
+    def set_base_to_lidar_offset(self, T, device_id=0):
         T = np.ascontiguousarray(T, np.float64).reshape(16)
-        lib().orc_slam_set_base_to_lidar_offset(self.h, ptr(T))
+        lib().orc_slam_set_base_to_lidar_offset(self.h, ptr(T), device_id)
+
+    def set_extractor_param(self, device_id, name, value):
+        assert lib().orc_slam_set_extractor_param(self.h, device_id, name.encode(), float(value)) == 0, name
+
+    def add_frames(self, frames, stamps_us, seq=0):
+        frames = [np.ascontiguousarray(f, POINT_DTYPE) for f in frames]
+        ptrs = (C.c_void_p * len(frames))(*[f.ctypes.data if f.size else None for f in frames])
+        sizes = np.array([f.size for f in frames], np.int32)
+        stamps = np.array(stamps_us, np.uint64)
+        self._n = max(getattr(self, "_n", 0), int(sizes.sum()))
+        lib().orc_slam_add_frames(self.h, ptrs, ptr(sizes), ptr(stamps), len(frames))
 
     def trajectory(self, cap=100000):
         """(n, 4, 4) poses, (n,) times, (n, 6, 6) covariances"""

@@ -72,6 +72,7 @@ struct SlamHandle
 {
   Slam s;
   std::vector<Point> frame;
+  std::vector<std::vector<Point>> frames;  // AddFrames
 };
 std::vector<Residual> RecordsToResiduals(const double* records, const uint8_t* status, int n, double sat)
 {
@@ -420,7 +421,10 @@ int orc_slam_add_frame(void* h, const lsa_point_t* pts, int n, uint64_t stampUs,
   std::vector<Point> f((const Point*)pts, (const Point*)pts + n);
   // the frame must outlive the call (GetRegisteredFrame reads it lazily)
   sh->frame.swap(f);
-  sh->s.AddFrame(sh->frame, stampUs, seq);
+  if (n > 0 && sh->frame[0].device_id != 0 && (!sh->s.OtherExtractors.empty() || !sh->s.OtherBaseToLidarOffsets.empty()))
+    sh->s.AddFrames({&sh->frame}, {stampUs});  // a device with an extractor or an offset of its own
+  else
+    sh->s.AddFrame(sh->frame, stampUs, seq);
   return 0;
 }
 int orc_slam_get_world_transform(void* h, double T[16], double* time)
@@ -484,9 +488,44 @@ int orc_slam_get_latency_compensated_world_transform(void* h, double T[16])
   IsoToRowMajor(((SlamHandle*)h)->s.GetLatencyCompensatedWorldTransform(), T);
   return 0;
 }
-int orc_slam_set_base_to_lidar_offset(void* h, const double T[16])
+int orc_slam_set_base_to_lidar_offset(void* h, const double T[16], int device)
 {
-  ((SlamHandle*)h)->s.BaseToLidarOffset = IsoFromRowMajor(T);
+  Slam& s = ((SlamHandle*)h)->s;
+  if (device == 0) s.BaseToLidarOffset = IsoFromRowMajor(T);
+  else s.OtherBaseToLidarOffsets[device] = IsoFromRowMajor(T);
+  return 0;
+}
+int orc_slam_set_extractor_param(void* h, int device, const char* name, double v)
+{
+  Slam& s = ((SlamHandle*)h)->s;
+  Extractor& ke = device == 0 ? s.KeyPointsExtractor : s.OtherExtractors[device];
+  const std::string n(name);
+  if (n == "NeighborWidth") ke.P.NeighborWidth = (int)v;
+  else if (n == "MinDistanceToSensor") ke.P.MinDistanceToSensor = (float)v;
+  else if (n == "MinBeamSurfaceAngle") ke.P.MinBeamSurfaceAngle = (float)v;
+  else if (n == "PlaneSinAngleThreshold") ke.P.PlaneSinAngleThreshold = (float)v;
+  else if (n == "EdgeSinAngleThreshold") ke.P.EdgeSinAngleThreshold = (float)v;
+  else if (n == "EdgeDepthGapThreshold") ke.P.EdgeDepthGapThreshold = (float)v;
+  else if (n == "EdgeSaliencyThreshold") ke.P.EdgeSaliencyThreshold = (float)v;
+  else if (n == "EdgeIntensityGapThreshold") ke.P.EdgeIntensityGapThreshold = (float)v;
+  else if (n == "AzimuthalResolution") ke.AzimuthalResolution = (float)v;
+  else return -3;
+  return 0;
+}
+int orc_slam_add_frames(void* h, const lsa_point_t* const* pts, const int* n, const uint64_t* stampsUs, int nframes)
+{
+  SlamHandle* sh = (SlamHandle*)h;
+  sh->frames.assign(nframes, std::vector<Point>());
+  std::vector<const std::vector<Point>*> ptrs;
+  std::vector<uint64_t> stamps;
+  for (int i = 0; i < nframes; ++i)
+  {
+    sh->frames[i].resize(n[i]);
+    if (n[i] > 0) std::memcpy(sh->frames[i].data(), pts[i], (size_t)n[i] * sizeof(Point));
+    ptrs.push_back(&sh->frames[i]);
+    stamps.push_back(stampsUs[i]);
+  }
+  sh->s.AddFrames(ptrs, stamps);
   return 0;
 }
 int orc_slam_set_world_transform_from_guess(void* h, const double T[16])

@@ -73,6 +73,7 @@ void Slam::AddFrame(const std::vector<Point>& frame, uint64_t stampUs, unsigned)
   if (!CheckFrame(frame, stampUs))
     return;
   CurrentFrame = &frame;
+  CurrentFrames.clear();
   CurrentStamp = stampUs;
   CurrentTime = StampToSec(stampUs);
 
@@ -91,6 +92,122 @@ void Slam::AddFrame(const std::vector<Point>& frame, uint64_t stampUs, unsigned)
   LogCurrentFrameState(CurrentTime);
   NbrFrameProcessed++;
   Times.total = total.Stop();
+}
+
+Iso Slam::GetBaseToLidarOffset(int deviceId) const
+{
+  if (deviceId == 0) return BaseToLidarOffset;
+  auto it = OtherBaseToLidarOffsets.find(deviceId);
+  return it == OtherBaseToLidarOffsets.end() ? iso_identity() : it->second;
+}
+
+// Slam.cxx:230-344 with several input frames; CheckFrames :709-743
+void Slam::AddFrames(const std::vector<const std::vector<Point>*>& frames, const std::vector<uint64_t>& stampsUs)
+{
+  Tick total;
+  Times = StageTimes();
+  bool allFramesEmpty = true;
+  for (auto* f : frames)
+    if (f && !f->empty()) allFramesEmpty = false;
+  if (frames.empty() || allFramesEmpty)
+    return;
+  if (stampsUs[0] == CurrentStamp)
+    return;
+  CurrentFrames.clear();
+  static const std::vector<Point> none;
+  for (size_t i = 0; i < frames.size(); ++i) CurrentFrames.push_back({frames[i] ? frames[i] : &none, stampsUs[i]});
+  CurrentFrame = CurrentFrames[0].cloud;
+  CurrentStamp = stampsUs[0];
+  CurrentTime = StampToSec(stampsUs[0]);
+
+  {
+    Tick t;
+    // Slam::ExtractKeypoints (Slam.cxx:746-810)
+    for (int k = 0; k < 3; ++k) PreviousRawKeypoints[k] = std::move(CurrentRawKeypoints[k]);
+    std::vector<std::vector<Point>> extracted[3];  // kept alive for the aggregation below
+    std::vector<uint64_t> extractedStamps;
+    for (const StampedCloud& frame : CurrentFrames)
+    {
+      if (frame.cloud->empty())
+        continue;
+      int lidarDevice = frame.cloud->front().device_id;
+      Extractor* ke = nullptr;
+      if (lidarDevice == 0) ke = &KeyPointsExtractor;
+      else if (OtherExtractors.count(lidarDevice)) ke = &OtherExtractors[lidarDevice];
+      else if (OtherExtractors.empty()) ke = &KeyPointsExtractor;  // single extractor: the default one stands in
+      else continue;                                              // otherwise the frame is ignored
+      ke->P.NbThreads = NbThreads;
+      ke->ComputeKeyPoints(*frame.cloud);
+      for (int k = 0; k < 3; ++k) extracted[k].push_back(ke->Keypoints[k]);
+      extractedStamps.push_back(frame.stampUs);
+    }
+    for (int k = 0; k < 3; ++k)
+    {
+      if (!UseKeypoints[k]) { CurrentRawKeypoints[k].clear(); continue; }
+      std::vector<StampedCloud> clouds;
+      for (size_t i = 0; i < extracted[k].size(); ++i) clouds.push_back({&extracted[k][i], extractedStamps[i]});
+      CurrentRawKeypoints[k] = AggregateFrames(clouds, false);
+    }
+    Times.extract = t.Stop();
+  }
+  ComputeEgoMotion();
+  Localization();
+  if (OverlapSamplingRatio > 0) EstimateOverlap();
+  if (TimeWindowDuration > 0) CheckMotionLimits();
+  if (MapUpdate == MappingMode::ADD_KPTS_TO_FIXED_MAP || MapUpdate == MappingMode::UPDATE)
+  {
+    Tick t;
+    UpdateMapsUsingTworld();
+    Times.maps = t.Stop();
+  }
+  LogCurrentFrameState(CurrentTime);
+  NbrFrameProcessed++;
+  Times.total = total.Stop();
+}
+
+// Slam.cxx:1512-1578
+std::vector<Point> Slam::AggregateFrames(const std::vector<StampedCloud>& frames, bool worldCoordinates) const
+{
+  std::vector<Point> aggregated;
+  const uint64_t aggregatedStamp = CurrentStamp;  // CurrentFrames[0]->header.stamp
+  for (const StampedCloud& frame : frames)
+  {
+    if (frame.cloud->empty())
+      continue;
+    const size_t startIdx = aggregated.size();
+    aggregated.insert(aggregated.end(), frame.cloud->begin(), frame.cloud->end());
+    const size_t endIdx = aggregated.size();
+    const double timeOffset = StampToSec(frame.stampUs) - StampToSec(aggregatedStamp);
+    const Iso baseToLidar = GetBaseToLidarOffset(frame.cloud->front().device_id);
+    if (worldCoordinates && Undistortion)
+    {
+      Interpolator interp = WithinFrameMotion;
+      interp.SetTransforms(iso_mul(iso_mul(Tworld, WithinFrameMotion.GetH0()), baseToLidar),
+                           iso_mul(iso_mul(Tworld, WithinFrameMotion.GetH1()), baseToLidar));
+      for (size_t i = startIdx; i < endIdx; ++i)
+      {
+        aggregated[i].time += timeOffset;
+        transform_point(aggregated[i], interp(aggregated[i].time));
+      }
+    }
+    else
+    {
+      const Iso tf = worldCoordinates ? iso_mul(Tworld, baseToLidar) : baseToLidar;
+      if (iso_is_approx(tf, iso_identity()))
+      {
+        for (size_t i = startIdx; i < endIdx; ++i) aggregated[i].time += timeOffset;
+      }
+      else
+      {
+        for (size_t i = startIdx; i < endIdx; ++i)
+        {
+          aggregated[i].time += timeOffset;
+          transform_point(aggregated[i], tf);
+        }
+      }
+    }
+  }
+  return aggregated;
 }
 
 // Slam.cxx:1512-1578 with worldCoordinates == false
@@ -527,6 +644,7 @@ std::vector<Point> Slam::GetRegisteredFrame()
 {
   std::vector<Point> out;
   if (!CurrentFrame) return out;
+  if (!CurrentFrames.empty()) return AggregateFrames(CurrentFrames, true);
   out = *CurrentFrame;
   if (Undistortion)
   {

@@ -42,6 +42,8 @@ public:
   Slam();
   void Reset(bool resetLog = true);
   void AddFrame(const std::vector<Point>& frame, uint64_t stampUs, unsigned seq = 0);
+  // Slam::AddFrames: one frame per LiDAR device, each with its own header stamp (Slam.cxx:230-344)
+  void AddFrames(const std::vector<const std::vector<Point>*>& frames, const std::vector<uint64_t>& stampsUs);
 
   Iso GetWorldTransform() const { return LogTrajectory.empty() ? iso_identity() : LogTrajectory.back().pose; }
   Iso GetLatencyCompensatedWorldTransform() const;          // Slam.cxx:555-590
@@ -73,9 +75,12 @@ public:
   unsigned MinNbMatchedKeypoints = 20;
   double KfDistanceThreshold = 0.5, KfAngleThreshold = 5.;
   MappingMode MapUpdate = MappingMode::UPDATE;
-  Iso BaseToLidarOffset = iso_identity();
+  Iso BaseToLidarOffset = iso_identity();  // device 0
+  std::map<int, Iso> OtherBaseToLidarOffsets;
+  Iso GetBaseToLidarOffset(int deviceId) const;  // identity for a device nobody configured
 
-  Extractor KeyPointsExtractor;
+  Extractor KeyPointsExtractor;                // device 0 (Slam::Slam allocates it, Slam.cxx:146)
+  std::map<int, Extractor> OtherExtractors;    // SetKeyPointsExtractor(extractor, deviceId != 0)
   std::shared_ptr<RollingGrid> LocalMaps[3];
 
   // state readable by the tests
@@ -116,6 +121,14 @@ private:
   void InitUndistortion();
   void RefineUndistortion();
   std::vector<Point> AggregateKeypoints(const std::vector<Point>& kpts) const;
+  // AggregateFrames (Slam.cxx:1512-1578) over clouds that carry a header stamp each
+  struct StampedCloud
+  {
+    const std::vector<Point>* cloud;
+    uint64_t stampUs;
+  };
+  std::vector<Point> AggregateFrames(const std::vector<StampedCloud>& frames, bool worldCoordinates) const;
+  std::vector<StampedCloud> CurrentFrames;  // all the frames of the current AddFrames call
 
   const std::vector<Point>* CurrentFrame = nullptr;
   uint64_t CurrentStamp = 0;

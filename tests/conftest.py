@@ -69,3 +69,24 @@ def pose_diff(ref, cur):
 def bits(a):
     a = np.ascontiguousarray(a)
     return a.view(np.uint32) if a.dtype == np.float32 else a.view(np.uint64) if a.dtype == np.float64 else a
+
+
+def two_device_rig(L, f, seed=1000, model=8):
+    """One synthetic scan split between two LiDAR devices of one platform: even rings stay device 0 (sensor = BASE),
+    odd rings become device 1, expressed in that sensor's own frame (BASE <- LIDAR = `offset`), stamped 500 us later
+    with the point times shifted to match.  Returns (frames, stamps, offset)."""
+    pts, stamp = L.synth_frame(model, seed, f)
+    a = np.deg2rad(30.0)
+    offset = np.eye(4)
+    offset[:2, :2] = [[np.cos(a), -np.sin(a)], [np.sin(a), np.cos(a)]]
+    offset[:3, 3] = [-0.4, 0.3, 0.25]
+    inv = np.linalg.inv(offset)
+    even = pts["laser_id"] % 2 == 0
+    d0, d1 = pts[even].copy(), pts[~even].copy()
+    d0["laser_id"] //= 2
+    d1["laser_id"] //= 2
+    xyz = np.stack([d1["x"], d1["y"], d1["z"]], 1).astype(np.float64) @ inv[:3, :3].T + inv[:3, 3]
+    d1["x"], d1["y"], d1["z"] = xyz[:, 0].astype(np.float32), xyz[:, 1].astype(np.float32), xyz[:, 2].astype(np.float32)
+    d1["device_id"] = 1
+    d1["time"] -= 500e-6
+    return [d0, d1], [stamp, stamp + 500], offset

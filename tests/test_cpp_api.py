@@ -62,3 +62,16 @@ def test_cpp_caller_matches_the_python_front_end(tmp_path, L):
     assert extra["extractor"] == [counts[0], counts[1], c.nb_laser_rings(), pts.size, 10]
     c.close()
     s.close()
+    # two devices: the same scan twice, the copy as device 1
+    rig = L.Slam(0)
+    rig.set_extractor_param(1, "EdgeIntensityGapThreshold", 40.0)
+    offset = np.eye(4)
+    offset[0, 3] = 0.5
+    rig.set_base_to_lidar_offset(offset, 1)
+    copy = pts.copy()
+    copy["device_id"] = 1
+    stamp = L.synth_frame(8, 1000, 3)[1]
+    rig.add_frames([pts, copy], [stamp, stamp + 1000], 3)
+    assert extra["rig"] == [rig.keypoints(L.EDGE).size, rig.keypoints(L.PLANE).size, 2 * pts.size]
+    assert rig.keypoints(L.PLANE).size > counts[1]
+    rig.close()

@@ -6,7 +6,7 @@ they agree to ~1e-12, the test keeps 1e-7 so that a real regression cannot hide.
 import numpy as np
 import pytest
 
-from conftest import pose_diff
+from conftest import pose_diff, two_device_rig
 
 pytestmark = pytest.mark.gpu
 
@@ -422,7 +422,7 @@ def test_result_getters_and_confidence_estimators_follow_the_oracle(L, O):
     sg.set_base_to_lidar_offset(offset), so.set_base_to_lidar_offset(offset)
     assert np.array_equal(sg.base_to_lidar_offset(), offset)
     with pytest.raises(L.LsaError):
-        sg.set_base_to_lidar_offset(offset, device_id=1)
+        sg.set_base_to_lidar_offset(offset, device_id=300)  # device ids are 8 bits
     comply = []
     for f in range(14):
         pts, stamp = L.synth_frame(8, 1000, f)
@@ -456,4 +456,46 @@ def test_result_getters_and_confidence_estimators_follow_the_oracle(L, O):
             assert sg.target_submap(k).size == so.submap(k).size
     # 5 m/s against a 5.05 m/s limit: compliant while cruising, not across the imposed jump
     assert comply[7] == 1.0 and 0.0 in comply[8:11]
+    sg.close()
+
+
+@pytest.mark.gpu
+def test_two_lidar_devices_follow_the_oracle(L, O):
+    """Slam::AddFrames with one frame per LiDAR device: per-device extractor (own parameters and azimuthal
+    resolution), BASE <- LIDAR offset and time shift, keypoints merged in frame order (bit-identical to the oracle),
+    poses, registered frame of all devices and the overlap estimator on the aggregated cloud."""
+    params = dict(EgoMotion=3, OverlapSamplingRatio=0.2)
+    sg, so = L.Slam(0, **params), O.Slam(**params)
+    for f in range(8):
+        frames, stamps, offset = two_device_rig(L, f)
+        if f == 0:
+            for s in (sg, so):
+                s.set_base_to_lidar_offset(offset, device_id=1)
+                s.set_extractor_param(1, "EdgeIntensityGapThreshold", 40.0)
+            assert sg.extractor_param(1, "EdgeIntensityGapThreshold") == 40.0 and sg.extractor_param(1, "NeighborWidth") == 4
+            assert np.array_equal(sg.base_to_lidar_offset(1), offset) and np.array_equal(sg.base_to_lidar_offset(7), np.eye(4))
+        if f == 5:
+            frames[0] = frames[0][:0]  # the first device drops a frame: the pose is still dated by its stamp
+        sg.add_frames(frames, stamps, f), so.add_frames(frames, stamps, f)
+        for k in (L.EDGE, L.PLANE):
+            kg, ko = sg.keypoints(k, 2), so.keypoints(k, 2)
+            assert kg.size == ko.size and kg.tobytes() == ko.tobytes(), (f, k)
+            if f != 5:
+                assert set(np.unique(kg["device_id"])) == {0, 1}
+        dt, dr = pose_diff(sg.world_transform(), so.world_transform())
+        assert dt < 1e-9 and dr < 1e-9, (f, dt, dr)
+        rg, ro = sg.registered_frame(), so.registered_frame()
+        assert rg.size == ro.size == frames[0].size + frames[1].size
+        for field in ("x", "y", "z"):
+            assert np.abs(rg[field] - ro[field]).max() < 1e-4
+        assert np.array_equal(rg["time"], ro["time"]) and np.array_equal(rg["device_id"], ro["device_id"])
+        if f > 0:
+            assert abs(sg.get_param("OverlapEstimation") - so.overlap()) < 1e-5, f
+    # single frames of the second device take the same route (extractor and offset of that device)
+    frames, stamps, offset = two_device_rig(L, 8)
+    sg.add_frame(frames[1], stamps[1], 8), so.add_frame(frames[1], stamps[1], 8)
+    kg, ko = sg.keypoints(L.PLANE, 2), so.keypoints(L.PLANE, 2)
+    assert kg.size == ko.size > 0 and kg.tobytes() == ko.tobytes()
+    dt, dr = pose_diff(sg.world_transform(), so.world_transform())
+    assert dt < 1e-9 and dr < 1e-9
     sg.close()

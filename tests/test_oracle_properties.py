@@ -4,7 +4,7 @@ cases, recovery of the known synthetic motion."""
 import numpy as np
 import pytest
 
-from conftest import pose_diff
+from conftest import pose_diff, two_device_rig
 
 
 # ---------------------------------------------------------------- portable math
@@ -301,3 +301,34 @@ def test_oracle_pose_log_motion_limits_and_latency_compensation(O, L):
     assert np.allclose(ahead[:3, 3], poses2[-1][:3, 3] + 0.05 * v, atol=1e-12)
     s.set_param("Latency", 1.0)  # more than MaxExtrapolationRatio x the frame period: no extrapolation
     assert np.array_equal(s.latency_compensated_world_transform(), poses2[-1])
+
+
+def test_oracle_two_lidar_devices_merge_into_one_frame(O, L):
+    """Slam::AddFrames with one frame per device (Slam.cxx:753-801, 1512-1578): the keypoints of the two devices are
+    merged in frame order in BASE coordinates with times relative to the first stamp, the pose follows the synthetic
+    motion as with the undivided scan, and the registered frame holds every input point."""
+    s2, s1 = O.Slam(EgoMotion=3), O.Slam(EgoMotion=3)
+    for f in range(6):
+        frames, stamps, offset = two_device_rig(L, f)
+        if f == 0:
+            s2.set_base_to_lidar_offset(offset, device_id=1)
+        s2.add_frames(frames, stamps, f)
+        pts, stamp = L.synth_frame(8, 1000, f)
+        s1.add_frame(pts, stamp, f)
+        dt, dr = pose_diff(s2.world_transform(), s1.world_transform())
+        assert dt < 0.05 and dr < 0.01, (f, dt, dr)  # same scene, rings split between two extractors
+        kp = s2.keypoints(L.PLANE, 2)
+        n0 = int((kp["device_id"] == 0).sum())
+        assert 0 < n0 < kp.size and np.all(kp["device_id"][:n0] == 0) and np.all(kp["device_id"][n0:] == 1)
+        assert kp["time"].min() >= -0.1001 and kp["time"].max() <= 1e-9
+        # in BASE the second device's keypoints lie in the same street canyon as the first one's
+        assert abs(np.median(kp["y"][n0:]) - np.median(kp["y"][:n0])) < 3.0
+        reg = s2.registered_frame()
+        assert reg.size == frames[0].size + frames[1].size
+    # a device without extractor while another device has one: its frame is ignored (Slam.cxx:774-779)
+    s3 = O.Slam(EgoMotion=3)
+    s3.set_extractor_param(2, "NeighborWidth", 4)
+    frames, stamps, offset = two_device_rig(L, 0)
+    s3.add_frames(frames, stamps, 0)
+    assert np.all(s3.keypoints(L.PLANE, 2)["device_id"] == 0)
+    assert s3.registered_frame().size == frames[0].size + frames[1].size

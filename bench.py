@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--host-frames", action="store_true", help="hand every scan over from a host buffer (PCIe inclusive; never the headline value)")
     ap.add_argument("--sequences-per-gpu", type=int, default=1, help="independent sequences replayed side by side on every GPU (the headline is 1: BASELINE.json shards 1 per GPU)")
     ap.add_argument("--batch-sequences", type=int, default=4, help="N=1 only: extra leg with this many sequences side by side on the GPU, reported as batch_replay (0 disables)")
+    ap.add_argument("--no-lookahead", action="store_true", help="do not extract the next stored frame's keypoints beside the current frame's registration")
     ap.add_argument("--profile-all", action="store_true", help="time every scope in the timed region too (costs ~10 %% of the frame rate)")
     return ap.parse_args()
 
@@ -91,6 +92,7 @@ def main():
     # further sequences of this rank (--sequences-per-gpu): a Slam, a context and a host thread each, free-running
     # beside the first one between the same start and end barriers; their latest poses travel with the first one's
     per_gpu = max(args.sequences_per_gpu, 1)
+    lookahead = not args.no_lookahead and not args.host_frames
     latest = np.zeros((per_gpu, 17))
     latest_lock = threading.Lock()
     others, gate = [], threading.Barrier(per_gpu)
@@ -117,6 +119,8 @@ def main():
             for f in range(total):
                 if f == args.warmup:
                     gate.wait()
+                if lookahead and f + 1 < total:
+                    o.hint_next_stored_frame(f + 1)
                 o.add_stored_frame(f, st[f], f)
                 publish(s, o, st[f])
             o.context().sync()
@@ -134,6 +138,8 @@ def main():
         if args.host_frames:
             slam.add_frame(host_frames[f], stamps[f], f)
         else:
+            if lookahead and f + 1 < total:
+                slam.hint_next_stored_frame(f + 1)
             slam.add_stored_frame(f, stamps[f], f)
         if not distributed:
             return None
@@ -222,6 +228,7 @@ def main():
                 "sequences": world * per_gpu,
                 "parallelism": f"{per_gpu} sequence{'s' if per_gpu > 1 else ''} per GPU x {world}, RCCL all-gather of poses",
                 "frames_resident_in_hbm": not args.host_frames,
+                "lookahead_extraction": lookahead,
             },
         }
         n = args.steps
@@ -279,7 +286,7 @@ def batch_replay(args, device):
     from lidarslam_amd.replay import ConcurrentReplay, sequence_seed
 
     n = args.batch_sequences
-    rep = ConcurrentReplay(device, args.model, [sequence_seed(s) for s in range(n)], args.warmup + args.steps, EgoMotion=3)
+    rep = ConcurrentReplay(device, args.model, [sequence_seed(s) for s in range(n)], args.warmup + args.steps, lookahead=not args.no_lookahead, EgoMotion=3)
     for kv in args.param:
         name, value = kv.split("=")
         for s in rep.slams:

@@ -160,6 +160,16 @@ int lsa_extract_keypoints(lsa_ctx* ctx, const lsa_extract_params_t* params, int 
  * time += time_offset, then the rigid transform sensor -> BASE (NULL = identity, coordinates untouched).
  * counts[] = keypoints of this frame per type. */
 int lsa_extract_keypoints_more(lsa_ctx* ctx, const lsa_extract_params_t* params, const double base_to_lidar[16], double time_offset, int counts[3]);
+/* Look-ahead for replay from the frame store: extracts the keypoints of the frame in `slot` on a stream of its own,
+ * beside whatever runs on the context's stream (the registration of the current frame), into spare buffers.  The
+ * next lsa_extract_keypoints adopts them -- no kernel, no wait -- if it is called for that very frame
+ * (lsa_frame_store_use(slot)) with the same parameters, keypoint types and azimuthal resolution; otherwise the
+ * look-ahead is dropped and the extraction runs as usual.  Same keypoints either way (the extraction does not depend
+ * on the pose).  Call it after the current frame's lsa_extract_keypoints; until the adoption lsa_download_debug is
+ * refused (the per-point arrays are being rewritten). */
+int lsa_extract_prefetch(lsa_ctx* ctx, int slot, const lsa_extract_params_t* params);
+/* how many look-aheads lsa_extract_keypoints has adopted so far on this context */
+int lsa_extract_prefetch_adopted(const lsa_ctx* ctx);
 /* Keypoint types lsa_extract_keypoints keeps (bit k = type k; Slam::UseKeypoints, Slam.h:406): the others
  * come out empty, exactly as Slam::ExtractKeypoints drops them (Slam.cxx:789-793).  Default: all three. */
 int lsa_set_keypoint_types(lsa_ctx* ctx, unsigned type_mask);
@@ -381,6 +391,10 @@ int lsa_slam_add_frame(lsa_slam* s, const lsa_point_t* pts, int n, uint64_t stam
 /* Same on a scan already resident in the frame store of the underlying context. */
 int lsa_slam_store_frame(lsa_slam* s, int slot, const lsa_point_t* pts, int n);
 int lsa_slam_add_stored_frame(lsa_slam* s, int slot, uint64_t stamp_us, uint32_t seq);
+/* Replay from the frame store: names the slot of the frame that will be added after the next one, so that its
+ * keypoints are extracted beside the registration of that frame (lsa_extract_prefetch).  Purely a scheduling hint:
+ * the results are the same with or without it, and a hint that does not come true costs one wasted extraction. */
+int lsa_slam_hint_next_stored_frame(lsa_slam* s, int slot);
 /* Slam::GetWorldTransform: row-major 4x4 + time [s]. */
 int lsa_slam_get_world_transform(const lsa_slam* s, double T[16], double* time);
 int lsa_slam_get_covariance(const lsa_slam* s, double cov[36]);
@@ -438,7 +452,8 @@ lsa_ctx* lsa_slam_context(lsa_slam* s);
  * uses, exposed so that a maintainer can swap it in on its own and so that the
  * tests can compare it with the oracle call by call (no GPU involved).
  * Parameter names: "GridSize", "VoxelResolution", "LeafSize",
- * "MinFramesPerVoxel", "Sampling" (0 FIRST .. 4 CENTROID), "DecayingThreshold". */
+ * "MinFramesPerVoxel", "Sampling" (0 FIRST .. 4 CENTROID), "DecayingThreshold", and "AddThreads" (host threads
+ * Add uses on a big cloud; an implementation knob, the map is the same for any value). */
 typedef struct lsa_rolling_grid lsa_rolling_grid;
 lsa_rolling_grid* lsa_rolling_grid_create(void);
 void lsa_rolling_grid_destroy(lsa_rolling_grid* g);

@@ -53,13 +53,13 @@ DEBUG_NAMES = [
 ABI_SYMBOLS = [
     "lsa_device_count", "lsa_ctx_create", "lsa_ctx_destroy", "lsa_last_error", "lsa_sync", "lsa_upload_frame", "lsa_upload_wire_frame",
     "lsa_frame_store_put", "lsa_frame_store_use", "lsa_frame_size", "lsa_get_azimuthal_resolution",
-    "lsa_set_azimuthal_resolution", "lsa_extract_keypoints", "lsa_extract_keypoints_more", "lsa_transform_frame_at", "lsa_set_keypoint_types", "lsa_download_keypoints", "lsa_keypoint_count",
+    "lsa_set_azimuthal_resolution", "lsa_extract_keypoints", "lsa_extract_keypoints_more", "lsa_extract_prefetch", "lsa_extract_prefetch_adopted", "lsa_transform_frame_at", "lsa_set_keypoint_types", "lsa_download_keypoints", "lsa_keypoint_count",
     "lsa_download_debug", "lsa_nb_laser_rings", "lsa_transform_keypoints", "lsa_set_target", "lsa_set_target_from_set", "lsa_target_staging", "lsa_set_target_staged",
     "lsa_target_size", "lsa_download_target", "lsa_set_target_cell_size", "lsa_set_knn_lanes", "lsa_set_knn_rounds", "lsa_match_slow_queries", "lsa_match_exhaustive_queries", "lsa_set_keypoints", "lsa_match", "lsa_match_types",
     "lsa_download_match", "lsa_overlap", "lsa_accumulate", "lsa_solve", "lsa_registration_error", "lsa_selftest_math", "lsa_reset_working_keypoints", "lsa_undistort", "lsa_working_time_range",
     "lsa_working_bbox", "lsa_working_bboxes", "lsa_keypoint_bboxes_begin", "lsa_keypoint_bboxes_end", "lsa_download_transformed", "lsa_stage_transformed", "lsa_staged_transformed", "lsa_transform_frame", "lsa_profile_enable", "lsa_profile_select", "lsa_profile_reset",
     "lsa_profile_get", "lsa_slam_create", "lsa_slam_destroy", "lsa_slam_last_error", "lsa_slam_set_param",
-    "lsa_slam_get_param", "lsa_slam_reset", "lsa_slam_add_frame", "lsa_slam_store_frame", "lsa_slam_add_stored_frame",
+    "lsa_slam_get_param", "lsa_slam_reset", "lsa_slam_add_frame", "lsa_slam_store_frame", "lsa_slam_add_stored_frame", "lsa_slam_hint_next_stored_frame",
     "lsa_slam_get_world_transform", "lsa_slam_get_covariance", "lsa_slam_get_keypoints", "lsa_slam_get_registered_frame",
     "lsa_slam_get_match_status", "lsa_slam_get_stats", "lsa_slam_context", "lsa_slam_get_latency_compensated_world_transform",
     "lsa_slam_set_world_transform_from_guess", "lsa_slam_get_trajectory", "lsa_slam_get_debug_information", "lsa_slam_get_map",
@@ -152,6 +152,7 @@ def lib():
     L.lsa_slam_get_latency_compensated_world_transform.argtypes = [vp, vp, vp]
     L.lsa_slam_set_world_transform_from_guess.argtypes = [vp, vp]
     L.lsa_slam_get_trajectory.argtypes = [vp, vp, vp, i32]
+    L.lsa_slam_hint_next_stored_frame.argtypes = [vp, i32]
     L.lsa_slam_add_frames.argtypes = [vp, vp, vp, vp, vp, i32]
     L.lsa_slam_set_extractor_param.argtypes = [vp, i32, C.c_char_p, f64]
     L.lsa_slam_get_extractor_param.argtypes = [vp, i32, C.c_char_p, vp]
@@ -467,6 +468,10 @@ class Slam:
     def store_frame(self, slot, pts):
         pts = np.ascontiguousarray(pts)
         self._check(self.L.lsa_slam_store_frame(self.h, slot, ptr(pts), pts.size), "lsa_slam_store_frame")
+
+    def hint_next_stored_frame(self, slot):
+        """replay: the slot that will be added after the next add_stored_frame (its extraction is overlapped)"""
+        self._check(self.L.lsa_slam_hint_next_stored_frame(self.h, slot), "lsa_slam_hint_next_stored_frame")
 
     def add_stored_frame(self, slot, stamp_us, seq=0):
         self._check(self.L.lsa_slam_add_stored_frame(self.h, slot, stamp_us, seq), "lsa_slam_add_stored_frame")

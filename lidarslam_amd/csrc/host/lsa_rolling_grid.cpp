@@ -175,6 +175,11 @@ void RollingGrid::Add(const lsa_point_t* points, size_t count, bool fixed, doubl
   // point; here the voxel remembers the serial of the last Add that touched it and is looked up once.
   // Insertions happen at the same moments (outer voxel on first use, then the leaf), so the iteration
   // order of both maps -- and with it the order of the sub-map points -- is unchanged.
+  if (AddCrew && Sampling != SamplingMode::CENTROID && count >= 2048)
+  {
+    this->AddParallel(points, count, fixed, currentTime);
+    return;
+  }
   const unsigned int serial = ++AddSerial;
   std::unordered_map<int, std::unordered_map<int, Voxel>> meanPts;
   bool updated = false;
@@ -269,6 +274,212 @@ void RollingGrid::Add(const lsa_point_t* points, size_t count, bool fixed, doubl
     }
   }
   if (updated) SubMapValid = false;  // KdTree.Reset() in the reference
+}
+
+// The per-point body of Add() for every sampling mode but CENTROID (whose running means couple the voxels).
+inline void RollingGrid::AddOne(const lsa_point_t& point, SamplingVG& outer, int idxIn, const int vi[3], const float centerIn[3], bool fixed,
+                                double currentTime, unsigned int serial, AddTally& tally)
+{
+  auto ins = outer.try_emplace(idxIn);
+  Voxel& voxel = ins.first->second;
+  if (ins.second)
+  {
+    voxel.point = point;
+    ++tally.inserted;
+    tally.updated = true;
+  }
+  else
+  {
+    if (voxel.point.label == 1) return;  // fixed map point
+    switch (Sampling)
+    {
+      case SamplingMode::LAST:
+        voxel.point = point;
+        tally.updated = true;
+        break;
+      case SamplingMode::MAX_INTENSITY:
+        if (point.intensity > voxel.point.intensity)
+        {
+          voxel.point = point;
+          tally.updated = true;
+        }
+        break;
+      case SamplingMode::CENTER_POINT:
+      {
+        const float leaf = static_cast<float>(LeafSize);
+        float c[3];
+        for (int i = 0; i < 3; ++i) c[i] = centerIn[i] - static_cast<float>(VoxelResolution / 2.f) + leaf * static_cast<float>(vi[i]);
+        if (Dist(point, c) < Dist(voxel.point, c))
+        {
+          voxel.point = point;
+          tally.updated = true;
+        }
+        break;
+      }
+      default:
+        break;  // FIRST
+    }
+  }
+  voxel.point.time = currentTime;
+  voxel.point.label = fixed ? 1 : 0;
+  if (voxel.seen != serial)
+  {
+    ++voxel.count;
+    voxel.seen = serial;
+  }
+}
+
+// Add() on several threads, same maps in the end (content and iteration order): see SetAddThreads.
+void RollingGrid::AddParallel(const lsa_point_t* points, std::size_t count, bool fixed, double currentTime)
+{
+  const float res = static_cast<float>(VoxelResolution);
+  float origin[3];
+  this->GridOrigin(origin);
+  const unsigned int serial = ++AddSerial;
+  const int threads = AddCrew->Size();
+  AddOut.resize(count);
+  AddIn.resize(count);
+  // 1. voxel indices of every point (pure arithmetic, contiguous shares)
+  AddCrew->Run([&](int tid) {
+    const std::size_t lo = count * tid / threads, hi = count * (tid + 1) / threads;
+    for (std::size_t pi = lo; pi < hi; ++pi)
+    {
+      const float p[3] = {points[pi].x, points[pi].y, points[pi].z};
+      int vo[3];
+      ToVoxel(p, origin, VoxelResolution, vo);
+      if (!(0 <= vo[0] && vo[0] < GridSize && 0 <= vo[1] && vo[1] < GridSize && 0 <= vo[2] && vo[2] < GridSize)) { AddOut[pi] = -1; continue; }
+      float centerIn[3];
+      for (int i = 0; i < 3; ++i) centerIn[i] = static_cast<float>(vo[i]) * res + origin[i];
+      int vi[3];
+      ToVoxel(p, centerIn, LeafSize, vi);
+      AddOut[pi] = this->To1d(vo);
+      AddIn[pi] = this->To1d(vi);
+    }
+  });
+  // 2. the outer voxels, created in the order in which the points reach them (this thread alone)
+  {
+    int lastOut = -1;
+    for (std::size_t pi = 0; pi < count; ++pi)
+      if (AddOut[pi] >= 0 && AddOut[pi] != lastOut)
+      {
+        (void)Voxels[AddOut[pi]];
+        lastOut = AddOut[pi];
+      }
+  }
+  // 3. the leaf voxels: every outer voxel belongs to one thread, which takes its points in their order; the outer
+  //    map is only read from here on
+  std::vector<AddTally> tally(threads);
+  AddCrew->Run([&](int tid) {
+    AddTally mine;
+    int lastOut = -1;
+    SamplingVG* outer = nullptr;
+    for (std::size_t pi = 0; pi < count; ++pi)
+    {
+      const int idxOut = AddOut[pi];
+      if (idxOut < 0 || static_cast<int>((static_cast<unsigned>(idxOut) * 2654435761u) >> 20) % threads != tid) continue;
+      if (idxOut != lastOut)
+      {
+        outer = &Voxels.find(idxOut)->second;
+        lastOut = idxOut;
+      }
+      // the leaf coordinates and the outer voxel's centre again, for CENTER_POINT (cheap next to the hash lookup)
+      int vo[3], vi[3];
+      this->To3d(idxOut, vo);
+      float centerIn[3];
+      for (int i = 0; i < 3; ++i) centerIn[i] = static_cast<float>(vo[i]) * res + origin[i];
+      if (Sampling == SamplingMode::CENTER_POINT)
+      {
+        const float p[3] = {points[pi].x, points[pi].y, points[pi].z};
+        ToVoxel(p, centerIn, LeafSize, vi);
+      }
+      else vi[0] = vi[1] = vi[2] = 0;
+      this->AddOne(points[pi], *outer, AddIn[pi], vi, centerIn, fixed, currentTime, serial, mine);
+    }
+    tally[tid] = mine;
+  });
+  bool updated = false;
+  for (const AddTally& t : tally)
+  {
+    NbPoints += t.inserted;
+    updated = updated || t.updated;
+  }
+  if (updated) SubMapValid = false;
+}
+
+// ---- Crew
+Crew::Crew(int threads)
+{
+  for (int t = 1; t < threads; ++t) Helpers.emplace_back([this, t] { this->Loop(t); });
+}
+
+Crew::~Crew()
+{
+  Quit.store(true);
+  {
+    std::lock_guard<std::mutex> lock(M);
+    Generation.fetch_add(1);
+  }
+  Cv.notify_all();
+  for (auto& h : Helpers) h.join();
+}
+
+void Crew::Wake()
+{
+  if (Sleeping.load(std::memory_order_acquire) > 0)
+  {
+    { std::lock_guard<std::mutex> lock(M); }
+    Cv.notify_all();
+  }
+}
+
+void Crew::Loop(int tid)
+{
+  unsigned seen = 0;
+  for (;;)
+  {
+    // spin for a while (about a quarter of a millisecond), then sleep until woken or until there is work
+    int spins = 0;
+    while (Generation.load(std::memory_order_acquire) == seen)
+    {
+      if (++spins < 20000) { __builtin_ia32_pause(); continue; }
+      std::unique_lock<std::mutex> lock(M);
+      if (Generation.load(std::memory_order_acquire) != seen) break;  // Run() bumps it under this lock
+      Sleeping.fetch_add(1, std::memory_order_acq_rel);
+      Cv.wait(lock);  // a wake-up without work just restarts the spinning
+      Sleeping.fetch_sub(1, std::memory_order_acq_rel);
+      spins = 0;
+    }
+    seen = Generation.load(std::memory_order_acquire);
+    if (Quit.load()) return;
+    (*Fn)(tid);
+    Pending.fetch_sub(1, std::memory_order_acq_rel);
+  }
+}
+
+void Crew::Run(const std::function<void(int)>& fn)
+{
+  Fn = &fn;
+  Pending.store(static_cast<int>(Helpers.size()), std::memory_order_release);
+  {
+    // under the lock: a helper about to sleep either sees the new generation or is notified
+    std::lock_guard<std::mutex> lock(M);
+    Generation.fetch_add(1, std::memory_order_acq_rel);
+  }
+  if (Sleeping.load(std::memory_order_acquire) > 0) Cv.notify_all();
+  fn(0);
+  while (Pending.load(std::memory_order_acquire) > 0)
+  {
+    if (Sleeping.load(std::memory_order_acquire) > 0) Cv.notify_all();  // a helper that went to sleep at the last moment
+    __builtin_ia32_pause();
+  }
+}
+
+void RollingGrid::SetAddThreads(int n)
+{
+  n = std::max(1, std::min(n, 16));
+  if (n == this->GetAddThreads()) return;
+  AddCrew.reset();
+  if (n > 1) AddCrew.reset(new Crew(n));
 }
 
 // RollingGrid.cxx:325-351

@@ -7,8 +7,13 @@
 // std::unordered_map<int, std::unordered_map<int, Voxel>> so that libstdc++'s iteration order --
 // which decides the order of the sub-map points and with it the PCA summation order -- is kept.
 #pragma once
+#include <atomic>
+#include <condition_variable>
 #include <cstddef>
 #include <functional>
+#include <memory>
+#include <mutex>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 #include "../../../include/lidarslam_amd.h"
@@ -19,6 +24,30 @@ namespace host
 {
 
 enum class SamplingMode { FIRST = 0, LAST = 1, MAX_INTENSITY = 2, CENTER_POINT = 3, CENTROID = 4 };
+
+// A few helper threads that run one function together with the caller (thread 0) and meet again at the end.
+// Between calls they spin for a short while (the phases of one Add follow each other within microseconds) and then
+// sleep on a condition variable; Wake() ends the sleep ahead of the next call.
+class Crew
+{
+public:
+  explicit Crew(int threads);
+  ~Crew();
+  int Size() const { return static_cast<int>(Helpers.size()) + 1; }
+  void Wake();
+  void Run(const std::function<void(int)>& fn);
+
+private:
+  void Loop(int tid);
+  std::vector<std::thread> Helpers;
+  std::mutex M;
+  std::condition_variable Cv;
+  const std::function<void(int)>* Fn = nullptr;
+  std::atomic<unsigned> Generation{0};
+  std::atomic<int> Pending{0};
+  std::atomic<bool> Quit{false};
+  std::atomic<int> Sleeping{0};
+};
 
 class RollingGrid
 {
@@ -48,6 +77,13 @@ public:
   void SetSampling(SamplingMode m) { this->Sampling = m; }
   SamplingMode GetSampling() const { return this->Sampling; }
   void SetDecayingThreshold(double d) { this->DecayingThreshold = d; }
+  // Threads Add() uses for a big cloud (1 = the caller alone).  The leaf voxels of different outer voxels are
+  // independent containers: the outer voxels are created first, in the order of the points, then every thread
+  // inserts the points of its share of the outer voxels, in the order of the points -- the maps end up with the
+  // same content and the same iteration order as after the sequential loop.
+  void SetAddThreads(int n);
+  int GetAddThreads() const { return this->AddCrew ? this->AddCrew->Size() : 1; }
+  void WakeAddThreads() { if (this->AddCrew) this->AddCrew->Wake(); }
   double GetDecayingThreshold() const { return this->DecayingThreshold; }
   bool IsTimeThreshold() const { return this->DecayingThreshold > 0; }
 
@@ -99,6 +135,17 @@ private:
   SamplingMode Sampling = SamplingMode::MAX_INTENSITY;
   double DecayingThreshold = -1;
 
+  std::unique_ptr<Crew> AddCrew;
+  std::vector<int> AddOut, AddIn;  // outer / leaf voxel index per point of the cloud being added (-1: outside)
+  void AddParallel(const lsa_point_t* points, std::size_t count, bool fixed, double currentTime);
+  struct AddTally
+  {
+    unsigned int inserted = 0;
+    bool updated = false;
+  };
+  // the per-point body of Add() once the voxel indices are known
+  inline void AddOne(const lsa_point_t& point, SamplingVG& outer, int idxIn, const int vi[3], const float centerIn[3], bool fixed, double currentTime,
+                     unsigned int serial, AddTally& tally);
   int To1d(const int v[3]) const { return v[2] * GridSize * GridSize + v[1] * GridSize + v[0]; }
   void To3d(int id, int v[3]) const;
   void GridOrigin(float o[3]) const;

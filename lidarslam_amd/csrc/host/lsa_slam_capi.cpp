@@ -150,6 +150,13 @@ int lsa_slam_get_base_to_lidar_offset(const lsa_slam* s, double T[16], int devic
   return LSA_OK;
 }
 
+int lsa_slam_hint_next_stored_frame(lsa_slam* s, int slot)
+{
+  if (!s) return LSA_E_ARG;
+  s->core.HintNextStoredFrame(slot);
+  return LSA_OK;
+}
+
 int lsa_slam_set_extractor_param(lsa_slam* s, int device_id, const char* name, double value)
 {
   if (!s || !name) return LSA_E_ARG;
@@ -250,6 +257,7 @@ int lsa_rolling_grid_set(lsa_rolling_grid* g, const char* name, double value)
     g->grid.SetSampling(static_cast<lsa::host::SamplingMode>(static_cast<int>(value)));
   }
   else if (n == "DecayingThreshold") g->grid.SetDecayingThreshold(value);
+  else if (n == "AddThreads") g->grid.SetAddThreads(static_cast<int>(value));
   else return LSA_E_ARG;
   return LSA_OK;
 }

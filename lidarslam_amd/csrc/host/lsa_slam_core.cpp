@@ -80,6 +80,9 @@ SlamCore::SlamCore(int device)
   ExtractParams.edge_saliency_threshold = 1.5f;
   ExtractParams.edge_intensity_gap_threshold = 50.f;
   for (int k = 0; k < 3; ++k) LocalMaps[k] = std::make_shared<RollingGrid>();
+  // the plane map takes the largest insertions (tens of thousands of keypoints per keyframe): three host threads
+  // keep them shorter than the ego-motion ICP they run beside ("MapAddThreads"; the map is the same for any value)
+  LocalMaps[LSA_PLANE]->SetAddThreads(3);
   for (int k = 0; k < 3; ++k) LocalMaps[k]->SetVoxelResolution(10.);
   for (int k = 0; k < 3; ++k) LocalMaps[k]->SetGridSize(50);
   LocalMaps[LSA_EDGE]->SetLeafSize(0.30);
@@ -395,6 +398,13 @@ int SlamCore::ExtractKeypoints()
   if (!IsApprox(BaseToLidarOffset, Pose::Identity()))
     for (int k = 0; k < 3; ++k)
       if (counts[k] > 0) LSA_TRY(lsa_transform_keypoints(Ctx, LSA_SET_RAW_CURRENT, k, BaseToLidarOffset.m, 0.));
+  if (NextStoredSlot >= 0)
+  {
+    // look-ahead: the next frame's extraction runs on its own stream beside this frame's registration; a slot that
+    // does not exist is reported and otherwise ignored
+    if (lsa_extract_prefetch(Ctx, NextStoredSlot, &ExtractParams) != LSA_OK) LastError = std::string("look-ahead ignored: ") + lsa_last_error(Ctx);
+    NextStoredSlot = -1;
+  }
   return LSA_OK;
 }
 
@@ -790,6 +800,7 @@ int SlamCore::UpdateMapsUsingTworld()
     const double time = CurrentTime;
     double* spent = &MapJobSeconds[k];
     MapWorker[k].Submit([map, ctx, k, time, spent] {
+      map->WakeAddThreads();  // they are spinning by the time the staged keypoints have arrived
       const lsa_point_t* pts = nullptr;
       int n = 0;
       if (lsa_staged_transformed(ctx, k, &pts, &n) != LSA_OK) return;
@@ -1046,6 +1057,8 @@ int SlamCore::SetParam(const std::string& name, double v)
     if (OverlapSamplingRatio == 0.f) OverlapEstimation = -1.f;
     return LSA_OK;
   }
+  if (name == "MapAddThreads") { LocalMaps[LSA_PLANE]->SetAddThreads(static_cast<int>(v)); return LSA_OK; }
+  if (name == "MapAddThreadsEdges") { LocalMaps[LSA_EDGE]->SetAddThreads(static_cast<int>(v)); return LSA_OK; }
   if (name == "LoggingTimeout") { LoggingTimeout = v; return LSA_OK; }
   if (name == "TimeWindowDuration") { TimeWindowDuration = static_cast<float>(v); return LSA_OK; }
   if (name == "VelocityLimitLinear") { VelocityLimits[0] = static_cast<float>(v); return LSA_OK; }
@@ -1085,6 +1098,9 @@ int SlamCore::GetParam(const std::string& name, double* v) const
   if (name == "OverlapSamplingRatio") { *v = OverlapSamplingRatio; return LSA_OK; }
   if (name == "OverlapEstimation") { *v = OverlapEstimation; return LSA_OK; }
   if (name == "SubMapSpeculationHits") { *v = SubMapSpecHitsTotal; return LSA_OK; }
+  if (name == "LookaheadAdopted") { *v = Ctx ? lsa_extract_prefetch_adopted(Ctx) : 0; return LSA_OK; }
+  if (name == "MapAddThreads") { *v = LocalMaps[LSA_PLANE]->GetAddThreads(); return LSA_OK; }
+  if (name == "MapAddThreadsEdges") { *v = LocalMaps[LSA_EDGE]->GetAddThreads(); return LSA_OK; }
   if (name == "LoggingTimeout") { *v = LoggingTimeout; return LSA_OK; }
   if (name == "TimeWindowDuration") { *v = TimeWindowDuration; return LSA_OK; }
   if (name == "VelocityLimitLinear") { *v = VelocityLimits[0]; return LSA_OK; }

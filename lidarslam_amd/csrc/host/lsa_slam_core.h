@@ -91,6 +91,9 @@ public:
   // Slam::AddFrame on a host scan / on a scan resident in the frame store
   int AddFrame(const lsa_point_t* pts, int n, uint64_t stampUs, uint32_t seq);
   int AddStoredFrame(int slot, uint64_t stampUs, uint32_t seq);
+  // Replay: the frame-store slot of the frame that will be added next.  Its keypoints are then extracted beside
+  // the registration of the current frame (lsa_extract_prefetch) and the next AddStoredFrame finds them ready.
+  void HintNextStoredFrame(int slot) { NextStoredSlot = slot; }
   // Slam::AddFrames with one frame per LiDAR device (Slam.cxx:230-344, 753-801)
   struct InputFrame
   {
@@ -225,6 +228,7 @@ private:
   std::vector<HeldFrame> CurrentFrames;
   float Device0AzimuthalResolution = 0.f;  // parked here while another device's frame is extracted
   int ExtractFrames();
+  int NextStoredSlot = -1;
   lsa_ctx* Ctx = nullptr;
   std::string LastError;
   uint64_t CurrentStamp = 0;

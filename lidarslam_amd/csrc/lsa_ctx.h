@@ -127,6 +127,20 @@ struct lsa_ctx
   int* ring_len = nullptr;         // [kMaxRings]
   // one 64-byte block read back per extraction: [0..3] keypoint counts, [4..11] ring_meta, [12..15] time range bits
   int* extract_out = nullptr;
+  // look-ahead extraction (lsa_extract_prefetch): the next frame's keypoints are extracted on a stream of their own
+  // while the current frame is registered; lsa_extract_keypoints adopts them when it is called for that very frame
+  hipStream_t prefetch_stream = nullptr;
+  hipEvent_t ev_prefetch = nullptr;
+  lsa_point_t* kp_next[3] = {nullptr, nullptr, nullptr};  // capacity cap_n, like the keypoint sets they are swapped with
+  int* extract_out_next = nullptr;  // device, 16 ints
+  int* host_next = nullptr;         // pinned, 16 ints
+  bool prefetch_pending = false;
+  int prefetch_adopted = 0;  // look-aheads that were adopted so far
+  const lsa_point_t* prefetch_frame = nullptr;
+  int prefetch_n = 0;
+  lsa_extract_params_t prefetch_params{};
+  float prefetch_az = 0.f;
+  unsigned prefetch_mask = 0;
   int* ring_meta = nullptr;        // = extract_out + 4: [0] nrings, [1] max laser id, [2] error flags
   float* score[4] = {nullptr, nullptr, nullptr, nullptr};  // angle, depth_gap, saliency, intensity_gap
   uint8_t* valid = nullptr;

@@ -21,6 +21,10 @@ int ensure_capacity(lsa_ctx* ctx, int n)
   // grow geometrically so that a sequence with slightly varying scan sizes allocates once
   int cap = std::max(n + n / 8, 4096);
   LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  // a look-ahead extraction in flight writes into buffers that are about to move: let it finish and forget it
+  if (ctx->prefetch_stream) LSA_HIP(ctx, hipStreamSynchronize(ctx->prefetch_stream));
+  ctx->prefetch_pending = false;
+  for (int k = 0; k < 3; ++k) LSA_HIP(ctx, dev_alloc(&ctx->kp_next[k], (size_t)cap));
   // keypoint sets must survive a growth (raw previous is still needed): copy them over
   lsa_point_t* old_kp[3][3];
   for (int s = 0; s < 3; ++s)
@@ -248,6 +252,10 @@ int lsa_ctx_create(int device_id, lsa_ctx** out)
   ok &= hipMalloc((void**)&ctx->ring_start, (kMaxRings + 1) * sizeof(int)) == hipSuccess;
   ok &= hipMalloc((void**)&ctx->ring_len, kMaxRings * sizeof(int)) == hipSuccess;
   ok &= hipMalloc((void**)&ctx->extract_out, 16 * sizeof(int)) == hipSuccess;
+  ok &= hipMalloc((void**)&ctx->extract_out_next, 16 * sizeof(int)) == hipSuccess;
+  ok &= hipHostMalloc((void**)&ctx->host_next, 16 * sizeof(int), hipHostMallocDefault) == hipSuccess;
+  ok &= hipStreamCreateWithFlags(&ctx->prefetch_stream, hipStreamNonBlocking) == hipSuccess;
+  ok &= hipEventCreateWithFlags(&ctx->ev_prefetch, hipEventDisableTiming) == hipSuccess;
   if (ok) { ctx->kp_count_dev = ctx->extract_out; ctx->ring_meta = ctx->extract_out + 4; }
   ok &= hipMalloc((void**)&ctx->ring_counts, kMaxRings * 3 * sizeof(int)) == hipSuccess;
   ok &= hipMalloc((void**)&ctx->partials, (size_t)kAccumBlocks * kAccumVals * sizeof(double)) == hipSuccess;
@@ -273,11 +281,16 @@ void lsa_ctx_destroy(lsa_ctx* ctx)
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   for (int i = 0; i < 2; ++i)
     if (ctx->side_stream[i]) (void)hipStreamSynchronize(ctx->side_stream[i]);
+  if (ctx->prefetch_stream) (void)hipStreamSynchronize(ctx->prefetch_stream);
   profile_collect(ctx);
   for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
   auto fr = [](void* p) { if (p) (void)hipFree(p); };
   fr(ctx->frame_own); fr(ctx->xyzi); fr(ctx->orig); fr(ctx->ring_of); fr(ctx->block_hist);
-  fr(ctx->ring_start); fr(ctx->ring_len); fr(ctx->extract_out);
+  fr(ctx->ring_start); fr(ctx->ring_len); fr(ctx->extract_out); fr(ctx->extract_out_next);
+  for (int k = 0; k < 3; ++k) fr(ctx->kp_next[k]);
+  if (ctx->host_next) (void)hipHostFree(ctx->host_next);
+  if (ctx->ev_prefetch) (void)hipEventDestroy(ctx->ev_prefetch);
+  if (ctx->prefetch_stream) (void)hipStreamDestroy(ctx->prefetch_stream);
   for (int i = 0; i < 4; ++i) fr(ctx->score[i]);
   fr(ctx->valid); fr(ctx->label); fr(ctx->ring_counts);
   for (int s = 0; s < 3; ++s) for (int k = 0; k < 3; ++k) fr(ctx->kp[s][k]);
@@ -457,6 +470,12 @@ int lsa_frame_store_put(lsa_ctx* ctx, int slot, const lsa_point_t* pts, int n)
   if (rc) return rc;
   if ((int)ctx->store.size() <= slot) { ctx->store.resize(slot + 1, {nullptr, 0}); ctx->store_cap.resize(slot + 1, 0); }
   lsa_point_t* d = ctx->store[slot].first;
+  if (ctx->prefetch_pending && d && ctx->prefetch_frame == d)
+  {
+    // the look-ahead extraction reads this slot: let it finish, its result no longer describes the slot
+    LSA_HIP(ctx, hipStreamSynchronize(ctx->prefetch_stream));
+    ctx->prefetch_pending = false;
+  }
   if (!d || ctx->store_cap[slot] < n)
   {
     // the frame in use may be this very slot: nothing may still read it

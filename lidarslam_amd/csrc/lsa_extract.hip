@@ -696,6 +696,50 @@ ExtractConst make_const(const lsa_extract_params_t* p, float az_res)
 
 extern "C" {
 
+// The extraction kernels of one frame on `st`: ring bucketing, validity, curvature scores, labels, compaction into
+// kp_out[type]; `out` receives the 64-byte summary (counts, ring meta, time range of the keypoints).  The per-point
+// scratch buffers of the context are shared by every caller: one frame at a time.
+static void enqueue_extract(lsa_ctx* ctx, const float4* frame4, int n, const ExtractConst& c, hipStream_t st, int* out, lsa_point_t* const kp_out[3],
+                            unsigned type_mask)
+{
+  int* ring_meta = out + 4;
+  const int nblocks = (n + kBucketChunk - 1) / kBucketChunk;
+  hipLaunchKernelGGL(k_extract_init, dim3(1), dim3(64), 0, st, out);
+  {
+    ProfScope ps(ctx, "ring_bucket", (double)n * (4 + 32 + 16 + 4 + 2 + 1), st);
+    hipLaunchKernelGGL(k_ring_hist, dim3(nblocks), dim3(256), 0, st, frame4, n, ctx->block_hist, ring_meta);
+    hipLaunchKernelGGL(k_ring_scan, dim3(kMaxRings), dim3(64), 0, st, ctx->block_hist, nblocks, ctx->ring_len, ring_meta);
+    hipLaunchKernelGGL(k_ring_scatter, dim3(nblocks), dim3(256), 0, st, frame4, n, ctx->block_hist, ctx->ring_len, ctx->ring_start,
+                       ctx->xyzi, ctx->orig, ctx->ring_of, ctx->valid);
+  }
+  {
+    ProfScope ps(ctx, "invalidate", (double)n * (16 + 2 + 1), st);
+    hipLaunchKernelGGL(k_invalidate, dim3((n + 255) / 256), dim3(256), 0, st, ctx->xyzi, ctx->ring_of, ctx->ring_start, ctx->ring_len, n, c,
+                       ctx->valid);
+  }
+  {
+    ProfScope ps(ctx, "curvature", (double)n * (16 + 2 + 1 + 16), st);
+    if (c.W <= 4)
+      hipLaunchKernelGGL(k_curvature<4>, dim3((n + 127) / 128), dim3(128), 0, st, ctx->xyzi, ctx->ring_of, ctx->ring_start, ctx->ring_len, n, c,
+                         ctx->valid, ctx->score[0], ctx->score[1], ctx->score[2], ctx->score[3]);
+    else
+      hipLaunchKernelGGL(k_curvature<8>, dim3((n + 127) / 128), dim3(128), 0, st, ctx->xyzi, ctx->ring_of, ctx->ring_start, ctx->ring_len, n, c,
+                         ctx->valid, ctx->score[0], ctx->score[1], ctx->score[2], ctx->score[3]);
+  }
+  {
+    ProfScope ps(ctx, "label_nms", (double)n * (16 + 1 + 1 + 1), st);
+    hipLaunchKernelGGL(k_label, dim3(kMaxRings), dim3(kLabelThreads), 0, st, ctx->score[0], ctx->score[1], ctx->score[2], ctx->score[3], ctx->ring_start,
+                       ctx->ring_len, ring_meta, c, ctx->valid, ctx->label, ctx->ring_counts);
+  }
+  {
+    ProfScope ps(ctx, "compact", (double)n * (1 + 4), st);
+    hipLaunchKernelGGL(k_compact, dim3(kMaxRings), dim3(256), 0, st, frame4, ctx->orig, ctx->label, ctx->ring_start, ctx->ring_len,
+                       ring_meta, ctx->ring_counts, reinterpret_cast<float4*>(kp_out[0]),
+                       reinterpret_cast<float4*>(kp_out[1]), reinterpret_cast<float4*>(kp_out[2]),
+                       out, type_mask, reinterpret_cast<unsigned long long*>(out + 12));
+  }
+}
+
 // One device frame through the extraction kernels.  append == false: Slam::ExtractKeypoints' first frame (the
 // current keypoints become the previous ones, Slam.cxx:751); append == true: a further frame of the same
 // AddFrames call, whose keypoints go behind those already there (AggregateFrames, Slam.cxx:1512-1578).
@@ -716,6 +760,18 @@ static int extract_frame(lsa_ctx* ctx, const lsa_extract_params_t* params, int c
   hipStream_t st = ctx->stream;
   const ExtractConst c = make_const(params, ctx->az_res);
 
+  // a look-ahead extraction (lsa_extract_prefetch) of exactly this frame with exactly these settings is adopted;
+  // any other one has to finish first, because the per-point scratch buffers are shared
+  bool adopt = false;
+  if (ctx->prefetch_pending)
+  {
+    adopt = !append && !base_to_lidar && time_offset == 0. && ctx->prefetch_frame == ctx->frame && ctx->prefetch_n == n &&
+            std::memcmp(&ctx->prefetch_params, params, sizeof(*params)) == 0 && ctx->prefetch_az == ctx->az_res &&
+            ctx->prefetch_mask == ctx->kp_type_mask;
+    if (adopt) LSA_HIP(ctx, hipEventSynchronize(ctx->ev_prefetch));
+    else LSA_HIP(ctx, hipStreamSynchronize(ctx->prefetch_stream));
+    ctx->prefetch_pending = false;
+  }
   if (!append)
   {
     // Slam::ExtractKeypoints: current keypoints become the previous ones (Slam.cxx:751)
@@ -731,46 +787,24 @@ static int extract_frame(lsa_ctx* ctx, const lsa_extract_params_t* params, int c
   }
   ctx->kp_time_valid[LSA_SET_RAW_CURRENT] = false;
 
-  const int nblocks = (n + kBucketChunk - 1) / kBucketChunk;
-  const float4* frame4 = reinterpret_cast<const float4*>(ctx->frame);
-  hipLaunchKernelGGL(k_extract_init, dim3(1), dim3(64), 0, st, ctx->extract_out);
-  {
-    ProfScope ps(ctx, "ring_bucket", (double)n * (4 + 32 + 16 + 4 + 2 + 1));
-    hipLaunchKernelGGL(k_ring_hist, dim3(nblocks), dim3(256), 0, st, frame4, n, ctx->block_hist, ctx->ring_meta);
-    hipLaunchKernelGGL(k_ring_scan, dim3(kMaxRings), dim3(64), 0, st, ctx->block_hist, nblocks, ctx->ring_len, ctx->ring_meta);
-    hipLaunchKernelGGL(k_ring_scatter, dim3(nblocks), dim3(256), 0, st, frame4, n, ctx->block_hist, ctx->ring_len, ctx->ring_start,
-                       ctx->xyzi, ctx->orig, ctx->ring_of, ctx->valid);
-  }
-  {
-    ProfScope ps(ctx, "invalidate", (double)n * (16 + 2 + 1));
-    hipLaunchKernelGGL(k_invalidate, dim3((n + 255) / 256), dim3(256), 0, st, ctx->xyzi, ctx->ring_of, ctx->ring_start, ctx->ring_len, n, c,
-                       ctx->valid);
-  }
-  {
-    ProfScope ps(ctx, "curvature", (double)n * (16 + 2 + 1 + 16));
-    if (c.W <= 4)
-      hipLaunchKernelGGL(k_curvature<4>, dim3((n + 127) / 128), dim3(128), 0, st, ctx->xyzi, ctx->ring_of, ctx->ring_start, ctx->ring_len, n, c,
-                         ctx->valid, ctx->score[0], ctx->score[1], ctx->score[2], ctx->score[3]);
-    else
-      hipLaunchKernelGGL(k_curvature<8>, dim3((n + 127) / 128), dim3(128), 0, st, ctx->xyzi, ctx->ring_of, ctx->ring_start, ctx->ring_len, n, c,
-                         ctx->valid, ctx->score[0], ctx->score[1], ctx->score[2], ctx->score[3]);
-  }
-  {
-    ProfScope ps(ctx, "label_nms", (double)n * (16 + 1 + 1 + 1));
-    hipLaunchKernelGGL(k_label, dim3(kMaxRings), dim3(kLabelThreads), 0, st, ctx->score[0], ctx->score[1], ctx->score[2], ctx->score[3], ctx->ring_start,
-                       ctx->ring_len, ctx->ring_meta, c, ctx->valid, ctx->label, ctx->ring_counts);
-  }
-  {
-    ProfScope ps(ctx, "compact", (double)n * (1 + 4));
-    hipLaunchKernelGGL(k_compact, dim3(kMaxRings), dim3(256), 0, st, frame4, ctx->orig, ctx->label, ctx->ring_start, ctx->ring_len,
-                       ctx->ring_meta, ctx->ring_counts, reinterpret_cast<float4*>(ctx->kp[LSA_SET_RAW_CURRENT][0] + base[0]),
-                       reinterpret_cast<float4*>(ctx->kp[LSA_SET_RAW_CURRENT][1] + base[1]), reinterpret_cast<float4*>(ctx->kp[LSA_SET_RAW_CURRENT][2] + base[2]),
-                       ctx->kp_count_dev, ctx->kp_type_mask, reinterpret_cast<unsigned long long*>(ctx->extract_out + 12));
-  }
-  // counts, ring_meta and the keypoints' time range (Slam::InitUndistortion needs it later) in one 64-byte read-back
   int* hp = reinterpret_cast<int*>(ctx->host_pinned);
-  LSA_HIP(ctx, hipMemcpyAsync(hp, ctx->extract_out, 16 * sizeof(int), hipMemcpyDeviceToHost, st));
-  LSA_HIP(ctx, hipStreamSynchronize(st));
+  if (adopt)
+  {
+    // the keypoints are there already: the look-ahead buffers become the current sets, their summary was copied
+    // to the host when the kernels finished
+    for (int k = 0; k < 3; ++k) std::swap(ctx->kp[LSA_SET_RAW_CURRENT][k], ctx->kp_next[k]);
+    hp = ctx->host_next;
+    ctx->prefetch_adopted++;
+  }
+  else
+  {
+    lsa_point_t* kp_out[3];
+    for (int k = 0; k < 3; ++k) kp_out[k] = ctx->kp[LSA_SET_RAW_CURRENT][k] + base[k];
+    enqueue_extract(ctx, reinterpret_cast<const float4*>(ctx->frame), n, c, st, ctx->extract_out, kp_out, ctx->kp_type_mask);
+    // counts, ring_meta and the keypoints' time range (Slam::InitUndistortion needs it later) in one 64-byte read-back
+    LSA_HIP(ctx, hipMemcpyAsync(hp, ctx->extract_out, 16 * sizeof(int), hipMemcpyDeviceToHost, st));
+    LSA_HIP(ctx, hipStreamSynchronize(st));
+  }
   unsigned long long hpt[2];
   std::memcpy(hpt, hp + 12, sizeof(hpt));
   if (hp[6] & 1) return ctx->fail(LSA_E_CAPACITY, "lsa_extract_keypoints: laser_id >= 512 is not supported");
@@ -802,6 +836,39 @@ int lsa_extract_keypoints(lsa_ctx* ctx, const lsa_extract_params_t* params, int 
 {
   return extract_frame(ctx, params, counts, false, nullptr, 0.);
 }
+
+int lsa_extract_prefetch(lsa_ctx* ctx, int slot, const lsa_extract_params_t* params)
+{
+  if (!ctx || !params) return ctx ? ctx->fail(LSA_E_ARG, "lsa_extract_prefetch: null argument") : LSA_E_ARG;
+  if (slot < 0 || slot >= (int)ctx->store.size() || !ctx->store[slot].first) return ctx->fail(LSA_E_ARG, "lsa_extract_prefetch: empty slot");
+  if (params->neighbor_width < 1 || params->neighbor_width > 8) return ctx->fail(LSA_E_ARG, "lsa_extract_prefetch: NeighborWidth must be in [1, 8]");
+  LSA_HIP(ctx, hipSetDevice(ctx->device));
+  if (ctx->prefetch_pending)
+  {
+    LSA_HIP(ctx, hipStreamSynchronize(ctx->prefetch_stream));  // one look-ahead at a time
+    ctx->prefetch_pending = false;
+  }
+  const int n = ctx->store[slot].second;
+  int rc = ensure_capacity(ctx, n);
+  if (rc) return rc;
+  if (!ctx->kp_next[0])
+    for (int k = 0; k < 3; ++k) LSA_HIP(ctx, hipMalloc((void**)&ctx->kp_next[k], (size_t)ctx->cap_n * sizeof(lsa_point_t)));
+  // the scratch buffers are free: the extraction of the current frame ended with a read-back on ctx->stream
+  const ExtractConst c = make_const(params, ctx->az_res);
+  enqueue_extract(ctx, reinterpret_cast<const float4*>(ctx->store[slot].first), n, c, ctx->prefetch_stream, ctx->extract_out_next, ctx->kp_next,
+                  ctx->kp_type_mask);
+  LSA_HIP(ctx, hipMemcpyAsync(ctx->host_next, ctx->extract_out_next, 16 * sizeof(int), hipMemcpyDeviceToHost, ctx->prefetch_stream));
+  LSA_HIP(ctx, hipEventRecord(ctx->ev_prefetch, ctx->prefetch_stream));
+  ctx->prefetch_pending = true;
+  ctx->prefetch_frame = ctx->store[slot].first;
+  ctx->prefetch_n = n;
+  ctx->prefetch_params = *params;
+  ctx->prefetch_az = ctx->az_res;
+  ctx->prefetch_mask = ctx->kp_type_mask;
+  return LSA_OK;
+}
+
+int lsa_extract_prefetch_adopted(const lsa_ctx* ctx) { return ctx ? ctx->prefetch_adopted : 0; }
 
 int lsa_extract_keypoints_more(lsa_ctx* ctx, const lsa_extract_params_t* params, const double base_to_lidar[16], double time_offset, int counts[3])
 {
@@ -850,6 +917,7 @@ int lsa_set_keypoints(lsa_ctx* ctx, int set, int type, const lsa_point_t* pts, i
 int lsa_download_debug(lsa_ctx* ctx, int array_id, float* out, int capacity)
 {
   if (!ctx || !out || array_id < 0 || array_id > 9) return ctx ? ctx->fail(LSA_E_ARG, "lsa_download_debug: bad argument") : LSA_E_ARG;
+  if (ctx->prefetch_pending) return ctx->fail(LSA_E_STATE, "lsa_download_debug: the per-point arrays are in use by a look-ahead extraction (lsa_extract_prefetch)");
   const int n = ctx->frame_n;
   if (capacity < n) return ctx->fail(LSA_E_CAPACITY, "lsa_download_debug: capacity < frame size");
   int rc = ensure_scratch(ctx, (size_t)n * sizeof(float));

@@ -71,10 +71,11 @@ class ConcurrentReplay:
     idle; independent sequences fill it.  Every thread drives its own handle, the library keeps no
     state outside of the handles, and the results are those of a lone run bit for bit (tests/test_gpu_pipeline.py)."""
 
-    def __init__(self, device, model, seeds, frames, **params):
+    def __init__(self, device, model, seeds, frames, lookahead=True, **params):
         import lidarslam_amd as L
 
         self.frames = frames
+        self.lookahead = lookahead  # extract frame f + 1 beside the registration of frame f (same results)
         self.slams, self.stamps = [], []
         for seed in seeds:
             slam = L.Slam(device, **params)
@@ -104,6 +105,8 @@ class ConcurrentReplay:
                 for f in range(self.frames):
                     if f == warmup:
                         gate.wait()
+                    if self.lookahead and f + 1 < self.frames:
+                        self.slams[s].hint_next_stored_frame(f + 1)
                     self.slams[s].add_stored_frame(f, self.stamps[s][f], f)
                     self.poses[s, f] = self.slams[s].world_transform()
                 self.slams[s].context().sync()

@@ -499,3 +499,49 @@ def test_two_lidar_devices_follow_the_oracle(L, O):
     dt, dr = pose_diff(sg.world_transform(), so.world_transform())
     assert dt < 1e-9 and dr < 1e-9
     sg.close()
+
+
+@pytest.mark.gpu
+def test_lookahead_extraction_changes_nothing_but_the_schedule(L):
+    """lsa_slam_hint_next_stored_frame / lsa_extract_prefetch: the next stored frame's keypoints are extracted on their
+    own stream beside the current frame's registration and adopted by the next AddStoredFrame.  Poses, keypoints and
+    match statistics are those of the plain run bit for bit -- with hints that come true, with hints that do not, and
+    when a parameter changes between the look-ahead and the frame."""
+    frames = [L.synth_frame(16, 1000, f) for f in range(12)]
+
+    def run(hints, change_at=None):
+        s = L.Slam(0, EgoMotion=3)
+        for f, (pts, _) in enumerate(frames):
+            s.store_frame(f, pts)
+        poses, kps, used = [], [], []
+        for f, (_, stamp) in enumerate(frames):
+            if f == change_at:
+                s.set_param("EdgeIntensityGapThreshold", 30.0)  # the look-ahead of this frame used 50: it is dropped
+            if hints(f) is not None:
+                s.hint_next_stored_frame(hints(f))
+            s.add_stored_frame(f, stamp, f)
+            poses.append(s.world_transform())
+            kps.append([s.keypoints(k, 2).tobytes() for k in (L.EDGE, L.PLANE)])
+            used.append(s.get_param("TotalMatchedKeypoints"))
+        hits = s.get_param("LookaheadAdopted")
+        s.close()
+        return np.array(poses), kps, used, hits
+
+    plain = run(lambda f: None)
+    ahead = run(lambda f: f + 1 if f + 1 < len(frames) else None)
+    wrong = run(lambda f: (f + 3) % len(frames))
+    assert plain[3] == 0 and ahead[3] == len(frames) - 1 and wrong[3] == 0
+    for other in (ahead, wrong):
+        assert np.array_equal(plain[0], other[0]) and plain[1] == other[1] and plain[2] == other[2]
+    plain_c = run(lambda f: None, change_at=6)
+    ahead_c = run(lambda f: f + 1 if f + 1 < len(frames) else None, change_at=6)
+    assert ahead_c[3] == len(frames) - 2  # all but the frame whose parameters changed under the look-ahead
+    assert np.array_equal(plain_c[0], ahead_c[0]) and plain_c[1] == ahead_c[1]
+    assert plain_c[1] != plain[1]
+    # the hint of a slot that does not exist is reported, not fatal
+    s = L.Slam(0, EgoMotion=3)
+    s.store_frame(0, frames[0][0])
+    s.hint_next_stored_frame(5)
+    s.add_stored_frame(0, frames[0][1], 0)
+    assert s.keypoints(L.PLANE, 2).tobytes() == plain[1][0][1]
+    s.close()

@@ -150,3 +150,27 @@ def test_changing_the_geometry_clears_the_map():
     assert g.size() == o.size() == 0
     with pytest.raises(L.LsaError):
         g.set("NoSuchParameter", 1.0)
+
+
+@pytest.mark.parametrize("sampling", [0, 1, 2, 3, 4])
+def test_add_on_several_threads_builds_the_same_map(sampling):
+    """"AddThreads" is an implementation knob: outer voxels are created in point order by one thread, the leaf voxels of
+    each outer voxel are filled by one thread in point order -- same content, same iteration order, same sub-maps as the
+    oracle's sequential loop (CENTROID couples the voxels and stays sequential)."""
+    rng = np.random.default_rng(40 + sampling)
+    g, o = pair(GridSize=16, VoxelResolution=6.0, LeafSize=0.5, Sampling=sampling, MinFramesPerVoxel=2)
+    g.set("AddThreads", 4)
+    for step in range(10):
+        centre = np.array([step * 4.0, step * 1.5, 0.0])
+        pts = cloud(rng, 6000 if step != 4 else 500, centre, spread=16.0, t=step * 0.1, labels=True)
+        for m in (g, o):
+            m.add(pts, fixed=(step == 2), time=step * 0.1)
+        same_state(g, o)
+        q = cloud(rng, 300, centre, spread=12.0)
+        mn = np.array([q["x"].min(), q["y"].min(), q["z"].min()], np.float32)
+        mx = np.array([q["x"].max(), q["y"].max(), q["z"].max()], np.float32)
+        assert same_submap(g, o, mn, mx, min_nb=150) > 0
+    g.set("AddThreads", 1)
+    pts = cloud(rng, 6000, np.zeros(3), spread=16.0)
+    g.add(pts), o.add(pts)
+    same_state(g, o)

@@ -14,7 +14,7 @@ if f and w:
                          capture_output=True, text=True, check=True).stdout
     open(os.path.join(dst, f"{rnd}_vls128_pmc_traffic.txt"), "w").write(out)
 lines = []
-for m in ("vls128", "hdl64", "vlp16", "vls128_noevents"):
+for m in ("vls128", "hdl64", "vlp16", "vls128_noevents", "vls128_nolookahead", "vls128_hostframes"):
     p = os.path.join(src, f"bench_{m}.json")
     if os.path.exists(p):
         for l in open(p):

@@ -320,6 +320,8 @@ int lsa_undistort(lsa_ctx* ctx, const double H0[16], const double H1[16], double
  * Slam.cxx:1291-1300) and bounding box of pose * working keypoints of one type
  * (Slam.cxx:1026-1029). */
 int lsa_working_time_range(lsa_ctx* ctx, double* tmin, double* tmax);
+/* ... of any keypoint set (the raw sets get theirs from the extraction at no cost) */
+int lsa_keypoint_time_range(lsa_ctx* ctx, int set, double* tmin, double* tmax);
 int lsa_working_bbox(lsa_ctx* ctx, int type, const double pose[16], float mn[3], float mx[3]);
 /* The same for the three keypoint types in one pass and one synchronisation:
  * mn / mx = [type][xyz]. */
@@ -327,6 +329,9 @@ int lsa_working_bboxes(lsa_ctx* ctx, const double pose[16], float mn[9], float m
 /* The same on any keypoint set, split in two: _begin only enqueues the reduction and its read-back, _end
  * waits for exactly that work.  Whatever the caller enqueues in between overlaps it. */
 int lsa_keypoint_bboxes_begin(lsa_ctx* ctx, int set, const double pose[16]);
+/* Same with the pose interpolated at every point's own time between H0 (at t0) and H1 (at t1), like lsa_undistort:
+ * the box the keypoints will have once they are undistorted with that motion. */
+int lsa_keypoint_bboxes_begin_interp(lsa_ctx* ctx, int set, const double H0[16], const double H1[16], double t0, double t1);
 int lsa_keypoint_bboxes_end(lsa_ctx* ctx, float mn[9], float mx[9]);
 
 /* Slam::TransformPointCloud (Slam.cxx:1491-1509) on a device keypoint set:

@@ -704,7 +704,29 @@ int SlamCore::BeginSubMapSpeculation(const Pose& predicted)
 {
   SpecPending = false;
   if (MapUpdate == MappingMode::NONE) return LSA_OK;
-  LSA_TRY(lsa_keypoint_bboxes_begin(Ctx, LSA_SET_RAW_CURRENT, predicted.m));
+  // Localization() will look at the keypoints after undistorting them with the motion between the previous pose
+  // and the (then known) current one: the prediction does the same with the predicted pose -- the scan poses of
+  // InterpolateScanPose at both ends of the keypoints' time range (Slam.cxx:1271-1285, 1288-1352).  Here Tworld
+  // still is the previous frame's pose.
+  bool interpolated = false;
+  if (Undistortion && !LogTrajectory.empty())
+  {
+    double t0 = 0., t1 = 0.;
+    LSA_TRY(lsa_keypoint_time_range(Ctx, LSA_SET_RAW_CURRENT, &t0, &t1));
+    const double prevPoseTime = LogTrajectory.back().time;
+    const double currPoseTime = StampToSec(CurrentStamp);
+    if (t1 - t0 >= 1e-6 && currPoseTime != prevPoseTime)
+    {
+      auto scanPose = [&](double time) {
+        if (std::abs(time / (currPoseTime - prevPoseTime)) > MaxExtrapolationRatio) return predicted;
+        return LinearInterpolation(Tworld, predicted, currPoseTime + time, prevPoseTime, currPoseTime);
+      };
+      const Pose begin = scanPose(t0), end = scanPose(t1);
+      LSA_TRY(lsa_keypoint_bboxes_begin_interp(Ctx, LSA_SET_RAW_CURRENT, begin.m, end.m, t0, t1));
+      interpolated = true;
+    }
+  }
+  if (!interpolated) LSA_TRY(lsa_keypoint_bboxes_begin(Ctx, LSA_SET_RAW_CURRENT, predicted.m));
   SpecPending = true;
   return LSA_OK;
 }

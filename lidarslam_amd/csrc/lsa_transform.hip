@@ -206,7 +206,7 @@ __global__ __launch_bounds__(256) void k_time_range3(KpSets sets, const int* __r
     atomicMax(&bits[1], hi);
   }
 }
-__global__ __launch_bounds__(256) void k_bbox3(KpSets sets, Rigid T, unsigned* __restrict__ bits)
+__global__ __launch_bounds__(256) void k_bbox3(KpSets sets, Rigid T0, int interpolate, InterpConst c, unsigned* __restrict__ bits)
 {
   __shared__ unsigned slo[4][3], shi[4][3];
   const int t = blockIdx.y;
@@ -217,6 +217,8 @@ __global__ __launch_bounds__(256) void k_bbox3(KpSets sets, Rigid T, unsigned* _
   if (i < n)
   {
     const float4 a = sets.pts[t][2 * (size_t)i];
+    Rigid T = T0;
+    if (interpolate) interp_eval(c, point_time(sets.pts[t][2 * (size_t)i + 1]), T);  // the pose at the point's own time
     double ox, oy, oz;
     rigid_apply(T, (double)a.x, (double)a.y, (double)a.z, ox, oy, oz);
     const float v[3] = {(float)ox, (float)oy, (float)oz};
@@ -393,26 +395,28 @@ int lsa_undistort(lsa_ctx* ctx, const double H0[16], const double H1[16], double
   return LSA_OK;
 }
 
-int lsa_working_time_range(lsa_ctx* ctx, double* tmin, double* tmax)
+int lsa_working_time_range(lsa_ctx* ctx, double* tmin, double* tmax) { return lsa_keypoint_time_range(ctx, LSA_SET_WORKING, tmin, tmax); }
+
+int lsa_keypoint_time_range(lsa_ctx* ctx, int set, double* tmin, double* tmax)
 {
-  if (!ctx || !tmin || !tmax) return ctx ? ctx->fail(LSA_E_ARG, "lsa_working_time_range: bad argument") : LSA_E_ARG;
+  if (!ctx || !tmin || !tmax || set < 0 || set > 2) return ctx ? ctx->fail(LSA_E_ARG, "lsa_keypoint_time_range: bad argument") : LSA_E_ARG;
   LSA_HIP(ctx, hipSetDevice(ctx->device));
-  if (!ctx->kp_time_valid[LSA_SET_WORKING])
+  if (!ctx->kp_time_valid[set])
   {
     // (the usual case costs nothing: lsa_extract_keypoints reduced the range of the raw keypoints and
     // lsa_reset_working_keypoints carried it over)
-    int rc = lsa::enqueue_time_range(ctx, LSA_SET_WORKING, nullptr);
+    int rc = lsa::enqueue_time_range(ctx, set, nullptr);
     if (rc) return rc;
     unsigned long long* hp = reinterpret_cast<unsigned long long*>(ctx->host_pinned + 128);
     LSA_HIP(ctx, hipMemcpyAsync(hp, ctx->range_bits, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
     LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    lsa::finish_time_range(ctx, LSA_SET_WORKING, hp);
+    lsa::finish_time_range(ctx, set, hp);
   }
-  *tmin = ctx->kp_time[LSA_SET_WORKING][0];
-  *tmax = ctx->kp_time[LSA_SET_WORKING][1];
+  *tmin = ctx->kp_time[set][0];
+  *tmax = ctx->kp_time[set][1];
   return LSA_OK;
 }
-int lsa_keypoint_bboxes_begin(lsa_ctx* ctx, int set, const double pose[16])
+static int bboxes_begin(lsa_ctx* ctx, int set, const double pose[16], const double pose_end[16], double t0, double t1)
 {
   if (!ctx || !pose || set < 0 || set > 2) return ctx ? ctx->fail(LSA_E_ARG, "lsa_keypoint_bboxes_begin: bad argument") : LSA_E_ARG;
   LSA_HIP(ctx, hipSetDevice(ctx->device));
@@ -430,10 +434,18 @@ int lsa_keypoint_bboxes_begin(lsa_ctx* ctx, int set, const double pose[16])
   row_major_to_rt(pose, T.R, T.t);
   unsigned* bits = reinterpret_cast<unsigned*>(ctx->range_bits + 16);
   hipLaunchKernelGGL(k_bbox_init, dim3(1), dim3(64), 0, ctx->stream, bits);
-  hipLaunchKernelGGL(k_bbox3, dim3((nmax + 255) / 256, 3), dim3(256), 0, ctx->stream, sets, T, bits);
+  InterpConst ic{};
+  if (pose_end) ic = make_interp(pose, pose_end, t0, t1);
+  hipLaunchKernelGGL(k_bbox3, dim3((nmax + 255) / 256, 3), dim3(256), 0, ctx->stream, sets, T, pose_end ? 1 : 0, ic, bits);
   LSA_HIP(ctx, hipMemcpyAsync(ctx->host_pinned + 160, bits, 18 * sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
   LSA_HIP(ctx, hipEventRecord(ctx->ev_bbox, ctx->stream));
   return LSA_OK;
+}
+int lsa_keypoint_bboxes_begin(lsa_ctx* ctx, int set, const double pose[16]) { return bboxes_begin(ctx, set, pose, nullptr, 0., 0.); }
+int lsa_keypoint_bboxes_begin_interp(lsa_ctx* ctx, int set, const double H0[16], const double H1[16], double t0, double t1)
+{
+  if (!H1) return ctx ? ctx->fail(LSA_E_ARG, "lsa_keypoint_bboxes_begin_interp: bad argument") : LSA_E_ARG;
+  return bboxes_begin(ctx, set, H0, H1, t0, t1);
 }
 int lsa_keypoint_bboxes_end(lsa_ctx* ctx, float mn[9], float mx[9])
 {

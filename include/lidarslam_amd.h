@@ -216,6 +216,14 @@ int lsa_set_target(lsa_ctx* ctx, int slot, int type, const lsa_point_t* pts, int
 lsa_point_t* lsa_target_staging(lsa_ctx* ctx, int slot, int type, int capacity);
 int lsa_set_target_staged(lsa_ctx* ctx, int slot, int type, int m);
 int lsa_set_target_from_set(lsa_ctx* ctx, int slot, int type, int set);
+/* Builds ahead of time the targets the NEXT frame's ego-motion will search: the current raw keypoints of the types
+ * in type_mask (which the next lsa_extract_keypoints turns into the previous ones) are copied and their search
+ * grids built on the look-ahead stream, beside the current frame's registration.  The next
+ * lsa_set_target_from_set(LSA_TARGET_PREVIOUS, type, LSA_SET_RAW_PREVIOUS) takes them over if the set was not
+ * written since and the cell size is the one they were built with; otherwise it builds as usual.  Same neighbours
+ * either way.  lsa_prepared_targets_adopted counts the take-overs. */
+int lsa_prepare_previous_targets(lsa_ctx* ctx, unsigned type_mask);
+int lsa_prepared_targets_adopted(const lsa_ctx* ctx);
 int lsa_target_size(const lsa_ctx* ctx, int slot, int type);
 /* The target's points as they were given (Slam::GetTargetSubMap, Slam.h:168): returns the number written. */
 int lsa_download_target(lsa_ctx* ctx, int slot, int type, lsa_point_t* out, int capacity);

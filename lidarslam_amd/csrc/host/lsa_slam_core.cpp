@@ -80,9 +80,9 @@ SlamCore::SlamCore(int device)
   ExtractParams.edge_saliency_threshold = 1.5f;
   ExtractParams.edge_intensity_gap_threshold = 50.f;
   for (int k = 0; k < 3; ++k) LocalMaps[k] = std::make_shared<RollingGrid>();
-  // the plane map takes the largest insertions (tens of thousands of keypoints per keyframe): three host threads
+  // the plane map takes the largest insertions (tens of thousands of keypoints per keyframe): four host threads
   // keep them shorter than the ego-motion ICP they run beside ("MapAddThreads"; the map is the same for any value)
-  LocalMaps[LSA_PLANE]->SetAddThreads(3);
+  LocalMaps[LSA_PLANE]->SetAddThreads(4);
   for (int k = 0; k < 3; ++k) LocalMaps[k]->SetVoxelResolution(10.);
   for (int k = 0; k < 3; ++k) LocalMaps[k]->SetGridSize(50);
   LocalMaps[LSA_EDGE]->SetLeafSize(0.30);
@@ -451,6 +451,16 @@ int SlamCore::ExtractFrames()
   return LSA_OK;
 }
 
+// The kd-trees ComputeEgoMotion builds on the previous frame's keypoints (Slam.cxx:845-860) only depend on this
+// frame's keypoints: their device counterparts are built now, beside this frame's registration, and found ready by
+// the next frame.
+int SlamCore::PrepareNextEgoMotionTargets()
+{
+  if (!BuildTargetsAhead) return LSA_OK;
+  if (!(EgoMotion == EgoMotionMode::REGISTRATION || EgoMotion == EgoMotionMode::MOTION_EXTRAPOLATION_AND_REGISTRATION)) return LSA_OK;
+  return lsa_prepare_previous_targets(Ctx, (1u << LSA_EDGE) | (1u << LSA_PLANE));
+}
+
 lsa_match_params_t SlamCore::EgoMatchParams() const
 {
   lsa_match_params_t p;
@@ -513,6 +523,8 @@ int SlamCore::ComputeEgoMotion()
     lsa_set_target_cell_size(Ctx, LSA_TARGET_PREVIOUS, k, static_cast<float>(k == LSA_EDGE ? KnnCellSizeEgoMotionEdges : KnnCellSizeEgoMotion));
     LSA_TRY(lsa_set_target_from_set(Ctx, LSA_TARGET_PREVIOUS, k, LSA_SET_RAW_PREVIOUS));
   }
+  // ... and those of the next frame, which are this frame's keypoints, are built beside this registration
+  LSA_TRY(PrepareNextEgoMotionTargets());
   TotalMatchedKeypoints = 0;
   lsa_match_params_t mp = EgoMatchParams();
 
@@ -1013,6 +1025,7 @@ int SlamCore::GetRegisteredFrame(std::vector<lsa_point_t>& out)
   X("UseEdges", UseKeypoints[LSA_EDGE], bool)                                                          \
   X("UsePlanes", UseKeypoints[LSA_PLANE], bool)                                                        \
   X("TwoDMode", TwoDMode, bool)                                                                        \
+  X("BuildTargetsAhead", BuildTargetsAhead, bool)                                                      \
   X("EgoMotionICPMaxIter", EgoMotionICPMaxIter, unsigned)                                              \
   X("LocalizationICPMaxIter", LocalizationICPMaxIter, unsigned)                                        \
   X("EgoMotionLMMaxIter", EgoMotionLMMaxIter, unsigned)                                                \
@@ -1121,6 +1134,7 @@ int SlamCore::GetParam(const std::string& name, double* v) const
   if (name == "OverlapEstimation") { *v = OverlapEstimation; return LSA_OK; }
   if (name == "SubMapSpeculationHits") { *v = SubMapSpecHitsTotal; return LSA_OK; }
   if (name == "LookaheadAdopted") { *v = Ctx ? lsa_extract_prefetch_adopted(Ctx) : 0; return LSA_OK; }
+  if (name == "TargetsBuiltAheadAdopted") { *v = Ctx ? lsa_prepared_targets_adopted(Ctx) : 0; return LSA_OK; }
   if (name == "MapAddThreads") { *v = LocalMaps[LSA_PLANE]->GetAddThreads(); return LSA_OK; }
   if (name == "MapAddThreadsEdges") { *v = LocalMaps[LSA_EDGE]->GetAddThreads(); return LSA_OK; }
   if (name == "LoggingTimeout") { *v = LoggingTimeout; return LSA_OK; }

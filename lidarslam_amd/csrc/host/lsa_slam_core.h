@@ -182,6 +182,8 @@ public:
   // lanes per query in the first kNN kernel (sparse edge targets: more lanes, fewer queries per wavefront)
   int KnnLanesEdges = 16, KnnLanesPlanes = 8, KnnLanesBlobs = 8;
   int KnnRoundsEdges = 2, KnnRoundsPlanes = 2, KnnRoundsBlobs = 2;  // rounds of the first kNN kernel (2 or 3)
+  // build the next frame's ego-motion targets beside this frame's registration (a scheduling knob: same results)
+  bool BuildTargetsAhead = true;
   bool KeepMatchDebug = false;  // download MatchingResults::Rejections/Weights every frame (Slam::GetDebugArray)
 
   std::shared_ptr<RollingGrid> LocalMaps[3];
@@ -228,6 +230,7 @@ private:
   std::vector<HeldFrame> CurrentFrames;
   float Device0AzimuthalResolution = 0.f;  // parked here while another device's frame is extracted
   int ExtractFrames();
+  int PrepareNextEgoMotionTargets();
   int NextStoredSlot = -1;
   lsa_ctx* Ctx = nullptr;
   std::string LastError;

@@ -159,7 +159,16 @@ struct lsa_ctx
   // lsa_target_staging: pinned host buffers a target's points are written into before lsa_set_target_staged
   lsa_point_t* tstage[6] = {};
   int tstage_cap[6] = {};
-  lsa::Target target[6];  // [slot * 3 + type]: slot 0 = map sub-maps (localization), slot 1 = previous scan (ego-motion)
+  lsa::Target target[9];  // [slot * 3 + type]: slot 0 = map sub-maps (localization), slot 1 = previous scan (ego-motion);
+                          // [6 + type] = the previous-scan targets of the NEXT frame, built ahead (lsa_prepare_previous_targets)
+  // content versions of the keypoint sets: every write takes a new number, the shift of the current keypoints to
+  // the previous ones carries it along -- that is how a target built ahead knows it still describes the set
+  unsigned long long kp_clock = 0;
+  unsigned long long kp_ver[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+  unsigned long long spare_ver[3] = {0, 0, 0};
+  bool spare_ready[3] = {false, false, false};
+  int spare_adopted = 0;
+  hipEvent_t ev_spare = nullptr, ev_kp_ready = nullptr;
   lsa::MatchBuf match[3];
 
   double* partials = nullptr;  // [kAccumBlocks][kAccumVals]

@@ -84,6 +84,7 @@ int ensure_target(lsa_ctx* ctx, int ti, int m)
   if (m <= t.cap) return LSA_OK;
   int cap = std::max(m + m / 4, 4096);
   LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (ctx->prefetch_stream) LSA_HIP(ctx, hipStreamSynchronize(ctx->prefetch_stream));  // targets built ahead live there
   LSA_HIP(ctx, dev_alloc(&t.pts, (size_t)cap));
   LSA_HIP(ctx, dev_alloc(&t.xyzl, (size_t)cap));
   for (int l = 0; l < kGridLevels; ++l)
@@ -256,6 +257,8 @@ int lsa_ctx_create(int device_id, lsa_ctx** out)
   ok &= hipHostMalloc((void**)&ctx->host_next, 16 * sizeof(int), hipHostMallocDefault) == hipSuccess;
   ok &= hipStreamCreateWithFlags(&ctx->prefetch_stream, hipStreamNonBlocking) == hipSuccess;
   ok &= hipEventCreateWithFlags(&ctx->ev_prefetch, hipEventDisableTiming) == hipSuccess;
+  ok &= hipEventCreateWithFlags(&ctx->ev_spare, hipEventDisableTiming) == hipSuccess;
+  ok &= hipEventCreateWithFlags(&ctx->ev_kp_ready, hipEventDisableTiming) == hipSuccess;
   if (ok) { ctx->kp_count_dev = ctx->extract_out; ctx->ring_meta = ctx->extract_out + 4; }
   ok &= hipMalloc((void**)&ctx->ring_counts, kMaxRings * 3 * sizeof(int)) == hipSuccess;
   ok &= hipMalloc((void**)&ctx->partials, (size_t)kAccumBlocks * kAccumVals * sizeof(double)) == hipSuccess;
@@ -290,11 +293,13 @@ void lsa_ctx_destroy(lsa_ctx* ctx)
   for (int k = 0; k < 3; ++k) fr(ctx->kp_next[k]);
   if (ctx->host_next) (void)hipHostFree(ctx->host_next);
   if (ctx->ev_prefetch) (void)hipEventDestroy(ctx->ev_prefetch);
+  if (ctx->ev_spare) (void)hipEventDestroy(ctx->ev_spare);
+  if (ctx->ev_kp_ready) (void)hipEventDestroy(ctx->ev_kp_ready);
   if (ctx->prefetch_stream) (void)hipStreamDestroy(ctx->prefetch_stream);
   for (int i = 0; i < 4; ++i) fr(ctx->score[i]);
   fr(ctx->valid); fr(ctx->label); fr(ctx->ring_counts);
   for (int s = 0; s < 3; ++s) for (int k = 0; k < 3; ++k) fr(ctx->kp[s][k]);
-  for (int k = 0; k < 6; ++k)
+  for (int k = 0; k < 9; ++k)
   {
     Target& t = ctx->target[k];
     fr(t.pts); fr(t.xyzl); fr(t.desc); fr(t.bbox_bits);

@@ -778,6 +778,7 @@ static int extract_frame(lsa_ctx* ctx, const lsa_extract_params_t* params, int c
     for (int k = 0; k < 3; ++k)
     {
       std::swap(ctx->kp[LSA_SET_RAW_CURRENT][k], ctx->kp[LSA_SET_RAW_PREVIOUS][k]);
+      ctx->kp_ver[LSA_SET_RAW_PREVIOUS][k] = ctx->kp_ver[LSA_SET_RAW_CURRENT][k];
       ctx->kp_n[LSA_SET_RAW_PREVIOUS][k] = ctx->kp_n[LSA_SET_RAW_CURRENT][k];
       ctx->kp_n[LSA_SET_RAW_CURRENT][k] = 0;
     }
@@ -814,6 +815,7 @@ static int extract_frame(lsa_ctx* ctx, const lsa_extract_params_t* params, int c
   {
     counts[k] = hp[k];
     ctx->kp_n[LSA_SET_RAW_CURRENT][k] = base[k] + hp[k];
+    ctx->kp_ver[LSA_SET_RAW_CURRENT][k] = ++ctx->kp_clock;
   }
   if (!append && !base_to_lidar && time_offset == 0.)
   {
@@ -910,6 +912,7 @@ int lsa_set_keypoints(lsa_ctx* ctx, int set, int type, const lsa_point_t* pts, i
     LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));  // pts may be pageable and reused by the caller
   }
   ctx->kp_n[set][type] = k;
+  ctx->kp_ver[set][type] = ++ctx->kp_clock;
   ctx->kp_time_valid[set] = false;
   return LSA_OK;
 }
@@ -938,6 +941,7 @@ int lsa_transform_keypoints(lsa_ctx* ctx, int set, int type, const double T[16],
   if (!ctx || !T || set < 0 || set > 2 || type < 0 || type > 2) return ctx ? ctx->fail(LSA_E_ARG, "lsa_transform_keypoints: bad argument") : LSA_E_ARG;
   const int n = ctx->kp_n[set][type];
   if (time_offset != 0.) ctx->kp_time_valid[set] = false;
+  ctx->kp_ver[set][type] = ++ctx->kp_clock;
   if (n <= 0) return LSA_OK;
   Rigid R;
   row_major_to_rt(T, R.R, R.t);

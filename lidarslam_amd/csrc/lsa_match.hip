@@ -1240,16 +1240,15 @@ __global__ __launch_bounds__(256) void k_overlap_score(OverlapConst c, int nb, f
   if (threadIdx.x == 0) partials[blockIdx.x] = ((ws[0] + ws[1]) + ws[2]) + ws[3];
 }
 
-// builds the search grids of every target marked dirty, all in one sequence of launches
-int flush_grids(lsa_ctx* ctx)
+// builds the search grids of the listed targets, all in one sequence of launches on `st`
+static int build_grids(lsa_ctx* ctx, const int* tis, int count, hipStream_t st)
 {
   GridBatch gb;
   int nt = 0, max_m = 0, max_cells = 0;
   double bytes = 0;
-  for (int ti = 0; ti < 6; ++ti)
+  for (int i = 0; i < count; ++i)
   {
-    Target& t = ctx->target[ti];
-    if (!t.dirty) continue;
+    Target& t = ctx->target[tis[i]];
     t.dirty = false;
     if (t.m == 0) continue;
     gb.m[nt] = t.m;
@@ -1273,8 +1272,7 @@ int flush_grids(lsa_ctx* ctx)
   }
   if (nt == 0) return LSA_OK;
   gb.ntargets = nt;
-  hipStream_t st = ctx->stream;
-  ProfScope ps(ctx, "target_grid_build", bytes);
+  ProfScope ps(ctx, st == ctx->stream ? "target_grid_build" : "target_grid_build_ahead", bytes, st);
   const int pb = (max_m + 255) / 256;
   const int cb = (max_cells + 1 + 1023) / 1024;  // the cell passes return at once beyond a grid's own cell count
   hipLaunchKernelGGL(k_target_prep, dim3(pb, nt), dim3(256), 0, st, gb);
@@ -1286,6 +1284,15 @@ int flush_grids(lsa_ctx* ctx)
   hipLaunchKernelGGL(k_scan_add, dim3(cb, nt * kGridLevels), dim3(256), 0, st, gb);
   hipLaunchKernelGGL(k_grid_scatter, dim3(pb, nt), dim3(256), 0, st, gb);
   return LSA_OK;
+}
+
+// ... of every target marked dirty
+int flush_grids(lsa_ctx* ctx)
+{
+  int tis[6], n = 0;
+  for (int ti = 0; ti < 6; ++ti)
+    if (ctx->target[ti].dirty) tis[n++] = ti;
+  return n ? build_grids(ctx, tis, n, ctx->stream) : LSA_OK;
 }
 
 template <int KMAX>
@@ -1396,6 +1403,21 @@ int lsa_set_target_from_set(lsa_ctx* ctx, int slot, int type, int set)
   LSA_HIP(ctx, hipSetDevice(ctx->device));
   const int m = ctx->kp_n[set][type];
   const int ti = slot * 3 + type;
+  if (slot == LSA_TARGET_PREVIOUS && set == LSA_SET_RAW_PREVIOUS && ctx->spare_ready[type])
+  {
+    // built ahead, beside the previous frame's registration (lsa_prepare_previous_targets): taken over if it still
+    // describes this very set and was built with the cell size asked for now
+    Target& spare = ctx->target[6 + type];
+    ctx->spare_ready[type] = false;
+    if (m > 0 && spare.m == m && ctx->spare_ver[type] == ctx->kp_ver[set][type] && spare.cell_hint == ctx->target[ti].cell_hint)
+    {
+      std::swap(ctx->target[ti], spare);
+      ctx->target[ti].dirty = false;
+      ctx->spare_adopted++;
+      LSA_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_spare, 0));
+      return LSA_OK;
+    }
+  }
   int rc = ensure_target(ctx, ti, m);
   if (rc) return rc;
   Target& t = ctx->target[ti];
@@ -1405,6 +1427,48 @@ int lsa_set_target_from_set(lsa_ctx* ctx, int slot, int type, int set)
   t.dirty = true;
   return LSA_OK;
 }
+
+int lsa_prepare_previous_targets(lsa_ctx* ctx, unsigned type_mask)
+{
+  if (!ctx || (type_mask & ~7u)) return ctx ? ctx->fail(LSA_E_ARG, "lsa_prepare_previous_targets: bad argument") : LSA_E_ARG;
+  LSA_HIP(ctx, hipSetDevice(ctx->device));
+  int tis[3], n = 0;
+  for (int k = 0; k < 3; ++k)
+  {
+    ctx->spare_ready[k] = false;
+    const int m = ctx->kp_n[LSA_SET_RAW_CURRENT][k];
+    if (!((type_mask >> k) & 1u) || m <= 0) continue;
+    int rc = ensure_target(ctx, 6 + k, m);
+    if (rc) return rc;
+    Target& t = ctx->target[6 + k];
+    t.m = m;
+    t.cell_hint = ctx->target[LSA_TARGET_PREVIOUS * 3 + k].cell_hint;
+    tis[n++] = 6 + k;
+  }
+  if (n == 0) return LSA_OK;
+  // the keypoints are final once everything enqueued so far has run; the copies and the grid build follow on the
+  // look-ahead stream, beside whatever comes next on the context's stream
+  LSA_HIP(ctx, hipEventRecord(ctx->ev_kp_ready, ctx->stream));
+  LSA_HIP(ctx, hipStreamWaitEvent(ctx->prefetch_stream, ctx->ev_kp_ready, 0));
+  for (int i = 0; i < n; ++i)
+  {
+    const int k = tis[i] - 6;
+    LSA_HIP(ctx, hipMemcpyAsync(ctx->target[tis[i]].pts, ctx->kp[LSA_SET_RAW_CURRENT][k], (size_t)ctx->target[tis[i]].m * sizeof(lsa_point_t),
+                                hipMemcpyDeviceToDevice, ctx->prefetch_stream));
+  }
+  int rc = build_grids(ctx, tis, n, ctx->prefetch_stream);
+  if (rc) return rc;
+  LSA_HIP(ctx, hipEventRecord(ctx->ev_spare, ctx->prefetch_stream));
+  for (int i = 0; i < n; ++i)
+  {
+    const int k = tis[i] - 6;
+    ctx->spare_ver[k] = ctx->kp_ver[LSA_SET_RAW_CURRENT][k];
+    ctx->spare_ready[k] = true;
+  }
+  return LSA_OK;
+}
+
+int lsa_prepared_targets_adopted(const lsa_ctx* ctx) { return ctx ? ctx->spare_adopted : 0; }
 
 int lsa_set_knn_rounds(lsa_ctx* ctx, int type, int rounds)
 {

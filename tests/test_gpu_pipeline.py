@@ -509,8 +509,8 @@ def test_lookahead_extraction_changes_nothing_but_the_schedule(L):
     when a parameter changes between the look-ahead and the frame."""
     frames = [L.synth_frame(16, 1000, f) for f in range(12)]
 
-    def run(hints, change_at=None):
-        s = L.Slam(0, EgoMotion=3)
+    def run(hints, change_at=None, ahead=1):
+        s = L.Slam(0, EgoMotion=3, BuildTargetsAhead=ahead)
         for f, (pts, _) in enumerate(frames):
             s.store_frame(f, pts)
         poses, kps, used = [], [], []
@@ -524,10 +524,17 @@ def test_lookahead_extraction_changes_nothing_but_the_schedule(L):
             kps.append([s.keypoints(k, 2).tobytes() for k in (L.EDGE, L.PLANE)])
             used.append(s.get_param("TotalMatchedKeypoints"))
         hits = s.get_param("LookaheadAdopted")
+        built[ahead] = s.get_param("TargetsBuiltAheadAdopted")
         s.close()
         return np.array(poses), kps, used, hits
 
-    plain = run(lambda f: None)
+    built = {}
+    plain = run(lambda f: None, ahead=0)
+    # the ego-motion targets of the next frame built beside this frame's registration: two per frame from the second
+    # frame on, same poses
+    ahead_targets = run(lambda f: None, ahead=1)
+    assert built == {0: 0, 1: 2 * (len(frames) - 1)}
+    assert np.array_equal(plain[0], ahead_targets[0]) and plain[1] == ahead_targets[1] and plain[2] == ahead_targets[2]
     ahead = run(lambda f: f + 1 if f + 1 < len(frames) else None)
     wrong = run(lambda f: (f + 3) % len(frames))
     assert plain[3] == 0 and ahead[3] == len(frames) - 1 and wrong[3] == 0

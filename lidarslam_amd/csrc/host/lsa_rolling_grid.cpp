@@ -356,15 +356,37 @@ void RollingGrid::AddParallel(const lsa_point_t* points, std::size_t count, bool
       AddIn[pi] = this->To1d(vi);
     }
   });
-  // 2. the outer voxels, created in the order in which the points reach them (this thread alone)
+  // 2. the outer voxels, created in the order in which the points reach them (this thread alone), and how many
+  //    points each receives: the keypoints crowd around the sensor, so the outer voxels are dealt out by weight
+  std::unordered_map<int, int> load;  // outer voxel -> points, then -> owning thread
   {
     int lastOut = -1;
+    int* counter = nullptr;
     for (std::size_t pi = 0; pi < count; ++pi)
-      if (AddOut[pi] >= 0 && AddOut[pi] != lastOut)
+    {
+      const int idxOut = AddOut[pi];
+      if (idxOut < 0) continue;
+      if (idxOut != lastOut)
       {
-        (void)Voxels[AddOut[pi]];
-        lastOut = AddOut[pi];
+        (void)Voxels[idxOut];
+        counter = &load[idxOut];
+        lastOut = idxOut;
       }
+      ++*counter;
+    }
+    std::vector<std::pair<int, int>> byWeight;  // (points, outer voxel), heaviest first; ties by index: deterministic
+    byWeight.reserve(load.size());
+    for (const auto& kv : load) byWeight.emplace_back(kv.second, kv.first);
+    std::sort(byWeight.begin(), byWeight.end(), [](const std::pair<int, int>& a, const std::pair<int, int>& b) {
+      return a.first != b.first ? a.first > b.first : a.second < b.second;
+    });
+    std::vector<long> assigned(threads, 0);
+    for (const auto& w : byWeight)
+    {
+      const int t = static_cast<int>(std::min_element(assigned.begin(), assigned.end()) - assigned.begin());
+      assigned[t] += w.first;
+      load[w.second] = t;
+    }
   }
   // 3. the leaf voxels: every outer voxel belongs to one thread, which takes its points in their order; the outer
   //    map is only read from here on
@@ -372,16 +394,19 @@ void RollingGrid::AddParallel(const lsa_point_t* points, std::size_t count, bool
   AddCrew->Run([&](int tid) {
     AddTally mine;
     int lastOut = -1;
+    bool mineNow = false;
     SamplingVG* outer = nullptr;
     for (std::size_t pi = 0; pi < count; ++pi)
     {
       const int idxOut = AddOut[pi];
-      if (idxOut < 0 || static_cast<int>((static_cast<unsigned>(idxOut) * 2654435761u) >> 20) % threads != tid) continue;
+      if (idxOut < 0) continue;
       if (idxOut != lastOut)
       {
-        outer = &Voxels.find(idxOut)->second;
         lastOut = idxOut;
+        mineNow = load.find(idxOut)->second == tid;
+        if (mineNow) outer = &Voxels.find(idxOut)->second;
       }
+      if (!mineNow) continue;
       // the leaf coordinates and the outer voxel's centre again, for CENTER_POINT (cheap next to the hash lookup)
       int vo[3], vi[3];
       this->To3d(idxOut, vo);
@@ -562,7 +587,32 @@ void RollingGrid::BuildSubMap(const float minPoint[3], const float maxPoint[3], 
     return lo[0] <= v[0] && v[0] <= hi[0] && lo[1] <= v[1] && v[1] <= hi[1] && lo[2] <= v[2] && v[2] <= hi[2];
   };
   this->BeginSubMap(NbPoints);
-  if (minNbPoints < 0 || MinFramesPerVoxel <= 1)
+  if ((minNbPoints < 0 || MinFramesPerVoxel <= 1) && AddCrew && NbPoints >= 8192)
+  {
+    // every outer voxel contributes all its points, as one run in the iteration order of the outer map: the runs'
+    // places are known from the sizes alone, and the helper threads copy them side by side
+    std::vector<const SamplingVG*> run;
+    std::vector<std::size_t> at;
+    std::size_t total = 0;
+    for (const auto& out : Voxels)
+      if (intersects(out.first))
+      {
+        run.push_back(&out.second);
+        at.push_back(total);
+        total += out.second.size();
+      }
+    std::atomic<std::size_t> next{0};
+    lsa_point_t* dst = SubMapPtr;
+    AddCrew->Run([&](int) {
+      for (std::size_t i = next.fetch_add(1); i < run.size(); i = next.fetch_add(1))
+      {
+        lsa_point_t* p = dst + at[i];
+        for (const auto& in : *run[i]) *p++ = in.second.point;
+      }
+    });
+    SubMapCount = total;
+  }
+  else if (minNbPoints < 0 || MinFramesPerVoxel <= 1)
   {
     for (const auto& out : Voxels)
       if (intersects(out.first))

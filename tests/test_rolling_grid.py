@@ -170,6 +170,11 @@ def test_add_on_several_threads_builds_the_same_map(sampling):
         mn = np.array([q["x"].min(), q["y"].min(), q["z"].min()], np.float32)
         mx = np.array([q["x"].max(), q["y"].max(), q["z"].max()], np.float32)
         assert same_submap(g, o, mn, mx, min_nb=150) > 0
+    # the sub-map extraction shares the helper threads once the map is big (all points of the voxels the box touches)
+    assert g.size() >= 8192 or sampling == 4
+    g.set("MinFramesPerVoxel", 0), o.set("MinFramesPerVoxel", 0)
+    assert same_submap(g, o, mn, mx, min_nb=150) > 0
+    assert same_submap(g, o, np.full(3, -1e6, np.float32), np.full(3, 1e6, np.float32), 10) == g.size()
     g.set("AddThreads", 1)
     pts = cloud(rng, 6000, np.zeros(3), spread=16.0)
     g.add(pts), o.add(pts)

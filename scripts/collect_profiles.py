@@ -5,10 +5,11 @@ import glob, json, os, shutil, subprocess, sys
 rnd = sys.argv[1] if len(sys.argv) > 1 else "r01"
 src, dst = os.path.join("gpurun_out", rnd), "profiles"
 os.makedirs(dst, exist_ok=True)
-ks = glob.glob(os.path.join(src, "trace", "*", "*kernel_stats.csv"))
+newest = lambda pattern: sorted(glob.glob(pattern), key=os.path.getmtime, reverse=True)  # gpurun_out keeps earlier runs too
+ks = newest(os.path.join(src, "trace", "*", "*kernel_stats.csv"))
 if ks: shutil.copy(ks[0], os.path.join(dst, f"{rnd}_vls128_kernel_stats.csv"))
-f = glob.glob(os.path.join(src, "pmc_fetch", "*", "*counter_collection.csv"))
-w = glob.glob(os.path.join(src, "pmc_write", "*", "*counter_collection.csv"))
+f = newest(os.path.join(src, "pmc_fetch", "*", "*counter_collection.csv"))
+w = newest(os.path.join(src, "pmc_write", "*", "*counter_collection.csv"))
 if f and w:
     out = subprocess.run([sys.executable, "scripts/pmc_summary.py", f[0], w[0], os.path.join(dst, f"{rnd}_vls128_pmc_traffic.json")],
                          capture_output=True, text=True, check=True).stdout

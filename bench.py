@@ -165,7 +165,7 @@ def main():
     if not args.no_profile and args.warmup > 0:
         warm_kernels = ctx.profile_stats()
         if warm_kernels:
-            dominant = max(warm_kernels, key=lambda k: k["total_ms"])["name"]
+            dominant = max(on_critical_path(warm_kernels), key=lambda k: k["total_ms"])["name"]
 
     stats_acc = np.zeros(16)
     if not args.no_profile:
@@ -246,7 +246,7 @@ def main():
         out["stage_ms_per_frame"]["maps_async"] = 1e3 * stats_acc[15] / n
         table, table_frames = (kernels, n) if (args.profile_all or not warm_kernels) else (warm_kernels, max(args.warmup, 1))
         if kernels:
-            dom = max(kernels, key=lambda k: k["total_ms"])
+            dom = max(on_critical_path(kernels), key=lambda k: k["total_ms"])
             ach = dom["bytes"] / (dom["total_ms"] * 1e-3) / 1e9 if dom["total_ms"] > 0 else 0.0
             out["roofline"] = {
                 "bound": "hbm",
@@ -278,6 +278,14 @@ def main():
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def on_critical_path(scopes):
+    """The scopes that run on the context's own stream.  "*_ahead" scopes are enqueued on the look-ahead stream beside
+    the registration: their events also bracket the time they wait for that stream, and they are off the frame's
+    critical path by construction -- they are listed in the table but never named the dominant kernel."""
+    kept = [k for k in scopes if not k["name"].endswith("_ahead")]
+    return kept or scopes
 
 
 def batch_replay(args, device):

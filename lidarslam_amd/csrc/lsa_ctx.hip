@@ -82,7 +82,7 @@ int ensure_target(lsa_ctx* ctx, int ti, int m)
     LSA_HIP(ctx, hipMemcpy(t.bbox_bits, init, sizeof(init), hipMemcpyHostToDevice));
   }
   if (m <= t.cap) return LSA_OK;
-  int cap = std::max(m + m / 4, 4096);
+  int cap = std::max(2 * m, 16384);  // doubling: a growing sub-map re-allocates (and synchronises) a handful of times
   LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
   if (ctx->prefetch_stream) LSA_HIP(ctx, hipStreamSynchronize(ctx->prefetch_stream));  // targets built ahead live there
   LSA_HIP(ctx, dev_alloc(&t.pts, (size_t)cap));

@@ -1371,7 +1371,9 @@ lsa_point_t* lsa_target_staging(lsa_ctx* ctx, int slot, int type, int capacity)
     if (ctx->tstage[ti]) (void)hipHostFree(ctx->tstage[ti]);  // waits for a copy still reading it
     ctx->tstage[ti] = nullptr;
     ctx->tstage_cap[ti] = 0;
-    const int cap = std::max(capacity + capacity / 4, 4096);
+    // the map grows keyframe after keyframe at the start of a sequence: doubling keeps the (slow) pinned
+    // re-allocations to a handful
+    const int cap = std::max(2 * capacity, 65536);
     if (hipHostMalloc((void**)&ctx->tstage[ti], (size_t)cap * sizeof(lsa_point_t), hipHostMallocDefault) != hipSuccess) return nullptr;
     ctx->tstage_cap[ti] = cap;
   }

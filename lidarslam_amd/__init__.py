@@ -124,6 +124,10 @@ def lib():
     L.lsa_reset_working_keypoints.argtypes = [vp]
     L.lsa_undistort.argtypes = [vp, vp, vp, f64, f64]
     L.lsa_working_time_range.argtypes = [vp, vp, vp]
+    L.lsa_keypoint_time_range.argtypes = [vp, i32, vp, vp]
+    L.lsa_keypoint_bboxes_begin.argtypes = [vp, i32, vp]
+    L.lsa_keypoint_bboxes_begin_interp.argtypes = [vp, i32, vp, vp, f64, f64]
+    L.lsa_keypoint_bboxes_end.argtypes = [vp, vp, vp]
     L.lsa_working_bbox.argtypes = [vp, i32, vp, vp, vp]
     L.lsa_download_transformed.argtypes = [vp, i32, i32, vp, vp, i32]
     L.lsa_transform_frame.argtypes = [vp, i32, vp, vp, f64, f64, vp, i32]
@@ -378,6 +382,31 @@ class Context:
         a, b = C.c_double(), C.c_double()
         self._check(self.L.lsa_working_time_range(self.h, C.byref(a), C.byref(b)), "lsa_working_time_range")
         return a.value, b.value
+
+    def keypoint_time_range(self, kset):
+        a, b = C.c_double(), C.c_double()
+        self._check(self.L.lsa_keypoint_time_range(self.h, kset, C.byref(a), C.byref(b)), "lsa_keypoint_time_range")
+        return a.value, b.value
+
+    def keypoint_bboxes(self, kset, H0, H1=None, t0=0.0, t1=0.0):
+        """bounding boxes of the three keypoint types of a set under a pose, or under the pose interpolated at
+        every point's time between H0 (t0) and H1 (t1); returns (mn[3][3], mx[3][3])"""
+        if H1 is None:
+            self._check(self.L.lsa_keypoint_bboxes_begin(self.h, kset, ptr(pose16(H0))), "lsa_keypoint_bboxes_begin")
+        else:
+            self._check(self.L.lsa_keypoint_bboxes_begin_interp(self.h, kset, ptr(pose16(H0)), ptr(pose16(H1)), C.c_double(t0), C.c_double(t1)),
+                        "lsa_keypoint_bboxes_begin_interp")
+        mn, mx = np.zeros(9, np.float32), np.zeros(9, np.float32)
+        self._check(self.L.lsa_keypoint_bboxes_end(self.h, ptr(mn), ptr(mx)), "lsa_keypoint_bboxes_end")
+        return mn.reshape(3, 3), mx.reshape(3, 3)
+
+    def match_serial(self, ktype):
+        return self.L.lsa_match_serial(self.h, ktype)
+
+    def match_histogram(self, ktype, serial):
+        h = np.zeros(8, np.int32)
+        self._check(self.L.lsa_match_histogram(self.h, ktype, serial, ptr(h)), "lsa_match_histogram")
+        return h
 
     def working_bbox(self, ktype, pose):
         mn, mx = np.zeros(3, np.float32), np.zeros(3, np.float32)

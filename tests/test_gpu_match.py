@@ -232,3 +232,48 @@ def test_concurrent_types_equal_sequential_calls(gpu_ctx, O, L, kps, model):
     acc = gpu_ctx.accumulate(7, np.zeros(6))
     assert acc[3] == ref_acc[3] == sum(int(seq[k][0][0]) for k in seq)
     assert acc[0] == ref_acc[0] and np.array_equal(acc[2], ref_acc[2])
+
+
+def test_histograms_of_earlier_matches_stay_readable(gpu_ctx, O, L, kps):
+    """lsa_match_serial / lsa_match_histogram (MatchingResults::NbMatches without a read-back on the critical path):
+    the histogram of a match is still there after later matches of the same type, up to 16 of them"""
+    prev, cur = kps[16]
+    pose = perturbed()
+    for k in (L.EDGE, L.PLANE):
+        gpu_ctx.set_keypoints(L.SET_WORKING, k, cur[k])
+        gpu_ctx.set_target(k, prev[k], cell=1.0)
+    seen = []
+    for i in range(20):
+        mp = L.MatchParams.localization(saturation_distance=2.0 - 0.05 * i)
+        mp.max_neighbors_distance = 5.0 - 0.2 * i  # a different histogram every time
+        hists = gpu_ctx.match_types(3, L.SET_WORKING, mp, pose)
+        seen.append((gpu_ctx.match_serial(L.EDGE), gpu_ctx.match_serial(L.PLANE), hists.copy()))
+    assert seen[-1][0] == seen[0][0] + 19
+    for se, sp, h in seen[-16:]:
+        assert gpu_ctx.match_histogram(L.EDGE, se).tolist() == h[L.EDGE].tolist()
+        assert gpu_ctx.match_histogram(L.PLANE, sp).tolist() == h[L.PLANE].tolist()
+    assert len({tuple(h[L.PLANE].tolist()) for _, _, h in seen}) > 5
+    with pytest.raises(L.LsaError):
+        gpu_ctx.match_histogram(L.EDGE, seen[0][0])  # 19 matches ago: gone
+    with pytest.raises(L.LsaError):
+        gpu_ctx.match_histogram(L.EDGE, seen[-1][0] + 1)  # not enqueued yet
+
+
+def test_interpolated_bounding_boxes_are_those_of_the_undistorted_keypoints(gpu_ctx, O, L, kps):
+    """lsa_keypoint_bboxes_begin_interp: the box of the keypoints under the pose interpolated at every point's own
+    time = the box of the same keypoints after lsa_undistort with that motion (what the sub-map prediction relies on)"""
+    _, cur = kps[16]
+    for k in (L.EDGE, L.PLANE, L.BLOB):
+        gpu_ctx.set_keypoints(L.SET_RAW_CURRENT, k, cur[k][:5000])
+    t0, t1 = gpu_ctx.keypoint_time_range(L.SET_RAW_CURRENT)
+    alltimes = np.concatenate([cur[k][:5000]["time"] for k in range(3)])
+    assert (t0, t1) == (alltimes.min(), alltimes.max()) and t1 - t0 > 0.05
+    H0, H1 = perturbed(0.4, 0.05), perturbed(-0.3, -0.04)
+    mn, mx = gpu_ctx.keypoint_bboxes(L.SET_RAW_CURRENT, H0, H1, t0, t1)
+    for k in (L.EDGE, L.PLANE, L.BLOB):
+        und = O.undistort(cur[k][:5000], H0, H1, t0, t1)
+        for d, f in enumerate("xyz"):
+            assert abs(mn[k, d] - und[f].min()) < 1e-5 and abs(mx[k, d] - und[f].max()) < 1e-5
+    # the rigid form, for comparison: the motion between H0 and H1 moves the boxes
+    rn, rx = gpu_ctx.keypoint_bboxes(L.SET_RAW_CURRENT, H0)
+    assert np.abs(rn - mn).max() > 0.05

@@ -29,7 +29,8 @@ constexpr int kGridLevels = 3;            // search grid resolutions: cell, 4 x 
 constexpr int kCellCap = 1 << 22;         // max cells of the finest kNN search grid
 __host__ __device__ constexpr int grid_level_cells(int level) { return level == 0 ? kCellCap : level == 1 ? (kCellCap >> 6) + 64 : (kCellCap >> 12) + 64; }
 constexpr int kKnnMax = 16;               // neighbours per query the kNN buffers hold
-constexpr int kAccumBlocks = 64;          // grid of the normal-equation kernel (grid-stride); the host folds the blocks' partial sums
+constexpr int kAccumBlocks = 96;          // grid of the normal-equation kernel (grid-stride); the host folds the blocks' partial sums
+constexpr int kAccumBlocksMax = 256;      // what the buffers hold (the grid size can be tuned with LSA_ACCUM_BLOCKS)
 constexpr int kMailboxStride = 40;        // doubles per block in the mailbox: ten 32-byte pieces of 3 partial sums + the sequence tag
 constexpr int kHistRing = 32;
 constexpr int kAccumVals = 29;            // cost, g[6], H upper[21], nvalid
@@ -171,7 +172,8 @@ struct lsa_ctx
   hipEvent_t ev_spare = nullptr, ev_kp_ready = nullptr;
   lsa::MatchBuf match[3];
 
-  double* partials = nullptr;  // [kAccumBlocks][kAccumVals]
+  int accum_blocks = lsa::kAccumBlocks;
+  double* partials = nullptr;  // [kAccumBlocksMax][kAccumVals]
   double* reduce_out = nullptr;
   double* host_pinned = nullptr;  // >= 64 doubles, pinned
   double* mailbox = nullptr;      // coherent host memory k_accumulate's blocks write directly: [kAccumBlocks][kMailboxStride]

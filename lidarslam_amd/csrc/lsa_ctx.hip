@@ -2,6 +2,7 @@
 // host-side azimuthal resolution estimate, per-kernel HIP-event profiling.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include "lsa_ctx.h"
 
 using namespace lsa;
@@ -261,15 +262,16 @@ int lsa_ctx_create(int device_id, lsa_ctx** out)
   ok &= hipEventCreateWithFlags(&ctx->ev_kp_ready, hipEventDisableTiming) == hipSuccess;
   if (ok) { ctx->kp_count_dev = ctx->extract_out; ctx->ring_meta = ctx->extract_out + 4; }
   ok &= hipMalloc((void**)&ctx->ring_counts, kMaxRings * 3 * sizeof(int)) == hipSuccess;
-  ok &= hipMalloc((void**)&ctx->partials, (size_t)kAccumBlocks * kAccumVals * sizeof(double)) == hipSuccess;
+  ok &= hipMalloc((void**)&ctx->partials, (size_t)kAccumBlocksMax * kAccumVals * sizeof(double)) == hipSuccess;
   ok &= hipMalloc((void**)&ctx->reduce_out, 64 * sizeof(double)) == hipSuccess;
   if (ok) ok &= hipMemset(ctx->reduce_out, 0, 64 * sizeof(double)) == hipSuccess;  // [32] holds the arrival ticket of k_accumulate
   ok &= hipMalloc((void**)&ctx->hist_dev, 3 * kHistRing * 16 * sizeof(int)) == hipSuccess;
   if (ok) ok &= hipMemset(ctx->hist_dev, 0, 3 * kHistRing * 16 * sizeof(int)) == hipSuccess;
   ok &= hipMalloc((void**)&ctx->range_bits, 32 * sizeof(unsigned long long)) == hipSuccess;
   ok &= hipHostMalloc((void**)&ctx->host_pinned, 512 * sizeof(double), hipHostMallocDefault) == hipSuccess;
-  if (hipHostMalloc((void**)&ctx->mailbox, (size_t)kAccumBlocks * kMailboxStride * sizeof(double), hipHostMallocCoherent | hipHostMallocMapped) == hipSuccess)
-    std::memset(ctx->mailbox, 0, (size_t)kAccumBlocks * kMailboxStride * sizeof(double));
+  if (hipHostMalloc((void**)&ctx->mailbox, (size_t)kAccumBlocksMax * kMailboxStride * sizeof(double), hipHostMallocCoherent | hipHostMallocMapped) == hipSuccess)
+    std::memset(ctx->mailbox, 0, (size_t)kAccumBlocksMax * kMailboxStride * sizeof(double));
+  if (const char* e = std::getenv("LSA_ACCUM_BLOCKS")) ctx->accum_blocks = std::min(std::max(std::atoi(e), 1), kAccumBlocksMax);
   else
     ctx->mailbox = nullptr;  // optional: lsa_accumulate falls back to a copy + synchronise
   if (!ok) { lsa_ctx_destroy(ctx); return LSA_E_HIP; }

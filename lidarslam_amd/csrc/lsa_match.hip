@@ -1831,7 +1831,7 @@ int lsa_accumulate(lsa_ctx* ctx, unsigned type_mask, const double w[6], int want
   hipStream_t st = ctx->stream;
   {
     ProfScope ps(ctx, want_jacobian ? "accumulate_jac" : "accumulate_cost", (double)total * (want_jacobian ? 129 : 129));
-    hipLaunchKernelGGL(k_accumulate, dim3(kAccumBlocks), dim3(256), 0, st, c, ctx->partials, ctx->mailbox, ++ctx->mailbox_seq);
+    hipLaunchKernelGGL(k_accumulate, dim3(ctx->accum_blocks), dim3(256), 0, st, c, ctx->partials, ctx->mailbox, ++ctx->mailbox_seq);
   }
   double* hp = ctx->host_pinned + 64;
   bool got = false;
@@ -1842,7 +1842,7 @@ int lsa_accumulate(lsa_ctx* ctx, unsigned type_mask, const double w[6], int want
     unsigned spins = 0;
     bool timeout = false;
     const unsigned long long want = ctx->mailbox_seq;
-    for (int b = 0; b < kAccumBlocks && !timeout; ++b)
+    for (int b = 0; b < ctx->accum_blocks && !timeout; ++b)
       for (int c = 0; c < kMailboxStride / 4 && !timeout; ++c)
       {
         volatile unsigned long long* tag = reinterpret_cast<volatile unsigned long long*>(ctx->mailbox + (size_t)b * kMailboxStride + c * 4 + 3);
@@ -1857,7 +1857,7 @@ int lsa_accumulate(lsa_ctx* ctx, unsigned type_mask, const double w[6], int want
     if (!timeout)
     {
       for (int v = 0; v < kAccumVals; ++v) hp[v] = 0.;
-      for (int b = 0; b < kAccumBlocks; ++b)
+      for (int b = 0; b < ctx->accum_blocks; ++b)
       {
         const volatile double* row = ctx->mailbox + (size_t)b * kMailboxStride;
         for (int v = 0; v < kAccumVals; ++v) hp[v] += row[(v / 3) * 4 + (v % 3)];
@@ -1867,7 +1867,7 @@ int lsa_accumulate(lsa_ctx* ctx, unsigned type_mask, const double w[6], int want
   }
   if (!got)
   {
-    hipLaunchKernelGGL(k_accumulate_final, dim3(1), dim3(64), 0, st, ctx->partials, kAccumBlocks, ctx->reduce_out);
+    hipLaunchKernelGGL(k_accumulate_final, dim3(1), dim3(64), 0, st, ctx->partials, ctx->accum_blocks, ctx->reduce_out);
     LSA_HIP(ctx, hipMemcpyAsync(hp, ctx->reduce_out, kAccumVals * sizeof(double), hipMemcpyDeviceToHost, st));
     LSA_HIP(ctx, hipStreamSynchronize(st));
   }

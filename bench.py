@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--sequences-per-gpu", type=int, default=1, help="independent sequences replayed side by side on every GPU (the headline is 1: BASELINE.json shards 1 per GPU)")
     ap.add_argument("--batch-sequences", type=int, default=4, help="N=1 only: extra leg with this many sequences side by side on the GPU, reported as batch_replay (0 disables)")
     ap.add_argument("--no-lookahead", action="store_true", help="do not extract the next stored frame's keypoints beside the current frame's registration")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="nccl (= RCCL over xGMI, the real run); gloo rehearses the multi-rank path on a box with fewer GPUs than ranks (ranks then share devices)")
     ap.add_argument("--profile-all", action="store_true", help="time every scope in the timed region too (costs ~10 %% of the frame rate)")
     return ap.parse_args()
 
@@ -65,11 +66,13 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the product path has no CPU fallback")
+    if args.backend == "gloo":
+        local_rank %= torch.cuda.device_count()  # rehearsal: more ranks than GPUs
     torch.cuda.set_device(local_rank)
     distributed = world > 1
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+        dist.init_process_group(backend=args.backend, rank=rank, world_size=world)
 
     # ---- inputs: one independent sequence per rank, generated on the host, made resident in HBM
     total = args.warmup + args.steps
@@ -132,7 +135,7 @@ def main():
     followers = [threading.Thread(target=follow, args=(s + 1, o, st), daemon=True) for s, (o, st) in enumerate(others)]
 
     # RCCL pose broadcast of the north star: every rank ends up with every sequence's pose table
-    exchange = PoseExchange(world, device="cuda", per_rank=per_gpu)
+    exchange = PoseExchange(world, device="cuda" if args.backend == "nccl" else "cpu", per_rank=per_gpu)
 
     def step(f):
         if args.host_frames:
@@ -200,7 +203,7 @@ def main():
     for o, _ in others:
         o.close()
     if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -226,7 +229,7 @@ def main():
                 + " synthetic spinning scan, street canyon, 5 m/s, EgoMotion=MOTION_EXTRAPOLATION_AND_REGISTRATION, Undistortion=REFINED, library defaults",
                 "points_per_frame": npts // (total * per_gpu),
                 "sequences": world * per_gpu,
-                "parallelism": f"{per_gpu} sequence{'s' if per_gpu > 1 else ''} per GPU x {world}, RCCL all-gather of poses",
+                "parallelism": f"{per_gpu} sequence{'s' if per_gpu > 1 else ''} per GPU x {world}, {'RCCL' if args.backend == 'nccl' else 'gloo (rehearsal, ranks share devices)'} all-gather of poses",
                 "frames_resident_in_hbm": not args.host_frames,
                 "lookahead_extraction": lookahead,
             },

@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--sequences-per-gpu", type=int, default=1, help="independent sequences replayed side by side on every GPU (the headline is 1: BASELINE.json shards 1 per GPU)")
     ap.add_argument("--batch-sequences", type=int, default=4, help="N=1 only: extra leg with this many sequences side by side on the GPU, reported as batch_replay (0 disables)")
     ap.add_argument("--no-lookahead", action="store_true", help="do not extract the next stored frame's keypoints beside the current frame's registration")
+    ap.add_argument("--no-numa-bind", action="store_true", help="leave the host threads wherever the scheduler puts them (default: on the GPU's NUMA node)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="nccl (= RCCL over xGMI, the real run); gloo rehearses the multi-rank path on a box with fewer GPUs than ranks (ranks then share devices)")
     ap.add_argument("--profile-all", action="store_true", help="time every scope in the timed region too (costs ~10 %% of the frame rate)")
     return ap.parse_args()
@@ -69,6 +70,7 @@ def main():
     if args.backend == "gloo":
         local_rank %= torch.cuda.device_count()  # rehearsal: more ranks than GPUs
     torch.cuda.set_device(local_rank)
+    numa_node = None if args.no_numa_bind else L.bind_host_to_device(local_rank)  # before any worker thread exists
     distributed = world > 1
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -232,6 +234,7 @@ def main():
                 "parallelism": f"{per_gpu} sequence{'s' if per_gpu > 1 else ''} per GPU x {world}, {'RCCL' if args.backend == 'nccl' else 'gloo (rehearsal, ranks share devices)'} all-gather of poses",
                 "frames_resident_in_hbm": not args.host_frames,
                 "lookahead_extraction": lookahead,
+                "host_threads_on_numa_node": numa_node if numa_node is not None and numa_node >= 0 else None,
             },
         }
         n = args.steps

@@ -105,6 +105,12 @@ typedef struct lsa_ctx lsa_ctx;
 
 int lsa_device_count(void);
 int lsa_ctx_create(int device_id, lsa_ctx** out);
+/* Restricts the calling thread (and the threads it creates afterwards: call it before lsa_ctx_create /
+ * lsa_slam_create) to the CPUs of the NUMA node the device is attached to.  A frame is tens of short host <-> device
+ * round trips (mailbox polls, pinned staging buffers); from the other socket of a two-socket host they take about
+ * twice as long.  Returns the node (>= 0), LSA_E_STATE when the host has no NUMA information or none of the node's
+ * CPUs may be used, LSA_E_NO_DEVICE for a bad device.  Optional: nothing else depends on it. */
+int lsa_bind_host_to_device(int device_id);
 void lsa_ctx_destroy(lsa_ctx* ctx);
 const char* lsa_last_error(const lsa_ctx* ctx);
 /* Blocks until everything queued on the context's stream has finished. */
@@ -215,6 +221,14 @@ int lsa_set_target(lsa_ctx* ctx, int slot, int type, const lsa_point_t* pts, int
  * points.  The buffer must stay untouched until the next match of that target has been waited for. */
 lsa_point_t* lsa_target_staging(lsa_ctx* ctx, int slot, int type, int capacity);
 int lsa_set_target_staged(lsa_ctx* ctx, int slot, int type, int m);
+/* Ahead of its use: the staging buffer of (LSA_TARGET_MAP, type) holds m points that will probably become the target
+ * (a sub-map extracted for the predicted pose).  They are uploaded and their search grid is built on the look-ahead
+ * stream into a spare target; lsa_set_target_staged with the same m and cell size then only swaps it in.  Before the
+ * staging buffer is rewritten instead (the prediction did not hold), lsa_drop_target_ahead waits for the copy out of
+ * it.  lsa_staged_targets_adopted counts the take-overs. */
+int lsa_stage_target_ahead(lsa_ctx* ctx, int slot, int type, int m);
+int lsa_drop_target_ahead(lsa_ctx* ctx, int slot, int type);
+int lsa_staged_targets_adopted(const lsa_ctx* ctx);
 int lsa_set_target_from_set(lsa_ctx* ctx, int slot, int type, int set);
 /* Builds ahead of time the targets the NEXT frame's ego-motion will search: the current raw keypoints of the types
  * in type_mask (which the next lsa_extract_keypoints turns into the previous ones) are copied and their search

@@ -51,10 +51,10 @@ DEBUG_NAMES = [
 
 # every symbol include/lidarslam_amd.h declares (tests/test_abi.py checks the .so exports them all)
 ABI_SYMBOLS = [
-    "lsa_device_count", "lsa_ctx_create", "lsa_ctx_destroy", "lsa_last_error", "lsa_sync", "lsa_upload_frame", "lsa_upload_wire_frame",
+    "lsa_device_count", "lsa_bind_host_to_device", "lsa_ctx_create", "lsa_ctx_destroy", "lsa_last_error", "lsa_sync", "lsa_upload_frame", "lsa_upload_wire_frame",
     "lsa_frame_store_put", "lsa_frame_store_use", "lsa_frame_size", "lsa_get_azimuthal_resolution",
     "lsa_set_azimuthal_resolution", "lsa_extract_keypoints", "lsa_extract_keypoints_more", "lsa_extract_prefetch", "lsa_extract_prefetch_adopted", "lsa_transform_frame_at", "lsa_set_keypoint_types", "lsa_download_keypoints", "lsa_keypoint_count",
-    "lsa_download_debug", "lsa_nb_laser_rings", "lsa_transform_keypoints", "lsa_set_target", "lsa_set_target_from_set", "lsa_prepare_previous_targets", "lsa_prepared_targets_adopted", "lsa_target_staging", "lsa_set_target_staged",
+    "lsa_download_debug", "lsa_nb_laser_rings", "lsa_transform_keypoints", "lsa_set_target", "lsa_set_target_from_set", "lsa_prepare_previous_targets", "lsa_prepared_targets_adopted", "lsa_target_staging", "lsa_set_target_staged", "lsa_stage_target_ahead", "lsa_drop_target_ahead", "lsa_staged_targets_adopted",
     "lsa_target_size", "lsa_download_target", "lsa_set_target_cell_size", "lsa_set_knn_lanes", "lsa_set_knn_rounds", "lsa_match_slow_queries", "lsa_match_exhaustive_queries", "lsa_set_keypoints", "lsa_match", "lsa_match_types",
     "lsa_download_match", "lsa_overlap", "lsa_accumulate", "lsa_solve", "lsa_registration_error", "lsa_selftest_math", "lsa_reset_working_keypoints", "lsa_undistort", "lsa_working_time_range",
     "lsa_working_bbox", "lsa_working_bboxes", "lsa_keypoint_bboxes_begin", "lsa_keypoint_bboxes_begin_interp", "lsa_keypoint_time_range", "lsa_keypoint_bboxes_end", "lsa_download_transformed", "lsa_stage_transformed", "lsa_staged_transformed", "lsa_transform_frame", "lsa_profile_enable", "lsa_profile_select", "lsa_profile_reset",
@@ -198,6 +198,12 @@ def _profile(L, h):
         {"name": buf[i].name.decode(), "launches": buf[i].launches, "total_ms": buf[i].total_ms, "bytes": buf[i].bytes}
         for i in range(max(n, 0))
     ]
+
+
+def bind_host_to_device(device=0):
+    """lsa_bind_host_to_device: keep this thread (and the ones created after) on the GPU's NUMA node; returns the
+    node, or a negative code when there is nothing to bind to"""
+    return lib().lsa_bind_host_to_device(int(device))
 
 
 class Context:

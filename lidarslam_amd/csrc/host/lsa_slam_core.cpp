@@ -144,6 +144,7 @@ void SlamCore::Reset(bool resetLog)
       for (int k = 0; k < 3; ++k) lsa_set_keypoints(Ctx, s, k, nullptr, 0);
   for (int k = 0; k < 3; ++k) { EgoDebug[k] = MatchDebug(); LocDebug[k] = MatchDebug(); KeypointCounts[k] = 0; SpecBuilt[k] = false; }
   SpecPending = false;
+  for (int k = 0; k < 3; ++k) { SpecDone[k].store(false); SpecStaged[k] = false; }
   CurrentFrames.clear();
   for (int k = 0; k < 3; ++k) EgoMatchSerial[k] = LocMatchSerial[k] = 0;
   if (resetLog)
@@ -537,6 +538,8 @@ int SlamCore::ComputeEgoMotion()
     // arrives with the optimizer's first evaluation
     LSA_TRY(lsa_match_types(Ctx, LSA_TARGET_PREVIOUS, (1u << LSA_EDGE) | (1u << LSA_PLANE), LSA_SET_RAW_CURRENT, &mp, Trelative.m, nullptr));
     for (int k : {LSA_EDGE, LSA_PLANE}) EgoMatchSerial[k] = lsa_match_serial(Ctx, k);
+    // while the device is busy with this iteration: sub-maps the workers have finished meanwhile go to the device
+    if (!SpecPending) LSA_TRY(StageSpeculativeSubMaps());
     Stats.ego_icp += ticp.Stop();
     Stats.ego_iters++;
 
@@ -623,6 +626,8 @@ int SlamCore::Localization()
         if (map->SubMapBuiltFor(mn + 3 * k, mx + 3 * k, minPts)) { Stats.submap_spec_hits++; SubMapSpecHitsTotal++; rebuild[k] = true; continue; }
         rebuild[k] = true;
       }
+      // the staging buffer is about to be rewritten: a copy out of it started ahead of time has to be over
+      LSA_TRY(lsa_drop_target_ahead(Ctx, LSA_TARGET_MAP, k));
       if (MapUpdate == MappingMode::NONE)
         MapWorker[k].Submit([map] { map->BuildSubMap(); });
       else
@@ -756,16 +761,36 @@ int SlamCore::FinishSubMapSpeculation()
     const double now = CurrentTime;
     const int minPts = KeypointCounts[k] / 2;
     bool* built = &SpecBuilt[k];
+    std::atomic<bool>* done = &SpecDone[k];
+    SpecDone[k].store(false);
+    SpecStaged[k] = false;
     const float* lo3 = mn + 3 * k;
     const float* hi3 = mx + 3 * k;
     // queued behind the previous keyframe's insertion on the same worker: it sees the final map
-    MapWorker[k].Submit([map, clear, now, minPts, built, mn0 = lo3[0], mn1 = lo3[1], mn2 = lo3[2], mx0 = hi3[0], mx1 = hi3[1], mx2 = hi3[2]] {
+    MapWorker[k].Submit([map, clear, now, minPts, built, done, mn0 = lo3[0], mn1 = lo3[1], mn2 = lo3[2], mx0 = hi3[0], mx1 = hi3[1], mx2 = hi3[2]] {
       if (map->IsSubMapValid()) return;  // the map did not change: Slam.cxx:1013 keeps the kd-tree
       if (clear) map->ClearOldPoints(now);
       const float lo[3] = {mn0, mn1, mn2}, hi[3] = {mx0, mx1, mx2};
       map->BuildSubMap(lo, hi, minPts);
       *built = true;
+      done->store(true, std::memory_order_release);
     });
+  }
+  return LSA_OK;
+}
+
+// Called between two steps of the ego-motion ICP: a sub-map the workers have finished for the predicted pose goes to
+// the device right away -- upload and search grid on the look-ahead stream -- so that Localization(), if the
+// prediction holds, only swaps it in.
+int SlamCore::StageSpeculativeSubMaps()
+{
+  if (!BuildTargetsAhead) return LSA_OK;
+  for (int k = 0; k < 3; ++k)
+  {
+    if (SpecStaged[k] || !SpecDone[k].load(std::memory_order_acquire)) continue;
+    SpecStaged[k] = true;
+    lsa_set_target_cell_size(Ctx, LSA_TARGET_MAP, k, static_cast<float>((k == LSA_EDGE ? KnnCellScaleMapsEdges : KnnCellScaleMaps) * LocalMaps[k]->GetLeafSize()));
+    LSA_TRY(lsa_stage_target_ahead(Ctx, LSA_TARGET_MAP, k, static_cast<int>(LocalMaps[k]->SubMapSize())));
   }
   return LSA_OK;
 }
@@ -1135,6 +1160,7 @@ int SlamCore::GetParam(const std::string& name, double* v) const
   if (name == "SubMapSpeculationHits") { *v = SubMapSpecHitsTotal; return LSA_OK; }
   if (name == "LookaheadAdopted") { *v = Ctx ? lsa_extract_prefetch_adopted(Ctx) : 0; return LSA_OK; }
   if (name == "TargetsBuiltAheadAdopted") { *v = Ctx ? lsa_prepared_targets_adopted(Ctx) : 0; return LSA_OK; }
+  if (name == "SubMapsStagedAheadAdopted") { *v = Ctx ? lsa_staged_targets_adopted(Ctx) : 0; return LSA_OK; }
   if (name == "MapAddThreads") { *v = LocalMaps[LSA_PLANE]->GetAddThreads(); return LSA_OK; }
   if (name == "MapAddThreadsEdges") { *v = LocalMaps[LSA_EDGE]->GetAddThreads(); return LSA_OK; }
   if (name == "LoggingTimeout") { *v = LoggingTimeout; return LSA_OK; }

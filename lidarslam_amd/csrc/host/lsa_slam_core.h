@@ -8,6 +8,7 @@
 // keypoint runs on the device through lidarslam_amd.h.
 #pragma once
 #include <array>
+#include <atomic>
 #include <condition_variable>
 #include <deque>
 #include <limits>
@@ -250,6 +251,11 @@ private:
   int FinishSubMapSpeculation();
   bool SpecPending = false;
   bool SpecBuilt[3] = {false, false, false};  // written by the workers, read after WaitMaps
+  // the same news for the thread that runs the ICP: it hands a finished sub-map to the device (upload and search
+  // grid on the look-ahead stream) at its next stop between two kernels' results
+  std::atomic<bool> SpecDone[3];
+  bool SpecStaged[3] = {false, false, false};
+  int StageSpeculativeSubMaps();
   double MapJobSeconds[3] = {0., 0., 0.};  // written by the workers, read after WaitMaps
   HostWorker MapWorker[3];                  // one per map: the three rolling grids are independent
   void WaitMaps() { for (auto& w : MapWorker) w.Wait(); }

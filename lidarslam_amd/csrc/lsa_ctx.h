@@ -160,8 +160,12 @@ struct lsa_ctx
   // lsa_target_staging: pinned host buffers a target's points are written into before lsa_set_target_staged
   lsa_point_t* tstage[6] = {};
   int tstage_cap[6] = {};
-  lsa::Target target[9];  // [slot * 3 + type]: slot 0 = map sub-maps (localization), slot 1 = previous scan (ego-motion);
+  lsa::Target target[12];  // [slot * 3 + type]: slot 0 = map sub-maps (localization), slot 1 = previous scan (ego-motion);
                           // [6 + type] = the previous-scan targets of the NEXT frame, built ahead (lsa_prepare_previous_targets)
+                          // [9 + type] = sub-map targets uploaded and built ahead of their use (lsa_stage_target_ahead)
+  bool map_ahead_ready[3] = {false, false, false};
+  int map_ahead_adopted = 0;
+  hipEvent_t ev_map_ahead[3] = {nullptr, nullptr, nullptr};
   // content versions of the keypoint sets: every write takes a new number, the shift of the current keypoints to
   // the previous ones carries it along -- that is how a target built ahead knows it still describes the set
   unsigned long long kp_clock = 0;

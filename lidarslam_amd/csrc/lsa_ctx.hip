@@ -2,7 +2,11 @@
 // host-side azimuthal resolution estimate, per-kernel HIP-event profiling.
 #include <algorithm>
 #include <cmath>
+#include <cctype>
+#include <cstdio>
 #include <cstdlib>
+#include <sched.h>
+#include <string>
 #include "lsa_ctx.h"
 
 using namespace lsa;
@@ -259,6 +263,7 @@ int lsa_ctx_create(int device_id, lsa_ctx** out)
   ok &= hipStreamCreateWithFlags(&ctx->prefetch_stream, hipStreamNonBlocking) == hipSuccess;
   ok &= hipEventCreateWithFlags(&ctx->ev_prefetch, hipEventDisableTiming) == hipSuccess;
   ok &= hipEventCreateWithFlags(&ctx->ev_spare, hipEventDisableTiming) == hipSuccess;
+  for (int k = 0; k < 3; ++k) ok &= hipEventCreateWithFlags(&ctx->ev_map_ahead[k], hipEventDisableTiming) == hipSuccess;
   ok &= hipEventCreateWithFlags(&ctx->ev_kp_ready, hipEventDisableTiming) == hipSuccess;
   if (ok) { ctx->kp_count_dev = ctx->extract_out; ctx->ring_meta = ctx->extract_out + 4; }
   ok &= hipMalloc((void**)&ctx->ring_counts, kMaxRings * 3 * sizeof(int)) == hipSuccess;
@@ -296,12 +301,14 @@ void lsa_ctx_destroy(lsa_ctx* ctx)
   if (ctx->host_next) (void)hipHostFree(ctx->host_next);
   if (ctx->ev_prefetch) (void)hipEventDestroy(ctx->ev_prefetch);
   if (ctx->ev_spare) (void)hipEventDestroy(ctx->ev_spare);
+  for (int k = 0; k < 3; ++k)
+    if (ctx->ev_map_ahead[k]) (void)hipEventDestroy(ctx->ev_map_ahead[k]);
   if (ctx->ev_kp_ready) (void)hipEventDestroy(ctx->ev_kp_ready);
   if (ctx->prefetch_stream) (void)hipStreamDestroy(ctx->prefetch_stream);
   for (int i = 0; i < 4; ++i) fr(ctx->score[i]);
   fr(ctx->valid); fr(ctx->label); fr(ctx->ring_counts);
   for (int s = 0; s < 3; ++s) for (int k = 0; k < 3; ++k) fr(ctx->kp[s][k]);
-  for (int k = 0; k < 9; ++k)
+  for (int k = 0; k < 12; ++k)
   {
     Target& t = ctx->target[k];
     fr(t.pts); fr(t.xyzl); fr(t.desc); fr(t.bbox_bits);
@@ -507,6 +514,47 @@ int lsa_frame_store_use(lsa_ctx* ctx, int slot)
   ctx->frame = ctx->store[slot].first;
   ctx->frame_n = ctx->store[slot].second;
   return LSA_OK;
+}
+
+// The host threads of a context talk to the device in tens of short round trips per frame (mailbox polls, pinned
+// staging buffers): on a two-socket host they belong on the socket the GPU hangs off.
+int lsa_bind_host_to_device(int device_id)
+{
+  char bus[64] = {0};
+  if (hipDeviceGetPCIBusId(bus, sizeof(bus), device_id) != hipSuccess) return LSA_E_NO_DEVICE;
+  for (char* c = bus; *c; ++c) *c = (char)std::tolower((unsigned char)*c);
+  int node = -1;
+  {
+    const std::string path = std::string("/sys/bus/pci/devices/") + bus + "/numa_node";
+    if (FILE* f = std::fopen(path.c_str(), "r")) { if (std::fscanf(f, "%d", &node) != 1) node = -1; std::fclose(f); }
+  }
+  if (node < 0) return LSA_E_STATE;  // single-socket host, or the kernel does not say
+  cpu_set_t want;
+  CPU_ZERO(&want);
+  {
+    const std::string path = "/sys/devices/system/node/node" + std::to_string(node) + "/cpulist";
+    FILE* f = std::fopen(path.c_str(), "r");
+    if (!f) return LSA_E_STATE;
+    int a = 0, b = 0;
+    // "0-63,128-191"
+    while (std::fscanf(f, "%d", &a) == 1)
+    {
+      b = a;
+      int ch = std::fgetc(f);
+      if (ch == '-') { if (std::fscanf(f, "%d", &b) != 1) b = a; ch = std::fgetc(f); }
+      for (int c = a; c <= b && c < CPU_SETSIZE; ++c) CPU_SET(c, &want);
+      if (ch != ',') break;
+    }
+    std::fclose(f);
+  }
+  cpu_set_t have;
+  CPU_ZERO(&have);
+  if (sched_getaffinity(0, sizeof(have), &have) != 0) return LSA_E_STATE;
+  cpu_set_t both;
+  CPU_AND(&both, &want, &have);
+  if (CPU_COUNT(&both) == 0) return LSA_E_STATE;  // the node's CPUs are not ours to use
+  if (sched_setaffinity(0, sizeof(both), &both) != 0) return LSA_E_STATE;
+  return node;
 }
 
 int lsa_frame_size(const lsa_ctx* ctx) { return ctx ? ctx->frame_n : 0; }

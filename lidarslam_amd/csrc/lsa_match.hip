@@ -1386,6 +1386,22 @@ int lsa_set_target_staged(lsa_ctx* ctx, int slot, int type, int m)
   const int ti = slot * 3 + type;
   if (m > ctx->tstage_cap[ti]) return ctx->fail(LSA_E_STATE, "lsa_set_target_staged: more points than the staging buffer holds");
   LSA_HIP(ctx, hipSetDevice(ctx->device));
+  if (slot == LSA_TARGET_MAP && ctx->map_ahead_ready[type])
+  {
+    // uploaded and built ahead on the look-ahead stream (lsa_stage_target_ahead): taken over when it is the same
+    // staged cloud with the same cell size; either way its copy out of the staging buffer has to be over
+    ctx->map_ahead_ready[type] = false;
+    Target& spare = ctx->target[9 + type];
+    if (m > 0 && spare.m == m && spare.cell_hint == ctx->target[ti].cell_hint)
+    {
+      std::swap(ctx->target[ti], spare);
+      ctx->target[ti].dirty = false;
+      ctx->map_ahead_adopted++;
+      LSA_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_map_ahead[type], 0));
+      return LSA_OK;
+    }
+    LSA_HIP(ctx, hipEventSynchronize(ctx->ev_map_ahead[type]));
+  }
   int rc = ensure_target(ctx, ti, m);
   if (rc) return rc;
   Target& t = ctx->target[ti];
@@ -1398,6 +1414,41 @@ int lsa_set_target_staged(lsa_ctx* ctx, int slot, int type, int m)
   t.dirty = true;  // the search grid is built with the other pending targets at the next match
   return LSA_OK;
 }
+
+int lsa_stage_target_ahead(lsa_ctx* ctx, int slot, int type, int m)
+{
+  if (!ctx || slot != LSA_TARGET_MAP || type < 0 || type > 2 || m < 0) return ctx ? ctx->fail(LSA_E_ARG, "lsa_stage_target_ahead: bad argument") : LSA_E_ARG;
+  const int ti = slot * 3 + type;
+  if (m > ctx->tstage_cap[ti]) return ctx->fail(LSA_E_STATE, "lsa_stage_target_ahead: more points than the staging buffer holds");
+  LSA_HIP(ctx, hipSetDevice(ctx->device));
+  if (ctx->map_ahead_ready[type]) LSA_HIP(ctx, hipEventSynchronize(ctx->ev_map_ahead[type]));
+  ctx->map_ahead_ready[type] = false;
+  if (m == 0) return LSA_OK;
+  int rc = ensure_target(ctx, 9 + type, m);
+  if (rc) return rc;
+  Target& t = ctx->target[9 + type];
+  t.m = m;
+  t.cell_hint = ctx->target[ti].cell_hint;
+  LSA_HIP(ctx, hipMemcpyAsync(t.pts, ctx->tstage[ti], (size_t)m * sizeof(lsa_point_t), hipMemcpyHostToDevice, ctx->prefetch_stream));
+  const int tis[1] = {9 + type};
+  rc = build_grids(ctx, tis, 1, ctx->prefetch_stream);
+  if (rc) return rc;
+  LSA_HIP(ctx, hipEventRecord(ctx->ev_map_ahead[type], ctx->prefetch_stream));
+  ctx->map_ahead_ready[type] = true;
+  return LSA_OK;
+}
+
+int lsa_drop_target_ahead(lsa_ctx* ctx, int slot, int type)
+{
+  if (!ctx || slot != LSA_TARGET_MAP || type < 0 || type > 2) return ctx ? ctx->fail(LSA_E_ARG, "lsa_drop_target_ahead: bad argument") : LSA_E_ARG;
+  if (!ctx->map_ahead_ready[type]) return LSA_OK;
+  LSA_HIP(ctx, hipSetDevice(ctx->device));
+  LSA_HIP(ctx, hipEventSynchronize(ctx->ev_map_ahead[type]));  // the staging buffer is free to be rewritten after this
+  ctx->map_ahead_ready[type] = false;
+  return LSA_OK;
+}
+
+int lsa_staged_targets_adopted(const lsa_ctx* ctx) { return ctx ? ctx->map_ahead_adopted : 0; }
 
 int lsa_set_target_from_set(lsa_ctx* ctx, int slot, int type, int set)
 {

@@ -525,15 +525,19 @@ def test_lookahead_extraction_changes_nothing_but_the_schedule(L):
             used.append(s.get_param("TotalMatchedKeypoints"))
         hits = s.get_param("LookaheadAdopted")
         built[ahead] = s.get_param("TargetsBuiltAheadAdopted")
+        staged[ahead] = s.get_param("SubMapsStagedAheadAdopted")
         s.close()
         return np.array(poses), kps, used, hits
 
-    built = {}
+    built, staged = {}, {}
     plain = run(lambda f: None, ahead=0)
     # the ego-motion targets of the next frame built beside this frame's registration: two per frame from the second
     # frame on, same poses
     ahead_targets = run(lambda f: None, ahead=1)
     assert built == {0: 0, 1: 2 * (len(frames) - 1)}
+    # ... and most of the sub-maps extracted for the predicted pose were on the device, grid built, before
+    # Localization asked for them (how many depends on when the host threads finish: a schedule, not a result)
+    assert staged[0] == 0 and 0 <= staged[1] <= 2 * len(frames)
     assert np.array_equal(plain[0], ahead_targets[0]) and plain[1] == ahead_targets[1] and plain[2] == ahead_targets[2]
     ahead = run(lambda f: f + 1 if f + 1 < len(frames) else None)
     wrong = run(lambda f: (f + 3) % len(frames))

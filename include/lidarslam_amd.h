@@ -311,6 +311,10 @@ int lsa_download_match(lsa_ctx* ctx, int type, uint8_t* status, double* weights,
  * 6x6 solve); see lidarslam_amd/csrc/host/lsa_lm.cpp. */
 int lsa_accumulate(lsa_ctx* ctx, unsigned type_mask, const double w[6], int want_jacobian, double* cost, double g[6],
                    double H[36], int* n_valid);
+/* 1 when the partial sums of lsa_accumulate arrive through coherent host memory the kernel writes directly (the
+ * normal case), 0 when that memory could not be mapped and every evaluation falls back to a copy + synchronise
+ * (same results, about twice the time per evaluation). */
+int lsa_mailbox_active(const lsa_ctx* ctx);
 
 /* LocalOptimizer::SetPosePrior + Solve + GetOptimizedPose (LocalOptimizer.cxx:44-48, 74-109) on the
  * device-resident residual blocks of type_mask: the Ceres trust-region Levenberg-Marquardt loop

@@ -276,9 +276,9 @@ int lsa_ctx_create(int device_id, lsa_ctx** out)
   ok &= hipHostMalloc((void**)&ctx->host_pinned, 512 * sizeof(double), hipHostMallocDefault) == hipSuccess;
   if (hipHostMalloc((void**)&ctx->mailbox, (size_t)kAccumBlocksMax * kMailboxStride * sizeof(double), hipHostMallocCoherent | hipHostMallocMapped) == hipSuccess)
     std::memset(ctx->mailbox, 0, (size_t)kAccumBlocksMax * kMailboxStride * sizeof(double));
-  if (const char* e = std::getenv("LSA_ACCUM_BLOCKS")) ctx->accum_blocks = std::min(std::max(std::atoi(e), 1), kAccumBlocksMax);
   else
     ctx->mailbox = nullptr;  // optional: lsa_accumulate falls back to a copy + synchronise
+  if (const char* e = std::getenv("LSA_ACCUM_BLOCKS")) ctx->accum_blocks = std::min(std::max(std::atoi(e), 1), kAccumBlocksMax);
   if (!ok) { lsa_ctx_destroy(ctx); return LSA_E_HIP; }
   *out = ctx;
   return LSA_OK;

@@ -1450,6 +1450,8 @@ int lsa_drop_target_ahead(lsa_ctx* ctx, int slot, int type)
 
 int lsa_staged_targets_adopted(const lsa_ctx* ctx) { return ctx ? ctx->map_ahead_adopted : 0; }
 
+int lsa_mailbox_active(const lsa_ctx* ctx) { return ctx && ctx->mailbox ? 1 : 0; }
+
 int lsa_set_target_from_set(lsa_ctx* ctx, int slot, int type, int set)
 {
   if (!ctx || slot < 0 || slot > 1 || type < 0 || type > 2 || set < 0 || set > 2) return ctx ? ctx->fail(LSA_E_ARG, "lsa_set_target_from_set: bad argument") : LSA_E_ARG;

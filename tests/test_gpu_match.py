@@ -277,3 +277,9 @@ def test_interpolated_bounding_boxes_are_those_of_the_undistorted_keypoints(gpu_
     # the rigid form, for comparison: the motion between H0 and H1 moves the boxes
     rn, rx = gpu_ctx.keypoint_bboxes(L.SET_RAW_CURRENT, H0)
     assert np.abs(rn - mn).max() > 0.05
+
+
+def test_normal_equations_arrive_through_the_mailbox(gpu_ctx, L):
+    """the fast hand-over of lsa_accumulate (partial sums written straight into coherent host memory) is in use: its
+    fallback gives the same numbers at about twice the latency, which only a benchmark would notice"""
+    assert L.lib().lsa_mailbox_active(gpu_ctx.h) == 1

@@ -144,7 +144,12 @@ void SlamCore::Reset(bool resetLog)
       for (int k = 0; k < 3; ++k) lsa_set_keypoints(Ctx, s, k, nullptr, 0);
   for (int k = 0; k < 3; ++k) { EgoDebug[k] = MatchDebug(); LocDebug[k] = MatchDebug(); KeypointCounts[k] = 0; SpecBuilt[k] = false; }
   SpecPending = false;
-  for (int k = 0; k < 3; ++k) { SpecDone[k].store(false); SpecStaged[k] = false; }
+  for (int k = 0; k < 3; ++k)
+  {
+    SpecDone[k].store(false);
+    SpecStaged[k] = false;
+    if (Ctx) (void)lsa_drop_target_ahead(Ctx, LSA_TARGET_MAP, k);  // nothing handed over ahead of time survives a reset
+  }
   CurrentFrames.clear();
   for (int k = 0; k < 3; ++k) EgoMatchSerial[k] = LocMatchSerial[k] = 0;
   if (resetLog)
@@ -615,6 +620,16 @@ int SlamCore::Localization()
     }
     float mn[9], mx[9];
     if (any && MapUpdate != MappingMode::NONE) LSA_TRY(lsa_working_bboxes(Ctx, Tworld.m, mn, mx));  // all types, one pass
+    // A sub-map handed to the device ahead of time is only good for the prediction it was extracted for: whatever
+    // does not hold gives it up here -- which also waits for the copy out of the staging buffer, so that the buffer
+    // may be rewritten below.
+    for (int k = 0; k < 3; ++k)
+    {
+      const bool holds = fresh[k] && MapUpdate != MappingMode::NONE && LocalMaps[k]->SubMapBuiltFor(mn + 3 * k, mx + 3 * k, KeypointCounts[k] / 2);
+      if (SpecStaged[k] && !holds) LSA_TRY(lsa_drop_target_ahead(Ctx, LSA_TARGET_MAP, k));
+      SpecStaged[k] = false;
+      SpecDone[k].store(false);
+    }
     for (int k = 0; k < 3; ++k)
     {
       if (!fresh[k] && !rebuild[k]) continue;
@@ -626,8 +641,7 @@ int SlamCore::Localization()
         if (map->SubMapBuiltFor(mn + 3 * k, mx + 3 * k, minPts)) { Stats.submap_spec_hits++; SubMapSpecHitsTotal++; rebuild[k] = true; continue; }
         rebuild[k] = true;
       }
-      // the staging buffer is about to be rewritten: a copy out of it started ahead of time has to be over
-      LSA_TRY(lsa_drop_target_ahead(Ctx, LSA_TARGET_MAP, k));
+
       if (MapUpdate == MappingMode::NONE)
         MapWorker[k].Submit([map] { map->BuildSubMap(); });
       else
@@ -753,6 +767,7 @@ int SlamCore::FinishSubMapSpeculation()
   SpecPending = false;
   float mn[9], mx[9];
   LSA_TRY(lsa_keypoint_bboxes_end(Ctx, mn, mx));
+  for (int k = 0; k < 3; ++k) { SpecDone[k].store(false); SpecStaged[k] = false; }
   for (int k = 0; k < 3; ++k)
   {
     if (!UseKeypoints[k] || KeypointCounts[k] <= 0) continue;
@@ -762,8 +777,6 @@ int SlamCore::FinishSubMapSpeculation()
     const int minPts = KeypointCounts[k] / 2;
     bool* built = &SpecBuilt[k];
     std::atomic<bool>* done = &SpecDone[k];
-    SpecDone[k].store(false);
-    SpecStaged[k] = false;
     const float* lo3 = mn + 3 * k;
     const float* hi3 = mx + 3 * k;
     // queued behind the previous keyframe's insertion on the same worker: it sees the final map

@@ -163,13 +163,15 @@ def test_map_maintenance_beside_the_device_work(L, O, params):
     sg.close()
 
 
-def test_degenerate_frames_in_the_middle_of_a_sequence(L, O):
+@pytest.mark.parametrize("replay", [False, True])
+def test_degenerate_frames_in_the_middle_of_a_sequence(L, O, replay):
     """frames that give too few keypoints, or none: "Not enough keypoints ... skipped for this frame" on both sides
     (Slam.cxx:919-923, 1098-1107), the pose is kept, the next good frame carries on -- with the map workers and the
     ahead-of-time sub-maps in between.  (Non-finite coordinates are not part of this: the reference builds kd-trees
     on them and queries with them, which is undefined there; here such keypoints simply find no neighbours.)"""
     sg, so = L.Slam(0, EgoMotion=3), O.Slam(EgoMotion=3)
     rng = np.random.default_rng(5)
+    scans = []
     for f in range(14):
         pts, stamp = L.synth_frame(8, 1000, f)
         if f in (4, 9):
@@ -177,7 +179,18 @@ def test_degenerate_frames_in_the_middle_of_a_sequence(L, O):
         elif f in (6, 10):
             keep = rng.random(pts.size) < 0.02                   # 2 % of the points: a few keypoints at best
             pts = pts[keep].copy()
-        sg.add_frame(pts, stamp, f)
+        scans.append((pts, stamp))
+        if replay:
+            sg.store_frame(f, pts)
+    for f, (pts, stamp) in enumerate(scans):
+        if replay:
+            # from the frame store with the look-ahead: the extraction of the next (possibly degenerate) frame,
+            # the ego-motion targets and the sub-maps are all prepared ahead of time
+            if f + 1 < len(scans):
+                sg.hint_next_stored_frame(f + 1)
+            sg.add_stored_frame(f, stamp, f)
+        else:
+            sg.add_frame(pts, stamp, f)
         so.add_frame(pts, stamp, f)
         dp, da = pose_diff(so.world_transform(), sg.world_transform())
         assert dp < 1e-7 and da < 1e-6, (f, dp, da)

@@ -282,7 +282,12 @@ int SlamCore::AddFrames(const InputFrame* frames, int nframes)
     if (!az && OtherExtractors.empty()) az = &Device0AzimuthalResolution;  // the default extractor stands in (Slam.cxx:766-772)
     lsa_set_azimuthal_resolution(Ctx, az ? *az : 1.f);
     const int slot = kFirstDeviceFrameSlot + i;
-    LSA_TRY(lsa_frame_store_put(Ctx, slot, frames[i].pts, frames[i].n));
+    if (lsa_frame_store_put(Ctx, slot, frames[i].pts, frames[i].n) != LSA_OK)
+    {
+      lsa_set_azimuthal_resolution(Ctx, Device0AzimuthalResolution);  // device 0's value goes back where it lives
+      CurrentFrames.clear();
+      return Fail(LSA_E_HIP, "AddFrames");
+    }
     if (az) *az = lsa_get_azimuthal_resolution(Ctx);
     CurrentFrames.push_back({slot, frames[i].n, device, StampToSec(frames[i].stampUs) - StampToSec(frames[0].stampUs)});
   }

@@ -306,6 +306,30 @@ class Context:
             self.L.lsa_set_target_cell_size(self.h, slot, ktype, cell)
         self._check(self.L.lsa_set_target_from_set(self.h, slot, ktype, kset), "lsa_set_target_from_set")
 
+    def stage_target(self, ktype, pts, ahead=False, cell=None, slot=TARGET_MAP):
+        """lsa_target_staging + lsa_stage_target_ahead / lsa_set_target_staged: the points are written into the
+        target's pinned staging buffer, then either handed to the device ahead of time (ahead=True) or made the target"""
+        pts = np.ascontiguousarray(pts, POINT_DTYPE)
+        self.L.lsa_target_staging.restype = C.c_void_p
+        self.L.lsa_target_staging.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]
+        buf = self.L.lsa_target_staging(self.h, slot, ktype, pts.size)
+        if not buf and pts.size:
+            raise LsaError("lsa_target_staging failed")
+        if pts.size:
+            C.memmove(buf, pts.ctypes.data, pts.nbytes)
+        if cell is not None:
+            self.L.lsa_set_target_cell_size(self.h, slot, ktype, cell)
+        if ahead:
+            self._check(self.L.lsa_stage_target_ahead(self.h, slot, ktype, pts.size), "lsa_stage_target_ahead")
+        else:
+            self._check(self.L.lsa_set_target_staged(self.h, slot, ktype, pts.size), "lsa_set_target_staged")
+
+    def drop_target_ahead(self, ktype, slot=TARGET_MAP):
+        self._check(self.L.lsa_drop_target_ahead(self.h, slot, ktype), "lsa_drop_target_ahead")
+
+    def prepare_previous_targets(self, type_mask):
+        self._check(self.L.lsa_prepare_previous_targets(self.h, type_mask), "lsa_prepare_previous_targets")
+
     def target(self, ktype, slot=TARGET_MAP):
         n = self.L.lsa_target_size(self.h, slot, ktype)
         out = np.zeros(max(n, 0), POINT_DTYPE)

@@ -283,3 +283,51 @@ def test_normal_equations_arrive_through_the_mailbox(gpu_ctx, L):
     """the fast hand-over of lsa_accumulate (partial sums written straight into coherent host memory) is in use: its
     fallback gives the same numbers at about twice the latency, which only a benchmark would notice"""
     assert L.lib().lsa_mailbox_active(gpu_ctx.h) == 1
+
+
+def test_targets_prepared_ahead_give_the_same_matches(O, L, kps):
+    """lsa_stage_target_ahead / lsa_drop_target_ahead / lsa_prepare_previous_targets through the C ABI: a target
+    uploaded and indexed ahead of time on the look-ahead stream is taken over only when it is the very cloud (and cell
+    size) that is asked for, and then gives the matches of a target set the usual way."""
+    prev, cur = kps[16]
+    mp, pose = L.MatchParams.localization(saturation_distance=2.0), perturbed()
+    ctx = L.Context(0)
+    adopted = lambda: ctx.L.lsa_staged_targets_adopted(ctx.h)
+    ctx.set_keypoints(L.SET_WORKING, L.PLANE, cur[L.PLANE])
+    ctx.set_target(L.PLANE, prev[L.PLANE], cell=1.0)
+    ref_hist = ctx.match(L.PLANE, L.SET_WORKING, mp, pose)
+    ref = ctx.match_results(L.PLANE, L.SET_WORKING)
+    # ahead, then the same cloud asked for: adopted
+    ctx.stage_target(L.PLANE, prev[L.PLANE], ahead=True, cell=1.0)
+    ctx.stage_target(L.PLANE, prev[L.PLANE], ahead=False, cell=1.0)
+    assert adopted() == 1
+    assert ctx.match(L.PLANE, L.SET_WORKING, mp, pose).tolist() == ref_hist.tolist()
+    got = ctx.match_results(L.PLANE, L.SET_WORKING)
+    assert all(np.array_equal(bits(a), bits(b)) for a, b in zip(got, ref))
+    assert ctx.target(L.PLANE).tobytes() == prev[L.PLANE].tobytes()
+    # ahead, then another cell size: built the usual way; ahead, then dropped: not adopted either
+    ctx.stage_target(L.PLANE, prev[L.PLANE], ahead=True, cell=1.0)
+    ctx.stage_target(L.PLANE, prev[L.PLANE], ahead=False, cell=0.7)
+    ctx.stage_target(L.PLANE, prev[L.PLANE][:-10], ahead=True, cell=0.7)
+    ctx.drop_target_ahead(L.PLANE)
+    ctx.stage_target(L.PLANE, prev[L.PLANE][:-10], ahead=False, cell=0.7)
+    assert adopted() == 1 and ctx.target(L.PLANE).size == prev[L.PLANE].size - 10
+    # the previous-scan targets of the next frame: current raw keypoints now, previous ones after the shift
+    taken = lambda: ctx.L.lsa_prepared_targets_adopted(ctx.h)
+    pts, _ = L.synth_frame(16, 1000, 0)
+    ctx.upload_frame(pts)
+    ctx.extract_keypoints()
+    ctx.L.lsa_set_target_cell_size(ctx.h, L.TARGET_PREVIOUS, L.PLANE, 0.25)
+    ctx.prepare_previous_targets(1 << L.PLANE)
+    first = ctx.keypoints(L.SET_RAW_CURRENT, L.PLANE)
+    ctx.upload_frame(L.synth_frame(16, 1000, 1)[0])
+    ctx.extract_keypoints()  # the shift: what was current is previous now
+    ctx.set_target_from_set(L.PLANE, L.SET_RAW_PREVIOUS, cell=0.25)
+    assert taken() == 1 and ctx.target(L.PLANE, L.TARGET_PREVIOUS).tobytes() == first.tobytes()
+    ctx.prepare_previous_targets(1 << L.PLANE)
+    ctx.set_keypoints(L.SET_RAW_CURRENT, L.PLANE, first[:100])  # the set is rewritten: the target built ahead is stale
+    ctx.upload_frame(L.synth_frame(16, 1000, 2)[0])
+    ctx.extract_keypoints()
+    ctx.set_target_from_set(L.PLANE, L.SET_RAW_PREVIOUS, cell=0.25)
+    assert taken() == 1 and ctx.target(L.PLANE, L.TARGET_PREVIOUS).tobytes() == first[:100].tobytes()
+    ctx.close()

@@ -324,6 +324,33 @@ int lsa_mailbox_active(const lsa_ctx* ctx);
  * [3] evaluations; costs[0] initial, [1] final. */
 int lsa_solve(lsa_ctx* ctx, unsigned type_mask, const double prior[16], int lm_max_iter, int two_d_mode, double optimized[16],
               int summary[4], double costs[2]);
+/* The same solve as ONE launch: the trust-region loop itself runs on the device (every block evaluates its share
+ * of the residual blocks, the blocks exchange their partial sums through tagged 8-byte granules, each block runs the
+ * 6x6 algebra), the host only reads the result.  prior / pose are the six parameters (x, y, z, rx, ry, rz) of
+ * LocalOptimizer::PoseArray (LocalOptimizer.h:99-101).  min_matches: Slam.cxx:919, 1098 skip the optimisation when
+ * fewer keypoints matched (skipped = 1, pose = prior).  cost, g, H: the normal equations at the returned pose (what
+ * EstimateRegistrationError needs).  Returns LSA_E_STATE when the device gave up (blocks not co-resident in time):
+ * the caller then runs lsa_solve / the host-driven loop; nothing was changed. */
+typedef struct lsa_solve_result
+{
+  double pose[6];
+  double initial_cost, final_cost;
+  double cost, g[6], H[36];
+  int num_successful_steps;   /* counts iteration 0, as ceres::Solver::Summary does */
+  int num_unsuccessful_steps;
+  int num_iterations;
+  int num_evaluations;
+  int num_matches;            /* residual blocks (successful matches) the problem was built from */
+  int skipped;
+  int termination;            /* 0 none, 1 not enough matches, 2 gradient tolerance at iteration 0, 3 max iterations,
+                                 4 gradient tolerance, 5 min trust region radius, 6 too many invalid steps,
+                                 7 parameter tolerance, 8 function tolerance */
+  const char* message;
+} lsa_solve_result_t;
+int lsa_solve_device(lsa_ctx* ctx, unsigned type_mask, const double prior[6], int two_d_mode, int lm_max_iter, int min_matches,
+                     lsa_solve_result_t* out);
+/* Solves the device gave up on so far (diagnostics; 0 on a healthy run). */
+int lsa_solve_device_fallbacks(const lsa_ctx* ctx);
 /* LocalOptimizer::EstimateRegistrationError (LocalOptimizer.cxx:112-140) at `pose`: covariance
  * (row-major 6x6, DoF order X,Y,Z,rX,rY,rZ), err[0] position error [m], err[1] orientation error [deg]. */
 int lsa_registration_error(lsa_ctx* ctx, unsigned type_mask, const double pose[16], int two_d_mode, double cov[36], double err[2]);

@@ -56,7 +56,7 @@ ABI_SYMBOLS = [
     "lsa_set_azimuthal_resolution", "lsa_extract_keypoints", "lsa_extract_keypoints_more", "lsa_extract_prefetch", "lsa_extract_prefetch_adopted", "lsa_transform_frame_at", "lsa_set_keypoint_types", "lsa_download_keypoints", "lsa_keypoint_count",
     "lsa_download_debug", "lsa_nb_laser_rings", "lsa_transform_keypoints", "lsa_set_target", "lsa_set_target_from_set", "lsa_prepare_previous_targets", "lsa_prepared_targets_adopted", "lsa_target_staging", "lsa_set_target_staged", "lsa_stage_target_ahead", "lsa_drop_target_ahead", "lsa_staged_targets_adopted",
     "lsa_target_size", "lsa_download_target", "lsa_set_target_cell_size", "lsa_set_knn_lanes", "lsa_set_knn_rounds", "lsa_match_slow_queries", "lsa_match_exhaustive_queries", "lsa_set_keypoints", "lsa_match", "lsa_match_types",
-    "lsa_download_match", "lsa_overlap", "lsa_accumulate", "lsa_mailbox_active", "lsa_solve", "lsa_registration_error", "lsa_selftest_math", "lsa_reset_working_keypoints", "lsa_undistort", "lsa_working_time_range",
+    "lsa_download_match", "lsa_overlap", "lsa_accumulate", "lsa_mailbox_active", "lsa_solve", "lsa_solve_device", "lsa_solve_device_fallbacks", "lsa_registration_error", "lsa_selftest_math", "lsa_reset_working_keypoints", "lsa_undistort", "lsa_working_time_range",
     "lsa_working_bbox", "lsa_working_bboxes", "lsa_keypoint_bboxes_begin", "lsa_keypoint_bboxes_begin_interp", "lsa_keypoint_time_range", "lsa_keypoint_bboxes_end", "lsa_download_transformed", "lsa_stage_transformed", "lsa_staged_transformed", "lsa_transform_frame", "lsa_profile_enable", "lsa_profile_select", "lsa_profile_reset",
     "lsa_profile_get", "lsa_slam_create", "lsa_slam_destroy", "lsa_slam_last_error", "lsa_slam_set_param",
     "lsa_slam_get_param", "lsa_slam_reset", "lsa_slam_add_frame", "lsa_slam_store_frame", "lsa_slam_add_stored_frame", "lsa_slam_hint_next_stored_frame",
@@ -73,6 +73,18 @@ ABI_SYMBOLS = [
 
 class LsaError(RuntimeError):
     pass
+
+
+class SolveResult(C.Structure):
+    """lsa_solve_result_t (include/lidarslam_amd.h)."""
+
+    _fields_ = [
+        ("pose", C.c_double * 6), ("initial_cost", C.c_double), ("final_cost", C.c_double),
+        ("cost", C.c_double), ("g", C.c_double * 6), ("H", C.c_double * 36),
+        ("num_successful_steps", C.c_int), ("num_unsuccessful_steps", C.c_int), ("num_iterations", C.c_int),
+        ("num_evaluations", C.c_int), ("num_matches", C.c_int), ("skipped", C.c_int), ("termination", C.c_int),
+        ("message", C.c_char_p),
+    ]
 
 
 _lib = None
@@ -120,6 +132,8 @@ def lib():
     L.lsa_accumulate.argtypes = [vp, C.c_uint, vp, i32, vp, vp, vp, vp]
     L.lsa_solve.argtypes = [vp, C.c_uint, vp, i32, i32, vp, vp, vp]
     L.lsa_registration_error.argtypes = [vp, C.c_uint, vp, i32, vp, vp]
+    L.lsa_solve_device.argtypes = [vp, C.c_uint, vp, i32, i32, i32, C.POINTER(SolveResult)]
+    L.lsa_solve_device_fallbacks.argtypes = [vp]
     L.lsa_selftest_math.argtypes = [vp, i32, vp, vp, i32, vp]
     L.lsa_reset_working_keypoints.argtypes = [vp]
     L.lsa_undistort.argtypes = [vp, vp, vp, f64, f64]
@@ -387,6 +401,16 @@ class Context:
         costs = np.zeros(2)
         self._check(self.L.lsa_solve(self.h, type_mask, ptr(pose16(prior)), max_iter, int(two_d), ptr(out), ptr(summ), ptr(costs)), "lsa_solve")
         return out.reshape(4, 4), summ, costs
+
+    def solve_device(self, type_mask, prior6, max_iter=15, two_d=False, min_matches=0):
+        """LocalOptimizer::Solve as one launch (the trust-region loop runs on the device): SolveResult."""
+        r = SolveResult()
+        w = np.ascontiguousarray(prior6, np.float64)
+        self._check(self.L.lsa_solve_device(self.h, type_mask, ptr(w), int(two_d), max_iter, min_matches, C.byref(r)), "lsa_solve_device")
+        return r
+
+    def solve_device_fallbacks(self):
+        return self.L.lsa_solve_device_fallbacks(self.h)
 
     def registration_error(self, type_mask, pose, two_d=False):
         cov = np.zeros((6, 6))

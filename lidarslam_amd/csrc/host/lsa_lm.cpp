@@ -109,6 +109,38 @@ void SymEigen(int n, const double* Ain, double* evals, double* evecs)
 
 int LocalOptimizer::Solve(SolveSummary& sum)
 {
+  HaveFinal = false;
+  if (DeviceLoop)
+  {
+    lsa_solve_result_t r;
+    const int rc = lsa_solve_device(Ctx, TypeMask, PoseArray, TwoDMode ? 1 : 0, static_cast<int>(LMMaxIter), static_cast<int>(MinMatches), &r);
+    if (rc == LSA_OK)
+    {
+      sum = SolveSummary();
+      sum.num_successful_steps = r.num_successful_steps;
+      sum.num_unsuccessful_steps = r.num_unsuccessful_steps;
+      sum.num_iterations = r.num_iterations;
+      sum.num_evaluations = r.num_evaluations;
+      sum.initial_cost = r.initial_cost;
+      sum.final_cost = r.final_cost;
+      sum.num_matches = r.num_matches;
+      sum.skipped = r.skipped != 0;
+      sum.message = r.message;
+      if (!sum.skipped)
+      {
+        std::memcpy(PoseArray, r.pose, sizeof(PoseArray));
+        std::memcpy(FinalH, r.H, sizeof(FinalH));
+        HaveFinal = true;
+      }
+      return LSA_OK;
+    }
+    if (rc != LSA_E_STATE) return rc;  // LSA_E_STATE: the device gave up, nothing was changed
+  }
+  return SolveOnHost(sum);
+}
+
+int LocalOptimizer::SolveOnHost(SolveSummary& sum)
+{
   sum = SolveSummary();
   int act[6], n = 0;
   for (int i = 0; i < 6; ++i)
@@ -251,8 +283,12 @@ int LocalOptimizer::EstimateRegistrationError(RegistrationError& err)
   for (int i = 0; i < 6; ++i)
     if (!(TwoDMode && (i == 2 || i == 3 || i == 4))) act[n++] = i;
   Eval cur;
-  int rc = lsa_accumulate(Ctx, TypeMask, PoseArray, 1, &cur.cost, cur.g, cur.H, &cur.nValid);
-  if (rc) return rc;
+  if (HaveFinal) std::memcpy(cur.H, FinalH, sizeof(FinalH));
+  else
+  {
+    const int rc = lsa_accumulate(Ctx, TypeMask, PoseArray, 1, &cur.cost, cur.g, cur.H, &cur.nValid);
+    if (rc) return rc;
+  }
   double H[36], evals[6], evecs[36];
   for (int a = 0; a < n; ++a)
     for (int b = 0; b < n; ++b) H[a * n + b] = cur.H[act[a] * 6 + act[b]];

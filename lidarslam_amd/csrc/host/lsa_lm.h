@@ -45,12 +45,15 @@ public:
   explicit LocalOptimizer(lsa_ctx* ctx) : Ctx(ctx) {}
   void SetTwoDMode(bool b) { TwoDMode = b; }
   void SetLMMaxIter(unsigned n) { LMMaxIter = n; }
-  void SetPosePrior(const Pose& prior) { ToXYZRPY(prior, PoseArray); }
+  void SetPosePrior(const Pose& prior) { ToXYZRPY(prior, PoseArray); HaveFinal = false; }
   // residual blocks = the device records of the last lsa_match of every type in the mask
   void UseDeviceResiduals(unsigned typeMask) { TypeMask = typeMask; }
   // Slam.cxx:919-923 / 1098-1107 skip the optimisation when too few keypoints matched.  The count comes
   // back with the first evaluation, so the caller does not have to read the match histograms first.
   void SetMinMatches(unsigned n) { MinMatches = n; }
+  // the trust-region loop on the device, one launch per solve (lsa_solve_device); when off, or when the device gives
+  // up, the loop runs here with one launch per evaluation.  Same decisions from the same sums either way.
+  void SetDeviceLoop(bool b) { DeviceLoop = b; }
   int Solve(SolveSummary& summary);
   Pose GetOptimizedPose() const { return FromXYZRPY(PoseArray); }
   int EstimateRegistrationError(RegistrationError& err);
@@ -62,6 +65,11 @@ private:
   unsigned LMMaxIter = 15;
   unsigned MinMatches = 0;
   double PoseArray[6] = {0, 0, 0, 0, 0, 0};
+  bool DeviceLoop = true;
+  // normal equations at PoseArray as the device solve returned them (EstimateRegistrationError needs no evaluation then)
+  bool HaveFinal = false;
+  double FinalH[36];
+  int SolveOnHost(SolveSummary& summary);
 };
 
 }  // namespace host

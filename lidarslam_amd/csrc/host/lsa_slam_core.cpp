@@ -555,6 +555,7 @@ int SlamCore::ComputeEgoMotion()
 
     Tick tlm;
     LocalOptimizer optimizer(Ctx);
+    optimizer.SetDeviceLoop(DeviceLM);
     optimizer.SetTwoDMode(TwoDMode);
     optimizer.SetPosePrior(Trelative);
     optimizer.SetLMMaxIter(EgoMotionLMMaxIter);
@@ -692,6 +693,7 @@ int SlamCore::Localization()
 
     Tick tlm;
     LocalOptimizer optimizer(Ctx);
+    optimizer.SetDeviceLoop(DeviceLM);
     optimizer.SetTwoDMode(TwoDMode);
     optimizer.SetPosePrior(Tworld);
     optimizer.SetLMMaxIter(LocalizationLMMaxIter);
@@ -1069,6 +1071,7 @@ int SlamCore::GetRegisteredFrame(std::vector<lsa_point_t>& out)
   X("UsePlanes", UseKeypoints[LSA_PLANE], bool)                                                        \
   X("TwoDMode", TwoDMode, bool)                                                                        \
   X("BuildTargetsAhead", BuildTargetsAhead, bool)                                                      \
+  X("DeviceLM", DeviceLM, bool)                                                                        \
   X("EgoMotionICPMaxIter", EgoMotionICPMaxIter, unsigned)                                              \
   X("LocalizationICPMaxIter", LocalizationICPMaxIter, unsigned)                                        \
   X("EgoMotionLMMaxIter", EgoMotionLMMaxIter, unsigned)                                                \

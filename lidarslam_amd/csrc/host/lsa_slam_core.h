@@ -185,6 +185,8 @@ public:
   int KnnRoundsEdges = 2, KnnRoundsPlanes = 2, KnnRoundsBlobs = 2;  // rounds of the first kNN kernel (2 or 3)
   // build the next frame's ego-motion targets beside this frame's registration (a scheduling knob: same results)
   bool BuildTargetsAhead = true;
+  // LocalOptimizer::Solve as one launch (the trust-region loop on the device) instead of one launch per evaluation
+  bool DeviceLM = true;
   bool KeepMatchDebug = false;  // download MatchingResults::Rejections/Weights every frame (Slam::GetDebugArray)
 
   std::shared_ptr<RollingGrid> LocalMaps[3];

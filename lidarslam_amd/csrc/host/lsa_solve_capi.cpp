@@ -13,6 +13,7 @@ int lsa_solve(lsa_ctx* ctx, unsigned type_mask, const double prior[16], int lm_m
   Pose p;
   std::memcpy(p.m, prior, sizeof(p.m));
   LocalOptimizer opt(ctx);
+  opt.SetDeviceLoop(false);  // this entry point is the host-driven loop; lsa_solve_device is the one-launch solve
   opt.SetTwoDMode(two_d_mode != 0);
   opt.SetLMMaxIter(lm_max_iter < 0 ? 0 : (unsigned)lm_max_iter);
   opt.SetPosePrior(p);

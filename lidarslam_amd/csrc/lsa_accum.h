@@ -1,0 +1,174 @@
+// lsa_accum.h -- what Ceres evaluates per LM step for one residual block, shared by the two kernels
+// that evaluate it: k_accumulate (one evaluation per launch, host-driven trust region, lsa_match.hip)
+// and k_lm_solve (the whole LocalOptimizer::Solve in one launch, lsa_lm.hip).
+//
+//   residual   r = A (R(rpy) X + t - P)              slam_lib/include/LidarSlam/CeresCostFunctions.h:105-152
+//   rotation   R = Rz(rz) Ry(ry) Rx(rx)              CeresCostFunctions.h:67-79
+//   loss       ScaledLoss(TukeyLoss(a), weight)      slam_lib/src/KeypointsMatcher.cxx:84-101 (Ceres >= 2)
+//   Jacobian   analytic: [A, A dR/drx X, A dR/dry X, A dR/drz X]  (replaces the Jet<double, 6> autodiff)
+// Since rho'' <= 0 the Triggs corrector only scales r and J by sqrt(rho'): H = sum rho' J^T J,
+// g = sum rho' J^T r, cost = 1/2 sum rho.
+#pragma once
+#include "lsa_ctx.h"
+
+namespace lsa
+{
+
+// the point of the evaluation: only ever indexed with constants (registers)
+struct RotConst
+{
+  double R[9], dRx[9], dRy[9], dRz[9];
+  double t[3];
+};
+// the residual blocks, per keypoint type: indexed with the type at run time, so it has to live in the kernel
+// arguments (a copy in registers would be demoted to scratch memory)
+struct RecordSet
+{
+  const double* rec[3];
+  const uint8_t* status[3];
+  int count[3];
+  int cap[3];
+  double sat2[3];  // Tukey a^2 per type
+};
+struct AccumConst
+{
+  RotConst rot;
+  RecordSet set;
+  int jac;
+};
+
+// R = Rz Ry Rx and its partial derivatives from the six parameters (x, y, z, rx, ry, rz) given the sines and
+// cosines of the three angles
+__host__ __device__ inline void rotation_and_derivatives(double cx, double sx, double cy, double sy, double cz, double sz, double R[9], double dRx[9],
+                                                         double dRy[9], double dRz[9])
+{
+  R[0] = cy * cz; R[1] = sx * sy * cz - cx * sz; R[2] = cx * sy * cz + sx * sz;
+  R[3] = cy * sz; R[4] = sx * sy * sz + cx * cz; R[5] = cx * sy * sz - sx * cz;
+  R[6] = -sy; R[7] = sx * cy; R[8] = cx * cy;
+  dRx[0] = 0; dRx[1] = cx * sy * cz + sx * sz; dRx[2] = -sx * sy * cz + cx * sz;
+  dRx[3] = 0; dRx[4] = cx * sy * sz - sx * cz; dRx[5] = -sx * sy * sz - cx * cz;
+  dRx[6] = 0; dRx[7] = cx * cy; dRx[8] = -sx * cy;
+  dRy[0] = -sy * cz; dRy[1] = sx * cy * cz; dRy[2] = cx * cy * cz;
+  dRy[3] = -sy * sz; dRy[4] = sx * cy * sz; dRy[5] = cx * cy * sz;
+  dRy[6] = -cy; dRy[7] = -sx * sy; dRy[8] = -cx * sy;
+  dRz[0] = -cy * sz; dRz[1] = -sx * sy * sz - cx * cz; dRz[2] = -cx * sy * sz + sx * cz;
+  dRz[3] = cy * cz; dRz[4] = sx * sy * cz - cx * sz; dRz[5] = cx * sy * cz + sx * sz;
+  dRz[6] = 0; dRz[7] = 0; dRz[8] = 0;
+}
+
+#if defined(__HIPCC__)
+__device__ __forceinline__ void mv3(const double M[9], double x, double y, double z, double& ox, double& oy, double& oz)
+{
+  ox = (M[0] * x + M[1] * y) + M[2] * z;
+  oy = (M[3] * x + M[4] * y) + M[5] * z;
+  oz = (M[6] * x + M[7] * y) + M[8] * z;
+}
+
+// x of this lane's half (rows) + x of the partner half (rows): first operand + second operand, as lane i < W gets
+// from a shuffle-down by W
+template <int W>
+__device__ __forceinline__ double swap_add(double x)
+{
+  const long long b = __double_as_longlong(x);
+  const unsigned xl = (unsigned)(b & 0xffffffffll), xh = (unsigned)((unsigned long long)b >> 32);
+  const auto lo = W == 32 ? __builtin_amdgcn_permlane32_swap(xl, xl, false, false) : __builtin_amdgcn_permlane16_swap(xl, xl, false, false);
+  const auto hi = W == 32 ? __builtin_amdgcn_permlane32_swap(xh, xh, false, false) : __builtin_amdgcn_permlane16_swap(xh, xh, false, false);
+  const double a = __longlong_as_double((long long)(((unsigned long long)hi[0] << 32) | lo[0]));  // lower half / even rows, everywhere
+  const double c = __longlong_as_double((long long)(((unsigned long long)hi[1] << 32) | lo[1]));  // upper half / odd rows, everywhere
+  return a + c;
+}
+
+// value of lane (i + o) of the same row of 16 lanes, 0 where that lane does not exist (o = 1, 2, 4, 8)
+__device__ __forceinline__ double dpp_row_shl(double x, int o)
+{
+  const long long b = __double_as_longlong(x);
+  int lo = (int)(b & 0xffffffffll), hi = (int)(b >> 32);
+  switch (o)
+  {
+    case 8: lo = __builtin_amdgcn_update_dpp(0, lo, 0x108, 0xF, 0xF, true); hi = __builtin_amdgcn_update_dpp(0, hi, 0x108, 0xF, 0xF, true); break;
+    case 4: lo = __builtin_amdgcn_update_dpp(0, lo, 0x104, 0xF, 0xF, true); hi = __builtin_amdgcn_update_dpp(0, hi, 0x104, 0xF, 0xF, true); break;
+    case 2: lo = __builtin_amdgcn_update_dpp(0, lo, 0x102, 0xF, 0xF, true); hi = __builtin_amdgcn_update_dpp(0, hi, 0x102, 0xF, 0xF, true); break;
+    default: lo = __builtin_amdgcn_update_dpp(0, lo, 0x101, 0xF, 0xF, true); hi = __builtin_amdgcn_update_dpp(0, hi, 0x101, 0xF, 0xF, true); break;
+  }
+  return __longlong_as_double(((long long)hi << 32) | (long long)(unsigned)lo);
+}
+
+// this thread's share of the residual blocks (grid stride over EDGE[0..), PLANE[0..), BLOB[0..)): acc += their
+// cost, gradient, J^T J and count
+__device__ __forceinline__ void accumulate_records(const RecordSet& rs, const RotConst& c, bool jac, int first, int stride, double acc[kAccumVals])
+{
+  const int total = rs.count[0] + rs.count[1] + rs.count[2];
+  for (int gidx = first; gidx < total; gidx += stride)
+  {
+    int t = 0, i = gidx;
+    if (i >= rs.count[0]) { i -= rs.count[0]; t = 1; if (i >= rs.count[1]) { i -= rs.count[1]; t = 2; } }
+    if (rs.status[t][i] != LSA_MATCH_SUCCESS) continue;
+    const double* rec = rs.rec[t];
+    const size_t cap = (size_t)rs.cap[t];
+    double A[9];
+#pragma unroll
+    for (int f = 0; f < 9; ++f) A[f] = rec[f * cap + i];
+    const double Px = rec[9 * cap + i], Py = rec[10 * cap + i], Pz = rec[11 * cap + i];
+    const double Xx = rec[12 * cap + i], Xy = rec[13 * cap + i], Xz = rec[14 * cap + i];
+    const double weight = rec[15 * cap + i];
+    double yx, yy, yz;
+    mv3(c.R, Xx, Xy, Xz, yx, yy, yz);
+    const double dx = (yx + c.t[0]) - Px, dy = (yy + c.t[1]) - Py, dz = (yz + c.t[2]) - Pz;
+    double r0, r1, r2;
+    mv3(A, dx, dy, dz, r0, r1, r2);
+    const double s = (r0 * r0 + r1 * r1) + r2 * r2;
+    const double a2 = rs.sat2[t];
+    double rho0, rho1;
+    if (s <= a2)
+    {
+      const double value = 1.0 - s / a2;
+      const double value_sq = value * value;
+      rho0 = a2 / 3.0 * (1.0 - value_sq * value);
+      rho1 = value_sq;
+    }
+    else { rho0 = a2 / 3.0; rho1 = 0.0; }
+    rho0 *= weight; rho1 *= weight;
+    acc[0] += 0.5 * rho0;
+    acc[28] += 1.0;
+    if (!jac) continue;
+    double J[3][6];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int b = 0; b < 3; ++b) J[a][b] = A[a * 3 + b];
+    double vx, vy, vz, cx, cy, cz;
+    mv3(c.dRx, Xx, Xy, Xz, vx, vy, vz); mv3(A, vx, vy, vz, cx, cy, cz); J[0][3] = cx; J[1][3] = cy; J[2][3] = cz;
+    mv3(c.dRy, Xx, Xy, Xz, vx, vy, vz); mv3(A, vx, vy, vz, cx, cy, cz); J[0][4] = cx; J[1][4] = cy; J[2][4] = cz;
+    mv3(c.dRz, Xx, Xy, Xz, vx, vy, vz); mv3(A, vx, vy, vz, cx, cy, cz); J[0][5] = cx; J[1][5] = cy; J[2][5] = cz;
+    int h = 7;
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+    {
+      acc[1 + a] += rho1 * ((J[0][a] * r0 + J[1][a] * r1) + J[2][a] * r2);
+#pragma unroll
+      for (int b = a; b < 6; ++b) acc[h++] += rho1 * ((J[0][a] * J[0][b] + J[1][a] * J[1][b]) + J[2][a] * J[2][b]);
+    }
+  }
+}
+
+// fixed-order reduction over the wavefront: afterwards lane 0 holds the wavefront's sums.  Across the four rows of
+// 16 lanes: v_permlane32_swap / v_permlane16_swap (gfx950) hand every lane its partner's value in one VALU pass --
+// lower half + upper half, then row 0 + row 1 -- the same pairs, in the same order, as a shuffle-down by 32 and by
+// 16 gives lane 0; inside a row the partner's value comes through a DPP operand (row_shl), not through LDS.  One
+// step for all 29 values at a time: 29 independent exchanges in flight instead of 29 chains of 6 dependent ones.
+__device__ __forceinline__ void wave_reduce_accum(double acc[kAccumVals])
+{
+#pragma unroll
+  for (int v = 0; v < kAccumVals; ++v) acc[v] = swap_add<32>(acc[v]);
+#pragma unroll
+  for (int v = 0; v < kAccumVals; ++v) acc[v] = swap_add<16>(acc[v]);
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1)
+  {
+#pragma unroll
+    for (int v = 0; v < kAccumVals; ++v) acc[v] += dpp_row_shl(acc[v], o);
+  }
+}
+#endif  // __HIPCC__
+
+}  // namespace lsa

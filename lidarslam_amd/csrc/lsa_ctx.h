@@ -31,7 +31,10 @@ __host__ __device__ constexpr int grid_level_cells(int level) { return level == 
 constexpr int kKnnMax = 16;               // neighbours per query the kNN buffers hold
 constexpr int kAccumBlocks = 96;          // grid of the normal-equation kernel (grid-stride); the host folds the blocks' partial sums
 constexpr int kAccumBlocksMax = 256;      // what the buffers hold (the grid size can be tuned with LSA_ACCUM_BLOCKS)
-constexpr int kMailboxStride = 40;        // doubles per block in the mailbox: ten 32-byte pieces of 3 partial sums + the sequence tag
+constexpr int kMailboxStride = 64;        // 8-byte granules per block in the mailbox: 2 x 29 used, {tag, half of a double} each
+constexpr int kLmBlocksMax = 128;         // grid limit of the one-launch LM solve (k_lm_solve); LSA_LM_BLOCKS tunes the grid
+constexpr int kLmBlocks = 64;
+constexpr int kLmOut = 48;                // doubles the LM kernel hands to the host (96 granules)
 constexpr int kHistRing = 32;
 constexpr int kAccumVals = 29;            // cost, g[6], H upper[21], nvalid
 
@@ -180,8 +183,20 @@ struct lsa_ctx
   double* partials = nullptr;  // [kAccumBlocksMax][kAccumVals]
   double* reduce_out = nullptr;
   double* host_pinned = nullptr;  // >= 64 doubles, pinned
-  double* mailbox = nullptr;      // coherent host memory k_accumulate's blocks write directly: [kAccumBlocks][kMailboxStride]
+  // coherent host memory k_accumulate's blocks write directly: [kAccumBlocksMax][kMailboxStride] granules.  A granule
+  // is ONE naturally aligned 8-byte word {evaluation tag (high), half of a double (low)} written by ONE store: the
+  // value cannot arrive without its tag, whatever the fabric does with the stores of different lanes
+  unsigned long long* mailbox = nullptr;
   unsigned long long mailbox_seq = 0;
+  bool mailbox_check = false;     // LSA_MAILBOX_CHECK: every evaluation also folds the device-side partials and compares
+  // one-launch LM solve (lsa_solve_device): granules the blocks exchange their partial sums through
+  // ([2 parities][kLmBlocksMax][kMailboxStride], device memory) and the result granules in coherent host memory
+  unsigned long long* lm_xchg = nullptr;
+  unsigned long long* lm_mailbox = nullptr;  // [2 * kLmOut]
+  unsigned lm_tag = 0;            // tags handed out so far (every launch takes max evaluations + 2)
+  unsigned long long lm_seq = 0;  // launches so far
+  int lm_blocks = lsa::kLmBlocks;
+  int lm_fallbacks = 0;           // solves that timed out on the device and were redone by the host-driven loop
   // per match type a ring of kHistRing blocks of 16 ints ([8] rejection histogram + 2 hand-over counters of the kNN
   // cascade): every match takes the next block, the ring is zeroed once per turn instead of one memset per match
   int* hist_dev = nullptr;

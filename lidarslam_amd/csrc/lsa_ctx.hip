@@ -274,11 +274,19 @@ int lsa_ctx_create(int device_id, lsa_ctx** out)
   if (ok) ok &= hipMemset(ctx->hist_dev, 0, 3 * kHistRing * 16 * sizeof(int)) == hipSuccess;
   ok &= hipMalloc((void**)&ctx->range_bits, 32 * sizeof(unsigned long long)) == hipSuccess;
   ok &= hipHostMalloc((void**)&ctx->host_pinned, 512 * sizeof(double), hipHostMallocDefault) == hipSuccess;
-  if (hipHostMalloc((void**)&ctx->mailbox, (size_t)kAccumBlocksMax * kMailboxStride * sizeof(double), hipHostMallocCoherent | hipHostMallocMapped) == hipSuccess)
-    std::memset(ctx->mailbox, 0, (size_t)kAccumBlocksMax * kMailboxStride * sizeof(double));
+  if (hipHostMalloc((void**)&ctx->mailbox, (size_t)kAccumBlocksMax * kMailboxStride * sizeof(unsigned long long), hipHostMallocCoherent | hipHostMallocMapped) == hipSuccess)
+    std::memset(ctx->mailbox, 0, (size_t)kAccumBlocksMax * kMailboxStride * sizeof(unsigned long long));
   else
     ctx->mailbox = nullptr;  // optional: lsa_accumulate falls back to a copy + synchronise
+  if (hipHostMalloc((void**)&ctx->lm_mailbox, (size_t)2 * kLmOut * sizeof(unsigned long long), hipHostMallocCoherent | hipHostMallocMapped) == hipSuccess)
+    std::memset(ctx->lm_mailbox, 0, (size_t)2 * kLmOut * sizeof(unsigned long long));
+  else
+    ctx->lm_mailbox = nullptr;  // optional: lsa_solve_device then reports LSA_E_STATE and the host-driven loop is used
+  ok &= hipMalloc((void**)&ctx->lm_xchg, (size_t)2 * kLmBlocksMax * kMailboxStride * sizeof(unsigned long long)) == hipSuccess;
+  if (ok) ok &= hipMemset(ctx->lm_xchg, 0, (size_t)2 * kLmBlocksMax * kMailboxStride * sizeof(unsigned long long)) == hipSuccess;
   if (const char* e = std::getenv("LSA_ACCUM_BLOCKS")) ctx->accum_blocks = std::min(std::max(std::atoi(e), 1), kAccumBlocksMax);
+  if (const char* e = std::getenv("LSA_LM_BLOCKS")) ctx->lm_blocks = std::min(std::max(std::atoi(e), 1), kLmBlocksMax);
+  if (const char* e = std::getenv("LSA_MAILBOX_CHECK")) ctx->mailbox_check = std::atoi(e) != 0;
   if (!ok) { lsa_ctx_destroy(ctx); return LSA_E_HIP; }
   *out = ctx;
   return LSA_OK;
@@ -322,6 +330,8 @@ void lsa_ctx_destroy(lsa_ctx* ctx)
   for (auto& s : ctx->store) fr(s.first);
   if (ctx->host_pinned) (void)hipHostFree(ctx->host_pinned);
   if (ctx->mailbox) (void)hipHostFree(ctx->mailbox);
+  if (ctx->lm_mailbox) (void)hipHostFree(ctx->lm_mailbox);
+  fr(ctx->lm_xchg);
   for (int i = 0; i < 2; ++i)
   {
     if (ctx->ev_join[i]) (void)hipEventDestroy(ctx->ev_join[i]);

@@ -1,0 +1,561 @@
+// lsa_lm.hip -- LocalOptimizer::Solve (slam_lib/src/LocalOptimizer.cxx:74-102) as ONE launch.
+//
+// The host-driven loop (host/lsa_lm.cpp) pays a kernel launch and a PCIe round trip per trust-region
+// evaluation, ~4 per solve, ~25 per frame.  Here the whole Levenberg-Marquardt loop of Ceres (unpinned
+// master >= 2.0 in the reference CI: TukeyLoss a^2/3, ScaledLoss(weight), DENSE_QR on a 6-column
+// Jacobian = the 6x6 normal equations, Solver::Options defaults) runs inside one kernel:
+//
+//   * every block evaluates its share of the residual blocks at the candidate pose (lsa_accum.h) and reduces
+//     it in a fixed order to 29 sums;
+//   * the blocks exchange those sums through 8-byte {tag, half of a double} granules in device memory, each
+//     ONE relaxed agent-scope atomic store / load (MI355X: `sc1`, write-through past the non-coherent per-XCD
+//     L2s): tag and payload are one memory object, so no fence, flag or ordering between locations is needed.
+//     Two parities of slots: a block can be at most one evaluation ahead of the slowest;
+//   * EVERY block folds all partial sums in block order and runs the 6x6 trust-region algebra itself -- same
+//     inputs, same instructions, same result in every block -- so the next candidate needs no broadcast;
+//   * block 0 hands pose, summary and the normal equations at the final point to the host through the same
+//     kind of granules in coherent host memory.
+// The arithmetic of the trust-region step is the host loop's, operation for operation (no FMA contraction, IEEE
+// division and square root): given the same sums both take the same decisions.  The sums differ in the last
+// bits (more blocks, and sin/cos of the angles come from lsa_pmath.h instead of libm).
+// Every spin is bounded: a block that waits too long gives up, the launch drains, the host falls back to the
+// host-driven loop and counts it (lsa_ctx::lm_fallbacks).
+#include <chrono>
+#include <cmath>
+#include "lsa_accum.h"
+#include "../../include/lsa_pmath.h"
+
+using namespace lsa;
+
+namespace
+{
+
+typedef unsigned long long u64;
+
+struct LmParams
+{
+  RecordSet set;
+  double x0[6];
+  int two_d;
+  int max_iter;
+  int min_matches;
+  unsigned tag_base;
+};
+
+// result layout (doubles): [0..5] pose, [6] initial cost, [7] final cost, [8..36] the 29 sums at the final
+// point, [37] successful steps, [38] unsuccessful steps, [39] iterations, [40] evaluations, [41] skipped,
+// [42] termination code, [43] matches, [44] failure (a spin ran out)
+constexpr int kResPose = 0, kResInitial = 6, kResFinal = 7, kResSums = 8, kResSuccessful = 37, kResUnsuccessful = 38, kResIterations = 39,
+              kResEvaluations = 40, kResSkipped = 41, kResCode = 42, kResMatches = 43, kResFailed = 44, kResCount = 45;
+static_assert(kResCount <= kLmOut, "result does not fit the mailbox");
+
+// index of H(a, b), a <= b, in the 29 sums (cost, g[6], upper triangle row by row, count)
+__device__ __forceinline__ constexpr int hidx(int a, int b) { return 7 + a * 6 - (a * (a - 1)) / 2 + (b - a); }
+__device__ __forceinline__ constexpr int hsym(int a, int b) { return a <= b ? hidx(a, b) : hidx(b, a); }
+
+// trust-region state between two evaluations (thread 0 of every block keeps its own copy in LDS: nothing of it is
+// live in registers while the residual blocks are evaluated)
+struct LmState
+{
+  double cur[kAccumVals];  // sums at the current point x
+  double x[6], scale[6], diag[6];
+  double radius, decrease_factor, x_norm, model_cost_change, delta_norm, initial_cost;
+  int reuse_diagonal, consecutive_invalid, iter;
+  int evaluations, successful, unsuccessful, iterations, code, skipped, matches;
+};
+
+struct Shared
+{
+  double wsum[4][kAccumVals];
+  unsigned gat[kLmBlocksMax][2 * kAccumVals];  // halves of every block's partial sums
+  double part[kAccumVals][8];
+  double tot[kAccumVals];   // the sums of the last evaluation over ALL residual blocks
+  double w[6];              // the point to evaluate next
+  double rot[39];           // R, dR/drx, dR/dry, dR/drz, t at w
+  LmState lm;
+  int failed;
+  int stop;
+};
+
+__device__ __forceinline__ double uniform(double v)
+{
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_readfirstlane((int)(b & 0xffffffffll)), hi = __builtin_amdgcn_readfirstlane((int)(b >> 32));
+  return __longlong_as_double(((long long)hi << 32) | (long long)(unsigned)lo);
+}
+
+// One evaluation at sh.w / sh.rot: sh.tot[] = the 29 sums over ALL residual blocks, identical in every block.
+// Returns false when a spin ran out (uniform over the block).
+__device__ __forceinline__ bool lm_evaluate(const LmParams& p, unsigned epoch, u64* __restrict__ xchg, Shared& sh)
+{
+  {
+    RotConst c;
+    // the same values in every lane: kept in scalar registers
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { c.R[i] = uniform(sh.rot[i]); c.dRx[i] = uniform(sh.rot[9 + i]); c.dRy[i] = uniform(sh.rot[18 + i]); c.dRz[i] = uniform(sh.rot[27 + i]); }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) c.t[i] = uniform(sh.rot[36 + i]);
+    double acc[kAccumVals];
+#pragma unroll
+    for (int v = 0; v < kAccumVals; ++v) acc[v] = 0.;
+    accumulate_records(p.set, c, true, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x, acc);
+    wave_reduce_accum(acc);
+    if ((threadIdx.x & 63) == 0)
+    {
+#pragma unroll
+      for (int v = 0; v < kAccumVals; ++v) sh.wsum[threadIdx.x >> 6][v] = acc[v];
+    }
+  }
+  if (threadIdx.x == 0) sh.failed = 0;
+  __syncthreads();
+  const unsigned tag = p.tag_base + epoch;
+  const int nb = gridDim.x;
+  u64* slots = xchg + (size_t)(epoch & 1u) * kLmBlocksMax * kMailboxStride;
+  if (threadIdx.x < 2 * kAccumVals)
+  {
+    const int v = threadIdx.x >> 1, half = threadIdx.x & 1;
+    const double r = ((sh.wsum[0][v] + sh.wsum[1][v]) + sh.wsum[2][v]) + sh.wsum[3][v];
+    const u64 bits = (u64)__double_as_longlong(r);
+    const unsigned word = half ? (unsigned)(bits >> 32) : (unsigned)(bits & 0xffffffffull);
+    __hip_atomic_store(slots + (size_t)blockIdx.x * kMailboxStride + threadIdx.x, ((u64)tag << 32) | word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  // gather: every thread sweeps its granules, a batch of loads in flight together, until every tag matches
+  const int total = nb * 2 * kAccumVals;
+  bool failed = false;
+  {
+    const unsigned long long t0 = wall_clock64();
+    unsigned spins = 0;
+    for (int base = threadIdx.x; base < total; base += 8 * 256)
+    {
+      while (true)
+      {
+        bool ok = true;
+        u64 x[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+        {
+          const int g = base + k * 256;
+          if (g < total)
+          {
+            const int b = g / (2 * kAccumVals), s = g - b * (2 * kAccumVals);
+            x[k] = __hip_atomic_load(slots + (size_t)b * kMailboxStride + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+        {
+          const int g = base + k * 256;
+          if (g < total)
+          {
+            if ((unsigned)(x[k] >> 32) == tag)
+            {
+              const int b = g / (2 * kAccumVals), s = g - b * (2 * kAccumVals);
+              sh.gat[b][s] = (unsigned)(x[k] & 0xffffffffull);
+            }
+            else ok = false;
+          }
+        }
+        if (ok) break;
+        // 100 MHz clock: 20 ms without the other blocks' sums (they are not resident, or gave up themselves)
+        if ((++spins & 15u) == 0 && wall_clock64() - t0 > 2000000ull) { failed = true; break; }
+        __builtin_amdgcn_s_sleep(2);
+      }
+      if (failed) break;
+    }
+  }
+  if (failed) atomicOr(&sh.failed, 1);
+  __syncthreads();
+  if (sh.failed) return false;
+  // fold in a fixed order: 8 partial sums per value over the blocks b = j, j + 8, ..., then the 8 in order
+  if (threadIdx.x < kAccumVals * 8)
+  {
+    const int v = threadIdx.x >> 3, j = threadIdx.x & 7;
+    double s = 0.;
+    for (int b = j; b < nb; b += 8)
+    {
+      const u64 bits = ((u64)sh.gat[b][2 * v + 1] << 32) | sh.gat[b][2 * v];
+      s += __longlong_as_double((long long)bits);
+    }
+    sh.part[v][j] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < kAccumVals)
+  {
+    double s = sh.part[threadIdx.x][0];
+#pragma unroll
+    for (int j = 1; j < 8; ++j) s += sh.part[threadIdx.x][j];
+    sh.tot[threadIdx.x] = s;
+  }
+  __syncthreads();
+  return true;
+}
+
+// dense symmetric positive definite solve, as SolveSPD of host/lsa_lm.cpp: Cholesky, forward, backward
+template <int N>
+__device__ __forceinline__ bool solve_spd(const double A[N * N], const double b[N], double x[N])
+{
+  double L[N * N];
+#pragma unroll
+  for (int i = 0; i < N * N; ++i) L[i] = 0.;
+  bool ok = true;
+#pragma unroll
+  for (int i = 0; i < N; ++i)
+#pragma unroll
+    for (int j = 0; j <= i; ++j)
+    {
+      double s = A[i * N + j];
+#pragma unroll
+      for (int k = 0; k < j; ++k) s -= L[i * N + k] * L[j * N + k];
+      if (i == j)
+      {
+        if (!(s > 0.0) || !isfinite(s)) ok = false;
+        L[i * N + i] = __builtin_sqrt(s);
+      }
+      else
+        L[i * N + j] = s / L[j * N + j];
+    }
+  if (!ok) return false;
+  double y[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i)
+  {
+    double s = b[i];
+#pragma unroll
+    for (int k = 0; k < i; ++k) s -= L[i * N + k] * y[k];
+    y[i] = s / L[i * N + i];
+  }
+#pragma unroll
+  for (int i = N - 1; i >= 0; --i)
+  {
+    double s = y[i];
+#pragma unroll
+    for (int k = i + 1; k < N; ++k) s -= L[k * N + i] * x[k];
+    x[i] = s / L[i * N + i];
+  }
+#pragma unroll
+  for (int i = 0; i < N; ++i)
+    if (!isfinite(x[i])) ok = false;
+  return ok;
+}
+
+enum LmCode
+{
+  kCodeNone = 0, kCodeNotEnoughMatches, kCodeGradient0, kCodeMaxIterations, kCodeGradient, kCodeMinRadius, kCodeInvalidSteps, kCodeParameterTolerance,
+  kCodeFunctionTolerance
+};
+
+// sh.w = the point to evaluate, sh.rot = its rotation and derivatives (CeresCostFunctions.h:67-79)
+__device__ __forceinline__ void set_point(Shared& sh, const double w[6])
+{
+#pragma unroll
+  for (int a = 0; a < 6; ++a) sh.w[a] = w[a];
+  double R[9], dRx[9], dRy[9], dRz[9];
+  rotation_and_derivatives(lsa_cos(w[3]), lsa_sin(w[3]), lsa_cos(w[4]), lsa_sin(w[4]), lsa_cos(w[5]), lsa_sin(w[5]), R, dRx, dRy, dRz);
+#pragma unroll
+  for (int i = 0; i < 9; ++i) { sh.rot[i] = R[i]; sh.rot[9 + i] = dRx[i]; sh.rot[18 + i] = dRy[i]; sh.rot[27 + i] = dRz[i]; }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) sh.rot[36 + i] = w[i];
+}
+
+// What the trust-region loop of host/lsa_lm.cpp (LocalOptimizer::Solve) does between two evaluations, N active
+// parameters: all 6, or (x, y, rz) in 2D mode (SubsetParameterization(6, {2, 3, 4}), LocalOptimizer.cxx:89-90).
+// In: sh.tot = the sums at sh.w (the start point when first, a candidate afterwards).  Out: sh.w / sh.rot = the next
+// candidate, or the return value true = the solve is over.  One thread runs it.
+template <int N>
+__device__ bool lm_step(const LmParams& p, Shared& sh, bool first)
+{
+  auto act = [](int a) constexpr { return N == 6 ? a : (a == 2 ? 5 : a); };
+  const double function_tolerance = 1e-6, gradient_tolerance = 1e-10, parameter_tolerance = 1e-8;
+  const double min_relative_decrease = 1e-3, min_trust_region_radius = 1e-32, max_radius = 1e16;
+  const double min_diagonal = 1e-6, max_diagonal = 1e32;
+  const int max_consecutive_invalid = 5;
+  LmState& lm = sh.lm;
+  auto grad_max = [&]() {
+    double m = 0;
+#pragma unroll
+    for (int a = 0; a < N; ++a) { const double v = __builtin_fabs(lm.cur[1 + act(a)]); m = m > v ? m : v; }  // std::max(m, v)
+    return m;
+  };
+  auto xnorm = [&]() {
+    double s = 0;
+#pragma unroll
+    for (int a = 0; a < N; ++a) s += lm.x[act(a)] * lm.x[act(a)];
+    return __builtin_sqrt(s);
+  };
+
+  if (first)
+  {
+    lm.matches = (int)sh.tot[28];
+    if (lm.matches < p.min_matches)
+    {
+      lm.skipped = 1;
+      lm.code = kCodeNotEnoughMatches;
+      return true;
+    }
+#pragma unroll
+    for (int v = 0; v < kAccumVals; ++v) lm.cur[v] = sh.tot[v];
+    lm.initial_cost = lm.cur[0];
+    lm.successful = 1;  // iteration 0 is reported as a successful step by Ceres
+#pragma unroll
+    for (int a = 0; a < N; ++a) lm.scale[a] = 1.0 / (1.0 + __builtin_sqrt(lm.cur[hidx(act(a), act(a))]));  // Jacobi scaling, once
+    if (grad_max() <= gradient_tolerance) { lm.code = kCodeGradient0; return true; }
+    lm.x_norm = xnorm();
+  }
+  else
+  {
+    // parameter / function tolerance terminate WITHOUT taking the candidate step
+    if (lm.delta_norm <= parameter_tolerance * (lm.x_norm + parameter_tolerance)) { lm.code = kCodeParameterTolerance; return true; }
+    const double cost_change = lm.cur[0] - sh.tot[0];
+    if (__builtin_fabs(cost_change) <= function_tolerance * lm.cur[0]) { lm.code = kCodeFunctionTolerance; return true; }
+    const double relative_decrease = cost_change / lm.model_cost_change;
+    if (relative_decrease > min_relative_decrease)
+    {
+#pragma unroll
+      for (int a = 0; a < 6; ++a) lm.x[a] = sh.w[a];
+      lm.x_norm = xnorm();
+      // cost AND Jacobian were evaluated at the candidate (Ceres evaluates the Jacobian again on acceptance, at the
+      // same point: same arithmetic, one evaluation less)
+#pragma unroll
+      for (int v = 0; v < kAccumVals; ++v) lm.cur[v] = sh.tot[v];
+      ++lm.successful;
+      const double t = 2.0 * relative_decrease - 1.0;
+      const double q = 1.0 - t * t * t;
+      const double d = (1.0 / 3.0) < q ? q : (1.0 / 3.0);  // std::max(1.0 / 3.0, q)
+      const double r = lm.radius / d;
+      lm.radius = r < max_radius ? r : max_radius;          // std::min(max_radius, r)
+      lm.decrease_factor = 2.0;
+      lm.reuse_diagonal = 0;
+    }
+    else
+    {
+      ++lm.unsuccessful;
+      lm.radius /= lm.decrease_factor; lm.decrease_factor *= 2.0; lm.reuse_diagonal = 1;
+    }
+  }
+
+  while (true)
+  {
+    if (lm.iter >= p.max_iter) { lm.code = kCodeMaxIterations; return true; }
+    if (grad_max() <= gradient_tolerance) { lm.code = kCodeGradient; return true; }
+    if (lm.radius < min_trust_region_radius) { lm.code = kCodeMinRadius; return true; }
+    ++lm.iter;
+    lm.iterations = lm.iter;
+
+    double Hs[N * N], gs[N];
+#pragma unroll
+    for (int a = 0; a < N; ++a)
+    {
+      gs[a] = lm.cur[1 + act(a)] * lm.scale[a];
+#pragma unroll
+      for (int b = 0; b < N; ++b) Hs[a * N + b] = lm.cur[hsym(act(a), act(b))] * lm.scale[a] * lm.scale[b];
+    }
+    if (!lm.reuse_diagonal)
+    {
+#pragma unroll
+      for (int a = 0; a < N; ++a)
+      {
+        const double h = Hs[a * N + a];
+        const double lo = h < min_diagonal ? min_diagonal : h;  // std::max(h, min_diagonal)
+        lm.diag[a] = max_diagonal < lo ? max_diagonal : lo;     // std::min(lo, max_diagonal)
+      }
+    }
+    double M[N * N], y[N], step[N];
+#pragma unroll
+    for (int i = 0; i < N * N; ++i) M[i] = Hs[i];
+#pragma unroll
+    for (int a = 0; a < N; ++a) M[a * N + a] += lm.diag[a] / lm.radius;
+#pragma unroll
+    for (int a = 0; a < N; ++a) y[a] = 0.;
+    bool ok = solve_spd<N>(M, gs, y);
+    lm.reuse_diagonal = 1;
+    double model_cost_change = 0;
+    if (ok)
+    {
+#pragma unroll
+      for (int a = 0; a < N; ++a) step[a] = -y[a];
+      double sg = 0, sHs = 0;
+#pragma unroll
+      for (int a = 0; a < N; ++a)
+      {
+        sg += step[a] * gs[a];
+        double t = 0;
+#pragma unroll
+        for (int b = 0; b < N; ++b) t += Hs[a * N + b] * step[b];
+        sHs += step[a] * t;
+      }
+      model_cost_change = -sg - 0.5 * sHs;
+      if (model_cost_change < 0.0) ok = false;
+    }
+    if (!ok)
+    {
+      ++lm.unsuccessful;
+      if (++lm.consecutive_invalid >= max_consecutive_invalid) { lm.code = kCodeInvalidSteps; return true; }
+      lm.radius /= lm.decrease_factor; lm.decrease_factor *= 2.0; lm.reuse_diagonal = 1;
+      continue;
+    }
+    lm.consecutive_invalid = 0;
+    lm.model_cost_change = model_cost_change;
+
+    double cand[6], delta_norm = 0;
+#pragma unroll
+    for (int a = 0; a < 6; ++a) cand[a] = lm.x[a];
+#pragma unroll
+    for (int a = 0; a < N; ++a)
+    {
+      cand[act(a)] = lm.x[act(a)] + step[a] * lm.scale[a];
+      const double e = lm.x[act(a)] - cand[act(a)];
+      delta_norm += e * e;
+    }
+    lm.delta_norm = __builtin_sqrt(delta_norm);
+    set_point(sh, cand);
+    ++lm.evaluations;
+    return false;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_lm_solve(LmParams p, u64* __restrict__ xchg, u64* __restrict__ mailbox, unsigned out_tag)
+{
+  __shared__ Shared sh;
+  if (threadIdx.x == 0)
+  {
+    LmState& lm = sh.lm;
+#pragma unroll
+    for (int v = 0; v < kAccumVals; ++v) lm.cur[v] = 0.;
+#pragma unroll
+    for (int a = 0; a < 6; ++a) { lm.x[a] = p.x0[a]; lm.scale[a] = 1.; lm.diag[a] = 0.; }
+    lm.radius = 1e4; lm.decrease_factor = 2.0; lm.x_norm = 0.; lm.model_cost_change = 0.; lm.delta_norm = 0.; lm.initial_cost = 0.;
+    lm.reuse_diagonal = 0; lm.consecutive_invalid = 0; lm.iter = 0;
+    lm.evaluations = 1; lm.successful = 0; lm.unsuccessful = 0; lm.iterations = 0; lm.code = kCodeNone; lm.skipped = 0; lm.matches = 0;
+    set_point(sh, p.x0);
+    sh.stop = 0;
+  }
+  __syncthreads();
+  bool failed = false;
+  // every evaluation of the launch has an epoch of its own; all blocks walk through the same sequence of them
+  for (unsigned epoch = 1;; ++epoch)
+  {
+    if (!lm_evaluate(p, epoch, xchg, sh)) { failed = true; break; }
+    if (threadIdx.x == 0) sh.stop = (p.two_d ? lm_step<3>(p, sh, epoch == 1) : lm_step<6>(p, sh, epoch == 1)) ? 1 : 0;
+    __syncthreads();
+    if (sh.stop) break;
+  }
+  if (blockIdx.x != 0) return;
+  // every block holds the same result; block 0's copy goes out as 2 granules per double
+  if (threadIdx.x < 2 * kResCount)
+  {
+    const LmState& lm = sh.lm;
+    const int v = threadIdx.x >> 1, half = threadIdx.x & 1;
+    double r = 0.;
+    if (v < kResInitial) r = lm.x[v - kResPose];
+    else if (v == kResInitial) r = lm.initial_cost;
+    else if (v == kResFinal) r = lm.cur[0];
+    else if (v < kResSums + kAccumVals) r = lm.cur[v - kResSums];
+    else if (v == kResSuccessful) r = lm.successful;
+    else if (v == kResUnsuccessful) r = lm.unsuccessful;
+    else if (v == kResIterations) r = lm.iterations;
+    else if (v == kResEvaluations) r = lm.evaluations;
+    else if (v == kResSkipped) r = lm.skipped;
+    else if (v == kResCode) r = lm.code;
+    else if (v == kResMatches) r = lm.matches;
+    else if (v == kResFailed) r = failed ? 1. : 0.;
+    const u64 bits = (u64)__double_as_longlong(r);
+    const unsigned word = half ? (unsigned)(bits >> 32) : (unsigned)(bits & 0xffffffffull);
+    __hip_atomic_store(mailbox + threadIdx.x, ((u64)out_tag << 32) | word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+const char* const kMessages[] = {"", "not enough matches", "gradient tolerance (iteration 0)", "max iterations", "gradient tolerance",
+                                 "min trust region radius", "too many invalid steps", "parameter tolerance", "function tolerance"};
+
+}  // namespace
+
+extern "C" {
+
+int lsa_solve_device(lsa_ctx* ctx, unsigned type_mask, const double prior[6], int two_d_mode, int lm_max_iter, int min_matches, lsa_solve_result_t* out)
+{
+  if (!ctx || !prior || !out) return ctx ? ctx->fail(LSA_E_ARG, "lsa_solve_device: bad argument") : LSA_E_ARG;
+  if (!ctx->lm_mailbox) return ctx->fail(LSA_E_STATE, "lsa_solve_device: no coherent host memory for the result");
+  LSA_HIP(ctx, hipSetDevice(ctx->device));
+  LmParams p;
+  int total = 0;
+  for (int k = 0; k < 3; ++k)
+  {
+    MatchBuf& mb = ctx->match[k];
+    const bool use = (type_mask >> k) & 1u && mb.valid && mb.k > 0;
+    p.set.rec[k] = mb.rec; p.set.status[k] = mb.status; p.set.cap[k] = mb.cap;
+    p.set.count[k] = use ? mb.k : 0;
+    p.set.sat2[k] = mb.sat * mb.sat;
+    total += p.set.count[k];
+  }
+  for (int a = 0; a < 6; ++a) p.x0[a] = prior[a];
+  p.two_d = two_d_mode ? 1 : 0;
+  p.max_iter = lm_max_iter < 0 ? 0 : lm_max_iter;
+  p.min_matches = min_matches;
+  // every evaluation of the launch takes a tag of its own; tags of earlier launches never come back within 2^32
+  p.tag_base = ctx->lm_tag;
+  ctx->lm_tag += (unsigned)p.max_iter + 4u;
+  const unsigned out_tag = (unsigned)(++ctx->lm_seq);
+  // about four residual blocks per thread, never more blocks than the exchange has slots for
+  const int nb = std::min(std::max((total + 1023) / 1024, 1), std::min(ctx->lm_blocks, kLmBlocksMax));
+  int stat = -1;
+  {
+    ProfScope ps(ctx, "lm_solve", 0.);
+    stat = ps.stat;
+    hipLaunchKernelGGL(k_lm_solve, dim3(nb), dim3(256), 0, ctx->stream, p, ctx->lm_xchg, ctx->lm_mailbox, out_tag);
+  }
+  // the result arrives as granules in coherent host memory (as lsa_accumulate's sums do)
+  double res[kResCount];
+  {
+    const auto t0 = std::chrono::steady_clock::now();
+    unsigned spins = 0;
+    for (int v = 0; v < kResCount; ++v)
+    {
+      unsigned long long g[2];
+      for (int h = 0; h < 2; ++h)
+        while (((g[h] = __atomic_load_n(ctx->lm_mailbox + 2 * v + h, __ATOMIC_RELAXED)) >> 32) != out_tag)
+        {
+          if ((++spins & 0x3ff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2000))
+          {
+            LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            return ctx->fail(LSA_E_STATE, "lsa_solve_device: no result from the device");
+          }
+#if defined(__x86_64__)
+          __builtin_ia32_pause();
+#endif
+        }
+      const unsigned long long bits = ((g[1] & 0xffffffffull) << 32) | (g[0] & 0xffffffffull);
+      std::memcpy(&res[v], &bits, sizeof(double));
+    }
+  }
+  if (res[kResFailed] != 0.)
+  {
+    LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));  // every block has given up or finished: the slots are quiet again
+    ctx->lm_fallbacks++;
+    return ctx->fail(LSA_E_STATE, "lsa_solve_device: a block waited too long for the others");
+  }
+  std::memset(out, 0, sizeof(*out));
+  for (int a = 0; a < 6; ++a) out->pose[a] = res[kResPose + a];
+  out->initial_cost = res[kResInitial];
+  out->final_cost = res[kResFinal];
+  out->cost = res[kResSums];
+  for (int a = 0; a < 6; ++a) out->g[a] = res[kResSums + 1 + a];
+  {
+    int h = kResSums + 7;
+    for (int a = 0; a < 6; ++a)
+      for (int b = a; b < 6; ++b) { out->H[a * 6 + b] = res[h]; out->H[b * 6 + a] = res[h]; ++h; }
+  }
+  out->num_successful_steps = (int)res[kResSuccessful];
+  out->num_unsuccessful_steps = (int)res[kResUnsuccessful];
+  out->num_iterations = (int)res[kResIterations];
+  out->num_evaluations = (int)res[kResEvaluations];
+  out->skipped = (int)res[kResSkipped];
+  out->termination = (int)res[kResCode];
+  out->num_matches = (int)res[kResMatches];
+  out->message = kMessages[std::min(std::max(out->termination, 0), 8)];
+  if (stat >= 0 && ctx->profiling) ctx->stats[stat].bytes += (double)out->num_evaluations * total * 129;
+  return LSA_OK;
+}
+
+int lsa_solve_device_fallbacks(const lsa_ctx* ctx) { return ctx ? ctx->lm_fallbacks : 0; }
+
+}  // extern "C"

@@ -27,6 +27,7 @@
 #include <cmath>
 #include "lsa_ctx.h"
 #include "lsa_device_math.h"
+#include "lsa_accum.h"
 
 using namespace lsa;
 
@@ -1023,152 +1024,40 @@ __global__ void k_fill_status(uint8_t* __restrict__ status, double* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------
-struct AccumConst
-{
-  double R[9], dRx[9], dRy[9], dRz[9];
-  double t[3];
-  const double* rec[3];
-  const uint8_t* status[3];
-  int count[3];
-  int cap[3];
-  double sat2[3];  // Tukey a^2 per type
-  int jac;
-};
-
-__device__ __forceinline__ void mv3(const double M[9], double x, double y, double z, double& ox, double& oy, double& oz)
-{
-  ox = (M[0] * x + M[1] * y) + M[2] * z;
-  oy = (M[3] * x + M[4] * y) + M[5] * z;
-  oz = (M[6] * x + M[7] * y) + M[8] * z;
-}
-
-// x of this lane's half (rows) + x of the partner half (rows): first operand + second operand, as lane i < W gets
-// from a shuffle-down by W
-template <int W>
-__device__ __forceinline__ double swap_add(double x)
-{
-  const long long b = __double_as_longlong(x);
-  const unsigned xl = (unsigned)(b & 0xffffffffll), xh = (unsigned)((unsigned long long)b >> 32);
-  const auto lo = W == 32 ? __builtin_amdgcn_permlane32_swap(xl, xl, false, false) : __builtin_amdgcn_permlane16_swap(xl, xl, false, false);
-  const auto hi = W == 32 ? __builtin_amdgcn_permlane32_swap(xh, xh, false, false) : __builtin_amdgcn_permlane16_swap(xh, xh, false, false);
-  const double a = __longlong_as_double((long long)(((unsigned long long)hi[0] << 32) | lo[0]));  // lower half / even rows, everywhere
-  const double c = __longlong_as_double((long long)(((unsigned long long)hi[1] << 32) | lo[1]));  // upper half / odd rows, everywhere
-  return a + c;
-}
-
-// value of lane (i + o) of the same row of 16 lanes, 0 where that lane does not exist (o = 1, 2, 4, 8)
-__device__ __forceinline__ double dpp_row_shl(double x, int o)
-{
-  const long long b = __double_as_longlong(x);
-  int lo = (int)(b & 0xffffffffll), hi = (int)(b >> 32);
-  switch (o)
-  {
-    case 8: lo = __builtin_amdgcn_update_dpp(0, lo, 0x108, 0xF, 0xF, true); hi = __builtin_amdgcn_update_dpp(0, hi, 0x108, 0xF, 0xF, true); break;
-    case 4: lo = __builtin_amdgcn_update_dpp(0, lo, 0x104, 0xF, 0xF, true); hi = __builtin_amdgcn_update_dpp(0, hi, 0x104, 0xF, 0xF, true); break;
-    case 2: lo = __builtin_amdgcn_update_dpp(0, lo, 0x102, 0xF, 0xF, true); hi = __builtin_amdgcn_update_dpp(0, hi, 0x102, 0xF, 0xF, true); break;
-    default: lo = __builtin_amdgcn_update_dpp(0, lo, 0x101, 0xF, 0xF, true); hi = __builtin_amdgcn_update_dpp(0, hi, 0x101, 0xF, 0xF, true); break;
-  }
-  return __longlong_as_double(((long long)hi << 32) | (long long)(unsigned)lo);
-}
-
-__global__ __launch_bounds__(256) void k_accumulate(AccumConst c, double* __restrict__ partials, double* __restrict__ mailbox, unsigned long long seq)
+// One evaluation of the residual blocks (lsa_accum.h) per launch: the host-driven trust region (lsa_accumulate).
+__global__ __launch_bounds__(256) void k_accumulate(AccumConst c, double* __restrict__ partials, unsigned long long* __restrict__ mailbox, unsigned tag)
 {
   double acc[kAccumVals];
 #pragma unroll
   for (int v = 0; v < kAccumVals; ++v) acc[v] = 0.;
-  const int total = c.count[0] + c.count[1] + c.count[2];
-  for (int gidx = blockIdx.x * blockDim.x + threadIdx.x; gidx < total; gidx += gridDim.x * blockDim.x)
-  {
-    int t = 0, i = gidx;
-    if (i >= c.count[0]) { i -= c.count[0]; t = 1; if (i >= c.count[1]) { i -= c.count[1]; t = 2; } }
-    if (c.status[t][i] != LSA_MATCH_SUCCESS) continue;
-    const double* rec = c.rec[t];
-    const size_t cap = (size_t)c.cap[t];
-    double A[9];
-#pragma unroll
-    for (int f = 0; f < 9; ++f) A[f] = rec[f * cap + i];
-    const double Px = rec[9 * cap + i], Py = rec[10 * cap + i], Pz = rec[11 * cap + i];
-    const double Xx = rec[12 * cap + i], Xy = rec[13 * cap + i], Xz = rec[14 * cap + i];
-    const double weight = rec[15 * cap + i];
-    double yx, yy, yz;
-    mv3(c.R, Xx, Xy, Xz, yx, yy, yz);
-    const double dx = (yx + c.t[0]) - Px, dy = (yy + c.t[1]) - Py, dz = (yz + c.t[2]) - Pz;
-    double r0, r1, r2;
-    mv3(A, dx, dy, dz, r0, r1, r2);
-    const double s = (r0 * r0 + r1 * r1) + r2 * r2;
-    const double a2 = c.sat2[t];
-    double rho0, rho1;
-    if (s <= a2)
-    {
-      const double value = 1.0 - s / a2;
-      const double value_sq = value * value;
-      rho0 = a2 / 3.0 * (1.0 - value_sq * value);
-      rho1 = value_sq;
-    }
-    else { rho0 = a2 / 3.0; rho1 = 0.0; }
-    rho0 *= weight; rho1 *= weight;
-    acc[0] += 0.5 * rho0;
-    acc[28] += 1.0;
-    if (!c.jac) continue;
-    double J[3][6];
-#pragma unroll
-    for (int a = 0; a < 3; ++a)
-#pragma unroll
-      for (int b = 0; b < 3; ++b) J[a][b] = A[a * 3 + b];
-    double vx, vy, vz, cx, cy, cz;
-    mv3(c.dRx, Xx, Xy, Xz, vx, vy, vz); mv3(A, vx, vy, vz, cx, cy, cz); J[0][3] = cx; J[1][3] = cy; J[2][3] = cz;
-    mv3(c.dRy, Xx, Xy, Xz, vx, vy, vz); mv3(A, vx, vy, vz, cx, cy, cz); J[0][4] = cx; J[1][4] = cy; J[2][4] = cz;
-    mv3(c.dRz, Xx, Xy, Xz, vx, vy, vz); mv3(A, vx, vy, vz, cx, cy, cz); J[0][5] = cx; J[1][5] = cy; J[2][5] = cz;
-    int h = 7;
-#pragma unroll
-    for (int a = 0; a < 6; ++a)
-    {
-      acc[1 + a] += rho1 * ((J[0][a] * r0 + J[1][a] * r1) + J[2][a] * r2);
-#pragma unroll
-      for (int b = a; b < 6; ++b) acc[h++] += rho1 * ((J[0][a] * J[0][b] + J[1][a] * J[1][b]) + J[2][a] * J[2][b]);
-    }
-  }
-  // fixed-order reduction: wavefront shuffles, then the 4 waves through LDS
+  accumulate_records(c.set, c.rot, c.jac != 0, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x, acc);
+  // fixed-order reduction: wavefront (permlane swaps + DPP), then the 4 waves through LDS
   __shared__ double wsum[4][kAccumVals];
-  // one shuffle step for all 29 values at a time: 29 independent LDS permutes in flight per step
-  // instead of 29 chains of 6 dependent ones
-  // across the four rows of 16 lanes: v_permlane32_swap / v_permlane16_swap (gfx950) hand every lane its partner's
-  // value in one VALU pass -- lower half + upper half, then row 0 + row 1 -- the same pairs, in the same order,
-  // as a shuffle-down by 32 and by 16 gives lane 0
-#pragma unroll
-  for (int v = 0; v < kAccumVals; ++v) acc[v] = swap_add<32>(acc[v]);
-#pragma unroll
-  for (int v = 0; v < kAccumVals; ++v) acc[v] = swap_add<16>(acc[v]);
-  // inside a row of 16 lanes the partner's value comes through a DPP operand (row_shr), not through LDS;
-  // lanes the shift leaves without a partner read 0 -- only lane 0's sum is kept
-#pragma unroll
-  for (int o = 8; o > 0; o >>= 1)
-  {
-#pragma unroll
-    for (int v = 0; v < kAccumVals; ++v) acc[v] += dpp_row_shl(acc[v], o);
-  }
+  wave_reduce_accum(acc);
   if ((threadIdx.x & 63) == 0)
   {
 #pragma unroll
     for (int v = 0; v < kAccumVals; ++v) wsum[threadIdx.x >> 6][v] = acc[v];
   }
   __syncthreads();
-  // Zero-copy hand-over: the block's 29 partial sums land in coherent host memory as ten aligned 32-byte
-  // pieces of 3 values + the evaluation's sequence number in the piece's last word.  One store instruction
-  // writes them all; 32 bytes is the smallest unit a write is ever split into, so a piece's tag never arrives
-  // without its values: the host polls the tags -- no fence, no flag, no second kernel, no D2H copy, no stream
-  // synchronisation on the LM critical path -- and folds the blocks in index order (as k_accumulate_final does).
-  if (threadIdx.x < kMailboxStride)
+  // Zero-copy hand-over: the block's 29 partial sums land in coherent host memory as 58 granules.  A granule is
+  // ONE naturally aligned 8-byte word -- the evaluation's tag above, one half of a double below -- written by ONE
+  // relaxed system-scope atomic store: tag and payload are the same memory object, so the payload can never be
+  // seen without its tag, whatever order the fabric delivers the lanes' stores in.  The host polls the granules
+  // (relaxed 64-bit atomic loads) and folds the blocks in index order (as k_accumulate_final does): no fence, no
+  // flag, no second kernel, no D2H copy, no stream synchronisation on the LM critical path.
+  if (threadIdx.x < 2 * kAccumVals)
   {
-    const int chunk = threadIdx.x >> 2, slot = threadIdx.x & 3, v = chunk * 3 + slot;
-    double r = 0.;
-    if (slot < 3 && v < kAccumVals)
+    const int v = threadIdx.x >> 1, half = threadIdx.x & 1;
+    const double r = ((wsum[0][v] + wsum[1][v]) + wsum[2][v]) + wsum[3][v];
+    if (half == 0) partials[(size_t)blockIdx.x * kAccumVals + v] = r;
+    if (mailbox)
     {
-      r = ((wsum[0][v] + wsum[1][v]) + wsum[2][v]) + wsum[3][v];
-      partials[(size_t)blockIdx.x * kAccumVals + v] = r;
+      const unsigned long long bits = (unsigned long long)__double_as_longlong(r);
+      const unsigned word = half ? (unsigned)(bits >> 32) : (unsigned)(bits & 0xffffffffull);
+      __hip_atomic_store(mailbox + (size_t)blockIdx.x * kMailboxStride + threadIdx.x, ((unsigned long long)tag << 32) | word, __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_SYSTEM);
     }
-    if (slot == 3) r = __longlong_as_double((long long)seq);
-    if (mailbox) mailbox[(size_t)blockIdx.x * kMailboxStride + threadIdx.x] = r;
   }
 }
 
@@ -1859,70 +1748,65 @@ int lsa_accumulate(lsa_ctx* ctx, unsigned type_mask, const double w[6], int want
   LSA_HIP(ctx, hipSetDevice(ctx->device));
   AccumConst c;
   // R = Rz Ry Rx and its partial derivatives (CeresCostFunctions.h:67-79), once per evaluation on the host
-  {
-    const double cx = std::cos(w[3]), sx = std::sin(w[3]);
-    const double cy = std::cos(w[4]), sy = std::sin(w[4]);
-    const double cz = std::cos(w[5]), sz = std::sin(w[5]);
-    const double R[9] = {cy * cz, sx * sy * cz - cx * sz, cx * sy * cz + sx * sz, cy * sz, sx * sy * sz + cx * cz, cx * sy * sz - sx * cz, -sy, sx * cy, cx * cy};
-    const double dRx[9] = {0, cx * sy * cz + sx * sz, -sx * sy * cz + cx * sz, 0, cx * sy * sz - sx * cz, -sx * sy * sz - cx * cz, 0, cx * cy, -sx * cy};
-    const double dRy[9] = {-sy * cz, sx * cy * cz, cx * cy * cz, -sy * sz, sx * cy * sz, cx * cy * sz, -cy, -sx * sy, -cx * sy};
-    const double dRz[9] = {-cy * sz, -sx * sy * sz - cx * cz, -cx * sy * sz + sx * cz, cy * cz, sx * sy * cz - cx * sz, cx * sy * cz + sx * sz, 0, 0, 0};
-    std::memcpy(c.R, R, sizeof(R)); std::memcpy(c.dRx, dRx, sizeof(R)); std::memcpy(c.dRy, dRy, sizeof(R)); std::memcpy(c.dRz, dRz, sizeof(R));
-    c.t[0] = w[0]; c.t[1] = w[1]; c.t[2] = w[2];
-  }
+  rotation_and_derivatives(std::cos(w[3]), std::sin(w[3]), std::cos(w[4]), std::sin(w[4]), std::cos(w[5]), std::sin(w[5]), c.rot.R, c.rot.dRx, c.rot.dRy, c.rot.dRz);
+  c.rot.t[0] = w[0]; c.rot.t[1] = w[1]; c.rot.t[2] = w[2];
   int total = 0;
   for (int k = 0; k < 3; ++k)
   {
     MatchBuf& mb = ctx->match[k];
     const bool use = (type_mask >> k) & 1u && mb.valid && mb.k > 0;
-    c.rec[k] = mb.rec; c.status[k] = mb.status; c.cap[k] = mb.cap;
-    c.count[k] = use ? mb.k : 0;
-    c.sat2[k] = mb.sat * mb.sat;
-    total += c.count[k];
+    c.set.rec[k] = mb.rec; c.set.status[k] = mb.status; c.set.cap[k] = mb.cap;
+    c.set.count[k] = use ? mb.k : 0;
+    c.set.sat2[k] = mb.sat * mb.sat;
+    total += c.set.count[k];
   }
   c.jac = want_jacobian;
   hipStream_t st = ctx->stream;
+  const unsigned want = (unsigned)(++ctx->mailbox_seq);
   {
-    ProfScope ps(ctx, want_jacobian ? "accumulate_jac" : "accumulate_cost", (double)total * (want_jacobian ? 129 : 129));
-    hipLaunchKernelGGL(k_accumulate, dim3(ctx->accum_blocks), dim3(256), 0, st, c, ctx->partials, ctx->mailbox, ++ctx->mailbox_seq);
+    ProfScope ps(ctx, want_jacobian ? "accumulate_jac" : "accumulate_cost", (double)total * 129);
+    hipLaunchKernelGGL(k_accumulate, dim3(ctx->accum_blocks), dim3(256), 0, st, c, ctx->partials, ctx->mailbox, want);
   }
   double* hp = ctx->host_pinned + 64;
   bool got = false;
   if (ctx->mailbox)
   {
-    // poll the pieces' tags (bounded: fall back to a device fold + synchronous copy if one does not arrive)
+    // poll the granules (bounded: fall back to a device fold + synchronous copy if one does not arrive); the blocks
+    // are folded in index order as they come in
     const auto t0 = std::chrono::steady_clock::now();
     unsigned spins = 0;
     bool timeout = false;
-    const unsigned long long want = ctx->mailbox_seq;
+    for (int v = 0; v < kAccumVals; ++v) hp[v] = 0.;
     for (int b = 0; b < ctx->accum_blocks && !timeout; ++b)
-      for (int c = 0; c < kMailboxStride / 4 && !timeout; ++c)
-      {
-        volatile unsigned long long* tag = reinterpret_cast<volatile unsigned long long*>(ctx->mailbox + (size_t)b * kMailboxStride + c * 4 + 3);
-        while (__atomic_load_n(tag, __ATOMIC_ACQUIRE) != want)
-        {
-          if ((++spins & 0x3ff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) { timeout = true; break; }
-#if defined(__x86_64__)
-          __builtin_ia32_pause();
-#endif
-        }
-      }
-    if (!timeout)
     {
-      for (int v = 0; v < kAccumVals; ++v) hp[v] = 0.;
-      for (int b = 0; b < ctx->accum_blocks; ++b)
+      const unsigned long long* row = ctx->mailbox + (size_t)b * kMailboxStride;
+      for (int v = 0; v < kAccumVals && !timeout; ++v)
       {
-        const volatile double* row = ctx->mailbox + (size_t)b * kMailboxStride;
-        for (int v = 0; v < kAccumVals; ++v) hp[v] += row[(v / 3) * 4 + (v % 3)];
+        unsigned long long g[2];
+        for (int h = 0; h < 2 && !timeout; ++h)
+          while (((g[h] = __atomic_load_n(row + 2 * v + h, __ATOMIC_RELAXED)) >> 32) != want)
+          {
+            if ((++spins & 0x3ff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) { timeout = true; break; }
+#if defined(__x86_64__)
+            __builtin_ia32_pause();
+#endif
+          }
+        const unsigned long long bits = ((g[1] & 0xffffffffull) << 32) | (g[0] & 0xffffffffull);
+        double d;
+        std::memcpy(&d, &bits, sizeof(d));
+        hp[v] += d;
       }
-      got = true;
     }
+    got = !timeout;
   }
-  if (!got)
+  if (!got || ctx->mailbox_check)
   {
+    double* dst = got ? ctx->host_pinned + 96 : hp;
     hipLaunchKernelGGL(k_accumulate_final, dim3(1), dim3(64), 0, st, ctx->partials, ctx->accum_blocks, ctx->reduce_out);
-    LSA_HIP(ctx, hipMemcpyAsync(hp, ctx->reduce_out, kAccumVals * sizeof(double), hipMemcpyDeviceToHost, st));
+    LSA_HIP(ctx, hipMemcpyAsync(dst, ctx->reduce_out, kAccumVals * sizeof(double), hipMemcpyDeviceToHost, st));
     LSA_HIP(ctx, hipStreamSynchronize(st));
+    // LSA_MAILBOX_CHECK: what came through the mailbox must be bit for bit what the device folds from its own partials
+    if (got && std::memcmp(dst, hp, kAccumVals * sizeof(double)) != 0) return ctx->fail(LSA_E_STATE, "lsa_accumulate: mailbox and device fold disagree");
   }
   *cost = hp[0];
   if (n_valid) *n_valid = (int)hp[28];

@@ -18,21 +18,33 @@ def sequence_seed(rank, base=1000):
 
 
 class PoseExchange:
-    """All-gathers the latest pose of every sequence.  `device` is 'cuda' (RCCL) or 'cpu' (gloo)."""
+    """All-gathers the latest pose of every sequence.  `device` is 'cuda' (RCCL) or 'cpu' (gloo).
 
-    def __init__(self, world, device="cuda", per_rank=1):
+    Exchanges may overlap the caller's next steps, and the caller may post step f + 1 before it waits for step f: every
+    exchange in flight owns one of `depth` buffer sets (pinned staging row, device row, gathered table), and a set is
+    only reused after the exchange that used it last has completed (`post_rows` waits for it itself if the caller did
+    not) -- no copy or collective ever reads or writes a buffer another one still uses."""
+
+    def __init__(self, world, device="cuda", per_rank=1, depth=2, always_collective=False):
         import torch
+
+        self.always_collective = always_collective  # world == 1 normally needs no process group: tests force the collective
 
         self.torch = torch
         self.world = world
         self.device = device
         self.per_rank = per_rank  # sequences replayed side by side on one GPU: their poses travel together
-        self.mine = torch.zeros(POSE_WORDS * per_rank, dtype=torch.float64, device=device)
-        self.table = torch.zeros(POSE_WORDS * per_rank * world, dtype=torch.float64, device=device)
-        self.host = torch.zeros(POSE_WORDS * per_rank, dtype=torch.float64)
+        n = POSE_WORDS * per_rank
+        self.depth = max(int(depth), 1)
+        self.mine = [torch.zeros(n, dtype=torch.float64, device=device) for _ in range(self.depth)]
+        self.tables = [torch.zeros(n * world, dtype=torch.float64, device=device) for _ in range(self.depth)]
+        self.hosts = [torch.zeros(n, dtype=torch.float64) for _ in range(self.depth)]
+        self.inflight = [None] * self.depth
+        self.posted = 0
+        self.table = self.tables[0]  # the table of the last completed exchange
         self.side = None
         if device == "cuda":
-            self.host = self.host.pin_memory()
+            self.hosts = [h.pin_memory() for h in self.hosts]
             self.side = torch.cuda.Stream()
 
     def post(self, pose4x4, stamp_s):
@@ -45,24 +57,57 @@ class PoseExchange:
     def post_rows(self, rows):
         """Same for the (per_rank, 17) latest pose rows of all the sequences this rank replays."""
         rows = self.torch.from_numpy(np.ascontiguousarray(rows, np.float64).reshape(POSE_WORDS * self.per_rank))
-        if self.world == 1:
-            self.table.copy_(rows)
+        slot = self.posted % self.depth
+        self.posted += 1
+        if self.inflight[slot] is not None:
+            self.inflight[slot].wait()  # the exchange that used this buffer set last
+        host, mine, table = self.hosts[slot], self.mine[slot], self.tables[slot]
+        if self.world == 1 and not self.always_collective:
+            table.copy_(rows)
+            self.table = table
             return None
         import torch.distributed as dist
 
-        self.host.copy_(rows)
+        host.copy_(rows)
+        done = None
         if self.side is not None:
             with self.torch.cuda.stream(self.side):
-                self.mine.copy_(self.host, non_blocking=True)
-                return dist.all_gather_into_tensor(self.table, self.mine, async_op=True)
-        self.mine.copy_(self.host)
-        return dist.all_gather_into_tensor(self.table, self.mine, async_op=True)
+                mine.copy_(host, non_blocking=True)
+                work = dist.all_gather_into_tensor(table, mine, async_op=True)
+                work.wait()  # RCCL: orders the side stream behind the collective, the host does not block
+                done = self.torch.cuda.Event()
+                done.record(self.side)  # copy and collective of THIS exchange are over when the event is
+        else:
+            mine.copy_(host)
+            work = dist.all_gather_into_tensor(table, mine, async_op=True)
+        handle = _Exchange(self, slot, work, done)
+        self.inflight[slot] = handle
+        return handle
 
     def poses(self):
         """(sequences, 4, 4) poses and (sequences,) stamps of the last completed exchange, rank-major."""
         n = self.world * self.per_rank
         t = self.table.detach().cpu().numpy().reshape(n, POSE_WORDS)
         return t[:, :16].reshape(n, 4, 4).copy(), t[:, 16].copy()
+
+
+class _Exchange:
+    """Handle of one exchange: wait() completes it (once) and makes its table the current one."""
+
+    def __init__(self, owner, slot, work, done=None):
+        self.owner, self.slot, self.work, self.done = owner, slot, work, done
+
+    def wait(self):
+        if self.work is None:
+            return
+        if self.done is not None:
+            self.done.synchronize()  # this exchange's copy and collective on the side stream, nothing later
+        else:
+            self.work.wait()
+        self.work = None
+        self.owner.table = self.owner.tables[self.slot]
+        if self.owner.inflight[self.slot] is self:
+            self.owner.inflight[self.slot] = None
 
 
 class ConcurrentReplay:

@@ -279,10 +279,83 @@ def test_interpolated_bounding_boxes_are_those_of_the_undistorted_keypoints(gpu_
     assert np.abs(rn - mn).max() > 0.05
 
 
-def test_normal_equations_arrive_through_the_mailbox(gpu_ctx, L):
-    """the fast hand-over of lsa_accumulate (partial sums written straight into coherent host memory) is in use: its
-    fallback gives the same numbers at about twice the latency, which only a benchmark would notice"""
+def test_normal_equations_arrive_through_the_mailbox(gpu_ctx, O, L, kps):
+    """the fast hand-over of lsa_accumulate (partial sums written straight into coherent host memory as 8-byte
+    {tag, half} granules, one atomic store each) is in use, and what arrives through it is bit for bit what the device
+    folds from its own per-block partials (LSA_MAILBOX_CHECK makes every evaluation do that comparison itself and
+    fail on a difference)"""
+    import os
+
     assert L.lib().lsa_mailbox_active(gpu_ctx.h) == 1
+    os.environ["LSA_MAILBOX_CHECK"] = "1"
+    try:
+        ctx = L.Context(0)
+    finally:
+        del os.environ["LSA_MAILBOX_CHECK"]
+    setup_residuals(ctx, O, L, kps, 128)
+    setup_residuals(gpu_ctx, O, L, kps, 128)
+    rng = np.random.default_rng(5)
+    for i in range(200):
+        w6 = np.array([0.45, 0.01, -0.02, 0.001, -0.002, 0.012]) + 0.01 * rng.standard_normal(6)
+        a = ctx.accumulate(7, w6)  # raises if mailbox and device fold disagree
+        if i % 20 == 0:
+            b = gpu_ctx.accumulate(7, w6)
+            assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and a[3] == b[3]
+    # a whole pipeline under the check
+    os.environ["LSA_MAILBOX_CHECK"] = "1"
+    try:
+        s = L.Slam(0, EgoMotion=3, DeviceLM=0)
+    finally:
+        del os.environ["LSA_MAILBOX_CHECK"]
+    for f in range(4):
+        pts, stamp = L.synth_frame(16, 1000, f)
+        s.add_frame(pts, stamp, f)
+    s.close()
+    ctx.close()
+
+
+@pytest.mark.parametrize("two_d", [False, True])
+@pytest.mark.parametrize("model", [16, 128])
+def test_one_launch_solve_equals_the_host_driven_loop(gpu_ctx, O, L, kps, two_d, model):
+    """lsa_solve_device: the trust-region loop of LocalOptimizer::Solve inside one kernel (blocks exchanging their
+    partial sums through tagged granules) takes the decisions of the host-driven loop and of the oracle"""
+    rec, st = setup_residuals(gpu_ctx, O, L, kps, model)
+    for dx, yaw in ((0.3, 0.0), (0.45, 0.01), (0.0, 0.0)):
+        prior = perturbed(dx, yaw)
+        w0 = np.array([dx, 0.02, 0.0, 0.0, 0.0, yaw])
+        r = gpu_ctx.solve_device(7, w0, max_iter=15, two_d=two_d)
+        pose, summ, costs = gpu_ctx.solve(7, prior, max_iter=15, two_d=two_d)
+        po, wo, so, co = O.lm_solve(rec, st, 5.0, prior, max_iter=15, two_d=two_d)
+        assert (r.num_successful_steps, r.num_iterations) == (summ[0], summ[2]) == (so[0], so[2])
+        assert r.num_evaluations == summ[3] and not r.skipped
+        assert np.abs(np.array(r.pose) - wo).max() < 1e-9, (list(r.pose), wo)
+        assert abs(r.final_cost - costs[1]) <= 1e-10 * costs[1] and abs(r.initial_cost - costs[0]) <= 1e-10 * costs[0]
+        # the normal equations it returns are those at the returned pose
+        c, g, H, nv = gpu_ctx.accumulate(7, np.array(r.pose))
+        assert nv == r.num_matches and abs(c - r.cost) <= 1e-10 * c
+        assert np.abs(np.array(r.H).reshape(6, 6) - H).max() <= 1e-10 * np.abs(H).max()
+        assert np.abs(np.array(r.g) - g).max() <= 1e-8 * max(np.abs(g).max(), 1e-3 * np.abs(H).max())
+    # bitwise reproducible, launch after launch
+    a = gpu_ctx.solve_device(7, w0, max_iter=15, two_d=two_d)
+    b = gpu_ctx.solve_device(7, w0, max_iter=15, two_d=two_d)
+    assert list(a.pose) == list(b.pose) and a.final_cost == b.final_cost and list(a.H) == list(b.H)
+    # fewer matches than asked for: nothing is optimised, the prior comes back (Slam.cxx:919-923, 1098-1107)
+    s = gpu_ctx.solve_device(7, w0, max_iter=15, two_d=two_d, min_matches=10 ** 7)
+    assert s.skipped == 1 and s.num_evaluations == 1 and list(s.pose) == list(w0) and s.num_matches == a.num_matches
+    # iteration cap
+    m = gpu_ctx.solve_device(7, np.array([0.45, 0.02, 0, 0, 0, 0.01]), max_iter=1, two_d=two_d)
+    assert m.num_iterations == 1 and m.termination in (3, 7, 8)
+    assert gpu_ctx.solve_device_fallbacks() == 0
+
+
+def test_one_launch_solve_with_no_residuals(gpu_ctx, L):
+    for k in range(3):
+        gpu_ctx.set_keypoints(L.SET_WORKING, k, np.zeros(0, L.POINT_DTYPE))
+        gpu_ctx.match(k, L.SET_WORKING, L.MatchParams.localization(saturation_distance=2.0), np.eye(4))
+    r = gpu_ctx.solve_device(7, np.zeros(6), min_matches=20)
+    assert r.skipped == 1 and r.num_matches == 0
+    r = gpu_ctx.solve_device(7, np.zeros(6), min_matches=0)
+    assert r.skipped == 0 and r.termination == 2 and r.num_successful_steps == 1
 
 
 def test_targets_prepared_ahead_give_the_same_matches(O, L, kps):

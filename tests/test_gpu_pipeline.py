@@ -569,3 +569,27 @@ def test_lookahead_extraction_changes_nothing_but_the_schedule(L):
     s.add_stored_frame(0, frames[0][1], 0)
     assert s.keypoints(L.PLANE, 2).tobytes() == plain[1][0][1]
     s.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("two_d", [0, 1])
+def test_one_launch_lm_and_host_driven_lm_agree(L, O, two_d):
+    """DeviceLM: LocalOptimizer::Solve as one launch (lsa_solve_device) against one launch per evaluation
+    (host/lsa_lm.cpp): the same trust-region decisions frame after frame (evaluations, ICP iterations, keyframes), poses
+    equal to rounding, both on the oracle; the covariance comes from the normal equations the solve returns"""
+    a, b, o = L.Slam(0, EgoMotion=3, DeviceLM=1, TwoDMode=two_d), L.Slam(0, EgoMotion=3, DeviceLM=0, TwoDMode=two_d), O.Slam(EgoMotion=3, TwoDMode=two_d)
+    for f in range(10):
+        pts, stamp = L.synth_frame(16, 1000, f)
+        for s in (a, b, o):
+            s.add_frame(pts, stamp, f)
+        dp, da = pose_diff(b.world_transform(), a.world_transform())
+        assert dp < 1e-9 and da < 1e-8, (f, dp, da)
+        dp, da = pose_diff(o.world_transform(), a.world_transform())
+        assert dp < 1e-7 and da < 1e-6, (f, dp, da)
+        sa, sb = a.stats(), b.stats()
+        assert sa[9:14].tolist() == sb[9:14].tolist(), (f, sa[9:14], sb[9:14])  # ICP iterations, LM evaluations, matches, keyframes
+        ca, cb = a.covariance(), b.covariance()
+        assert np.abs(ca - cb).max() <= 1e-8 * max(np.abs(cb).max(), 1e-30)
+    assert a.context().solve_device_fallbacks() == 0
+    a.close()
+    b.close()

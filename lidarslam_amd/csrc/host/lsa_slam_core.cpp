@@ -365,6 +365,7 @@ int SlamCore::ProcessCurrentFrame(uint64_t stampUs)
   lsa_set_knn_rounds(Ctx, LSA_EDGE, KnnRoundsEdges);
   lsa_set_knn_rounds(Ctx, LSA_PLANE, KnnRoundsPlanes);
   lsa_set_knn_rounds(Ctx, LSA_BLOB, KnnRoundsBlobs);
+  lsa_set_fused_match(Ctx, FusedMatch ? 1 : 0);
   {
     Tick t;
     int rc = ExtractKeypoints();
@@ -1072,6 +1073,7 @@ int SlamCore::GetRegisteredFrame(std::vector<lsa_point_t>& out)
   X("TwoDMode", TwoDMode, bool)                                                                        \
   X("BuildTargetsAhead", BuildTargetsAhead, bool)                                                      \
   X("DeviceLM", DeviceLM, bool)                                                                        \
+  X("FusedMatch", FusedMatch, bool)                                                                    \
   X("EgoMotionICPMaxIter", EgoMotionICPMaxIter, unsigned)                                              \
   X("LocalizationICPMaxIter", LocalizationICPMaxIter, unsigned)                                        \
   X("EgoMotionLMMaxIter", EgoMotionLMMaxIter, unsigned)                                                \

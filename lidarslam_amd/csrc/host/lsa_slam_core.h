@@ -187,6 +187,8 @@ public:
   bool BuildTargetsAhead = true;
   // LocalOptimizer::Solve as one launch (the trust-region loop on the device) instead of one launch per evaluation
   bool DeviceLM = true;
+  // one ICP iteration's matching step as one launch (search + model fit fused, all types) instead of staged kernels
+  bool FusedMatch = true;
   bool KeepMatchDebug = false;  // download MatchingResults::Rejections/Weights every frame (Slam::GetDebugArray)
 
   std::shared_ptr<RollingGrid> LocalMaps[3];

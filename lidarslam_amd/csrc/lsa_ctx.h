@@ -205,7 +205,10 @@ struct lsa_ctx
   int last_match_type = 0;
   // lanes cooperating on one query in the first kNN kernel, per keypoint type (8, 16 or 32)
   int knn_lanes[3] = {16, 8, 8};
-  int knn_rounds[3] = {2, 2, 2};  // blocks of 3^3 .. (2 rounds + 1)^3 cells the first kernel tries
+  int knn_rounds[3] = {2, 2, 2};
+  // lsa_match_types as one launch for all types, search and model fit fused (lsa_match_fused.hip); off: the staged
+  // kernels of lsa_match.hip, types side by side on streams (same results, kept for comparison)
+  bool fused_match = true;  // blocks of 3^3 .. (2 rounds + 1)^3 cells the first kernel tries
   // lsa_match_types: the keypoint types of one ICP iteration are matched concurrently, the first on
   // `stream`, the others on these, forked and joined with events (no host synchronisation)
   hipStream_t side_stream[2] = {nullptr, nullptr};

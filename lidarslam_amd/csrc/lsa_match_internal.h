@@ -1,0 +1,23 @@
+// lsa_match_internal.h -- what lsa_match.hip (targets, staged kernels, C ABI) and lsa_match_fused.hip (one launch
+// per ICP iteration) share on the host side.
+#pragma once
+#include "lsa_knn.h"
+
+namespace lsa
+{
+
+// one keypoint type's match, ready to be enqueued: parameters resolved, histogram block taken
+struct MatchPrep
+{
+  int type;
+  int ti;                       // target index (slot * 3 + type)
+  const lsa_point_t* queries;
+  int nq;
+  MatchConst mc;
+  float far_d2;                 // planes / blobs: the search may stop once the k-th neighbour is known to be farther
+  int* hist;                    // device, 16 ints: [8] rejection histogram, [8], [9] hand-over counters
+};
+
+int enqueue_fused_match(lsa_ctx* ctx, const MatchPrep* preps, int count, const double pose[16], hipStream_t st);
+
+}  // namespace lsa

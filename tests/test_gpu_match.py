@@ -404,3 +404,55 @@ def test_targets_prepared_ahead_give_the_same_matches(O, L, kps):
     ctx.set_target_from_set(L.PLANE, L.SET_RAW_PREVIOUS, cell=0.25)
     assert taken() == 1 and ctx.target(L.PLANE, L.TARGET_PREVIOUS).tobytes() == first[:100].tobytes()
     ctx.close()
+
+
+@pytest.mark.parametrize("model", [16, 128])
+def test_fused_and_staged_matching_agree(O, L, kps, model):
+    """lsa_set_fused_match: one launch per ICP iteration (adaptive block search by the cell counts, per-lane sorted
+    lists, model fit in the same kernel, tail kernel for what no block settles) against the staged kernels (first
+    stage -> second stage -> model fit): histograms, status, weights and records bit for bit, for every keypoint type,
+    ego-motion and localization parameters, several cell sizes and neighbour counts"""
+    prev, cur = kps[model]
+    a, b = L.Context(0), L.Context(0)
+    a.set_fused_match(1)
+    b.set_fused_match(0)
+    cases = [
+        (L.MatchParams.ego_motion(saturation_distance=5.0), (0.5, 0.25, 0.5)),
+        (L.MatchParams.localization(saturation_distance=2.0), (0.75, 0.6, 0.3)),
+        (L.MatchParams.localization(saturation_distance=2.0), (4.0, 3.0, 5.0)),
+        (L.MatchParams.localization(saturation_distance=2.0), (0.1, 0.1, 0.1)),
+    ]
+    odd = L.MatchParams.localization(saturation_distance=1.0)
+    odd.edge_nb_neighbors, odd.plane_nb_neighbors, odd.blob_nb_neighbors = 16, 7, 13
+    cases.append((odd, (0.75, 0.6, 0.3)))
+    for mp, cells in cases:
+        for ctx in (a, b):
+            for k in (L.EDGE, L.PLANE, L.BLOB):
+                n = 20000 if k == L.BLOB else None
+                ctx.set_keypoints(L.SET_WORKING, k, cur[k][:n])
+                ctx.set_target(k, prev[k], cell=cells[k])
+        ha = a.match_types(7, L.SET_WORKING, mp, perturbed())
+        hb = b.match_types(7, L.SET_WORKING, mp, perturbed())
+        assert ha.tolist() == hb.tolist()
+        for k in (L.EDGE, L.PLANE, L.BLOB):
+            sa, wa, ra = a.match_results(k, L.SET_WORKING)
+            sb, wb, rb = b.match_results(k, L.SET_WORKING)
+            assert np.array_equal(sa, sb), (k, cells, np.flatnonzero(sa != sb)[:10])
+            assert np.array_equal(bits(wa), bits(wb)) and np.array_equal(bits(ra), bits(rb))
+    # keypoints far from a sparse target: no block of the grid holds k points -> tail kernel (edges), FAR (planes)
+    far = cur[L.EDGE][:500].copy()
+    far["x"] += 300.0
+    for ctx in (a, b):
+        ctx.set_keypoints(L.SET_WORKING, L.EDGE, np.concatenate([cur[L.EDGE][:500], far]))
+        ctx.set_target(L.EDGE, prev[L.EDGE][::7], cell=0.3)
+        ctx.set_keypoints(L.SET_WORKING, L.PLANE, np.concatenate([cur[L.PLANE][:500], far]))
+        ctx.set_target(L.PLANE, prev[L.PLANE][::50], cell=0.3)
+    mp = L.MatchParams.localization(saturation_distance=2.0)
+    ha, hb = a.match_types(3, L.SET_WORKING, mp, np.eye(4)), b.match_types(3, L.SET_WORKING, mp, np.eye(4))
+    assert ha.tolist() == hb.tolist()
+    for k in (L.EDGE, L.PLANE):
+        sa, wa, ra = a.match_results(k, L.SET_WORKING)
+        sb, wb, rb = b.match_results(k, L.SET_WORKING)
+        assert np.array_equal(sa, sb) and np.array_equal(bits(ra), bits(rb))
+    a.close()
+    b.close()

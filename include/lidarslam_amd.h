@@ -263,6 +263,10 @@ int lsa_match_histogram(lsa_ctx* ctx, int type, long long serial, int histogram[
 int lsa_set_fused_match(lsa_ctx* ctx, int on);
 /* Diagnostics: queries of the last lsa_match that the first kNN kernel handed to the second stage. */
 int lsa_match_slow_queries(lsa_ctx* ctx);
+/* Diagnostics of the last fused match of `type` (LSA_ROUTE_STATS=1 when the context is created): [0] queries handed
+ * to the tail kernel, [1] of them done, [2] second scans, [3] first block beyond shell 2, [4] candidates walked,
+ * [5] NEIGHBORS_TOO_FAR by the counts, [6] first block = 3^3 finest cells, [7] longest walk of one lane. */
+int lsa_match_route_stats(lsa_ctx* ctx, int type, int out[8]);
 /* ... and those of them that ended up scanning the whole target. */
 int lsa_match_exhaustive_queries(lsa_ctx* ctx);
 

@@ -208,7 +208,8 @@ struct lsa_ctx
   int knn_rounds[3] = {2, 2, 2};
   // lsa_match_types as one launch for all types, search and model fit fused (lsa_match_fused.hip); off: the staged
   // kernels of lsa_match.hip, types side by side on streams (same results, kept for comparison)
-  bool fused_match = true;  // blocks of 3^3 .. (2 rounds + 1)^3 cells the first kernel tries
+  bool fused_match = true;
+  bool route_stats = false;  // LSA_ROUTE_STATS: the fused search counts the routes it takes (lsa_match_route_stats)  // blocks of 3^3 .. (2 rounds + 1)^3 cells the first kernel tries
   // lsa_match_types: the keypoint types of one ICP iteration are matched concurrently, the first on
   // `stream`, the others on these, forked and joined with events (no host synchronisation)
   hipStream_t side_stream[2] = {nullptr, nullptr};

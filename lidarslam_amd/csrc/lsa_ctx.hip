@@ -286,6 +286,7 @@ int lsa_ctx_create(int device_id, lsa_ctx** out)
   if (ok) ok &= hipMemset(ctx->lm_xchg, 0, (size_t)2 * kLmBlocksMax * kMailboxStride * sizeof(unsigned long long)) == hipSuccess;
   if (const char* e = std::getenv("LSA_ACCUM_BLOCKS")) ctx->accum_blocks = std::min(std::max(std::atoi(e), 1), kAccumBlocksMax);
   if (const char* e = std::getenv("LSA_LM_BLOCKS")) ctx->lm_blocks = std::min(std::max(std::atoi(e), 1), kLmBlocksMax);
+  if (const char* e = std::getenv("LSA_ROUTE_STATS")) ctx->route_stats = std::atoi(e) != 0;
   if (const char* e = std::getenv("LSA_FUSED_MATCH")) ctx->fused_match = std::atoi(e) != 0;
   if (const char* e = std::getenv("LSA_MAILBOX_CHECK")) ctx->mailbox_check = std::atoi(e) != 0;
   if (!ok) { lsa_ctx_destroy(ctx); return LSA_E_HIP; }

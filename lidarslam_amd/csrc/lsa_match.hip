@@ -1492,6 +1492,14 @@ int lsa_match_slow_queries(lsa_ctx* ctx)
   return v;
 }
 
+int lsa_match_route_stats(lsa_ctx* ctx, int type, int out[8])
+{
+  if (!ctx || type < 0 || type > 2 || !out) return LSA_E_ARG;
+  if (hipStreamSynchronize(ctx->stream) != hipSuccess) return LSA_E_HIP;
+  if (hipMemcpy(out, ctx->hist_dev + ((size_t)type * kHistRing + ctx->hist_pos[type]) * 16 + LSA_MATCH_NSTATUS, 8 * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return LSA_E_HIP;
+  return LSA_OK;
+}
+
 int lsa_match_exhaustive_queries(lsa_ctx* ctx)
 {
   if (!ctx) return LSA_E_ARG;

@@ -181,7 +181,7 @@ __device__ __forceinline__ unsigned store_rows(uint32_t* __restrict__ lb, uint32
 // candidate is in flight while the current one is compared
 template <int KMAX>
 __device__ __forceinline__ void scan_rows(LaneList<KMAX>& L, const uint32_t* __restrict__ lb, const uint32_t* __restrict__ le, int tid, int slot_begin,
-                                          int slot_end, const float4* __restrict__ sorted, float qx, float qy, float qz)
+                                          int slot_end, const float4* __restrict__ sorted, float qx, float qy, float qz, int* route)
 {
   int e = slot_begin - 1;
   uint32_t c = 0, end = 0;
@@ -197,8 +197,10 @@ __device__ __forceinline__ void scan_rows(LaneList<KMAX>& L, const uint32_t* __r
   bool more = advance();
   float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
   if (more) p = sorted[c];
+  int walked = 0;
   while (__any(more))
   {
+    if (more) ++walked;
     const float4 cur = p;
     const bool has = more;
     if (more)
@@ -213,6 +215,11 @@ __device__ __forceinline__ void scan_rows(LaneList<KMAX>& L, const uint32_t* __r
       L.insert(make_key((dx * dx + dy * dy) + dz * dz, __float_as_int(cur.w)));
     }
   }
+  if (route)
+  {
+    atomicAdd(&route[2], walked);
+    atomicMax(&route[5], walked);
+  }
 }
 
 enum { kOutNone = 0, kOutFound = 1, kOutFar = 2, kOutTail = 3 };
@@ -222,7 +229,7 @@ enum { kOutNone = 0, kOutFound = 1, kOutFar = 2, kOutTail = 3 };
 template <int KMAX, int G>
 __device__ __forceinline__ int group_search(const GridDesc* __restrict__ desc, const GridPtrs& gp, float qx, float qy, float qz, int k, float far_d2,
                                             bool active, int gl, int tid, uint32_t* __restrict__ lb, uint32_t* __restrict__ le, knn_key (&best)[KMAX],
-                                            float& ub_out)
+                                            float& ub_out, int* route)
 {
   constexpr int E1 = (9 + G - 1) / G, E2 = (25 + G - 1) / G, E3 = (49 + G - 1) / G;
   static_assert(2 * E1 + E2 <= kSlots && E3 <= kSlots, "row slots");
@@ -306,6 +313,12 @@ __device__ __forceinline__ int group_search(const GridDesc* __restrict__ desc, c
     }
   }
   if (need) outcome = kOutTail;  // not even the largest block holds k points
+  if (route && gl == 0 && active)
+  {
+    if (sh >= 3) atomicAdd(&route[1], 1);
+    if (sh == 0) atomicAdd(&route[4], 1);
+    if (outcome == kOutFar) atomicAdd(&route[3], 1);
+  }
 
   // first scan
   int sh2 = -1;
@@ -314,7 +327,7 @@ __device__ __forceinline__ int group_search(const GridDesc* __restrict__ desc, c
     LaneList<KMAX> L;
     L.reset();
     const float4* sorted = sh < 2 ? gp.sorted[0] : (sh < 4 ? gp.sorted[1] : gp.sorted[2]);
-    scan_rows<KMAX>(L, lb, le, tid, sh >= 0 ? slot_begin : 0, sh >= 0 ? slot_end : 0, sorted, qx, qy, qz);
+    scan_rows<KMAX>(L, lb, le, tid, sh >= 0 ? slot_begin : 0, sh >= 0 ? slot_end : 0, sorted, qx, qy, qz, route);
     merge_lists<KMAX, G>(L, k, best);
     if (sh >= 0)
     {
@@ -336,6 +349,7 @@ __device__ __forceinline__ int group_search(const GridDesc* __restrict__ desc, c
         for (int s = sh + 1; s < kShells && sh2 < 0; ++s)
           if (bound2(s) > ub) sh2 = s;
         if (sh2 < 0) outcome = kOutTail;
+        else if (route && gl == 0) atomicAdd(&route[0], 1);
       }
     }
   }
@@ -359,7 +373,7 @@ __device__ __forceinline__ int group_search(const GridDesc* __restrict__ desc, c
     L.reset();
     const float4* sorted = sh2 < 2 ? gp.sorted[0] : (sh2 < 4 ? gp.sorted[1] : gp.sorted[2]);
     knn_key second[KMAX];
-    scan_rows<KMAX>(L, lb, le, tid, begin2, end2, sorted, qx, qy, qz);
+    scan_rows<KMAX>(L, lb, le, tid, begin2, end2, sorted, qx, qy, qz, route);
     merge_lists<KMAX, G>(L, k, second);
     if (sh2 >= 0)
     {
@@ -389,6 +403,7 @@ struct FusedType
   int* hist;              // [8] rejection histogram, [8] queries handed to the tail kernel
   int* list;
   float4* list_pts;
+  int route_stats;        // diagnostics: count the routes the searches take (hist[10..15])
 };
 struct FusedArgs
 {
@@ -409,6 +424,7 @@ struct FusedShared
   float d2[kKnnMax * kNbCols];
   int cnt[kNbCols];
   int lh[LSA_MATCH_NSTATUS];
+  int route[6];  // diagnostics: [0] second scans, [1] first block beyond shell 2, [2] candidates scanned / 64, [3] far, [4] first block = shell 0, [5] longest lane walk
 };
 
 template <int KMAX, int G, int TYPE>
@@ -420,6 +436,8 @@ __device__ __forceinline__ void fused_type(const Rigid& pose, const FusedType& t
   const int q = block * QB + ql;
   const bool active = q < t.nq && !t.mc.bad_param;
   if (tid < LSA_MATCH_NSTATUS) sh.lh[tid] = 0;
+  if (tid < 6) sh.route[tid] = 0;
+  if (t.route_stats) __syncthreads();
   float qx = 0.f, qy = 0.f, qz = 0.f;
   if (active)
   {
@@ -434,7 +452,7 @@ __device__ __forceinline__ void fused_type(const Rigid& pose, const FusedType& t
 #pragma unroll
   for (int s = 0; s < KMAX; ++s) best[s] = kKeyEmpty;
   float ub = INFINITY;
-  const int outcome = group_search<KMAX, G>(t.desc, t.gp, qx, qy, qz, t.k, t.far_d2, active, gl, tid, sh.u.rows.lb, sh.u.rows.le, best, ub);
+  const int outcome = group_search<KMAX, G>(t.desc, t.gp, qx, qy, qz, t.k, t.far_d2, active, gl, tid, sh.u.rows.lb, sh.u.rows.le, best, ub, t.route_stats ? sh.route : nullptr);
   if (gl == 0)
   {
     int cnt = 0;
@@ -476,6 +494,11 @@ __device__ __forceinline__ void fused_type(const Rigid& pose, const FusedType& t
   }
   __syncthreads();
   if (tid < LSA_MATCH_NSTATUS && sh.lh[tid]) atomicAdd(&t.hist[tid], sh.lh[tid]);
+  if (t.route_stats && tid < 6 && sh.route[tid])
+  {
+    if (tid == 5) atomicMax(&t.hist[LSA_MATCH_NSTATUS + 2 + tid], sh.route[tid]);
+    else atomicAdd(&t.hist[LSA_MATCH_NSTATUS + 2 + tid], sh.route[tid]);
+  }
 }
 
 // lanes per query of the three types
@@ -554,11 +577,15 @@ __global__ __launch_bounds__(256) void k_match_tail(FusedArgs a)
 }
 
 template <int KE, int KP, int KB>
-void launch_fused(const FusedArgs& a, int plane_lanes, hipStream_t st)
+void launch_fused(lsa_ctx* ctx, const FusedArgs& a, int plane_lanes, double bytes, hipStream_t st)
 {
   const int grid = 8 * ((a.nblocks + 7) / 8);
-  if (plane_lanes >= 8) hipLaunchKernelGGL((k_match_fused<KE, KP, KB, 8>), dim3(grid), dim3(256), 0, st, a);
-  else hipLaunchKernelGGL((k_match_fused<KE, KP, KB, 4>), dim3(grid), dim3(256), 0, st, a);
+  {
+    ProfScope ps(ctx, "match_fused", bytes, st);
+    if (plane_lanes >= 8) hipLaunchKernelGGL((k_match_fused<KE, KP, KB, 8>), dim3(grid), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((k_match_fused<KE, KP, KB, 4>), dim3(grid), dim3(256), 0, st, a);
+  }
+  ProfScope ps(ctx, "match_tail", 0., st);
   hipLaunchKernelGGL((k_match_tail<KE, KP, KB>), dim3(3 * kTailBlocks), dim3(256), 0, st, a);
 }
 
@@ -594,6 +621,7 @@ int enqueue_fused_match(lsa_ctx* ctx, const MatchPrep* preps, int count, const d
     t.rec = mb.rec; t.status = mb.status; t.cap = mb.cap;
     t.hist = p.hist;
     t.list = mb.slow_list; t.list_pts = mb.slow_pts;
+    t.route_stats = ctx->route_stats ? 1 : 0;
     kmax[p.type] = p.mc.k;
     // algorithmic bytes (B_icp): keypoint in, k gathered target points, residual record out
     bytes += (double)p.nq * (32 + p.mc.k * 32 + 136);
@@ -608,12 +636,11 @@ int enqueue_fused_match(lsa_ctx* ctx, const MatchPrep* preps, int count, const d
   }
   a.nblocks = block0;
   if (block0 == 0) return LSA_OK;
-  ProfScope ps(ctx, "match_fused", bytes, st);
   const int ke = kmax[0], kp = kmax[1], kb = kmax[2];
-  if (ke <= 8 && kp <= 5) launch_fused<8, 5, 16>(a, lanes[1], st);
-  else if (kp <= 5) launch_fused<16, 5, 16>(a, lanes[1], st);
-  else if (kp <= 8) launch_fused<16, 8, 16>(a, lanes[1], st);
-  else launch_fused<16, 16, 16>(a, lanes[1], st);
+  if (ke <= 8 && kp <= 5) launch_fused<8, 5, 16>(ctx, a, lanes[1], bytes, st);
+  else if (kp <= 5) launch_fused<16, 5, 16>(ctx, a, lanes[1], bytes, st);
+  else if (kp <= 8) launch_fused<16, 8, 16>(ctx, a, lanes[1], bytes, st);
+  else launch_fused<16, 16, 16>(ctx, a, lanes[1], bytes, st);
   (void)kb;
   return LSA_OK;
 }

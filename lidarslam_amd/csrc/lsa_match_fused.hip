@@ -162,58 +162,125 @@ __device__ __forceinline__ void shell_rows(const GridDesc& g, const uint32_t* __
   }
 }
 
-template <int E>
-__device__ __forceinline__ unsigned store_rows(uint32_t* __restrict__ lb, uint32_t* __restrict__ le, int slot0, int tid, const uint32_t (&b)[E],
-                                               const uint32_t (&en)[E])
+// The rows a group fetched, flattened lane by lane (entry f = lane * E + e): start and end of the run in the
+// cell-sorted array and the number of candidates in front of it.  Kept in LDS at [slot0 + e][thread].  Returns the
+// block's population (uniform across the group).  live == false: nothing is stored, the lane counts as empty.
+template <int G, int E>
+__device__ __forceinline__ unsigned store_rows(uint32_t* __restrict__ lb, uint32_t* __restrict__ le, uint32_t* __restrict__ lp, int slot0, int tid, int gl,
+                                               bool live, const uint32_t (&b)[E], const uint32_t (&en)[E])
 {
   unsigned mine = 0;
 #pragma unroll
-  for (int e = 0; e < E; ++e)
+  for (int e = 0; e < E; ++e) mine += en[e] - b[e];
+  if (!live) mine = 0;
+  unsigned inc = mine;
+#pragma unroll
+  for (int o = 1; o < G; o <<= 1)
   {
-    lb[(slot0 + e) * 256 + tid] = b[e];
-    le[(slot0 + e) * 256 + tid] = en[e];
-    mine += en[e] - b[e];
+    const unsigned t = (unsigned)__shfl_up((int)inc, o, G);
+    if (gl >= o) inc += t;
   }
-  return mine;
+  const unsigned total = (unsigned)__shfl((int)inc, G - 1, G);
+  if (live)
+  {
+    unsigned run = inc - mine;
+#pragma unroll
+    for (int e = 0; e < E; ++e)
+    {
+      lb[(slot0 + e) * 256 + tid] = b[e];
+      le[(slot0 + e) * 256 + tid] = en[e];
+      lp[(slot0 + e) * 256 + tid] = run;
+      run += en[e] - b[e];
+    }
+  }
+  return total;
 }
 
-// every lane walks its rows [slot_begin, slot_end) of the block and keeps its k best; the load of the next
-// candidate is in flight while the current one is compared
-template <int KMAX>
-__device__ __forceinline__ void scan_rows(LaneList<KMAX>& L, const uint32_t* __restrict__ lb, const uint32_t* __restrict__ le, int tid, int slot_begin,
-                                          int slot_end, const float4* __restrict__ sorted, float qx, float qy, float qz, int* route)
+// The scan of a block: its `total` candidates are dealt EVENLY to the G lanes of the group, whatever the rows'
+// lengths (lane gl takes the flattened range [gl total / G, (gl + 1) total / G)), every lane walks its range four
+// candidates at a time -- the loads of the next four in flight while the current four are compared -- and keeps
+// its k best in a sorted list in registers.  E: entries per lane of the block's row table, slot0: where it starts.
+template <int KMAX, int G>
+__device__ __forceinline__ void scan_rows(LaneList<KMAX>& L, const uint32_t* __restrict__ lb, const uint32_t* __restrict__ le,
+                                          const uint32_t* __restrict__ lp, int tid, int gl, int slot0, int E, unsigned total,
+                                          const float4* __restrict__ sorted, float qx, float qy, float qz, int* route)
 {
-  int e = slot_begin - 1;
-  uint32_t c = 0, end = 0;
-  auto advance = [&]() -> bool {
-    while (c >= end)
-    {
-      if (++e >= slot_end) return false;
-      c = lb[e * 256 + tid];
-      end = le[e * 256 + tid];
-    }
-    return true;
+  constexpr int U = 4;
+  const int gbase = tid - gl;
+  const unsigned S = (unsigned)(((unsigned long long)gl * total) / G);
+  unsigned n = (unsigned)(((unsigned long long)(gl + 1) * total) / G) - S;  // candidates of this lane
+  // entry f of the flattened table lives at [slot0 + f % E][gbase + f / E]; E is one of three constants: the division
+  // is a multiplication (exact for f < 5000)
+  constexpr int E1 = (9 + G - 1) / G, E2 = (25 + G - 1) / G, E3 = (49 + G - 1) / G;
+  const int inv = E == E1 ? (65536 / E1 + 1) : (E == E2 ? (65536 / E2 + 1) : (65536 / E3 + 1));
+  auto at = [&](int f) {
+    const int lane = (f * inv) >> 16;
+    return (slot0 + f - lane * E) * 256 + gbase + lane;
   };
-  bool more = advance();
-  float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (more) p = sorted[c];
-  int walked = 0;
-  while (__any(more))
+  int f = 0;
+  uint32_t c = 0, cend = 0;
+  if (n > 0)
   {
-    if (more) ++walked;
-    const float4 cur = p;
-    const bool has = more;
-    if (more)
+    // the last entry whose prefix is <= S (entries in front of it may be empty and share its prefix)
+    int lo = 0, hi = G * E - 1;
+    while (lo < hi)
     {
-      ++c;
-      more = advance();
+      const int mid = (lo + hi + 1) >> 1;
+      if (lp[at(mid)] <= S) lo = mid; else hi = mid - 1;
     }
-    if (more) p = sorted[c];
-    if (has)
+    f = lo;
+    const int a0 = at(f);
+    c = lb[a0] + (S - lp[a0]);
+    cend = le[a0];
+  }
+  // the next U candidates of the range: addresses (0 = none)
+  auto gen = [&](uint32_t (&addr)[U], bool (&ok)[U]) {
+#pragma unroll
+    for (int u = 0; u < U; ++u)
     {
-      const float dx = qx - cur.x, dy = qy - cur.y, dz = qz - cur.z;
-      L.insert(make_key((dx * dx + dy * dy) + dz * dz, __float_as_int(cur.w)));
+      ok[u] = n > 0;
+      addr[u] = 0;
+      if (ok[u])
+      {
+        while (c >= cend)
+        {
+          ++f;
+          const int a1 = at(f);
+          c = lb[a1];
+          cend = le[a1];
+        }
+        addr[u] = c++;
+        --n;
+      }
     }
+  };
+  uint32_t addr[U];
+  bool ok[U];
+  float4 p[U];
+  gen(addr, ok);
+#pragma unroll
+  for (int u = 0; u < U; ++u) p[u] = sorted[addr[u]];
+  int walked = 0;
+  while (__any(ok[0]))
+  {
+    float4 cur[U];
+    bool has[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) { cur[u] = p[u]; has[u] = ok[u]; }
+    gen(addr, ok);
+    if (__any(ok[0]))
+    {
+#pragma unroll
+      for (int u = 0; u < U; ++u) p[u] = sorted[addr[u]];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (has[u])
+      {
+        ++walked;
+        const float dx = qx - cur[u].x, dy = qy - cur[u].y, dz = qz - cur[u].z;
+        L.insert(make_key((dx * dx + dy * dy) + dz * dz, __float_as_int(cur[u].w)));
+      }
   }
   if (route)
   {
@@ -228,8 +295,8 @@ enum { kOutNone = 0, kOutFound = 1, kOutFar = 2, kOutTail = 3 };
 // the group.  Every lane of the wavefront calls it; groups without a query (active == false) come back with kOutNone.
 template <int KMAX, int G>
 __device__ __forceinline__ int group_search(const GridDesc* __restrict__ desc, const GridPtrs& gp, float qx, float qy, float qz, int k, float far_d2,
-                                            bool active, int gl, int tid, uint32_t* __restrict__ lb, uint32_t* __restrict__ le, knn_key (&best)[KMAX],
-                                            float& ub_out, int* route)
+                                            bool active, int gl, int tid, uint32_t* __restrict__ lb, uint32_t* __restrict__ le, uint32_t* __restrict__ lp,
+                                            knn_key (&best)[KMAX], float& ub_out, int* route)
 {
   constexpr int E1 = (9 + G - 1) / G, E2 = (25 + G - 1) / G, E3 = (49 + G - 1) / G;
   static_assert(2 * E1 + E2 <= kSlots && E3 <= kSlots, "row slots");
@@ -242,7 +309,8 @@ __device__ __forceinline__ int group_search(const GridDesc* __restrict__ desc, c
     const int l = shell_level(s), r = shell_r(s);
     return l == 0 ? proven2(g0, v0, r) : (l == 1 ? proven2(g1, v1, r) : proven2(g2, v2, r));
   };
-  // rows of the block of shell s (any shell, per group) into slots [0, E3)
+  // rows of the block of shell s (any shell, per group) into slots [0, E3); groups that are not concerned keep what
+  // their slots hold (rows of shells 0..2 they may still scan)
   auto fetch_any = [&](int s, bool live, bool& covered) -> unsigned {
     const int l = shell_level(s), r = shell_r(s);
     const GridDesc& g = l == 0 ? g0 : (l == 1 ? g1 : g2);
@@ -250,38 +318,36 @@ __device__ __forceinline__ int group_search(const GridDesc* __restrict__ desc, c
     const uint32_t* cs = l == 0 ? gp.cell_start[0] : (l == 1 ? gp.cell_start[1] : gp.cell_start[2]);
     uint32_t b[E3], en[E3];
     shell_rows<G, E3>(g, cs, v, r, gl, live, b, en, covered);
-    // groups that are not concerned keep what their slots hold (rows of shells 0..2 they may still scan)
-    unsigned mine = 0;
-    if (live) mine = store_rows<E3>(lb, le, 0, tid, b, en);
-    return group_sum<G>(mine);
+    return store_rows<G, E3>(lb, le, lp, 0, tid, gl, live, b, en);
   };
 
   int outcome = kOutNone;
-  int sh = -1, slot_begin = 0, slot_end = 0;
+  int sh = -1, slot0 = 0, ents = E1;
+  unsigned total = 0;
   bool sh_covered = false;
   bool need = active;
   ub_out = INFINITY;
 
   // shells 0, 1, 2: the bounds of all their rows in one memory round trip
+  unsigned tot3[3];
   {
     uint32_t b0[E1], e0[E1], b1[E2], e1[E2], b2[E1], e2[E1];
     bool c0, c1, c2;
     shell_rows<G, E1>(g0, gp.cell_start[0], v0, 1, gl, active, b0, e0, c0);
     shell_rows<G, E2>(g0, gp.cell_start[0], v0, 2, gl, active, b1, e1, c1);
     shell_rows<G, E1>(g1, gp.cell_start[1], v1, 1, gl, active, b2, e2, c2);
-    const unsigned t0 = group_sum<G>(store_rows<E1>(lb, le, 0, tid, b0, e0));
-    const unsigned t1 = group_sum<G>(store_rows<E2>(lb, le, E1, tid, b1, e1));
-    const unsigned t2 = group_sum<G>(store_rows<E1>(lb, le, E1 + E2, tid, b2, e2));
-    const unsigned tot[3] = {t0, t1, t2};
+    tot3[0] = store_rows<G, E1>(lb, le, lp, 0, tid, gl, active, b0, e0);
+    tot3[1] = store_rows<G, E2>(lb, le, lp, E1, tid, gl, active, b1, e1);
+    tot3[2] = store_rows<G, E1>(lb, le, lp, E1 + E2, tid, gl, active, b2, e2);
     const bool cov[3] = {c0, c1, c2};
     const int first[3] = {0, E1, E1 + E2}, count[3] = {E1, E2, E1};
 #pragma unroll
     for (int s = 0; s < 3; ++s)
       if (need)
       {
-        if (tot[s] >= (unsigned)k || cov[s])
+        if (tot3[s] >= (unsigned)k || cov[s])
         {
-          sh = s; sh_covered = cov[s]; slot_begin = first[s]; slot_end = first[s] + count[s];
+          sh = s; sh_covered = cov[s]; slot0 = first[s]; ents = count[s]; total = tot3[s];
           need = false;
         }
         else if (bound2(s) > far_d2)
@@ -302,7 +368,7 @@ __device__ __forceinline__ int group_search(const GridDesc* __restrict__ desc, c
     {
       if (tot >= (unsigned)k || cov)
       {
-        sh = s; sh_covered = cov; slot_begin = 0; slot_end = E3;
+        sh = s; sh_covered = cov; slot0 = 0; ents = E3; total = tot;
         need = false;
       }
       else if (bound2(s) > far_d2)
@@ -327,7 +393,7 @@ __device__ __forceinline__ int group_search(const GridDesc* __restrict__ desc, c
     LaneList<KMAX> L;
     L.reset();
     const float4* sorted = sh < 2 ? gp.sorted[0] : (sh < 4 ? gp.sorted[1] : gp.sorted[2]);
-    scan_rows<KMAX>(L, lb, le, tid, sh >= 0 ? slot_begin : 0, sh >= 0 ? slot_end : 0, sorted, qx, qy, qz, route);
+    scan_rows<KMAX, G>(L, lb, le, lp, tid, gl, slot0, ents, sh >= 0 ? total : 0u, sorted, qx, qy, qz, route);
     merge_lists<KMAX, G>(L, k, best);
     if (sh >= 0)
     {
@@ -356,24 +422,26 @@ __device__ __forceinline__ int group_search(const GridDesc* __restrict__ desc, c
   // second scan, certain
   if (__any(sh2 >= 0))
   {
-    int begin2 = 0, end2 = 0;
+    int slot2 = 0, ents2 = E1;
+    unsigned total2 = 0;
     if (sh2 >= 0 && sh2 < 3)
     {
       // still in its slots from the first round trip (this group fetched nothing since)
-      begin2 = sh2 == 1 ? E1 : E1 + E2;
-      end2 = sh2 == 1 ? E1 + E2 : 2 * E1 + E2;
+      slot2 = sh2 == 1 ? E1 : E1 + E2;
+      ents2 = sh2 == 1 ? E2 : E1;
+      total2 = sh2 == 1 ? tot3[1] : tot3[2];
     }
     if (__any(sh2 >= 3))
     {
       bool cov;
-      (void)fetch_any(sh2 >= 3 ? sh2 : 3, sh2 >= 3, cov);
-      if (sh2 >= 3) { begin2 = 0; end2 = E3; }
+      const unsigned tot = fetch_any(sh2 >= 3 ? sh2 : 3, sh2 >= 3, cov);
+      if (sh2 >= 3) { slot2 = 0; ents2 = E3; total2 = tot; }
     }
     LaneList<KMAX> L;
     L.reset();
     const float4* sorted = sh2 < 2 ? gp.sorted[0] : (sh2 < 4 ? gp.sorted[1] : gp.sorted[2]);
     knn_key second[KMAX];
-    scan_rows<KMAX>(L, lb, le, tid, begin2, end2, sorted, qx, qy, qz, route);
+    scan_rows<KMAX, G>(L, lb, le, lp, tid, gl, slot2, ents2, sh2 >= 0 ? total2 : 0u, sorted, qx, qy, qz, route);
     merge_lists<KMAX, G>(L, k, second);
     if (sh2 >= 0)
     {
@@ -417,7 +485,7 @@ struct FusedShared
 {
   union
   {
-    struct { uint32_t lb[kSlots * 256], le[kSlots * 256]; } rows;  // during the search
+    struct { uint32_t lb[kSlots * 256], le[kSlots * 256], lp[kSlots * 256]; } rows;  // during the search
     struct { float4 nb[kKnnMax * kNbCols]; float nd[kKnnMax * kNbCols]; } edge;  // during the model fit (edges)
   } u;
   int idx[kKnnMax * kNbCols];
@@ -452,7 +520,7 @@ __device__ __forceinline__ void fused_type(const Rigid& pose, const FusedType& t
 #pragma unroll
   for (int s = 0; s < KMAX; ++s) best[s] = kKeyEmpty;
   float ub = INFINITY;
-  const int outcome = group_search<KMAX, G>(t.desc, t.gp, qx, qy, qz, t.k, t.far_d2, active, gl, tid, sh.u.rows.lb, sh.u.rows.le, best, ub, t.route_stats ? sh.route : nullptr);
+  const int outcome = group_search<KMAX, G>(t.desc, t.gp, qx, qy, qz, t.k, t.far_d2, active, gl, tid, sh.u.rows.lb, sh.u.rows.le, sh.u.rows.lp, best, ub, t.route_stats ? sh.route : nullptr);
   if (gl == 0)
   {
     int cnt = 0;

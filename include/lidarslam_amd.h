@@ -267,6 +267,9 @@ int lsa_match_slow_queries(lsa_ctx* ctx);
  * to the tail kernel, [1] of them done, [2] second scans, [3] first block beyond shell 2, [4] candidates walked,
  * [5] NEIGHBORS_TOO_FAR by the counts, [6] first block = 3^3 finest cells, [7] longest walk of one lane. */
 int lsa_match_route_stats(lsa_ctx* ctx, int type, int out[8]);
+/* Diagnostics (LSA_ROUTE_STATS=1): {start, search end, model end, XCC | HW_ID} of the hardware blocks of the last
+ * fused match, 100 MHz ticks. */
+int lsa_match_trace(lsa_ctx* ctx, unsigned long long* out, int blocks);
 /* ... and those of them that ended up scanning the whole target. */
 int lsa_match_exhaustive_queries(lsa_ctx* ctx);
 
@@ -356,6 +359,9 @@ typedef struct lsa_solve_result
 } lsa_solve_result_t;
 int lsa_solve_device(lsa_ctx* ctx, unsigned type_mask, const double prior[6], int two_d_mode, int lm_max_iter, int min_matches,
                      lsa_solve_result_t* out);
+/* Diagnostics (LSA_ROUTE_STATS=1): 100 MHz ticks block 0 spent evaluating, exchanging, folding, stepping, summed over
+ * the solves so far; [4] evaluations, [5] ticks inside the kernel, [6] solves. */
+int lsa_solve_device_trace(lsa_ctx* ctx, unsigned long long out[8]);
 /* Solves the device gave up on so far (diagnostics; 0 on a healthy run). */
 int lsa_solve_device_fallbacks(const lsa_ctx* ctx);
 /* LocalOptimizer::EstimateRegistrationError (LocalOptimizer.cxx:112-140) at `pose`: covariance

@@ -55,8 +55,8 @@ ABI_SYMBOLS = [
     "lsa_frame_store_put", "lsa_frame_store_use", "lsa_frame_size", "lsa_get_azimuthal_resolution",
     "lsa_set_azimuthal_resolution", "lsa_extract_keypoints", "lsa_extract_keypoints_more", "lsa_extract_prefetch", "lsa_extract_prefetch_adopted", "lsa_transform_frame_at", "lsa_set_keypoint_types", "lsa_download_keypoints", "lsa_keypoint_count",
     "lsa_download_debug", "lsa_nb_laser_rings", "lsa_transform_keypoints", "lsa_set_target", "lsa_set_target_from_set", "lsa_prepare_previous_targets", "lsa_prepared_targets_adopted", "lsa_target_staging", "lsa_set_target_staged", "lsa_stage_target_ahead", "lsa_drop_target_ahead", "lsa_staged_targets_adopted",
-    "lsa_target_size", "lsa_download_target", "lsa_set_target_cell_size", "lsa_set_knn_lanes", "lsa_set_fused_match", "lsa_set_knn_rounds", "lsa_match_slow_queries", "lsa_match_exhaustive_queries", "lsa_match_route_stats", "lsa_set_keypoints", "lsa_match", "lsa_match_types",
-    "lsa_download_match", "lsa_overlap", "lsa_accumulate", "lsa_mailbox_active", "lsa_solve", "lsa_solve_device", "lsa_solve_device_fallbacks", "lsa_registration_error", "lsa_selftest_math", "lsa_reset_working_keypoints", "lsa_undistort", "lsa_working_time_range",
+    "lsa_target_size", "lsa_download_target", "lsa_set_target_cell_size", "lsa_set_knn_lanes", "lsa_set_fused_match", "lsa_set_knn_rounds", "lsa_match_slow_queries", "lsa_match_exhaustive_queries", "lsa_match_route_stats", "lsa_match_trace", "lsa_set_keypoints", "lsa_match", "lsa_match_types",
+    "lsa_download_match", "lsa_overlap", "lsa_accumulate", "lsa_mailbox_active", "lsa_solve", "lsa_solve_device", "lsa_solve_device_fallbacks", "lsa_solve_device_trace", "lsa_registration_error", "lsa_selftest_math", "lsa_reset_working_keypoints", "lsa_undistort", "lsa_working_time_range",
     "lsa_working_bbox", "lsa_working_bboxes", "lsa_keypoint_bboxes_begin", "lsa_keypoint_bboxes_begin_interp", "lsa_keypoint_time_range", "lsa_keypoint_bboxes_end", "lsa_download_transformed", "lsa_stage_transformed", "lsa_staged_transformed", "lsa_transform_frame", "lsa_profile_enable", "lsa_profile_select", "lsa_profile_reset",
     "lsa_profile_get", "lsa_slam_create", "lsa_slam_destroy", "lsa_slam_last_error", "lsa_slam_set_param",
     "lsa_slam_get_param", "lsa_slam_reset", "lsa_slam_add_frame", "lsa_slam_store_frame", "lsa_slam_add_stored_frame", "lsa_slam_hint_next_stored_frame",
@@ -389,6 +389,12 @@ class Context:
         self._check(self.L.lsa_match_route_stats(self.h, ktype, ptr(out)), "lsa_match_route_stats")
         return out
 
+    def match_trace(self, blocks):
+        out = np.zeros((blocks, 12), np.uint64)
+        self.L.lsa_match_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        self._check(self.L.lsa_match_trace(self.h, ptr(out), blocks), "lsa_match_trace")
+        return out
+
     def set_fused_match(self, on):
         self._check(self.L.lsa_set_fused_match(self.h, int(on)), "lsa_set_fused_match")
 
@@ -418,6 +424,12 @@ class Context:
         w = np.ascontiguousarray(prior6, np.float64)
         self._check(self.L.lsa_solve_device(self.h, type_mask, ptr(w), int(two_d), max_iter, min_matches, C.byref(r)), "lsa_solve_device")
         return r
+
+    def solve_device_trace(self):
+        out = np.zeros(8, np.uint64)
+        self.L.lsa_solve_device_trace.argtypes = [C.c_void_p, C.c_void_p]
+        self._check(self.L.lsa_solve_device_trace(self.h, ptr(out)), "lsa_solve_device_trace")
+        return out
 
     def solve_device_fallbacks(self):
         return self.L.lsa_solve_device_fallbacks(self.h)

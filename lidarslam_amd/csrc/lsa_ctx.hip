@@ -287,6 +287,7 @@ int lsa_ctx_create(int device_id, lsa_ctx** out)
   if (const char* e = std::getenv("LSA_ACCUM_BLOCKS")) ctx->accum_blocks = std::min(std::max(std::atoi(e), 1), kAccumBlocksMax);
   if (const char* e = std::getenv("LSA_LM_BLOCKS")) ctx->lm_blocks = std::min(std::max(std::atoi(e), 1), kLmBlocksMax);
   if (const char* e = std::getenv("LSA_ROUTE_STATS")) ctx->route_stats = std::atoi(e) != 0;
+  if (ctx->route_stats) ok &= hipMalloc(&ctx->trace_dev, ((size_t)8192 * 12 + 16) * sizeof(unsigned long long)) == hipSuccess && hipMemset(ctx->trace_dev, 0, ((size_t)8192 * 12 + 16) * sizeof(unsigned long long)) == hipSuccess;
   if (const char* e = std::getenv("LSA_FUSED_MATCH")) ctx->fused_match = std::atoi(e) != 0;
   if (const char* e = std::getenv("LSA_MAILBOX_CHECK")) ctx->mailbox_check = std::atoi(e) != 0;
   if (!ok) { lsa_ctx_destroy(ctx); return LSA_E_HIP; }
@@ -334,6 +335,7 @@ void lsa_ctx_destroy(lsa_ctx* ctx)
   if (ctx->mailbox) (void)hipHostFree(ctx->mailbox);
   if (ctx->lm_mailbox) (void)hipHostFree(ctx->lm_mailbox);
   fr(ctx->lm_xchg);
+  fr(ctx->trace_dev);
   for (int i = 0; i < 2; ++i)
   {
     if (ctx->ev_join[i]) (void)hipEventDestroy(ctx->ev_join[i]);

@@ -75,6 +75,7 @@ struct Shared
   LmState lm;
   int failed;
   int stop;
+  unsigned long long lap[6], tk;  // diagnostics (block 0): evaluate, exchange, fold, step [100 MHz ticks], evaluations, total
 };
 
 __device__ __forceinline__ double uniform(double v)
@@ -86,7 +87,17 @@ __device__ __forceinline__ double uniform(double v)
 
 // One evaluation at sh.w / sh.rot: sh.tot[] = the 29 sums over ALL residual blocks, identical in every block.
 // Returns false when a spin ran out (uniform over the block).
-__device__ __forceinline__ bool lm_evaluate(const LmParams& p, unsigned epoch, u64* __restrict__ xchg, Shared& sh)
+__device__ __forceinline__ void lm_lap(Shared& sh, int slot)
+{
+  if (threadIdx.x == 0)
+  {
+    const unsigned long long now = wall_clock64();
+    sh.lap[slot] += now - sh.tk;
+    sh.tk = now;
+  }
+}
+
+__device__ __forceinline__ bool lm_evaluate(const LmParams& p, unsigned epoch, u64* __restrict__ xchg, Shared& sh, bool trace)
 {
   {
     RotConst c;
@@ -108,6 +119,7 @@ __device__ __forceinline__ bool lm_evaluate(const LmParams& p, unsigned epoch, u
   }
   if (threadIdx.x == 0) sh.failed = 0;
   __syncthreads();
+  if (trace) lm_lap(sh, 0);
   const unsigned tag = p.tag_base + epoch;
   const int nb = gridDim.x;
   u64* slots = xchg + (size_t)(epoch & 1u) * kLmBlocksMax * kMailboxStride;
@@ -165,6 +177,7 @@ __device__ __forceinline__ bool lm_evaluate(const LmParams& p, unsigned epoch, u
   }
   if (failed) atomicOr(&sh.failed, 1);
   __syncthreads();
+  if (trace) lm_lap(sh, 1);
   if (sh.failed) return false;
   // fold in a fixed order: 8 partial sums per value over the blocks b = j, j + 8, ..., then the 8 in order
   if (threadIdx.x < kAccumVals * 8)
@@ -187,6 +200,7 @@ __device__ __forceinline__ bool lm_evaluate(const LmParams& p, unsigned epoch, u
     sh.tot[threadIdx.x] = s;
   }
   __syncthreads();
+  if (trace) lm_lap(sh, 2);
   return true;
 }
 
@@ -413,11 +427,15 @@ __device__ bool lm_step(const LmParams& p, Shared& sh, bool first)
   }
 }
 
-__global__ __launch_bounds__(256) void k_lm_solve(LmParams p, u64* __restrict__ xchg, u64* __restrict__ mailbox, unsigned out_tag)
+__global__ __launch_bounds__(256) void k_lm_solve(LmParams p, u64* __restrict__ xchg, u64* __restrict__ mailbox, unsigned out_tag, unsigned long long* trace)
 {
   __shared__ Shared sh;
+  const bool tr = trace != nullptr && blockIdx.x == 0;
   if (threadIdx.x == 0)
   {
+    for (int i = 0; i < 6; ++i) sh.lap[i] = 0;
+    sh.tk = wall_clock64();
+    sh.lap[5] = sh.tk;
     LmState& lm = sh.lm;
 #pragma unroll
     for (int v = 0; v < kAccumVals; ++v) lm.cur[v] = 0.;
@@ -434,12 +452,20 @@ __global__ __launch_bounds__(256) void k_lm_solve(LmParams p, u64* __restrict__ 
   // every evaluation of the launch has an epoch of its own; all blocks walk through the same sequence of them
   for (unsigned epoch = 1;; ++epoch)
   {
-    if (!lm_evaluate(p, epoch, xchg, sh)) { failed = true; break; }
+    if (!lm_evaluate(p, epoch, xchg, sh, tr)) { failed = true; break; }
     if (threadIdx.x == 0) sh.stop = (p.two_d ? lm_step<3>(p, sh, epoch == 1) : lm_step<6>(p, sh, epoch == 1)) ? 1 : 0;
     __syncthreads();
+    if (tr) lm_lap(sh, 3);
     if (sh.stop) break;
   }
   if (blockIdx.x != 0) return;
+  if (tr && threadIdx.x == 0)
+  {
+    for (int i = 0; i < 4; ++i) trace[i] += sh.lap[i];
+    trace[4] += (unsigned long long)sh.lm.evaluations;
+    trace[5] += wall_clock64() - sh.lap[5];
+    trace[6] += 1;
+  }
   // every block holds the same result; block 0's copy goes out as 2 granules per double
   if (threadIdx.x < 2 * kResCount)
   {
@@ -501,7 +527,8 @@ int lsa_solve_device(lsa_ctx* ctx, unsigned type_mask, const double prior[6], in
   {
     ProfScope ps(ctx, "lm_solve", 0.);
     stat = ps.stat;
-    hipLaunchKernelGGL(k_lm_solve, dim3(nb), dim3(256), 0, ctx->stream, p, ctx->lm_xchg, ctx->lm_mailbox, out_tag);
+    hipLaunchKernelGGL(k_lm_solve, dim3(nb), dim3(256), 0, ctx->stream, p, ctx->lm_xchg, ctx->lm_mailbox, out_tag,
+                       ctx->route_stats && ctx->trace_dev ? reinterpret_cast<unsigned long long*>(ctx->trace_dev) + (size_t)8192 * 12 : nullptr);
   }
   // the result arrives as granules in coherent host memory (as lsa_accumulate's sums do)
   double res[kResCount];
@@ -557,5 +584,13 @@ int lsa_solve_device(lsa_ctx* ctx, unsigned type_mask, const double prior[6], in
 }
 
 int lsa_solve_device_fallbacks(const lsa_ctx* ctx) { return ctx ? ctx->lm_fallbacks : 0; }
+
+int lsa_solve_device_trace(lsa_ctx* ctx, unsigned long long out[8])
+{
+  if (!ctx || !out || !ctx->trace_dev) return LSA_E_ARG;
+  if (hipStreamSynchronize(ctx->stream) != hipSuccess) return LSA_E_HIP;
+  if (hipMemcpy(out, reinterpret_cast<unsigned long long*>(ctx->trace_dev) + (size_t)8192 * 12, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return LSA_E_HIP;
+  return LSA_OK;
+}
 
 }  // extern "C"

@@ -1500,6 +1500,14 @@ int lsa_match_route_stats(lsa_ctx* ctx, int type, int out[8])
   return LSA_OK;
 }
 
+int lsa_match_trace(lsa_ctx* ctx, unsigned long long* out, int blocks)
+{
+  if (!ctx || !out || blocks < 0 || blocks > 8192 || !ctx->trace_dev) return LSA_E_ARG;
+  if (hipStreamSynchronize(ctx->stream) != hipSuccess) return LSA_E_HIP;
+  if (hipMemcpy(out, ctx->trace_dev, (size_t)blocks * 12 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return LSA_E_HIP;
+  return LSA_OK;
+}
+
 int lsa_match_exhaustive_queries(lsa_ctx* ctx)
 {
   if (!ctx) return LSA_E_ARG;

@@ -32,9 +32,9 @@ using namespace lsa;
 namespace
 {
 
-constexpr int kSlots = 13;    // row slots per lane: 3 + 7 + 3 rows of shells 0..2 at G = 4, 49 rows of a 7^3 block over 4 lanes
-constexpr int kPending = -2;  // neighbour count of a query handed to the tail kernel
+constexpr int kPending = -2;  // neighbour count of a query no block of the grid settles
 constexpr int kShells = 7;
+constexpr int kFill = 3;       // a block is scanned first when it holds kFill x k points
 
 __device__ __forceinline__ constexpr int shell_level(int s) { return s < 2 ? 0 : (s < 4 ? 1 : 2); }
 __device__ __forceinline__ constexpr int shell_r(int s) { return s == 6 ? 3 : ((s & 1) ? 2 : 1); }
@@ -81,17 +81,19 @@ struct LaneList
 
 // best <- the k smallest keys of the G lanes' lists, uniform across the group (the lists are consumed)
 template <int KMAX, int G>
-__device__ __forceinline__ void merge_lists(LaneList<KMAX>& L, int k, knn_key (&best)[KMAX])
+__device__ __forceinline__ void merge_lists(LaneList<KMAX>& L, int k, knn_key (&best)[KMAX], bool take = true)
 {
+  // take == false: the group is not concerned (it takes part in the exchanges with empty lists) and keeps its best
 #pragma unroll
-  for (int s = 0; s < KMAX; ++s) best[s] = kKeyEmpty;
+  for (int s = 0; s < KMAX; ++s)
+    if (take) best[s] = kKeyEmpty;
 #pragma unroll
   for (int s = 0; s < KMAX; ++s)
     if (s < k)
     {
       knn_key m = L.v[0];
       group_min<G>(m);
-      best[s] = m;
+      if (take) best[s] = m;
       if (L.v[0] == m)  // the owner retires it (keys of real candidates are unique; empty heads all look alike, harmless)
       {
 #pragma unroll
@@ -162,35 +164,79 @@ __device__ __forceinline__ void shell_rows(const GridDesc& g, const uint32_t* __
   }
 }
 
-// The rows a group fetched, flattened lane by lane (entry f = lane * E + e): start and end of the run in the
-// cell-sorted array and the number of candidates in front of it.  Kept in LDS at [slot0 + e][thread].  Returns the
-// block's population (uniform across the group).  live == false: nothing is stored, the lane counts as empty.
+// inclusive scan / maximum over the G lanes of a group (G <= 16: DPP inside a row of 16 lanes, no LDS round trip)
+template <int G>
+__device__ __forceinline__ unsigned group_scan(unsigned v, int gl)
+{
+  static_assert(G <= 16, "groups live inside a DPP row");
+  if (G > 1) { const unsigned t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true); if (gl >= 1) v += t; }  // row_shr:1
+  if (G > 2) { const unsigned t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true); if (gl >= 2) v += t; }
+  if (G > 4) { const unsigned t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true); if (gl >= 4) v += t; }
+  if (G > 8) { const unsigned t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true); if (gl >= 8) v += t; }
+  return v;
+}
+template <int G>
+__device__ __forceinline__ unsigned group_max(unsigned v)
+{
+  auto step = [&](auto ctrl) {
+    const unsigned o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, decltype(ctrl)::value, 0xF, 0xF, true);
+    v = o > v ? o : v;
+  };
+  if (G >= 2) step(std::integral_constant<int, 0xB1>());
+  if (G >= 4) step(std::integral_constant<int, 0x4E>());
+  if (G >= 8) step(std::integral_constant<int, 0x141>());
+  if (G >= 16) step(std::integral_constant<int, 0x140>());
+  return v;
+}
+
+// A group's table of candidate runs in LDS: the NON-EMPTY rows of a block, one entry each -- start and end of the run in
+// the cell-sorted array and the number of candidates in front of it -- followed by one (0, 0, total) sentinel.
+struct RowTable
+{
+  uint32_t* b;
+  uint32_t* e;
+  uint32_t* p;
+};
+template <int G>
+__device__ __forceinline__ constexpr int table_capacity()
+{
+  constexpr int E1 = (9 + G - 1) / G, E2 = (25 + G - 1) / G, E3 = (49 + G - 1) / G;
+  return (G * (2 * E1 + E2) + 3) > (G * E3 + 1) ? (G * (2 * E1 + E2) + 3) : (G * E3 + 1);
+}
+constexpr int kTableEntries = 2144;  // a block's tables: 256 / G groups x table_capacity<G>() (G = 8: 32 x 67, G = 16: 16 x 67)
+
+// Appends this lane's non-empty rows to the group's table at `base` (lane after lane, so that the table is
+// contiguous).  Returns (entries << 20 | candidates) of the whole block, uniform across the group.  live == false:
+// the lane contributes nothing and writes nothing.
 template <int G, int E>
-__device__ __forceinline__ unsigned store_rows(uint32_t* __restrict__ lb, uint32_t* __restrict__ le, uint32_t* __restrict__ lp, int slot0, int tid, int gl,
-                                               bool live, const uint32_t (&b)[E], const uint32_t (&en)[E])
+__device__ __forceinline__ unsigned store_rows(const RowTable& tb, int base, int gl, bool live, const uint32_t (&b)[E], const uint32_t (&en)[E])
 {
   unsigned mine = 0;
 #pragma unroll
-  for (int e = 0; e < E; ++e) mine += en[e] - b[e];
+  for (int e = 0; e < E; ++e)
+    if (en[e] > b[e]) mine += (1u << 20) + (en[e] - b[e]);
   if (!live) mine = 0;
-  unsigned inc = mine;
-#pragma unroll
-  for (int o = 1; o < G; o <<= 1)
-  {
-    const unsigned t = (unsigned)__shfl_up((int)inc, o, G);
-    if (gl >= o) inc += t;
-  }
-  const unsigned total = (unsigned)__shfl((int)inc, G - 1, G);
+  const unsigned inc = group_scan<G>(mine, gl);
+  const unsigned total = group_max<G>(inc);  // the scan does not decrease along the group: its last value
   if (live)
   {
     unsigned run = inc - mine;
 #pragma unroll
     for (int e = 0; e < E; ++e)
+      if (en[e] > b[e])
+      {
+        const int pos = base + (int)(run >> 20);
+        tb.b[pos] = b[e];
+        tb.e[pos] = en[e];
+        tb.p[pos] = run & 0xfffffu;
+        run += (1u << 20) + (en[e] - b[e]);
+      }
+    if (gl == G - 1)
     {
-      lb[(slot0 + e) * 256 + tid] = b[e];
-      le[(slot0 + e) * 256 + tid] = en[e];
-      lp[(slot0 + e) * 256 + tid] = run;
-      run += en[e] - b[e];
+      const int pos = base + (int)(total >> 20);
+      tb.b[pos] = 0;
+      tb.e[pos] = 0;
+      tb.p[pos] = total & 0xfffffu;
     }
   }
   return total;
@@ -198,40 +244,36 @@ __device__ __forceinline__ unsigned store_rows(uint32_t* __restrict__ lb, uint32
 
 // The scan of a block: its `total` candidates are dealt EVENLY to the G lanes of the group, whatever the rows'
 // lengths (lane gl takes the flattened range [gl total / G, (gl + 1) total / G)), every lane walks its range four
-// candidates at a time -- the loads of the next four in flight while the current four are compared -- and keeps
-// its k best in a sorted list in registers.  E: entries per lane of the block's row table, slot0: where it starts.
+// candidates at a time -- the loads of the next four in flight while the current four are compared, the bounds of
+// the next run fetched from LDS while the current run is walked -- and keeps its k best in a sorted list in
+// registers.  base: the group's table of the block, nent: its entries.
 template <int KMAX, int G>
-__device__ __forceinline__ void scan_rows(LaneList<KMAX>& L, const uint32_t* __restrict__ lb, const uint32_t* __restrict__ le,
-                                          const uint32_t* __restrict__ lp, int tid, int gl, int slot0, int E, unsigned total,
+__device__ __forceinline__ void scan_rows(LaneList<KMAX>& L, const RowTable& tb, int base, int nent, unsigned total, int gl,
                                           const float4* __restrict__ sorted, float qx, float qy, float qz, int* route)
 {
-  constexpr int U = 4;
-  const int gbase = tid - gl;
-  const unsigned S = (unsigned)(((unsigned long long)gl * total) / G);
-  unsigned n = (unsigned)(((unsigned long long)(gl + 1) * total) / G) - S;  // candidates of this lane
-  // entry f of the flattened table lives at [slot0 + f % E][gbase + f / E]; E is one of three constants: the division
-  // is a multiplication (exact for f < 5000)
-  constexpr int E1 = (9 + G - 1) / G, E2 = (25 + G - 1) / G, E3 = (49 + G - 1) / G;
-  const int inv = E == E1 ? (65536 / E1 + 1) : (E == E2 ? (65536 / E2 + 1) : (65536 / E3 + 1));
-  auto at = [&](int f) {
-    const int lane = (f * inv) >> 16;
-    return (slot0 + f - lane * E) * 256 + gbase + lane;
-  };
-  int f = 0;
-  uint32_t c = 0, cend = 0;
-  if (n > 0)
+  constexpr int U = KMAX > 8 ? 2 : 4;  // long lists: fewer candidates in flight, fewer registers
+  const unsigned S = (gl * total) / G;                // G is a power of two, total < 2^20
+  unsigned n = ((gl + 1) * total) / G - S;            // candidates of this lane
+  int f = base;
+  uint32_t c = 0, cend = 0, nb = 0, nen = 0;
   {
-    // the last entry whose prefix is <= S (entries in front of it may be empty and share its prefix)
-    int lo = 0, hi = G * E - 1;
-    while (lo < hi)
+    // the entry that holds candidate S: the last one whose prefix is <= S (prefixes increase strictly)
+    int lo = 0, hi = nent - 1;
+    if (n == 0) hi = 0;
+    while (__any(lo < hi))
     {
       const int mid = (lo + hi + 1) >> 1;
-      if (lp[at(mid)] <= S) lo = mid; else hi = mid - 1;
+      const uint32_t pm = tb.p[base + mid];
+      if (lo < hi) { if (pm <= S) lo = mid; else hi = mid - 1; }
     }
-    f = lo;
-    const int a0 = at(f);
-    c = lb[a0] + (S - lp[a0]);
-    cend = le[a0];
+    if (n > 0)
+    {
+      f = base + lo;
+      c = tb.b[f] + (S - tb.p[f]);
+      cend = tb.e[f];
+      nb = tb.b[f + 1];
+      nen = tb.e[f + 1];
+    }
   }
   // the next U candidates of the range: addresses (0 = none)
   auto gen = [&](uint32_t (&addr)[U], bool (&ok)[U]) {
@@ -242,12 +284,13 @@ __device__ __forceinline__ void scan_rows(LaneList<KMAX>& L, const uint32_t* __r
       addr[u] = 0;
       if (ok[u])
       {
-        while (c >= cend)
+        if (c >= cend)
         {
+          // next run: its bounds are in registers already, those of the one after it are on their way
+          c = nb; cend = nen;
           ++f;
-          const int a1 = at(f);
-          c = lb[a1];
-          cend = le[a1];
+          nb = tb.b[f + 1];
+          nen = tb.e[f + 1];
         }
         addr[u] = c++;
         --n;
@@ -295,11 +338,13 @@ enum { kOutNone = 0, kOutFound = 1, kOutFar = 2, kOutTail = 3 };
 // the group.  Every lane of the wavefront calls it; groups without a query (active == false) come back with kOutNone.
 template <int KMAX, int G>
 __device__ __forceinline__ int group_search(const GridDesc* __restrict__ desc, const GridPtrs& gp, float qx, float qy, float qz, int k, float far_d2,
-                                            bool active, int gl, int tid, uint32_t* __restrict__ lb, uint32_t* __restrict__ le, uint32_t* __restrict__ lp,
-                                            knn_key (&best)[KMAX], float& ub_out, int* route)
+                                            bool active, int gl, int tid, const RowTable& tb, knn_key (&best)[KMAX], float& ub_out, int* route)
 {
   constexpr int E1 = (9 + G - 1) / G, E2 = (25 + G - 1) / G, E3 = (49 + G - 1) / G;
-  static_assert(2 * E1 + E2 <= kSlots && E3 <= kSlots, "row slots");
+  constexpr int CAP = table_capacity<G>();
+  static_assert((256 / G) * CAP <= kTableEntries, "row tables");
+  const int gbase = ((tid - gl) / G) * CAP;  // this group's tables
+  const int base3[3] = {gbase, gbase + G * E1 + 1, gbase + G * (E1 + E2) + 2};
   const GridDesc g0 = desc[0], g1 = desc[1], g2 = desc[2];
   LevelView v0, v1, v2;
   level_view(v0, g0, qx, qy, qz);
@@ -309,8 +354,8 @@ __device__ __forceinline__ int group_search(const GridDesc* __restrict__ desc, c
     const int l = shell_level(s), r = shell_r(s);
     return l == 0 ? proven2(g0, v0, r) : (l == 1 ? proven2(g1, v1, r) : proven2(g2, v2, r));
   };
-  // rows of the block of shell s (any shell, per group) into slots [0, E3); groups that are not concerned keep what
-  // their slots hold (rows of shells 0..2 they may still scan)
+  // rows of the block of shell s (any shell, per group) into the table at gbase; groups that are not concerned keep
+  // what their tables hold (blocks of shells 0..2 they may still scan)
   auto fetch_any = [&](int s, bool live, bool& covered) -> unsigned {
     const int l = shell_level(s), r = shell_r(s);
     const GridDesc& g = l == 0 ? g0 : (l == 1 ? g1 : g2);
@@ -318,45 +363,51 @@ __device__ __forceinline__ int group_search(const GridDesc* __restrict__ desc, c
     const uint32_t* cs = l == 0 ? gp.cell_start[0] : (l == 1 ? gp.cell_start[1] : gp.cell_start[2]);
     uint32_t b[E3], en[E3];
     shell_rows<G, E3>(g, cs, v, r, gl, live, b, en, covered);
-    return store_rows<G, E3>(lb, le, lp, 0, tid, gl, live, b, en);
+    return store_rows<G, E3>(tb, gbase, gl, live, b, en);
   };
 
   int outcome = kOutNone;
-  int sh = -1, slot0 = 0, ents = E1;
-  unsigned total = 0;
+  int sh = -1, base = gbase;
+  unsigned total = 0;  // (entries << 20 | candidates) of the block to scan
   bool sh_covered = false;
   bool need = active;
   ub_out = INFINITY;
 
   // shells 0, 1, 2: the bounds of all their rows in one memory round trip
+  constexpr int kBatch[3] = {0, 1, 2};
   unsigned tot3[3];
+  bool batch_ok = true;  // the group's tables still hold those three blocks
   {
     uint32_t b0[E1], e0[E1], b1[E2], e1[E2], b2[E1], e2[E1];
     bool c0, c1, c2;
     shell_rows<G, E1>(g0, gp.cell_start[0], v0, 1, gl, active, b0, e0, c0);
     shell_rows<G, E2>(g0, gp.cell_start[0], v0, 2, gl, active, b1, e1, c1);
     shell_rows<G, E1>(g1, gp.cell_start[1], v1, 1, gl, active, b2, e2, c2);
-    tot3[0] = store_rows<G, E1>(lb, le, lp, 0, tid, gl, active, b0, e0);
-    tot3[1] = store_rows<G, E2>(lb, le, lp, E1, tid, gl, active, b1, e1);
-    tot3[2] = store_rows<G, E1>(lb, le, lp, E1 + E2, tid, gl, active, b2, e2);
+    tot3[0] = store_rows<G, E1>(tb, base3[0], gl, active, b0, e0);
+    tot3[1] = store_rows<G, E2>(tb, base3[1], gl, active, b1, e1);
+    tot3[2] = store_rows<G, E1>(tb, base3[2], gl, active, b2, e2);
     const bool cov[3] = {c0, c1, c2};
-    const int first[3] = {0, E1, E1 + E2}, count[3] = {E1, E2, E1};
+    // fewer than k points inside a radius beyond the rejection distance
 #pragma unroll
-    for (int s = 0; s < 3; ++s)
-      if (need)
+    for (int j = 0; j < 3; ++j)
+      if (need && !cov[j] && (tot3[j] & 0xfffffu) < (unsigned)k && bound2(kBatch[j]) > far_d2)
       {
-        if (tot3[s] >= (unsigned)k || cov[s])
-        {
-          sh = s; sh_covered = cov[s]; slot0 = first[s]; ents = count[s]; total = tot3[s];
-          need = false;
-        }
-        else if (bound2(s) > far_d2)
-        {
-          // fewer than k points inside a radius beyond the rejection distance
-          outcome = kOutFar;
-          need = false;
-        }
+        outcome = kOutFar;
+        need = false;
       }
+    auto choose = [&](int j) {
+      sh = kBatch[j]; sh_covered = cov[j]; base = base3[j]; total = tot3[j];
+      need = false;
+    };
+    // A block that holds just k points seldom proves them nearest (they sit in its corners): the first block with a
+    // few times k is the one to scan -- most queries then need no second scan; failing that, the largest of the three
+    // that holds k at all.
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+      if (need && (cov[j] || (tot3[j] & 0xfffffu) >= (unsigned)(kFill * k))) choose(j);
+#pragma unroll
+    for (int j = 2; j >= 0; --j)
+      if (need && (tot3[j] & 0xfffffu) >= (unsigned)k) choose(j);
   }
   // sparser neighbourhoods: one larger block after the other, by the counts alone
   for (int s = 3; s < kShells; ++s)
@@ -366,9 +417,10 @@ __device__ __forceinline__ int group_search(const GridDesc* __restrict__ desc, c
     const unsigned tot = fetch_any(s, need, cov);
     if (need)
     {
-      if (tot >= (unsigned)k || cov)
+      batch_ok = false;
+      if ((tot & 0xfffffu) >= (unsigned)k || cov)
       {
-        sh = s; sh_covered = cov; slot0 = 0; ents = E3; total = tot;
+        sh = s; sh_covered = cov; base = gbase; total = tot;
         need = false;
       }
       else if (bound2(s) > far_d2)
@@ -393,7 +445,7 @@ __device__ __forceinline__ int group_search(const GridDesc* __restrict__ desc, c
     LaneList<KMAX> L;
     L.reset();
     const float4* sorted = sh < 2 ? gp.sorted[0] : (sh < 4 ? gp.sorted[1] : gp.sorted[2]);
-    scan_rows<KMAX, G>(L, lb, le, lp, tid, gl, slot0, ents, sh >= 0 ? total : 0u, sorted, qx, qy, qz, route);
+    scan_rows<KMAX, G>(L, tb, base, sh >= 0 ? (int)(total >> 20) : 0, sh >= 0 ? (total & 0xfffffu) : 0u, gl, sorted, qx, qy, qz, route);
     merge_lists<KMAX, G>(L, k, best);
     if (sh >= 0)
     {
@@ -422,33 +474,28 @@ __device__ __forceinline__ int group_search(const GridDesc* __restrict__ desc, c
   // second scan, certain
   if (__any(sh2 >= 0))
   {
-    int slot2 = 0, ents2 = E1;
+    int base2 = gbase;
     unsigned total2 = 0;
-    if (sh2 >= 0 && sh2 < 3)
+    // shells 1 and 2 are still in their tables from the first round trip if this group fetched nothing since
+    const bool kept = sh2 >= 0 && batch_ok && (sh2 == 1 || sh2 == 2);
+    if (kept)
     {
-      // still in its slots from the first round trip (this group fetched nothing since)
-      slot2 = sh2 == 1 ? E1 : E1 + E2;
-      ents2 = sh2 == 1 ? E2 : E1;
+      base2 = sh2 == 1 ? base3[1] : base3[2];
       total2 = sh2 == 1 ? tot3[1] : tot3[2];
     }
-    if (__any(sh2 >= 3))
+    const bool fetch2 = sh2 >= 0 && !kept;
+    if (__any(fetch2))
     {
       bool cov;
-      const unsigned tot = fetch_any(sh2 >= 3 ? sh2 : 3, sh2 >= 3, cov);
-      if (sh2 >= 3) { slot2 = 0; ents2 = E3; total2 = tot; }
+      const unsigned tot = fetch_any(fetch2 ? sh2 : 3, fetch2, cov);
+      if (fetch2) { base2 = gbase; total2 = tot; }
     }
     LaneList<KMAX> L;
     L.reset();
     const float4* sorted = sh2 < 2 ? gp.sorted[0] : (sh2 < 4 ? gp.sorted[1] : gp.sorted[2]);
-    knn_key second[KMAX];
-    scan_rows<KMAX, G>(L, lb, le, lp, tid, gl, slot2, ents2, sh2 >= 0 ? total2 : 0u, sorted, qx, qy, qz, route);
-    merge_lists<KMAX, G>(L, k, second);
-    if (sh2 >= 0)
-    {
-#pragma unroll
-      for (int s = 0; s < KMAX; ++s) best[s] = second[s];
-      outcome = kOutFound;
-    }
+    scan_rows<KMAX, G>(L, tb, base2, sh2 >= 0 ? (int)(total2 >> 20) : 0, sh2 >= 0 ? (total2 & 0xfffffu) : 0u, gl, sorted, qx, qy, qz, route);
+    merge_lists<KMAX, G>(L, k, best, sh2 >= 0);
+    if (sh2 >= 0) outcome = kOutFound;
   }
   return outcome;
 }
@@ -457,7 +504,8 @@ struct FusedType
 {
   const float4* queries;  // AoS keypoints, two float4 each
   int nq;
-  int block0, nblocks;    // this type's logical blocks [block0, block0 + nblocks)
+  int nblocks;            // search blocks of this type
+  int mblocks;            // model blocks of this type
   int k;
   float far_d2;
   MatchConst mc;
@@ -465,47 +513,40 @@ struct FusedType
   GridPtrs gp;
   const float4* xyzl;
   int npoints;
+  int* knn_idx;           // [k][cap] neighbour lists: written by the search, read by the model fit
+  float* knn_d2;
+  int* knn_cnt;
   double* rec;
   uint8_t* status;
   int cap;
-  int* hist;              // [8] rejection histogram, [8] queries handed to the tail kernel
-  int* list;
-  float4* list_pts;
+  int* hist;              // [8] rejection histogram, [8] diagnostics
   int route_stats;        // diagnostics: count the routes the searches take (hist[10..15])
+  unsigned long long* trace;  // diagnostics: per hardware block {start, end, 0, where} (100 MHz clock)
 };
 struct FusedArgs
 {
   Rigid pose;
   FusedType t[3];
-  int nblocks;  // logical blocks of all types
 };
 
-constexpr int kNbCols = 64;  // keypoints a block fits models for at most (G >= 4)
-struct FusedShared
+struct SearchShared
 {
-  union
-  {
-    struct { uint32_t lb[kSlots * 256], le[kSlots * 256], lp[kSlots * 256]; } rows;  // during the search
-    struct { float4 nb[kKnnMax * kNbCols]; float nd[kKnnMax * kNbCols]; } edge;  // during the model fit (edges)
-  } u;
-  int idx[kKnnMax * kNbCols];
-  float d2[kKnnMax * kNbCols];
-  int cnt[kNbCols];
-  int lh[LSA_MATCH_NSTATUS];
-  int route[6];  // diagnostics: [0] second scans, [1] first block beyond shell 2, [2] candidates scanned / 64, [3] far, [4] first block = shell 0, [5] longest lane walk
+  uint32_t b[kTableEntries], e[kTableEntries], p[kTableEntries];  // the groups' row tables
+  int route[6];  // diagnostics: [0] second scans, [1] first block beyond shell 2, [2] candidates walked, [3] far, [4] first block = shell 0, [5] longest lane walk
 };
 
-template <int KMAX, int G, int TYPE>
-__device__ __forceinline__ void fused_type(const Rigid& pose, const FusedType& t, int block, FusedShared& sh)
+template <int KMAX, int G>
+__device__ __forceinline__ void search_type(const Rigid& pose, const FusedType& t, int block, SearchShared& sh)
 {
   constexpr int QB = 256 / G;
-  static_assert(QB <= kNbCols, "LDS columns");
   const int tid = threadIdx.x, gl = tid % G, ql = tid / G;
   const int q = block * QB + ql;
-  const bool active = q < t.nq && !t.mc.bad_param;
-  if (tid < LSA_MATCH_NSTATUS) sh.lh[tid] = 0;
-  if (tid < 6) sh.route[tid] = 0;
-  if (t.route_stats) __syncthreads();
+  const bool active = q < t.nq;
+  if (t.route_stats)
+  {
+    if (tid < 6) sh.route[tid] = 0;
+    __syncthreads();
+  }
   float qx = 0.f, qy = 0.f, qz = 0.f;
   if (active)
   {
@@ -520,141 +561,170 @@ __device__ __forceinline__ void fused_type(const Rigid& pose, const FusedType& t
 #pragma unroll
   for (int s = 0; s < KMAX; ++s) best[s] = kKeyEmpty;
   float ub = INFINITY;
-  const int outcome = group_search<KMAX, G>(t.desc, t.gp, qx, qy, qz, t.k, t.far_d2, active, gl, tid, sh.u.rows.lb, sh.u.rows.le, sh.u.rows.lp, best, ub, t.route_stats ? sh.route : nullptr);
-  if (gl == 0)
+  const unsigned long long tick0 = t.trace ? wall_clock64() : 0ull;
+  const RowTable tb = {sh.b, sh.e, sh.p};
+  const int outcome = group_search<KMAX, G>(t.desc, t.gp, qx, qy, qz, t.k, t.far_d2, active, gl, tid, tb, best, ub, t.route_stats ? sh.route : nullptr);
+  if (gl == 0 && active)
   {
     int cnt = 0;
 #pragma unroll
     for (int s = 0; s < KMAX; ++s)
       if (s < t.k)
       {
-        sh.idx[s * kNbCols + ql] = key_idx(best[s]);
-        sh.d2[s * kNbCols + ql] = key_d2(best[s]);
+        t.knn_idx[(size_t)s * t.cap + q] = key_idx(best[s]);
+        t.knn_d2[(size_t)s * t.cap + q] = key_d2(best[s]);
         if (best[s] != kKeyEmpty) ++cnt;
       }
-    if (outcome == kOutTail)
-    {
-      // handed to the tail kernel: the query in target coordinates and what is known about its k-th distance
-      const int slot = atomicAdd(t.hist + LSA_MATCH_NSTATUS, 1);
-      t.list[slot] = q;
-      t.list_pts[slot] = make_float4(qx, qy, qz, ub);
-      cnt = kPending;
-    }
-    else if (outcome == kOutFar) cnt = kKnnFar;
-    sh.cnt[ql] = cnt;
+    // kPending: no block of the grid settles it -- the model kernel's wavefront searches the whole target for it
+    t.knn_cnt[q] = outcome == kOutTail ? kPending : (outcome == kOutFar ? kKnnFar : cnt);
   }
-  __syncthreads();  // the search is over for the whole block: its row slots become the edge staging area
-  if (tid < QB)
+  if (t.route_stats)
   {
-    const int i = block * QB + tid;
-    if (i < t.nq)
+    __syncthreads();
+    if (t.trace && tid == 0)
     {
-      const int n = t.mc.bad_param ? 0 : sh.cnt[tid];
-      if (n != kPending)
-      {
-        const int st = fit_model<KMAX, TYPE>(
-          t.queries[2 * (size_t)i], t.mc, n, [&](int s) { return sh.idx[s * kNbCols + tid]; }, [&](int s) { return sh.d2[s * kNbCols + tid]; }, t.xyzl,
-          sh.u.edge.nb, sh.u.edge.nd, kNbCols, tid, t.rec, t.cap, i);
-        t.status[i] = (uint8_t)st;
-        atomicAdd(&sh.lh[st], 1);
-      }
+      const unsigned long long tick1 = wall_clock64();
+      unsigned xcc = 0, hwid = 0;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+      unsigned long long* tr = t.trace + (size_t)blockIdx.x * 12;
+      tr[0] = tick0; tr[1] = tick1; tr[2] = tick1; tr[3] = ((unsigned long long)xcc << 32) | hwid;
+      for (int i = 0; i < 6; ++i) tr[4 + i] = (unsigned long long)sh.route[i];
     }
-  }
-  __syncthreads();
-  if (tid < LSA_MATCH_NSTATUS && sh.lh[tid]) atomicAdd(&t.hist[tid], sh.lh[tid]);
-  if (t.route_stats && tid < 6 && sh.route[tid])
-  {
-    if (tid == 5) atomicMax(&t.hist[LSA_MATCH_NSTATUS + 2 + tid], sh.route[tid]);
-    else atomicAdd(&t.hist[LSA_MATCH_NSTATUS + 2 + tid], sh.route[tid]);
+    if (tid < 6 && sh.route[tid])
+    {
+      if (tid == 5) atomicMax(&t.hist[LSA_MATCH_NSTATUS + 2 + tid], sh.route[tid]);
+      else atomicAdd(&t.hist[LSA_MATCH_NSTATUS + 2 + tid], sh.route[tid]);
+    }
   }
 }
 
-// lanes per query of the three types
-constexpr int kGE = 8, kGB = 8;
+// lanes per query
+constexpr int kGE = 8, kGP = 8, kGB = 8;
 
-template <int KE, int KP, int KB, int GP>
-__global__ __launch_bounds__(256) void k_match_fused(FusedArgs a)
+// The searches of one ICP iteration, all keypoint types in one launch.
+template <int KE, int KP, int KB>
+__global__ __launch_bounds__(256, 4) void k_search_all(FusedArgs a)
 {
-  __shared__ FusedShared sh;
-  // consecutive logical blocks hold neighbouring keypoints (scan order): they are dealt to ONE XCD, whose L2 then
-  // serves a compact region of the target (hardware blocks b, b + 8, ... share an XCD)
-  const int per_xcd = (a.nblocks + 7) / 8;
-  const int block = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
-  if (block >= a.nblocks) return;
-  if (block < a.t[1].block0) fused_type<KE, kGE, LSA_EDGE>(a.pose, a.t[0], block - a.t[0].block0, sh);
-  else if (block < a.t[2].block0) fused_type<KP, GP, LSA_PLANE>(a.pose, a.t[1], block - a.t[1].block0, sh);
-  else fused_type<KB, kGB, LSA_BLOB>(a.pose, a.t[2], block - a.t[2].block0, sh);
+  __shared__ SearchShared sh;
+  // Hardware blocks b, b + 8, ... share an XCD (and its L2).  Every XCD gets one contiguous eighth of EVERY type's
+  // blocks -- neighbouring keypoints (scan order) search a compact region of the target through one L2 -- and the
+  // types with the longest searches (edges: no early out, larger k) first.
+  const int xcd = blockIdx.x % 8, j = blockIdx.x / 8;
+  const int se = (a.t[0].nblocks + 7) / 8, sp = (a.t[1].nblocks + 7) / 8;
+  if (j < se)
+  {
+    const int block = xcd * se + j;
+    if (block < a.t[0].nblocks) search_type<KE, kGE>(a.pose, a.t[0], block, sh);
+  }
+  else if (j < se + sp)
+  {
+    const int block = xcd * sp + (j - se);
+    if (block < a.t[1].nblocks) search_type<KP, kGP>(a.pose, a.t[1], block, sh);
+  }
+  else
+  {
+    if constexpr (KB > 0)
+    {
+      const int sb = (a.t[2].nblocks + 7) / 8;
+      const int block = xcd * sb + (j - se - sp);
+      if (block < a.t[2].nblocks) search_type<KB, kGB>(a.pose, a.t[2], block, sh);
+    }
+  }
 }
 
-// Tail: the queries no block of the grid could settle, one wavefront each over the whole target (every lane
-// keeps the k best of its share, one merge at the end), then their model fit.
-constexpr int kTailBlocks = 16;  // per type
-template <int KMAX, int TYPE>
-__device__ __forceinline__ void tail_type(const FusedType& t, int block, FusedShared& sh)
+// The model fits of one ICP iteration, one thread per keypoint, all types in one launch.  What the search could not
+// settle inside the grid's blocks (kPending) is searched here first: the wavefront of such a keypoint walks the whole
+// target for it, every lane keeping the k best of its share, one merge at the end.
+template <int KE>
+struct ModelShared
 {
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  float4 nb[KE * kModelBlock];  // edge candidates staged in LDS
+  float nd[KE * kModelBlock];
+  int lh[LSA_MATCH_NSTATUS];
+};
+
+template <int KMAX, int TYPE, typename SH>
+__device__ __forceinline__ void model_type(const Rigid& pose, const FusedType& t, int block, SH& sh)
+{
+  const int tid = threadIdx.x, lane = tid & 63;
   if (tid < LSA_MATCH_NSTATUS) sh.lh[tid] = 0;
   __syncthreads();
-  const int nwork = t.nq > 0 ? t.hist[LSA_MATCH_NSTATUS] : 0;
-  const float4* __restrict__ sorted = t.gp.sorted[0];
-  for (int w = block * 4 + wv; w < nwork; w += kTailBlocks * 4)
+  const int i = block * kModelBlock + tid;
+  const bool have = i < t.nq;
+  int n = 0;
+  if (have && !t.mc.bad_param) n = t.knn_cnt[i];
+  unsigned long long pending = __ballot(have && n == kPending);
+  while (pending)
   {
-    const int q = t.list[w];
-    const float4 qp = t.list_pts[w];
+    const int src = __ffsll((long long)pending) - 1;
+    pending &= pending - 1;
+    const int qi = block * kModelBlock + (tid - lane) + src;
+    const float4 q4 = t.queries[2 * (size_t)qi];
+    double wx, wy, wz;
+    rigid_apply(pose, (double)q4.x, (double)q4.y, (double)q4.z, wx, wy, wz);
+    const float qx = (float)wx, qy = (float)wy, qz = (float)wz;
     LaneList<KMAX> L;
     L.reset();
+    const float4* __restrict__ sorted = t.gp.sorted[0];
     for (int c = lane; c < t.npoints; c += 64)
     {
       const float4 p = sorted[c];
-      const float dx = qp.x - p.x, dy = qp.y - p.y, dz = qp.z - p.z;
+      const float dx = qx - p.x, dy = qy - p.y, dz = qz - p.z;
       L.insert(make_key((dx * dx + dy * dy) + dz * dz, __float_as_int(p.w)));
     }
     knn_key best[KMAX];
     merge_lists<KMAX, 64>(L, t.k, best);
-    if (lane == 0)
+    if (lane == src)
     {
       int cnt = 0;
 #pragma unroll
       for (int s = 0; s < KMAX; ++s)
         if (s < t.k)
         {
-          sh.idx[s * kNbCols + wv] = key_idx(best[s]);
-          sh.d2[s * kNbCols + wv] = key_d2(best[s]);
+          t.knn_idx[(size_t)s * t.cap + qi] = key_idx(best[s]);
+          t.knn_d2[(size_t)s * t.cap + qi] = key_d2(best[s]);
           if (best[s] != kKeyEmpty) ++cnt;
         }
-      atomicAdd(t.hist + LSA_MATCH_NSTATUS + 1, 1);
-      const int st = fit_model<KMAX, TYPE>(
-        t.queries[2 * (size_t)q], t.mc, cnt, [&](int s) { return sh.idx[s * kNbCols + wv]; }, [&](int s) { return sh.d2[s * kNbCols + wv]; }, t.xyzl,
-        sh.u.edge.nb, sh.u.edge.nd, kNbCols, wv, t.rec, t.cap, q);
-      t.status[q] = (uint8_t)st;
-      atomicAdd(&sh.lh[st], 1);
+      n = cnt;
+      atomicAdd(t.hist + LSA_MATCH_NSTATUS, 1);
     }
+  }
+  if (have)
+  {
+    const int st = fit_model<KMAX, TYPE>(
+      t.queries[2 * (size_t)i], t.mc, n, [&](int s) { return t.knn_idx[(size_t)s * t.cap + i]; }, [&](int s) { return t.knn_d2[(size_t)s * t.cap + i]; },
+      t.xyzl, sh.nb, sh.nd, kModelBlock, tid, t.rec, t.cap, i);
+    t.status[i] = (uint8_t)st;
+    atomicAdd(&sh.lh[st], 1);
   }
   __syncthreads();
   if (tid < LSA_MATCH_NSTATUS && sh.lh[tid]) atomicAdd(&t.hist[tid], sh.lh[tid]);
 }
 
 template <int KE, int KP, int KB>
-__global__ __launch_bounds__(256) void k_match_tail(FusedArgs a)
+__global__ __launch_bounds__(kModelBlock) void k_model_all(FusedArgs a)
 {
-  __shared__ FusedShared sh;
-  const int type = blockIdx.x / kTailBlocks, block = blockIdx.x % kTailBlocks;
-  if (type == 0) tail_type<KE, LSA_EDGE>(a.t[0], block, sh);
-  else if (type == 1) tail_type<KP, LSA_PLANE>(a.t[1], block, sh);
-  else tail_type<KB, LSA_BLOB>(a.t[2], block, sh);
+  __shared__ ModelShared<KE> sh;
+  int b = blockIdx.x;
+  if (b < a.t[0].mblocks) { model_type<KE, LSA_EDGE>(a.pose, a.t[0], b, sh); return; }
+  b -= a.t[0].mblocks;
+  if (b < a.t[1].mblocks) { model_type<KP, LSA_PLANE>(a.pose, a.t[1], b, sh); return; }
+  b -= a.t[1].mblocks;
+  if constexpr (KB > 0) model_type<KB, LSA_BLOB>(a.pose, a.t[2], b, sh);
 }
 
 template <int KE, int KP, int KB>
-void launch_fused(lsa_ctx* ctx, const FusedArgs& a, int plane_lanes, double bytes, hipStream_t st)
+void launch_fused(lsa_ctx* ctx, const FusedArgs& a, double search_bytes, double model_bytes, hipStream_t st)
 {
-  const int grid = 8 * ((a.nblocks + 7) / 8);
+  const int grid = 8 * ((a.t[0].nblocks + 7) / 8 + (a.t[1].nblocks + 7) / 8 + (a.t[2].nblocks + 7) / 8);
+  if (grid > 0)
   {
-    ProfScope ps(ctx, "match_fused", bytes, st);
-    if (plane_lanes >= 8) hipLaunchKernelGGL((k_match_fused<KE, KP, KB, 8>), dim3(grid), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((k_match_fused<KE, KP, KB, 4>), dim3(grid), dim3(256), 0, st, a);
+    ProfScope ps(ctx, "match_search", search_bytes, st);
+    hipLaunchKernelGGL((k_search_all<KE, KP, KB>), dim3(grid), dim3(256), 0, st, a);
   }
-  ProfScope ps(ctx, "match_tail", 0., st);
-  hipLaunchKernelGGL((k_match_tail<KE, KP, KB>), dim3(3 * kTailBlocks), dim3(256), 0, st, a);
+  ProfScope ps(ctx, "match_model", model_bytes, st);
+  hipLaunchKernelGGL((k_model_all<KE, KP, KB>), dim3(a.t[0].mblocks + a.t[1].mblocks + a.t[2].mblocks), dim3(kModelBlock), 0, st, a);
 }
 
 }  // namespace
@@ -663,14 +733,15 @@ namespace lsa
 {
 
 // Enqueues the matches `preps` describes (at most one per keypoint type, every one with a non-empty target and at
-// least one keypoint) as one launch + the tail launch on `st`.
+// least one keypoint) as two launches on `st`: the searches of all types, then their model fits.
 int enqueue_fused_match(lsa_ctx* ctx, const MatchPrep* preps, int count, const double pose[16], hipStream_t st)
 {
   FusedArgs a;
   std::memset(&a, 0, sizeof(a));
   row_major_to_rt(pose, a.pose.R, a.pose.t);
   int kmax[3] = {1, 1, 1};
-  double bytes = 0;
+  const int lanes[3] = {kGE, kGP, kGB};
+  double search_bytes = 0, model_bytes = 0;
   for (int i = 0; i < count; ++i)
   {
     const MatchPrep& p = preps[i];
@@ -686,30 +757,30 @@ int enqueue_fused_match(lsa_ctx* ctx, const MatchPrep* preps, int count, const d
     for (int l = 0; l < kGridLevels; ++l) { t.gp.cell_start[l] = tg.lv[l].cell_start; t.gp.sorted[l] = tg.lv[l].sorted; }
     t.xyzl = tg.xyzl;
     t.npoints = tg.m;
+    t.knn_idx = mb.knn_idx; t.knn_d2 = mb.knn_d2; t.knn_cnt = mb.knn_cnt;
     t.rec = mb.rec; t.status = mb.status; t.cap = mb.cap;
     t.hist = p.hist;
-    t.list = mb.slow_list; t.list_pts = mb.slow_pts;
     t.route_stats = ctx->route_stats ? 1 : 0;
+    t.trace = ctx->route_stats ? reinterpret_cast<unsigned long long*>(ctx->trace_dev) : nullptr;
     kmax[p.type] = p.mc.k;
-    // algorithmic bytes (B_icp): keypoint in, k gathered target points, residual record out
-    bytes += (double)p.nq * (32 + p.mc.k * 32 + 136);
+    // a type whose parameters are invalid is not searched (BAD_MODEL_PARAMETRIZATION for every keypoint)
+    t.nblocks = p.mc.bad_param ? 0 : (int)(((size_t)p.nq * lanes[p.type] + 255) / 256);
+    t.mblocks = (p.nq + kModelBlock - 1) / kModelBlock;
+    // algorithmic bytes (B_icp = K (32 + 32 k + 136)): keypoint in, k candidate points examined at
+    // least, k (index, distance) pairs out | keypoint and neighbour lists in, k gathered target points, record out
+    search_bytes += (double)p.nq * (32 + p.mc.k * 16 + p.mc.k * 8);
+    model_bytes += (double)p.nq * (32 + p.mc.k * 8 + p.mc.k * 16 + 136);
   }
-  const int lanes[3] = {kGE, ctx->knn_lanes[LSA_PLANE] >= 8 ? 8 : 4, kGB};
-  int block0 = 0;
-  for (int k = 0; k < 3; ++k)
-  {
-    a.t[k].block0 = block0;
-    a.t[k].nblocks = a.t[k].nq > 0 ? (int)(((size_t)a.t[k].nq * lanes[k] + 255) / 256) : 0;
-    block0 += a.t[k].nblocks;
-  }
-  a.nblocks = block0;
-  if (block0 == 0) return LSA_OK;
-  const int ke = kmax[0], kp = kmax[1], kb = kmax[2];
-  if (ke <= 8 && kp <= 5) launch_fused<8, 5, 16>(ctx, a, lanes[1], bytes, st);
-  else if (kp <= 5) launch_fused<16, 5, 16>(ctx, a, lanes[1], bytes, st);
-  else if (kp <= 8) launch_fused<16, 8, 16>(ctx, a, lanes[1], bytes, st);
-  else launch_fused<16, 16, 16>(ctx, a, lanes[1], bytes, st);
-  (void)kb;
+  if (a.t[0].mblocks + a.t[1].mblocks + a.t[2].mblocks == 0) return LSA_OK;
+  // the list lengths compiled in: the reference's defaults (edges 8 ego-motion / 10 localization, planes 5, no blobs)
+  // get kernels of their own -- one kernel has one register budget, the longest list in it sets it for every type
+  const int ke = kmax[0], kp = kmax[1];
+  const bool blobs = a.t[2].nq > 0;
+  if (!blobs && ke <= 8 && kp <= 5) launch_fused<8, 5, 0>(ctx, a, search_bytes, model_bytes, st);
+  else if (!blobs && ke <= 10 && kp <= 5) launch_fused<10, 5, 0>(ctx, a, search_bytes, model_bytes, st);
+  else if (kp <= 5) launch_fused<16, 5, 16>(ctx, a, search_bytes, model_bytes, st);
+  else if (kp <= 8) launch_fused<16, 8, 16>(ctx, a, search_bytes, model_bytes, st);
+  else launch_fused<16, 16, 16>(ctx, a, search_bytes, model_bytes, st);
   return LSA_OK;
 }
 

@@ -1,0 +1,37 @@
+"""Timeline of the hardware blocks of the LAST fused match launch of a replayed sequence (as bench.py runs it)."""
+import os, sys
+os.environ["LSA_ROUTE_STATS"] = "1"
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import lidarslam_amd as L
+
+lookahead = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+slam = L.Slam(0, EgoMotion=3)
+n = 30
+stamps = []
+for f in range(n):
+    pts, stamp = L.synth_frame(128, 1000, f)
+    slam.store_frame(f, pts)
+    stamps.append(stamp)
+ctx = slam.context()
+for f in range(n):
+    if lookahead and f + 1 < n:
+        slam.hint_next_stored_frame(f + 1)
+    slam.add_stored_frame(f, stamps[f], f)
+ctx.sync()
+tr = ctx.match_trace(2048)
+ok = tr[:, 0] > 0
+# only the blocks of the last launch: those that started within 1 ms of the latest start
+last = tr[ok, 0].max()
+ok &= tr[:, 0] + 100000 > last
+t0 = tr[ok, 0].min()
+start, mid, end = (tr[:, 0] - t0) / 100.0, (tr[:, 1] - t0) / 100.0, (tr[:, 2] - t0) / 100.0
+print("lookahead", lookahead, "blocks", int(ok.sum()), "span us %.1f" % end[ok].max(), "search p50/max %.1f %.1f" % (np.median((mid - start)[ok]), (mid - start)[ok].max()),
+      "model p50/max %.1f %.1f" % (np.median((end - mid)[ok]), (end - mid)[ok].max()), "start p50/max %.1f %.1f" % (np.median(start[ok]), start[ok].max()))
+for t in range(0, int(end[ok].max()) + 10, 10):
+    print("t=%3d us running blocks %4d" % (t, int(((start <= t) & (end > t) & ok).sum())))
+
+lt = ctx.solve_device_trace().astype(np.float64)
+if lt[6] > 0:
+    print("LM solves %d, evaluations/solve %.2f, in-kernel us/solve %.1f; per evaluation us: evaluate %.2f exchange %.2f fold %.2f step %.2f" % (
+        lt[6], lt[4] / lt[6], lt[5] / lt[6] / 100, lt[0] / lt[4] / 100, lt[1] / lt[4] / 100, lt[2] / lt[4] / 100, lt[3] / lt[4] / 100))

@@ -15,7 +15,7 @@ names = ["tail", "tail done", "second scans", "first block > shell 2", "walked",
 for name, mp, cells in (("ego", L.MatchParams.ego_motion(saturation_distance=5.0), (0.5, 0.25)), ("loc", L.MatchParams.localization(saturation_distance=2.0), (0.75, 0.6))):
     for k in (L.EDGE, L.PLANE):
         ctx.set_target_from_set(k, L.SET_RAW_PREVIOUS, cell=cells[k])
-    for rep in range(3):
+    for rep in range(5):
         ctx.match_types(3, L.SET_RAW_CURRENT, mp, T, slot=L.TARGET_PREVIOUS, histograms=False)
     ctx.sync()
     for k in (L.EDGE, L.PLANE):

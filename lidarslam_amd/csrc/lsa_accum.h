@@ -93,6 +93,48 @@ __device__ __forceinline__ double dpp_row_shl(double x, int o)
   return __longlong_as_double(((long long)hi << 32) | (long long)(unsigned)lo);
 }
 
+// one residual block's contribution: acc += its cost, gradient, J^T J and count
+__device__ __forceinline__ void accumulate_one(const double A[9], double Px, double Py, double Pz, double Xx, double Xy, double Xz, double weight, double a2,
+                                               const RotConst& c, bool jac, double acc[kAccumVals])
+{
+  double yx, yy, yz;
+  mv3(c.R, Xx, Xy, Xz, yx, yy, yz);
+  const double dx = (yx + c.t[0]) - Px, dy = (yy + c.t[1]) - Py, dz = (yz + c.t[2]) - Pz;
+  double r0, r1, r2;
+  mv3(A, dx, dy, dz, r0, r1, r2);
+  const double s = (r0 * r0 + r1 * r1) + r2 * r2;
+  double rho0, rho1;
+  if (s <= a2)
+  {
+    const double value = 1.0 - s / a2;
+    const double value_sq = value * value;
+    rho0 = a2 / 3.0 * (1.0 - value_sq * value);
+    rho1 = value_sq;
+  }
+  else { rho0 = a2 / 3.0; rho1 = 0.0; }
+  rho0 *= weight; rho1 *= weight;
+  acc[0] += 0.5 * rho0;
+  acc[28] += 1.0;
+  if (!jac) return;
+  double J[3][6];
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int b = 0; b < 3; ++b) J[a][b] = A[a * 3 + b];
+  double vx, vy, vz, cx, cy, cz;
+  mv3(c.dRx, Xx, Xy, Xz, vx, vy, vz); mv3(A, vx, vy, vz, cx, cy, cz); J[0][3] = cx; J[1][3] = cy; J[2][3] = cz;
+  mv3(c.dRy, Xx, Xy, Xz, vx, vy, vz); mv3(A, vx, vy, vz, cx, cy, cz); J[0][4] = cx; J[1][4] = cy; J[2][4] = cz;
+  mv3(c.dRz, Xx, Xy, Xz, vx, vy, vz); mv3(A, vx, vy, vz, cx, cy, cz); J[0][5] = cx; J[1][5] = cy; J[2][5] = cz;
+  int h = 7;
+#pragma unroll
+  for (int a = 0; a < 6; ++a)
+  {
+    acc[1 + a] += rho1 * ((J[0][a] * r0 + J[1][a] * r1) + J[2][a] * r2);
+#pragma unroll
+    for (int b = a; b < 6; ++b) acc[h++] += rho1 * ((J[0][a] * J[0][b] + J[1][a] * J[1][b]) + J[2][a] * J[2][b]);
+  }
+}
+
 // this thread's share of the residual blocks (grid stride over EDGE[0..), PLANE[0..), BLOB[0..)): acc += their
 // cost, gradient, J^T J and count
 __device__ __forceinline__ void accumulate_records(const RecordSet& rs, const RotConst& c, bool jac, int first, int stride, double acc[kAccumVals])
@@ -111,43 +153,60 @@ __device__ __forceinline__ void accumulate_records(const RecordSet& rs, const Ro
     const double Px = rec[9 * cap + i], Py = rec[10 * cap + i], Pz = rec[11 * cap + i];
     const double Xx = rec[12 * cap + i], Xy = rec[13 * cap + i], Xz = rec[14 * cap + i];
     const double weight = rec[15 * cap + i];
-    double yx, yy, yz;
-    mv3(c.R, Xx, Xy, Xz, yx, yy, yz);
-    const double dx = (yx + c.t[0]) - Px, dy = (yy + c.t[1]) - Py, dz = (yz + c.t[2]) - Pz;
-    double r0, r1, r2;
-    mv3(A, dx, dy, dz, r0, r1, r2);
-    const double s = (r0 * r0 + r1 * r1) + r2 * r2;
-    const double a2 = rs.sat2[t];
-    double rho0, rho1;
-    if (s <= a2)
+    accumulate_one(A, Px, Py, Pz, Xx, Xy, Xz, weight, rs.sat2[t], c, jac, acc);
+  }
+}
+
+// The same with the thread's first `cslots` residual blocks kept in LDS between the evaluations of one launch
+// (cache[f * cstride + slot * 256 + thread], f = 0..16: A, P, X, weight, a^2; weight < 0 marks a rejected keypoint):
+// the first evaluation (fill == true) reads global memory and fills the cache, the others read the cache.  Same
+// records, same order, same arithmetic as accumulate_records.
+__device__ __forceinline__ void accumulate_records_cached(const RecordSet& rs, const RotConst& c, int first, int stride, double* __restrict__ cache,
+                                                          int cslots, int cstride, bool fill, double acc[kAccumVals])
+{
+  const int total = rs.count[0] + rs.count[1] + rs.count[2];
+  int j = 0;
+  for (int gidx = first; gidx < total; gidx += stride, ++j)
+  {
+    double A[9], Px, Py, Pz, Xx, Xy, Xz, weight, a2;
+    const int at = j * 256 + (int)threadIdx.x;
+    if (j < cslots && !fill)
     {
-      const double value = 1.0 - s / a2;
-      const double value_sq = value * value;
-      rho0 = a2 / 3.0 * (1.0 - value_sq * value);
-      rho1 = value_sq;
+      weight = cache[15 * cstride + at];
+      if (weight < 0.) continue;
+#pragma unroll
+      for (int f = 0; f < 9; ++f) A[f] = cache[f * cstride + at];
+      Px = cache[9 * cstride + at]; Py = cache[10 * cstride + at]; Pz = cache[11 * cstride + at];
+      Xx = cache[12 * cstride + at]; Xy = cache[13 * cstride + at]; Xz = cache[14 * cstride + at];
+      a2 = cache[16 * cstride + at];
     }
-    else { rho0 = a2 / 3.0; rho1 = 0.0; }
-    rho0 *= weight; rho1 *= weight;
-    acc[0] += 0.5 * rho0;
-    acc[28] += 1.0;
-    if (!jac) continue;
-    double J[3][6];
-#pragma unroll
-    for (int a = 0; a < 3; ++a)
-#pragma unroll
-      for (int b = 0; b < 3; ++b) J[a][b] = A[a * 3 + b];
-    double vx, vy, vz, cx, cy, cz;
-    mv3(c.dRx, Xx, Xy, Xz, vx, vy, vz); mv3(A, vx, vy, vz, cx, cy, cz); J[0][3] = cx; J[1][3] = cy; J[2][3] = cz;
-    mv3(c.dRy, Xx, Xy, Xz, vx, vy, vz); mv3(A, vx, vy, vz, cx, cy, cz); J[0][4] = cx; J[1][4] = cy; J[2][4] = cz;
-    mv3(c.dRz, Xx, Xy, Xz, vx, vy, vz); mv3(A, vx, vy, vz, cx, cy, cz); J[0][5] = cx; J[1][5] = cy; J[2][5] = cz;
-    int h = 7;
-#pragma unroll
-    for (int a = 0; a < 6; ++a)
+    else
     {
-      acc[1 + a] += rho1 * ((J[0][a] * r0 + J[1][a] * r1) + J[2][a] * r2);
+      int t = 0, i = gidx;
+      if (i >= rs.count[0]) { i -= rs.count[0]; t = 1; if (i >= rs.count[1]) { i -= rs.count[1]; t = 2; } }
+      if (rs.status[t][i] != LSA_MATCH_SUCCESS)
+      {
+        if (j < cslots) cache[15 * cstride + at] = -1.;
+        continue;
+      }
+      const double* rec = rs.rec[t];
+      const size_t cap = (size_t)rs.cap[t];
 #pragma unroll
-      for (int b = a; b < 6; ++b) acc[h++] += rho1 * ((J[0][a] * J[0][b] + J[1][a] * J[1][b]) + J[2][a] * J[2][b]);
+      for (int f = 0; f < 9; ++f) A[f] = rec[f * cap + i];
+      Px = rec[9 * cap + i]; Py = rec[10 * cap + i]; Pz = rec[11 * cap + i];
+      Xx = rec[12 * cap + i]; Xy = rec[13 * cap + i]; Xz = rec[14 * cap + i];
+      weight = rec[15 * cap + i];
+      a2 = rs.sat2[t];
+      if (j < cslots)
+      {
+#pragma unroll
+        for (int f = 0; f < 9; ++f) cache[f * cstride + at] = A[f];
+        cache[9 * cstride + at] = Px; cache[10 * cstride + at] = Py; cache[11 * cstride + at] = Pz;
+        cache[12 * cstride + at] = Xx; cache[13 * cstride + at] = Xy; cache[14 * cstride + at] = Xz;
+        cache[15 * cstride + at] = weight; cache[16 * cstride + at] = a2;
+      }
     }
+    accumulate_one(A, Px, Py, Pz, Xx, Xy, Xz, weight, a2, c, true, acc);
   }
 }
 

@@ -196,6 +196,7 @@ struct lsa_ctx
   unsigned lm_tag = 0;            // tags handed out so far (every launch takes max evaluations + 2)
   unsigned long long lm_seq = 0;  // launches so far
   int lm_blocks = lsa::kLmBlocks;
+  int lm_cache_slots = 0;         // layers of residual blocks the solve kernel keeps in LDS (LSA_LM_CACHE caps it)
   int lm_fallbacks = 0;           // solves that timed out on the device and were redone by the host-driven loop
   // per match type a ring of kHistRing blocks of 16 ints ([8] rejection histogram + 2 hand-over counters of the kNN
   // cascade): every match takes the next block, the ring is zeroed once per turn instead of one memset per match
@@ -252,6 +253,7 @@ namespace lsa
       return (ctx)->fail(LSA_E_HIP, std::string(#call) + ": " + hipGetErrorString(e__));                \
   } while (0)
 
+int lm_cache_capacity();
 int ensure_capacity(lsa_ctx* ctx, int n);
 int ensure_target(lsa_ctx* ctx, int ti, int m);
 int ensure_match(lsa_ctx* ctx, int type, int k);

@@ -40,6 +40,7 @@ struct LmParams
   int max_iter;
   int min_matches;
   unsigned tag_base;
+  int cslots;  // residual blocks per thread kept in LDS between the evaluations
 };
 
 // result layout (doubles): [0..5] pose, [6] initial cost, [7] final cost, [8..36] the 29 sums at the final
@@ -97,7 +98,7 @@ __device__ __forceinline__ void lm_lap(Shared& sh, int slot)
   }
 }
 
-__device__ __forceinline__ bool lm_evaluate(const LmParams& p, unsigned epoch, u64* __restrict__ xchg, Shared& sh, bool trace)
+__device__ __forceinline__ bool lm_evaluate(const LmParams& p, unsigned epoch, u64* __restrict__ xchg, Shared& sh, double* __restrict__ cache, bool trace)
 {
   {
     RotConst c;
@@ -109,7 +110,7 @@ __device__ __forceinline__ bool lm_evaluate(const LmParams& p, unsigned epoch, u
     double acc[kAccumVals];
 #pragma unroll
     for (int v = 0; v < kAccumVals; ++v) acc[v] = 0.;
-    accumulate_records(p.set, c, true, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x, acc);
+    accumulate_records_cached(p.set, c, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x, cache, p.cslots, p.cslots * 256, epoch == 1, acc);
     wave_reduce_accum(acc);
     if ((threadIdx.x & 63) == 0)
     {
@@ -430,6 +431,7 @@ __device__ bool lm_step(const LmParams& p, Shared& sh, bool first)
 __global__ __launch_bounds__(256) void k_lm_solve(LmParams p, u64* __restrict__ xchg, u64* __restrict__ mailbox, unsigned out_tag, unsigned long long* trace)
 {
   __shared__ Shared sh;
+  extern __shared__ double lm_cache[];  // [17][cslots * 256]
   const bool tr = trace != nullptr && blockIdx.x == 0;
   if (threadIdx.x == 0)
   {
@@ -452,7 +454,7 @@ __global__ __launch_bounds__(256) void k_lm_solve(LmParams p, u64* __restrict__ 
   // every evaluation of the launch has an epoch of its own; all blocks walk through the same sequence of them
   for (unsigned epoch = 1;; ++epoch)
   {
-    if (!lm_evaluate(p, epoch, xchg, sh, tr)) { failed = true; break; }
+    if (!lm_evaluate(p, epoch, xchg, sh, lm_cache, tr)) { failed = true; break; }
     if (threadIdx.x == 0) sh.stop = (p.two_d ? lm_step<3>(p, sh, epoch == 1) : lm_step<6>(p, sh, epoch == 1)) ? 1 : 0;
     __syncthreads();
     if (tr) lm_lap(sh, 3);
@@ -495,6 +497,20 @@ const char* const kMessages[] = {"", "not enough matches", "gradient tolerance (
 
 }  // namespace
 
+namespace lsa
+{
+// how many 256-thread layers of residual blocks (34 KB each) the solve kernel may keep in LDS beside its own data
+int lm_cache_capacity()
+{
+  int slots = 0;
+  for (int want = 3; want >= 1 && slots == 0; --want)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_lm_solve), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(want * 17 * 256 * sizeof(double))) == hipSuccess)
+      slots = want;
+  (void)hipGetLastError();
+  return slots;
+}
+}  // namespace lsa
+
 extern "C" {
 
 int lsa_solve_device(lsa_ctx* ctx, unsigned type_mask, const double prior[6], int two_d_mode, int lm_max_iter, int min_matches, lsa_solve_result_t* out)
@@ -523,11 +539,16 @@ int lsa_solve_device(lsa_ctx* ctx, unsigned type_mask, const double prior[6], in
   const unsigned out_tag = (unsigned)(++ctx->lm_seq);
   // about four residual blocks per thread, never more blocks than the exchange has slots for
   const int nb = std::min(std::max((total + 1023) / 1024, 1), std::min(ctx->lm_blocks, kLmBlocksMax));
+  // the thread's first residual blocks stay in LDS between the evaluations (17 doubles each): as many per thread as
+  // the block's share needs, as many as the LDS holds beside the kernel's own 34 KB (the rest is read again)
+  const int per_thread = (total + nb * 256 - 1) / (nb * 256);
+  const size_t slot_bytes = (size_t)17 * 256 * sizeof(double);
+  p.cslots = std::min(per_thread, std::max(ctx->lm_cache_slots, 0));
   int stat = -1;
   {
     ProfScope ps(ctx, "lm_solve", 0.);
     stat = ps.stat;
-    hipLaunchKernelGGL(k_lm_solve, dim3(nb), dim3(256), 0, ctx->stream, p, ctx->lm_xchg, ctx->lm_mailbox, out_tag,
+    hipLaunchKernelGGL(k_lm_solve, dim3(nb), dim3(256), p.cslots * slot_bytes, ctx->stream, p, ctx->lm_xchg, ctx->lm_mailbox, out_tag,
                        ctx->route_stats && ctx->trace_dev ? reinterpret_cast<unsigned long long*>(ctx->trace_dev) + (size_t)8192 * 12 : nullptr);
   }
   // the result arrives as granules in coherent host memory (as lsa_accumulate's sums do)

@@ -374,9 +374,7 @@ __device__ __forceinline__ int group_search(const GridDesc* __restrict__ desc, c
   ub_out = INFINITY;
 
   // shells 0, 1, 2: the bounds of all their rows in one memory round trip
-  constexpr int kBatch[3] = {0, 1, 2};
   unsigned tot3[3];
-  bool batch_ok = true;  // the group's tables still hold those three blocks
   {
     uint32_t b0[E1], e0[E1], b1[E2], e1[E2], b2[E1], e2[E1];
     bool c0, c1, c2;
@@ -390,13 +388,13 @@ __device__ __forceinline__ int group_search(const GridDesc* __restrict__ desc, c
     // fewer than k points inside a radius beyond the rejection distance
 #pragma unroll
     for (int j = 0; j < 3; ++j)
-      if (need && !cov[j] && (tot3[j] & 0xfffffu) < (unsigned)k && bound2(kBatch[j]) > far_d2)
+      if (need && !cov[j] && (tot3[j] & 0xfffffu) < (unsigned)k && bound2(j) > far_d2)
       {
         outcome = kOutFar;
         need = false;
       }
     auto choose = [&](int j) {
-      sh = kBatch[j]; sh_covered = cov[j]; base = base3[j]; total = tot3[j];
+      sh = j; sh_covered = cov[j]; base = base3[j]; total = tot3[j];
       need = false;
     };
     // A block that holds just k points seldom proves them nearest (they sit in its corners): the first block with a
@@ -417,7 +415,6 @@ __device__ __forceinline__ int group_search(const GridDesc* __restrict__ desc, c
     const unsigned tot = fetch_any(s, need, cov);
     if (need)
     {
-      batch_ok = false;
       if ((tot & 0xfffffu) >= (unsigned)k || cov)
       {
         sh = s; sh_covered = cov; base = gbase; total = tot;
@@ -476,8 +473,9 @@ __device__ __forceinline__ int group_search(const GridDesc* __restrict__ desc, c
   {
     int base2 = gbase;
     unsigned total2 = 0;
-    // shells 1 and 2 are still in their tables from the first round trip if this group fetched nothing since
-    const bool kept = sh2 >= 0 && batch_ok && (sh2 == 1 || sh2 == 2);
+    // shells 1 and 2 are still in their tables from the first round trip: a group that scans one of them second has
+    // scanned shell 0 or 1 first and fetched nothing since
+    const bool kept = sh2 >= 0 && sh2 < 3;
     if (kept)
     {
       base2 = sh2 == 1 ? base3[1] : base3[2];

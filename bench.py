@@ -1,24 +1,30 @@
 #!/usr/bin/env python3
-"""bench.py -- LiDAR frames/s of Slam::AddFrame (end to end) on synthetic VLS-128 sequences.
+"""bench.py -- LiDAR frames/s of Slam::AddFrame (end to end, from a HOST cloud) on synthetic VLS-128 sequences.
 
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-A step = one AddFrame (keypoint extraction + ego-motion ICP + localization ICP + map update) on one
-VLS-128-shaped scan (128 x 2048 firings, ~260k points) that is already resident in HBM (frame
-store); every rank replays its own independent sequence (seed 1000 + rank) on its own GPU -- the
-path shards by sequence, so scaling is weak and the only exchange is the RCCL
-all-gather of the 4x4 pose + stamp of every sequence after each step.
-Rank 0 prints ONE JSON line (contract in the task description) with two extra objects:
-  roofline      achieved algorithmic GB/s of the dominant kernel (HIP events on the context's own
-                stream, live during the timed region) against the 8 TB/s HBM peak
-  cpu_baseline  the CPU oracle ("port": restatement of the reference algorithm, OpenMP where the
-                reference has it) on a bounded sample of the same sequence, on the host cores
+A step = one AddFrame (upload of the scan over PCIe + keypoint extraction + ego-motion ICP + localization ICP + map
+update) on one VLS-128-shaped scan (128 x 2048 firings, ~260k points) that is handed over as a host buffer, the way
+Slam::AddFrames receives it (slam_lib/src/Slam.cxx:230-237): the upload is INSIDE the timed region.  It is a replay:
+the caller holds the next cloud while the current one is registered and announces it (lsa_slam_hint_next_frame), so
+the upload (pinned staging, copy stream) and the extraction of frame f + 1 run beside the registration of frame f.
+Two more legs are reported beside the headline (N = 1): the same replay from scans already resident in HBM
+("replay_resident") and the strictly causal one -- host clouds, nothing announced ahead ("causal_no_lookahead").
+Every rank replays its own independent sequence (seed 1000 + rank) on its own GPU -- the path shards by sequence
+(SURVEY.md 8e), scaling is weak, the only exchange is the all-gather of the 4x4 pose + stamp of every sequence
+after each step (RCCL when there is more than one rank).  Without a launcher, `--gpus N` with N > 1 starts the N
+ranks itself.  Rank 0 prints ONE JSON line with two extra objects:
+  roofline      achieved algorithmic GB/s of the dominant kernel FAMILY (summed launch time; HIP events on the
+                context's own stream, live during the timed region) against the 8 TB/s HBM peak
+  cpu_baseline  the CPU oracle ("port": restatement of the reference algorithm, OpenMP where the reference has it)
+                on the very frames of the timed region, on the host cores
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import threading
 import time
@@ -26,9 +32,16 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import numpy as np  # noqa: E402
-
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+# profiling scopes -> kernel families (a family is what one step of the algorithm launches, whatever its kernels are)
+FAMILIES = {
+    "match": ("match_search", "match_model", "knn_fine_", "knn_coarse_", "model_"),  # KeypointsMatcher::BuildMatchResiduals
+    "lm_solve": ("lm_solve", "accumulate_"),                                       # LocalOptimizer::Solve
+    "extract": ("ring_bucket", "invalidate", "curvature", "label_nms", "compact"),  # SpinningSensorKeypointExtractor
+    "target_grid": ("target_grid_build",),
+}
+FAMILY_PREFIX = {"match": "match_", "lm_solve": "lm_solve"}  # what lsa_profile_select takes for the timed region
 
 
 def parse():
@@ -37,28 +50,77 @@ def parse():
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--model", type=int, default=128, help="16 VLP-16, 64 HDL-64, 128 VLS-128 (headline)")
-    ap.add_argument("--cpu-frames", type=int, default=160, help="frames of the CPU baseline sample (0 disables); 160 VLS-128 frames are about 10 s of CPU work")
-    ap.add_argument("--cpu-threads", type=int, default=0, help="0 = all host cores available to this process")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="0 = all host cores available to this process (at most 16)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--param", action="append", default=[], help="Slam parameter override NAME=VALUE (reference setter names)")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events at all")
-    ap.add_argument("--host-frames", action="store_true", help="hand every scan over from a host buffer (PCIe inclusive; never the headline value)")
+    ap.add_argument("--resident", action="store_true", help="headline leg from scans already resident in HBM (never the default)")
+    ap.add_argument("--causal", action="store_true", help="headline leg without announcing the next cloud (no look-ahead)")
+    ap.add_argument("--no-extra-legs", action="store_true", help="N=1: skip the replay_resident / causal_no_lookahead / batch_replay legs")
     ap.add_argument("--sequences-per-gpu", type=int, default=1, help="independent sequences replayed side by side on every GPU (the headline is 1: BASELINE.json shards 1 per GPU)")
     ap.add_argument("--batch-sequences", type=int, default=4, help="N=1 only: extra leg with this many sequences side by side on the GPU, reported as batch_replay (0 disables)")
-    ap.add_argument("--no-lookahead", action="store_true", help="do not extract the next stored frame's keypoints beside the current frame's registration")
     ap.add_argument("--no-numa-bind", action="store_true", help="leave the host threads wherever the scheduler puts them (default: on the GPU's NUMA node)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="nccl (= RCCL over xGMI, the real run); gloo rehearses the multi-rank path on a box with fewer GPUs than ranks (ranks then share devices)")
     ap.add_argument("--profile-all", action="store_true", help="time every scope in the timed region too (costs ~10 %% of the frame rate)")
     return ap.parse_args()
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as fresh processes (this process has not touched
+    the GPU), hand rank 0's JSON line through, fail if any rank fails."""
+    import socket
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rcs = [p.wait() for p in procs]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    if any(rcs):
+        raise SystemExit(f"ranks exited with {rcs}")
+
+
+def family_of(scope):
+    for fam, prefixes in FAMILIES.items():
+        if scope.startswith(prefixes):
+            return fam
+    return None
+
+
+def by_family(scopes):
+    """{family: {"total_ms", "bytes", "launches" (of its first scope = steps of the algorithm), "scopes"}} over the
+    scopes of the context's own stream ("*_ahead" scopes run on the look-ahead stream, off the critical path)."""
+    fams = {}
+    for k in scopes:
+        fam = family_of(k["name"])
+        if fam is None or k["name"].endswith("_ahead"):
+            continue
+        f = fams.setdefault(fam, {"total_ms": 0.0, "bytes": 0.0, "launches": 0, "scopes": []})
+        f["total_ms"] += k["total_ms"]
+        f["bytes"] += k["bytes"]
+        f["launches"] = max(f["launches"], k["launches"])
+        f["scopes"].append(k["name"])
+    return fams
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(args)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
+    import numpy as np
     import torch
     import torch.distributed as dist
 
@@ -76,87 +138,94 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend=args.backend, rank=rank, world_size=world)
 
-    # ---- inputs: one independent sequence per rank, generated on the host, made resident in HBM
     total = args.warmup + args.steps
-    slam = L.Slam(local_rank, EgoMotion=3)  # MOTION_EXTRAPOLATION_AND_REGISTRATION: the default mode skips the ego-motion ICP
-    for kv in args.param:
-        name, value = kv.split("=")
-        slam.set_param(name, float(value))
-    seed = sequence_seed(rank)
-    stamps, npts, host_frames = [], 0, []
-    for f in range(total):
-        pts, stamp = L.synth_frame(args.model, seed, f)
-        if args.host_frames:
-            host_frames.append(pts)
-        else:
-            slam.store_frame(f, pts)
-        stamps.append(stamp)
-        npts += pts.size
+    per_gpu = max(args.sequences_per_gpu, 1)
+    mode = "resident" if args.resident else ("causal" if args.causal else "announced")
+
+    def make_slam():
+        s = L.Slam(local_rank, EgoMotion=3)  # MOTION_EXTRAPOLATION_AND_REGISTRATION: the default mode skips the ego-motion ICP
+        for kv in args.param:
+            name, value = kv.split("=")
+            s.set_param(name, float(value))
+        return s
+
+    # ---- inputs: one independent sequence per (rank, sequence), generated on the host, kept as host clouds
+    sequences = []
+    npts = 0
+    for s in range(per_gpu):
+        seed = sequence_seed(rank * per_gpu + s)
+        frames = [L.synth_frame(args.model, seed, f) for f in range(total)]
+        npts += sum(p.size for p, _ in frames)
+        sequences.append((seed, frames))
+
+    class Replay:
+        """One sequence on one Slam handle, in one of the three modes."""
+
+        def __init__(self, frames, mode):
+            self.frames, self.mode = frames, mode
+            self.slam = make_slam()
+            if mode == "resident":
+                for f, (pts, _) in enumerate(frames):
+                    self.slam.store_frame(f, pts)
+
+        def step(self, f):
+            pts, stamp = self.frames[f]
+            nxt = f + 1 < len(self.frames)
+            if self.mode == "resident":
+                if nxt:
+                    self.slam.hint_next_stored_frame(f + 1)
+                self.slam.add_stored_frame(f, stamp, f)
+            else:
+                if self.mode == "announced" and nxt:
+                    self.slam.hint_next_frame(self.frames[f + 1][0])  # the replay holds the next cloud already
+                self.slam.add_frame(pts, stamp, f)
+
+    main_replay = Replay(sequences[0][1], mode)
+    slam = main_replay.slam
     ctx = slam.context()
 
     # further sequences of this rank (--sequences-per-gpu): a Slam, a context and a host thread each, free-running
     # beside the first one between the same start and end barriers; their latest poses travel with the first one's
-    per_gpu = max(args.sequences_per_gpu, 1)
-    lookahead = not args.no_lookahead and not args.host_frames
     latest = np.zeros((per_gpu, 17))
     latest_lock = threading.Lock()
-    others, gate = [], threading.Barrier(per_gpu)
-    for s in range(1, per_gpu):
-        o = L.Slam(local_rank, EgoMotion=3)
-        for kv in args.param:
-            name, value = kv.split("=")
-            o.set_param(name, float(value))
-        st = []
-        for f in range(total):
-            pts, stamp = L.synth_frame(args.model, sequence_seed(rank * per_gpu + s), f)
-            o.store_frame(f, pts)
-            st.append(stamp)
-            npts += pts.size
-        others.append((o, st))
+    others, gate = [Replay(fr, mode) for _, fr in sequences[1:]], threading.Barrier(per_gpu)
 
     def publish(s, o, stamp):
         with latest_lock:
             latest[s, :16] = np.asarray(o.world_transform()).reshape(16)
             latest[s, 16] = stamp * 1e-6
 
-    def follow(s, o, st):
+    def follow(s, rp):
         try:
             for f in range(total):
                 if f == args.warmup:
                     gate.wait()
-                if lookahead and f + 1 < total:
-                    o.hint_next_stored_frame(f + 1)
-                o.add_stored_frame(f, st[f], f)
-                publish(s, o, st[f])
-            o.context().sync()
+                rp.step(f)
+                publish(s, rp.slam, rp.frames[f][1])
+            rp.slam.context().sync()
         except BaseException:
             gate.abort()  # the first sequence then stops with BrokenBarrierError instead of waiting for ever
             raise
         gate.wait()
 
-    followers = [threading.Thread(target=follow, args=(s + 1, o, st), daemon=True) for s, (o, st) in enumerate(others)]
+    followers = [threading.Thread(target=follow, args=(s + 1, rp), daemon=True) for s, rp in enumerate(others)]
 
-    # RCCL pose broadcast of the north star: every rank ends up with every sequence's pose table
+    # pose table of the north star: every rank ends up with every sequence's pose (a collective only when world > 1)
     exchange = PoseExchange(world, device="cuda" if args.backend == "nccl" else "cpu", per_rank=per_gpu)
 
     def step(f):
-        if args.host_frames:
-            slam.add_frame(host_frames[f], stamps[f], f)
-        else:
-            if lookahead and f + 1 < total:
-                slam.hint_next_stored_frame(f + 1)
-            slam.add_stored_frame(f, stamps[f], f)
+        main_replay.step(f)
         if not distributed:
             return None
-        publish(0, slam, stamps[f])
+        publish(0, slam, main_replay.frames[f][1])
         with latest_lock:
             rows = latest.copy()
         return exchange.post_rows(rows)
 
     # Warm-up frames carry HIP events around every scope: that gives the per-kernel table and names the dominant
-    # kernel.  Events cost a few microseconds each on a launch-bound path, so the timed region only keeps them on
-    # that one kernel, one launch in four (its launches are all counted): the roofline figure is measured live
-    # over the timed region without slowing what is being timed.
+    # kernel FAMILY (largest summed launch time).  Events cost a few microseconds each on this launch-bound path, so
+    # the timed region only keeps them on that family, one step in four (all its launches are counted): the roofline
+    # figure is measured live over the timed region without slowing what is being timed.
     if not args.no_profile:
         ctx.profile(True)
         ctx.profile_reset()
@@ -169,14 +238,15 @@ def main():
     warm_kernels, dominant = [], None
     if not args.no_profile and args.warmup > 0:
         warm_kernels = ctx.profile_stats()
-        if warm_kernels:
-            dominant = max(on_critical_path(warm_kernels), key=lambda k: k["total_ms"])["name"]
+        fams = by_family(warm_kernels)
+        if fams:
+            dominant = max(fams, key=lambda k: fams[k]["total_ms"])
 
     stats_acc = np.zeros(16)
     if not args.no_profile:
         ctx.profile_reset()
-        if dominant is not None and not args.profile_all:
-            ctx.profile_select(dominant, 4)
+        if dominant in FAMILY_PREFIX and not args.profile_all:
+            ctx.profile_select(FAMILY_PREFIX[dominant], 4)
         else:
             ctx.profile(True)
     if distributed:
@@ -202,8 +272,8 @@ def main():
     elapsed = time.perf_counter() - t0
     for t in followers:
         t.join()
-    for o, _ in others:
-        o.close()
+    for rp in others:
+        rp.slam.close()
     if distributed:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -211,10 +281,14 @@ def main():
 
     kernels = [] if args.no_profile else ctx.profile_stats()
     ctx.profile(False)
+    extra = {"uploads_taken_over": slam.get_param("UploadsAdopted"), "extractions_taken_over": slam.get_param("LookaheadAdopted"),
+             "device_solve_fallbacks": slam.get_param("DeviceSolveFallbacks")}
 
     if rank == 0:
+        name = {128: "VLS-128", 64: "HDL-64", 16: "VLP-16"}.get(args.model, str(args.model))
+        exchange_txt = "" if world == 1 else (", RCCL all-gather of poses" if args.backend == "nccl" else ", gloo all-gather of poses (rehearsal, ranks share devices)")
         out = {
-            "metric": "LiDAR frames/sec (AddFrame end-to-end), VLS-128 scan" if args.model == 128 else f"LiDAR frames/sec (AddFrame end-to-end), model {args.model}",
+            "metric": f"LiDAR frames/sec (AddFrame end-to-end), {name} scan",
             "value": world * per_gpu * args.steps / elapsed,
             "unit": "frames/s",
             "n_gpus": world,
@@ -227,16 +301,18 @@ def main():
             "dtype": "f32+f64",
             "data": "synthetic",
             "config": {
-                "workload": {128: "VLS-128", 64: "HDL-64", 16: "VLP-16"}.get(args.model, str(args.model))
-                + " synthetic spinning scan, street canyon, 5 m/s, EgoMotion=MOTION_EXTRAPOLATION_AND_REGISTRATION, Undistortion=REFINED, library defaults",
+                "workload": name + " synthetic spinning scan, street canyon, 5 m/s, EgoMotion=MOTION_EXTRAPOLATION_AND_REGISTRATION, Undistortion=REFINED, library defaults",
                 "points_per_frame": npts // (total * per_gpu),
                 "sequences": world * per_gpu,
-                "parallelism": f"{per_gpu} sequence{'s' if per_gpu > 1 else ''} per GPU x {world}, {'RCCL' if args.backend == 'nccl' else 'gloo (rehearsal, ranks share devices)'} all-gather of poses",
-                "frames_resident_in_hbm": not args.host_frames,
-                "lookahead_extraction": lookahead,
+                "parallelism": f"{per_gpu} sequence{'s' if per_gpu > 1 else ''} per GPU x {world}{exchange_txt}",
+                "frames_resident_in_hbm": mode == "resident",
+                "frames_from": {"announced": "host clouds, next cloud announced to AddFrame's caller API (offline replay): upload + extraction overlap the previous frame",
+                                "causal": "host clouds, nothing announced ahead", "resident": "frame store in HBM, look-ahead extraction"}[mode],
+                "upload_in_timed_region": mode != "resident",
                 "host_threads_on_numa_node": numa_node if numa_node is not None and numa_node >= 0 else None,
             },
         }
+        out["config"].update(extra)
         n = args.steps
         icp_iters = max(stats_acc[9] + stats_acc[10], 1)
         out["ms_per_icp_iter"] = 1e3 * (stats_acc[2] + stats_acc[3] + stats_acc[4] + stats_acc[5]) / icp_iters
@@ -244,54 +320,66 @@ def main():
             k: 1e3 * stats_acc[i] / n
             for i, k in enumerate(["total", "extract", "ego_icp", "ego_lm", "loc_icp", "loc_lm", "undistort", "submap", "maps"])
         }
-        try:
-            out["submap_speculation_hits_per_frame"] = slam.get_param("SubMapSpeculationHits") / (args.steps + args.warmup)
-        except Exception:
-            pass
         out["stage_ms_per_frame"]["maps_wait"] = 1e3 * stats_acc[14] / n
         out["stage_ms_per_frame"]["maps_async"] = 1e3 * stats_acc[15] / n
         table, table_frames = (kernels, n) if (args.profile_all or not warm_kernels) else (warm_kernels, max(args.warmup, 1))
         if kernels:
-            dom = max(on_critical_path(kernels), key=lambda k: k["total_ms"])
+            fams = by_family(kernels)
+            fam = dominant if dominant in fams else max(fams, key=lambda k: fams[k]["total_ms"])
+            dom = fams[fam]
             ach = dom["bytes"] / (dom["total_ms"] * 1e-3) / 1e9 if dom["total_ms"] > 0 else 0.0
             out["roofline"] = {
                 "bound": "hbm",
-                "kernel": dom["name"],
+                "kernel": fam,
+                "scopes": dom["scopes"],
                 "achieved": ach,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": ach / HBM_PEAK_GBS,
-                "traffic": pmc_traffic(dom["name"], args.model),
+                "traffic": pmc_traffic(fam, args.model),
                 "avg_launch_us": 1e3 * dom["total_ms"] / max(dom["launches"], 1),
                 "algorithmic_bytes_per_launch": dom["bytes"] / max(dom["launches"], 1),
+                "launches_per_frame": dom["launches"] / n,
+                "chosen_by": "largest summed launch time by kernel family over the warm-up frames",
             }
             out["kernels_from"] = "timed region" if table is kernels else "warm-up frames (every scope timed)"
             out["kernels"] = {
                 k["name"]: {
+                    "family": family_of(k["name"]),
                     "launches_per_frame": k["launches"] / table_frames,
                     "us_per_launch": 1e3 * k["total_ms"] / max(k["launches"], 1),
                     "GBps": (k["bytes"] / (k["total_ms"] * 1e-3) / 1e9) if k["total_ms"] > 0 else 0.0,
                 }
                 for k in sorted(table, key=lambda k: -k["total_ms"])
             }
-        if world == 1 and args.cpu_frames > 0:
-            out["cpu_baseline"] = cpu_baseline(args, seed)
     slam.close()
     if rank == 0:
-        if world == 1 and per_gpu == 1 and args.batch_sequences > 1 and not args.host_frames:
-            out["batch_replay"] = batch_replay(args, local_rank)
+        if world == 1 and per_gpu == 1 and not args.no_extra_legs:
+            for key, m in (("replay_resident", "resident"), ("causal_no_lookahead", "causal"), ("replay_announced", "announced")):
+                if m != mode:
+                    out[key] = extra_leg(Replay(sequences[0][1], m), args)
+            if args.batch_sequences > 1:
+                out["batch_replay"] = batch_replay(args, local_rank)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, sequences[0])
         print(json.dumps(out), flush=True)
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def on_critical_path(scopes):
-    """The scopes that run on the context's own stream.  "*_ahead" scopes are enqueued on the look-ahead stream beside
-    the registration: their events also bracket the time they wait for that stream, and they are off the frame's
-    critical path by construction -- they are listed in the table but never named the dominant kernel."""
-    kept = [k for k in scopes if not k["name"].endswith("_ahead")]
-    return kept or scopes
+def extra_leg(rp, args):
+    """Not the headline: the same frames through another way of handing them over, timed like the headline."""
+    for f in range(args.warmup):
+        rp.step(f)
+    rp.slam.context().sync()
+    t0 = time.perf_counter()
+    for f in range(args.warmup, args.warmup + args.steps):
+        rp.step(f)
+    rp.slam.context().sync()
+    dt = time.perf_counter() - t0
+    rp.slam.close()
+    return {"value": args.steps / dt, "unit": "frames/s", "ms_per_step": 1e3 * dt / args.steps}
 
 
 def batch_replay(args, device):
@@ -300,77 +388,73 @@ def batch_replay(args, device):
     from lidarslam_amd.replay import ConcurrentReplay, sequence_seed
 
     n = args.batch_sequences
-    rep = ConcurrentReplay(device, args.model, [sequence_seed(s) for s in range(n)], args.warmup + args.steps, lookahead=not args.no_lookahead, EgoMotion=3)
+    rep = ConcurrentReplay(device, args.model, [sequence_seed(s) for s in range(n)], args.warmup + args.steps, lookahead=True, EgoMotion=3)
     for kv in args.param:
         name, value = kv.split("=")
         for s in rep.slams:
             s.set_param(name, float(value))
     fps = rep.run(args.warmup)
     rep.close()
-    return {"sequences_on_one_gpu": n, "value": fps, "unit": "frames/s", "per_sequence": fps / n, "steps": args.steps, "warmup": args.warmup}
+    return {"sequences_on_one_gpu": n, "value": fps, "unit": "frames/s", "per_sequence": fps / n, "steps": args.steps, "warmup": args.warmup,
+            "frames_from": "frame store in HBM, look-ahead extraction"}
 
 
-# profiling scope -> device kernel, for looking a scope up in the committed PMC table
-SCOPE_KERNEL = {
-    "accumulate_jac": ["k_accumulate"], "accumulate_cost": ["k_accumulate"],
-    "knn_fine_edge": ["k_knn_first<8, 16, 2>", "k_knn_first<16, 16, 2>"], "knn_fine_plane": ["k_knn_first<5, 8, 2>"],
-    "knn_coarse_edge": ["k_knn_second<8>", "k_knn_second<16>"], "knn_coarse_plane": ["k_knn_second<5>"],
-    "label_nms": ["k_label"], "curvature": ["k_curvature<4>"],
+# kernel family -> device kernels, for looking the family up in the committed PMC table
+FAMILY_KERNELS = {
+    "match": ["k_search_all", "k_model_all", "k_knn_first", "k_knn_second", "k_model<"],
+    "lm_solve": ["k_lm_solve", "k_accumulate"],
 }
 
 
-STREAMING_SCOPES = {"accumulate_jac", "accumulate_cost", "curvature", "label_nms"}
-
-
-def pmc_traffic(scope, model):
-    """HBM bytes per launch of the roofline kernel from the newest committed rocprofv3 --pmc table
-    (profiles/rNN_vls128_pmc_traffic.json, made by scripts/round_measure.sh + collect_profiles.py from
-    separate FETCH_SIZE and WRITE_SIZE passes of this same command).  The counters cannot be read from
-    inside the process, so this is the figure of the profiled run, or None when no table matches."""
+def pmc_traffic(family, model):
+    """HBM bytes per launch of the roofline family from the newest committed rocprofv3 --pmc table
+    (profiles/rNN_vls128_pmc_traffic.json, made by scripts/round_measure.sh + collect_profiles.py from separate
+    FETCH_SIZE and WRITE_SIZE passes of this same command).  The counters cannot be read from inside the process, so
+    this is the figure of the profiled run, or None when no table matches.  FETCH_SIZE is left as the counter reports
+    it (gather kernels: the guide calls their access width uncalibrated)."""
     import glob
 
-    if model != 128 or scope not in SCOPE_KERNEL:
+    if model != 128 or family not in FAMILY_KERNELS:
         return None
-    tabs = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_vls128_pmc_traffic.json")))
+    tabs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_vls128_pmc_traffic.json")))
     if not tabs:
         return None
     tab = json.load(open(tabs[-1]))
-    rows = [tab[k] for k in SCOPE_KERNEL[scope] if k in tab]
-    calls = sum(r["calls"] for r in rows)
-    if not rows or calls == 0:
+    rows = [v for k, v in tab.items() if any(p in k for p in FAMILY_KERNELS[family])]
+    if not rows:
         return None
-    # launch-weighted over the kernel instances behind the scope.  gfx950 FETCH_SIZE reports half the bytes of
-    # wide coalesced streaming reads (MI355X_MICROARCH.md, HBM): doubled for the kernels that stream their input
-    # (the normal-equation and per-point kernels; 2 x FETCH then lands within 10 % of the algorithmic bytes), raw for
-    # the gather kernels (kNN), whose access width the guide calls uncalibrated.
-    fetch_scale = 2.0 if scope in STREAMING_SCOPES else 1.0
-    return sum((fetch_scale * r["fetch_kib"] + r["write_kib"]) * 1024.0 * r["calls"] for r in rows) / calls
+    # per step of the algorithm = one launch of every kernel of the family: sum of the kernels' per-launch means,
+    # weighted by how often each is launched relative to the most frequent one
+    most = max(r["calls"] for r in rows)
+    if most == 0:
+        return None
+    return sum((r["fetch_kib"] + r["write_kib"]) * 1024.0 * r["calls"] for r in rows) / most
 
 
-def cpu_baseline(args, seed):
-    """The CPU oracle (restatement of the reference algorithm, OpenMP over rings / keypoints like the
-    reference) on the first frames of the same sequence, timed on this box's host cores."""
+def cpu_baseline(args, sequence):
+    """The CPU oracle (restatement of the reference algorithm, OpenMP over rings / keypoints like the reference) on the
+    frames of the timed region: it registers the warm-up frames too (the maps have to exist) but only the timed ones
+    count, exactly as on the GPU."""
+    import numpy as np
+
     from oracle import oracle as O
 
-    import lidarslam_amd as L
-
+    seed, frames = sequence
     # the GPU box gives one GPU job a share of 16 host cores, whatever the affinity mask says
     threads = args.cpu_threads or min(16, len(os.sched_getaffinity(0)))
     s = O.Slam(EgoMotion=3, NbThreads=threads)
     times = []
-    skip = 2  # the first frames build the map from nothing and are not representative
-    for f in range(args.cpu_frames + skip):
-        pts, stamp = L.synth_frame(args.model, seed, f)
+    for f, (pts, stamp) in enumerate(frames):
         t = time.perf_counter()
         s.add_frame(pts, stamp, f)
         times.append(time.perf_counter() - t)
-    t = np.array(times[skip:])
+    t = np.array(times[args.warmup:])
     return {
         "value": float(len(t) / t.sum()),
         "unit": "frames/s",
         "cores": threads,
         "kind": "port",
-        "sample": f"frames {skip}..{skip + len(t) - 1} of the same sequence (seed {seed}), median {1e3 * float(np.median(t)):.1f} ms/frame",
+        "sample": f"frames {args.warmup}..{args.warmup + len(t) - 1} of the same sequence (seed {seed}): the frames of the timed region, after the same {args.warmup} warm-up frames; median {1e3 * float(np.median(t)):.1f} ms/frame",
     }
 
 

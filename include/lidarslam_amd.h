@@ -166,6 +166,20 @@ int lsa_extract_keypoints(lsa_ctx* ctx, const lsa_extract_params_t* params, int 
  * time += time_offset, then the rigid transform sensor -> BASE (NULL = identity, coordinates untouched).
  * counts[] = keypoints of this frame per type. */
 int lsa_extract_keypoints_more(lsa_ctx* ctx, const lsa_extract_params_t* params, const double base_to_lidar[16], double time_offset, int counts[3]);
+/* A frame handed over AHEAD of the AddFrame call that will use it (offline / batch replay: the caller holds the
+ * next cloud while the current one is being registered).  lsa_upload_frame_begin returns at once: a thread of the
+ * context copies the (pageable) cloud into pinned staging memory and enqueues the DMA on a copy stream of its own,
+ * into one of three device buffers, so that the upload of frame f + 1 runs beside the registration of frame f.
+ * `pts` must stay valid and unchanged until lsa_upload_frame_adopt (or the next lsa_upload_frame_begin) has returned.
+ * lsa_upload_frame_ready: 1 once the DMA has been enqueued (lsa_extract_prefetch_uploaded may follow).
+ * lsa_upload_frame_adopt(pts, n): makes that frame the current one (as lsa_upload_frame would) when it is the very
+ * cloud that was announced -- returns 1 --, returns 0 when nothing or another cloud was announced (the caller then
+ * calls lsa_upload_frame).  lsa_extract_prefetch_uploaded: lsa_extract_prefetch for the frame uploaded ahead. */
+int lsa_upload_frame_begin(lsa_ctx* ctx, const lsa_point_t* pts, int n);
+int lsa_upload_frame_ready(const lsa_ctx* ctx);
+int lsa_upload_frame_adopt(lsa_ctx* ctx, const lsa_point_t* pts, int n);
+int lsa_uploads_adopted(const lsa_ctx* ctx);
+int lsa_extract_prefetch_uploaded(lsa_ctx* ctx, const lsa_extract_params_t* params);
 /* Look-ahead for replay from the frame store: extracts the keypoints of the frame in `slot` on a stream of its own,
  * beside whatever runs on the context's stream (the registration of the current frame), into spare buffers.  The
  * next lsa_extract_keypoints adopts them -- no kernel, no wait -- if it is called for that very frame
@@ -466,6 +480,12 @@ int lsa_slam_add_stored_frame(lsa_slam* s, int slot, uint64_t stamp_us, uint32_t
  * keypoints are extracted beside the registration of that frame (lsa_extract_prefetch).  Purely a scheduling hint:
  * the results are the same with or without it, and a hint that does not come true costs one wasted extraction. */
 int lsa_slam_hint_next_stored_frame(lsa_slam* s, int slot);
+/* The same for replay from HOST clouds: announces the cloud of the lsa_slam_add_frame call after the next one.  Its
+ * upload starts at once and runs beside the registration of the frame in between (pinned staging, a copy stream and a
+ * thread of its own: lsa_upload_frame_begin), its keypoints are extracted as soon as it has arrived; the
+ * lsa_slam_add_frame that is handed this very buffer (same pointer, same size) takes both over.  The buffer must stay
+ * valid and unchanged until that call returns.  Results are the same with or without the hint. */
+int lsa_slam_hint_next_frame(lsa_slam* s, const lsa_point_t* pts, int n);
 /* Slam::GetWorldTransform: row-major 4x4 + time [s]. */
 int lsa_slam_get_world_transform(const lsa_slam* s, double T[16], double* time);
 int lsa_slam_get_covariance(const lsa_slam* s, double cov[36]);

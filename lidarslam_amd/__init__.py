@@ -59,7 +59,7 @@ ABI_SYMBOLS = [
     "lsa_download_match", "lsa_overlap", "lsa_accumulate", "lsa_mailbox_active", "lsa_solve", "lsa_solve_device", "lsa_solve_device_fallbacks", "lsa_solve_device_trace", "lsa_registration_error", "lsa_selftest_math", "lsa_reset_working_keypoints", "lsa_undistort", "lsa_working_time_range",
     "lsa_working_bbox", "lsa_working_bboxes", "lsa_keypoint_bboxes_begin", "lsa_keypoint_bboxes_begin_interp", "lsa_keypoint_time_range", "lsa_keypoint_bboxes_end", "lsa_download_transformed", "lsa_stage_transformed", "lsa_staged_transformed", "lsa_transform_frame", "lsa_profile_enable", "lsa_profile_select", "lsa_profile_reset",
     "lsa_profile_get", "lsa_slam_create", "lsa_slam_destroy", "lsa_slam_last_error", "lsa_slam_set_param",
-    "lsa_slam_get_param", "lsa_slam_reset", "lsa_slam_add_frame", "lsa_slam_store_frame", "lsa_slam_add_stored_frame", "lsa_slam_hint_next_stored_frame",
+    "lsa_slam_get_param", "lsa_slam_reset", "lsa_slam_add_frame", "lsa_slam_store_frame", "lsa_slam_add_stored_frame", "lsa_slam_hint_next_stored_frame", "lsa_slam_hint_next_frame", "lsa_upload_frame_begin", "lsa_upload_frame_ready", "lsa_upload_frame_adopt", "lsa_uploads_adopted", "lsa_extract_prefetch_uploaded",
     "lsa_slam_get_world_transform", "lsa_slam_get_covariance", "lsa_slam_get_keypoints", "lsa_slam_get_registered_frame",
     "lsa_slam_get_match_status", "lsa_slam_get_stats", "lsa_slam_context", "lsa_slam_get_latency_compensated_world_transform",
     "lsa_slam_set_world_transform_from_guess", "lsa_slam_get_trajectory", "lsa_slam_get_debug_information", "lsa_slam_get_map",
@@ -172,6 +172,12 @@ def lib():
     L.lsa_slam_set_world_transform_from_guess.argtypes = [vp, vp]
     L.lsa_slam_get_trajectory.argtypes = [vp, vp, vp, i32]
     L.lsa_slam_hint_next_stored_frame.argtypes = [vp, i32]
+    L.lsa_slam_hint_next_frame.argtypes = [vp, vp, i32]
+    L.lsa_upload_frame_begin.argtypes = [vp, vp, i32]
+    L.lsa_upload_frame_ready.argtypes = [vp]
+    L.lsa_upload_frame_adopt.argtypes = [vp, vp, i32]
+    L.lsa_uploads_adopted.argtypes = [vp]
+    L.lsa_extract_prefetch_uploaded.argtypes = [vp, C.POINTER(ExtractParams)]
     L.lsa_slam_add_frames.argtypes = [vp, vp, vp, vp, vp, i32]
     L.lsa_slam_set_extractor_param.argtypes = [vp, i32, C.c_char_p, f64]
     L.lsa_slam_get_extractor_param.argtypes = [vp, i32, C.c_char_p, vp]
@@ -577,6 +583,11 @@ class Slam:
     def hint_next_stored_frame(self, slot):
         """replay: the slot that will be added after the next add_stored_frame (its extraction is overlapped)"""
         self._check(self.L.lsa_slam_hint_next_stored_frame(self.h, slot), "lsa_slam_hint_next_stored_frame")
+
+    def hint_next_frame(self, pts):
+        """replay from host clouds: the array of the add_frame call after the next one; its upload and extraction overlap
+        the frame in between.  The very same (contiguous) array must then be passed to add_frame and stay alive until then."""
+        self._check(self.L.lsa_slam_hint_next_frame(self.h, ptr(pts), pts.size), "lsa_slam_hint_next_frame")
 
     def add_stored_frame(self, slot, stamp_us, seq=0):
         self._check(self.L.lsa_slam_add_stored_frame(self.h, slot, stamp_us, seq), "lsa_slam_add_stored_frame")

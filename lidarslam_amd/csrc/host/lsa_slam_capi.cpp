@@ -157,6 +157,12 @@ int lsa_slam_hint_next_stored_frame(lsa_slam* s, int slot)
   return LSA_OK;
 }
 
+int lsa_slam_hint_next_frame(lsa_slam* s, const lsa_point_t* pts, int n)
+{
+  if (!s) return LSA_E_ARG;
+  return s->core.HintNextFrame(pts, n);
+}
+
 int lsa_slam_set_extractor_param(lsa_slam* s, int device_id, const char* name, double value)
 {
   if (!s || !name) return LSA_E_ARG;

@@ -235,7 +235,12 @@ int SlamCore::AddFrame(const lsa_point_t* pts, int n, uint64_t stampUs, uint32_t
     return AddFrames(&f, 1);
   }
   CurrentFrames.clear();
-  LSA_TRY(lsa_upload_frame(Ctx, pts, n));
+  {
+    // the cloud may have been announced and uploaded ahead (HintNextFrame): it is taken over, otherwise copied now
+    const int adopted = lsa_upload_frame_adopt(Ctx, pts, n);
+    if (adopted < 0) return Fail(adopted, "lsa_upload_frame_adopt");
+    if (adopted == 0) LSA_TRY(lsa_upload_frame(Ctx, pts, n));
+  }
   int rc = ProcessCurrentFrame(stampUs);
   Latency = Stats.total = total.Stop();
   return rc;
@@ -252,6 +257,27 @@ int SlamCore::AddStoredFrame(int slot, uint64_t stampUs, uint32_t)
   int rc = ProcessCurrentFrame(stampUs);
   Latency = Stats.total = total.Stop();
   return rc;
+}
+
+int SlamCore::HintNextFrame(const lsa_point_t* pts, int n)
+{
+  if (!Ctx) return LSA_E_NO_DEVICE;
+  if (!pts || n <= 0) return LSA_OK;
+  NextFrameHinted = false;
+  LSA_TRY(lsa_upload_frame_begin(Ctx, pts, n));
+  NextFrameHinted = true;
+  return LSA_OK;
+}
+
+// The look-ahead extraction of the cloud announced with HintNextFrame starts as soon as (i) the current frame's own
+// extraction is over and (ii) the uploader thread has enqueued the DMA: asked for after the extraction and between
+// the steps of the ICP loops.
+int SlamCore::TryStartLookahead()
+{
+  if (!NextFrameHinted || !lsa_upload_frame_ready(Ctx)) return LSA_OK;
+  NextFrameHinted = false;
+  if (lsa_extract_prefetch_uploaded(Ctx, &ExtractParams) != LSA_OK) LastError = std::string("look-ahead ignored: ") + lsa_last_error(Ctx);
+  return LSA_OK;
 }
 
 // Slam::AddFrames with several frames, one per LiDAR device (Slam.cxx:230-344; CheckFrames :709-743)
@@ -417,6 +443,7 @@ int SlamCore::ExtractKeypoints()
     if (lsa_extract_prefetch(Ctx, NextStoredSlot, &ExtractParams) != LSA_OK) LastError = std::string("look-ahead ignored: ") + lsa_last_error(Ctx);
     NextStoredSlot = -1;
   }
+  LSA_TRY(TryStartLookahead());
   return LSA_OK;
 }
 
@@ -551,6 +578,7 @@ int SlamCore::ComputeEgoMotion()
     for (int k : {LSA_EDGE, LSA_PLANE}) EgoMatchSerial[k] = lsa_match_serial(Ctx, k);
     // while the device is busy with this iteration: sub-maps the workers have finished meanwhile go to the device
     if (!SpecPending) LSA_TRY(StageSpeculativeSubMaps());
+    LSA_TRY(TryStartLookahead());
     Stats.ego_icp += ticp.Stop();
     Stats.ego_iters++;
 
@@ -689,6 +717,7 @@ int SlamCore::Localization()
     LSA_TRY(lsa_match_types(Ctx, LSA_TARGET_MAP, mask, LSA_SET_WORKING, &mp, Tworld.m, nullptr));
     for (int k = 0; k < 3; ++k)
       if ((mask >> k) & 1u) LocMatchSerial[k] = lsa_match_serial(Ctx, k);
+    LSA_TRY(TryStartLookahead());
     Stats.loc_icp += ticp.Stop();
     Stats.loc_iters++;
 
@@ -1182,6 +1211,8 @@ int SlamCore::GetParam(const std::string& name, double* v) const
   if (name == "OverlapEstimation") { *v = OverlapEstimation; return LSA_OK; }
   if (name == "SubMapSpeculationHits") { *v = SubMapSpecHitsTotal; return LSA_OK; }
   if (name == "LookaheadAdopted") { *v = Ctx ? lsa_extract_prefetch_adopted(Ctx) : 0; return LSA_OK; }
+  if (name == "UploadsAdopted") { *v = Ctx ? lsa_uploads_adopted(Ctx) : 0; return LSA_OK; }
+  if (name == "DeviceSolveFallbacks") { *v = Ctx ? lsa_solve_device_fallbacks(Ctx) : 0; return LSA_OK; }
   if (name == "TargetsBuiltAheadAdopted") { *v = Ctx ? lsa_prepared_targets_adopted(Ctx) : 0; return LSA_OK; }
   if (name == "SubMapsStagedAheadAdopted") { *v = Ctx ? lsa_staged_targets_adopted(Ctx) : 0; return LSA_OK; }
   if (name == "MapAddThreads") { *v = LocalMaps[LSA_PLANE]->GetAddThreads(); return LSA_OK; }

@@ -95,6 +95,10 @@ public:
   // Replay: the frame-store slot of the frame that will be added next.  Its keypoints are then extracted beside
   // the registration of the current frame (lsa_extract_prefetch) and the next AddStoredFrame finds them ready.
   void HintNextStoredFrame(int slot) { NextStoredSlot = slot; }
+  // Replay from host clouds: the cloud of the AddFrame call after the next one.  Its upload starts at once (pinned
+  // staging, copy stream, a thread of its own), its keypoints are extracted beside the registration of the frame in
+  // between; AddFrame adopts both when it is handed this very cloud.  The cloud must stay valid until then.
+  int HintNextFrame(const lsa_point_t* pts, int n);
   // Slam::AddFrames with one frame per LiDAR device (Slam.cxx:230-344, 753-801)
   struct InputFrame
   {
@@ -237,6 +241,8 @@ private:
   int ExtractFrames();
   int PrepareNextEgoMotionTargets();
   int NextStoredSlot = -1;
+  bool NextFrameHinted = false;   // a cloud was announced (HintNextFrame) and its look-ahead extraction not started yet
+  int TryStartLookahead();        // starts it as soon as the upload has been enqueued
   lsa_ctx* Ctx = nullptr;
   std::string LastError;
   uint64_t CurrentStamp = 0;

@@ -16,6 +16,11 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <atomic>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
+#include <thread>
 #include <vector>
 #include "../../include/lidarslam_amd.h"
 
@@ -89,6 +94,21 @@ struct MatchBuf
   bool valid = false;
 };
 
+// A frame on its way from the caller's (pageable) cloud to the device, ahead of the AddFrame call that will use it:
+// the uploader thread copies it into pinned memory and enqueues the DMA on the copy stream, the context's own
+// thread never waits for either.  Three of them: the current frame, the one uploaded ahead, and room for the hint
+// that may come before the current one has been given up.
+struct FrameInbox
+{
+  lsa_point_t* dev = nullptr;     // device buffer
+  lsa_point_t* pinned = nullptr;  // pinned staging buffer the DMA reads
+  int cap = 0;
+  int n = 0;
+  const lsa_point_t* src = nullptr;  // the caller's buffer (identity of the frame; read by the uploader thread only)
+  hipEvent_t ev = nullptr;           // recorded on the copy stream behind the DMA
+  std::atomic<int> state{0};         // 0 free, 1 posted to the uploader, 2 DMA enqueued and event recorded, -1 failed
+};
+
 struct KernelStat
 {
   std::string name;
@@ -131,6 +151,19 @@ struct lsa_ctx
   int* ring_len = nullptr;         // [kMaxRings]
   // one 64-byte block read back per extraction: [0..3] keypoint counts, [4..11] ring_meta, [12..15] time range bits
   int* extract_out = nullptr;
+  // frames uploaded ahead of their AddFrame (lsa_upload_frame_begin): a pinned, triple-buffered inbox filled by a thread
+  // of its own over a copy stream
+  lsa::FrameInbox inbox[3];
+  int inbox_next = 0;      // slot the next lsa_upload_frame_begin takes
+  int inbox_pending = -1;  // slot uploaded ahead and not adopted yet
+  int inbox_current = -1;  // slot the current frame lives in (-1: not an inbox frame)
+  hipStream_t copy_stream = nullptr;
+  std::thread uploader;
+  std::mutex up_mutex;
+  std::condition_variable up_cv, up_done;
+  std::deque<int> up_jobs;
+  bool up_quit = false;
+  int uploads_adopted = 0;
   // look-ahead extraction (lsa_extract_prefetch): the next frame's keypoints are extracted on a stream of their own
   // while the current frame is registered; lsa_extract_keypoints adopts them when it is called for that very frame
   hipStream_t prefetch_stream = nullptr;
@@ -272,6 +305,7 @@ struct ProfScope
   ~ProfScope();
 };
 void profile_collect(lsa_ctx* ctx);
+void profile_add_bytes(lsa_ctx* ctx, const char* name, double bytes);  // for scopes whose work is only known afterwards
 
 // host-side 4x4 row-major -> Rigid
 inline void row_major_to_rt(const double T[16], double R[9], double t[3])

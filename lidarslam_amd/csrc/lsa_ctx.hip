@@ -134,7 +134,8 @@ ProfScope::ProfScope(lsa_ctx* c, const char* name, double bytes, hipStream_t str
   if (!ctx->profiling) return;
   for (size_t i = 0; i < ctx->stats.size(); ++i)
     if (ctx->stats[i].name == name) { stat = (int)i; break; }
-  if (!ctx->prof_only.empty() && ctx->prof_only != name) return;
+  // a selection names a scope or a family of scopes by their common prefix ("match_": match_search and match_model)
+  if (!ctx->prof_only.empty() && std::strncmp(name, ctx->prof_only.c_str(), ctx->prof_only.size()) != 0) return;
   if (stat < 0)
   {
     KernelStat ks;
@@ -162,6 +163,13 @@ ProfScope::~ProfScope()
   (void)hipEventRecord(b, st);
   ctx->pending.push_back({stat, a, b});
 }
+void profile_add_bytes(lsa_ctx* ctx, const char* name, double bytes)
+{
+  if (!ctx->profiling) return;
+  for (auto& st : ctx->stats)
+    if (st.name == name) { st.bytes += bytes; return; }
+}
+
 void profile_collect(lsa_ctx* ctx)
 {
   for (auto& p : ctx->pending)
@@ -224,9 +232,124 @@ static void maybe_estimate_resolution(lsa_ctx* ctx, const lsa_point_t* pts, int 
   }
 }
 
+// the uploader thread of a context: pageable cloud -> pinned staging -> DMA on the copy stream -> event
+static void uploader_main(lsa_ctx* ctx)
+{
+  (void)hipSetDevice(ctx->device);
+  std::unique_lock<std::mutex> l(ctx->up_mutex);
+  while (true)
+  {
+    ctx->up_cv.wait(l, [ctx] { return ctx->up_quit || !ctx->up_jobs.empty(); });
+    if (ctx->up_jobs.empty()) return;
+    const int slot = ctx->up_jobs.front();
+    ctx->up_jobs.pop_front();
+    l.unlock();
+    FrameInbox& in = ctx->inbox[slot];
+    std::memcpy(in.pinned, in.src, (size_t)in.n * sizeof(lsa_point_t));
+    bool ok = hipMemcpyAsync(in.dev, in.pinned, (size_t)in.n * sizeof(lsa_point_t), hipMemcpyHostToDevice, ctx->copy_stream) == hipSuccess;
+    ok = ok && hipEventRecord(in.ev, ctx->copy_stream) == hipSuccess;
+    l.lock();
+    in.state.store(ok ? 2 : -1, std::memory_order_release);
+    ctx->up_done.notify_all();
+  }
+}
+
 }  // namespace lsa
 
 extern "C" {
+
+int lsa_upload_frame_begin(lsa_ctx* ctx, const lsa_point_t* pts, int n)
+{
+  if (!ctx || !pts || n <= 0) return ctx ? ctx->fail(LSA_E_ARG, "lsa_upload_frame_begin: empty frame") : LSA_E_ARG;
+  LSA_HIP(ctx, hipSetDevice(ctx->device));
+  if (ctx->inbox_pending >= 0)
+  {
+    // one frame ahead at a time: the earlier one is given up (its DMA has to be over before its buffers are reused)
+    FrameInbox& old = ctx->inbox[ctx->inbox_pending];
+    {
+      std::unique_lock<std::mutex> l(ctx->up_mutex);
+      ctx->up_done.wait(l, [&] { return old.state.load() != 1; });
+    }
+    if (old.state.load() == 2) LSA_HIP(ctx, hipEventSynchronize(old.ev));
+    if (ctx->prefetch_pending && ctx->prefetch_frame == old.dev)
+    {
+      LSA_HIP(ctx, hipStreamSynchronize(ctx->prefetch_stream));
+      ctx->prefetch_pending = false;
+    }
+    old.state.store(0);
+    ctx->inbox_pending = -1;
+  }
+  int slot = ctx->inbox_next;
+  if (slot == ctx->inbox_current) slot = (slot + 1) % 3;  // never the buffer the current frame lives in
+  ctx->inbox_next = (slot + 1) % 3;
+  FrameInbox& in = ctx->inbox[slot];
+  if (!ctx->copy_stream)
+  {
+    LSA_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    ctx->uploader = std::thread(uploader_main, ctx);
+  }
+  if (!in.ev) LSA_HIP(ctx, hipEventCreateWithFlags(&in.ev, hipEventDisableTiming));
+  if (in.cap < n)
+  {
+    // (this slot's last frame is two AddFrame calls old: nothing reads it any more)
+    LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (in.dev) (void)hipFree(in.dev);
+    if (in.pinned) (void)hipHostFree(in.pinned);
+    in.dev = nullptr; in.pinned = nullptr; in.cap = 0;
+    const int cap = n + n / 8;
+    LSA_HIP(ctx, hipMalloc((void**)&in.dev, (size_t)cap * sizeof(lsa_point_t)));
+    LSA_HIP(ctx, hipHostMalloc((void**)&in.pinned, (size_t)cap * sizeof(lsa_point_t), hipHostMallocDefault));
+    in.cap = cap;
+  }
+  in.n = n;
+  in.src = pts;
+  in.state.store(1, std::memory_order_release);
+  ctx->inbox_pending = slot;
+  {
+    std::lock_guard<std::mutex> l(ctx->up_mutex);
+    ctx->up_jobs.push_back(slot);
+  }
+  ctx->up_cv.notify_one();
+  return LSA_OK;
+}
+
+int lsa_upload_frame_ready(const lsa_ctx* ctx)
+{
+  if (!ctx || ctx->inbox_pending < 0) return 0;
+  return ctx->inbox[ctx->inbox_pending].state.load(std::memory_order_acquire) == 2 ? 1 : 0;
+}
+
+int lsa_upload_frame_adopt(lsa_ctx* ctx, const lsa_point_t* pts, int n)
+{
+  if (!ctx) return LSA_E_ARG;
+  if (ctx->inbox_pending < 0) return 0;
+  FrameInbox& in = ctx->inbox[ctx->inbox_pending];
+  if (in.src != pts || in.n != n) return 0;  // another frame was announced: the caller uploads this one itself
+  LSA_HIP(ctx, hipSetDevice(ctx->device));
+  {
+    std::unique_lock<std::mutex> l(ctx->up_mutex);
+    ctx->up_done.wait(l, [&] { return in.state.load() != 1; });
+  }
+  if (in.state.load() != 2)
+  {
+    in.state.store(0);
+    ctx->inbox_pending = -1;
+    return ctx->fail(LSA_E_HIP, "lsa_upload_frame_adopt: the upload failed");
+  }
+  int rc = ensure_capacity(ctx, n);
+  if (rc) return rc;
+  maybe_estimate_resolution(ctx, pts, n);
+  LSA_HIP(ctx, hipStreamWaitEvent(ctx->stream, in.ev, 0));
+  ctx->frame = in.dev;
+  ctx->frame_n = n;
+  ctx->inbox_current = ctx->inbox_pending;
+  ctx->inbox_pending = -1;
+  in.state.store(0);
+  ctx->uploads_adopted++;
+  return 1;
+}
+
+int lsa_uploads_adopted(const lsa_ctx* ctx) { return ctx ? ctx->uploads_adopted : 0; }
 
 int lsa_device_count(void)
 {
@@ -305,6 +428,22 @@ void lsa_ctx_destroy(lsa_ctx* ctx)
   for (int i = 0; i < 2; ++i)
     if (ctx->side_stream[i]) (void)hipStreamSynchronize(ctx->side_stream[i]);
   if (ctx->prefetch_stream) (void)hipStreamSynchronize(ctx->prefetch_stream);
+  if (ctx->uploader.joinable())
+  {
+    {
+      std::lock_guard<std::mutex> l(ctx->up_mutex);
+      ctx->up_quit = true;
+    }
+    ctx->up_cv.notify_all();
+    ctx->uploader.join();
+  }
+  if (ctx->copy_stream) { (void)hipStreamSynchronize(ctx->copy_stream); (void)hipStreamDestroy(ctx->copy_stream); }
+  for (auto& in : ctx->inbox)
+  {
+    if (in.dev) (void)hipFree(in.dev);
+    if (in.pinned) (void)hipHostFree(in.pinned);
+    if (in.ev) (void)hipEventDestroy(in.ev);
+  }
   profile_collect(ctx);
   for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
   auto fr = [](void* p) { if (p) (void)hipFree(p); };
@@ -476,6 +615,7 @@ int lsa_upload_wire_frame(lsa_ctx* ctx, const void* data, int n, const lsa_wire_
   LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the caller's buffer may be pageable and go away
   ctx->frame = ctx->frame_own;
   ctx->frame_n = n;
+  ctx->inbox_current = -1;
   return LSA_OK;
 }
 
@@ -489,6 +629,7 @@ int lsa_upload_frame(lsa_ctx* ctx, const lsa_point_t* pts, int n)
   LSA_HIP(ctx, hipMemcpyAsync(ctx->frame_own, pts, (size_t)n * sizeof(lsa_point_t), hipMemcpyHostToDevice, ctx->stream));
   ctx->frame = ctx->frame_own;
   ctx->frame_n = n;
+  ctx->inbox_current = -1;
   return LSA_OK;
 }
 
@@ -529,6 +670,7 @@ int lsa_frame_store_use(lsa_ctx* ctx, int slot)
     return ctx ? ctx->fail(LSA_E_ARG, "lsa_frame_store_use: empty slot") : LSA_E_ARG;
   ctx->frame = ctx->store[slot].first;
   ctx->frame_n = ctx->store[slot].second;
+  ctx->inbox_current = -1;
   return LSA_OK;
 }
 

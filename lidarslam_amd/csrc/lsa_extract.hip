@@ -839,10 +839,9 @@ int lsa_extract_keypoints(lsa_ctx* ctx, const lsa_extract_params_t* params, int 
   return extract_frame(ctx, params, counts, false, nullptr, 0.);
 }
 
-int lsa_extract_prefetch(lsa_ctx* ctx, int slot, const lsa_extract_params_t* params)
+// look-ahead extraction of `frame` (n points) on the look-ahead stream, behind `after` when given
+static int prefetch_enqueue(lsa_ctx* ctx, const lsa_point_t* frame, int n, const lsa_extract_params_t* params, hipEvent_t after)
 {
-  if (!ctx || !params) return ctx ? ctx->fail(LSA_E_ARG, "lsa_extract_prefetch: null argument") : LSA_E_ARG;
-  if (slot < 0 || slot >= (int)ctx->store.size() || !ctx->store[slot].first) return ctx->fail(LSA_E_ARG, "lsa_extract_prefetch: empty slot");
   if (params->neighbor_width < 1 || params->neighbor_width > 8) return ctx->fail(LSA_E_ARG, "lsa_extract_prefetch: NeighborWidth must be in [1, 8]");
   LSA_HIP(ctx, hipSetDevice(ctx->device));
   if (ctx->prefetch_pending)
@@ -850,24 +849,41 @@ int lsa_extract_prefetch(lsa_ctx* ctx, int slot, const lsa_extract_params_t* par
     LSA_HIP(ctx, hipStreamSynchronize(ctx->prefetch_stream));  // one look-ahead at a time
     ctx->prefetch_pending = false;
   }
-  const int n = ctx->store[slot].second;
   int rc = ensure_capacity(ctx, n);
   if (rc) return rc;
   if (!ctx->kp_next[0])
     for (int k = 0; k < 3; ++k) LSA_HIP(ctx, hipMalloc((void**)&ctx->kp_next[k], (size_t)ctx->cap_n * sizeof(lsa_point_t)));
+  if (after) LSA_HIP(ctx, hipStreamWaitEvent(ctx->prefetch_stream, after, 0));
   // the scratch buffers are free: the extraction of the current frame ended with a read-back on ctx->stream
   const ExtractConst c = make_const(params, ctx->az_res);
-  enqueue_extract(ctx, reinterpret_cast<const float4*>(ctx->store[slot].first), n, c, ctx->prefetch_stream, ctx->extract_out_next, ctx->kp_next,
-                  ctx->kp_type_mask);
+  enqueue_extract(ctx, reinterpret_cast<const float4*>(frame), n, c, ctx->prefetch_stream, ctx->extract_out_next, ctx->kp_next, ctx->kp_type_mask);
   LSA_HIP(ctx, hipMemcpyAsync(ctx->host_next, ctx->extract_out_next, 16 * sizeof(int), hipMemcpyDeviceToHost, ctx->prefetch_stream));
   LSA_HIP(ctx, hipEventRecord(ctx->ev_prefetch, ctx->prefetch_stream));
   ctx->prefetch_pending = true;
-  ctx->prefetch_frame = ctx->store[slot].first;
+  ctx->prefetch_frame = frame;
   ctx->prefetch_n = n;
   ctx->prefetch_params = *params;
   ctx->prefetch_az = ctx->az_res;
   ctx->prefetch_mask = ctx->kp_type_mask;
   return LSA_OK;
+}
+
+int lsa_extract_prefetch(lsa_ctx* ctx, int slot, const lsa_extract_params_t* params)
+{
+  if (!ctx || !params) return ctx ? ctx->fail(LSA_E_ARG, "lsa_extract_prefetch: null argument") : LSA_E_ARG;
+  if (slot < 0 || slot >= (int)ctx->store.size() || !ctx->store[slot].first) return ctx->fail(LSA_E_ARG, "lsa_extract_prefetch: empty slot");
+  return prefetch_enqueue(ctx, ctx->store[slot].first, ctx->store[slot].second, params, nullptr);
+}
+
+int lsa_extract_prefetch_uploaded(lsa_ctx* ctx, const lsa_extract_params_t* params)
+{
+  if (!ctx || !params) return ctx ? ctx->fail(LSA_E_ARG, "lsa_extract_prefetch_uploaded: null argument") : LSA_E_ARG;
+  if (ctx->inbox_pending < 0) return ctx->fail(LSA_E_STATE, "lsa_extract_prefetch_uploaded: no frame uploaded ahead");
+  lsa::FrameInbox& in = ctx->inbox[ctx->inbox_pending];
+  if (in.state.load(std::memory_order_acquire) != 2) return ctx->fail(LSA_E_STATE, "lsa_extract_prefetch_uploaded: the upload has not been enqueued yet");
+  // the azimuthal resolution has to be known: it is estimated from the first frame when that frame is handed over
+  if (ctx->az_res < 1e-6f) return ctx->fail(LSA_E_STATE, "lsa_extract_prefetch_uploaded: azimuthal resolution not estimated yet");
+  return prefetch_enqueue(ctx, in.dev, in.n, params, in.ev);
 }
 
 int lsa_extract_prefetch_adopted(const lsa_ctx* ctx) { return ctx ? ctx->prefetch_adopted : 0; }

@@ -544,10 +544,8 @@ int lsa_solve_device(lsa_ctx* ctx, unsigned type_mask, const double prior[6], in
   const int per_thread = (total + nb * 256 - 1) / (nb * 256);
   const size_t slot_bytes = (size_t)17 * 256 * sizeof(double);
   p.cslots = std::min(per_thread, std::max(ctx->lm_cache_slots, 0));
-  int stat = -1;
   {
     ProfScope ps(ctx, "lm_solve", 0.);
-    stat = ps.stat;
     hipLaunchKernelGGL(k_lm_solve, dim3(nb), dim3(256), p.cslots * slot_bytes, ctx->stream, p, ctx->lm_xchg, ctx->lm_mailbox, out_tag,
                        ctx->route_stats && ctx->trace_dev ? reinterpret_cast<unsigned long long*>(ctx->trace_dev) + (size_t)8192 * 12 : nullptr);
   }
@@ -600,7 +598,8 @@ int lsa_solve_device(lsa_ctx* ctx, unsigned type_mask, const double prior[6], in
   out->termination = (int)res[kResCode];
   out->num_matches = (int)res[kResMatches];
   out->message = kMessages[std::min(std::max(out->termination, 0), 8)];
-  if (stat >= 0 && ctx->profiling) ctx->stats[stat].bytes += (double)out->num_evaluations * total * 129;
+  // algorithmic bytes: every evaluation reads the record of every residual block (128 B + status)
+  profile_add_bytes(ctx, "lm_solve", (double)out->num_evaluations * out->num_matches * 129);
   return LSA_OK;
 }
 

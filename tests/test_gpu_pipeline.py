@@ -593,3 +593,75 @@ def test_one_launch_lm_and_host_driven_lm_agree(L, O, two_d):
     assert a.context().solve_device_fallbacks() == 0
     a.close()
     b.close()
+
+
+@pytest.mark.gpu
+def test_host_frames_announced_ahead_change_nothing_but_the_schedule(L):
+    """lsa_slam_hint_next_frame: the next HOST cloud is uploaded (pinned staging, copy stream, uploader thread) and its
+    keypoints extracted beside the current frame's registration; AddFrame takes both over when it gets that very cloud.
+    Poses, keypoints and match counts are those of the plain run bit for bit -- with hints that come true, with a hint
+    for a cloud that is never added, and when the announced cloud is replaced by another one."""
+    frames = [L.synth_frame(16, 1000, f) for f in range(12)]
+
+    def run(hint):
+        s = L.Slam(0, EgoMotion=3)
+        poses, kps, used = [], [], []
+        for f, (pts, stamp) in enumerate(frames):
+            h = hint(f)
+            if h is not None:
+                s.hint_next_frame(frames[h][0])
+            s.add_frame(pts, stamp, f)
+            poses.append(s.world_transform())
+            kps.append([s.keypoints(k, 2).tobytes() for k in (L.EDGE, L.PLANE)])
+            used.append(s.get_param("TotalMatchedKeypoints"))
+        up, la = s.get_param("UploadsAdopted"), s.get_param("LookaheadAdopted")
+        s.close()
+        return np.array(poses), kps, used, up, la
+
+    plain = run(lambda f: None)
+    ahead = run(lambda f: f + 1 if f + 1 < len(frames) else None)
+    wrong = run(lambda f: (f + 5) % len(frames))
+    assert plain[3] == 0 and plain[4] == 0
+    assert ahead[3] == len(frames) - 1  # every announced cloud was the one that came
+    assert 1 <= ahead[4] <= len(frames) - 1  # the extraction ran ahead whenever the upload was enqueued in time
+    assert wrong[3] == 0 and wrong[4] == 0
+    for other in (ahead, wrong):
+        assert np.array_equal(plain[0], other[0]) and plain[1] == other[1] and plain[2] == other[2]
+
+
+@pytest.mark.gpu
+def test_upload_ahead_through_the_c_abi(gpu_ctx, O, L):
+    """lsa_upload_frame_begin / _ready / _adopt / lsa_extract_prefetch_uploaded: the frame uploaded ahead gives the
+    keypoints of lsa_upload_frame + lsa_extract_keypoints; a frame that was not the announced one is not adopted"""
+    import ctypes as C
+    import time
+
+    lib, h = L.lib(), gpu_ctx.h
+    a, b = L.synth_frame(16, 1000, 0)[0], L.synth_frame(16, 1000, 1)[0]
+    gpu_ctx.upload_frame(a)
+    ref_a = gpu_ctx.extract_keypoints().copy()
+    kp_a = [gpu_ctx.keypoints(L.SET_RAW_CURRENT, k).tobytes() for k in range(3)]
+    gpu_ctx.upload_frame(b)
+    ref_b = gpu_ctx.extract_keypoints().copy()
+    kp_b = [gpu_ctx.keypoints(L.SET_RAW_CURRENT, k).tobytes() for k in range(3)]
+    params = L.ExtractParams()
+    assert lib.lsa_upload_frame_adopt(h, L.ptr(a), a.size) == 0  # nothing announced
+    assert lib.lsa_upload_frame_begin(h, L.ptr(a), a.size) == 0
+    t0 = time.time()
+    while not lib.lsa_upload_frame_ready(h) and time.time() - t0 < 5:
+        time.sleep(0.0005)
+    assert lib.lsa_upload_frame_ready(h) == 1
+    assert lib.lsa_extract_prefetch_uploaded(h, C.byref(params)) == 0
+    assert lib.lsa_upload_frame_adopt(h, L.ptr(b), b.size) == 0  # another cloud than the announced one
+    assert lib.lsa_upload_frame_adopt(h, L.ptr(a), a.size) == 1
+    adopted0 = lib.lsa_extract_prefetch_adopted(h)
+    counts = gpu_ctx.extract_keypoints()
+    assert lib.lsa_extract_prefetch_adopted(h) == adopted0 + 1
+    assert np.array_equal(counts, ref_a) and [gpu_ctx.keypoints(L.SET_RAW_CURRENT, k).tobytes() for k in range(3)] == kp_a
+    # announced, then replaced by a second announcement before it was used: the first one is given up cleanly
+    assert lib.lsa_upload_frame_begin(h, L.ptr(a), a.size) == 0
+    assert lib.lsa_upload_frame_begin(h, L.ptr(b), b.size) == 0
+    assert lib.lsa_upload_frame_adopt(h, L.ptr(a), a.size) == 0
+    assert lib.lsa_upload_frame_adopt(h, L.ptr(b), b.size) == 1
+    counts = gpu_ctx.extract_keypoints()
+    assert np.array_equal(counts, ref_b) and [gpu_ctx.keypoints(L.SET_RAW_CURRENT, k).tobytes() for k in range(3)] == kp_b

@@ -170,11 +170,14 @@ int lsa_extract_keypoints_more(lsa_ctx* ctx, const lsa_extract_params_t* params,
  * next cloud while the current one is being registered).  lsa_upload_frame_begin returns at once: a thread of the
  * context copies the (pageable) cloud into pinned staging memory and enqueues the DMA on a copy stream of its own,
  * into one of three device buffers, so that the upload of frame f + 1 runs beside the registration of frame f.
- * `pts` must stay valid and unchanged until lsa_upload_frame_adopt (or the next lsa_upload_frame_begin) has returned.
- * lsa_upload_frame_ready: 1 once the DMA has been enqueued (lsa_extract_prefetch_uploaded may follow).
- * lsa_upload_frame_adopt(pts, n): makes that frame the current one (as lsa_upload_frame would) when it is the very
- * cloud that was announced -- returns 1 --, returns 0 when nothing or another cloud was announced (the caller then
- * calls lsa_upload_frame).  lsa_extract_prefetch_uploaded: lsa_extract_prefetch for the frame uploaded ahead. */
+ * Up to two clouds may be announced before the first of them is used (the replay announces frame f + 1 just before it
+ * adds frame f, which it announced one call earlier); a third announcement gives the oldest up.  `pts` must stay valid
+ * and unchanged until the frame has been adopted or given up.
+ * lsa_upload_frame_ready: 1 once the DMA of the OLDEST announced cloud has been enqueued (lsa_extract_prefetch_uploaded
+ * may follow).  lsa_upload_frame_adopt(pts, n): makes an announced cloud the current frame (as lsa_upload_frame would)
+ * when it is the very buffer that was announced -- returns 1; clouds announced before it are given up --, returns 0
+ * when it was not announced (the caller then calls lsa_upload_frame).  lsa_extract_prefetch_uploaded:
+ * lsa_extract_prefetch for the oldest announced cloud. */
 int lsa_upload_frame_begin(lsa_ctx* ctx, const lsa_point_t* pts, int n);
 int lsa_upload_frame_ready(const lsa_ctx* ctx);
 int lsa_upload_frame_adopt(lsa_ctx* ctx, const lsa_point_t* pts, int n);

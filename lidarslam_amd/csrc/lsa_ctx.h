@@ -154,8 +154,8 @@ struct lsa_ctx
   // frames uploaded ahead of their AddFrame (lsa_upload_frame_begin): a pinned, triple-buffered inbox filled by a thread
   // of its own over a copy stream
   lsa::FrameInbox inbox[3];
-  int inbox_next = 0;      // slot the next lsa_upload_frame_begin takes
-  int inbox_pending = -1;  // slot uploaded ahead and not adopted yet
+  std::deque<int> inbox_queue;  // slots uploaded ahead and not adopted yet, oldest first (at most two: the cloud of the
+                                // next AddFrame, announced during the previous one, and the one after it)
   int inbox_current = -1;  // slot the current frame lives in (-1: not an inbox frame)
   hipStream_t copy_stream = nullptr;
   std::thread uploader;

@@ -258,30 +258,43 @@ static void uploader_main(lsa_ctx* ctx)
 
 extern "C" {
 
+// gives up the oldest frame uploaded ahead: its DMA has to be over before its buffers are reused
+static int inbox_drop_front(lsa_ctx* ctx)
+{
+  FrameInbox& old = ctx->inbox[ctx->inbox_queue.front()];
+  {
+    std::unique_lock<std::mutex> l(ctx->up_mutex);
+    ctx->up_done.wait(l, [&] { return old.state.load() != 1; });
+  }
+  if (old.state.load() == 2) LSA_HIP(ctx, hipEventSynchronize(old.ev));
+  if (ctx->prefetch_pending && ctx->prefetch_frame == old.dev)
+  {
+    LSA_HIP(ctx, hipStreamSynchronize(ctx->prefetch_stream));
+    ctx->prefetch_pending = false;
+  }
+  old.state.store(0);
+  ctx->inbox_queue.pop_front();
+  return LSA_OK;
+}
+
 int lsa_upload_frame_begin(lsa_ctx* ctx, const lsa_point_t* pts, int n)
 {
   if (!ctx || !pts || n <= 0) return ctx ? ctx->fail(LSA_E_ARG, "lsa_upload_frame_begin: empty frame") : LSA_E_ARG;
   LSA_HIP(ctx, hipSetDevice(ctx->device));
-  if (ctx->inbox_pending >= 0)
+  // two frames ahead at most: the cloud of the next AddFrame (announced during the previous one) and the one after it
+  while (ctx->inbox_queue.size() >= 2)
   {
-    // one frame ahead at a time: the earlier one is given up (its DMA has to be over before its buffers are reused)
-    FrameInbox& old = ctx->inbox[ctx->inbox_pending];
-    {
-      std::unique_lock<std::mutex> l(ctx->up_mutex);
-      ctx->up_done.wait(l, [&] { return old.state.load() != 1; });
-    }
-    if (old.state.load() == 2) LSA_HIP(ctx, hipEventSynchronize(old.ev));
-    if (ctx->prefetch_pending && ctx->prefetch_frame == old.dev)
-    {
-      LSA_HIP(ctx, hipStreamSynchronize(ctx->prefetch_stream));
-      ctx->prefetch_pending = false;
-    }
-    old.state.store(0);
-    ctx->inbox_pending = -1;
+    const int rc = inbox_drop_front(ctx);
+    if (rc) return rc;
   }
-  int slot = ctx->inbox_next;
-  if (slot == ctx->inbox_current) slot = (slot + 1) % 3;  // never the buffer the current frame lives in
-  ctx->inbox_next = (slot + 1) % 3;
+  int slot = -1;
+  for (int c = 0; c < 3 && slot < 0; ++c)
+  {
+    bool used = c == ctx->inbox_current;
+    for (int q : ctx->inbox_queue) used = used || q == c;
+    if (!used) slot = c;
+  }
+  if (slot < 0) return ctx->fail(LSA_E_STATE, "lsa_upload_frame_begin: no free buffer");
   FrameInbox& in = ctx->inbox[slot];
   if (!ctx->copy_stream)
   {
@@ -291,7 +304,7 @@ int lsa_upload_frame_begin(lsa_ctx* ctx, const lsa_point_t* pts, int n)
   if (!in.ev) LSA_HIP(ctx, hipEventCreateWithFlags(&in.ev, hipEventDisableTiming));
   if (in.cap < n)
   {
-    // (this slot's last frame is two AddFrame calls old: nothing reads it any more)
+    // (this slot's last frame is at least two AddFrame calls old: nothing reads it any more)
     LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (in.dev) (void)hipFree(in.dev);
     if (in.pinned) (void)hipHostFree(in.pinned);
@@ -304,7 +317,7 @@ int lsa_upload_frame_begin(lsa_ctx* ctx, const lsa_point_t* pts, int n)
   in.n = n;
   in.src = pts;
   in.state.store(1, std::memory_order_release);
-  ctx->inbox_pending = slot;
+  ctx->inbox_queue.push_back(slot);
   {
     std::lock_guard<std::mutex> l(ctx->up_mutex);
     ctx->up_jobs.push_back(slot);
@@ -315,25 +328,34 @@ int lsa_upload_frame_begin(lsa_ctx* ctx, const lsa_point_t* pts, int n)
 
 int lsa_upload_frame_ready(const lsa_ctx* ctx)
 {
-  if (!ctx || ctx->inbox_pending < 0) return 0;
-  return ctx->inbox[ctx->inbox_pending].state.load(std::memory_order_acquire) == 2 ? 1 : 0;
+  if (!ctx || ctx->inbox_queue.empty()) return 0;
+  return ctx->inbox[ctx->inbox_queue.front()].state.load(std::memory_order_acquire) == 2 ? 1 : 0;
 }
 
 int lsa_upload_frame_adopt(lsa_ctx* ctx, const lsa_point_t* pts, int n)
 {
   if (!ctx) return LSA_E_ARG;
-  if (ctx->inbox_pending < 0) return 0;
-  FrameInbox& in = ctx->inbox[ctx->inbox_pending];
-  if (in.src != pts || in.n != n) return 0;  // another frame was announced: the caller uploads this one itself
+  // the announced cloud this one is, if any (clouds announced before it were skipped by the caller: given up)
+  size_t at = ctx->inbox_queue.size();
+  for (size_t i = 0; i < ctx->inbox_queue.size() && at == ctx->inbox_queue.size(); ++i)
+    if (ctx->inbox[ctx->inbox_queue[i]].src == pts && ctx->inbox[ctx->inbox_queue[i]].n == n) at = i;
+  if (at == ctx->inbox_queue.size()) return 0;  // not announced: the caller uploads this one itself
   LSA_HIP(ctx, hipSetDevice(ctx->device));
+  for (size_t i = 0; i < at; ++i)
+  {
+    const int rc = inbox_drop_front(ctx);
+    if (rc) return rc;
+  }
+  const int slot = ctx->inbox_queue.front();
+  FrameInbox& in = ctx->inbox[slot];
   {
     std::unique_lock<std::mutex> l(ctx->up_mutex);
     ctx->up_done.wait(l, [&] { return in.state.load() != 1; });
   }
+  ctx->inbox_queue.pop_front();
   if (in.state.load() != 2)
   {
     in.state.store(0);
-    ctx->inbox_pending = -1;
     return ctx->fail(LSA_E_HIP, "lsa_upload_frame_adopt: the upload failed");
   }
   int rc = ensure_capacity(ctx, n);
@@ -342,8 +364,7 @@ int lsa_upload_frame_adopt(lsa_ctx* ctx, const lsa_point_t* pts, int n)
   LSA_HIP(ctx, hipStreamWaitEvent(ctx->stream, in.ev, 0));
   ctx->frame = in.dev;
   ctx->frame_n = n;
-  ctx->inbox_current = ctx->inbox_pending;
-  ctx->inbox_pending = -1;
+  ctx->inbox_current = slot;
   in.state.store(0);
   ctx->uploads_adopted++;
   return 1;

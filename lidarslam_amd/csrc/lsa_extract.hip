@@ -878,8 +878,8 @@ int lsa_extract_prefetch(lsa_ctx* ctx, int slot, const lsa_extract_params_t* par
 int lsa_extract_prefetch_uploaded(lsa_ctx* ctx, const lsa_extract_params_t* params)
 {
   if (!ctx || !params) return ctx ? ctx->fail(LSA_E_ARG, "lsa_extract_prefetch_uploaded: null argument") : LSA_E_ARG;
-  if (ctx->inbox_pending < 0) return ctx->fail(LSA_E_STATE, "lsa_extract_prefetch_uploaded: no frame uploaded ahead");
-  lsa::FrameInbox& in = ctx->inbox[ctx->inbox_pending];
+  if (ctx->inbox_queue.empty()) return ctx->fail(LSA_E_STATE, "lsa_extract_prefetch_uploaded: no frame uploaded ahead");
+  lsa::FrameInbox& in = ctx->inbox[ctx->inbox_queue.front()];
   if (in.state.load(std::memory_order_acquire) != 2) return ctx->fail(LSA_E_STATE, "lsa_extract_prefetch_uploaded: the upload has not been enqueued yet");
   // the azimuthal resolution has to be known: it is estimated from the first frame when that frame is handed over
   if (ctx->az_res < 1e-6f) return ctx->fail(LSA_E_STATE, "lsa_extract_prefetch_uploaded: azimuthal resolution not estimated yet");

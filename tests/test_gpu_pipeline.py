@@ -658,10 +658,10 @@ def test_upload_ahead_through_the_c_abi(gpu_ctx, O, L):
     counts = gpu_ctx.extract_keypoints()
     assert lib.lsa_extract_prefetch_adopted(h) == adopted0 + 1
     assert np.array_equal(counts, ref_a) and [gpu_ctx.keypoints(L.SET_RAW_CURRENT, k).tobytes() for k in range(3)] == kp_a
-    # announced, then replaced by a second announcement before it was used: the first one is given up cleanly
+    # two clouds announced; the caller skips the first: it is given up cleanly, the second is adopted
     assert lib.lsa_upload_frame_begin(h, L.ptr(a), a.size) == 0
     assert lib.lsa_upload_frame_begin(h, L.ptr(b), b.size) == 0
-    assert lib.lsa_upload_frame_adopt(h, L.ptr(a), a.size) == 0
     assert lib.lsa_upload_frame_adopt(h, L.ptr(b), b.size) == 1
+    assert lib.lsa_upload_frame_adopt(h, L.ptr(a), a.size) == 0
     counts = gpu_ctx.extract_keypoints()
     assert np.array_equal(counts, ref_b) and [gpu_ctx.keypoints(L.SET_RAW_CURRENT, k).tobytes() for k in range(3)] == kp_b

@@ -474,6 +474,8 @@ const char* lsa_slam_last_error(const lsa_slam* s);
 int lsa_slam_set_param(lsa_slam* s, const char* name, double value);
 int lsa_slam_get_param(const lsa_slam* s, const char* name, double* value);
 void lsa_slam_reset(lsa_slam* s, int reset_log);
+/* Slam::ClearMaps: empties the three keypoint maps; poses and parameters stay. */
+int lsa_slam_clear_maps(lsa_slam* s);
 /* Slam::AddFrame: frame = host scan, stamp_us = pcl header.stamp, seq = header.seq. */
 int lsa_slam_add_frame(lsa_slam* s, const lsa_point_t* pts, int n, uint64_t stamp_us, uint32_t seq);
 /* Same on a scan already resident in the frame store of the underlying context. */

@@ -157,6 +157,13 @@ int lsa_slam_hint_next_stored_frame(lsa_slam* s, int slot)
   return LSA_OK;
 }
 
+int lsa_slam_clear_maps(lsa_slam* s)
+{
+  if (!s) return LSA_E_ARG;
+  s->core.ClearMaps();
+  return LSA_OK;
+}
+
 int lsa_slam_hint_next_frame(lsa_slam* s, const lsa_point_t* pts, int n)
 {
   if (!s) return LSA_E_ARG;

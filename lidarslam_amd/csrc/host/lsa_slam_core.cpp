@@ -1205,6 +1205,9 @@ int SlamCore::GetParam(const std::string& name, double* v) const
   if (name == "VoxelGridLeafSizeBlobs") { *v = LocalMaps[LSA_BLOB]->GetLeafSize(); return LSA_OK; }
   if (name == "VoxelGridSize") { *v = LocalMaps[0]->GetGridSize(); return LSA_OK; }
   if (name == "VoxelGridResolution") { *v = LocalMaps[0]->GetVoxelResolution(); return LSA_OK; }
+  if (name == "VoxelGridSamplingMode") { *v = static_cast<int>(LocalMaps[0]->GetSampling()); return LSA_OK; }
+  if (name == "VoxelGridDecayingThreshold") { *v = LocalMaps[0]->GetDecayingThreshold(); return LSA_OK; }
+  if (name == "VoxelGridMinFramesPerVoxel") { *v = LocalMaps[0]->GetMinFramesPerVoxel(); return LSA_OK; }
   if (name == "NbrFrameProcessed") { *v = NbrFrameProcessed; return LSA_OK; }
   if (name == "TotalMatchedKeypoints") { *v = TotalMatchedKeypoints; return LSA_OK; }
   if (name == "OverlapSamplingRatio") { *v = OverlapSamplingRatio; return LSA_OK; }

@@ -94,6 +94,12 @@ public:
   int AddStoredFrame(int slot, uint64_t stampUs, uint32_t seq);
   // Replay: the frame-store slot of the frame that will be added next.  Its keypoints are then extracted beside
   // the registration of the current frame (lsa_extract_prefetch) and the next AddStoredFrame finds them ready.
+  // Slam::ClearMaps (Slam.cxx:1639-1643)
+  void ClearMaps()
+  {
+    WaitMaps();
+    for (auto& m : LocalMaps) m->Reset();
+  }
   void HintNextStoredFrame(int slot) { NextStoredSlot = slot; }
   // Replay from host clouds: the cloud of the AddFrame call after the next one.  Its upload starts at once (pinned
   // staging, copy stream, a thread of its own), its keypoints are extracted beside the registration of the frame in

@@ -12,15 +12,19 @@
 // without PCL (such as the build container).  Poses are exchanged as row-major 4x4 doubles; with Eigen
 // present Transform::GetIsometry() is offered as well.
 //
-// Not mirrored (outside the hot path): pose-graph optimisation, GPS calibration, wheel
-// odometry / IMU constraints, PCD map IO, keypoint logging.
+// Outside the hot path and therefore present as signature-compatible "not supported on this build"
+// members only (they warn once and change nothing): pose-graph optimisation, PCD map IO, wheel odometry / IMU
+// constraints, keypoint logging storage.
 #pragma once
 #include <algorithm>
 #include <array>
+#include <cmath>
+#include <cstdio>
 #include <cstdint>
 #include <cstring>
 #include <map>
 #include <memory>
+#include <set>
 #include <stdexcept>
 #include <string>
 #include <unordered_map>
@@ -34,18 +38,49 @@
 namespace LidarSlam
 {
 
-// slam_lib/include/LidarSlam/Transform.h:28-79
+// slam_lib/include/LidarSlam/Transform.h:25-79.  The pose is kept as a row-major 4x4 (what the C ABI speaks); with
+// Eigen present (LSA_HAVE_EIGEN) the reference's Eigen constructors and accessors are offered with their own types.
 struct Transform
 {
   std::array<double, 16> matrix{{1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1}};  // row-major
   double time = 0.;
   std::string frameid;
+
+  Transform() = default;
+  // Euler angles ZYX convention (R = Rz(rz) Ry(ry) Rx(rx)), as Utils::XYZRPYtoIsometry (slam_lib/src/Utilities.cxx:62-69)
+  Transform(double x, double y, double z, double rx, double ry, double rz, double t = 0., const std::string& frame = "") : time(t), frameid(frame)
+  {
+    const double cx = std::cos(rx), sx = std::sin(rx), cy = std::cos(ry), sy = std::sin(ry), cz = std::cos(rz), sz = std::sin(rz);
+    matrix = {{cy * cz, sx * sy * cz - cx * sz, cx * sy * cz + sx * sz, x,
+               cy * sz, sx * sy * sz + cx * cz, cx * sy * sz - sx * cz, y,
+               -sy, sx * cy, cx * cy, z,
+               0, 0, 0, 1}};
+  }
+  explicit Transform(const std::array<double, 16>& rowMajor, double t = 0., const std::string& frame = "") : matrix(rowMajor), time(t), frameid(frame) {}
   static Transform Identity() { return Transform(); }
+
+  double& x() { return matrix[3]; }
+  double& y() { return matrix[7]; }
+  double& z() { return matrix[11]; }
   double x() const { return matrix[3]; }
   double y() const { return matrix[7]; }
   double z() const { return matrix[11]; }
-  const std::array<double, 16>& GetMatrix() const { return matrix; }
+  const std::array<double, 16>& GetMatrixArray() const { return matrix; }
 #ifdef LSA_HAVE_EIGEN
+  Transform(const Eigen::Matrix<double, 6, 1>& xyzrpy, double t = 0., const std::string& frame = "")
+    : Transform(xyzrpy(0), xyzrpy(1), xyzrpy(2), xyzrpy(3), xyzrpy(4), xyzrpy(5), t, frame) {}
+  Transform(const Eigen::Vector3d& trans, const Eigen::Vector3d& rpy, double t = 0., const std::string& frame = "")
+    : Transform(trans(0), trans(1), trans(2), rpy(0), rpy(1), rpy(2), t, frame) {}
+  Transform(const Eigen::Isometry3d& transform, double t = 0., const std::string& frame = "") : time(t), frameid(frame) { this->SetIsometry(transform); }
+  Transform(const Eigen::Translation3d& trans, const Eigen::Quaterniond& rot, double t = 0., const std::string& frame = "") : time(t), frameid(frame)
+  {
+    this->SetIsometry(Eigen::Isometry3d(trans * rot.normalized()));
+  }
+  void SetIsometry(const Eigen::Isometry3d& isometry)
+  {
+    for (int r = 0; r < 4; ++r)
+      for (int c = 0; c < 4; ++c) matrix[r * 4 + c] = isometry.matrix()(r, c);
+  }
   Eigen::Isometry3d GetIsometry() const
   {
     Eigen::Isometry3d iso = Eigen::Isometry3d::Identity();
@@ -53,8 +88,39 @@ struct Transform
       for (int c = 0; c < 4; ++c) iso(r, c) = matrix[r * 4 + c];
     return iso;
   }
+  Eigen::Vector3d GetPosition() const { return Eigen::Vector3d(matrix[3], matrix[7], matrix[11]); }
+  Eigen::Translation3d GetTranslation() const { return Eigen::Translation3d(this->GetPosition()); }
+  Eigen::Quaterniond GetRotation() const { return Eigen::Quaterniond(this->GetIsometry().linear()); }
+  Eigen::Matrix4d GetMatrix() const { return this->GetIsometry().matrix(); }
+#else
+  // without Eigen: position as an array, the matrix as the row-major array
+  std::array<double, 3> GetPosition() const { return {{matrix[3], matrix[7], matrix[11]}}; }
+  const std::array<double, 16>& GetMatrix() const { return matrix; }
 #endif
 };
+
+// slam_lib/include/LidarSlam/PointCloudStorage.h:60-75 (the values callers pass to SaveMapsToPCD / SetLoggingStorage)
+enum PCDFormat { ASCII = 0, BINARY = 1, BINARY_COMPRESSED = 2 };
+enum PointCloudStorageType { PCL_CLOUD = 0, OCTREE_COMPRESSED = 1, PCD_ASCII = 2, PCD_BINARY = 3, PCD_BINARY_COMPRESSED = 4 };
+
+// slam_lib/include/LidarSlam/SensorConstraints.h:13-23 (external sensors: accepted, not used -- see the Slam methods)
+namespace SensorConstraints
+{
+struct WheelOdomMeasurement
+{
+  double Time = 0.;
+  double Distance = 0.;
+};
+struct GravityMeasurement
+{
+  double Time = 0.;
+#ifdef LSA_HAVE_EIGEN
+  Eigen::Vector3d Acceleration = Eigen::Vector3d::Zero();
+#else
+  std::array<double, 3> Acceleration{{0., 0., 0.}};
+#endif
+};
+}  // namespace SensorConstraints
 
 #define LSA_SLAM_PARAM(name, type)                                                          \
   void Set##name(type v) { this->SetParam(#name, static_cast<double>(v)); }                 \
@@ -86,7 +152,13 @@ public:
   // one frame per LiDAR device (at most 16): extracted with the device's extractor, merged in BASE (Slam.cxx:753-801)
   void AddFrames(const std::vector<PointCloud::Ptr>& frames)
   {
-    if (frames.empty() || !frames[0] || frames.size() > 16) return;
+    if (frames.empty() || !frames[0]) return;
+    if (frames.size() > 16)
+    {
+      this->LastError = "AddFrames: at most 16 frames (LiDAR devices) per call";
+      std::fprintf(stderr, "\033[1;31m[ERROR] %s\033[0m\n", this->LastError.c_str());
+      return;
+    }
     const lsa_point_t* pts[16];
     int n[16];
     std::uint64_t stamps[16];
@@ -203,6 +275,46 @@ public:
   }
   const std::string& GetLastError() const { return this->LastError; }
 
+  // ---- outside the scan-matching hot path (pose-graph optimisation, PCD map IO, external sensors, keypoint
+  // logging).  Present with the reference's signatures so that LidarSlamNode.cxx / vtkSlam.cxx compile unchanged; each
+  // warns once and does nothing, the way the reference itself answers RunPoseGraphOptimization without g2o
+  // (slam_lib/src/Slam.cxx:355-366: "SLAM PoseGraphOptimization requires G2O, but it was not found.").
+#ifdef LSA_HAVE_EIGEN
+  void RunPoseGraphOptimization(const std::vector<Transform>&, const std::vector<std::array<double, 9>>&, Eigen::Isometry3d&, const std::string& = "")
+#else
+  void RunPoseGraphOptimization(const std::vector<Transform>&, const std::vector<std::array<double, 9>>&, std::array<double, 16>&, const std::string& = "")
+#endif
+  {
+    this->NotSupported("RunPoseGraphOptimization", "pose-graph optimisation (g2o) is not part of this build: maps and trajectory are left unchanged");
+  }
+  void SaveMapsToPCD(const std::string&, PCDFormat = PCDFormat::BINARY_COMPRESSED, bool = true) const
+  {
+    this->NotSupported("SaveMapsToPCD", "PCD map IO is not part of this build: use GetMap() and the caller's own writer");
+  }
+  void LoadMapsFromPCD(const std::string&, bool = true)
+  {
+    this->NotSupported("LoadMapsFromPCD", "PCD map IO is not part of this build: the maps are left unchanged");
+  }
+  // keypoint logging feeds the pose-graph optimisation only: the value is remembered, nothing is logged
+  void SetLoggingStorage(PointCloudStorageType s) { this->LoggingStorage = s; }
+  PointCloudStorageType GetLoggingStorage() const { return this->LoggingStorage; }
+  // wheel odometer / IMU constraints: weights and time offset are remembered, measurements are dropped
+  void SetWheelOdomWeight(double w) { this->WheelOdomWeight = w; }
+  double GetWheelOdomWeight() const { return this->WheelOdomWeight; }
+  void SetGravityWeight(double w) { this->GravityWeight = w; }
+  double GetGravityWeight() const { return this->GravityWeight; }
+  void SetSensorTimeOffset(double t) { this->SensorTimeOffset = t; }
+  double GetSensorTimeOffset() const { return this->SensorTimeOffset; }
+  void AddGravityMeasurement(const SensorConstraints::GravityMeasurement&)
+  {
+    this->NotSupported("AddGravityMeasurement", "IMU gravity constraints are not part of this build: the measurement is ignored");
+  }
+  void AddWheelOdomMeasurement(const SensorConstraints::WheelOdomMeasurement&)
+  {
+    this->NotSupported("AddWheelOdomMeasurement", "wheel odometry constraints are not part of this build: the measurement is ignored");
+  }
+  void ClearSensorMeasurements() {}
+
   // ---- general parameters (Slam.h:201-232)
   void SetNbThreads(int) {}  // OpenMP thread count of the reference: meaningless on the device path
   int GetNbThreads() const { return 1; }
@@ -265,6 +377,11 @@ public:
   std::array<float, 2> GetVelocityLimits() const { return {{static_cast<float>(this->GetParam("VelocityLimitLinear")), static_cast<float>(this->GetParam("VelocityLimitAngular"))}}; }
   void SetAccelerationLimits(const std::array<float, 2>& l) { this->SetParam("AccelerationLimitLinear", l[0]); this->SetParam("AccelerationLimitAngular", l[1]); }
   std::array<float, 2> GetAccelerationLimits() const { return {{static_cast<float>(this->GetParam("AccelerationLimitLinear")), static_cast<float>(this->GetParam("AccelerationLimitAngular"))}}; }
+#ifdef LSA_HAVE_EIGEN
+  // the reference's own argument type (Slam.h:385-392)
+  void SetVelocityLimits(const Eigen::Array2f& l) { this->SetVelocityLimits(std::array<float, 2>{{l(0), l(1)}}); }
+  void SetAccelerationLimits(const Eigen::Array2f& l) { this->SetAccelerationLimits(std::array<float, 2>{{l(0), l(1)}}); }
+#endif
   LSA_SLAM_PARAM(TimeWindowDuration, float)
   bool GetComplyMotionLimits() const { return this->GetParam("ComplyMotionLimits") != 0.; }
   void SetBaseFrameId(const std::string& s) { this->BaseFrameId = s; }
@@ -310,6 +427,10 @@ public:
   void SetVoxelGridMinFramesPerVoxel(unsigned int n) { this->SetParam("VoxelGridMinFramesPerVoxel", n); }
   void SetVoxelGridDecayingThreshold(double d) { this->SetParam("VoxelGridDecayingThreshold", d); }
   void SetVoxelGridSamplingMode(Keypoint, SamplingMode sm) { this->SetParam("VoxelGridSamplingMode", static_cast<int>(sm)); }
+  SamplingMode GetVoxelGridSamplingMode(Keypoint) { return static_cast<SamplingMode>(static_cast<int>(this->GetParam("VoxelGridSamplingMode"))); }
+  double GetVoxelGridDecayingThreshold() { return this->GetParam("VoxelGridDecayingThreshold"); }
+  // Slam::ClearMaps (Slam.cxx): empties the three keypoint maps, poses and parameters stay
+  void ClearMaps() { lsa_slam_clear_maps(this->Handle); }
 
   // ---- keypoint extractor parameters (SpinningSensorKeypointExtractor.h:44-70); one extractor (device 0)
   LSA_SLAM_PARAM(NeighborWidth, int)
@@ -354,7 +475,15 @@ private:
     return pc;
   }
 
+  void NotSupported(const char* what, const char* why) const
+  {
+    if (this->Warned.insert(what).second) std::fprintf(stderr, "\033[1;33m[WARNING] LidarSlam::Slam::%s: %s\033[0m\n", what, why);
+  }
+
   lsa_slam* Handle = nullptr;
+  mutable std::set<std::string> Warned;
+  PointCloudStorageType LoggingStorage = PointCloudStorageType::PCL_CLOUD;
+  double WheelOdomWeight = 0., GravityWeight = 0., SensorTimeOffset = 0.;
   std::map<std::uint8_t, KeypointExtractorPtr> KeyPointsExtractors;
   std::uint64_t CurrentStamp = 0;
   std::string WorldFrameId = "world", BaseFrameId = "base", LastError;

@@ -210,6 +210,11 @@ def covariance(records, status, sat, pose):
     return cov, err
 
 
+def set_libm_trig(on):
+    """the oracle's eigen-solver / slerp trigonometry: libm (as the reference's PCL / Eigen) instead of lsa_pmath.h"""
+    lib().orc_set_libm_trig(int(bool(on)))
+
+
 def math(fn, x, y=None):
     """Same function ids as lsa_selftest_math, evaluated on the host."""
     x = np.ascontiguousarray(x, np.float64)

@@ -224,6 +224,9 @@ int orc_covariance(const double* records, const uint8_t* status, int n, double s
 }
 
 // ---- elementary functions (same ids as lsa_selftest_math) ----
+// 1: the eigen-solver and the slerp call libm (glibc) like the reference's PCL / Eigen do, 0: lsa_pmath.h (default)
+void orc_set_libm_trig(int on) { orc::libm_trig() = on ? 1 : 0; }
+
 int orc_math(int fn, const double* x, const double* y, int n, double* out)
 {
   for (int i = 0; i < n; ++i)

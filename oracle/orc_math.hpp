@@ -36,6 +36,15 @@
 
 namespace orc
 {
+// The trigonometry inside the analytic eigen-solver and the slerp: lsa_pmath.h (what the device evaluates, bit for bit)
+// by default; libm (what the reference's PCL / Eigen call: std::atan2 / cos / sin of glibc) when asked for.  The
+// switch exists for ONE purpose: tests/test_oracle_properties.py counts how many decisions (keypoint labels, match
+// status) and how many low bits change between the two, i.e. what the shared header could hide.
+inline int& libm_trig() { static int on = 0; return on; }
+inline double t_sin(double x) { return libm_trig() ? std::sin(x) : lsa_sin(x); }
+inline double t_cos(double x) { return libm_trig() ? std::cos(x) : lsa_cos(x); }
+inline double t_atan2(double y, double x) { return libm_trig() ? std::atan2(y, x) : lsa_atan2(y, x); }
+
 
 // ---------------------------------------------------------------------------
 // 32-byte point, same layout as LidarSlam::LidarPoint
@@ -161,9 +170,9 @@ template <typename T> inline void compute_roots(const M3<T>& m, T roots[3])
   if (q > T(0)) q = T(0);
 
   T rho = std::sqrt(-a_over_3);
-  T theta = T(lsa_atan2((double)std::sqrt(-q), (double)half_b)) * s_inv3;
-  T cos_theta = T(lsa_cos((double)theta));
-  T sin_theta = T(lsa_sin((double)theta));
+  T theta = T(t_atan2((double)std::sqrt(-q), (double)half_b)) * s_inv3;
+  T cos_theta = T(t_cos((double)theta));
+  T sin_theta = T(t_sin((double)theta));
   roots[0] = c2_over_3 + T(2) * rho * cos_theta;
   roots[1] = c2_over_3 - rho * (cos_theta + s_sqrt3 * sin_theta);
   roots[2] = c2_over_3 - rho * (cos_theta - s_sqrt3 * sin_theta);
@@ -388,7 +397,7 @@ inline SlerpConst slerp_prepare(const Quat& a, const Quat& b)
   double absD = std::abs(c.d);
   c.linear = absD >= one;
   c.theta = c.linear ? 0.0 : std::acos(absD);
-  c.sin_theta = c.linear ? 1.0 : lsa_sin(c.theta);
+  c.sin_theta = c.linear ? 1.0 : t_sin(c.theta);
   return c;
 }
 inline Quat slerp_eval(const SlerpConst& c, double t)
@@ -397,8 +406,8 @@ inline Quat slerp_eval(const SlerpConst& c, double t)
   if (c.linear) { s0 = 1.0 - t; s1 = t; }
   else
   {
-    s0 = lsa_sin((1.0 - t) * c.theta) / c.sin_theta;
-    s1 = lsa_sin(t * c.theta) / c.sin_theta;
+    s0 = t_sin((1.0 - t) * c.theta) / c.sin_theta;
+    s1 = t_sin(t * c.theta) / c.sin_theta;
   }
   if (c.d < 0.0) s1 = -s1;
   return {s0 * c.a.w + s1 * c.b.w, s0 * c.a.x + s1 * c.b.x, s0 * c.a.y + s1 * c.b.y, s0 * c.a.z + s1 * c.b.z};

@@ -10,13 +10,36 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def build_example(tmp_path):
-    exe = str(tmp_path / "slam_example")
+def build_example(tmp_path, name="slam_example"):
+    exe = str(tmp_path / name)
     pkg = os.path.join(ROOT, "lidarslam_amd")
-    cmd = ["g++", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(pkg, "include"),
-           os.path.join(ROOT, "examples", "slam_example.cpp"), "-L" + pkg, "-llidarslam_amd", "-Wl,-rpath," + pkg, "-o", exe]
+    cmd = ["g++", "-std=c++17", "-Wall", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(pkg, "include"),
+           os.path.join(ROOT, "examples", name + ".cpp"), "-L" + pkg, "-llidarslam_amd", "-Wl,-rpath," + pkg, "-o", exe]
     subprocess.check_call(cmd)
     return exe
+
+
+def test_every_call_of_the_reference_wrappers_compiles_against_the_mirror(tmp_path, L):
+    """examples/slam_wrapper_calls.cpp makes every call LidarSlamNode.cxx and vtkSlam.cxx make on LidarSlam::Slam (all the
+    setters of SetSlamParameters, the getters of PublishOutput, the commands): it compiles and links; without a GPU
+    it refuses to run"""
+    exe = build_example(tmp_path, "slam_wrapper_calls")
+    if L.lib().lsa_device_count() == 0:
+        r = subprocess.run([exe, "1"], capture_output=True, text=True)
+        assert r.returncode == 1 and "no usable HIP device" in r.stderr
+
+
+@pytest.mark.gpu
+def test_wrapper_calls_run_and_the_out_of_scope_ones_warn(tmp_path, L):
+    exe = build_example(tmp_path, "slam_wrapper_calls")
+    r = subprocess.run([exe, "3"], capture_output=True, text=True, check=True)
+    extra = {line.split()[1]: line.split()[2:] for line in r.stdout.strip().splitlines() if line.startswith("#")}
+    assert int(extra["clouds"][3]) == int(extra["clouds"][4]) and int(extra["clouds"][0]) > 0  # registered frame: every point
+    assert extra["state"][:4] == ["3", "2", "3", "2"] and extra["sampling"] == ["2", "-1", "odom"]
+    assert 0.0 < float(extra["confidence"][0]) <= 1.0 and int(extra["confidence"][2]) > 20
+    assert extra["debug"] == ["9", "10", "1"] and extra["cleared"] == ["1", "0"] and extra["reset"] == ["0"]
+    for what in ("SaveMapsToPCD", "LoadMapsFromPCD", "RunPoseGraphOptimization", "AddGravityMeasurement", "AddWheelOdomMeasurement"):
+        assert f"LidarSlam::Slam::{what}" in r.stderr  # present, warns once, changes nothing
 
 
 def test_cpp_caller_compiles_links_and_refuses_to_run_without_a_gpu(tmp_path, L):

@@ -140,9 +140,24 @@ typedef struct lsa_wire_layout_t
  * ring when mapping_len == 0), device_id, time = the record's time offset.  When the time field is not usable
  * (last - first <= 1e-8, :74) the time is built from the azimuth advancement exactly as the node does
  * (SpinningFrameAdvancementEstimator, lidar_conversions/src/Utilities.h:62-114, rpm and timestamp_first_packet
- * as its parameters); that sequential path, and the first frame, are converted on the host. */
+ * as its parameters): per ring that is "the first descent of the advancement and everything after it", found on the
+ * ring-bucketed frame on the device (portable arc tangent: the time agrees with the node's to rounding).  The first
+ * frame (azimuthal resolution estimate) is converted on the host. */
 int lsa_upload_wire_frame(lsa_ctx* ctx, const void* records, int n, const lsa_wire_layout_t* layout, const uint16_t* laser_id_mapping,
                           int mapping_len, int device_id, double rpm, int timestamp_first_packet);
+
+/* lsa_upload_frame for a LidarView / ParaView frame, converted on the device as vtkSlam::PolyDataToPointCloud does on the
+ * host (paraview_wrapping/Plugin/vtkLidarSlam/vtkSlam.cxx:668-707), from the vtkPolyData's own arrays -- structure
+ * of arrays, no LidarPoint cloud is built on the host: xyz = 3 n interleaved coordinates (vtkPoints, float or double),
+ * time / laser_id / intensity = the point-data arrays named by the filter (any of the scalar types below).  The
+ * frame's end is the largest time; *stamp_us = end * (time_to_seconds * 1e6), a point's time = (t - end) *
+ * time_to_seconds, laser_id = mapping[id] (or id when mapping_len == 0); points whose three coordinates are all zero
+ * are dropped, the others keep their order.  *n_valid = points kept (= the size of the current frame).  Returns 1
+ * when every point was kept ("allPointsAreValid"), 0 when some were dropped, < 0 on error. */
+enum { LSA_SCALAR_F32 = 0, LSA_SCALAR_F64 = 1, LSA_SCALAR_U8 = 2, LSA_SCALAR_U16 = 3, LSA_SCALAR_U32 = 4, LSA_SCALAR_I32 = 5 };
+int lsa_upload_polydata_frame(lsa_ctx* ctx, int n, const void* xyz, int xyz_type, const void* time, int time_type, const void* laser_id, int laser_type,
+                              const void* intensity, int intensity_type, const uint16_t* laser_id_mapping, int mapping_len, double time_to_seconds,
+                              uint64_t* stamp_us, int* n_valid);
 
 /* Frame store: keeps scans resident in HBM so that a replay (bench.py) can
  * time the path without the PCIe copy.  Slots are created on demand. */

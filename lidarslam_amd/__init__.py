@@ -51,7 +51,7 @@ DEBUG_NAMES = [
 
 # every symbol include/lidarslam_amd.h declares (tests/test_abi.py checks the .so exports them all)
 ABI_SYMBOLS = [
-    "lsa_device_count", "lsa_bind_host_to_device", "lsa_ctx_create", "lsa_ctx_destroy", "lsa_last_error", "lsa_sync", "lsa_upload_frame", "lsa_upload_wire_frame",
+    "lsa_device_count", "lsa_bind_host_to_device", "lsa_ctx_create", "lsa_ctx_destroy", "lsa_last_error", "lsa_sync", "lsa_upload_frame", "lsa_upload_wire_frame", "lsa_upload_polydata_frame",
     "lsa_frame_store_put", "lsa_frame_store_use", "lsa_frame_size", "lsa_get_azimuthal_resolution",
     "lsa_set_azimuthal_resolution", "lsa_extract_keypoints", "lsa_extract_keypoints_more", "lsa_extract_prefetch", "lsa_extract_prefetch_adopted", "lsa_transform_frame_at", "lsa_set_keypoint_types", "lsa_download_keypoints", "lsa_keypoint_count",
     "lsa_download_debug", "lsa_nb_laser_rings", "lsa_transform_keypoints", "lsa_set_target", "lsa_set_target_from_set", "lsa_prepare_previous_targets", "lsa_prepared_targets_adopted", "lsa_target_staging", "lsa_set_target_staged", "lsa_stage_target_ahead", "lsa_drop_target_ahead", "lsa_staged_targets_adopted",
@@ -285,6 +285,22 @@ class Context:
         self._check(self.L.lsa_upload_wire_frame(self.h, rec.ctypes.data_as(C.c_void_p), n, lay, ptr(mp) if mp is not None else None,
                                                  0 if mp is None else mp.size, device_id, C.c_double(rpm), int(timestamp_first_packet)),
                     "lsa_upload_wire_frame")
+
+    def upload_polydata_frame(self, xyz, time, laser_id, intensity, mapping=None, time_to_seconds=1.0):
+        """lsa_upload_polydata_frame: the arrays of a vtkPolyData frame (xyz (n, 3) float32 / float64, the others any of
+        float32, float64, uint8, uint16, uint32, int32); returns (stamp_us, points kept, all points valid)."""
+        codes = {np.dtype(np.float32): 0, np.dtype(np.float64): 1, np.dtype(np.uint8): 2, np.dtype(np.uint16): 3, np.dtype(np.uint32): 4, np.dtype(np.int32): 5}
+        arrs = [np.ascontiguousarray(a) for a in (xyz, time, laser_id, intensity)]
+        mp = np.ascontiguousarray(mapping, np.uint16) if mapping is not None else None
+        stamp, kept = C.c_uint64(0), C.c_int(0)
+        f = self.L.lsa_upload_polydata_frame
+        f.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p, C.c_int] * 4 + [C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_void_p]
+        args = []
+        for a in arrs:
+            args += [a.ctypes.data_as(C.c_void_p), codes[a.dtype]]
+        rc = self._check(f(self.h, arrs[1].size, *args, ptr(mp) if mp is not None else None, 0 if mp is None else mp.size, C.c_double(time_to_seconds),
+                           C.byref(stamp), C.byref(kept)), "lsa_upload_polydata_frame")
+        return stamp.value, kept.value, rc == 1
 
     def extract_keypoints(self, params=None):
         params = params or ExtractParams()

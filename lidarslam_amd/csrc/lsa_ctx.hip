@@ -8,6 +8,7 @@
 #include <sched.h>
 #include <string>
 #include "lsa_ctx.h"
+#include "../../include/lsa_pmath.h"
 
 using namespace lsa;
 
@@ -528,6 +529,7 @@ namespace
 {
 struct WireMap
 {
+  int advancement;  // 1: the time field receives the azimuth advancement in [0, 1) instead of the record's time
   lsa_wire_layout_t lay;
   int mapping_len;
   int device_id;
@@ -544,7 +546,22 @@ __global__ __launch_bounds__(256) void k_wire_to_points(const unsigned char* __r
   uint16_t ring;
   memcpy(&ring, r + m.lay.off_ring, sizeof(ring));
   const unsigned id = m.mapping_len > 0 ? (ring < m.mapping_len ? m.mapping[ring] : 0xffffu) : ring;
-  const double t = (double)f32(m.lay.off_time);
+  double t = (double)f32(m.lay.off_time);
+  if (m.advancement)
+  {
+    // SpinningFrameAdvancementEstimator (lidar_conversions/src/Utilities.h:88-100): the azimuth of the point as a
+    // fraction of a turn, relative to the frame's first point, wrapped into [0, 1).  std::fmod is exact, and so is
+    // x - trunc(x) for |x| < 2^52: wrap() below IS std::fmod(1 + std::fmod(x, 1), 1).  The arc tangent is the portable
+    // one evaluated in double and rounded to float (the node calls the float overload).
+    auto adv_of = [&](const unsigned char* rr) {
+      float x, y;
+      memcpy(&x, rr + m.lay.off_x, sizeof(x));
+      memcpy(&y, rr + m.lay.off_y, sizeof(y));
+      return (3.14159265358979323846 - (double)(float)lsa_atan2((double)y, (double)x)) / (2 * 3.14159265358979323846);
+    };
+    auto wrap = [](double x) { const double f = x - trunc(x); const double g = 1.0 + f; return g - trunc(g); };
+    t = wrap(adv_of(r) - adv_of(raw));
+  }
   const long long tb = __double_as_longlong(t);
   float4 a = make_float4(f32(m.lay.off_x), f32(m.lay.off_y), f32(m.lay.off_z), 1.f);
   float4 b;
@@ -588,11 +605,10 @@ int lsa_upload_wire_frame(lsa_ctx* ctx, const void* data, int n, const lsa_wire_
   auto f32 = [&](int i, int off) { float v; std::memcpy(&v, raw + (size_t)i * lay->point_step + off, sizeof(v)); return v; };
   // "If first and last points have same timestamps, this is not normal" (VelodyneToLidarNode.cxx:74)
   const bool isTimeValid = f32(n - 1, lay->off_time) - f32(0, lay->off_time) > 1e-8;
-  if (!isTimeValid || ctx->az_res <= 0.f)
-  {
-    // host conversion: the time has to be built from the azimuth advancement, ring by ring in arrival order
-    // (libm atan2 / fmod, as the driver node does), or this is the first frame, whose azimuthal resolution is
-    // estimated on the host from the converted points anyway
+  auto on_host = [&]() -> int {
+    // host conversion (libm atan2 / fmod, ring by ring in arrival order, as the driver node does): the first frame,
+    // whose azimuthal resolution is estimated on the host from the converted points anyway, and frames the device
+    // cannot bucket by ring
     std::vector<lsa_point_t> pts(n);
     FrameAdvancementEstimator est;
     for (int i = 0; i < n; ++i)
@@ -616,13 +632,15 @@ int lsa_upload_wire_frame(lsa_ctx* ctx, const void* data, int n, const lsa_wire_
     if (rc) return rc;
     LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));  // pts goes away
     return LSA_OK;
-  }
+  };
+  if (ctx->az_res <= 0.f) return on_host();
   int rc = ensure_capacity(ctx, n);
   if (rc) return rc;
   const size_t bytes = (size_t)n * lay->point_step;
   rc = ensure_scratch(ctx, bytes);
   if (rc) return rc;
   WireMap m;
+  m.advancement = isTimeValid ? 0 : 1;
   m.lay = *lay;
   m.mapping_len = mapping_len;
   m.device_id = device_id;
@@ -652,6 +670,203 @@ int lsa_upload_frame(lsa_ctx* ctx, const lsa_point_t* pts, int n)
   ctx->frame_n = n;
   ctx->inbox_current = -1;
   return LSA_OK;
+}
+
+// ---- vtkSlam::PolyDataToPointCloud (paraview_wrapping/Plugin/vtkLidarSlam/vtkSlam.cxx:668-707) on the device -----------
+namespace
+{
+struct SoaFrame
+{
+  const void* xyz; const void* time; const void* laser; const void* intensity;
+  int xyz_type, time_type, laser_type, intensity_type;
+  int n;
+  int mapping_len;
+  double factor;  // TimeToSecondsFactor
+  uint16_t mapping[kMaxRings];
+};
+__device__ __forceinline__ double soa_value(const void* base, int type, size_t i)
+{
+  switch (type)
+  {
+    case LSA_SCALAR_F32: return (double)static_cast<const float*>(base)[i];
+    case LSA_SCALAR_F64: return static_cast<const double*>(base)[i];
+    case LSA_SCALAR_U8: return (double)static_cast<const unsigned char*>(base)[i];
+    case LSA_SCALAR_U16: return (double)static_cast<const unsigned short*>(base)[i];
+    case LSA_SCALAR_U32: return (double)static_cast<const unsigned int*>(base)[i];
+    default: return (double)static_cast<const int*>(base)[i];
+  }
+}
+__device__ __forceinline__ long long ordered_bits(double v)
+{
+  const long long b = __double_as_longlong(v);
+  return b >= 0 ? b : b ^ 0x7fffffffffffffffll;
+}
+// frame end time = the largest value of the time array (arrayTime->GetRange()[1]); points with all-zero coordinates
+// are dropped: per chunk of 1024 points, how many stay
+__global__ __launch_bounds__(256) void k_soa_scan_chunks(SoaFrame f, long long* __restrict__ tmax, int* __restrict__ chunk_count)
+{
+  __shared__ int cnt[4];
+  __shared__ long long mx[4];
+  int mine = 0;
+  long long m = (long long)0x8000000000000000ull;
+  for (int q = 0; q < 4; ++q)
+  {
+    const int i = blockIdx.x * 1024 + q * 256 + threadIdx.x;
+    if (i < f.n)
+    {
+      const double x = soa_value(f.xyz, f.xyz_type, 3 * (size_t)i), y = soa_value(f.xyz, f.xyz_type, 3 * (size_t)i + 1), z = soa_value(f.xyz, f.xyz_type, 3 * (size_t)i + 2);
+      if (x != 0. || y != 0. || z != 0.) ++mine;
+      const long long t = ordered_bits(soa_value(f.time, f.time_type, i));
+      m = t > m ? t : m;
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1)
+  {
+    mine += __shfl_down(mine, o);
+    const long long t = __shfl_down(m, o);
+    m = t > m ? t : m;
+  }
+  if ((threadIdx.x & 63) == 0) { cnt[threadIdx.x >> 6] = mine; mx[threadIdx.x >> 6] = m; }
+  __syncthreads();
+  if (threadIdx.x == 0)
+  {
+    chunk_count[blockIdx.x] = cnt[0] + cnt[1] + cnt[2] + cnt[3];
+    long long a = mx[0] > mx[1] ? mx[0] : mx[1], b = mx[2] > mx[3] ? mx[2] : mx[3];
+    atomicMax(tmax, a > b ? a : b);
+  }
+}
+// exclusive scan of the chunk counts (one block; a frame has a few hundred chunks)
+__global__ __launch_bounds__(1024) void k_soa_scan_counts(int* __restrict__ chunk_count, int nchunks, int* __restrict__ total)
+{
+  __shared__ int s[1024];
+  int run = 0;
+  for (int base = 0; base < nchunks; base += 1024)
+  {
+    const int i = base + threadIdx.x;
+    const int v = i < nchunks ? chunk_count[i] : 0;
+    s[threadIdx.x] = v;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1)
+    {
+      const int a = threadIdx.x >= (unsigned)o ? s[threadIdx.x - o] : 0;
+      __syncthreads();
+      s[threadIdx.x] += a;
+      __syncthreads();
+    }
+    if (i < nchunks) chunk_count[i] = run + s[threadIdx.x] - v;
+    run += s[1023];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *total = run;
+}
+// the points that stay, in order, as LidarPoints: time relative to the frame's end [s], laser id (mapped), intensity
+__global__ __launch_bounds__(256) void k_soa_to_points(SoaFrame f, const long long* __restrict__ tmax, const int* __restrict__ chunk_start, float4* __restrict__ out)
+{
+  __shared__ int wave_base[4];
+  const long long tb = *tmax;
+  const double end_time = __longlong_as_double(tb >= 0 ? tb : tb ^ 0x7fffffffffffffffll);
+  int run = chunk_start[blockIdx.x];
+  for (int q = 0; q < 4; ++q)
+  {
+    const int i = blockIdx.x * 1024 + q * 256 + threadIdx.x;
+    double x = 0., y = 0., z = 0.;
+    if (i < f.n)
+    {
+      x = soa_value(f.xyz, f.xyz_type, 3 * (size_t)i); y = soa_value(f.xyz, f.xyz_type, 3 * (size_t)i + 1); z = soa_value(f.xyz, f.xyz_type, 3 * (size_t)i + 2);
+    }
+    const bool keep = i < f.n && (x != 0. || y != 0. || z != 0.);
+    const unsigned long long ballot = __ballot(keep);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) wave_base[wv] = __popcll(ballot);
+    __syncthreads();
+    int base = run;
+    for (int w = 0; w < wv; ++w) base += wave_base[w];
+    const int batch = wave_base[0] + wave_base[1] + wave_base[2] + wave_base[3];
+    if (keep)
+    {
+      const int at = base + __popcll(ballot & ((1ull << lane) - 1ull));
+      const double t = (soa_value(f.time, f.time_type, i) - end_time) * f.factor;
+      const double lid = soa_value(f.laser, f.laser_type, i);
+      unsigned id = f.mapping_len > 0 ? ((size_t)lid < (size_t)f.mapping_len ? f.mapping[(size_t)lid] : 0xffffu) : (unsigned)(unsigned short)lid;
+      const long long bits = __double_as_longlong(t);
+      float4 a = make_float4((float)x, (float)y, (float)z, 1.f), b;
+      b.x = __int_as_float((int)(bits & 0xffffffffll));
+      b.y = __int_as_float((int)(bits >> 32));
+      b.z = (float)soa_value(f.intensity, f.intensity_type, i);
+      b.w = __uint_as_float(id & 0xffffu);  // device_id 0, label 0
+      out[2 * (size_t)at] = a;
+      out[2 * (size_t)at + 1] = b;
+    }
+    run += batch;
+    __syncthreads();
+  }
+}
+int scalar_size(int type) { return type == LSA_SCALAR_F64 ? 8 : type == LSA_SCALAR_U8 ? 1 : type == LSA_SCALAR_U16 ? 2 : 4; }
+}  // namespace
+
+int lsa_upload_polydata_frame(lsa_ctx* ctx, int n, const void* xyz, int xyz_type, const void* time, int time_type, const void* laser_id, int laser_type,
+                              const void* intensity, int intensity_type, const uint16_t* laser_id_mapping, int mapping_len, double time_to_seconds,
+                              uint64_t* stamp_us, int* n_valid)
+{
+  if (!ctx || n <= 0 || !xyz || !time || !laser_id || !intensity || mapping_len < 0 || (mapping_len > 0 && !laser_id_mapping) ||
+      (xyz_type != LSA_SCALAR_F32 && xyz_type != LSA_SCALAR_F64))
+    return ctx ? ctx->fail(LSA_E_ARG, "lsa_upload_polydata_frame: bad argument") : LSA_E_ARG;
+  for (int t : {time_type, laser_type, intensity_type})
+    if (t < LSA_SCALAR_F32 || t > LSA_SCALAR_I32) return ctx->fail(LSA_E_ARG, "lsa_upload_polydata_frame: unknown scalar type");
+  if (mapping_len > kMaxRings) return ctx->fail(LSA_E_CAPACITY, "lsa_upload_polydata_frame: more than 512 entries in the laser id mapping");
+  LSA_HIP(ctx, hipSetDevice(ctx->device));
+  int rc = ensure_capacity(ctx, n);
+  if (rc) return rc;
+  // the four arrays go to the device as they are (structure of arrays, no LidarPoint cloud is built on the host)
+  const size_t sz[4] = {(size_t)3 * n * scalar_size(xyz_type), (size_t)n * scalar_size(time_type), (size_t)n * scalar_size(laser_type),
+                        (size_t)n * scalar_size(intensity_type)};
+  size_t off[4], total = 0;
+  for (int i = 0; i < 4; ++i) { off[i] = total; total += (sz[i] + 255) / 256 * 256; }
+  const int nchunks = (n + 1023) / 1024;
+  const size_t off_counts = total, off_tmax = off_counts + ((size_t)(nchunks + 1) * sizeof(int) + 255) / 256 * 256;
+  rc = ensure_scratch(ctx, off_tmax + 64);
+  if (rc) return rc;
+  char* base = static_cast<char*>(ctx->scratch_out);
+  const void* src[4] = {xyz, time, laser_id, intensity};
+  for (int i = 0; i < 4; ++i) LSA_HIP(ctx, hipMemcpyAsync(base + off[i], src[i], sz[i], hipMemcpyHostToDevice, ctx->stream));
+  SoaFrame f;
+  f.xyz = base + off[0]; f.time = base + off[1]; f.laser = base + off[2]; f.intensity = base + off[3];
+  f.xyz_type = xyz_type; f.time_type = time_type; f.laser_type = laser_type; f.intensity_type = intensity_type;
+  f.n = n;
+  f.mapping_len = mapping_len;
+  f.factor = time_to_seconds;
+  if (mapping_len > 0) std::memcpy(f.mapping, laser_id_mapping, (size_t)mapping_len * sizeof(uint16_t));
+  int* counts = reinterpret_cast<int*>(base + off_counts);
+  long long* tmax = reinterpret_cast<long long*>(base + off_tmax);
+  const long long lowest = (long long)0x8000000000000000ull;
+  LSA_HIP(ctx, hipMemcpyAsync(tmax, &lowest, sizeof(lowest), hipMemcpyHostToDevice, ctx->stream));
+  {
+    ProfScope ps(ctx, "polydata_to_points", (double)total + (double)n * 32);
+    hipLaunchKernelGGL(k_soa_scan_chunks, dim3(nchunks), dim3(256), 0, ctx->stream, f, tmax, counts);
+    hipLaunchKernelGGL(k_soa_scan_counts, dim3(1), dim3(1024), 0, ctx->stream, counts, nchunks, counts + nchunks);
+    hipLaunchKernelGGL(k_soa_to_points, dim3(nchunks), dim3(256), 0, ctx->stream, f, tmax, counts, reinterpret_cast<float4*>(ctx->frame_own));
+  }
+  long long tb = 0;
+  int kept = 0;
+  LSA_HIP(ctx, hipMemcpyAsync(&tb, tmax, sizeof(tb), hipMemcpyDeviceToHost, ctx->stream));
+  LSA_HIP(ctx, hipMemcpyAsync(&kept, counts + nchunks, sizeof(kept), hipMemcpyDeviceToHost, ctx->stream));
+  LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the caller's arrays may go away; stamp and size are needed now
+  tb = tb >= 0 ? tb : tb ^ 0x7fffffffffffffffll;
+  double end_time;
+  std::memcpy(&end_time, &tb, sizeof(end_time));
+  if (stamp_us) *stamp_us = (uint64_t)(end_time * (time_to_seconds * 1e6));  // pc->header.stamp = frameEndTime * (factor * 1e6) (:683)
+  if (n_valid) *n_valid = kept;
+  ctx->frame = kept > 0 ? ctx->frame_own : nullptr;
+  ctx->frame_n = kept;
+  ctx->inbox_current = -1;
+  if (kept > 0 && (ctx->az_res < 1e-6 || M_PI / 4. < ctx->az_res))
+  {
+    // first usable frame: the azimuthal resolution is estimated on the host from the converted points (SSKE.cxx:593-637)
+    std::vector<lsa_point_t> pts(kept);
+    LSA_HIP(ctx, hipMemcpy(pts.data(), ctx->frame_own, (size_t)kept * sizeof(lsa_point_t), hipMemcpyDeviceToHost));
+    maybe_estimate_resolution(ctx, pts.data(), kept);
+  }
+  return kept == n ? 1 : 0;  // allPointsAreValid
 }
 
 int lsa_frame_store_put(lsa_ctx* ctx, int slot, const lsa_point_t* pts, int n)

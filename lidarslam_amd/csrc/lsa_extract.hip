@@ -834,6 +834,77 @@ static int extract_frame(lsa_ctx* ctx, const lsa_extract_params_t* params, int c
   return LSA_OK;
 }
 
+// ---- SpinningFrameAdvancementEstimator on the device (lidar_conversions/src/Utilities.h:62-114) --------------------
+// The estimator walks the frame in arrival order and keeps, per laser ring, the advancement of the ring's previous point:
+// a point whose advancement (in [0, 1)) is lower than its ring's previous one has passed the turn and gets + 1 -- and
+// from then on so does every later point of that ring (their advancement < 1 <= the stored value).  Per ring that is
+// "the first descent and everything after it": with the frame bucketed by ring (arrival order kept inside a ring) the
+// first descent is one comparison with the ring-major predecessor and a minimum per ring.
+__global__ __launch_bounds__(256) void k_first_wrap(const float4* __restrict__ frame, const uint32_t* __restrict__ orig, const uint16_t* __restrict__ ring_of,
+                                                    const int* __restrict__ ring_start, int n, int* __restrict__ first_wrap)
+{
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  const int ring = ring_of[p];
+  if (p == ring_start[ring]) return;  // the ring's first point compares with 0.0: never lower
+  const float4 b = frame[2 * (size_t)orig[p] + 1], a = frame[2 * (size_t)orig[p - 1] + 1];
+  const double cur = __hiloint2double(__float_as_int(b.y), __float_as_int(b.x)), prev = __hiloint2double(__float_as_int(a.y), __float_as_int(a.x));
+  if (cur < prev) atomicMin(&first_wrap[ring], p - ring_start[ring]);
+}
+__global__ __launch_bounds__(256) void k_time_from_advancement(float4* __restrict__ frame, const uint32_t* __restrict__ orig, const uint16_t* __restrict__ ring_of,
+                                                               const int* __restrict__ ring_start, int n, const int* __restrict__ first_wrap, double rpm,
+                                                               int first_packet)
+{
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  const int ring = ring_of[p];
+  float4 b = frame[2 * (size_t)orig[p] + 1];
+  double adv = __hiloint2double(__float_as_int(b.y), __float_as_int(b.x));
+  if (p - ring_start[ring] >= first_wrap[ring]) adv += 1.;
+  const double t = (first_packet ? adv : adv - 1) / rpm * 60.;  // VelodyneToLidarNode.cxx:106
+  const long long tb = __double_as_longlong(t);
+  b.x = __int_as_float((int)(tb & 0xffffffffll));
+  b.y = __int_as_float((int)(tb >> 32));
+  frame[2 * (size_t)orig[p] + 1] = b;
+}
+
+}  // extern "C"
+
+namespace lsa
+{
+// frame (AoS, n points on the device) holds in its time field the advancement of every point in [0, 1): replaces it by
+// the estimator's time.  Returns LSA_E_CAPACITY when a laser id cannot be bucketed (>= 512 rings): the caller converts
+// on the host then.
+int time_from_advancement(lsa_ctx* ctx, lsa_point_t* frame, int n, double rpm, int first_packet)
+{
+  hipStream_t st = ctx->stream;
+  if (ctx->prefetch_pending)
+  {
+    LSA_HIP(ctx, hipStreamSynchronize(ctx->prefetch_stream));  // the bucketing buffers are shared with the look-ahead extraction
+  }
+  float4* f4 = reinterpret_cast<float4*>(frame);
+  const int nblocks = (n + kBucketChunk - 1) / kBucketChunk;
+  int* meta = ctx->extract_out + 4;
+  hipLaunchKernelGGL(k_extract_init, dim3(1), dim3(64), 0, st, ctx->extract_out);
+  hipLaunchKernelGGL(k_ring_hist, dim3(nblocks), dim3(256), 0, st, f4, n, ctx->block_hist, meta);
+  hipLaunchKernelGGL(k_ring_scan, dim3(kMaxRings), dim3(64), 0, st, ctx->block_hist, nblocks, ctx->ring_len, meta);
+  hipLaunchKernelGGL(k_ring_scatter, dim3(nblocks), dim3(256), 0, st, f4, n, ctx->block_hist, ctx->ring_len, ctx->ring_start, ctx->xyzi, ctx->orig,
+                     ctx->ring_of, ctx->valid);
+  int* first_wrap = ctx->ring_counts;  // [kMaxRings] of its 3 x kMaxRings ints
+  LSA_HIP(ctx, hipMemsetAsync(first_wrap, 0x7f, kMaxRings * sizeof(int), st));
+  hipLaunchKernelGGL(k_first_wrap, dim3((n + 255) / 256), dim3(256), 0, st, f4, ctx->orig, ctx->ring_of, ctx->ring_start, n, first_wrap);
+  hipLaunchKernelGGL(k_time_from_advancement, dim3((n + 255) / 256), dim3(256), 0, st, f4, ctx->orig, ctx->ring_of, ctx->ring_start, n, first_wrap, rpm,
+                     first_packet);
+  int* hp = reinterpret_cast<int*>(ctx->host_pinned);
+  LSA_HIP(ctx, hipMemcpyAsync(hp, ctx->extract_out, 16 * sizeof(int), hipMemcpyDeviceToHost, st));
+  LSA_HIP(ctx, hipStreamSynchronize(st));
+  if (hp[6] & 3) return LSA_E_CAPACITY;
+  return LSA_OK;
+}
+}  // namespace lsa
+
+extern "C" {
+
 int lsa_extract_keypoints(lsa_ctx* ctx, const lsa_extract_params_t* params, int counts[3])
 {
   return extract_frame(ctx, params, counts, false, nullptr, 0.);

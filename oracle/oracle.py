@@ -251,6 +251,25 @@ def velodyne_to_lidar(records, layout, mapping=None, device_id=0, rpm=600.0, tim
     return out, rc == 1
 
 
+def polydata_to_point_cloud(xyz, time, laser_id, intensity, mapping=None, time_to_seconds=1.0):
+    """vtkSlam::PolyDataToPointCloud (paraview_wrapping/Plugin/vtkLidarSlam/vtkSlam.cxx:668-707), numpy restatement:
+    frame end = max of the time array (:682), stamp = end * (factor * 1e6) as an integer (:683), points with all-zero
+    coordinates dropped (:691), time = (t - end) * factor (:697), laser_id through the mapping (:698).
+    Returns (LidarPoint array, stamp_us, allPointsAreValid)."""
+    xyz = np.asarray(xyz, np.float64).reshape(-1, 3)  # poly->GetPoint(i, double pos[3])
+    t = np.asarray(time, np.float64)                   # GetTuple1 returns double whatever the array holds
+    end = t.max()
+    stamp = int(np.uint64(end * (time_to_seconds * 1e6)))
+    keep = (xyz != 0).any(axis=1)
+    out = np.zeros(int(keep.sum()), POINT_DTYPE)
+    out["x"], out["y"], out["z"], out["w"] = xyz[keep, 0], xyz[keep, 1], xyz[keep, 2], 1.0
+    out["time"] = (t[keep] - end) * time_to_seconds
+    lid = np.asarray(laser_id, np.float64)[keep]
+    out["laser_id"] = (np.asarray(mapping)[lid.astype(np.int64)] if mapping is not None else lid).astype(np.uint16)
+    out["intensity"] = np.asarray(intensity, np.float64)[keep]
+    return out, stamp, bool(keep.all())
+
+
 def lcp(cloud, ratio, targets, leaves):
     """Confidence::LCPEstimator on a registered cloud; targets / leaves: per keypoint type (None = map not used)."""
     cloud = np.ascontiguousarray(cloud)

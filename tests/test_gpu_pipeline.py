@@ -384,8 +384,28 @@ def test_wire_format_upload_follows_the_driver_node(O, L):
         for first in (False, True):
             want, valid = O.velodyne_to_lidar(rec, VELODYNE_LAYOUT, None, 0, 600.0, first)
             assert not valid and np.ptp(want["time"]) > 0.05
+            # on the device: per ring "the first descent of the advancement and everything after it" on the ring-bucketed
+            # frame; the arc tangent is the portable one, so the time agrees with the node's libm value to rounding
             ctx.upload_wire_frame(rec, VELODYNE_LAYOUT, None, 0, 600.0, first)
-            assert same_points(ctx.transform_frame(eye), want)
+            got = ctx.transform_frame(eye)
+            assert np.abs(got["time"] - want["time"]).max() < 2e-8 and np.ptp(got["time"]) > 0.05
+            got["time"] = want["time"]
+            assert same_points(got, want)
+        # more than one turn in a frame, rings starting at different azimuths: the + 1 of the estimator comes into play
+        rng = np.random.default_rng(3)
+        n = 40000
+        az = np.sort(rng.uniform(0.3, 0.3 + 2.3 * np.pi, n))  # 1.15 turns
+        ring = rng.integers(0, 16, n)
+        rr = rng.uniform(5, 30, n)
+        spin = np.zeros(n, L.POINT_DTYPE)
+        spin["x"], spin["y"], spin["z"], spin["w"] = rr * np.cos(-az), rr * np.sin(-az), 0.1 * ring, 1.0
+        spin["laser_id"], spin["intensity"] = ring, 10.0
+        rec = wire_records(spin, with_time=False)
+        for first in (False, True):
+            want, valid = O.velodyne_to_lidar(rec, VELODYNE_LAYOUT, None, 0, 600.0, first)
+            ctx.upload_wire_frame(rec, VELODYNE_LAYOUT, None, 0, 600.0, first)
+            got = ctx.transform_frame(eye)
+            assert not valid and np.ptp(want["time"]) > 0.105 and np.abs(got["time"] - want["time"]).max() < 2e-8
     finally:
         ctx.close()
 
@@ -665,3 +685,38 @@ def test_upload_ahead_through_the_c_abi(gpu_ctx, O, L):
     assert lib.lsa_upload_frame_adopt(h, L.ptr(a), a.size) == 0
     counts = gpu_ctx.extract_keypoints()
     assert np.array_equal(counts, ref_b) and [gpu_ctx.keypoints(L.SET_RAW_CURRENT, k).tobytes() for k in range(3)] == kp_b
+
+
+@pytest.mark.gpu
+def test_polydata_arrays_upload_follows_the_paraview_filter(O, L):
+    """vtkSlam::PolyDataToPointCloud (vtkSlam.cxx:668-707) on the device, from the frame's own arrays (structure of
+    arrays, several scalar types): the frame the context holds is the cloud the filter would build, value for value --
+    stamp, relative times, mapped laser ids, null points dropped with the order kept -- and gives the same keypoints"""
+    ctx = L.Context(0)
+    eye = np.eye(4)
+    try:
+        for f, (xyz_t, time_t, lid_t, int_t, mapping, factor) in enumerate((
+                (np.float32, np.float64, np.uint8, np.float32, None, 1.0),
+                (np.float64, np.float64, np.uint16, np.uint8, np.arange(16, dtype=np.uint16)[::-1].copy(), 1e-6),
+                (np.float32, np.float32, np.int32, np.float64, None, 1.0))):
+            pts, stamp = L.synth_frame(16, 1000, f)
+            xyz = np.stack([pts["x"], pts["y"], pts["z"]], axis=1).astype(xyz_t)
+            t = ((pts["time"] + stamp * 1e-6) / factor).astype(time_t)  # absolute lidar time in the filter's unit
+            inten = pts["intensity"].astype(int_t)
+            lid = pts["laser_id"].astype(lid_t)
+            xyz[5::97] = 0  # null returns, as LidarView delivers them
+            want, want_stamp, all_valid = O.polydata_to_point_cloud(xyz, t, lid, inten, mapping, factor)
+            got_stamp, kept, ok = ctx.upload_polydata_frame(xyz, t, lid, inten, mapping, factor)
+            assert (got_stamp, kept, ok) == (want_stamp, want.size, all_valid) and not ok
+            assert same_points(ctx.transform_frame(eye), want)
+        counts = ctx.extract_keypoints()
+        ctx2 = L.Context(0)
+        ctx2.azimuthal_resolution = ctx.azimuthal_resolution
+        ctx2.upload_frame(want)
+        assert counts.tolist() == ctx2.extract_keypoints().tolist() and counts[1] > 50
+        ctx2.close()
+        # nothing dropped: "allPointsAreValid"
+        xyz = np.stack([pts["x"], pts["y"], pts["z"]], axis=1)
+        assert ctx.upload_polydata_frame(xyz, pts["time"], pts["laser_id"], pts["intensity"])[1:] == (pts.size, True)
+    finally:
+        ctx.close()

@@ -652,6 +652,14 @@ int lsa_upload_wire_frame(lsa_ctx* ctx, const void* data, int n, const lsa_wire_
                        reinterpret_cast<float4*>(ctx->frame_own));
   }
   LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the caller's buffer may be pageable and go away
+  if (!isTimeValid)
+  {
+    // no usable time field: built from the azimuth advancement (a per-ring "first descent" found on the ring-bucketed
+    // frame), on the device; laser ids the bucketing cannot hold go through the host
+    rc = time_from_advancement(ctx, ctx->frame_own, n, rpm, timestamp_first_packet);
+    if (rc == LSA_E_CAPACITY) return on_host();
+    if (rc) return rc;
+  }
   ctx->frame = ctx->frame_own;
   ctx->frame_n = n;
   ctx->inbox_current = -1;

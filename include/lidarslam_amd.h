@@ -556,6 +556,42 @@ int lsa_slam_get_target_submap(lsa_slam* s, int type, lsa_point_t* out, int capa
 lsa_ctx* lsa_slam_context(lsa_slam* s);
 
 
+/* ------------------------------------------------------------------------- */
+/* LidarSlam::RollingGrid ON THE DEVICE (slam_lib/include/LidarSlam/RollingGrid.h:63-212, slam_lib/src/RollingGrid.cxx): the
+ * rolling voxel map of one keypoint type as ONE array of voxels sorted by (outer voxel index, leaf voxel index), living
+ * in the memory of the context it was created on.  Add / Roll / ClearOldPoints / BuildSubMapKdTree are sequences of
+ * kernels on the context's stream (sort of the batch, one thread per voxel folding the batch's points for it in arrival
+ * order through the reference's per-point rule, merge by rank, stable compactions); the sub-map is written straight
+ * into a kNN target of the context.  Points come out in KEY ORDER (outer index, then leaf index) where the reference
+ * hands them out in its hash containers' iteration order -- a defined order in place of an accidental one, adopted by
+ * the oracle and the host grid as well ("OrderedMaps").  Sampling modes FIRST, LAST, MAX_INTENSITY, CENTER_POINT;
+ * CENTROID (whose reference loop is quadratic in the batch size, RollingGrid.cxx:282-297) is refused: lsa_slam keeps
+ * that mode on the host grid.  Parameters by the reference's setter names: "GridSize", "VoxelResolution", "LeafSize",
+ * "MinFramesPerVoxel", "Sampling", "DecayingThreshold". */
+typedef struct lsa_device_grid lsa_device_grid;
+int lsa_device_grid_create(lsa_ctx* ctx, lsa_device_grid** out);
+void lsa_device_grid_destroy(lsa_device_grid* g); /* before lsa_ctx_destroy of its context */
+int lsa_device_grid_set(lsa_device_grid* g, const char* name, double value);
+double lsa_device_grid_get_param(const lsa_device_grid* g, const char* name);
+/* RollingGrid::Reset(position) / Clear(). */
+int lsa_device_grid_reset(lsa_device_grid* g, const float position[3]);
+int lsa_device_grid_clear(lsa_device_grid* g);
+/* RollingGrid::Size() (waits for the modifications enqueued so far). */
+int lsa_device_grid_size(lsa_device_grid* g);
+/* RollingGrid::Add(pointcloud, fixed, currentTime, roll) from host points ... */
+int lsa_device_grid_add(lsa_device_grid* g, const lsa_point_t* pts, int n, int fixed, double time, int roll);
+/* ... and from a keypoint set of the context moved by `pose` (Slam::UpdateMapsUsingTworld, Slam.cxx:1178-1222): nothing
+ * leaves the device and nothing is waited for. */
+int lsa_device_grid_add_keypoints(lsa_device_grid* g, int set, int type, const double pose[16], double time);
+int lsa_device_grid_roll(lsa_device_grid* g, const float min_point[3], const float max_point[3]);
+int lsa_device_grid_clear_old_points(lsa_device_grid* g, double current_time);
+/* RollingGrid::Get(clean): points written. */
+int lsa_device_grid_get(lsa_device_grid* g, int clean, lsa_point_t* out, int capacity);
+/* RollingGrid::BuildSubMapKdTree(): the sub-map (the whole map when min_point == NULL) becomes the kNN target (slot,
+ * type) of the context; returns its size.  lsa_device_grid_submap_valid: RollingGrid::IsSubMapKdTreeValid(). */
+int lsa_device_grid_build_submap(lsa_device_grid* g, const float min_point[3], const float max_point[3], int min_nb_points, int slot, int type);
+int lsa_device_grid_submap_valid(lsa_device_grid* g);
+
 /* ---- the rolling voxel map (host) ---------------------------
  * LidarSlam::RollingGrid -- slam_lib/include/LidarSlam/RollingGrid.h:63-212,
  * slam_lib/src/RollingGrid.cxx.  Map maintenance runs on host threads beside the

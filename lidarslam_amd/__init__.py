@@ -65,6 +65,9 @@ ABI_SYMBOLS = [
     "lsa_slam_set_world_transform_from_guess", "lsa_slam_get_trajectory", "lsa_slam_get_debug_information", "lsa_slam_get_map",
     "lsa_slam_get_target_submap", "lsa_slam_set_base_to_lidar_offset", "lsa_slam_get_base_to_lidar_offset", "lsa_slam_add_frames", "lsa_slam_set_extractor_param", "lsa_slam_get_extractor_param", "lsa_match_serial", "lsa_match_histogram", "lsa_synth_sensor", "lsa_synth_frame",
     "lsa_synth_pose",
+    "lsa_device_grid_create", "lsa_device_grid_destroy", "lsa_device_grid_set", "lsa_device_grid_get_param", "lsa_device_grid_reset", "lsa_device_grid_clear",
+    "lsa_device_grid_size", "lsa_device_grid_add", "lsa_device_grid_add_keypoints", "lsa_device_grid_roll", "lsa_device_grid_clear_old_points",
+    "lsa_device_grid_get", "lsa_device_grid_build_submap", "lsa_device_grid_submap_valid",
     "lsa_rolling_grid_create", "lsa_rolling_grid_destroy", "lsa_rolling_grid_set", "lsa_rolling_grid_reset", "lsa_rolling_grid_clear",
     "lsa_rolling_grid_size", "lsa_rolling_grid_roll", "lsa_rolling_grid_add", "lsa_rolling_grid_clear_old_points", "lsa_rolling_grid_get",
     "lsa_rolling_grid_build_submap", "lsa_rolling_grid_submap_valid", "lsa_rolling_grid_submap",
@@ -770,3 +773,88 @@ class RollingGrid:
         out = np.zeros(max(self.size(), 1), POINT_DTYPE)
         n = self.L.lsa_rolling_grid_submap(self.h, ptr(out), out.size)
         return out[:n].copy()
+
+
+class DeviceGrid:
+    """LidarSlam::RollingGrid resident on the device (lsa_device_grid_*): same calls as RollingGrid, the map lives in the
+    memory of `ctx` and its sub-map becomes a kNN target of that context."""
+
+    def __init__(self, ctx, **params):
+        self.L = lib()
+        self.ctx = ctx
+        h = C.c_void_p()
+        vp, i32, f64 = C.c_void_p, C.c_int, C.c_double
+        self.L.lsa_device_grid_create.argtypes = [vp, C.POINTER(vp)]
+        self.L.lsa_device_grid_destroy.argtypes = [vp]
+        self.L.lsa_device_grid_set.argtypes = [vp, C.c_char_p, f64]
+        self.L.lsa_device_grid_reset.argtypes = [vp, vp]
+        self.L.lsa_device_grid_clear.argtypes = [vp]
+        self.L.lsa_device_grid_size.argtypes = [vp]
+        self.L.lsa_device_grid_add.argtypes = [vp, vp, i32, i32, f64, i32]
+        self.L.lsa_device_grid_add_keypoints.argtypes = [vp, i32, i32, vp, f64]
+        self.L.lsa_device_grid_roll.argtypes = [vp, vp, vp]
+        self.L.lsa_device_grid_clear_old_points.argtypes = [vp, f64]
+        self.L.lsa_device_grid_get.argtypes = [vp, i32, vp, i32]
+        self.L.lsa_device_grid_build_submap.argtypes = [vp, vp, vp, i32, i32, i32]
+        self.L.lsa_device_grid_submap_valid.argtypes = [vp]
+        if self.L.lsa_device_grid_create(ctx.h, C.byref(h)) != 0:
+            raise LsaError("lsa_device_grid_create failed")
+        self.h = h
+        for k, v in params.items():
+            self.set(k, v)
+
+    def close(self):
+        if getattr(self, "h", None):
+            if self.ctx.h:  # a grid must go before its context (include/lidarslam_amd.h); one that outlived it is dropped
+                self.L.lsa_device_grid_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def _check(self, rc, what):
+        if rc < 0:
+            raise LsaError(f"{what} failed ({rc}): {self.L.lsa_last_error(self.ctx.h).decode()}")
+        return rc
+
+    def set(self, name, value):
+        self._check(self.L.lsa_device_grid_set(self.h, name.encode(), float(value)), f"lsa_device_grid_set({name})")
+
+    def reset(self, position=None):
+        pos = None if position is None else np.ascontiguousarray(position, np.float32)
+        self._check(self.L.lsa_device_grid_reset(self.h, None if pos is None else ptr(pos)), "lsa_device_grid_reset")
+
+    def clear(self):
+        self._check(self.L.lsa_device_grid_clear(self.h), "lsa_device_grid_clear")
+
+    def size(self):
+        return self._check(self.L.lsa_device_grid_size(self.h), "lsa_device_grid_size")
+
+    def roll(self, mn, mx):
+        mn, mx = np.ascontiguousarray(mn, np.float32), np.ascontiguousarray(mx, np.float32)
+        self._check(self.L.lsa_device_grid_roll(self.h, ptr(mn), ptr(mx)), "lsa_device_grid_roll")
+
+    def add(self, pts, fixed=False, time=-1.0, roll=True):
+        pts = np.ascontiguousarray(pts, POINT_DTYPE)
+        self._check(self.L.lsa_device_grid_add(self.h, ptr(pts) if pts.size else None, pts.size, int(fixed), float(time), int(roll)), "lsa_device_grid_add")
+
+    def add_keypoints(self, kset, ktype, pose, time):
+        self._check(self.L.lsa_device_grid_add_keypoints(self.h, kset, ktype, ptr(pose16(pose)), float(time)), "lsa_device_grid_add_keypoints")
+
+    def clear_old_points(self, time):
+        self._check(self.L.lsa_device_grid_clear_old_points(self.h, float(time)), "lsa_device_grid_clear_old_points")
+
+    def get(self, clean=False, capacity=1 << 22):
+        out = np.zeros(capacity, POINT_DTYPE)
+        n = self._check(self.L.lsa_device_grid_get(self.h, int(clean), ptr(out), out.size), "lsa_device_grid_get")
+        return out[:n].copy()
+
+    def build_submap(self, mn=None, mx=None, min_nb_points=-1, ktype=PLANE, slot=TARGET_MAP):
+        """the sub-map becomes target (slot, ktype) of the context; returns its size"""
+        if mn is None:
+            return self._check(self.L.lsa_device_grid_build_submap(self.h, None, None, -1, slot, ktype), "lsa_device_grid_build_submap")
+        mn, mx = np.ascontiguousarray(mn, np.float32), np.ascontiguousarray(mx, np.float32)
+        return self._check(self.L.lsa_device_grid_build_submap(self.h, ptr(mn), ptr(mx), int(min_nb_points), slot, ktype), "lsa_device_grid_build_submap")
+
+    def submap_valid(self):
+        return bool(self.L.lsa_device_grid_submap_valid(self.h))

@@ -105,9 +105,30 @@ void RollingGrid::SetVoxelResolution(double resolution)
 }
 
 // RollingGrid.cxx:95-114
+template <typename Pred> void RollingGrid::AppendOrdered(Pred pred, lsa_point_t* out, std::size_t& count) const
+{
+  struct Ref { unsigned out, in; const Voxel* v; };
+  std::vector<Ref> refs;
+  refs.reserve(NbPoints);
+  for (const auto& o : Voxels)
+    for (const auto& i : o.second)
+      if (pred(o.first, i.second)) refs.push_back({static_cast<unsigned>(o.first), static_cast<unsigned>(i.first), &i.second});
+  std::sort(refs.begin(), refs.end(), [](const Ref& a, const Ref& b) { return a.out != b.out ? a.out < b.out : a.in < b.in; });
+  for (const Ref& r : refs) out[count++] = r.v->point;
+}
+
 RollingGrid::PointCloud RollingGrid::Get(bool clean) const
 {
   PointCloud pc;
+  if (Ordered)
+  {
+    pc.resize(NbPoints);
+    std::size_t n = 0;
+    const unsigned minFrames = MinFramesPerVoxel;
+    this->AppendOrdered([&](int, const Voxel& v) { return !clean || v.count > minFrames; }, pc.data(), n);
+    pc.resize(n);
+    return pc;
+  }
   pc.reserve(NbPoints);
   for (const auto& out : Voxels)
     for (const auto& in : out.second)
@@ -544,6 +565,13 @@ void RollingGrid::BeginSubMap(std::size_t capacity)
 void RollingGrid::BuildSubMap()
 {
   this->BeginSubMap(NbPoints);
+  if (Ordered)
+  {
+    this->AppendOrdered([](int, const Voxel&) { return true; }, SubMapPtr, SubMapCount);
+    SubMapValid = true;
+    SubMapBoxed = false;
+    return;
+  }
   for (const auto& out : Voxels)
     for (const auto& in : out.second) SubMapPtr[SubMapCount++] = in.second.point;
   SubMapValid = true;
@@ -587,6 +615,20 @@ void RollingGrid::BuildSubMap(const float minPoint[3], const float maxPoint[3], 
     return lo[0] <= v[0] && v[0] <= hi[0] && lo[1] <= v[1] && v[1] <= hi[1] && lo[2] <= v[2] && v[2] <= hi[2];
   };
   this->BeginSubMap(NbPoints);
+  if (Ordered)
+  {
+    const unsigned minFrames = MinFramesPerVoxel;
+    if (minNbPoints < 0 || MinFramesPerVoxel <= 1)
+      this->AppendOrdered([&](int id, const Voxel&) { return intersects(id); }, SubMapPtr, SubMapCount);
+    else
+    {
+      this->AppendOrdered([&](int id, const Voxel& v) { return intersects(id) && (v.count >= minFrames || v.point.label == 1); }, SubMapPtr, SubMapCount);
+      if (static_cast<int>(SubMapCount) < minNbPoints)
+        this->AppendOrdered([&](int id, const Voxel& v) { return intersects(id) && v.count < minFrames && v.point.label != 1; }, SubMapPtr, SubMapCount);
+    }
+    SubMapValid = true;
+    return;
+  }
   if ((minNbPoints < 0 || MinFramesPerVoxel <= 1) && AddCrew && NbPoints >= 8192)
   {
     // every outer voxel contributes all its points, as one run in the iteration order of the outer map: the runs'

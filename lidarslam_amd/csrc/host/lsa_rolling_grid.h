@@ -77,6 +77,10 @@ public:
   void SetSampling(SamplingMode m) { this->Sampling = m; }
   SamplingMode GetSampling() const { return this->Sampling; }
   void SetDecayingThreshold(double d) { this->DecayingThreshold = d; }
+  // Order in which Get / BuildSubMap hand the voxels out: true (default) ascending (outer index, leaf index as
+  // unsigned), the defined order the device map uses; false: the iteration order of the reference's own containers.
+  void SetOrdered(bool b) { this->Ordered = b; }
+  bool GetOrdered() const { return this->Ordered; }
   // Threads Add() uses for a big cloud (1 = the caller alone).  The leaf voxels of different outer voxels are
   // independent containers: the outer voxels are created first, in the order of the points, then every thread
   // inserts the points of its share of the outer voxels, in the order of the points -- the maps end up with the
@@ -134,6 +138,9 @@ private:
   unsigned int MinFramesPerVoxel = 0;
   SamplingMode Sampling = SamplingMode::MAX_INTENSITY;
   double DecayingThreshold = -1;
+  bool Ordered = true;
+  // the voxels pred(outer index, voxel) keeps, in key order, appended to out
+  template <typename Pred> void AppendOrdered(Pred pred, lsa_point_t* out, std::size_t& count) const;
 
   std::unique_ptr<Crew> AddCrew;
   std::vector<int> AddOut, AddIn;  // outer / leaf voxel index per point of the cloud being added (-1: outside)

@@ -231,8 +231,9 @@ int lsa_slam_get_debug_information(lsa_slam* s, double out[10])
 int lsa_slam_get_map(lsa_slam* s, int type, int clean, lsa_point_t* out, int capacity)
 {
   if (!s || type < 0 || type > 2 || capacity < 0 || (capacity > 0 && !out)) return LSA_E_ARG;
-  const lsa::host::RollingGrid::PointCloud pc = s->core.Map(type).Get(clean != 0);
-  const int n = static_cast<int>(pc.size());
+  std::vector<lsa_point_t> pc;
+  const int n = s->core.GetMap(type, clean != 0, pc);
+  if (n < 0) return n;
   if (std::min(n, capacity) > 0) std::memcpy(out, pc.data(), static_cast<size_t>(std::min(n, capacity)) * sizeof(lsa_point_t));
   return n;
 }
@@ -240,9 +241,10 @@ int lsa_slam_get_map(lsa_slam* s, int type, int clean, lsa_point_t* out, int cap
 int lsa_slam_get_target_submap(lsa_slam* s, int type, lsa_point_t* out, int capacity)
 {
   if (!s || type < 0 || type > 2 || capacity < 0 || (capacity > 0 && !out)) return LSA_E_ARG;
-  const lsa::host::RollingGrid& map = s->core.Map(type);
-  const int n = static_cast<int>(map.SubMapSize());
-  if (std::min(n, capacity) > 0) std::memcpy(out, map.SubMapData(), static_cast<size_t>(std::min(n, capacity)) * sizeof(lsa_point_t));
+  std::vector<lsa_point_t> pc;
+  const int n = s->core.GetTargetSubMap(type, pc);
+  if (n < 0) return n;
+  if (std::min(n, capacity) > 0) std::memcpy(out, pc.data(), static_cast<size_t>(std::min(n, capacity)) * sizeof(lsa_point_t));
   return n;
 }
 
@@ -271,6 +273,7 @@ int lsa_rolling_grid_set(lsa_rolling_grid* g, const char* name, double value)
   }
   else if (n == "DecayingThreshold") g->grid.SetDecayingThreshold(value);
   else if (n == "AddThreads") g->grid.SetAddThreads(static_cast<int>(value));
+  else if (n == "Ordered") g->grid.SetOrdered(value != 0);
   else return LSA_E_ARG;
   return LSA_OK;
 }

@@ -98,6 +98,13 @@ SlamCore::SlamCore(int device)
     for (int k = 0; k < 3; ++k)
     {
       lsa_ctx* ctx = Ctx;
+      if (lsa_device_grid_create(ctx, &DevMaps[k]) == LSA_OK)
+      {
+        // the other parameters start from the same defaults as RollingGrid's (RollingGrid.h:170-212) and follow the same
+        // setters afterwards (SetVoxelResolution snaps to the leaf size of the moment on both sides, RollingGrid.cxx:73-88)
+        lsa_device_grid_set(DevMaps[k], "LeafSize", LocalMaps[k]->GetLeafSize());
+      }
+      else DevMaps[k] = nullptr;
       LocalMaps[k]->SetSubMapStorage([ctx, k](std::size_t n) { return lsa_target_staging(ctx, LSA_TARGET_MAP, k, static_cast<int>(n)); });
     }
   Reset();
@@ -106,6 +113,8 @@ SlamCore::SlamCore(int device)
 SlamCore::~SlamCore()
 {
   WaitMaps();
+  for (auto* g : DevMaps)
+    if (g) lsa_device_grid_destroy(g);
   if (Ctx) lsa_ctx_destroy(Ctx);
 }
 
@@ -132,6 +141,8 @@ void SlamCore::Reset(bool resetLog)
 {
   WaitMaps();
   for (int k = 0; k < 3; ++k) LocalMaps[k]->Reset();
+  for (auto* g : DevMaps)
+    if (g) lsa_device_grid_reset(g, nullptr);
   KfLastPose = Pose::Identity();
   KfCounter = 0;
   Tworld = PreviousTworld = Trelative = Pose::Identity();
@@ -633,6 +644,34 @@ int SlamCore::Localization()
     Stats.undistort += t.Stop();
   }
 
+  if (DeviceMapsInUse())
+  {
+    // Slam.cxx:1003-1037 with the maps on the device: a map whose last keyframe changed a point gives a new sub-map --
+    // the voxels the box of the current keypoints (at the initial pose guess) touches -- written straight into the
+    // target; only the box (read back once for all types) and the sub-maps' sizes cross the bus
+    Tick t;
+    bool need[3], any = false;
+    for (int k = 0; k < 3; ++k)
+    {
+      need[k] = UseKeypoints[k] && !lsa_device_grid_submap_valid(DevMaps[k]);
+      any = any || need[k];
+    }
+    float mn[9], mx[9];
+    if (any && MapUpdate != MappingMode::NONE) LSA_TRY(lsa_working_bboxes(Ctx, Tworld.m, mn, mx));
+    for (int k = 0; k < 3; ++k)
+    {
+      if (!need[k]) continue;
+      lsa_set_target_cell_size(Ctx, LSA_TARGET_MAP, k, static_cast<float>((k == LSA_EDGE ? KnnCellScaleMapsEdges : KnnCellScaleMaps) * LocalMaps[k]->GetLeafSize()));
+      if (MapUpdate == MappingMode::NONE) LSA_TRY(lsa_device_grid_build_submap(DevMaps[k], nullptr, nullptr, -1, LSA_TARGET_MAP, k));
+      else
+      {
+        if (LocalMaps[k]->IsTimeThreshold()) LSA_TRY(lsa_device_grid_clear_old_points(DevMaps[k], CurrentTime));
+        LSA_TRY(lsa_device_grid_build_submap(DevMaps[k], mn + 3 * k, mx + 3 * k, KeypointCounts[k] / 2, LSA_TARGET_MAP, k));
+      }
+    }
+    Stats.submap += t.Stop();
+  }
+  else
   {
     Tick t;
     if (SpecPending)
@@ -771,7 +810,7 @@ int SlamCore::Localization()
 int SlamCore::BeginSubMapSpeculation(const Pose& predicted)
 {
   SpecPending = false;
-  if (MapUpdate == MappingMode::NONE) return LSA_OK;
+  if (MapUpdate == MappingMode::NONE || DeviceMapsInUse()) return LSA_OK;  // device maps: the sub-map never leaves the device
   // Localization() will look at the keypoints after undistorting them with the motion between the previous pose
   // and the (then known) current one: the prediction does the same with the predicted pose -- the scan poses of
   // InterpolateScanPose at both ends of the keypoints' time range (Slam.cxx:1271-1285, 1288-1352).  Here Tworld
@@ -853,7 +892,7 @@ int SlamCore::EstimateOverlap()
   for (int k = 0; k < 3; ++k)
   {
     leaf[k] = LocalMaps[k]->GetLeafSize();
-    if (UseKeypoints[k] && LocalMaps[k]->IsSubMapValid()) mask |= 1u << k;
+    if (UseKeypoints[k] && (DeviceMapsInUse() ? lsa_target_size(Ctx, LSA_TARGET_MAP, k) > 0 : LocalMaps[k]->IsSubMapValid())) mask |= 1u << k;
   }
   if (!CurrentFrames.empty())
   {
@@ -891,13 +930,22 @@ int SlamCore::UpdateMapsUsingTworld()
   WaitMaps();
   const double thresholdCoef = std::min(KfCounter / MIN_KF_NB, 1.);
   unsigned nbMapKpts = 0;
-  for (int k = 0; k < 3; ++k) nbMapKpts += LocalMaps[k]->Size();
+  const bool onDevice = DeviceMapsInUse();
+  for (int k = 0; k < 3; ++k) nbMapKpts += onDevice ? static_cast<unsigned>(std::max(lsa_device_grid_size(DevMaps[k]), 0)) : LocalMaps[k]->Size();
   const bool isNewKeyFrame = nbMapKpts < MinNbMatchedKeypoints * 10 || trans >= thresholdCoef * KfDistanceThreshold ||
                              rot >= (thresholdCoef * KfAngleThreshold) / 180. * M_PI;
   if (!isNewKeyFrame) return LSA_OK;
   KfCounter++;
   KfLastPose = Tworld;
   for (double& v : MapJobSeconds) v = 0.;
+  if (onDevice)
+  {
+    // the keyframe's keypoints go into the device maps as they are (WORLD transform, keying, sort, fold, merge: kernels on
+    // the context's stream, nothing is waited for)
+    for (int k = 0; k < 3; ++k)
+      if (UseKeypoints[k]) LSA_TRY(lsa_device_grid_add_keypoints(DevMaps[k], LSA_SET_WORKING, k, Tworld.m, CurrentTime));
+    return LSA_OK;
+  }
   // the device writes the world keypoints into pinned host memory; the map workers wait for exactly that and
   // insert them while this thread goes on with the next frame
   LSA_TRY(lsa_stage_transformed(Ctx, LSA_SET_WORKING, Tworld.m));
@@ -1024,6 +1072,38 @@ int SlamCore::RefineUndistortion()
   return LSA_OK;
 }
 
+// Slam::GetMap / GetTargetSubMap (Slam.h:155-158)
+int SlamCore::GetMap(int k, bool clean, std::vector<lsa_point_t>& out)
+{
+  if (!Ctx) return LSA_E_NO_DEVICE;
+  if (DeviceMapsInUse())
+  {
+    const int size = std::max(lsa_device_grid_size(DevMaps[k]), 0);
+    out.resize(size);
+    const int n = size > 0 ? lsa_device_grid_get(DevMaps[k], clean ? 1 : 0, out.data(), size) : 0;
+    if (n < 0) return Fail(n, "lsa_device_grid_get");
+    out.resize(n);
+    return n;
+  }
+  out = Map(k).Get(clean);
+  return static_cast<int>(out.size());
+}
+
+int SlamCore::GetTargetSubMap(int k, std::vector<lsa_point_t>& out)
+{
+  if (!Ctx) return LSA_E_NO_DEVICE;
+  if (DeviceMapsInUse())
+  {
+    const int size = std::max(lsa_target_size(Ctx, LSA_TARGET_MAP, k), 0);
+    out.resize(size);
+    if (size > 0) LSA_TRY(lsa_download_target(Ctx, LSA_TARGET_MAP, k, out.data(), size));
+    return size;
+  }
+  const RollingGrid& map = Map(k);
+  out.assign(map.SubMapData(), map.SubMapData() + map.SubMapSize());
+  return static_cast<int>(out.size());
+}
+
 int SlamCore::GetKeypoints(int type, bool world, std::vector<lsa_point_t>& out)
 {
   if (!Ctx) return LSA_E_NO_DEVICE;
@@ -1102,6 +1182,7 @@ int SlamCore::GetRegisteredFrame(std::vector<lsa_point_t>& out)
   X("TwoDMode", TwoDMode, bool)                                                                        \
   X("BuildTargetsAhead", BuildTargetsAhead, bool)                                                      \
   X("DeviceLM", DeviceLM, bool)                                                                        \
+  X("MapsOnDevice", MapsOnDevice, bool)                                                                \
   X("FusedMatch", FusedMatch, bool)                                                                    \
   X("EgoMotionICPMaxIter", EgoMotionICPMaxIter, unsigned)                                              \
   X("LocalizationICPMaxIter", LocalizationICPMaxIter, unsigned)                                        \
@@ -1151,9 +1232,46 @@ int SlamCore::GetRegisteredFrame(std::vector<lsa_point_t>& out)
   X("EdgeSaliencyThreshold", ExtractParams.edge_saliency_threshold, float)                             \
   X("EdgeIntensityGapThreshold", ExtractParams.edge_intensity_gap_threshold, float)
 
+// The maps live either in the device grids or in the host grids (CENTROID sampling, "MapsOnDevice" = 0): a setter that
+// moves them from one side to the other takes the points along, the way RollingGrid's own geometry setters do
+// (prevMap = Get(); Clear(); Add(prevMap), RollingGrid.cxx:59-88: counts start again, the points keep their place).
+int SlamCore::MigrateMaps(bool fromDevice)
+{
+  for (int k = 0; k < 3; ++k)
+  {
+    if (!DevMaps[k]) continue;
+    if (fromDevice)
+    {
+      const int size = std::max(lsa_device_grid_size(DevMaps[k]), 0);
+      std::vector<lsa_point_t> pts(static_cast<size_t>(size));
+      const int n = size > 0 ? lsa_device_grid_get(DevMaps[k], 0, pts.data(), size) : 0;
+      if (n < 0) return Fail(n, "lsa_device_grid_get");
+      LocalMaps[k]->Clear();
+      LocalMaps[k]->Add(pts.data(), static_cast<size_t>(n), false, CurrentTime);
+      LSA_TRY(lsa_device_grid_clear(DevMaps[k]));
+    }
+    else
+    {
+      const RollingGrid::PointCloud pts = LocalMaps[k]->Get();
+      LSA_TRY(lsa_device_grid_clear(DevMaps[k]));
+      if (!pts.empty()) LSA_TRY(lsa_device_grid_add(DevMaps[k], pts.data(), static_cast<int>(pts.size()), 0, CurrentTime, 1));
+      LocalMaps[k]->Clear();
+    }
+  }
+  return LSA_OK;
+}
+
 int SlamCore::SetParam(const std::string& name, double v)
 {
   WaitMaps();
+  const bool onDevice = DeviceMapsInUse();
+  const int rc = SetParamValue(name, v);
+  if (rc == LSA_OK && DeviceMapsInUse() != onDevice) return MigrateMaps(onDevice);
+  return rc;
+}
+
+int SlamCore::SetParamValue(const std::string& name, double v)
+{
 #define X(NAME, MEMBER, TYPE) if (name == NAME) { MEMBER = static_cast<TYPE>(v); return LSA_OK; }
   LSA_PARAMS(X)
 #undef X
@@ -1178,14 +1296,16 @@ int SlamCore::SetParam(const std::string& name, double v)
   if (name == "AccelerationLimitLinear") { AccelerationLimits[0] = static_cast<float>(v); return LSA_OK; }
   if (name == "AccelerationLimitAngular") { AccelerationLimits[1] = static_cast<float>(v); return LSA_OK; }
   if (name == "AzimuthalResolution") { if (Ctx) lsa_set_azimuthal_resolution(Ctx, static_cast<float>(v)); return LSA_OK; }
-  if (name == "VoxelGridLeafSizeEdges") { LocalMaps[LSA_EDGE]->SetLeafSize(v); return LSA_OK; }
-  if (name == "VoxelGridLeafSizePlanes") { LocalMaps[LSA_PLANE]->SetLeafSize(v); return LSA_OK; }
-  if (name == "VoxelGridLeafSizeBlobs") { LocalMaps[LSA_BLOB]->SetLeafSize(v); return LSA_OK; }
-  if (name == "VoxelGridSize") { for (auto& m : LocalMaps) m->SetGridSize(static_cast<int>(v)); return LSA_OK; }
-  if (name == "VoxelGridResolution") { for (auto& m : LocalMaps) m->SetVoxelResolution(v); return LSA_OK; }
-  if (name == "VoxelGridMinFramesPerVoxel") { for (auto& m : LocalMaps) m->SetMinFramesPerVoxel(static_cast<unsigned>(v)); return LSA_OK; }
-  if (name == "VoxelGridDecayingThreshold") { for (auto& m : LocalMaps) m->SetDecayingThreshold(v); return LSA_OK; }
-  if (name == "VoxelGridSamplingMode") { for (auto& m : LocalMaps) m->SetSampling(static_cast<SamplingMode>(static_cast<int>(v))); return LSA_OK; }
+  auto dev = [&](int k, const char* what, double value) { if (DevMaps[k]) lsa_device_grid_set(DevMaps[k], what, value); };
+  if (name == "VoxelGridLeafSizeEdges") { LocalMaps[LSA_EDGE]->SetLeafSize(v); dev(LSA_EDGE, "LeafSize", v); return LSA_OK; }
+  if (name == "VoxelGridLeafSizePlanes") { LocalMaps[LSA_PLANE]->SetLeafSize(v); dev(LSA_PLANE, "LeafSize", v); return LSA_OK; }
+  if (name == "VoxelGridLeafSizeBlobs") { LocalMaps[LSA_BLOB]->SetLeafSize(v); dev(LSA_BLOB, "LeafSize", v); return LSA_OK; }
+  if (name == "VoxelGridSize") { for (int k = 0; k < 3; ++k) { LocalMaps[k]->SetGridSize(static_cast<int>(v)); dev(k, "GridSize", v); } return LSA_OK; }
+  if (name == "VoxelGridResolution") { for (int k = 0; k < 3; ++k) { LocalMaps[k]->SetVoxelResolution(v); dev(k, "VoxelResolution", v); } return LSA_OK; }
+  if (name == "VoxelGridMinFramesPerVoxel") { for (int k = 0; k < 3; ++k) { LocalMaps[k]->SetMinFramesPerVoxel(static_cast<unsigned>(v)); dev(k, "MinFramesPerVoxel", v); } return LSA_OK; }
+  if (name == "VoxelGridDecayingThreshold") { for (int k = 0; k < 3; ++k) { LocalMaps[k]->SetDecayingThreshold(v); dev(k, "DecayingThreshold", v); } return LSA_OK; }
+  if (name == "VoxelGridSamplingMode") { for (int k = 0; k < 3; ++k) { LocalMaps[k]->SetSampling(static_cast<SamplingMode>(static_cast<int>(v))); dev(k, "Sampling", v); } return LSA_OK; }
+  if (name == "OrderedMaps") { OrderedMaps = v != 0; for (auto& m : LocalMaps) m->SetOrdered(OrderedMaps); return LSA_OK; }
   LastError = "unknown parameter " + name;
   return LSA_E_ARG;
 }
@@ -1214,6 +1334,8 @@ int SlamCore::GetParam(const std::string& name, double* v) const
   if (name == "OverlapEstimation") { *v = OverlapEstimation; return LSA_OK; }
   if (name == "SubMapSpeculationHits") { *v = SubMapSpecHitsTotal; return LSA_OK; }
   if (name == "LookaheadAdopted") { *v = Ctx ? lsa_extract_prefetch_adopted(Ctx) : 0; return LSA_OK; }
+  if (name == "OrderedMaps") { *v = OrderedMaps ? 1. : 0.; return LSA_OK; }
+  if (name == "DeviceMapsInUse") { *v = DeviceMapsInUse() ? 1. : 0.; return LSA_OK; }
   if (name == "UploadsAdopted") { *v = Ctx ? lsa_uploads_adopted(Ctx) : 0; return LSA_OK; }
   if (name == "DeviceSolveFallbacks") { *v = Ctx ? lsa_solve_device_fallbacks(Ctx) : 0; return LSA_OK; }
   if (name == "TargetsBuiltAheadAdopted") { *v = Ctx ? lsa_prepared_targets_adopted(Ctx) : 0; return LSA_OK; }

@@ -99,6 +99,8 @@ public:
   {
     WaitMaps();
     for (auto& m : LocalMaps) m->Reset();
+    for (auto* g : DevMaps)
+      if (g) lsa_device_grid_reset(g, nullptr);
   }
   void HintNextStoredFrame(int slot) { NextStoredSlot = slot; }
   // Replay from host clouds: the cloud of the AddFrame call after the next one.  Its upload starts at once (pinned
@@ -202,6 +204,18 @@ public:
   bool KeepMatchDebug = false;  // download MatchingResults::Rejections/Weights every frame (Slam::GetDebugArray)
 
   std::shared_ptr<RollingGrid> LocalMaps[3];
+  // The same three maps resident on the device (lsa_device_grid: SURVEY.md 8f-1).  "MapsOnDevice" (default): keyframes
+  // are inserted and sub-maps extracted without leaving the device -- no staging of the keypoints in host memory, no map
+  // threads, no sub-map upload.  Off, or with CENTROID sampling (kept on the host): the host containers above.  Both
+  // hand their points out in key order ("OrderedMaps"), so the two give the same sub-maps and the same poses.
+  lsa_device_grid* DevMaps[3] = {nullptr, nullptr, nullptr};
+  bool MapsOnDevice = true;
+  bool OrderedMaps = true;
+  bool DeviceMapsInUse() const { return MapsOnDevice && DevMaps[0] && LocalMaps[0]->GetSampling() != SamplingMode::CENTROID; }
+  int MigrateMaps(bool fromDevice);
+  int SetParamValue(const std::string& name, double v);
+  int GetMap(int k, bool clean, std::vector<lsa_point_t>& out);
+  int GetTargetSubMap(int k, std::vector<lsa_point_t>& out);
 
   // ---- state ----
   Pose Tworld, PreviousTworld, Trelative;

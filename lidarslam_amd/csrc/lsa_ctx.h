@@ -287,6 +287,7 @@ namespace lsa
   } while (0)
 
 int lm_cache_capacity();
+int transform_points_to(lsa_ctx* ctx, const lsa_point_t* src, int n, const double pose[16], lsa_point_t* dst);  // lsa_transform.hip
 int time_from_advancement(lsa_ctx* ctx, lsa_point_t* frame, int n, double rpm, int first_packet);  // lsa_extract.hip
 int ensure_capacity(lsa_ctx* ctx, int n);
 int ensure_target(lsa_ctx* ctx, int ti, int m);

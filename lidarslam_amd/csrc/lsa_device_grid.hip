@@ -1,0 +1,982 @@
+// lsa_device_grid.hip -- LidarSlam::RollingGrid (slam_lib/include/LidarSlam/RollingGrid.h:63-212,
+// slam_lib/src/RollingGrid.cxx) resident on the device: voxel insertion with the sampling modes, rolling,
+// decay, bounding-box sub-map extraction straight into a kNN target.  SURVEY.md 8f-1.
+//
+// The reference keeps the map as unordered_map<outer voxel, unordered_map<leaf voxel, Voxel>>.  Here the map is ONE
+// array of voxels sorted by the 64-bit key (outer index << 32 | leaf index) -- keys, points and counts in three
+// parallel arrays, double-buffered:
+//   Add      the batch is keyed and sorted by (key, arrival order) (radix sort: rocPRIM); one thread per distinct key
+//            finds the voxel by binary search and folds the batch's points for it IN ARRIVAL ORDER through the
+//            reference's per-point rule (FIRST / LAST / MAX_INTENSITY / CENTER_POINT, fixed points, one count per Add
+//            call), exactly what the sequential loop of RollingGrid.cxx:183-312 does to that voxel; new voxels are
+//            merged in by rank (two binary searches, one scatter) -- no hash table, no atomics on voxels
+//   Roll     a shift of the outer coordinates keeps the key order: transform + stable compaction
+//   decay    ClearOldPoints: stable compaction
+//   sub-map  voxels whose outer index lies in the box, stable compaction straight into the target's point buffer
+// Iteration order.  The reference's Get / BuildSubMapKdTree hand the points out in libstdc++'s hash iteration order,
+// an accident of the container; the device map hands them out in KEY ORDER (outer index, then leaf index as
+// unsigned), and so do the oracle and the host RollingGrid when "OrderedMaps" is set (the default): a defined order
+// in place of an accidental one, documented with the other deviations in DESIGN.md 4.3.
+// Nothing here waits for the device except the calls that return a size or points to the host.
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <string.h>
+#include <rocprim/rocprim.hpp>
+#include "lsa_ctx.h"
+#include "lsa_device_math.h"
+
+using namespace lsa;
+
+namespace
+{
+typedef unsigned long long u64;
+constexpr u64 kNoKey = ~0ull;  // points outside the grid: sorted behind every voxel
+
+struct GridParams
+{
+  int grid_size;
+  float resolution;   // (float)VoxelResolution
+  double resolution_d;
+  float leaf;         // (float)LeafSize
+  double leaf_d;
+  int sampling;
+  unsigned min_frames;
+};
+// state the kernels read and write (device memory, kStInts ints)
+enum { kStN = 0, kStNbPoints = 1, kStUpdated = 2, kStPosX = 3, kStGroups = 6, kStNew = 7, kStOff = 8, kStSub = 11, kStTmp = 12 /* 6 ints */, kStSubFirst = 18, kStCompact = 19, kStInts = 32 };
+
+__device__ __forceinline__ int round_to_int(float v)
+{
+  // Eigen's .round().cast<int>(): round half away from zero, then a C cast (out of range: INT_MIN, as on x86-64)
+  const float r = roundf(v);
+  return (r >= -2147483648.f && r < 2147483648.f) ? (int)r : (int)0x80000000;
+}
+
+// ---- stable compaction: chunk counts -> exclusive scan -> scatter (the predicate is evaluated twice) --------------------
+template <typename Pred>
+__global__ __launch_bounds__(256) void k_compact_count(Pred pred, const int* __restrict__ n_ptr, int n_fixed, int* __restrict__ chunk_count)
+{
+  __shared__ int cnt[4];
+  const int n = n_ptr ? *n_ptr : n_fixed;
+  if (blockIdx.x * 1024 >= n) { if (threadIdx.x == 0) chunk_count[blockIdx.x] = 0; return; }
+  int mine = 0;
+  for (int q = 0; q < 4; ++q)
+  {
+    const int i = blockIdx.x * 1024 + q * 256 + threadIdx.x;
+    if (i < n && pred(i)) ++mine;
+  }
+  for (int o = 32; o > 0; o >>= 1) mine += __shfl_down(mine, o);
+  if ((threadIdx.x & 63) == 0) cnt[threadIdx.x >> 6] = mine;
+  __syncthreads();
+  if (threadIdx.x == 0) chunk_count[blockIdx.x] = cnt[0] + cnt[1] + cnt[2] + cnt[3];
+}
+__global__ __launch_bounds__(1024) void k_compact_scan(int* __restrict__ chunk_count, int nchunks, int* __restrict__ total, int add_to_total)
+{
+  __shared__ int s[1024];
+  int run = add_to_total ? *total : 0;
+  const int start = run;
+  for (int base = 0; base < nchunks; base += 1024)
+  {
+    const int i = base + threadIdx.x;
+    const int v = i < nchunks ? chunk_count[i] : 0;
+    s[threadIdx.x] = v;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1)
+    {
+      const int a = threadIdx.x >= (unsigned)o ? s[threadIdx.x - o] : 0;
+      __syncthreads();
+      s[threadIdx.x] += a;
+      __syncthreads();
+    }
+    if (i < nchunks) chunk_count[i] = run + s[threadIdx.x] - v;
+    run += s[1023];
+    __syncthreads();
+  }
+  (void)start;
+  if (threadIdx.x == 0) *total = run;
+}
+template <typename Pred, typename Emit>
+__global__ __launch_bounds__(256) void k_compact_scatter(Pred pred, Emit emit, const int* __restrict__ n_ptr, int n_fixed, const int* __restrict__ chunk_start)
+{
+  __shared__ int wave_cnt[4];
+  const int n = n_ptr ? *n_ptr : n_fixed;
+  if (blockIdx.x * 1024 >= n) return;
+  int run = chunk_start[blockIdx.x];
+  for (int q = 0; q < 4; ++q)
+  {
+    const int i = blockIdx.x * 1024 + q * 256 + threadIdx.x;
+    const bool keep = i < n && pred(i);
+    const u64 ballot = __ballot(keep);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) wave_cnt[wv] = __popcll(ballot);
+    __syncthreads();
+    int base = run;
+    for (int w = 0; w < wv; ++w) base += wave_cnt[w];
+    if (keep) emit(i, base + __popcll(ballot & ((1ull << lane) - 1ull)));
+    run += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+    __syncthreads();
+  }
+}
+
+struct MapView
+{
+  u64* keys;
+  float4* pts;      // two float4 per voxel point
+  unsigned* count;
+};
+
+// ---- Roll (RollingGrid.cxx:117-157) --------------------------------------------------------------------------------
+// bounding box of the batch: ordered-int atomics into st[kStTmp .. +5]
+__device__ __forceinline__ int f2o_i(float f) { const int i = __float_as_int(f); return i >= 0 ? i : i ^ 0x7fffffff; }
+__device__ __forceinline__ float o2f_i(int i) { return __int_as_float(i >= 0 ? i : i ^ 0x7fffffff); }
+__global__ __launch_bounds__(256) void k_batch_bbox(const float4* __restrict__ batch, int n, int* __restrict__ st)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+  if (i < n)
+  {
+    const float4 a = batch[2 * (size_t)i];
+    mn[0] = mx[0] = a.x; mn[1] = mx[1] = a.y; mn[2] = mx[2] = a.z;
+  }
+  for (int d = 0; d < 3; ++d)
+    for (int o = 32; o > 0; o >>= 1)
+    {
+      mn[d] = fminf(mn[d], __shfl_down(mn[d], o));
+      mx[d] = fmaxf(mx[d], __shfl_down(mx[d], o));
+    }
+  if ((threadIdx.x & 63) == 0)
+    for (int d = 0; d < 3; ++d)
+    {
+      atomicMin(&st[kStTmp + d], f2o_i(mn[d]));
+      atomicMax(&st[kStTmp + 3 + d], f2o_i(mx[d]));
+    }
+}
+// how many outer voxels the grid has to move so that the box fits (one thread); explicit box: roll_to != nullptr
+__global__ void k_roll_decide(GridParams p, int* __restrict__ st, int use_box)
+{
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const double halfGridSize = static_cast<double>(p.grid_size) / 2 * p.resolution_d;
+  const float h = (float)halfGridSize;
+  for (int d = 0; d < 3; ++d)
+  {
+    int off = 0;
+    if (use_box)
+    {
+      const float mnv = o2f_i(st[kStTmp + d]), mxv = o2f_i(st[kStTmp + 3 + d]);
+      const float pos = __int_as_float(st[kStPosX + d]);
+      const float down = mnv - (pos - h);
+      const float up = mxv - (pos + h);
+      float o = (up + down) / 2.f;
+      const float lo = fminf(down, 0.f), hi = fmaxf(up, 0.f);
+      o = fminf(fmaxf(o, lo), hi);
+      off = round_to_int(o / p.resolution);
+    }
+    st[kStOff + d] = off;
+    st[kStPosX + d] = __float_as_int(__int_as_float(st[kStPosX + d]) + (float)off * p.resolution);
+  }
+  // re-arm the box for the next batch
+  for (int d = 0; d < 3; ++d) { st[kStTmp + d] = 0x7fffffff; st[kStTmp + 3 + d] = (int)0x80000000; }
+}
+struct RollPred
+{
+  const u64* keys;
+  const int* st;
+  int grid_size;
+  __device__ bool shifted(int i, u64& out) const
+  {
+    const u64 k = keys[i];
+    int id = (int)(unsigned)(k >> 32);
+    const int g = grid_size;
+    int z = id / (g * g);
+    id -= z * g * g;
+    int y = id / g;
+    int x = id - y * g;
+    x -= st[kStOff + 0]; y -= st[kStOff + 1]; z -= st[kStOff + 2];
+    if (x < 0 || y < 0 || z < 0 || x >= g || y >= g || z >= g) return false;
+    out = ((u64)(unsigned)(z * g * g + y * g + x) << 32) | (k & 0xffffffffull);
+    return true;
+  }
+  __device__ bool operator()(int i) const { u64 o; return shifted(i, o); }
+};
+struct RollEmit
+{
+  RollPred pred;
+  MapView src, dst;
+  __device__ void operator()(int i, int at) const
+  {
+    u64 k;
+    pred.shifted(i, k);
+    dst.keys[at] = k;
+    dst.pts[2 * (size_t)at] = src.pts[2 * (size_t)i];
+    dst.pts[2 * (size_t)at + 1] = src.pts[2 * (size_t)i + 1];
+    dst.count[at] = src.count[i];
+  }
+};
+__global__ void k_after_roll(int* __restrict__ st)
+{
+  if (threadIdx.x == 0 && blockIdx.x == 0) st[kStNbPoints] = st[kStN];  // Roll recounts the points (RollingGrid.cxx:155)
+}
+
+// ---- Add (RollingGrid.cxx:160-318) ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_batch_keys(const float4* __restrict__ batch, int n, GridParams p, const int* __restrict__ st, u64* __restrict__ keys,
+                                                    unsigned* __restrict__ order)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float4 a = batch[2 * (size_t)i];
+  const float pt[3] = {a.x, a.y, a.z};
+  int out[3], in[3];
+  bool inside = true;
+  float center[3];
+  for (int d = 0; d < 3; ++d)
+  {
+    // voxelGridOrigin = VoxelGridPosition - int(GridSize / 2) * VoxelResolution (:177)
+    const float origin = __int_as_float(st[kStPosX + d]) - (float)((double)(p.grid_size / 2) * p.resolution_d);
+    out[d] = round_to_int((pt[d] - origin) / p.resolution);
+    inside = inside && out[d] >= 0 && out[d] < p.grid_size;
+    center[d] = (float)out[d] * p.resolution + origin;
+    in[d] = round_to_int((pt[d] - center[d]) / p.leaf);
+  }
+  const int g = p.grid_size;
+  const unsigned idx_out = (unsigned)(out[2] * g * g + out[1] * g + out[0]);
+  const unsigned idx_in = (unsigned)(in[2] * g * g + in[1] * g + in[0]);  // possibly "negative": the reference's own index (:200-202)
+  keys[i] = inside ? (((u64)idx_out << 32) | idx_in) : kNoKey;
+  order[i] = (unsigned)i;
+}
+struct HeadPred
+{
+  const u64* keys;
+  __device__ bool operator()(int j) const { return keys[j] != kNoKey && (j == 0 || keys[j] != keys[j - 1]); }
+};
+struct HeadEmit
+{
+  int* heads;
+  __device__ void operator()(int j, int at) const { heads[at] = j; }
+};
+__device__ __forceinline__ int lower_bound_u64(const u64* __restrict__ a, int n, u64 key)
+{
+  int lo = 0, hi = n;
+  while (lo < hi)
+  {
+    const int mid = (lo + hi) >> 1;
+    if (a[mid] < key) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+// One thread per distinct key of the batch: the voxel's state after the sequential loop has seen the batch's points
+// for it, in arrival order.  Existing voxels are updated in place; new ones go to the `fresh` arrays (key order).
+__global__ __launch_bounds__(128) void k_fold(const float4* __restrict__ batch, int nbatch, const u64* __restrict__ skeys, const unsigned* __restrict__ sorder,
+                                              const int* __restrict__ heads, GridParams p, int* __restrict__ st, MapView map, MapView fresh,
+                                              int* __restrict__ fresh_flag, int fixed, double time)
+{
+  const int gidx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int ngroups = st[kStGroups];
+  if (gidx >= ngroups) return;
+  const int j0 = heads[gidx];
+  const u64 key = skeys[j0];
+  const int n = st[kStN];
+  const int at = lower_bound_u64(map.keys, n, key);
+  const bool exists = at < n && map.keys[at] == key;
+  float4 va, vb;      // the voxel's point
+  unsigned count = 0;
+  bool have = exists;
+  bool changed = false;
+  if (exists) { va = map.pts[2 * (size_t)at]; vb = map.pts[2 * (size_t)at + 1]; count = map.count[at]; }
+  else { va = make_float4(0.f, 0.f, 0.f, 0.f); vb = va; }
+  // CENTER_POINT (:253): the centre is that of the leaf voxel of the point at hand, voxelGridCenterIn - VoxelResolution / 2.f
+  // + LeafSize * voxelCoordIn -- two leaf voxels of one outer voxel can share an inner index (To1d of coordinates around
+  // zero), so the points of one group do not all have the same centre
+  float base[3] = {0.f, 0.f, 0.f};  // voxelGridCenterIn: the same for the whole group
+  if (p.sampling == 3)
+  {
+    const int g = p.grid_size;
+    int id = (int)(unsigned)(key >> 32);
+    const int oz = id / (g * g); id -= oz * g * g;
+    const int oy = id / g; const int ox = id - oy * g;
+    const int out[3] = {ox, oy, oz};
+    for (int d = 0; d < 3; ++d)
+    {
+      const float origin = __int_as_float(st[kStPosX + d]) - (float)((double)(g / 2) * p.resolution_d);
+      base[d] = (float)out[d] * p.resolution + origin;
+    }
+  }
+  bool counted = false;
+  for (int j = j0; j < nbatch && skeys[j] == key; ++j)
+  {
+    const unsigned src = sorder[j];
+    const float4 a = batch[2 * (size_t)src], b = batch[2 * (size_t)src + 1];
+    if (!have)
+    {
+      va = a; vb = b; have = true; changed = true;  // new voxel: the point as it is (:206-212)
+    }
+    else
+    {
+      const unsigned label = (__float_as_uint(vb.w) >> 24) & 0xffu;
+      if (label == 1) continue;  // the voxel holds a fixed point: nothing of this point is taken, not even its time (:219-220)
+      if (p.sampling == 1) { va = a; vb = b; changed = true; }                       // LAST
+      else if (p.sampling == 2) { if (b.z > vb.z) { va = a; vb = b; changed = true; } }  // MAX_INTENSITY
+      else if (p.sampling == 3)
+      {
+        const float pt[3] = {a.x, a.y, a.z};
+        float centre[3];
+        for (int d = 0; d < 3; ++d) centre[d] = base[d] - p.resolution / 2.f + p.leaf * (float)round_to_int((pt[d] - base[d]) / p.leaf);
+        const float d1x = a.x - centre[0], d1y = a.y - centre[1], d1z = a.z - centre[2];
+        const float d0x = va.x - centre[0], d0y = va.y - centre[1], d0z = va.z - centre[2];
+        // Eigen's Vector3f norm: sqrt(x^2 + (y^2 + z^2))
+        if (sqrtf(d1x * d1x + (d1y * d1y + d1z * d1z)) < sqrtf(d0x * d0x + (d0y * d0y + d0z * d0z))) { va = a; vb = b; changed = true; }
+      }
+    }
+    // voxel.point.time = currentTime; label = fixed (:300-306); one count per Add call (:307-311)
+    const long long tb = __double_as_longlong(time);
+    vb.x = __int_as_float((int)(tb & 0xffffffffll));
+    vb.y = __int_as_float((int)(tb >> 32));
+    vb.w = __uint_as_float((__float_as_uint(vb.w) & 0x00ffffffu) | ((fixed ? 1u : 0u) << 24));
+    if (!counted) { ++count; counted = true; }
+  }
+  if (exists)
+  {
+    map.pts[2 * (size_t)at] = va;
+    map.pts[2 * (size_t)at + 1] = vb;
+    map.count[at] = count;
+    fresh_flag[gidx] = 0;
+  }
+  else
+  {
+    fresh.keys[gidx] = key;  // compacted to the new voxels' own array below
+    fresh.pts[2 * (size_t)gidx] = va;
+    fresh.pts[2 * (size_t)gidx + 1] = vb;
+    fresh.count[gidx] = count;
+    fresh_flag[gidx] = 1;
+  }
+  if (changed) st[kStUpdated] = 1;
+}
+struct FreshPred
+{
+  const int* flag;
+  __device__ bool operator()(int i) const { return flag[i] != 0; }
+};
+struct FreshEmit
+{
+  MapView src, dst;
+  __device__ void operator()(int i, int at) const
+  {
+    dst.keys[at] = src.keys[i];
+    dst.pts[2 * (size_t)at] = src.pts[2 * (size_t)i];
+    dst.pts[2 * (size_t)at + 1] = src.pts[2 * (size_t)i + 1];
+    dst.count[at] = src.count[i];
+  }
+};
+// merge by rank: a voxel's place is its index plus the number of voxels of the other array in front of it
+__global__ __launch_bounds__(256) void k_merge(MapView map, MapView fresh, MapView dst, const int* __restrict__ st, int capacity_hint)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n = st[kStN], m = st[kStNew];
+  (void)capacity_hint;
+  if (i < n)
+  {
+    const int at = i + lower_bound_u64(fresh.keys, m, map.keys[i]);
+    dst.keys[at] = map.keys[i];
+    dst.pts[2 * (size_t)at] = map.pts[2 * (size_t)i];
+    dst.pts[2 * (size_t)at + 1] = map.pts[2 * (size_t)i + 1];
+    dst.count[at] = map.count[i];
+  }
+  else if (i - n < m)
+  {
+    const int j = i - n;
+    const int at = j + lower_bound_u64(map.keys, n, fresh.keys[j]);
+    dst.keys[at] = fresh.keys[j];
+    dst.pts[2 * (size_t)at] = fresh.pts[2 * (size_t)j];
+    dst.pts[2 * (size_t)at + 1] = fresh.pts[2 * (size_t)j + 1];
+    dst.count[at] = fresh.count[j];
+  }
+}
+__global__ void k_after_merge(int* __restrict__ st)
+{
+  if (threadIdx.x == 0 && blockIdx.x == 0)
+  {
+    st[kStN] += st[kStNew];
+    st[kStNbPoints] += st[kStNew];
+  }
+}
+
+// ---- ClearOldPoints (RollingGrid.cxx:325-351) ----------------------------------------------------------------------
+struct DecayPred
+{
+  const float4* pts;
+  double now, threshold;
+  __device__ bool operator()(int i) const
+  {
+    const float4 b = pts[2 * (size_t)i + 1];
+    const unsigned label = (__float_as_uint(b.w) >> 24) & 0xffu;
+    const double t = __hiloint2double(__float_as_int(b.y), __float_as_int(b.x));
+    return !(!label && now - t > threshold);
+  }
+};
+struct CopyEmit
+{
+  MapView src, dst;
+  __device__ void operator()(int i, int at) const
+  {
+    dst.keys[at] = src.keys[i];
+    dst.pts[2 * (size_t)at] = src.pts[2 * (size_t)i];
+    dst.pts[2 * (size_t)at + 1] = src.pts[2 * (size_t)i + 1];
+    dst.count[at] = src.count[i];
+  }
+};
+
+// ---- Get / BuildSubMapKdTree (RollingGrid.cxx:95-114, 353-442) ---------------------------------------------------------
+struct SubMapPred
+{
+  const u64* keys;
+  const float4* pts;
+  const unsigned* count;
+  const int* st;
+  int lo[3], hi[3];
+  int grid_size;
+  int mode;          // 0 every voxel in the box; 1 count >= min_frames or fixed; 2 the others (count < min_frames and not fixed), only if pass 1 was short
+  unsigned min_frames;
+  int min_points;
+  int boxed;         // 0: the whole map (Get / BuildSubMapKdTree()), 3: count > min_frames (Get(clean))
+  __device__ bool operator()(int i) const
+  {
+    if (boxed == 0) return true;
+    if (boxed == 3) return count[i] > min_frames;
+    int id = (int)(unsigned)(keys[i] >> 32);
+    const int g = grid_size;
+    const int z = id / (g * g); id -= z * g * g;
+    const int y = id / g; const int x = id - y * g;
+    if (x < lo[0] || x > hi[0] || y < lo[1] || y > hi[1] || z < lo[2] || z > hi[2]) return false;
+    if (mode == 0) return true;
+    const unsigned label = (__float_as_uint(pts[2 * (size_t)i + 1].w) >> 24) & 0xffu;
+    if (mode == 1) return count[i] >= min_frames || label == 1;
+    return st[kStSubFirst] < min_points && count[i] < min_frames && label != 1;  // st[kStSubFirst]: what pass 1 kept
+  }
+};
+struct PointEmit
+{
+  const float4* pts;
+  float4* out;
+  __device__ void operator()(int i, int at) const
+  {
+    out[2 * (size_t)at] = pts[2 * (size_t)i];
+    out[2 * (size_t)at + 1] = pts[2 * (size_t)i + 1];
+  }
+};
+__global__ void k_set_int(int* __restrict__ p, int v) { if (threadIdx.x == 0 && blockIdx.x == 0) *p = v; }
+__global__ void k_copy_int(int* __restrict__ dst, const int* __restrict__ src) { if (threadIdx.x == 0 && blockIdx.x == 0) *dst = *src; }
+
+}  // namespace
+
+struct lsa_device_grid
+{
+  lsa_ctx* ctx = nullptr;
+  // parameters (RollingGrid.h:170-212)
+  int GridSize = 50;
+  double VoxelResolution = 10.;
+  double LeafSize = 0.2;
+  unsigned MinFramesPerVoxel = 0;
+  int Sampling = 2;  // MAX_INTENSITY
+  double DecayingThreshold = -1.;
+  // the map
+  MapView buf[2] = {};
+  int cur = 0;
+  int cap = 0;
+  int n_upper = 0;  // upper bound of the number of voxels (what has been added so far)
+  int* st = nullptr;           // device state (16 ints)
+  int* host_st = nullptr;      // pinned copy of it, refreshed behind every modification
+  hipEvent_t ev_state = nullptr;
+  bool submap_valid = false;
+  int submap_count = 0;
+  // batch scratch
+  int bcap = 0;
+  float4* batch = nullptr;
+  u64 *bkeys = nullptr, *skeys = nullptr;
+  unsigned *border = nullptr, *sorder = nullptr;
+  int *heads = nullptr, *fresh_flag = nullptr, *chunks = nullptr;
+  MapView fresh = {}, fresh2 = {};
+  void* sort_tmp = nullptr;
+  size_t sort_tmp_bytes = 0;
+  int chunk_cap = 0;
+};
+
+namespace
+{
+#define G_HIP(call)                                                                                    \
+  do                                                                                                   \
+  {                                                                                                    \
+    hipError_t e__ = (call);                                                                           \
+    if (e__ != hipSuccess) return g->ctx->fail(LSA_E_HIP, std::string(#call) + ": " + hipGetErrorString(e__)); \
+  } while (0)
+
+GridParams params_of(const lsa_device_grid* g)
+{
+  GridParams p;
+  p.grid_size = g->GridSize;
+  p.resolution = (float)g->VoxelResolution;
+  p.resolution_d = g->VoxelResolution;
+  p.leaf = (float)g->LeafSize;
+  p.leaf_d = g->LeafSize;
+  p.sampling = g->Sampling;
+  p.min_frames = g->MinFramesPerVoxel;
+  return p;
+}
+
+int alloc_view(lsa_device_grid* g, MapView& v, int cap)
+{
+  G_HIP(hipMalloc((void**)&v.keys, (size_t)cap * sizeof(u64)));
+  G_HIP(hipMalloc((void**)&v.pts, (size_t)cap * 2 * sizeof(float4)));
+  G_HIP(hipMalloc((void**)&v.count, (size_t)cap * sizeof(unsigned)));
+  return LSA_OK;
+}
+void free_view(MapView& v)
+{
+  if (v.keys) (void)hipFree(v.keys);
+  if (v.pts) (void)hipFree(v.pts);
+  if (v.count) (void)hipFree(v.count);
+  v = MapView{};
+}
+
+// room for `want` voxels in both buffers of the map (contents kept) and for the chunk counters of a compaction over them
+int ensure_map(lsa_device_grid* g, int want)
+{
+  if (want > g->cap)
+  {
+    const int cap = std::max(2 * want, 1 << 16);
+    G_HIP(hipStreamSynchronize(g->ctx->stream));
+    MapView nb[2];
+    for (int b = 0; b < 2; ++b)
+    {
+      int rc = alloc_view(g, nb[b], cap);
+      if (rc) return rc;
+    }
+    if (g->cap > 0)
+    {
+      const MapView& o = g->buf[g->cur];
+      G_HIP(hipMemcpy(nb[0].keys, o.keys, (size_t)g->cap * sizeof(u64), hipMemcpyDeviceToDevice));
+      G_HIP(hipMemcpy(nb[0].pts, o.pts, (size_t)g->cap * 2 * sizeof(float4), hipMemcpyDeviceToDevice));
+      G_HIP(hipMemcpy(nb[0].count, o.count, (size_t)g->cap * sizeof(unsigned), hipMemcpyDeviceToDevice));
+      free_view(g->buf[0]);
+      free_view(g->buf[1]);
+    }
+    g->buf[0] = nb[0];
+    g->buf[1] = nb[1];
+    g->cur = 0;
+    g->cap = cap;
+  }
+  const int nchunks = (std::max(g->cap, g->bcap) + 1023) / 1024 + 1;
+  if (nchunks > g->chunk_cap)
+  {
+    G_HIP(hipStreamSynchronize(g->ctx->stream));
+    if (g->chunks) (void)hipFree(g->chunks);
+    G_HIP(hipMalloc((void**)&g->chunks, (size_t)nchunks * sizeof(int)));
+    g->chunk_cap = nchunks;
+  }
+  return LSA_OK;
+}
+
+int ensure_batch(lsa_device_grid* g, int n)
+{
+  if (n <= g->bcap) return LSA_OK;
+  const int cap = std::max(n + n / 4, 1 << 14);
+  G_HIP(hipStreamSynchronize(g->ctx->stream));
+  auto fr = [](void* p) { if (p) (void)hipFree(p); };
+  fr(g->batch); fr(g->bkeys); fr(g->skeys); fr(g->border); fr(g->sorder); fr(g->heads); fr(g->fresh_flag); fr(g->sort_tmp);
+  free_view(g->fresh);
+  free_view(g->fresh2);
+  G_HIP(hipMalloc((void**)&g->batch, (size_t)cap * 2 * sizeof(float4)));
+  G_HIP(hipMalloc((void**)&g->bkeys, (size_t)cap * sizeof(u64)));
+  G_HIP(hipMalloc((void**)&g->skeys, (size_t)cap * sizeof(u64)));
+  G_HIP(hipMalloc((void**)&g->border, (size_t)cap * sizeof(unsigned)));
+  G_HIP(hipMalloc((void**)&g->sorder, (size_t)cap * sizeof(unsigned)));
+  G_HIP(hipMalloc((void**)&g->heads, (size_t)cap * sizeof(int)));
+  G_HIP(hipMalloc((void**)&g->fresh_flag, (size_t)cap * sizeof(int)));
+  int rc = alloc_view(g, g->fresh, cap);
+  if (rc) return rc;
+  rc = alloc_view(g, g->fresh2, cap);
+  if (rc) return rc;
+  size_t bytes = 0;
+  if (rocprim::radix_sort_pairs((void*)nullptr, bytes, g->bkeys, g->skeys, g->border, g->sorder, (size_t)cap, 0, 64, g->ctx->stream) != hipSuccess)
+    return g->ctx->fail(LSA_E_HIP, "lsa_device_grid: radix sort sizing failed");
+  G_HIP(hipMalloc(&g->sort_tmp, bytes + 256));
+  g->sort_tmp_bytes = bytes + 256;
+  g->bcap = cap;
+  return LSA_OK;
+}
+
+// stable compaction of [0, n) (n on the device when n_ptr is given) by pred, emit(i, position); the number kept lands in
+// *total (added to what is there when `append`)
+template <typename Pred, typename Emit>
+void compact(lsa_device_grid* g, Pred pred, Emit emit, const int* n_ptr, int n_bound, int* total, bool append = false)
+{
+  hipStream_t st = g->ctx->stream;
+  const int nchunks = std::max((n_bound + 1023) / 1024, 1);
+  hipLaunchKernelGGL((k_compact_count<Pred>), dim3(nchunks), dim3(256), 0, st, pred, n_ptr, n_bound, g->chunks);
+  // compacting in place of the count it reads (Roll, ClearOldPoints): the scatter still needs the old count, the new one
+  // waits in a slot of its own until it is through
+  int* const sum = (n_ptr == total) ? g->st + kStCompact : total;
+  hipLaunchKernelGGL(k_compact_scan, dim3(1), dim3(1024), 0, st, g->chunks, nchunks, sum, append ? 1 : 0);
+  hipLaunchKernelGGL((k_compact_scatter<Pred, Emit>), dim3(nchunks), dim3(256), 0, st, pred, emit, n_ptr, n_bound, g->chunks);
+  if (sum != total) hipLaunchKernelGGL(k_copy_int, dim3(1), dim3(64), 0, st, total, sum);
+}
+
+// the host's copy of the state follows every modification (asynchronously)
+int refresh_state(lsa_device_grid* g)
+{
+  G_HIP(hipMemcpyAsync(g->host_st, g->st, kStInts * sizeof(int), hipMemcpyDeviceToHost, g->ctx->stream));
+  G_HIP(hipEventRecord(g->ev_state, g->ctx->stream));
+  return LSA_OK;
+}
+
+// Roll (always a pass into the other buffer: the host does not know whether the grid moves)
+int roll(lsa_device_grid* g, bool use_box)
+{
+  hipStream_t st = g->ctx->stream;
+  const GridParams p = params_of(g);
+  hipLaunchKernelGGL(k_roll_decide, dim3(1), dim3(64), 0, st, p, g->st, use_box ? 1 : 0);
+  const MapView src = g->buf[g->cur], dst = g->buf[1 - g->cur];
+  RollPred pred{src.keys, g->st, g->GridSize};
+  RollEmit emit{pred, src, dst};
+  compact(g, pred, emit, g->st + kStN, std::max(g->n_upper, 1), g->st + kStN);
+  hipLaunchKernelGGL(k_after_roll, dim3(1), dim3(64), 0, st, g->st);
+  g->cur = 1 - g->cur;
+  return LSA_OK;
+}
+
+// Add of the n points in g->batch (device)
+int add_batch(lsa_device_grid* g, int n, bool fixed, double time, bool do_roll)
+{
+  hipStream_t st = g->ctx->stream;
+  int rc = ensure_map(g, g->n_upper + n);
+  if (rc) return rc;
+  const GridParams p = params_of(g);
+  ProfScope ps(g->ctx, "map_add", (double)n * (32 + 12 + 44) + (double)g->n_upper * 44 * (do_roll ? 2 : 1));
+  if (do_roll)
+  {
+    hipLaunchKernelGGL(k_batch_bbox, dim3((n + 255) / 256), dim3(256), 0, st, g->batch, n, g->st);
+    rc = roll(g, true);
+    if (rc) return rc;
+  }
+  hipLaunchKernelGGL(k_batch_keys, dim3((n + 255) / 256), dim3(256), 0, st, g->batch, n, p, g->st, g->bkeys, g->border);
+  size_t bytes = g->sort_tmp_bytes;
+  if (rocprim::radix_sort_pairs(g->sort_tmp, bytes, g->bkeys, g->skeys, g->border, g->sorder, (size_t)n, 0, 64, st) != hipSuccess)
+    return g->ctx->fail(LSA_E_HIP, "lsa_device_grid: radix sort failed");
+  // one group per distinct key (points outside the grid are not grouped)
+  compact(g, HeadPred{g->skeys}, HeadEmit{g->heads}, nullptr, n, g->st + kStGroups);
+  const MapView map = g->buf[g->cur], dst = g->buf[1 - g->cur];
+  hipLaunchKernelGGL(k_fold, dim3((n + 127) / 128), dim3(128), 0, st, g->batch, n, g->skeys, g->sorder, g->heads, p, g->st, map, g->fresh, g->fresh_flag,
+                     fixed ? 1 : 0, time);
+  compact(g, FreshPred{g->fresh_flag}, FreshEmit{g->fresh, g->fresh2}, g->st + kStGroups, n, g->st + kStNew);
+  hipLaunchKernelGGL(k_merge, dim3((g->n_upper + n + 255) / 256), dim3(256), 0, st, map, g->fresh2, dst, g->st, 0);
+  hipLaunchKernelGGL(k_after_merge, dim3(1), dim3(64), 0, st, g->st);
+  g->cur = 1 - g->cur;
+  g->n_upper += n;
+  return refresh_state(g);  // whether a point changed (the kd-tree is only dropped then, :315-317) is read by lsa_device_grid_submap_valid
+}
+
+}  // namespace
+
+extern "C" {
+
+int lsa_device_grid_create(lsa_ctx* ctx, lsa_device_grid** out)
+{
+  if (!ctx || !out) return LSA_E_ARG;
+  *out = nullptr;
+  if (hipSetDevice(ctx->device) != hipSuccess) return LSA_E_HIP;
+  lsa_device_grid* g = new lsa_device_grid;
+  g->ctx = ctx;
+  bool ok = hipMalloc((void**)&g->st, kStInts * sizeof(int)) == hipSuccess;
+  ok = ok && hipHostMalloc((void**)&g->host_st, kStInts * sizeof(int), hipHostMallocDefault) == hipSuccess;
+  ok = ok && hipEventCreateWithFlags(&g->ev_state, hipEventDisableTiming) == hipSuccess;
+  if (!ok) { delete g; return LSA_E_HIP; }
+  *out = g;
+  return lsa_device_grid_reset(g, nullptr);
+}
+
+void lsa_device_grid_destroy(lsa_device_grid* g)
+{
+  if (!g) return;
+  (void)hipSetDevice(g->ctx->device);
+  (void)hipStreamSynchronize(g->ctx->stream);
+  free_view(g->buf[0]); free_view(g->buf[1]); free_view(g->fresh); free_view(g->fresh2);
+  auto fr = [](void* p) { if (p) (void)hipFree(p); };
+  fr(g->st); fr(g->batch); fr(g->bkeys); fr(g->skeys); fr(g->border); fr(g->sorder); fr(g->heads); fr(g->fresh_flag); fr(g->chunks); fr(g->sort_tmp);
+  if (g->host_st) (void)hipHostFree(g->host_st);
+  if (g->ev_state) (void)hipEventDestroy(g->ev_state);
+  delete g;
+}
+
+// RollingGrid::Reset (RollingGrid.cxx:40-48): the map is emptied, the grid is centred on `position` (snapped to the
+// voxel resolution)
+int lsa_device_grid_reset(lsa_device_grid* g, const float position[3])
+{
+  if (!g) return LSA_E_ARG;
+  G_HIP(hipSetDevice(g->ctx->device));
+  int h[kStInts] = {0};
+  const float r = (float)g->VoxelResolution;
+  for (int d = 0; d < 3; ++d)
+  {
+    const float v = std::floor((position ? position[d] : 0.f) / r) * r;
+    std::memcpy(&h[kStPosX + d], &v, sizeof(float));
+    h[kStTmp + d] = 0x7fffffff;
+    h[kStTmp + 3 + d] = (int)0x80000000;
+  }
+  G_HIP(hipStreamSynchronize(g->ctx->stream));
+  G_HIP(hipMemcpy(g->st, h, sizeof(h), hipMemcpyHostToDevice));
+  std::memcpy(g->host_st, h, sizeof(h));
+  g->n_upper = 0;
+  g->submap_valid = false;
+  return LSA_OK;
+}
+
+int lsa_device_grid_clear(lsa_device_grid* g)
+{
+  if (!g) return LSA_E_ARG;
+  G_HIP(hipSetDevice(g->ctx->device));
+  hipLaunchKernelGGL(k_set_int, dim3(1), dim3(64), 0, g->ctx->stream, g->st + kStN, 0);
+  hipLaunchKernelGGL(k_set_int, dim3(1), dim3(64), 0, g->ctx->stream, g->st + kStNbPoints, 0);
+  g->n_upper = 0;
+  g->submap_valid = false;
+  return refresh_state(g);
+}
+
+static int readd_everything(lsa_device_grid* g);
+
+int lsa_device_grid_set(lsa_device_grid* g, const char* name, double value)
+{
+  if (!g || !name) return LSA_E_ARG;
+  const std::string n(name);
+  if (n == "LeafSize") { g->LeafSize = value; return LSA_OK; }
+  if (n == "MinFramesPerVoxel") { g->MinFramesPerVoxel = (unsigned)value; return LSA_OK; }
+  if (n == "Sampling") { g->Sampling = (int)value; return LSA_OK; }
+  if (n == "DecayingThreshold") { g->DecayingThreshold = value; return LSA_OK; }
+  if (n == "GridSize")
+  {
+    // RollingGrid::SetGridSize (:59-70): the points are put back into the resized grid
+    g->GridSize = (int)value;
+    return readd_everything(g);
+  }
+  if (n == "VoxelResolution")
+  {
+    // RollingGrid::SetVoxelResolution (:73-88): a multiple of the leaf size; the grid position is snapped to it
+    g->VoxelResolution = int(value / g->LeafSize) * g->LeafSize;
+    G_HIP(hipSetDevice(g->ctx->device));
+    G_HIP(hipStreamSynchronize(g->ctx->stream));
+    int h[kStInts];
+    G_HIP(hipMemcpy(h, g->st, sizeof(h), hipMemcpyDeviceToHost));
+    const float r = (float)g->VoxelResolution;
+    for (int d = 0; d < 3; ++d)
+    {
+      float v;
+      std::memcpy(&v, &h[kStPosX + d], sizeof(float));
+      v = std::floor(v / r) * r;
+      std::memcpy(&h[kStPosX + d], &v, sizeof(float));
+    }
+    G_HIP(hipMemcpy(g->st, h, sizeof(h), hipMemcpyHostToDevice));
+    return readd_everything(g);
+  }
+  return g->ctx->fail(LSA_E_ARG, "lsa_device_grid_set: unknown parameter " + n);
+}
+
+double lsa_device_grid_get_param(const lsa_device_grid* g, const char* name)
+{
+  if (!g || !name) return 0.;
+  const std::string n(name);
+  if (n == "LeafSize") return g->LeafSize;
+  if (n == "MinFramesPerVoxel") return g->MinFramesPerVoxel;
+  if (n == "Sampling") return g->Sampling;
+  if (n == "DecayingThreshold") return g->DecayingThreshold;
+  if (n == "GridSize") return g->GridSize;
+  if (n == "VoxelResolution") return g->VoxelResolution;
+  return 0.;
+}
+
+// RollingGrid::Size() as of the last modification that has completed on the device (waits for it)
+int lsa_device_grid_size(lsa_device_grid* g)
+{
+  if (!g) return LSA_E_ARG;
+  if (hipSetDevice(g->ctx->device) != hipSuccess || hipEventSynchronize(g->ev_state) != hipSuccess) return LSA_E_HIP;
+  return g->host_st[kStNbPoints];
+}
+
+
+int lsa_device_grid_add(lsa_device_grid* g, const lsa_point_t* pts, int n, int fixed, double time, int roll_first)
+{
+  if (!g || n < 0 || (!pts && n > 0)) return g ? g->ctx->fail(LSA_E_ARG, "lsa_device_grid_add: bad argument") : LSA_E_ARG;
+  if (n == 0) return LSA_OK;  // "Pointcloud is empty, voxel grid not updated."
+  if (g->Sampling == 4) return g->ctx->fail(LSA_E_STATE, "lsa_device_grid_add: CENTROID sampling is kept on the host grid");
+  G_HIP(hipSetDevice(g->ctx->device));
+  int rc = ensure_batch(g, n);
+  if (rc) return rc;
+  G_HIP(hipMemcpyAsync(g->batch, pts, (size_t)n * sizeof(lsa_point_t), hipMemcpyHostToDevice, g->ctx->stream));
+  G_HIP(hipStreamSynchronize(g->ctx->stream));  // pts may be pageable and go away
+  return add_batch(g, n, fixed != 0, time, roll_first != 0);
+}
+
+// the keypoints of a device set, moved by `pose` (WORLD), added without leaving the device: Slam::UpdateMapsUsingTworld
+// (slam_lib/src/Slam.cxx:1178-1222)
+int lsa_device_grid_add_keypoints(lsa_device_grid* g, int set, int type, const double pose[16], double time)
+{
+  if (!g || !pose || set < 0 || set > 2 || type < 0 || type > 2) return g ? g->ctx->fail(LSA_E_ARG, "lsa_device_grid_add_keypoints: bad argument") : LSA_E_ARG;
+  if (g->Sampling == 4) return g->ctx->fail(LSA_E_STATE, "lsa_device_grid_add_keypoints: CENTROID sampling is kept on the host grid");
+  lsa_ctx* ctx = g->ctx;
+  const int n = ctx->kp_n[set][type];
+  if (n <= 0) return LSA_OK;
+  G_HIP(hipSetDevice(ctx->device));
+  int rc = ensure_batch(g, n);
+  if (rc) return rc;
+  rc = transform_points_to(ctx, ctx->kp[set][type], n, pose, reinterpret_cast<lsa_point_t*>(g->batch));
+  if (rc) return rc;
+  return add_batch(g, n, false, time, true);
+}
+
+int lsa_device_grid_roll(lsa_device_grid* g, const float mn[3], const float mx[3])
+{
+  if (!g || !mn || !mx) return LSA_E_ARG;
+  G_HIP(hipSetDevice(g->ctx->device));
+  int rc = ensure_map(g, std::max(g->n_upper, 1));
+  if (rc) return rc;
+  int box[6];
+  for (int d = 0; d < 3; ++d)
+  {
+    int a, b;
+    std::memcpy(&a, &mn[d], sizeof(int));
+    std::memcpy(&b, &mx[d], sizeof(int));
+    box[d] = a >= 0 ? a : a ^ 0x7fffffff;
+    box[3 + d] = b >= 0 ? b : b ^ 0x7fffffff;
+  }
+  G_HIP(hipMemcpyAsync(g->st + kStTmp, box, sizeof(box), hipMemcpyHostToDevice, g->ctx->stream));
+  G_HIP(hipStreamSynchronize(g->ctx->stream));
+  rc = roll(g, true);
+  if (rc) return rc;
+  return refresh_state(g);
+}
+
+int lsa_device_grid_clear_old_points(lsa_device_grid* g, double now)
+{
+  if (!g) return LSA_E_ARG;
+  G_HIP(hipSetDevice(g->ctx->device));
+  int rc = ensure_map(g, std::max(g->n_upper, 1));
+  if (rc) return rc;
+  const MapView src = g->buf[g->cur], dst = g->buf[1 - g->cur];
+  compact(g, DecayPred{src.pts, now, g->DecayingThreshold}, CopyEmit{src, dst}, g->st + kStN, std::max(g->n_upper, 1), g->st + kStN);
+  g->cur = 1 - g->cur;
+  return refresh_state(g);
+}
+
+// RollingGrid::Get(clean) (:95-114) in key order; returns the number of points written
+int lsa_device_grid_get(lsa_device_grid* g, int clean, lsa_point_t* out, int capacity)
+{
+  if (!g || (!out && capacity > 0)) return LSA_E_ARG;
+  lsa_ctx* ctx = g->ctx;
+  G_HIP(hipSetDevice(ctx->device));
+  if (g->n_upper == 0) return 0;
+  int rc = ensure_map(g, g->n_upper);
+  if (rc) return rc;
+  rc = ensure_scratch(ctx, (size_t)g->n_upper * sizeof(lsa_point_t));
+  if (rc) return rc;
+  const MapView m = g->buf[g->cur];
+  SubMapPred pred{m.keys, m.pts, m.count, g->st, {0, 0, 0}, {0, 0, 0}, g->GridSize, 0, g->MinFramesPerVoxel, -1, clean ? 3 : 0};
+  compact(g, pred, PointEmit{m.pts, reinterpret_cast<float4*>(ctx->scratch_out)}, g->st + kStN, g->n_upper, g->st + kStSub);
+  int kept = 0;
+  G_HIP(hipMemcpyAsync(&kept, g->st + kStSub, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  G_HIP(hipStreamSynchronize(ctx->stream));
+  const int n = std::min(kept, capacity);
+  if (n > 0) G_HIP(hipMemcpy(out, ctx->scratch_out, (size_t)n * sizeof(lsa_point_t), hipMemcpyDeviceToHost));
+  return n;
+}
+
+// RollingGrid::BuildSubMapKdTree (:353-442): the sub-map becomes the kNN target (slot, type) of the context without
+// leaving the device -- the points in key order, the search grid is built with the next match.  mn == NULL: the whole
+// map.  Returns the number of points of the sub-map.
+int lsa_device_grid_build_submap(lsa_device_grid* g, const float mn[3], const float mx[3], int min_nb_points, int slot, int type)
+{
+  if (!g || slot < 0 || slot > 1 || type < 0 || type > 2 || (mn && !mx)) return g ? g->ctx->fail(LSA_E_ARG, "lsa_device_grid_build_submap: bad argument") : LSA_E_ARG;
+  lsa_ctx* ctx = g->ctx;
+  G_HIP(hipSetDevice(ctx->device));
+  const int ti = slot * 3 + type;
+  Target& t = ctx->target[ti];
+  g->submap_valid = true;
+  if (g->n_upper == 0) { t.m = 0; g->submap_count = 0; (void)hipEventSynchronize(g->ev_state); g->host_st[kStUpdated] = 0; return 0; }
+  int rc = ensure_map(g, g->n_upper);
+  if (rc) return rc;
+  rc = ensure_target(ctx, ti, g->n_upper);
+  if (rc) return rc;
+  const MapView m = g->buf[g->cur];
+  SubMapPred pred{m.keys, m.pts, m.count, g->st, {0, 0, 0}, {0, 0, 0}, g->GridSize, 0, g->MinFramesPerVoxel, min_nb_points, mn ? 1 : 0};
+  bool filtered = false;
+  if (mn)
+  {
+    // the sub-grid the box touches (:365-370); PositionToVoxel on the host, with the grid position the device holds
+    G_HIP(hipEventSynchronize(g->ev_state));
+    for (int d = 0; d < 3; ++d)
+    {
+      float pos;
+      std::memcpy(&pos, &g->host_st[kStPosX + d], sizeof(float));
+      const float origin = pos - (float)(int(g->GridSize / 2) * g->VoxelResolution);
+      const float r = (float)g->VoxelResolution;
+      auto to_voxel = [&](float v) {
+        const float q = std::round((v - origin) / r);
+        return (q >= -2147483648.f && q < 2147483648.f) ? (int)q : std::numeric_limits<int>::min();
+      };
+      pred.lo[d] = std::max(to_voxel(mn[d]), 0);
+      pred.hi[d] = std::min(to_voxel(mx[d]), g->GridSize - 1);
+    }
+    filtered = !(min_nb_points < 0 || g->MinFramesPerVoxel <= 1);
+    pred.mode = filtered ? 1 : 0;
+  }
+  {
+    ProfScope ps(ctx, "map_submap", (double)g->n_upper * 44);
+    compact(g, pred, PointEmit{m.pts, reinterpret_cast<float4*>(t.pts)}, g->st + kStN, g->n_upper, g->st + kStSub);
+    if (filtered)
+    {
+      // "Moving objects constraint was too strong, removing constraint": the rejected voxels follow when too few stayed
+      pred.mode = 2;
+      // the second pass appends behind what the first one kept (its predicate reads the first pass's count from a slot
+      // of its own: the total moves while it runs)
+      hipLaunchKernelGGL(k_copy_int, dim3(1), dim3(64), 0, ctx->stream, g->st + kStSubFirst, g->st + kStSub);
+      compact(g, pred, PointEmit{m.pts, reinterpret_cast<float4*>(t.pts)}, g->st + kStN, g->n_upper, g->st + kStSub, true);
+    }
+  }
+  int kept = 0;
+  G_HIP(hipMemcpyAsync(&kept, g->st + kStSub, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  G_HIP(hipStreamSynchronize(ctx->stream));
+  t.m = kept;
+  t.dirty = kept > 0;
+  g->submap_count = kept;
+  // the sub-map is of the map as it is now: the changes the Adds before it flagged are in it
+  hipLaunchKernelGGL(k_set_int, dim3(1), dim3(64), 0, ctx->stream, g->st + kStUpdated, 0);
+  g->host_st[kStUpdated] = 0;  // every refresh enqueued before the synchronize above has landed
+  return kept;
+}
+
+// RollingGrid::IsSubMapKdTreeValid(): an Add that changed a voxel's point has dropped the sub-map (RollingGrid.cxx:315-317);
+// rolling and decay do not (as in the reference).  Waits for the modifications enqueued so far.
+int lsa_device_grid_submap_valid(lsa_device_grid* g)
+{
+  if (!g) return 0;
+  if (hipSetDevice(g->ctx->device) != hipSuccess || hipEventSynchronize(g->ev_state) != hipSuccess) return 0;
+  if (g->host_st[kStUpdated])
+  {
+    hipLaunchKernelGGL(k_set_int, dim3(1), dim3(64), 0, g->ctx->stream, g->st + kStUpdated, 0);
+    g->host_st[kStUpdated] = 0;
+    g->submap_valid = false;
+  }
+  return g->submap_valid && g->submap_count > 0 ? 1 : 0;  // an empty sub-map counts as invalid (RollingGrid.h:154)
+}
+
+static int readd_everything(lsa_device_grid* g)
+{
+  // prevMap = Get(); Clear(); Add(prevMap)
+  std::vector<lsa_point_t> all(std::max(g->n_upper, 1));
+  const int n = lsa_device_grid_get(g, 0, all.data(), (int)all.size());
+  if (n < 0) return n;
+  int rc = lsa_device_grid_clear(g);
+  if (rc) return rc;
+  if (n > 0) return lsa_device_grid_add(g, all.data(), n, 0, -1., 1);
+  return LSA_OK;
+}
+
+}  // extern "C"

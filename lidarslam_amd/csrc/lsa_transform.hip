@@ -511,6 +511,27 @@ int lsa_stage_transformed(lsa_ctx* ctx, int set, const double pose[16])
   ctx->stage_pending = true;
   return LSA_OK;
 }
+}  // extern "C"
+
+namespace lsa
+{
+// src (n points on the device) moved by `pose` into dst (device), on the context's stream
+int transform_points_to(lsa_ctx* ctx, const lsa_point_t* src, int n, const double pose[16], lsa_point_t* dst)
+{
+  if (n <= 0) return LSA_OK;
+  StageOut so{};
+  so.in[0] = reinterpret_cast<const float4*>(src);
+  so.out[0] = reinterpret_cast<float4*>(dst);
+  so.n[0] = n;
+  Rigid T;
+  row_major_to_rt(pose, T.R, T.t);
+  hipLaunchKernelGGL(k_transform_stage, dim3((n + 255) / 256, 1), dim3(256), 0, ctx->stream, so, T);
+  return LSA_OK;
+}
+}  // namespace lsa
+
+extern "C" {
+
 int lsa_staged_transformed(lsa_ctx* ctx, int type, const lsa_point_t** pts, int* n)
 {
   if (!ctx || type < 0 || type > 2 || !pts || !n) return LSA_E_ARG;

@@ -41,7 +41,7 @@ class PoseExchange:
         self.hosts = [torch.zeros(n, dtype=torch.float64) for _ in range(self.depth)]
         self.inflight = [None] * self.depth
         self.posted = 0
-        self.table = self.tables[0]  # the table of the last completed exchange
+        self.table = self.tables[0].clone()  # the table of the last completed exchange (its own copy, never a buffer in rotation)
         self.side = None
         if device == "cuda":
             self.hosts = [h.pin_memory() for h in self.hosts]
@@ -64,7 +64,7 @@ class PoseExchange:
         host, mine, table = self.hosts[slot], self.mine[slot], self.tables[slot]
         if self.world == 1 and not self.always_collective:
             table.copy_(rows)
-            self.table = table
+            self.table = table.clone()
             return None
         import torch.distributed as dist
 
@@ -105,7 +105,8 @@ class _Exchange:
         else:
             self.work.wait()
         self.work = None
-        self.owner.table = self.owner.tables[self.slot]
+        # a copy: the buffer set goes back into rotation and a later post may gather into it while the caller reads
+        self.owner.table = self.owner.tables[self.slot].clone()
         if self.owner.inflight[self.slot] is self:
             self.owner.inflight[self.slot] = None
 

@@ -406,6 +406,7 @@ int orc_slam_set_param(void* h, const char* name, double v)
   P("VoxelGridMinFramesPerVoxel", for (int k = 0; k < 3; ++k) s.LocalMaps[k]->SetMinFramesPerVoxel((unsigned)v))
   P("VoxelGridDecayingThreshold", for (int k = 0; k < 3; ++k) s.LocalMaps[k]->SetDecayingThreshold(v))
   P("VoxelGridSamplingMode", for (int k = 0; k < 3; ++k) s.LocalMaps[k]->SetSampling((SamplingMode)(int)v))
+  P("OrderedMaps", for (int k = 0; k < 3; ++k) s.LocalMaps[k]->SetOrdered(v != 0))
   P("NeighborWidth", s.KeyPointsExtractor.P.NeighborWidth = (int)v)
   P("MinDistanceToSensor", s.KeyPointsExtractor.P.MinDistanceToSensor = (float)v)
   P("MinBeamSurfaceAngle", s.KeyPointsExtractor.P.MinBeamSurfaceAngle = (float)v)
@@ -587,6 +588,7 @@ int orc_grid_set(void* h, const char* name, double v)
   else if (n == "LeafSize") g.SetLeafSize(v);
   else if (n == "MinFramesPerVoxel") g.SetMinFramesPerVoxel((unsigned)v);
   else if (n == "Sampling") g.SetSampling((SamplingMode)(int)v);
+  else if (n == "Ordered") g.SetOrdered(v != 0);
   else if (n == "DecayingThreshold") g.SetDecayingThreshold(v);
   else return -1;
   return 0;

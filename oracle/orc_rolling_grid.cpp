@@ -77,10 +77,9 @@ std::vector<Point> RollingGrid::Get(bool clean) const
 {
   std::vector<Point> pc;
   pc.reserve(NbPoints);
-  for (const auto& kvOut : Voxels)
-    for (const auto& kvIn : kvOut.second)
-      if (!clean || kvIn.second.count > MinFramesPerVoxel)
-        pc.push_back(kvIn.second.point);
+  ForEachVoxel([&](int, const Voxel& v) {
+    if (!clean || v.count > MinFramesPerVoxel) pc.push_back(v.point);
+  });
   return pc;
 }
 
@@ -283,24 +282,20 @@ void RollingGrid::BuildSubMapKdTree(const float minPoint[3], const float maxPoin
   SubMap.reserve(NbPoints);
   if (minNbPoints < 0 || MinFramesPerVoxel <= 1)
   {
-    for (const auto& kvOut : Voxels)
-      if (inside(kvOut.first))
-        for (const auto& kvIn : kvOut.second) SubMap.push_back(kvIn.second.point);
+    ForEachVoxel([&](int idxOut, const Voxel& v) {
+      if (inside(idxOut)) SubMap.push_back(v.point);
+    });
   }
   else
   {
-    for (const auto& kvOut : Voxels)
-      if (inside(kvOut.first))
-        for (const auto& kvIn : kvOut.second)
-          if (kvIn.second.count >= MinFramesPerVoxel || kvIn.second.point.label == 1)
-            SubMap.push_back(kvIn.second.point);
+    ForEachVoxel([&](int idxOut, const Voxel& v) {
+      if (inside(idxOut) && (v.count >= MinFramesPerVoxel || v.point.label == 1)) SubMap.push_back(v.point);
+    });
     if (int(SubMap.size()) < minNbPoints)
     {
-      for (const auto& kvOut : Voxels)
-        if (inside(kvOut.first))
-          for (const auto& kvIn : kvOut.second)
-            if (kvIn.second.count < MinFramesPerVoxel && kvIn.second.point.label != 1)
-              SubMap.push_back(kvIn.second.point);
+      ForEachVoxel([&](int idxOut, const Voxel& v) {
+        if (inside(idxOut) && v.count < MinFramesPerVoxel && v.point.label != 1) SubMap.push_back(v.point);
+      });
     }
   }
   KdTree.Reset(&SubMap);

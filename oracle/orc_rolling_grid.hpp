@@ -8,6 +8,7 @@
 // therefore the summation order of every PCA fed from it -- is libstdc++'s,
 // exactly as in a reference build on this platform.
 #pragma once
+#include <algorithm>
 #include <unordered_map>
 #include <vector>
 #include "orc_math.hpp"
@@ -35,6 +36,12 @@ public:
   void SetMinFramesPerVoxel(unsigned n) { MinFramesPerVoxel = n; }
   void SetSampling(SamplingMode m) { Sampling = m; }
   void SetDecayingThreshold(double d) { DecayingThreshold = d; }
+  // Order in which Get / BuildSubMapKdTree hand the voxels out.  false: the iteration order of the reference's own
+  // containers (std::unordered_map of libstdc++: an accident of the hash tables' history).  true (default): ascending
+  // (outer voxel index, leaf voxel index as unsigned) -- the DEFINED order the device map uses; the product and the
+  // oracle adopt it together, the reference's order stays available for comparison.
+  void SetOrdered(bool b) { Ordered = b; }
+  bool GetOrdered() const { return Ordered; }
   bool IsTimeThreshold() const { return DecayingThreshold > 0; }
 
   std::vector<Point> Get(bool clean = false) const;
@@ -60,6 +67,9 @@ private:
   unsigned MinFramesPerVoxel = 0;
   SamplingMode Sampling = SamplingMode::MAX_INTENSITY;
   double DecayingThreshold = -1;
+  bool Ordered = true;
+  // calls f(outer index, voxel) for every voxel, in the order above
+  template <typename F> void ForEachVoxel(F f) const;
 
   int To1d(const int v[3]) const { return v[2] * GridSize * GridSize + v[1] * GridSize + v[0]; }
   void To3d(int id, int v[3]) const
@@ -71,5 +81,22 @@ private:
     v[0] = id; v[1] = y; v[2] = z;
   }
 };
+
+template <typename F> void RollingGrid::ForEachVoxel(F f) const
+{
+  if (!Ordered)
+  {
+    for (const auto& kvOut : Voxels)
+      for (const auto& kvIn : kvOut.second) f(kvOut.first, kvIn.second);
+    return;
+  }
+  struct Ref { unsigned out, in; const Voxel* v; };
+  std::vector<Ref> refs;
+  refs.reserve(NbPoints);
+  for (const auto& kvOut : Voxels)
+    for (const auto& kvIn : kvOut.second) refs.push_back({(unsigned)kvOut.first, (unsigned)kvIn.first, &kvIn.second});
+  std::sort(refs.begin(), refs.end(), [](const Ref& a, const Ref& b) { return a.out != b.out ? a.out < b.out : a.in < b.in; });
+  for (const Ref& r : refs) f((int)r.out, *r.v);
+}
 
 }  // namespace orc

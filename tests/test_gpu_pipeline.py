@@ -77,7 +77,8 @@ def test_registered_frame_bit_exact(gpu_ctx, O, L, scan):
 # ---------------------------------------------------------------------------------------- pipeline
 def run_both(L, O, model, nframes, seed=1000, check_keypoints=True, **params):
     params.setdefault("EgoMotion", 3)
-    sg, so = L.Slam(0, **params), O.Slam(**params)
+    oracle_params = {k: v for k, v in params.items() if k != "MapsOnDevice"}  # where the maps live is ours alone
+    sg, so = L.Slam(0, **params), O.Slam(**oracle_params)
     worst = (0.0, 0.0)
     poses = []
     for f in range(nframes):
@@ -152,12 +153,22 @@ def test_pipeline_modes(L, O, params):
         dict(MapUpdate=0),                                                  # no map: localization has nothing to match
     ],
 )
-def test_map_maintenance_beside_the_device_work(L, O, params):
-    """30 frames: the keyframe insertions run on worker threads beside the next frame, the sub-maps are extracted
-    ahead of time under the predicted pose -- the trajectory must not know (same maps, same sub-map order)."""
-    sg, so, poses, _ = run_both(L, O, 8, 30, check_keypoints=False, **params)
+@pytest.mark.parametrize("on_device", [1, 0])
+def test_map_maintenance_beside_the_device_work(L, O, params, on_device):
+    """30 frames against the oracle's maps.  Maps on the device (the default): keyframes are keyed, sorted, folded and
+    merged into the sorted voxel arrays by kernels, the sub-maps are compacted straight into the kNN target.  Maps on
+    the host ("MapsOnDevice" = 0, and CENTROID sampling always): the insertions run on worker threads beside the next
+    frame, the sub-maps are extracted ahead of time under the predicted pose.  Either way the trajectory must not
+    know (same maps, same sub-map order), and map and sub-map are the oracle's, byte for byte."""
+    sg, so, poses, _ = run_both(L, O, 8, 30, check_keypoints=False, MapsOnDevice=on_device, **params)
+    centroid = params.get("VoxelGridSamplingMode") == 4
+    assert sg.get_param("DeviceMapsInUse") == (1.0 if on_device and not centroid else 0.0)
     if params.get("MapUpdate", 2) != 0:
-        assert sg.get_param("SubMapSpeculationHits") > 0
+        assert (sg.get_param("SubMapSpeculationHits") > 0) == (not on_device or centroid)
+    for k in range(3):
+        assert sg.map(k).tobytes() == so.map(k).tobytes()
+        assert sg.map(k, clean=True).tobytes() == so.map(k, clean=True).tobytes()
+        assert sg.target_submap(k).tobytes() == so.submap(k).tobytes()
     step = np.linalg.norm(poses[-1][:3, 3] - poses[10][:3, 3])
     assert step > 5.0 or params.get("MapUpdate", 2) == 0  # it moved: 5 m/s for 2 s
     sg.close()
@@ -720,3 +731,28 @@ def test_polydata_arrays_upload_follows_the_paraview_filter(O, L):
         assert ctx.upload_polydata_frame(xyz, pts["time"], pts["laser_id"], pts["intensity"])[1:] == (pts.size, True)
     finally:
         ctx.close()
+
+
+def test_the_maps_follow_a_setter_that_moves_them_between_device_and_host(L, O):
+    """"MapsOnDevice" or CENTROID sampling set in the middle of a sequence: the points change sides (as RollingGrid's own
+    geometry setters put them back, counts start again) and the sequence goes on -- close to the trajectory that never
+    switched, with the same number of map points right after the move"""
+    ref = L.Slam(0, EgoMotion=3)
+    sw = L.Slam(0, EgoMotion=3)
+    for f in range(16):
+        pts, stamp = L.synth_frame(8, 1000, f)
+        if f == 6:
+            before = [sw.map(k).size for k in range(3)]
+            sw.set_param("MapsOnDevice", 0)
+            assert sw.get_param("DeviceMapsInUse") == 0.0
+            assert [sw.map(k).size for k in range(3)] == before and sum(before) > 500
+        if f == 11:
+            before = [sw.map(k).size for k in range(3)]
+            sw.set_param("MapsOnDevice", 1)
+            assert sw.get_param("DeviceMapsInUse") == 1.0
+            assert [sw.map(k).size for k in range(3)] == before
+        ref.add_frame(pts, stamp, f)
+        sw.add_frame(pts, stamp, f)
+        dp, da = pose_diff(ref.world_transform(), sw.world_transform())
+        assert dp < 2e-2 and da < 2e-3, (f, dp, da)
+    ref.close(), sw.close()

@@ -179,3 +179,22 @@ def test_add_on_several_threads_builds_the_same_map(sampling):
     pts = cloud(rng, 6000, np.zeros(3), spread=16.0)
     g.add(pts), o.add(pts)
     same_state(g, o)
+
+
+def test_the_order_of_the_reference_containers_is_still_available():
+    """"Ordered" = 0: Get / BuildSubMap hand the voxels out in the iteration order of the reference's own
+    unordered_map<int, unordered_map<int, Voxel>> (libstdc++), host grid and oracle alike; the default is key order"""
+    rng = np.random.default_rng(9)
+    g, o = pair(GridSize=12, VoxelResolution=8.0, LeafSize=0.6)
+    g.set("Ordered", 0), o.set("Ordered", 0)
+    g2, o2 = pair(GridSize=12, VoxelResolution=8.0, LeafSize=0.6)
+    for step in range(5):
+        pts = cloud(rng, 3000, np.array([step * 4.0, 0, 0]), spread=12.0, t=step * 0.1)
+        for m in (g, o, g2, o2):
+            m.add(pts, time=step * 0.1)
+    same_state(g, o)
+    same_state(g2, o2)
+    a, b = g.get(), g2.get()
+    assert a.tobytes() != b.tobytes() and np.array_equal(np.sort(a, order=["x", "y", "z"]), np.sort(b, order=["x", "y", "z"]))
+    mn, mx = np.array([0, -10, -5], np.float32), np.array([20, 10, 5], np.float32)
+    assert same_submap(g, o, mn, mx) == same_submap(g2, o2, mn, mx) > 0

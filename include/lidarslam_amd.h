@@ -560,9 +560,10 @@ lsa_ctx* lsa_slam_context(lsa_slam* s);
 /* LidarSlam::RollingGrid ON THE DEVICE (slam_lib/include/LidarSlam/RollingGrid.h:63-212, slam_lib/src/RollingGrid.cxx): the
  * rolling voxel map of one keypoint type as ONE array of voxels sorted by (outer voxel index, leaf voxel index), living
  * in the memory of the context it was created on.  Add / Roll / ClearOldPoints / BuildSubMapKdTree are sequences of
- * kernels on the context's stream (sort of the batch, one thread per voxel folding the batch's points for it in arrival
- * order through the reference's per-point rule, merge by rank, stable compactions); the sub-map is written straight
- * into a kNN target of the context.  Points come out in KEY ORDER (outer index, then leaf index) where the reference
+ * kernels on a stream of the grid's own (sort of the batch, one thread per voxel folding the batch's points for it in
+ * arrival order through the reference's per-point rule, merge by rank, stable compactions), ordered by events against
+ * the context's stream wherever the two share data; the sub-map is written straight into a kNN target of the context.
+ * One grid is driven by one host thread at a time (not necessarily the context's).  Points come out in KEY ORDER (outer index, then leaf index) where the reference
  * hands them out in its hash containers' iteration order -- a defined order in place of an accidental one, adopted by
  * the oracle and the host grid as well ("OrderedMaps").  Sampling modes FIRST, LAST, MAX_INTENSITY, CENTER_POINT;
  * CENTROID (whose reference loop is quadratic in the batch size, RollingGrid.cxx:282-297) is refused: lsa_slam keeps
@@ -583,6 +584,10 @@ int lsa_device_grid_add(lsa_device_grid* g, const lsa_point_t* pts, int n, int f
 /* ... and from a keypoint set of the context moved by `pose` (Slam::UpdateMapsUsingTworld, Slam.cxx:1178-1222): nothing
  * leaves the device and nothing is waited for. */
 int lsa_device_grid_add_keypoints(lsa_device_grid* g, int set, int type, const double pose[16], double time);
+/* The same in two steps, for a caller that hands the insertion proper to another host thread: _stage_keypoints (on the
+ * context's thread) reads the keypoints -- the set may be rewritten right after --, _add_staged inserts them. */
+int lsa_device_grid_stage_keypoints(lsa_device_grid* g, int set, int type, const double pose[16]);
+int lsa_device_grid_add_staged(lsa_device_grid* g, double time);
 int lsa_device_grid_roll(lsa_device_grid* g, const float min_point[3], const float max_point[3]);
 int lsa_device_grid_clear_old_points(lsa_device_grid* g, double current_time);
 /* RollingGrid::Get(clean): points written. */
@@ -590,6 +595,12 @@ int lsa_device_grid_get(lsa_device_grid* g, int clean, lsa_point_t* out, int cap
 /* RollingGrid::BuildSubMapKdTree(): the sub-map (the whole map when min_point == NULL) becomes the kNN target (slot,
  * type) of the context; returns its size.  lsa_device_grid_submap_valid: RollingGrid::IsSubMapKdTreeValid(). */
 int lsa_device_grid_build_submap(lsa_device_grid* g, const float min_point[3], const float max_point[3], int min_nb_points, int slot, int type);
+/* The same in two steps: _begin enqueues the extraction, _end waits for it and returns the size -- several grids build
+ * side by side.  _begin_for_keypoints takes the box of keypoint type `box_type` as lsa_keypoint_bboxes_begin (which must
+ * come right before, and needs no lsa_keypoint_bboxes_end then) left it on the device: nothing is read back. */
+int lsa_device_grid_build_submap_begin(lsa_device_grid* g, const float min_point[3], const float max_point[3], int min_nb_points, int slot, int type);
+int lsa_device_grid_build_submap_begin_for_keypoints(lsa_device_grid* g, int box_type, int min_nb_points, int slot, int type);
+int lsa_device_grid_build_submap_end(lsa_device_grid* g);
 int lsa_device_grid_submap_valid(lsa_device_grid* g);
 
 /* ---- the rolling voxel map (host) ---------------------------

@@ -67,7 +67,8 @@ ABI_SYMBOLS = [
     "lsa_synth_pose",
     "lsa_device_grid_create", "lsa_device_grid_destroy", "lsa_device_grid_set", "lsa_device_grid_get_param", "lsa_device_grid_reset", "lsa_device_grid_clear",
     "lsa_device_grid_size", "lsa_device_grid_add", "lsa_device_grid_add_keypoints", "lsa_device_grid_roll", "lsa_device_grid_clear_old_points",
-    "lsa_device_grid_get", "lsa_device_grid_build_submap", "lsa_device_grid_submap_valid",
+    "lsa_device_grid_get", "lsa_device_grid_build_submap", "lsa_device_grid_submap_valid", "lsa_device_grid_stage_keypoints", "lsa_device_grid_add_staged",
+    "lsa_device_grid_build_submap_begin", "lsa_device_grid_build_submap_begin_for_keypoints", "lsa_device_grid_build_submap_end",
     "lsa_rolling_grid_create", "lsa_rolling_grid_destroy", "lsa_rolling_grid_set", "lsa_rolling_grid_reset", "lsa_rolling_grid_clear",
     "lsa_rolling_grid_size", "lsa_rolling_grid_roll", "lsa_rolling_grid_add", "lsa_rolling_grid_clear_old_points", "lsa_rolling_grid_get",
     "lsa_rolling_grid_build_submap", "lsa_rolling_grid_submap_valid", "lsa_rolling_grid_submap",
@@ -797,6 +798,11 @@ class DeviceGrid:
         self.L.lsa_device_grid_get.argtypes = [vp, i32, vp, i32]
         self.L.lsa_device_grid_build_submap.argtypes = [vp, vp, vp, i32, i32, i32]
         self.L.lsa_device_grid_submap_valid.argtypes = [vp]
+        self.L.lsa_device_grid_stage_keypoints.argtypes = [vp, i32, i32, vp]
+        self.L.lsa_device_grid_add_staged.argtypes = [vp, f64]
+        self.L.lsa_device_grid_build_submap_begin.argtypes = [vp, vp, vp, i32, i32, i32]
+        self.L.lsa_device_grid_build_submap_begin_for_keypoints.argtypes = [vp, i32, i32, i32, i32]
+        self.L.lsa_device_grid_build_submap_end.argtypes = [vp]
         if self.L.lsa_device_grid_create(ctx.h, C.byref(h)) != 0:
             raise LsaError("lsa_device_grid_create failed")
         self.h = h
@@ -840,6 +846,20 @@ class DeviceGrid:
 
     def add_keypoints(self, kset, ktype, pose, time):
         self._check(self.L.lsa_device_grid_add_keypoints(self.h, kset, ktype, ptr(pose16(pose)), float(time)), "lsa_device_grid_add_keypoints")
+
+    def stage_keypoints(self, kset, ktype, pose):
+        self._check(self.L.lsa_device_grid_stage_keypoints(self.h, kset, ktype, ptr(pose16(pose))), "lsa_device_grid_stage_keypoints")
+
+    def add_staged(self, time):
+        """the insertion of what stage_keypoints read; any host thread"""
+        self._check(self.L.lsa_device_grid_add_staged(self.h, float(time)), "lsa_device_grid_add_staged")
+
+    def build_submap_begin_for_keypoints(self, box_type, min_nb_points, ktype=PLANE, slot=TARGET_MAP):
+        """box of the keypoints of `box_type` as Context.keypoint_bboxes_begin left it on the device"""
+        self._check(self.L.lsa_device_grid_build_submap_begin_for_keypoints(self.h, box_type, int(min_nb_points), slot, ktype), "lsa_device_grid_build_submap_begin_for_keypoints")
+
+    def build_submap_end(self):
+        return self._check(self.L.lsa_device_grid_build_submap_end(self.h), "lsa_device_grid_build_submap_end")
 
     def clear_old_points(self, time):
         self._check(self.L.lsa_device_grid_clear_old_points(self.h, float(time)), "lsa_device_grid_clear_old_points")

@@ -650,25 +650,31 @@ int SlamCore::Localization()
     // the voxels the box of the current keypoints (at the initial pose guess) touches -- written straight into the
     // target; only the box (read back once for all types) and the sub-maps' sizes cross the bus
     Tick t;
+    WaitMaps();  // the workers have enqueued the previous keyframe's insertions
+    Stats.maps_wait = t.Stop();
+    for (int k = 0; k < 3; ++k)
+      if (MapJobFailed[k]) { MapJobFailed[k] = 0; return Fail(LSA_E_HIP, "lsa_device_grid_add_staged (map worker)"); }
     bool need[3], any = false;
     for (int k = 0; k < 3; ++k)
     {
       need[k] = UseKeypoints[k] && !lsa_device_grid_submap_valid(DevMaps[k]);
       any = any || need[k];
     }
-    float mn[9], mx[9];
-    if (any && MapUpdate != MappingMode::NONE) LSA_TRY(lsa_working_bboxes(Ctx, Tworld.m, mn, mx));
+    // the boxes of the current keypoints under the pose guess stay on the device: the grids read them there
+    if (any && MapUpdate != MappingMode::NONE) LSA_TRY(lsa_keypoint_bboxes_begin(Ctx, LSA_SET_WORKING, Tworld.m));
     for (int k = 0; k < 3; ++k)
     {
       if (!need[k]) continue;
       lsa_set_target_cell_size(Ctx, LSA_TARGET_MAP, k, static_cast<float>((k == LSA_EDGE ? KnnCellScaleMapsEdges : KnnCellScaleMaps) * LocalMaps[k]->GetLeafSize()));
-      if (MapUpdate == MappingMode::NONE) LSA_TRY(lsa_device_grid_build_submap(DevMaps[k], nullptr, nullptr, -1, LSA_TARGET_MAP, k));
+      if (MapUpdate == MappingMode::NONE) LSA_TRY(lsa_device_grid_build_submap_begin(DevMaps[k], nullptr, nullptr, -1, LSA_TARGET_MAP, k));
       else
       {
         if (LocalMaps[k]->IsTimeThreshold()) LSA_TRY(lsa_device_grid_clear_old_points(DevMaps[k], CurrentTime));
-        LSA_TRY(lsa_device_grid_build_submap(DevMaps[k], mn + 3 * k, mx + 3 * k, KeypointCounts[k] / 2, LSA_TARGET_MAP, k));
+        LSA_TRY(lsa_device_grid_build_submap_begin_for_keypoints(DevMaps[k], k, KeypointCounts[k] / 2, LSA_TARGET_MAP, k));
       }
     }
+    for (int k = 0; k < 3; ++k)  // the three extractions run side by side, each on its grid's stream
+      if (need[k]) LSA_TRY(lsa_device_grid_build_submap_end(DevMaps[k]));
     Stats.submap += t.Stop();
   }
   else
@@ -942,8 +948,17 @@ int SlamCore::UpdateMapsUsingTworld()
   {
     // the keyframe's keypoints go into the device maps as they are (WORLD transform, keying, sort, fold, merge: kernels on
     // the context's stream, nothing is waited for)
+    // this thread only hands the keypoints over (one transform kernel per type on the grid's stream); the workers
+    // enqueue the insertions, which run on the grids' streams beside the next frame
     for (int k = 0; k < 3; ++k)
-      if (UseKeypoints[k]) LSA_TRY(lsa_device_grid_add_keypoints(DevMaps[k], LSA_SET_WORKING, k, Tworld.m, CurrentTime));
+    {
+      if (!UseKeypoints[k]) continue;
+      LSA_TRY(lsa_device_grid_stage_keypoints(DevMaps[k], LSA_SET_WORKING, k, Tworld.m));
+      lsa_device_grid* grid = DevMaps[k];
+      const double time = CurrentTime;
+      int* failed = &MapJobFailed[k];
+      MapWorker[k].Submit([grid, time, failed] { if (lsa_device_grid_add_staged(grid, time) < 0) *failed = 1; });
+    }
     return LSA_OK;
   }
   // the device writes the world keypoints into pinned host memory; the map workers wait for exactly that and
@@ -1078,6 +1093,7 @@ int SlamCore::GetMap(int k, bool clean, std::vector<lsa_point_t>& out)
   if (!Ctx) return LSA_E_NO_DEVICE;
   if (DeviceMapsInUse())
   {
+    WaitMaps();
     const int size = std::max(lsa_device_grid_size(DevMaps[k]), 0);
     out.resize(size);
     const int n = size > 0 ? lsa_device_grid_get(DevMaps[k], clean ? 1 : 0, out.data(), size) : 0;

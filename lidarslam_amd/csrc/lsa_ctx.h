@@ -259,6 +259,7 @@ struct lsa_ctx
   hipEvent_t ev_stage = nullptr;
   bool stage_pending = false;
   bool bbox_pending = false;
+  std::mutex prof_mutex;  // stats / pending / event_pool of the profiling scopes
   int bbox_n[3] = {0, 0, 0};
 
   // profiling
@@ -287,7 +288,7 @@ namespace lsa
   } while (0)
 
 int lm_cache_capacity();
-int transform_points_to(lsa_ctx* ctx, const lsa_point_t* src, int n, const double pose[16], lsa_point_t* dst);  // lsa_transform.hip
+int transform_points_to(lsa_ctx* ctx, const lsa_point_t* src, int n, const double pose[16], lsa_point_t* dst, hipStream_t stream = nullptr);  // lsa_transform.hip
 int time_from_advancement(lsa_ctx* ctx, lsa_point_t* frame, int n, double rpm, int first_packet);  // lsa_extract.hip
 int ensure_capacity(lsa_ctx* ctx, int n);
 int ensure_target(lsa_ctx* ctx, int ti, int m);

@@ -133,6 +133,7 @@ int ensure_scratch(lsa_ctx* ctx, size_t bytes)
 ProfScope::ProfScope(lsa_ctx* c, const char* name, double bytes, hipStream_t stream) : ctx(c), st(stream ? stream : c->stream)
 {
   if (!ctx->profiling) return;
+  std::lock_guard<std::mutex> lock(ctx->prof_mutex);  // the device maps' insertions are enqueued (and timed) by other host threads
   for (size_t i = 0; i < ctx->stats.size(); ++i)
     if (ctx->stats[i].name == name) { stat = (int)i; break; }
   // a selection names a scope or a family of scopes by their common prefix ("match_": match_search and match_model)
@@ -162,17 +163,20 @@ ProfScope::~ProfScope()
 {
   if (stat < 0) return;
   (void)hipEventRecord(b, st);
+  std::lock_guard<std::mutex> lock(ctx->prof_mutex);
   ctx->pending.push_back({stat, a, b});
 }
 void profile_add_bytes(lsa_ctx* ctx, const char* name, double bytes)
 {
   if (!ctx->profiling) return;
+  std::lock_guard<std::mutex> lock(ctx->prof_mutex);
   for (auto& st : ctx->stats)
     if (st.name == name) { st.bytes += bytes; return; }
 }
 
 void profile_collect(lsa_ctx* ctx)
 {
+  std::lock_guard<std::mutex> lock(ctx->prof_mutex);
   for (auto& p : ctx->pending)
   {
     (void)hipEventSynchronize(p.b);

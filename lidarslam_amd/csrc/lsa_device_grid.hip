@@ -46,7 +46,7 @@ struct GridParams
   unsigned min_frames;
 };
 // state the kernels read and write (device memory, kStInts ints)
-enum { kStN = 0, kStNbPoints = 1, kStUpdated = 2, kStPosX = 3, kStGroups = 6, kStNew = 7, kStOff = 8, kStSub = 11, kStTmp = 12 /* 6 ints */, kStSubFirst = 18, kStCompact = 19, kStInts = 32 };
+enum { kStN = 0, kStNbPoints = 1, kStUpdated = 2, kStPosX = 3, kStGroups = 6, kStNew = 7, kStOff = 8, kStSub = 11, kStTmp = 12 /* 6 ints */, kStSubFirst = 18, kStCompact = 19, kStBox = 20 /* 6 ints: lo[3], hi[3] of the sub-map's box in voxels */, kStInts = 32 };
 
 __device__ __forceinline__ int round_to_int(float v)
 {
@@ -433,8 +433,7 @@ struct SubMapPred
   const u64* keys;
   const float4* pts;
   const unsigned* count;
-  const int* st;
-  int lo[3], hi[3];
+  const int* st;   // st[kStBox ..]: lo[3], hi[3] of the box in outer voxels (k_submap_box)
   int grid_size;
   int mode;          // 0 every voxel in the box; 1 count >= min_frames or fixed; 2 the others (count < min_frames and not fixed), only if pass 1 was short
   unsigned min_frames;
@@ -448,6 +447,8 @@ struct SubMapPred
     const int g = grid_size;
     const int z = id / (g * g); id -= z * g * g;
     const int y = id / g; const int x = id - y * g;
+    const int* lo = st + kStBox;
+    const int* hi = st + kStBox + 3;
     if (x < lo[0] || x > hi[0] || y < lo[1] || y > hi[1] || z < lo[2] || z > hi[2]) return false;
     if (mode == 0) return true;
     const unsigned label = (__float_as_uint(pts[2 * (size_t)i + 1].w) >> 24) & 0xffu;
@@ -465,6 +466,22 @@ struct PointEmit
     out[2 * (size_t)at + 1] = pts[2 * (size_t)i + 1];
   }
 };
+// the outer voxels the box [mn, mx] touches (:365-370): PositionToVoxel of both corners against the grid position the
+// device holds, clamped to the grid.  The box comes from the caller (floats) or from the bounding-box words the context's
+// lsa_keypoint_bboxes_begin left on the device (ordered unsigned, 6 per keypoint type).
+__device__ __forceinline__ float ordered_to_float(unsigned u) { return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u); }
+struct BoxArg { float mn[3], mx[3]; };
+__global__ void k_submap_box(BoxArg box, const unsigned* __restrict__ ctx_box, GridParams p, int* __restrict__ st)
+{
+  const int d = threadIdx.x;
+  if (d >= 3 || blockIdx.x != 0) return;
+  const float lo_f = ctx_box ? ordered_to_float(ctx_box[d]) : box.mn[d];
+  const float hi_f = ctx_box ? ordered_to_float(ctx_box[3 + d]) : box.mx[d];
+  const float origin = __int_as_float(st[kStPosX + d]) - (float)((double)(p.grid_size / 2) * p.resolution_d);
+  const int lo = round_to_int((lo_f - origin) / p.resolution), hi = round_to_int((hi_f - origin) / p.resolution);
+  st[kStBox + d] = lo > 0 ? lo : 0;
+  st[kStBox + 3 + d] = hi < p.grid_size - 1 ? hi : p.grid_size - 1;
+}
 __global__ void k_set_int(int* __restrict__ p, int v) { if (threadIdx.x == 0 && blockIdx.x == 0) *p = v; }
 __global__ void k_copy_int(int* __restrict__ dst, const int* __restrict__ src) { if (threadIdx.x == 0 && blockIdx.x == 0) *dst = *src; }
 
@@ -488,6 +505,14 @@ struct lsa_device_grid
   int* st = nullptr;           // device state (16 ints)
   int* host_st = nullptr;      // pinned copy of it, refreshed behind every modification
   hipEvent_t ev_state = nullptr;
+  // Every kernel of the grid runs on its own stream: a keyframe goes into the map beside the next frame's work on the
+  // context's stream (and may be enqueued by another host thread).  Where the two meet -- keypoints read, a target or
+  // the scratch buffer written -- events order them: ev_in (context -> grid) before, ev_out (grid -> context) after.
+  hipStream_t stream = nullptr;
+  hipEvent_t ev_in = nullptr, ev_out = nullptr, ev_sub = nullptr;
+  int* host_sub = nullptr;     // pinned: the size of the sub-map being built
+  int sub_target = -1;         // target index (slot * 3 + type) of the sub-map between _begin and _end
+  int staged = 0;              // keypoints staged in `batch` by lsa_device_grid_stage_keypoints
   bool submap_valid = false;
   int submap_count = 0;
   // batch scratch
@@ -510,6 +535,19 @@ namespace
     hipError_t e__ = (call);                                                                           \
     if (e__ != hipSuccess) return g->ctx->fail(LSA_E_HIP, std::string(#call) + ": " + hipGetErrorString(e__)); \
   } while (0)
+
+int order_after_context(lsa_device_grid* g)
+{
+  G_HIP(hipEventRecord(g->ev_in, g->ctx->stream));
+  G_HIP(hipStreamWaitEvent(g->stream, g->ev_in, 0));
+  return LSA_OK;
+}
+int order_context_after(lsa_device_grid* g)
+{
+  G_HIP(hipEventRecord(g->ev_out, g->stream));
+  G_HIP(hipStreamWaitEvent(g->ctx->stream, g->ev_out, 0));
+  return LSA_OK;
+}
 
 GridParams params_of(const lsa_device_grid* g)
 {
@@ -545,7 +583,7 @@ int ensure_map(lsa_device_grid* g, int want)
   if (want > g->cap)
   {
     const int cap = std::max(2 * want, 1 << 16);
-    G_HIP(hipStreamSynchronize(g->ctx->stream));
+    G_HIP(hipStreamSynchronize(g->stream));
     MapView nb[2];
     for (int b = 0; b < 2; ++b)
     {
@@ -569,7 +607,7 @@ int ensure_map(lsa_device_grid* g, int want)
   const int nchunks = (std::max(g->cap, g->bcap) + 1023) / 1024 + 1;
   if (nchunks > g->chunk_cap)
   {
-    G_HIP(hipStreamSynchronize(g->ctx->stream));
+    G_HIP(hipStreamSynchronize(g->stream));
     if (g->chunks) (void)hipFree(g->chunks);
     G_HIP(hipMalloc((void**)&g->chunks, (size_t)nchunks * sizeof(int)));
     g->chunk_cap = nchunks;
@@ -581,7 +619,7 @@ int ensure_batch(lsa_device_grid* g, int n)
 {
   if (n <= g->bcap) return LSA_OK;
   const int cap = std::max(n + n / 4, 1 << 14);
-  G_HIP(hipStreamSynchronize(g->ctx->stream));
+  G_HIP(hipStreamSynchronize(g->stream));
   auto fr = [](void* p) { if (p) (void)hipFree(p); };
   fr(g->batch); fr(g->bkeys); fr(g->skeys); fr(g->border); fr(g->sorder); fr(g->heads); fr(g->fresh_flag); fr(g->sort_tmp);
   free_view(g->fresh);
@@ -598,7 +636,7 @@ int ensure_batch(lsa_device_grid* g, int n)
   rc = alloc_view(g, g->fresh2, cap);
   if (rc) return rc;
   size_t bytes = 0;
-  if (rocprim::radix_sort_pairs((void*)nullptr, bytes, g->bkeys, g->skeys, g->border, g->sorder, (size_t)cap, 0, 64, g->ctx->stream) != hipSuccess)
+  if (rocprim::radix_sort_pairs((void*)nullptr, bytes, g->bkeys, g->skeys, g->border, g->sorder, (size_t)cap, 0, 64, g->stream) != hipSuccess)
     return g->ctx->fail(LSA_E_HIP, "lsa_device_grid: radix sort sizing failed");
   G_HIP(hipMalloc(&g->sort_tmp, bytes + 256));
   g->sort_tmp_bytes = bytes + 256;
@@ -611,7 +649,7 @@ int ensure_batch(lsa_device_grid* g, int n)
 template <typename Pred, typename Emit>
 void compact(lsa_device_grid* g, Pred pred, Emit emit, const int* n_ptr, int n_bound, int* total, bool append = false)
 {
-  hipStream_t st = g->ctx->stream;
+  hipStream_t st = g->stream;
   const int nchunks = std::max((n_bound + 1023) / 1024, 1);
   hipLaunchKernelGGL((k_compact_count<Pred>), dim3(nchunks), dim3(256), 0, st, pred, n_ptr, n_bound, g->chunks);
   // compacting in place of the count it reads (Roll, ClearOldPoints): the scatter still needs the old count, the new one
@@ -625,15 +663,15 @@ void compact(lsa_device_grid* g, Pred pred, Emit emit, const int* n_ptr, int n_b
 // the host's copy of the state follows every modification (asynchronously)
 int refresh_state(lsa_device_grid* g)
 {
-  G_HIP(hipMemcpyAsync(g->host_st, g->st, kStInts * sizeof(int), hipMemcpyDeviceToHost, g->ctx->stream));
-  G_HIP(hipEventRecord(g->ev_state, g->ctx->stream));
+  G_HIP(hipMemcpyAsync(g->host_st, g->st, kStInts * sizeof(int), hipMemcpyDeviceToHost, g->stream));
+  G_HIP(hipEventRecord(g->ev_state, g->stream));
   return LSA_OK;
 }
 
 // Roll (always a pass into the other buffer: the host does not know whether the grid moves)
 int roll(lsa_device_grid* g, bool use_box)
 {
-  hipStream_t st = g->ctx->stream;
+  hipStream_t st = g->stream;
   const GridParams p = params_of(g);
   hipLaunchKernelGGL(k_roll_decide, dim3(1), dim3(64), 0, st, p, g->st, use_box ? 1 : 0);
   const MapView src = g->buf[g->cur], dst = g->buf[1 - g->cur];
@@ -648,11 +686,11 @@ int roll(lsa_device_grid* g, bool use_box)
 // Add of the n points in g->batch (device)
 int add_batch(lsa_device_grid* g, int n, bool fixed, double time, bool do_roll)
 {
-  hipStream_t st = g->ctx->stream;
+  hipStream_t st = g->stream;
   int rc = ensure_map(g, g->n_upper + n);
   if (rc) return rc;
   const GridParams p = params_of(g);
-  ProfScope ps(g->ctx, "map_add", (double)n * (32 + 12 + 44) + (double)g->n_upper * 44 * (do_roll ? 2 : 1));
+  ProfScope ps(g->ctx, "map_add", (double)n * (32 + 12 + 44) + (double)g->n_upper * 44 * (do_roll ? 2 : 1), g->stream);
   if (do_roll)
   {
     hipLaunchKernelGGL(k_batch_bbox, dim3((n + 255) / 256), dim3(256), 0, st, g->batch, n, g->st);
@@ -689,8 +727,10 @@ int lsa_device_grid_create(lsa_ctx* ctx, lsa_device_grid** out)
   g->ctx = ctx;
   bool ok = hipMalloc((void**)&g->st, kStInts * sizeof(int)) == hipSuccess;
   ok = ok && hipHostMalloc((void**)&g->host_st, kStInts * sizeof(int), hipHostMallocDefault) == hipSuccess;
-  ok = ok && hipEventCreateWithFlags(&g->ev_state, hipEventDisableTiming) == hipSuccess;
-  if (!ok) { delete g; return LSA_E_HIP; }
+  ok = ok && hipHostMalloc((void**)&g->host_sub, sizeof(int), hipHostMallocDefault) == hipSuccess;
+  ok = ok && hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking) == hipSuccess;
+  for (hipEvent_t* e : {&g->ev_state, &g->ev_in, &g->ev_out, &g->ev_sub}) ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
+  if (!ok) { lsa_device_grid_destroy(g); return LSA_E_HIP; }
   *out = g;
   return lsa_device_grid_reset(g, nullptr);
 }
@@ -699,12 +739,16 @@ void lsa_device_grid_destroy(lsa_device_grid* g)
 {
   if (!g) return;
   (void)hipSetDevice(g->ctx->device);
-  (void)hipStreamSynchronize(g->ctx->stream);
+  if (g->stream) (void)hipStreamSynchronize(g->stream);
+  (void)hipStreamSynchronize(g->ctx->stream);  // a match may still read a sub-map: nothing of the grid is in use after this
   free_view(g->buf[0]); free_view(g->buf[1]); free_view(g->fresh); free_view(g->fresh2);
   auto fr = [](void* p) { if (p) (void)hipFree(p); };
   fr(g->st); fr(g->batch); fr(g->bkeys); fr(g->skeys); fr(g->border); fr(g->sorder); fr(g->heads); fr(g->fresh_flag); fr(g->chunks); fr(g->sort_tmp);
   if (g->host_st) (void)hipHostFree(g->host_st);
-  if (g->ev_state) (void)hipEventDestroy(g->ev_state);
+  if (g->host_sub) (void)hipHostFree(g->host_sub);
+  for (hipEvent_t e : {g->ev_state, g->ev_in, g->ev_out, g->ev_sub})
+    if (e) (void)hipEventDestroy(e);
+  if (g->stream) (void)hipStreamDestroy(g->stream);
   delete g;
 }
 
@@ -723,7 +767,7 @@ int lsa_device_grid_reset(lsa_device_grid* g, const float position[3])
     h[kStTmp + d] = 0x7fffffff;
     h[kStTmp + 3 + d] = (int)0x80000000;
   }
-  G_HIP(hipStreamSynchronize(g->ctx->stream));
+  G_HIP(hipStreamSynchronize(g->stream));
   G_HIP(hipMemcpy(g->st, h, sizeof(h), hipMemcpyHostToDevice));
   std::memcpy(g->host_st, h, sizeof(h));
   g->n_upper = 0;
@@ -735,8 +779,8 @@ int lsa_device_grid_clear(lsa_device_grid* g)
 {
   if (!g) return LSA_E_ARG;
   G_HIP(hipSetDevice(g->ctx->device));
-  hipLaunchKernelGGL(k_set_int, dim3(1), dim3(64), 0, g->ctx->stream, g->st + kStN, 0);
-  hipLaunchKernelGGL(k_set_int, dim3(1), dim3(64), 0, g->ctx->stream, g->st + kStNbPoints, 0);
+  hipLaunchKernelGGL(k_set_int, dim3(1), dim3(64), 0, g->stream, g->st + kStN, 0);
+  hipLaunchKernelGGL(k_set_int, dim3(1), dim3(64), 0, g->stream, g->st + kStNbPoints, 0);
   g->n_upper = 0;
   g->submap_valid = false;
   return refresh_state(g);
@@ -763,7 +807,7 @@ int lsa_device_grid_set(lsa_device_grid* g, const char* name, double value)
     // RollingGrid::SetVoxelResolution (:73-88): a multiple of the leaf size; the grid position is snapped to it
     g->VoxelResolution = int(value / g->LeafSize) * g->LeafSize;
     G_HIP(hipSetDevice(g->ctx->device));
-    G_HIP(hipStreamSynchronize(g->ctx->stream));
+    G_HIP(hipStreamSynchronize(g->stream));
     int h[kStInts];
     G_HIP(hipMemcpy(h, g->st, sizeof(h), hipMemcpyDeviceToHost));
     const float r = (float)g->VoxelResolution;
@@ -810,26 +854,46 @@ int lsa_device_grid_add(lsa_device_grid* g, const lsa_point_t* pts, int n, int f
   G_HIP(hipSetDevice(g->ctx->device));
   int rc = ensure_batch(g, n);
   if (rc) return rc;
-  G_HIP(hipMemcpyAsync(g->batch, pts, (size_t)n * sizeof(lsa_point_t), hipMemcpyHostToDevice, g->ctx->stream));
-  G_HIP(hipStreamSynchronize(g->ctx->stream));  // pts may be pageable and go away
+  G_HIP(hipMemcpyAsync(g->batch, pts, (size_t)n * sizeof(lsa_point_t), hipMemcpyHostToDevice, g->stream));
+  G_HIP(hipStreamSynchronize(g->stream));  // pts may be pageable and go away
   return add_batch(g, n, fixed != 0, time, roll_first != 0);
 }
 
 // the keypoints of a device set, moved by `pose` (WORLD), added without leaving the device: Slam::UpdateMapsUsingTworld
-// (slam_lib/src/Slam.cxx:1178-1222)
-int lsa_device_grid_add_keypoints(lsa_device_grid* g, int set, int type, const double pose[16], double time)
+// (slam_lib/src/Slam.cxx:1178-1222).  In two steps for callers that hand the insertion to another host thread: _stage
+// reads the context's keypoints (ordered behind what the context's stream has enqueued, and the context's stream behind
+// it: the set may be rewritten right after), _add_staged is the insertion proper, on the grid's stream alone.
+int lsa_device_grid_stage_keypoints(lsa_device_grid* g, int set, int type, const double pose[16])
 {
-  if (!g || !pose || set < 0 || set > 2 || type < 0 || type > 2) return g ? g->ctx->fail(LSA_E_ARG, "lsa_device_grid_add_keypoints: bad argument") : LSA_E_ARG;
-  if (g->Sampling == 4) return g->ctx->fail(LSA_E_STATE, "lsa_device_grid_add_keypoints: CENTROID sampling is kept on the host grid");
+  if (!g || !pose || set < 0 || set > 2 || type < 0 || type > 2) return g ? g->ctx->fail(LSA_E_ARG, "lsa_device_grid_stage_keypoints: bad argument") : LSA_E_ARG;
+  if (g->Sampling == 4) return g->ctx->fail(LSA_E_STATE, "lsa_device_grid_stage_keypoints: CENTROID sampling is kept on the host grid");
   lsa_ctx* ctx = g->ctx;
   const int n = ctx->kp_n[set][type];
+  g->staged = 0;
   if (n <= 0) return LSA_OK;
   G_HIP(hipSetDevice(ctx->device));
   int rc = ensure_batch(g, n);
   if (rc) return rc;
-  rc = transform_points_to(ctx, ctx->kp[set][type], n, pose, reinterpret_cast<lsa_point_t*>(g->batch));
+  rc = order_after_context(g);
   if (rc) return rc;
+  rc = transform_points_to(ctx, ctx->kp[set][type], n, pose, reinterpret_cast<lsa_point_t*>(g->batch), g->stream);
+  if (rc) return rc;
+  g->staged = n;
+  return order_context_after(g);
+}
+int lsa_device_grid_add_staged(lsa_device_grid* g, double time)
+{
+  if (!g) return LSA_E_ARG;
+  const int n = g->staged;
+  g->staged = 0;
+  if (n <= 0) return LSA_OK;  // "Pointcloud is empty, voxel grid not updated."
+  G_HIP(hipSetDevice(g->ctx->device));
   return add_batch(g, n, false, time, true);
+}
+int lsa_device_grid_add_keypoints(lsa_device_grid* g, int set, int type, const double pose[16], double time)
+{
+  const int rc = lsa_device_grid_stage_keypoints(g, set, type, pose);
+  return rc ? rc : lsa_device_grid_add_staged(g, time);
 }
 
 int lsa_device_grid_roll(lsa_device_grid* g, const float mn[3], const float mx[3])
@@ -847,8 +911,8 @@ int lsa_device_grid_roll(lsa_device_grid* g, const float mn[3], const float mx[3
     box[d] = a >= 0 ? a : a ^ 0x7fffffff;
     box[3 + d] = b >= 0 ? b : b ^ 0x7fffffff;
   }
-  G_HIP(hipMemcpyAsync(g->st + kStTmp, box, sizeof(box), hipMemcpyHostToDevice, g->ctx->stream));
-  G_HIP(hipStreamSynchronize(g->ctx->stream));
+  G_HIP(hipMemcpyAsync(g->st + kStTmp, box, sizeof(box), hipMemcpyHostToDevice, g->stream));
+  G_HIP(hipStreamSynchronize(g->stream));
   rc = roll(g, true);
   if (rc) return rc;
   return refresh_state(g);
@@ -878,57 +942,57 @@ int lsa_device_grid_get(lsa_device_grid* g, int clean, lsa_point_t* out, int cap
   rc = ensure_scratch(ctx, (size_t)g->n_upper * sizeof(lsa_point_t));
   if (rc) return rc;
   const MapView m = g->buf[g->cur];
-  SubMapPred pred{m.keys, m.pts, m.count, g->st, {0, 0, 0}, {0, 0, 0}, g->GridSize, 0, g->MinFramesPerVoxel, -1, clean ? 3 : 0};
+  rc = order_after_context(g);  // the scratch buffer is the context's
+  if (rc) return rc;
+  SubMapPred pred{m.keys, m.pts, m.count, g->st, g->GridSize, 0, g->MinFramesPerVoxel, -1, clean ? 3 : 0};
   compact(g, pred, PointEmit{m.pts, reinterpret_cast<float4*>(ctx->scratch_out)}, g->st + kStN, g->n_upper, g->st + kStSub);
   int kept = 0;
-  G_HIP(hipMemcpyAsync(&kept, g->st + kStSub, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-  G_HIP(hipStreamSynchronize(ctx->stream));
+  G_HIP(hipMemcpyAsync(&kept, g->st + kStSub, sizeof(int), hipMemcpyDeviceToHost, g->stream));
+  G_HIP(hipStreamSynchronize(g->stream));
   const int n = std::min(kept, capacity);
   if (n > 0) G_HIP(hipMemcpy(out, ctx->scratch_out, (size_t)n * sizeof(lsa_point_t), hipMemcpyDeviceToHost));
   return n;
 }
 
 // RollingGrid::BuildSubMapKdTree (:353-442): the sub-map becomes the kNN target (slot, type) of the context without
-// leaving the device -- the points in key order, the search grid is built with the next match.  mn == NULL: the whole
-// map.  Returns the number of points of the sub-map.
-int lsa_device_grid_build_submap(lsa_device_grid* g, const float mn[3], const float mx[3], int min_nb_points, int slot, int type)
+// leaving the device -- the points in key order, the search grid is built with the next match.  _begin enqueues it (on
+// the grid's stream; the context's stream goes on behind it), _end waits for its size: several grids build side by
+// side and are waited for once.  The box: mn/mx given; or, box_type >= 0, the box of that keypoint type as
+// lsa_keypoint_bboxes_begin left it on the device (nothing is read back); or none: the whole map.
+static int build_submap_begin(lsa_device_grid* g, const float mn[3], const float mx[3], int box_type, int min_nb_points, int slot, int type)
 {
-  if (!g || slot < 0 || slot > 1 || type < 0 || type > 2 || (mn && !mx)) return g ? g->ctx->fail(LSA_E_ARG, "lsa_device_grid_build_submap: bad argument") : LSA_E_ARG;
+  if (!g || slot < 0 || slot > 1 || type < 0 || type > 2 || (mn && !mx) || box_type > 2)
+    return g ? g->ctx->fail(LSA_E_ARG, "lsa_device_grid_build_submap: bad argument") : LSA_E_ARG;
   lsa_ctx* ctx = g->ctx;
+  if (g->sub_target >= 0) return ctx->fail(LSA_E_STATE, "lsa_device_grid_build_submap_begin: the previous one has not been ended");
   G_HIP(hipSetDevice(ctx->device));
   const int ti = slot * 3 + type;
-  Target& t = ctx->target[ti];
+  g->sub_target = ti;
   g->submap_valid = true;
-  if (g->n_upper == 0) { t.m = 0; g->submap_count = 0; (void)hipEventSynchronize(g->ev_state); g->host_st[kStUpdated] = 0; return 0; }
+  *g->host_sub = 0;
+  if (g->n_upper == 0) return LSA_OK;
   int rc = ensure_map(g, g->n_upper);
   if (rc) return rc;
   rc = ensure_target(ctx, ti, g->n_upper);
   if (rc) return rc;
+  rc = order_after_context(g);  // earlier matches may still read the target; the box words are the context's
+  if (rc) return rc;
+  Target& t = ctx->target[ti];
   const MapView m = g->buf[g->cur];
-  SubMapPred pred{m.keys, m.pts, m.count, g->st, {0, 0, 0}, {0, 0, 0}, g->GridSize, 0, g->MinFramesPerVoxel, min_nb_points, mn ? 1 : 0};
+  const bool boxed = mn || box_type >= 0;
+  SubMapPred pred{m.keys, m.pts, m.count, g->st, g->GridSize, 0, g->MinFramesPerVoxel, min_nb_points, boxed ? 1 : 0};
   bool filtered = false;
-  if (mn)
+  if (boxed)
   {
-    // the sub-grid the box touches (:365-370); PositionToVoxel on the host, with the grid position the device holds
-    G_HIP(hipEventSynchronize(g->ev_state));
-    for (int d = 0; d < 3; ++d)
-    {
-      float pos;
-      std::memcpy(&pos, &g->host_st[kStPosX + d], sizeof(float));
-      const float origin = pos - (float)(int(g->GridSize / 2) * g->VoxelResolution);
-      const float r = (float)g->VoxelResolution;
-      auto to_voxel = [&](float v) {
-        const float q = std::round((v - origin) / r);
-        return (q >= -2147483648.f && q < 2147483648.f) ? (int)q : std::numeric_limits<int>::min();
-      };
-      pred.lo[d] = std::max(to_voxel(mn[d]), 0);
-      pred.hi[d] = std::min(to_voxel(mx[d]), g->GridSize - 1);
-    }
+    BoxArg box{};
+    if (mn) for (int d = 0; d < 3; ++d) { box.mn[d] = mn[d]; box.mx[d] = mx[d]; }
+    const unsigned* words = mn ? nullptr : reinterpret_cast<const unsigned*>(ctx->range_bits + 16) + 6 * box_type;
+    hipLaunchKernelGGL(k_submap_box, dim3(1), dim3(64), 0, g->stream, box, words, params_of(g), g->st);
     filtered = !(min_nb_points < 0 || g->MinFramesPerVoxel <= 1);
     pred.mode = filtered ? 1 : 0;
   }
   {
-    ProfScope ps(ctx, "map_submap", (double)g->n_upper * 44);
+    ProfScope ps(ctx, "map_submap", (double)g->n_upper * 44, g->stream);
     compact(g, pred, PointEmit{m.pts, reinterpret_cast<float4*>(t.pts)}, g->st + kStN, g->n_upper, g->st + kStSub);
     if (filtered)
     {
@@ -936,20 +1000,47 @@ int lsa_device_grid_build_submap(lsa_device_grid* g, const float mn[3], const fl
       pred.mode = 2;
       // the second pass appends behind what the first one kept (its predicate reads the first pass's count from a slot
       // of its own: the total moves while it runs)
-      hipLaunchKernelGGL(k_copy_int, dim3(1), dim3(64), 0, ctx->stream, g->st + kStSubFirst, g->st + kStSub);
+      hipLaunchKernelGGL(k_copy_int, dim3(1), dim3(64), 0, g->stream, g->st + kStSubFirst, g->st + kStSub);
       compact(g, pred, PointEmit{m.pts, reinterpret_cast<float4*>(t.pts)}, g->st + kStN, g->n_upper, g->st + kStSub, true);
     }
   }
-  int kept = 0;
-  G_HIP(hipMemcpyAsync(&kept, g->st + kStSub, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-  G_HIP(hipStreamSynchronize(ctx->stream));
+  // the sub-map is of the map as it is now: the changes the Adds before it flagged are in it
+  hipLaunchKernelGGL(k_set_int, dim3(1), dim3(64), 0, g->stream, g->st + kStUpdated, 0);
+  G_HIP(hipMemcpyAsync(g->host_sub, g->st + kStSub, sizeof(int), hipMemcpyDeviceToHost, g->stream));
+  G_HIP(hipEventRecord(g->ev_sub, g->stream));
+  return order_context_after(g);
+}
+int lsa_device_grid_build_submap_begin(lsa_device_grid* g, const float mn[3], const float mx[3], int min_nb_points, int slot, int type)
+{
+  return build_submap_begin(g, mn, mx, -1, min_nb_points, slot, type);
+}
+int lsa_device_grid_build_submap_begin_for_keypoints(lsa_device_grid* g, int box_type, int min_nb_points, int slot, int type)
+{
+  if (box_type < 0) return g ? g->ctx->fail(LSA_E_ARG, "lsa_device_grid_build_submap_begin_for_keypoints: bad argument") : LSA_E_ARG;
+  if (g) g->ctx->bbox_pending = false;  // the box stays on the device: no lsa_keypoint_bboxes_end follows
+  return build_submap_begin(g, nullptr, nullptr, box_type, min_nb_points, slot, type);
+}
+int lsa_device_grid_build_submap_end(lsa_device_grid* g)
+{
+  if (!g) return LSA_E_ARG;
+  lsa_ctx* ctx = g->ctx;
+  if (g->sub_target < 0) return ctx->fail(LSA_E_STATE, "lsa_device_grid_build_submap_end: no lsa_device_grid_build_submap_begin before");
+  G_HIP(hipSetDevice(ctx->device));
+  Target& t = ctx->target[g->sub_target];
+  g->sub_target = -1;
+  if (g->n_upper > 0) G_HIP(hipEventSynchronize(g->ev_sub));
+  else G_HIP(hipEventSynchronize(g->ev_state));
+  const int kept = *g->host_sub;
   t.m = kept;
   t.dirty = kept > 0;
   g->submap_count = kept;
-  // the sub-map is of the map as it is now: the changes the Adds before it flagged are in it
-  hipLaunchKernelGGL(k_set_int, dim3(1), dim3(64), 0, ctx->stream, g->st + kStUpdated, 0);
-  g->host_st[kStUpdated] = 0;  // every refresh enqueued before the synchronize above has landed
+  g->host_st[kStUpdated] = 0;  // every refresh enqueued before the sub-map has landed
   return kept;
+}
+int lsa_device_grid_build_submap(lsa_device_grid* g, const float mn[3], const float mx[3], int min_nb_points, int slot, int type)
+{
+  const int rc = lsa_device_grid_build_submap_begin(g, mn, mx, min_nb_points, slot, type);
+  return rc ? rc : lsa_device_grid_build_submap_end(g);
 }
 
 // RollingGrid::IsSubMapKdTreeValid(): an Add that changed a voxel's point has dropped the sub-map (RollingGrid.cxx:315-317);
@@ -960,7 +1051,7 @@ int lsa_device_grid_submap_valid(lsa_device_grid* g)
   if (hipSetDevice(g->ctx->device) != hipSuccess || hipEventSynchronize(g->ev_state) != hipSuccess) return 0;
   if (g->host_st[kStUpdated])
   {
-    hipLaunchKernelGGL(k_set_int, dim3(1), dim3(64), 0, g->ctx->stream, g->st + kStUpdated, 0);
+    hipLaunchKernelGGL(k_set_int, dim3(1), dim3(64), 0, g->stream, g->st + kStUpdated, 0);
     g->host_st[kStUpdated] = 0;
     g->submap_valid = false;
   }

@@ -515,8 +515,8 @@ int lsa_stage_transformed(lsa_ctx* ctx, int set, const double pose[16])
 
 namespace lsa
 {
-// src (n points on the device) moved by `pose` into dst (device), on the context's stream
-int transform_points_to(lsa_ctx* ctx, const lsa_point_t* src, int n, const double pose[16], lsa_point_t* dst)
+// src (n points on the device) moved by `pose` into dst (device), on `stream` (the context's when null)
+int transform_points_to(lsa_ctx* ctx, const lsa_point_t* src, int n, const double pose[16], lsa_point_t* dst, hipStream_t stream)
 {
   if (n <= 0) return LSA_OK;
   StageOut so{};
@@ -525,7 +525,7 @@ int transform_points_to(lsa_ctx* ctx, const lsa_point_t* src, int n, const doubl
   so.n[0] = n;
   Rigid T;
   row_major_to_rt(pose, T.R, T.t);
-  hipLaunchKernelGGL(k_transform_stage, dim3((n + 255) / 256, 1), dim3(256), 0, ctx->stream, so, T);
+  hipLaunchKernelGGL(k_transform_stage, dim3((n + 255) / 256, 1), dim3(256), 0, stream ? stream : ctx->stream, so, T);
   return LSA_OK;
 }
 }  // namespace lsa

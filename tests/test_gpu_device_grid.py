@@ -181,3 +181,41 @@ def test_keypoints_of_the_context_go_into_the_map_without_leaving_the_device(ctx
     same_state(g, o)
     assert g.size() > 500
     g.close()
+
+
+def test_the_two_step_calls_of_the_pipeline(ctx):
+    """what lsa_slam does per keyframe: stage the keypoints on the caller's thread, insert them from ANOTHER thread on the
+    grid's own stream, then sub-maps of several grids side by side whose boxes are the keypoints' boxes left on the device
+    (nothing read back) -- same maps and sub-maps as the one-call forms and as the oracle"""
+    import threading
+
+    pts, _ = L.synth_frame(16, 1000, 0)
+    ctx.upload_frame(pts)
+    ctx.extract_keypoints()
+    ctx.reset_working_keypoints()
+    grids = {k: pair(ctx, LeafSize=leaf) for k, leaf in ((L.EDGE, 0.3), (L.PLANE, 0.6))}
+    for step in range(3):
+        T = np.eye(4)
+        T[:3, 3] = [2.0 * step, 0.5 * step, 0.0]
+        for k, (g, o) in grids.items():
+            g.stage_keypoints(L.SET_WORKING, k, T)
+        workers = [threading.Thread(target=g.add_staged, args=(0.1 * step,)) for g, _ in grids.values()]
+        for w in workers:
+            w.start()
+        for w in workers:
+            w.join()
+        for k, (g, o) in grids.items():
+            o.add(O.transform(ctx.keypoints(L.SET_WORKING, k), T), time=0.1 * step)
+            same_state(g, o)
+    # the box of the keypoints under a pose a little off the last keyframe's
+    T[:3, 3] += [25.0, 0.0, 0.0]
+    mn, mx = ctx.keypoint_bboxes(L.SET_WORKING, T)
+    ctx._check(ctx.L.lsa_keypoint_bboxes_begin(ctx.h, L.SET_WORKING, L.ptr(L.pose16(T))), "lsa_keypoint_bboxes_begin")
+    for k, (g, o) in grids.items():
+        g.build_submap_begin_for_keypoints(k, 50, ktype=k)
+    for k, (g, o) in grids.items():
+        n = g.build_submap_end()
+        assert n == o.build_submap(mn[k], mx[k], 50) and 0 < n < g.size()
+        assert ctx.target(k).tobytes() == o.submap().tobytes()
+        assert g.submap_valid()
+        g.close()

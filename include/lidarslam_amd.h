@@ -456,6 +456,8 @@ int lsa_transform_frame_at(lsa_ctx* ctx, int interpolate, const double H0[16], c
  * inputs.  fn: 0 lsa_sin(x) 1 lsa_cos(x) 2 lsa_atan2(y, x) 3 (float)sqrt((float)x)
  * 4 (float)x / (float)y  5 sqrt(x)  6 x / y.  Results as doubles. */
 int lsa_selftest_math(lsa_ctx* ctx, int fn, const double* x, const double* y, int n, double* out);
+/* Diagnostic: `blocks` single-wave workgroups sleep-spinning for `ms` (<= 2000) milliseconds on a side stream. */
+int lsa_selftest_keep_busy(lsa_ctx* ctx, int ms, int blocks);
 
 /* ------------------------------------------------------------------------- */
 /* Per-kernel timing of the last call sequence (HIP events on the context's   */

@@ -536,6 +536,13 @@ namespace
     if (e__ != hipSuccess) return g->ctx->fail(LSA_E_HIP, std::string(#call) + ": " + hipGetErrorString(e__)); \
   } while (0)
 
+// n_upper counts every point ever added; the exact number of voxels comes back with the state copy that follows each
+// modification, and replaces the bound as soon as the last of those copies has landed
+void tighten(lsa_device_grid* g)
+{
+  if (g->n_upper > 0 && hipEventQuery(g->ev_state) == hipSuccess) g->n_upper = std::min(g->n_upper, std::max(g->host_st[kStN], 0));
+}
+
 int order_after_context(lsa_device_grid* g)
 {
   G_HIP(hipEventRecord(g->ev_in, g->ctx->stream));
@@ -582,7 +589,7 @@ int ensure_map(lsa_device_grid* g, int want)
 {
   if (want > g->cap)
   {
-    const int cap = std::max(2 * want, 1 << 16);
+    const int cap = std::max(2 * want, 1 << 19);  // 46 MB for both buffers: growth (a device-wide stall) is rare
     G_HIP(hipStreamSynchronize(g->stream));
     MapView nb[2];
     for (int b = 0; b < 2; ++b)
@@ -687,6 +694,7 @@ int roll(lsa_device_grid* g, bool use_box)
 int add_batch(lsa_device_grid* g, int n, bool fixed, double time, bool do_roll)
 {
   hipStream_t st = g->stream;
+  tighten(g);
   int rc = ensure_map(g, g->n_upper + n);
   if (rc) return rc;
   const GridParams p = params_of(g);
@@ -970,6 +978,7 @@ static int build_submap_begin(lsa_device_grid* g, const float mn[3], const float
   g->sub_target = ti;
   g->submap_valid = true;
   *g->host_sub = 0;
+  tighten(g);
   if (g->n_upper == 0) return LSA_OK;
   int rc = ensure_map(g, g->n_upper);
   if (rc) return rc;

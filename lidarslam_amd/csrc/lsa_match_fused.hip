@@ -35,6 +35,7 @@ namespace
 constexpr int kPending = -2;  // neighbour count of a query no block of the grid settles
 constexpr int kShells = 7;
 constexpr int kFill = 3;       // a block is scanned first when it holds kFill x k points
+constexpr int kHeavyPerLane = 24;  // a block with more candidates per lane of its group than this is scanned by the whole wavefront
 
 __device__ __forceinline__ constexpr int shell_level(int s) { return s < 2 ? 0 : (s < 4 ? 1 : 2); }
 __device__ __forceinline__ constexpr int shell_r(int s) { return s == 6 ? 3 : ((s & 1) ? 2 : 1); }
@@ -332,13 +333,58 @@ __device__ __forceinline__ void scan_rows(LaneList<KMAX>& L, const RowTable& tb,
   }
 }
 
+// A block of the coarse levels next to a dense part of the target can hold a thousand candidates, and the launch lasts
+// as long as its longest walk.  Such a block is scanned by the WHOLE wavefront, one heavy group's after the other: the
+// group's table is in LDS, its query travels by lane reads, every lane keeps its k best and the 64 lists merge into the
+// group's slot in LDS -- where the lists all groups hold so far wait meanwhile (the caller puts them there and takes
+// them back: the registers go to the wavefront's lists).  Rare, and kept out of line: its registers are not the
+// kernel's.
+template <int KMAX>
+__device__ __noinline__ void scan_heavy_blocks(unsigned long long pending, int G, const RowTable tb, knn_key* save, const float4* s0, const float4* s1,
+                                               const float4* s2, int cur, int cbase, int nent, unsigned cand, float qx, float qy, float qz, int k, int* route)
+{
+  const int tid = threadIdx.x, lane = tid & 63;
+  while (pending)
+  {
+    const int lead = __ffsll((long long)pending) - 1;
+    pending &= pending - 1;
+    const int hcur = __shfl(cur, lead), hbase = __shfl(cbase, lead), hnent = __shfl(nent, lead);
+    const unsigned hcand = (unsigned)__shfl((int)cand, lead);
+    const float hx = __shfl(qx, lead), hy = __shfl(qy, lead), hz = __shfl(qz, lead);
+    const float4* hsorted = hcur < 2 ? s0 : (hcur < 4 ? s1 : s2);
+    knn_key* const hslot = save + (size_t)(((tid & ~63) + lead) / G) * KMAX;
+    LaneList<KMAX> H;
+    H.reset();
+    scan_rows<KMAX, 64>(H, tb, hbase, hnent, hcand, lane, hsorted, hx, hy, hz, nullptr);
+#pragma unroll
+    for (int s = 0; s < KMAX; ++s)
+    {
+      knn_key m = kKeyEmpty;
+      if (s < k)
+      {
+        m = H.v[0];
+        group_min<64>(m);
+        if (H.v[0] == m)
+        {
+#pragma unroll
+          for (int j = 0; j + 1 < KMAX; ++j) H.v[j] = H.v[j + 1];
+          H.v[KMAX - 1] = kKeyEmpty;
+        }
+      }
+      if (lane == 0) hslot[s] = m;
+    }
+    if (route && lane == 0) atomicAdd(&route[2], (int)hcand);
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the same wavefront wrote the slots: in order, only the counter to wait for
+}
+
 enum { kOutNone = 0, kOutFound = 1, kOutFar = 2, kOutTail = 3 };
 
 // The exact k nearest neighbours of this group's query: best[0 .. k) ascending by (distance, index), uniform across
 // the group.  Every lane of the wavefront calls it; groups without a query (active == false) come back with kOutNone.
 template <int KMAX, int G>
 __device__ __forceinline__ int group_search(const GridDesc* __restrict__ desc, const GridPtrs& gp, float qx, float qy, float qz, int k, float far_d2,
-                                            bool active, int gl, int tid, const RowTable& tb, knn_key (&best)[KMAX], float& ub_out, int* route)
+                                            bool active, int gl, int tid, const RowTable& tb, knn_key* save, knn_key (&best)[KMAX], float& ub_out, int* route)
 {
   constexpr int E1 = (9 + G - 1) / G, E2 = (25 + G - 1) / G, E3 = (49 + G - 1) / G;
   constexpr int CAP = table_capacity<G>();
@@ -439,11 +485,23 @@ __device__ __forceinline__ int group_search(const GridDesc* __restrict__ desc, c
   int sh2 = -1;
   if (__any(sh >= 0))
   {
+    const unsigned cand = sh >= 0 ? (total & 0xfffffu) : 0u;
+    const int nent = sh >= 0 ? (int)(total >> 20) : 0;
+    const bool heavy = cand > (unsigned)(kHeavyPerLane * G);
+    const unsigned long long pending = __ballot(heavy && gl == 0);
+    if (pending)  // nothing held yet: only the heavy groups' results come back
+      scan_heavy_blocks<KMAX>(pending, G, tb, save, gp.sorted[0], gp.sorted[1], gp.sorted[2], sh, base, nent, cand, qx, qy, qz, k, route);
     LaneList<KMAX> L;
     L.reset();
     const float4* sorted = sh < 2 ? gp.sorted[0] : (sh < 4 ? gp.sorted[1] : gp.sorted[2]);
-    scan_rows<KMAX, G>(L, tb, base, sh >= 0 ? (int)(total >> 20) : 0, sh >= 0 ? (total & 0xfffffu) : 0u, gl, sorted, qx, qy, qz, route);
-    merge_lists<KMAX, G>(L, k, best);
+    scan_rows<KMAX, G>(L, tb, base, heavy ? 0 : nent, heavy ? 0u : cand, gl, sorted, qx, qy, qz, route);
+    merge_lists<KMAX, G>(L, k, best, !heavy);
+    if (heavy)
+    {
+      const knn_key* slot = save + (size_t)((tid - gl) / G) * KMAX;
+#pragma unroll
+      for (int s = 0; s < KMAX; ++s) best[s] = slot[s];
+    }
     if (sh >= 0)
     {
       const float b2 = bound2(sh);
@@ -488,11 +546,23 @@ __device__ __forceinline__ int group_search(const GridDesc* __restrict__ desc, c
       const unsigned tot = fetch_any(fetch2 ? sh2 : 3, fetch2, cov);
       if (fetch2) { base2 = gbase; total2 = tot; }
     }
+    const unsigned cand = sh2 >= 0 ? (total2 & 0xfffffu) : 0u;
+    const int nent = sh2 >= 0 ? (int)(total2 >> 20) : 0;
+    const bool heavy = cand > (unsigned)(kHeavyPerLane * G);
+    const unsigned long long pending = __ballot(heavy && gl == 0);
+    if (pending)
+      scan_heavy_blocks<KMAX>(pending, G, tb, save, gp.sorted[0], gp.sorted[1], gp.sorted[2], sh2, base2, nent, cand, qx, qy, qz, k, route);
     LaneList<KMAX> L;
     L.reset();
     const float4* sorted = sh2 < 2 ? gp.sorted[0] : (sh2 < 4 ? gp.sorted[1] : gp.sorted[2]);
-    scan_rows<KMAX, G>(L, tb, base2, sh2 >= 0 ? (int)(total2 >> 20) : 0, sh2 >= 0 ? (total2 & 0xfffffu) : 0u, gl, sorted, qx, qy, qz, route);
-    merge_lists<KMAX, G>(L, k, best, sh2 >= 0);
+    scan_rows<KMAX, G>(L, tb, base2, heavy ? 0 : nent, heavy ? 0u : cand, gl, sorted, qx, qy, qz, route);
+    merge_lists<KMAX, G>(L, k, best, sh2 >= 0 && !heavy);
+    if (heavy)  // the second block holds the first: its k best are the answer
+    {
+      const knn_key* slot = save + (size_t)((tid - gl) / G) * KMAX;
+#pragma unroll
+      for (int s = 0; s < KMAX; ++s) best[s] = slot[s];
+    }
     if (sh2 >= 0) outcome = kOutFound;
   }
   return outcome;
@@ -530,6 +600,7 @@ struct FusedArgs
 struct SearchShared
 {
   uint32_t b[kTableEntries], e[kTableEntries], p[kTableEntries];  // the groups' row tables
+  knn_key save[(256 / 8) * 16];  // the groups' lists while the wavefront scans a heavy block for one of them
   int route[6];  // diagnostics: [0] second scans, [1] first block beyond shell 2, [2] candidates walked, [3] far, [4] first block = shell 0, [5] longest lane walk
 };
 
@@ -561,7 +632,7 @@ __device__ __forceinline__ void search_type(const Rigid& pose, const FusedType& 
   float ub = INFINITY;
   const unsigned long long tick0 = t.trace ? wall_clock64() : 0ull;
   const RowTable tb = {sh.b, sh.e, sh.p};
-  const int outcome = group_search<KMAX, G>(t.desc, t.gp, qx, qy, qz, t.k, t.far_d2, active, gl, tid, tb, best, ub, t.route_stats ? sh.route : nullptr);
+  const int outcome = group_search<KMAX, G>(t.desc, t.gp, qx, qy, qz, t.k, t.far_d2, active, gl, tid, tb, sh.save, best, ub, t.route_stats ? sh.route : nullptr);
   if (gl == 0 && active)
   {
     int cnt = 0;

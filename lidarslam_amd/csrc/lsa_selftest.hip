@@ -43,3 +43,21 @@ extern "C" int lsa_selftest_math(lsa_ctx* ctx, int fn, const double* x, const do
   LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return LSA_OK;
 }
+
+// Diagnostic (scripts/clock_probe.py): `blocks` single-wave workgroups that sleep-spin for `ms` milliseconds of the
+// constant 100 MHz wall clock on a stream of their own and then exit -- a load that occupies next to nothing, to see what the
+// clock management of a mostly idle GPU does to the latency of the pipeline's short kernels.
+__global__ void k_keep_busy(unsigned long long ticks)
+{
+  const unsigned long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+extern "C" int lsa_selftest_keep_busy(lsa_ctx* ctx, int ms, int blocks)
+{
+  if (!ctx || ms < 0 || ms > 2000 || blocks < 1 || blocks > 256) return ctx ? ctx->fail(LSA_E_ARG, "lsa_selftest_keep_busy: bad argument") : LSA_E_ARG;
+  LSA_HIP(ctx, hipSetDevice(ctx->device));
+  static hipStream_t side = nullptr;
+  if (!side) LSA_HIP(ctx, hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+  hipLaunchKernelGGL(k_keep_busy, dim3(blocks), dim3(64), 0, side, (unsigned long long)ms * 100000ull);
+  return LSA_OK;
+}

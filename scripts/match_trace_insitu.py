@@ -35,3 +35,15 @@ lt = ctx.solve_device_trace().astype(np.float64)
 if lt[6] > 0:
     print("LM solves %d, evaluations/solve %.2f, in-kernel us/solve %.1f; per evaluation us: evaluate %.2f exchange %.2f fold %.2f step %.2f" % (
         lt[6], lt[4] / lt[6], lt[5] / lt[6] / 100, lt[0] / lt[4] / 100, lt[1] / lt[4] / 100, lt[2] / lt[4] / 100, lt[3] / lt[4] / 100))
+
+dur = (mid - start)
+idx = np.argsort(-np.where(ok, dur, -1))[:25]
+print("slowest blocks: dur us | second scans, beyond shell2, candidates, far, shell0, longest lane walk")
+for i in idx:
+    print("  %5.1f | %s" % (dur[i], " ".join("%6d" % int(v) for v in tr[i, 4:10])))
+sel = np.nonzero(ok)[0]
+for name, col in (("second", 4), ("beyond2", 5), ("cands", 6), ("far", 7), ("shell0", 8), ("lanewalk", 9)):
+    c = np.corrcoef(dur[sel], tr[sel, col].astype(np.float64))[0, 1]
+    print("corr(dur, %s) = %.2f   mean %.1f" % (name, c, tr[sel, col].mean()))
+fast = sel[dur[sel] < np.percentile(dur[sel], 50)]
+print("fast half means:", [round(float(tr[fast, c].mean()), 1) for c in range(4, 10)])

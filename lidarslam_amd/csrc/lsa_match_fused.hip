@@ -35,7 +35,7 @@ namespace
 constexpr int kPending = -2;  // neighbour count of a query no block of the grid settles
 constexpr int kShells = 7;
 constexpr int kFill = 3;       // a block is scanned first when it holds kFill x k points
-constexpr int kHeavyPerLane = 24;  // a block with more candidates per lane of its group than this is scanned by the whole wavefront
+constexpr int kHeavyCandidates = 192;  // a block with more candidates than this is scanned by the whole wavefront
 
 __device__ __forceinline__ constexpr int shell_level(int s) { return s < 2 ? 0 : (s < 4 ? 1 : 2); }
 __device__ __forceinline__ constexpr int shell_r(int s) { return s == 6 ? 3 : ((s & 1) ? 2 : 1); }
@@ -487,7 +487,7 @@ __device__ __forceinline__ int group_search(const GridDesc* __restrict__ desc, c
   {
     const unsigned cand = sh >= 0 ? (total & 0xfffffu) : 0u;
     const int nent = sh >= 0 ? (int)(total >> 20) : 0;
-    const bool heavy = cand > (unsigned)(kHeavyPerLane * G);
+    const bool heavy = cand > (unsigned)kHeavyCandidates;
     const unsigned long long pending = __ballot(heavy && gl == 0);
     if (pending)  // nothing held yet: only the heavy groups' results come back
       scan_heavy_blocks<KMAX>(pending, G, tb, save, gp.sorted[0], gp.sorted[1], gp.sorted[2], sh, base, nent, cand, qx, qy, qz, k, route);
@@ -548,7 +548,7 @@ __device__ __forceinline__ int group_search(const GridDesc* __restrict__ desc, c
     }
     const unsigned cand = sh2 >= 0 ? (total2 & 0xfffffu) : 0u;
     const int nent = sh2 >= 0 ? (int)(total2 >> 20) : 0;
-    const bool heavy = cand > (unsigned)(kHeavyPerLane * G);
+    const bool heavy = cand > (unsigned)kHeavyCandidates;
     const unsigned long long pending = __ballot(heavy && gl == 0);
     if (pending)
       scan_heavy_blocks<KMAX>(pending, G, tb, save, gp.sorted[0], gp.sorted[1], gp.sorted[2], sh2, base2, nent, cand, qx, qy, qz, k, route);

@@ -229,6 +229,7 @@ struct lsa_ctx
   unsigned lm_tag = 0;            // tags handed out so far (every launch takes max evaluations + 2)
   unsigned long long lm_seq = 0;  // launches so far
   int lm_blocks = lsa::kLmBlocks;
+  int lm_records = 512;   // residual blocks per workgroup of the solve kernel the launch aims at (LSA_LM_RECORDS)
   int lm_cache_slots = 0;         // layers of residual blocks the solve kernel keeps in LDS (LSA_LM_CACHE caps it)
   int lm_fallbacks = 0;           // solves that timed out on the device and were redone by the host-driven loop
   // per match type a ring of kHistRing blocks of 16 ints ([8] rejection histogram + 2 hand-over counters of the kNN

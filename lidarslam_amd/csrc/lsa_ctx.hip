@@ -437,6 +437,7 @@ int lsa_ctx_create(int device_id, lsa_ctx** out)
   ctx->lm_cache_slots = lm_cache_capacity();
   if (const char* e = std::getenv("LSA_LM_CACHE")) ctx->lm_cache_slots = std::min(std::max(std::atoi(e), 0), ctx->lm_cache_slots);
   if (const char* e = std::getenv("LSA_LM_BLOCKS")) ctx->lm_blocks = std::min(std::max(std::atoi(e), 1), kLmBlocksMax);
+  if (const char* e = std::getenv("LSA_LM_RECORDS")) ctx->lm_records = std::min(std::max(std::atoi(e), 256), 4096);
   if (const char* e = std::getenv("LSA_ROUTE_STATS")) ctx->route_stats = std::atoi(e) != 0;
   if (ctx->route_stats) ok &= hipMalloc(&ctx->trace_dev, ((size_t)8192 * 12 + 16) * sizeof(unsigned long long)) == hipSuccess && hipMemset(ctx->trace_dev, 0, ((size_t)8192 * 12 + 16) * sizeof(unsigned long long)) == hipSuccess;
   if (const char* e = std::getenv("LSA_FUSED_MATCH")) ctx->fused_match = std::atoi(e) != 0;

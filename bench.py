@@ -58,7 +58,7 @@ def parse():
     ap.add_argument("--causal", action="store_true", help="headline leg without announcing the next cloud (no look-ahead)")
     ap.add_argument("--no-extra-legs", action="store_true", help="N=1: skip the replay_resident / causal_no_lookahead / batch_replay legs")
     ap.add_argument("--sequences-per-gpu", type=int, default=1, help="independent sequences replayed side by side on every GPU (the headline is 1: BASELINE.json shards 1 per GPU)")
-    ap.add_argument("--batch-sequences", type=int, default=4, help="N=1 only: extra leg with this many sequences side by side on the GPU, reported as batch_replay (0 disables)")
+    ap.add_argument("--batch-sequences", type=int, default=8, help="N=1 only: extra leg with this many sequences side by side on the GPU, reported as batch_replay (0 disables)")
     ap.add_argument("--no-numa-bind", action="store_true", help="leave the host threads wherever the scheduler puts them (default: on the GPU's NUMA node)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="nccl (= RCCL over xGMI, the real run); gloo rehearses the multi-rank path on a box with fewer GPUs than ranks (ranks then share devices)")
     ap.add_argument("--profile-all", action="store_true", help="time every scope in the timed region too (costs ~10 %% of the frame rate)")
@@ -394,9 +394,10 @@ def batch_replay(args, device):
         for s in rep.slams:
             s.set_param(name, float(value))
     fps = rep.run(args.warmup)
+    maps = "device" if rep.slams and rep.slams[0].get_param("DeviceMapsInUse") else "host"
     rep.close()
     return {"sequences_on_one_gpu": n, "value": fps, "unit": "frames/s", "per_sequence": fps / n, "steps": args.steps, "warmup": args.warmup,
-            "frames_from": "frame store in HBM, look-ahead extraction"}
+            "frames_from": "frame store in HBM, look-ahead extraction", "rolling_maps": maps}
 
 
 # kernel family -> device kernels, for looking the family up in the committed PMC table

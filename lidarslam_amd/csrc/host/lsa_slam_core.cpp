@@ -573,8 +573,6 @@ int SlamCore::ComputeEgoMotion()
     lsa_set_target_cell_size(Ctx, LSA_TARGET_PREVIOUS, k, static_cast<float>(k == LSA_EDGE ? KnnCellSizeEgoMotionEdges : KnnCellSizeEgoMotion));
     LSA_TRY(lsa_set_target_from_set(Ctx, LSA_TARGET_PREVIOUS, k, LSA_SET_RAW_PREVIOUS));
   }
-  // ... and those of the next frame, which are this frame's keypoints, are built beside this registration
-  LSA_TRY(PrepareNextEgoMotionTargets());
   TotalMatchedKeypoints = 0;
   lsa_match_params_t mp = EgoMatchParams();
 
@@ -587,6 +585,9 @@ int SlamCore::ComputeEgoMotion()
     // arrives with the optimizer's first evaluation
     LSA_TRY(lsa_match_types(Ctx, LSA_TARGET_PREVIOUS, (1u << LSA_EDGE) | (1u << LSA_PLANE), LSA_SET_RAW_CURRENT, &mp, Trelative.m, nullptr));
     for (int k : {LSA_EDGE, LSA_PLANE}) EgoMatchSerial[k] = lsa_match_serial(Ctx, k);
+    // the targets of the NEXT frame's ego-motion, which are this frame's keypoints, are built beside this registration:
+    // enqueued (ten launches on the look-ahead stream) once the first iteration's kernels are on their way
+    if (icpIter == 0) LSA_TRY(PrepareNextEgoMotionTargets());
     // while the device is busy with this iteration: sub-maps the workers have finished meanwhile go to the device
     if (!SpecPending) LSA_TRY(StageSpeculativeSubMaps());
     LSA_TRY(TryStartLookahead());
@@ -652,6 +653,7 @@ int SlamCore::Localization()
     Tick t;
     WaitMaps();  // the workers have enqueued the previous keyframe's insertions
     Stats.maps_wait = t.Stop();
+    Stats.maps_async = std::max(MapJobSeconds[0], std::max(MapJobSeconds[1], MapJobSeconds[2]));
     for (int k = 0; k < 3; ++k)
       if (MapJobFailed[k]) { MapJobFailed[k] = 0; return Fail(LSA_E_HIP, "lsa_device_grid_add_staged (map worker)"); }
     bool need[3], any = false;
@@ -957,7 +959,12 @@ int SlamCore::UpdateMapsUsingTworld()
       lsa_device_grid* grid = DevMaps[k];
       const double time = CurrentTime;
       int* failed = &MapJobFailed[k];
-      MapWorker[k].Submit([grid, time, failed] { if (lsa_device_grid_add_staged(grid, time) < 0) *failed = 1; });
+      double* spent = &MapJobSeconds[k];
+      MapWorker[k].Submit([grid, time, failed, spent] {
+        Tick t;
+        if (lsa_device_grid_add_staged(grid, time) < 0) *failed = 1;
+        *spent += t.Stop();  // host time of the enqueue (the kernels run on behind it)
+      });
     }
     return LSA_OK;
   }

@@ -21,6 +21,8 @@
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
+#include <chrono>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <string.h>
@@ -46,7 +48,7 @@ struct GridParams
   unsigned min_frames;
 };
 // state the kernels read and write (device memory, kStInts ints)
-enum { kStN = 0, kStNbPoints = 1, kStUpdated = 2, kStPosX = 3, kStGroups = 6, kStNew = 7, kStOff = 8, kStSub = 11, kStTmp = 12 /* 6 ints */, kStSubFirst = 18, kStCompact = 19, kStBox = 20 /* 6 ints: lo[3], hi[3] of the sub-map's box in voxels */, kStInts = 32 };
+enum { kStN = 0, kStNbPoints = 1, kStUpdated = 2, kStPosX = 3, kStGroups = 6, kStNew = 7, kStOff = 8, kStSub = 11, kStTmp = 12 /* 6 ints */, kStSubFirst = 18, kStCompact = 19, kStInts = 32 };
 
 __device__ __forceinline__ int round_to_int(float v)
 {
@@ -55,7 +57,9 @@ __device__ __forceinline__ int round_to_int(float v)
   return (r >= -2147483648.f && r < 2147483648.f) ? (int)r : (int)0x80000000;
 }
 
-// ---- stable compaction: chunk counts -> exclusive scan -> scatter (the predicate is evaluated twice) --------------------
+// ---- stable compaction: chunk counts -> scatter (the predicate is evaluated twice) ---------------------------------------
+// Two launches: every scatter block sums the counts of the chunks before it itself (a map of a few hundred thousand voxels
+// is a few hundred chunks), the last block leaves the total.
 template <typename Pred>
 __global__ __launch_bounds__(256) void k_compact_count(Pred pred, const int* __restrict__ n_ptr, int n_fixed, int* __restrict__ chunk_count)
 {
@@ -73,51 +77,44 @@ __global__ __launch_bounds__(256) void k_compact_count(Pred pred, const int* __r
   __syncthreads();
   if (threadIdx.x == 0) chunk_count[blockIdx.x] = cnt[0] + cnt[1] + cnt[2] + cnt[3];
 }
-__global__ __launch_bounds__(1024) void k_compact_scan(int* __restrict__ chunk_count, int nchunks, int* __restrict__ total, int add_to_total)
-{
-  __shared__ int s[1024];
-  int run = add_to_total ? *total : 0;
-  const int start = run;
-  for (int base = 0; base < nchunks; base += 1024)
-  {
-    const int i = base + threadIdx.x;
-    const int v = i < nchunks ? chunk_count[i] : 0;
-    s[threadIdx.x] = v;
-    __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1)
-    {
-      const int a = threadIdx.x >= (unsigned)o ? s[threadIdx.x - o] : 0;
-      __syncthreads();
-      s[threadIdx.x] += a;
-      __syncthreads();
-    }
-    if (i < nchunks) chunk_count[i] = run + s[threadIdx.x] - v;
-    run += s[1023];
-    __syncthreads();
-  }
-  (void)start;
-  if (threadIdx.x == 0) *total = run;
-}
+// total_out: where the number kept goes (never the word n_ptr points at: the other blocks still read that one);
+// base_ptr: the output starts behind *base_ptr elements (appending), at 0 when null
 template <typename Pred, typename Emit>
-__global__ __launch_bounds__(256) void k_compact_scatter(Pred pred, Emit emit, const int* __restrict__ n_ptr, int n_fixed, const int* __restrict__ chunk_start)
+__global__ __launch_bounds__(256) void k_compact_scatter(Pred pred, Emit emit, const int* __restrict__ n_ptr, int n_fixed, const int* __restrict__ chunk_count,
+                                                         const int* __restrict__ base_ptr, int* __restrict__ total_out,
+                                                         u64* __restrict__ host_out = nullptr, unsigned host_tag = 0, int* __restrict__ clear_flag = nullptr)
 {
   __shared__ int wave_cnt[4];
+  __shared__ int before[4];
   const int n = n_ptr ? *n_ptr : n_fixed;
-  if (blockIdx.x * 1024 >= n) return;
-  int run = chunk_start[blockIdx.x];
+  const bool last = blockIdx.x == gridDim.x - 1;
+  if (blockIdx.x * 1024 >= n && !last) return;
+  int mine = 0;
+  for (int c = threadIdx.x; c < (int)blockIdx.x; c += 256) mine += chunk_count[c];
+  for (int o = 32; o > 0; o >>= 1) mine += __shfl_down(mine, o);
+  if ((threadIdx.x & 63) == 0) before[threadIdx.x >> 6] = mine;
+  __syncthreads();
+  int run = (base_ptr ? *base_ptr : 0) + before[0] + before[1] + before[2] + before[3];
   for (int q = 0; q < 4; ++q)
   {
     const int i = blockIdx.x * 1024 + q * 256 + threadIdx.x;
     const bool keep = i < n && pred(i);
     const u64 ballot = __ballot(keep);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    __syncthreads();  // wave_cnt of the round before has been read
     if (lane == 0) wave_cnt[wv] = __popcll(ballot);
     __syncthreads();
     int base = run;
     for (int w = 0; w < wv; ++w) base += wave_cnt[w];
     if (keep) emit(i, base + __popcll(ballot & ((1ull << lane) - 1ull)));
     run += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
-    __syncthreads();
+  }
+  if (last && threadIdx.x == 0)
+  {
+    *total_out = run;
+    if (clear_flag) *clear_flag = 0;
+    // the total for the host: tag and count in ONE 8-byte store into coherent host memory (no copy, no event)
+    if (host_out) __hip_atomic_store(host_out, ((u64)host_tag << 32) | (u64)(unsigned)run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 
@@ -217,7 +214,11 @@ struct RollEmit
 };
 __global__ void k_after_roll(int* __restrict__ st)
 {
-  if (threadIdx.x == 0 && blockIdx.x == 0) st[kStNbPoints] = st[kStN];  // Roll recounts the points (RollingGrid.cxx:155)
+  if (threadIdx.x == 0 && blockIdx.x == 0)
+  {
+    st[kStN] = st[kStCompact];  // what the compaction kept
+    if (st[kStOff] | st[kStOff + 1] | st[kStOff + 2]) st[kStNbPoints] = st[kStCompact];  // Roll recounts the points when the grid moved (RollingGrid.cxx:136-137, 155)
+  }
 }
 
 // ---- Add (RollingGrid.cxx:160-318) ---------------------------------------------------------------------------------
@@ -402,6 +403,425 @@ __global__ void k_after_merge(int* __restrict__ st)
   }
 }
 
+// ---- Add in seven launches ------------------------------------------------------------------------------------------------
+// The chain above (bounding box, roll decision, roll compaction, keys, library sort, heads, fold, fresh compaction, merge,
+// state) is some twenty-five dependent launches; the next localization waits for the last of them.  This one does the same
+// work in seven: box -> keys of the batch + survivors of the roll counted -> runs of 4096 sorted in LDS -> runs merged by
+// rank -> fold per voxel (straight off the sorted batch) -> map = surviving old voxels (re-keyed) merged with the new ones
+// by rank -> state.  Nothing is decided in a launch of its own: every kernel works the roll's shift out for itself from the
+// committed grid position and the batch's box, and the last kernel commits position and counts.
+struct Shift
+{
+  int off[3];     // outer voxels the grid moves by (Roll, RollingGrid.cxx:117-157)
+  float pos[3];   // grid position after the move
+  bool any;
+};
+__device__ __forceinline__ Shift roll_shift(const GridParams& p, const int* __restrict__ st, int use_box)
+{
+  Shift s;
+  const double halfGridSize = static_cast<double>(p.grid_size) / 2 * p.resolution_d;
+  const float h = (float)halfGridSize;
+  s.any = false;
+#pragma unroll
+  for (int d = 0; d < 3; ++d)
+  {
+    const float pos = __int_as_float(st[kStPosX + d]);
+    int off = 0;
+    if (use_box)
+    {
+      const float mnv = o2f_i(st[kStTmp + d]), mxv = o2f_i(st[kStTmp + 3 + d]);
+      const float down = mnv - (pos - h);
+      const float up = mxv - (pos + h);
+      float o = (up + down) / 2.f;
+      const float lo = fminf(down, 0.f), hi = fmaxf(up, 0.f);
+      o = fminf(fmaxf(o, lo), hi);
+      off = round_to_int(o / p.resolution);
+    }
+    s.off[d] = off;
+    s.pos[d] = pos + (float)off * p.resolution;
+    s.any = s.any || off != 0;
+  }
+  return s;
+}
+// A voxel's place in the order of the map, comparable between the grid before and after a move: (z, y, x) of the outer
+// voxel in the coordinates BEFORE the move (biased, 21 bits each: a voxel that is about to enter the grid has coordinates
+// outside of it), then the leaf index.  Without a move the outer index itself does.
+struct VKey
+{
+  u64 hi;
+  unsigned lo;
+};
+__device__ __forceinline__ bool vless(const VKey& a, const VKey& b) { return a.hi < b.hi || (a.hi == b.hi && a.lo < b.lo); }
+__device__ __forceinline__ u64 biased3(int x, int y, int z)
+{
+  auto c = [](int v) { const int lim = (1 << 20) - 1; return (u64)(unsigned)((v < -lim ? -lim : (v > lim ? lim : v)) + (1 << 20)); };
+  return (c(z) << 42) | (c(y) << 21) | c(x);
+}
+__device__ __forceinline__ VKey vkey_of_old(u64 key, bool any, int g)
+{
+  VKey k;
+  k.lo = (unsigned)(key & 0xffffffffull);
+  int id = (int)(unsigned)(key >> 32);
+  if (!any) { k.hi = (u64)(unsigned)id; return k; }
+  const int z = id / (g * g); id -= z * g * g;
+  const int y = id / g; const int x = id - y * g;
+  k.hi = biased3(x, y, z);
+  return k;
+}
+// the key of a voxel of the grid AFTER the move, in that order
+__device__ __forceinline__ VKey vkey_of_new(u64 key, const Shift& s, int g)
+{
+  VKey k;
+  k.lo = (unsigned)(key & 0xffffffffull);
+  int id = (int)(unsigned)(key >> 32);
+  if (!s.any) { k.hi = (u64)(unsigned)id; return k; }
+  const int z = id / (g * g); id -= z * g * g;
+  const int y = id / g; const int x = id - y * g;
+  k.hi = biased3(x + s.off[0], y + s.off[1], z + s.off[2]);
+  return k;
+}
+__device__ __forceinline__ int lower_bound_old(const u64* __restrict__ keys, int n, const VKey& t, bool any, int g)
+{
+  int lo = 0, hi = n;
+  while (lo < hi)
+  {
+    const int mid = (lo + hi) >> 1;
+    if (vless(vkey_of_old(keys[mid], any, g), t)) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+// does the voxel survive the move, and under which key
+__device__ __forceinline__ bool shifted_key(u64 k, const Shift& s, int g, u64& out)
+{
+  int id = (int)(unsigned)(k >> 32);
+  int z = id / (g * g);
+  id -= z * g * g;
+  int y = id / g;
+  int x = id - y * g;
+  x -= s.off[0]; y -= s.off[1]; z -= s.off[2];
+  if (x < 0 || y < 0 || z < 0 || x >= g || y >= g || z >= g) return false;
+  out = ((u64)(unsigned)(z * g * g + y * g + x) << 32) | (k & 0xffffffffull);
+  return true;
+}
+
+// launch 2: blocks [0, kblocks): the keys of the batch in the grid after the move; the others: 1024 old voxels each, which
+// of them survive the move -- every voxel's rank among the survivors of its chunk, and the chunk's count
+__global__ __launch_bounds__(256) void k_add_keys(const float4* __restrict__ batch, int n, int kblocks, GridParams p, const int* __restrict__ st, int use_box,
+                                                  u64* __restrict__ keys, const u64* __restrict__ old_keys, int* __restrict__ old_local,
+                                                  int* __restrict__ old_chunks)
+{
+  const Shift s = roll_shift(p, st, use_box);
+  const int g = p.grid_size;
+  if ((int)blockIdx.x < kblocks)
+  {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float4 a = batch[2 * (size_t)i];
+    const float pt[3] = {a.x, a.y, a.z};
+    int out[3], in[3];
+    bool inside = true;
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+    {
+      // voxelGridOrigin = VoxelGridPosition - int(GridSize / 2) * VoxelResolution (:177)
+      const float origin = s.pos[d] - (float)((double)(g / 2) * p.resolution_d);
+      out[d] = round_to_int((pt[d] - origin) / p.resolution);
+      inside = inside && out[d] >= 0 && out[d] < g;
+      const float center = (float)out[d] * p.resolution + origin;
+      in[d] = round_to_int((pt[d] - center) / p.leaf);
+    }
+    const unsigned idx_out = (unsigned)(out[2] * g * g + out[1] * g + out[0]);
+    const unsigned idx_in = (unsigned)(in[2] * g * g + in[1] * g + in[0]);  // possibly "negative": the reference's own index (:200-202)
+    keys[i] = inside ? (((u64)idx_out << 32) | idx_in) : kNoKey;
+    return;
+  }
+  __shared__ int wave_cnt[4];
+  const int chunk = blockIdx.x - kblocks;
+  const int N = st[kStN];
+  int run = 0;
+  for (int q = 0; q < 4; ++q)
+  {
+    const int i = chunk * 1024 + q * 256 + threadIdx.x;
+    u64 nk;
+    const bool keep = i < N && shifted_key(old_keys[i], s, g, nk);
+    const u64 ballot = __ballot(keep);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) wave_cnt[wv] = __popcll(ballot);
+    __syncthreads();
+    int base = run;
+    for (int w = 0; w < wv; ++w) base += wave_cnt[w];
+    if (i < N) old_local[i] = base + __popcll(ballot & ((1ull << lane) - 1ull));
+    run += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+  }
+  if (threadIdx.x == 0) old_chunks[chunk] = run;
+}
+
+// launch 3: runs of 4096 (key, arrival index) pairs sorted in LDS (bitonic; the pairs are unique, so the order is the
+// stable order by key)
+constexpr int kRun = 4096;
+__global__ __launch_bounds__(1024) void k_sort_runs(const u64* keys, int n, u64* out_keys, unsigned* __restrict__ out_idx)  // keys == out_keys: in place, run by run
+{
+  __shared__ u64 sk[kRun];
+  __shared__ unsigned si[kRun];
+  const int base = blockIdx.x * kRun;
+  for (int t = threadIdx.x; t < kRun; t += 1024)
+  {
+    const int i = base + t;
+    sk[t] = i < n ? keys[i] : kNoKey;
+    si[t] = i < n ? (unsigned)i : 0xffffffffu;
+  }
+  __syncthreads();
+  for (int k = 2; k <= kRun; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1)
+    {
+      for (int t = threadIdx.x; t < kRun / 2; t += 1024)
+      {
+        // the t-th pair of this step: a = t with a zero inserted at bit log2(j)
+        const int a = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+        const int b = a | j;
+        const bool up = (a & k) == 0;
+        const u64 ka = sk[a], kb = sk[b];
+        const unsigned ia = si[a], ib = si[b];
+        const bool gt = ka > kb || (ka == kb && ia > ib);
+        if (gt == up) { sk[a] = kb; sk[b] = ka; si[a] = ib; si[b] = ia; }
+      }
+      __syncthreads();
+    }
+  for (int t = threadIdx.x; t < kRun; t += 1024)
+  {
+    const int i = base + t;
+    if (i < n) { out_keys[i] = sk[t]; out_idx[i] = si[t]; }
+  }
+}
+// launch 4 (more than one run): every pair's place is the number of pairs of all runs in front of it
+__global__ __launch_bounds__(256) void k_merge_runs(const u64* __restrict__ keys, const unsigned* __restrict__ idx, int n, u64* __restrict__ out_keys,
+                                                    unsigned* __restrict__ out_idx)
+{
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= n) return;
+  const u64 k = keys[e];
+  const unsigned id = idx[e];
+  const int mine = e / kRun;
+  int rank = e - mine * kRun;
+  for (int q = 0; q * kRun < n; ++q)
+  {
+    if (q == mine) continue;
+    int lo = q * kRun, hi = min(n, (q + 1) * kRun);
+    const int first = lo;
+    while (lo < hi)
+    {
+      const int mid = (lo + hi) >> 1;
+      const u64 km = keys[mid];
+      if (km < k || (km == k && idx[mid] < id)) lo = mid + 1; else hi = mid;
+    }
+    rank += lo - first;
+  }
+  out_keys[rank] = k;
+  out_idx[rank] = id;
+}
+
+// launch 5: one thread per place of the sorted batch; the first of a run of equal keys folds the run's points into the
+// voxel, in arrival order, by the reference's per-point rule.  An existing voxel is updated where it is (the old array);
+// a new one is left at the thread's own place in `fresh`, flagged, with its rank among the new ones of the block.
+__global__ __launch_bounds__(256) void k_add_fold(const float4* __restrict__ batch, int n, const u64* __restrict__ skeys, const unsigned* __restrict__ sorder,
+                                                  GridParams p, int* __restrict__ st, int use_box, MapView map, MapView fresh, int* __restrict__ fresh_flag,
+                                                  int* __restrict__ fresh_chunks, int fixed, double time)
+{
+  __shared__ int wave_cnt[4];
+  const Shift sft = roll_shift(p, st, use_box);
+  const int g = p.grid_size;
+  const int j0 = blockIdx.x * 256 + threadIdx.x;
+  const u64 key = j0 < n ? skeys[j0] : kNoKey;
+  const bool head = j0 < n && key != kNoKey && (j0 == 0 || skeys[j0 - 1] != key);
+  bool is_fresh = false;
+  if (head)
+  {
+    const int N = st[kStN];
+    const VKey target = vkey_of_new(key, sft, g);
+    const int at = lower_bound_old(map.keys, N, target, sft.any, g);
+    bool exists = false;
+    if (at < N)
+    {
+      const VKey k = vkey_of_old(map.keys[at], sft.any, g);
+      exists = k.hi == target.hi && k.lo == target.lo;
+    }
+    float4 va, vb;      // the voxel's point
+    unsigned count = 0;
+    bool have = exists;
+    bool changed = false;
+    if (exists) { va = map.pts[2 * (size_t)at]; vb = map.pts[2 * (size_t)at + 1]; count = map.count[at]; }
+    else { va = make_float4(0.f, 0.f, 0.f, 0.f); vb = va; }
+    // CENTER_POINT (:253): the centre is that of the leaf voxel of the point at hand, voxelGridCenterIn - VoxelResolution / 2.f
+    // + LeafSize * voxelCoordIn -- two leaf voxels of one outer voxel can share an inner index (To1d of coordinates around
+    // zero), so the points of one run do not all have the same centre
+    float base[3] = {0.f, 0.f, 0.f};  // voxelGridCenterIn: the same for the whole run
+    if (p.sampling == 3)
+    {
+      int id = (int)(unsigned)(key >> 32);
+      const int oz = id / (g * g); id -= oz * g * g;
+      const int oy = id / g; const int ox = id - oy * g;
+      const int out[3] = {ox, oy, oz};
+#pragma unroll
+      for (int d = 0; d < 3; ++d)
+      {
+        const float origin = sft.pos[d] - (float)((double)(g / 2) * p.resolution_d);
+        base[d] = (float)out[d] * p.resolution + origin;
+      }
+    }
+    bool counted = false;
+    for (int j = j0; j < n && skeys[j] == key; ++j)
+    {
+      const unsigned src = sorder[j];
+      const float4 a = batch[2 * (size_t)src], b = batch[2 * (size_t)src + 1];
+      if (!have)
+      {
+        va = a; vb = b; have = true; changed = true;  // new voxel: the point as it is (:206-212)
+      }
+      else
+      {
+        const unsigned label = (__float_as_uint(vb.w) >> 24) & 0xffu;
+        if (label == 1) continue;  // the voxel holds a fixed point: nothing of this point is taken, not even its time (:219-220)
+        if (p.sampling == 1) { va = a; vb = b; changed = true; }                       // LAST
+        else if (p.sampling == 2) { if (b.z > vb.z) { va = a; vb = b; changed = true; } }  // MAX_INTENSITY
+        else if (p.sampling == 3)
+        {
+          const float pt[3] = {a.x, a.y, a.z};
+          float centre[3];
+#pragma unroll
+          for (int d = 0; d < 3; ++d) centre[d] = base[d] - p.resolution / 2.f + p.leaf * (float)round_to_int((pt[d] - base[d]) / p.leaf);
+          const float d1x = a.x - centre[0], d1y = a.y - centre[1], d1z = a.z - centre[2];
+          const float d0x = va.x - centre[0], d0y = va.y - centre[1], d0z = va.z - centre[2];
+          // Eigen's Vector3f norm: sqrt(x^2 + (y^2 + z^2))
+          if (sqrtf(d1x * d1x + (d1y * d1y + d1z * d1z)) < sqrtf(d0x * d0x + (d0y * d0y + d0z * d0z))) { va = a; vb = b; changed = true; }
+        }
+      }
+      // voxel.point.time = currentTime; label = fixed (:300-306); one count per Add call (:307-311)
+      const long long tb = __double_as_longlong(time);
+      vb.x = __int_as_float((int)(tb & 0xffffffffll));
+      vb.y = __int_as_float((int)(tb >> 32));
+      vb.w = __uint_as_float((__float_as_uint(vb.w) & 0x00ffffffu) | ((fixed ? 1u : 0u) << 24));
+      if (!counted) { ++count; counted = true; }
+    }
+    if (exists)
+    {
+      map.pts[2 * (size_t)at] = va;
+      map.pts[2 * (size_t)at + 1] = vb;
+      map.count[at] = count;
+    }
+    else
+    {
+      is_fresh = true;
+      fresh.keys[j0] = key;
+      fresh.pts[2 * (size_t)j0] = va;
+      fresh.pts[2 * (size_t)j0 + 1] = vb;
+      fresh.count[j0] = count;
+    }
+    if (changed) st[kStUpdated] = 1;
+  }
+  // rank of every place among the block's new voxels (the places that hold none get the rank the next one would)
+  const u64 ballot = __ballot(is_fresh);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (lane == 0) wave_cnt[wv] = __popcll(ballot);
+  __syncthreads();
+  int before = 0;
+  for (int w = 0; w < wv; ++w) before += wave_cnt[w];
+  if (j0 < n) fresh_flag[j0] = ((before + __popcll(ballot & ((1ull << lane) - 1ull))) << 1) | (is_fresh ? 1 : 0);
+  if (threadIdx.x == 0) fresh_chunks[blockIdx.x] = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+}
+
+// launch 6: the new map.  Blocks [0, oblocks): 1024 old voxels each -- a survivor's place is its rank among the survivors
+// plus the number of new voxels in front of it; the other blocks: 256 places of the sorted batch each -- a new voxel's
+// place is its rank among the new ones plus the number of survivors in front of it.  Every block scans the chunk counts
+// of both arrays for itself (dynamic LDS: ochunks + fchunks + 2 ints).
+__global__ __launch_bounds__(256) void k_add_merge(GridParams p, int* __restrict__ st, int use_box, MapView old, const int* __restrict__ old_local,
+                                                   const int* __restrict__ old_chunks, int ochunks, int oblocks, const u64* __restrict__ skeys, int n, MapView fresh,
+                                                   const int* __restrict__ fresh_flag, const int* __restrict__ fresh_chunks, int fchunks, MapView dst)
+{
+  extern __shared__ int scan[];  // [ochunks + 1] exclusive scan of the survivors per chunk, then [fchunks + 1] of the new voxels per block
+  __shared__ int carry;
+  int* const oscan = scan;
+  int* const fscan = scan + ochunks + 1;
+  const Shift sft = roll_shift(p, st, use_box);
+  const int g = p.grid_size;
+  const int N = st[kStN];
+  // both scans, 256 entries at a time
+  for (int which = 0; which < 2; ++which)
+  {
+    const int* src = which ? fresh_chunks : old_chunks;
+    int* out = which ? fscan : oscan;
+    const int cnt = which ? fchunks : ochunks;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int b0 = 0; b0 < cnt; b0 += 256)
+    {
+      const int c = b0 + threadIdx.x;
+      const int v = c < cnt ? src[c] : 0;
+      int inc = v;
+      for (int o = 1; o < 64; o <<= 1)
+      {
+        const int t = __shfl_up(inc, o);
+        if ((threadIdx.x & 63) >= o) inc += t;
+      }
+      __shared__ int wsum[4];
+      if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = inc;
+      __syncthreads();
+      int add = carry;
+      for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) add += wsum[w];
+      if (c < cnt) out[c] = add + inc - v;
+      __syncthreads();
+      if (threadIdx.x == 255) carry = add + inc;
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) out[cnt] = carry;
+    __syncthreads();
+  }
+  const int survivors = oscan[ochunks], created = fscan[fchunks];
+  if (blockIdx.x == 0 && threadIdx.x == 0) { st[kStCompact] = survivors; st[kStNew] = created; }
+  auto fresh_before = [&](int j) { return j >= n ? created : fscan[j >> 8] + (fresh_flag[j] >> 1); };
+  auto survivors_before = [&](int i) { return i >= N ? survivors : oscan[i >> 10] + old_local[i]; };
+  if ((int)blockIdx.x < oblocks)
+  {
+    for (int q = 0; q < 4; ++q)
+    {
+      const int i = blockIdx.x * 1024 + q * 256 + threadIdx.x;
+      if (i >= N) continue;
+      u64 nk;
+      if (!shifted_key(old.keys[i], sft, g, nk)) continue;
+      const int at = survivors_before(i) + fresh_before(lower_bound_u64(skeys, n, nk));
+      dst.keys[at] = nk;
+      dst.pts[2 * (size_t)at] = old.pts[2 * (size_t)i];
+      dst.pts[2 * (size_t)at + 1] = old.pts[2 * (size_t)i + 1];
+      dst.count[at] = old.count[i];
+    }
+    return;
+  }
+  const int j = (blockIdx.x - oblocks) * 256 + threadIdx.x;
+  if (j >= n || !(fresh_flag[j] & 1)) return;
+  const u64 key = skeys[j];
+  const int at = fresh_before(j) + survivors_before(lower_bound_old(old.keys, N, vkey_of_new(key, sft, g), sft.any, g));
+  dst.keys[at] = key;
+  dst.pts[2 * (size_t)at] = fresh.pts[2 * (size_t)j];
+  dst.pts[2 * (size_t)at + 1] = fresh.pts[2 * (size_t)j + 1];
+  dst.count[at] = fresh.count[j];
+}
+// launch 7: the move and the counts become the grid's state (Roll recounts the points when the grid moved, :155)
+__global__ void k_add_commit(GridParams p, int* __restrict__ st, int use_box)
+{
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const Shift s = roll_shift(p, st, use_box);
+  const int survivors = st[kStCompact], created = st[kStNew];
+  st[kStNbPoints] = (s.any ? survivors : st[kStNbPoints]) + created;
+  st[kStN] = survivors + created;
+  for (int d = 0; d < 3; ++d)
+  {
+    st[kStOff + d] = s.off[d];
+    st[kStPosX + d] = __float_as_int(s.pos[d]);
+    st[kStTmp + d] = 0x7fffffff;            // the box is re-armed for the next batch
+    st[kStTmp + 3 + d] = (int)0x80000000;
+  }
+}
+
 // ---- ClearOldPoints (RollingGrid.cxx:325-351) ----------------------------------------------------------------------
 struct DecayPred
 {
@@ -428,13 +848,23 @@ struct CopyEmit
 };
 
 // ---- Get / BuildSubMapKdTree (RollingGrid.cxx:95-114, 353-442) ---------------------------------------------------------
+// the outer voxels the box [mn, mx] touches (:365-370): PositionToVoxel of both corners against the grid position the
+// device holds, clamped to the grid.  The box comes from the caller (floats) or from the bounding-box words the context's
+// lsa_keypoint_bboxes_begin left on the device (ordered unsigned, 6 per keypoint type).  Every thread works it out for
+// itself (a handful of operations against a launch of its own).
+__device__ __forceinline__ float ordered_to_float(unsigned u) { return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u); }
+struct BoxArg { float mn[3], mx[3]; };
 struct SubMapPred
 {
   const u64* keys;
   const float4* pts;
   const unsigned* count;
-  const int* st;   // st[kStBox ..]: lo[3], hi[3] of the box in outer voxels (k_submap_box)
+  const int* st;
+  BoxArg box;
+  const unsigned* ctx_box;
   int grid_size;
+  float resolution;
+  double resolution_d;
   int mode;          // 0 every voxel in the box; 1 count >= min_frames or fixed; 2 the others (count < min_frames and not fixed), only if pass 1 was short
   unsigned min_frames;
   int min_points;
@@ -447,9 +877,16 @@ struct SubMapPred
     const int g = grid_size;
     const int z = id / (g * g); id -= z * g * g;
     const int y = id / g; const int x = id - y * g;
-    const int* lo = st + kStBox;
-    const int* hi = st + kStBox + 3;
-    if (x < lo[0] || x > hi[0] || y < lo[1] || y > hi[1] || z < lo[2] || z > hi[2]) return false;
+    const int c[3] = {x, y, z};
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+    {
+      const float lo_f = ctx_box ? ordered_to_float(ctx_box[d]) : box.mn[d];
+      const float hi_f = ctx_box ? ordered_to_float(ctx_box[3 + d]) : box.mx[d];
+      const float origin = __int_as_float(st[kStPosX + d]) - (float)((double)(g / 2) * resolution_d);
+      const int lo = round_to_int((lo_f - origin) / resolution), hi = round_to_int((hi_f - origin) / resolution);
+      if (c[d] < (lo > 0 ? lo : 0) || c[d] > (hi < g - 1 ? hi : g - 1)) return false;
+    }
     if (mode == 0) return true;
     const unsigned label = (__float_as_uint(pts[2 * (size_t)i + 1].w) >> 24) & 0xffu;
     if (mode == 1) return count[i] >= min_frames || label == 1;
@@ -466,22 +903,6 @@ struct PointEmit
     out[2 * (size_t)at + 1] = pts[2 * (size_t)i + 1];
   }
 };
-// the outer voxels the box [mn, mx] touches (:365-370): PositionToVoxel of both corners against the grid position the
-// device holds, clamped to the grid.  The box comes from the caller (floats) or from the bounding-box words the context's
-// lsa_keypoint_bboxes_begin left on the device (ordered unsigned, 6 per keypoint type).
-__device__ __forceinline__ float ordered_to_float(unsigned u) { return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u); }
-struct BoxArg { float mn[3], mx[3]; };
-__global__ void k_submap_box(BoxArg box, const unsigned* __restrict__ ctx_box, GridParams p, int* __restrict__ st)
-{
-  const int d = threadIdx.x;
-  if (d >= 3 || blockIdx.x != 0) return;
-  const float lo_f = ctx_box ? ordered_to_float(ctx_box[d]) : box.mn[d];
-  const float hi_f = ctx_box ? ordered_to_float(ctx_box[3 + d]) : box.mx[d];
-  const float origin = __int_as_float(st[kStPosX + d]) - (float)((double)(p.grid_size / 2) * p.resolution_d);
-  const int lo = round_to_int((lo_f - origin) / p.resolution), hi = round_to_int((hi_f - origin) / p.resolution);
-  st[kStBox + d] = lo > 0 ? lo : 0;
-  st[kStBox + 3 + d] = hi < p.grid_size - 1 ? hi : p.grid_size - 1;
-}
 __global__ void k_set_int(int* __restrict__ p, int v) { if (threadIdx.x == 0 && blockIdx.x == 0) *p = v; }
 __global__ void k_copy_int(int* __restrict__ dst, const int* __restrict__ src) { if (threadIdx.x == 0 && blockIdx.x == 0) *dst = *src; }
 
@@ -510,8 +931,10 @@ struct lsa_device_grid
   // the scratch buffer written -- events order them: ev_in (context -> grid) before, ev_out (grid -> context) after.
   hipStream_t stream = nullptr;
   hipEvent_t ev_in = nullptr, ev_out = nullptr, ev_sub = nullptr;
-  int* host_sub = nullptr;     // pinned: the size of the sub-map being built
+  u64* host_sub = nullptr;     // coherent host memory: {tag, size} of the sub-map being built, one 8-byte store by the kernel
+  unsigned sub_tag = 0;
   int sub_target = -1;         // target index (slot * 3 + type) of the sub-map between _begin and _end
+  bool sub_pending = false;    // kernels of a sub-map are on their way
   int staged = 0;              // keypoints staged in `batch` by lsa_device_grid_stage_keypoints
   bool submap_valid = false;
   int submap_count = 0;
@@ -521,6 +944,8 @@ struct lsa_device_grid
   u64 *bkeys = nullptr, *skeys = nullptr;
   unsigned *border = nullptr, *sorder = nullptr;
   int *heads = nullptr, *fresh_flag = nullptr, *chunks = nullptr;
+  int* old_local = nullptr;    // [cap] rank of an old voxel among the survivors of its chunk (Add)
+  bool legacy_add = false;     // LSA_MAP_ADD=legacy: the chain of library sort and compactions the seven-launch Add replaced
   MapView fresh = {}, fresh2 = {};
   void* sort_tmp = nullptr;
   size_t sort_tmp_bytes = 0;
@@ -541,6 +966,13 @@ namespace
 void tighten(lsa_device_grid* g)
 {
   if (g->n_upper > 0 && hipEventQuery(g->ev_state) == hipSuccess) g->n_upper = std::min(g->n_upper, std::max(g->host_st[kStN], 0));
+}
+
+// a sub-map extraction (on the context's stream) reads the map and uses the grid's scratch: modifications come behind it
+int after_submap(lsa_device_grid* g)
+{
+  G_HIP(hipStreamWaitEvent(g->stream, g->ev_sub, 0));
+  return LSA_OK;
 }
 
 int order_after_context(lsa_device_grid* g)
@@ -610,6 +1042,9 @@ int ensure_map(lsa_device_grid* g, int want)
     g->buf[1] = nb[1];
     g->cur = 0;
     g->cap = cap;
+    if (g->old_local) (void)hipFree(g->old_local);
+    g->old_local = nullptr;
+    G_HIP(hipMalloc((void**)&g->old_local, (size_t)cap * sizeof(int)));
   }
   const int nchunks = (std::max(g->cap, g->bcap) + 1023) / 1024 + 1;
   if (nchunks > g->chunk_cap)
@@ -654,17 +1089,19 @@ int ensure_batch(lsa_device_grid* g, int n)
 // stable compaction of [0, n) (n on the device when n_ptr is given) by pred, emit(i, position); the number kept lands in
 // *total (added to what is there when `append`)
 template <typename Pred, typename Emit>
-void compact(lsa_device_grid* g, Pred pred, Emit emit, const int* n_ptr, int n_bound, int* total, bool append = false)
+void compact(lsa_device_grid* g, Pred pred, Emit emit, const int* n_ptr, int n_bound, int* total, bool append = false, bool copy_back = true,
+             hipStream_t on = nullptr, u64* host_out = nullptr, unsigned host_tag = 0, int* clear_flag = nullptr)
 {
-  hipStream_t st = g->stream;
+  hipStream_t st = on ? on : g->stream;
   const int nchunks = std::max((n_bound + 1023) / 1024, 1);
   hipLaunchKernelGGL((k_compact_count<Pred>), dim3(nchunks), dim3(256), 0, st, pred, n_ptr, n_bound, g->chunks);
-  // compacting in place of the count it reads (Roll, ClearOldPoints): the scatter still needs the old count, the new one
-  // waits in a slot of its own until it is through
-  int* const sum = (n_ptr == total) ? g->st + kStCompact : total;
-  hipLaunchKernelGGL(k_compact_scan, dim3(1), dim3(1024), 0, st, g->chunks, nchunks, sum, append ? 1 : 0);
-  hipLaunchKernelGGL((k_compact_scatter<Pred, Emit>), dim3(nchunks), dim3(256), 0, st, pred, emit, n_ptr, n_bound, g->chunks);
-  if (sum != total) hipLaunchKernelGGL(k_copy_int, dim3(1), dim3(64), 0, st, total, sum);
+  // compacting in place of the count it reads (Roll, ClearOldPoints), or appending behind it: the blocks of the
+  // scatter still read the old count, the new one waits in a slot of its own until they are through
+  const bool aside = n_ptr == total || append;
+  int* const sum = aside ? g->st + kStCompact : total;
+  hipLaunchKernelGGL((k_compact_scatter<Pred, Emit>), dim3(nchunks), dim3(256), 0, st, pred, emit, n_ptr, n_bound, g->chunks, append ? total : (const int*)nullptr, sum,
+                     host_out, host_tag, clear_flag);
+  if (aside && copy_back) hipLaunchKernelGGL(k_copy_int, dim3(1), dim3(64), 0, st, total, sum);  // otherwise the caller's next kernel takes it from st[kStCompact]
 }
 
 // the host's copy of the state follows every modification (asynchronously)
@@ -672,6 +1109,7 @@ int refresh_state(lsa_device_grid* g)
 {
   G_HIP(hipMemcpyAsync(g->host_st, g->st, kStInts * sizeof(int), hipMemcpyDeviceToHost, g->stream));
   G_HIP(hipEventRecord(g->ev_state, g->stream));
+  G_HIP(hipEventRecord(g->ev_out, g->stream));
   return LSA_OK;
 }
 
@@ -684,18 +1122,20 @@ int roll(lsa_device_grid* g, bool use_box)
   const MapView src = g->buf[g->cur], dst = g->buf[1 - g->cur];
   RollPred pred{src.keys, g->st, g->GridSize};
   RollEmit emit{pred, src, dst};
-  compact(g, pred, emit, g->st + kStN, std::max(g->n_upper, 1), g->st + kStN);
+  compact(g, pred, emit, g->st + kStN, std::max(g->n_upper, 1), g->st + kStN, false, false);
   hipLaunchKernelGGL(k_after_roll, dim3(1), dim3(64), 0, st, g->st);
   g->cur = 1 - g->cur;
   return LSA_OK;
 }
 
-// Add of the n points in g->batch (device)
-int add_batch(lsa_device_grid* g, int n, bool fixed, double time, bool do_roll)
+// Add of the n points in g->batch (device): the first version's chain, kept for comparison (LSA_MAP_ADD=legacy)
+int add_batch_legacy(lsa_device_grid* g, int n, bool fixed, double time, bool do_roll)
 {
   hipStream_t st = g->stream;
   tighten(g);
-  int rc = ensure_map(g, g->n_upper + n);
+  int rc = after_submap(g);
+  if (rc) return rc;
+  rc = ensure_map(g, g->n_upper + n);
   if (rc) return rc;
   const GridParams p = params_of(g);
   ProfScope ps(g->ctx, "map_add", (double)n * (32 + 12 + 44) + (double)g->n_upper * 44 * (do_roll ? 2 : 1), g->stream);
@@ -722,6 +1162,43 @@ int add_batch(lsa_device_grid* g, int n, bool fixed, double time, bool do_roll)
   return refresh_state(g);  // whether a point changed (the kd-tree is only dropped then, :315-317) is read by lsa_device_grid_submap_valid
 }
 
+// Add of the n points in g->batch (device)
+int add_batch(lsa_device_grid* g, int n, bool fixed, double time, bool do_roll)
+{
+  hipStream_t st = g->stream;
+  tighten(g);
+  {
+    const int rc = after_submap(g);
+    if (rc) return rc;
+  }
+  const int kblocks = (n + 255) / 256, ochunks = std::max((g->n_upper + 1023) / 1024, 1);
+  const size_t lds = (size_t)(ochunks + kblocks + 2) * sizeof(int);
+  if (g->legacy_add || lds > 48 * 1024) return add_batch_legacy(g, n, fixed, time, do_roll);
+  int rc = ensure_map(g, g->n_upper + n);
+  if (rc) return rc;
+  const GridParams p = params_of(g);
+  const int roll = do_roll ? 1 : 0;
+  ProfScope ps(g->ctx, "map_add", (double)n * (32 + 12 + 44) + (double)g->n_upper * 44 * 2, g->stream);
+  if (do_roll) hipLaunchKernelGGL(k_batch_bbox, dim3(kblocks), dim3(256), 0, st, g->batch, n, g->st);
+  const MapView map = g->buf[g->cur], dst = g->buf[1 - g->cur];
+  hipLaunchKernelGGL(k_add_keys, dim3(kblocks + ochunks), dim3(256), 0, st, g->batch, n, kblocks, p, g->st, roll, g->bkeys, map.keys, g->old_local, g->chunks);
+  const int runs = (n + kRun - 1) / kRun;
+  if (runs == 1) hipLaunchKernelGGL(k_sort_runs, dim3(1), dim3(1024), 0, st, g->bkeys, n, g->skeys, g->sorder);
+  else
+  {
+    hipLaunchKernelGGL(k_sort_runs, dim3(runs), dim3(1024), 0, st, g->bkeys, n, g->bkeys, g->border);
+    hipLaunchKernelGGL(k_merge_runs, dim3(kblocks), dim3(256), 0, st, g->bkeys, g->border, n, g->skeys, g->sorder);
+  }
+  hipLaunchKernelGGL(k_add_fold, dim3(kblocks), dim3(256), 0, st, g->batch, n, g->skeys, g->sorder, p, g->st, roll, map, g->fresh, g->fresh_flag, g->heads,
+                     fixed ? 1 : 0, time);
+  hipLaunchKernelGGL(k_add_merge, dim3(ochunks + kblocks), dim3(256), lds, st, p, g->st, roll, map, g->old_local, g->chunks, ochunks, ochunks, g->skeys, n, g->fresh,
+                     g->fresh_flag, g->heads, kblocks, dst);
+  hipLaunchKernelGGL(k_add_commit, dim3(1), dim3(64), 0, st, p, g->st, roll);
+  g->cur = 1 - g->cur;
+  g->n_upper += n;
+  return refresh_state(g);  // whether a point changed (the kd-tree is only dropped then, :315-317) is read by lsa_device_grid_submap_valid
+}
+
 }  // namespace
 
 extern "C" {
@@ -735,10 +1212,22 @@ int lsa_device_grid_create(lsa_ctx* ctx, lsa_device_grid** out)
   g->ctx = ctx;
   bool ok = hipMalloc((void**)&g->st, kStInts * sizeof(int)) == hipSuccess;
   ok = ok && hipHostMalloc((void**)&g->host_st, kStInts * sizeof(int), hipHostMallocDefault) == hipSuccess;
-  ok = ok && hipHostMalloc((void**)&g->host_sub, sizeof(int), hipHostMallocDefault) == hipSuccess;
-  ok = ok && hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking) == hipSuccess;
+  ok = ok && hipHostMalloc((void**)&g->host_sub, sizeof(u64), hipHostMallocCoherent | hipHostMallocMapped) == hipSuccess;
+  if (ok) *g->host_sub = 0;
+  {
+    // the map's chains of small dependent kernels are what the next localization waits for: they go first wherever the
+    // queues are shared (LSA_MAP_STREAM_PRIORITY=0: default priority)
+    int least = 0, greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+    const char* e = std::getenv("LSA_MAP_STREAM_PRIORITY");
+    const int prio = (e && std::atoi(e) == 0) ? least : greatest;
+    if (const char* k = std::getenv("LSA_MAP_STREAM_SKIP"))  // experiment: shifts the stream's place in the runtime's round robin over hardware queues
+      for (int i = 0; i < std::atoi(k); ++i) { hipStream_t pad; (void)hipStreamCreateWithFlags(&pad, hipStreamNonBlocking); }
+    ok = ok && hipStreamCreateWithPriority(&g->stream, hipStreamNonBlocking, prio) == hipSuccess;
+  }
   for (hipEvent_t* e : {&g->ev_state, &g->ev_in, &g->ev_out, &g->ev_sub}) ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
   if (!ok) { lsa_device_grid_destroy(g); return LSA_E_HIP; }
+  if (const char* e = std::getenv("LSA_MAP_ADD")) g->legacy_add = std::string(e) == "legacy";
   *out = g;
   return lsa_device_grid_reset(g, nullptr);
 }
@@ -751,7 +1240,7 @@ void lsa_device_grid_destroy(lsa_device_grid* g)
   (void)hipStreamSynchronize(g->ctx->stream);  // a match may still read a sub-map: nothing of the grid is in use after this
   free_view(g->buf[0]); free_view(g->buf[1]); free_view(g->fresh); free_view(g->fresh2);
   auto fr = [](void* p) { if (p) (void)hipFree(p); };
-  fr(g->st); fr(g->batch); fr(g->bkeys); fr(g->skeys); fr(g->border); fr(g->sorder); fr(g->heads); fr(g->fresh_flag); fr(g->chunks); fr(g->sort_tmp);
+  fr(g->st); fr(g->batch); fr(g->bkeys); fr(g->skeys); fr(g->border); fr(g->sorder); fr(g->heads); fr(g->fresh_flag); fr(g->chunks); fr(g->sort_tmp); fr(g->old_local);
   if (g->host_st) (void)hipHostFree(g->host_st);
   if (g->host_sub) (void)hipHostFree(g->host_sub);
   for (hipEvent_t e : {g->ev_state, g->ev_in, g->ev_out, g->ev_sub})
@@ -787,6 +1276,10 @@ int lsa_device_grid_clear(lsa_device_grid* g)
 {
   if (!g) return LSA_E_ARG;
   G_HIP(hipSetDevice(g->ctx->device));
+  {
+    const int rc = after_submap(g);
+    if (rc) return rc;
+  }
   hipLaunchKernelGGL(k_set_int, dim3(1), dim3(64), 0, g->stream, g->st + kStN, 0);
   hipLaunchKernelGGL(k_set_int, dim3(1), dim3(64), 0, g->stream, g->st + kStNbPoints, 0);
   g->n_upper = 0;
@@ -882,12 +1375,14 @@ int lsa_device_grid_stage_keypoints(lsa_device_grid* g, int set, int type, const
   G_HIP(hipSetDevice(ctx->device));
   int rc = ensure_batch(g, n);
   if (rc) return rc;
-  rc = order_after_context(g);
-  if (rc) return rc;
-  rc = transform_points_to(ctx, ctx->kp[set][type], n, pose, reinterpret_cast<lsa_point_t*>(g->batch), g->stream);
+  // the transform runs on the context's stream, in order with whatever rewrites the keypoints next (a few microseconds
+  // on a stream that is idle at the end of a frame); the grid's stream only waits for it.  The batch buffer is free: the
+  // last insertion that read it is over (ev_out, recorded behind every insertion).
+  G_HIP(hipStreamWaitEvent(ctx->stream, g->ev_out, 0));
+  rc = transform_points_to(ctx, ctx->kp[set][type], n, pose, reinterpret_cast<lsa_point_t*>(g->batch), ctx->stream);
   if (rc) return rc;
   g->staged = n;
-  return order_context_after(g);
+  return order_after_context(g);
 }
 int lsa_device_grid_add_staged(lsa_device_grid* g, double time)
 {
@@ -908,7 +1403,9 @@ int lsa_device_grid_roll(lsa_device_grid* g, const float mn[3], const float mx[3
 {
   if (!g || !mn || !mx) return LSA_E_ARG;
   G_HIP(hipSetDevice(g->ctx->device));
-  int rc = ensure_map(g, std::max(g->n_upper, 1));
+  int rc = after_submap(g);
+  if (rc) return rc;
+  rc = ensure_map(g, std::max(g->n_upper, 1));
   if (rc) return rc;
   int box[6];
   for (int d = 0; d < 3; ++d)
@@ -930,7 +1427,9 @@ int lsa_device_grid_clear_old_points(lsa_device_grid* g, double now)
 {
   if (!g) return LSA_E_ARG;
   G_HIP(hipSetDevice(g->ctx->device));
-  int rc = ensure_map(g, std::max(g->n_upper, 1));
+  int rc = after_submap(g);
+  if (rc) return rc;
+  rc = ensure_map(g, std::max(g->n_upper, 1));
   if (rc) return rc;
   const MapView src = g->buf[g->cur], dst = g->buf[1 - g->cur];
   compact(g, DecayPred{src.pts, now, g->DecayingThreshold}, CopyEmit{src, dst}, g->st + kStN, std::max(g->n_upper, 1), g->st + kStN);
@@ -950,9 +1449,9 @@ int lsa_device_grid_get(lsa_device_grid* g, int clean, lsa_point_t* out, int cap
   rc = ensure_scratch(ctx, (size_t)g->n_upper * sizeof(lsa_point_t));
   if (rc) return rc;
   const MapView m = g->buf[g->cur];
-  rc = order_after_context(g);  // the scratch buffer is the context's
+  rc = order_after_context(g);  // the scratch buffer is the context's; a sub-map extraction on its stream comes first too
   if (rc) return rc;
-  SubMapPred pred{m.keys, m.pts, m.count, g->st, g->GridSize, 0, g->MinFramesPerVoxel, -1, clean ? 3 : 0};
+  SubMapPred pred{m.keys, m.pts, m.count, g->st, BoxArg{}, nullptr, g->GridSize, (float)g->VoxelResolution, g->VoxelResolution, 0, g->MinFramesPerVoxel, -1, clean ? 3 : 0};
   compact(g, pred, PointEmit{m.pts, reinterpret_cast<float4*>(ctx->scratch_out)}, g->st + kStN, g->n_upper, g->st + kStSub);
   int kept = 0;
   G_HIP(hipMemcpyAsync(&kept, g->st + kStSub, sizeof(int), hipMemcpyDeviceToHost, g->stream));
@@ -977,47 +1476,49 @@ static int build_submap_begin(lsa_device_grid* g, const float mn[3], const float
   const int ti = slot * 3 + type;
   g->sub_target = ti;
   g->submap_valid = true;
-  *g->host_sub = 0;
   tighten(g);
   if (g->n_upper == 0) return LSA_OK;
   int rc = ensure_map(g, g->n_upper);
   if (rc) return rc;
   rc = ensure_target(ctx, ti, g->n_upper);
   if (rc) return rc;
-  rc = order_after_context(g);  // earlier matches may still read the target; the box words are the context's
-  if (rc) return rc;
+  // The extraction runs on the CONTEXT's stream, behind the grid's last modification (ev_out): the box words, the target
+  // and the next match are the context's anyway, so nothing else has to be ordered, and the size comes back through
+  // coherent host memory -- no copy, no event, no host call between the kernels.
+  hipStream_t st = ctx->stream;
+  G_HIP(hipStreamWaitEvent(st, g->ev_out, 0));
   Target& t = ctx->target[ti];
   const MapView m = g->buf[g->cur];
   const bool boxed = mn || box_type >= 0;
-  SubMapPred pred{m.keys, m.pts, m.count, g->st, g->GridSize, 0, g->MinFramesPerVoxel, min_nb_points, boxed ? 1 : 0};
+  SubMapPred pred{m.keys, m.pts, m.count, g->st, BoxArg{}, nullptr, g->GridSize, (float)g->VoxelResolution, g->VoxelResolution, 0, g->MinFramesPerVoxel, min_nb_points, boxed ? 1 : 0};
   bool filtered = false;
   if (boxed)
   {
-    BoxArg box{};
-    if (mn) for (int d = 0; d < 3; ++d) { box.mn[d] = mn[d]; box.mx[d] = mx[d]; }
-    const unsigned* words = mn ? nullptr : reinterpret_cast<const unsigned*>(ctx->range_bits + 16) + 6 * box_type;
-    hipLaunchKernelGGL(k_submap_box, dim3(1), dim3(64), 0, g->stream, box, words, params_of(g), g->st);
+    if (mn) for (int d = 0; d < 3; ++d) { pred.box.mn[d] = mn[d]; pred.box.mx[d] = mx[d]; }
+    pred.ctx_box = mn ? nullptr : reinterpret_cast<const unsigned*>(ctx->range_bits + 16) + 6 * box_type;
     filtered = !(min_nb_points < 0 || g->MinFramesPerVoxel <= 1);
     pred.mode = filtered ? 1 : 0;
   }
+  const unsigned tag = ++g->sub_tag;
   {
-    ProfScope ps(ctx, "map_submap", (double)g->n_upper * 44, g->stream);
-    compact(g, pred, PointEmit{m.pts, reinterpret_cast<float4*>(t.pts)}, g->st + kStN, g->n_upper, g->st + kStSub);
+    ProfScope ps(ctx, "map_submap", (double)g->n_upper * 44, st);
+    // the sub-map is of the map as it is now: the changes the Adds before it flagged are in it (the flag goes with the
+    // last kernel)
+    compact(g, pred, PointEmit{m.pts, reinterpret_cast<float4*>(t.pts)}, g->st + kStN, g->n_upper, g->st + kStSub, false, true, st, filtered ? nullptr : g->host_sub,
+            tag, filtered ? nullptr : g->st + kStUpdated);
     if (filtered)
     {
       // "Moving objects constraint was too strong, removing constraint": the rejected voxels follow when too few stayed
       pred.mode = 2;
       // the second pass appends behind what the first one kept (its predicate reads the first pass's count from a slot
       // of its own: the total moves while it runs)
-      hipLaunchKernelGGL(k_copy_int, dim3(1), dim3(64), 0, g->stream, g->st + kStSubFirst, g->st + kStSub);
-      compact(g, pred, PointEmit{m.pts, reinterpret_cast<float4*>(t.pts)}, g->st + kStN, g->n_upper, g->st + kStSub, true);
+      hipLaunchKernelGGL(k_copy_int, dim3(1), dim3(64), 0, st, g->st + kStSubFirst, g->st + kStSub);
+      compact(g, pred, PointEmit{m.pts, reinterpret_cast<float4*>(t.pts)}, g->st + kStN, g->n_upper, g->st + kStSub, true, true, st, g->host_sub, tag, g->st + kStUpdated);
     }
   }
-  // the sub-map is of the map as it is now: the changes the Adds before it flagged are in it
-  hipLaunchKernelGGL(k_set_int, dim3(1), dim3(64), 0, g->stream, g->st + kStUpdated, 0);
-  G_HIP(hipMemcpyAsync(g->host_sub, g->st + kStSub, sizeof(int), hipMemcpyDeviceToHost, g->stream));
-  G_HIP(hipEventRecord(g->ev_sub, g->stream));
-  return order_context_after(g);
+  G_HIP(hipEventRecord(g->ev_sub, st));  // the grid's next modification comes behind the extraction
+  g->sub_pending = true;
+  return LSA_OK;
 }
 int lsa_device_grid_build_submap_begin(lsa_device_grid* g, const float mn[3], const float mx[3], int min_nb_points, int slot, int type)
 {
@@ -1037,13 +1538,31 @@ int lsa_device_grid_build_submap_end(lsa_device_grid* g)
   G_HIP(hipSetDevice(ctx->device));
   Target& t = ctx->target[g->sub_target];
   g->sub_target = -1;
-  if (g->n_upper > 0) G_HIP(hipEventSynchronize(g->ev_sub));
+  int kept = 0;
+  if (g->sub_pending)
+  {
+    g->sub_pending = false;
+    // {tag, size} arrives as one 8-byte store (bounded wait: 2 s)
+    const auto t0 = std::chrono::steady_clock::now();
+    unsigned spins = 0;
+    while (true)
+    {
+      const u64 v = __atomic_load_n(g->host_sub, __ATOMIC_ACQUIRE);
+      if ((unsigned)(v >> 32) == g->sub_tag) { kept = (int)(unsigned)(v & 0xffffffffull); break; }
+      if ((++spins & 1023u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2))
+      {
+        G_HIP(hipStreamSynchronize(ctx->stream));  // surfaces a failed launch as an error rather than a timeout
+        return ctx->fail(LSA_E_HIP, "lsa_device_grid_build_submap_end: the sub-map's size did not arrive");
+      }
+    }
+    // every refresh of the state enqueued before the extraction has landed (the extraction came behind ev_out)
+    G_HIP(hipEventSynchronize(g->ev_state));
+  }
   else G_HIP(hipEventSynchronize(g->ev_state));
-  const int kept = *g->host_sub;
   t.m = kept;
   t.dirty = kept > 0;
   g->submap_count = kept;
-  g->host_st[kStUpdated] = 0;  // every refresh enqueued before the sub-map has landed
+  g->host_st[kStUpdated] = 0;
   return kept;
 }
 int lsa_device_grid_build_submap(lsa_device_grid* g, const float mn[3], const float mx[3], int min_nb_points, int slot, int type)
@@ -1058,12 +1577,7 @@ int lsa_device_grid_submap_valid(lsa_device_grid* g)
 {
   if (!g) return 0;
   if (hipSetDevice(g->ctx->device) != hipSuccess || hipEventSynchronize(g->ev_state) != hipSuccess) return 0;
-  if (g->host_st[kStUpdated])
-  {
-    hipLaunchKernelGGL(k_set_int, dim3(1), dim3(64), 0, g->stream, g->st + kStUpdated, 0);
-    g->host_st[kStUpdated] = 0;
-    g->submap_valid = false;
-  }
+  if (g->host_st[kStUpdated]) g->submap_valid = false;  // the flag is taken back by the next sub-map (lsa_device_grid_build_submap_begin)
   return g->submap_valid && g->submap_count > 0 ? 1 : 0;  // an empty sub-map counts as invalid (RollingGrid.h:154)
 }
 

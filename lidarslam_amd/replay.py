@@ -120,6 +120,12 @@ class ConcurrentReplay:
     def __init__(self, device, model, seeds, frames, lookahead=True, **params):
         import lidarslam_amd as L
 
+        # Where the rolling maps live ("MapsOnDevice", the caller's choice when given).  One sequence: on the device --
+        # nothing of the map crosses the bus and the frame does not wait for host threads (measured on MI355X, VLS-128:
+        # 830 against 680 frames/s).  Several sequences side by side: on the host -- a process has 4 hardware queues,
+        # the maps' chains of small kernels compete for them with the ICP kernels of the other sequences (8 sequences:
+        # 1580 against 2420 frames/s), and the host cores are there (2.5 per sequence against 1.4).
+        params.setdefault("MapsOnDevice", 1 if len(seeds) == 1 else 0)
         self.frames = frames
         self.lookahead = lookahead  # extract frame f + 1 beside the registration of frame f (same results)
         self.slams, self.stamps = [], []

@@ -136,6 +136,29 @@ def test_decaying_threshold_and_fixed_points(ctx):
     same_state(g, o)
     assert 0 < g.get().size < before == g.size()
     same_submap(g, o)
+    # Size() after the decay: an Add that does not move the grid keeps counting from the old figure (Roll returns before
+    # its recount, RollingGrid.cxx:136-137), one that moves it recounts
+    pts = cloud(rng, 800, np.array([8.0, 0, 0]), spread=8.0, t=1.0)
+    for m in (g, o):
+        m.add(pts, time=1.0)
+    same_state(g, o)
+    pts = cloud(rng, 800, np.array([60.0, 0, 0]), spread=8.0, t=1.1)
+    for m in (g, o):
+        m.add(pts, time=1.1)
+    same_state(g, o)
+    g.close()
+
+
+@pytest.mark.parametrize("n", [1, 255, 4096, 4097, 12289])
+def test_batches_around_the_sizes_the_sort_is_built_of(ctx, n):
+    """one point, just under a block, exactly one run of the LDS sort, one more, three runs and a bit"""
+    rng = np.random.default_rng(n)
+    g, o = pair(ctx, GridSize=30, VoxelResolution=6.0, LeafSize=0.5, Sampling=1)
+    for step in range(3):
+        pts = cloud(rng, n, np.array([step * 7.0, 0, 0]), spread=25.0, t=step * 0.1)
+        for m in (g, o):
+            m.add(pts, time=step * 0.1)
+        same_state(g, o)
     g.close()
 
 

@@ -396,6 +396,10 @@ int lsa_solve_device(lsa_ctx* ctx, unsigned type_mask, const double prior[6], in
 int lsa_solve_device_trace(lsa_ctx* ctx, unsigned long long out[8]);
 /* Solves the device gave up on so far (diagnostics; 0 on a healthy run). */
 int lsa_solve_device_fallbacks(const lsa_ctx* ctx);
+/* Host work for the time the next solve runs on the device: `fn(arg)` is called once, on the calling thread, by the
+ * next lsa_solve_device after it has enqueued its kernel and before it waits for the result (enqueueing work that does
+ * not depend on the solve, e.g. on another stream).  NULL withdraws it. */
+int lsa_solve_device_interlude(lsa_ctx* ctx, void (*fn)(void*), void* arg);
 /* LocalOptimizer::EstimateRegistrationError (LocalOptimizer.cxx:112-140) at `pose`: covariance
  * (row-major 6x6, DoF order X,Y,Z,rX,rY,rZ), err[0] position error [m], err[1] orientation error [deg]. */
 int lsa_registration_error(lsa_ctx* ctx, unsigned type_mask, const double pose[16], int two_d_mode, double cov[36], double err[2]);

@@ -65,7 +65,7 @@ ABI_SYMBOLS = [
     "lsa_slam_set_world_transform_from_guess", "lsa_slam_get_trajectory", "lsa_slam_get_debug_information", "lsa_slam_get_map",
     "lsa_slam_get_target_submap", "lsa_slam_set_base_to_lidar_offset", "lsa_slam_get_base_to_lidar_offset", "lsa_slam_add_frames", "lsa_slam_set_extractor_param", "lsa_slam_get_extractor_param", "lsa_match_serial", "lsa_match_histogram", "lsa_synth_sensor", "lsa_synth_frame",
     "lsa_synth_pose",
-    "lsa_selftest_keep_busy", "lsa_device_grid_create", "lsa_device_grid_destroy", "lsa_device_grid_set", "lsa_device_grid_get_param", "lsa_device_grid_reset", "lsa_device_grid_clear",
+    "lsa_selftest_keep_busy", "lsa_solve_device_interlude", "lsa_device_grid_create", "lsa_device_grid_destroy", "lsa_device_grid_set", "lsa_device_grid_get_param", "lsa_device_grid_reset", "lsa_device_grid_clear",
     "lsa_device_grid_size", "lsa_device_grid_add", "lsa_device_grid_add_keypoints", "lsa_device_grid_roll", "lsa_device_grid_clear_old_points",
     "lsa_device_grid_get", "lsa_device_grid_build_submap", "lsa_device_grid_submap_valid", "lsa_device_grid_stage_keypoints", "lsa_device_grid_add_staged",
     "lsa_device_grid_build_submap_begin", "lsa_device_grid_build_submap_begin_for_keypoints", "lsa_device_grid_build_submap_end",

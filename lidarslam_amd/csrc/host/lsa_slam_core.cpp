@@ -586,8 +586,20 @@ int SlamCore::ComputeEgoMotion()
     LSA_TRY(lsa_match_types(Ctx, LSA_TARGET_PREVIOUS, (1u << LSA_EDGE) | (1u << LSA_PLANE), LSA_SET_RAW_CURRENT, &mp, Trelative.m, nullptr));
     for (int k : {LSA_EDGE, LSA_PLANE}) EgoMatchSerial[k] = lsa_match_serial(Ctx, k);
     // the targets of the NEXT frame's ego-motion, which are this frame's keypoints, are built beside this registration:
-    // enqueued (ten launches on the look-ahead stream) once the first iteration's kernels are on their way
-    if (icpIter == 0) LSA_TRY(PrepareNextEgoMotionTargets());
+    // enqueued (ten launches on the look-ahead stream) while the first iteration's kernels -- the solve's included --
+    // are on their way
+    if (icpIter == 0)
+    {
+      InterludeDone = false;
+      InterludeStatus = 0;
+      if (DeviceLM)
+        lsa_solve_device_interlude(Ctx, [](void* self) {
+          SlamCore* core = static_cast<SlamCore*>(self);
+          core->InterludeStatus = core->PrepareNextEgoMotionTargets();
+          core->InterludeDone = true;
+        }, this);
+      else LSA_TRY(PrepareNextEgoMotionTargets());
+    }
     // while the device is busy with this iteration: sub-maps the workers have finished meanwhile go to the device
     if (!SpecPending) LSA_TRY(StageSpeculativeSubMaps());
     LSA_TRY(TryStartLookahead());
@@ -604,6 +616,13 @@ int SlamCore::ComputeEgoMotion()
     optimizer.UseDeviceResiduals((1u << LSA_EDGE) | (1u << LSA_PLANE));
     SolveSummary summary;
     LSA_TRY(optimizer.Solve(summary));
+    if (icpIter == 0 && DeviceLM)
+    {
+      // the solve did not get as far as its launch (it fell back to the host loop): the interlude is still due
+      lsa_solve_device_interlude(Ctx, nullptr, nullptr);
+      if (!InterludeDone) InterludeStatus = PrepareNextEgoMotionTargets();
+      if (InterludeStatus < 0) return InterludeStatus;
+    }
     TotalMatchedKeypoints = summary.num_matches;
     if (SpecPending)
     {

@@ -229,6 +229,8 @@ struct lsa_ctx
   unsigned lm_tag = 0;            // tags handed out so far (every launch takes max evaluations + 2)
   unsigned long long lm_seq = 0;  // launches so far
   int lm_blocks = lsa::kLmBlocks;
+  void (*solve_hook)(void*) = nullptr;  // lsa_solve_device_interlude
+  void* solve_hook_arg = nullptr;
   int lm_records = 512;   // residual blocks per workgroup of the solve kernel the launch aims at (LSA_LM_RECORDS)
   int lm_cache_slots = 0;         // layers of residual blocks the solve kernel keeps in LDS (LSA_LM_CACHE caps it)
   int lm_fallbacks = 0;           // solves that timed out on the device and were redone by the host-driven loop

@@ -1215,12 +1215,12 @@ int lsa_device_grid_create(lsa_ctx* ctx, lsa_device_grid** out)
   ok = ok && hipHostMalloc((void**)&g->host_sub, sizeof(u64), hipHostMallocCoherent | hipHostMallocMapped) == hipSuccess;
   if (ok) *g->host_sub = 0;
   {
-    // the map's chains of small dependent kernels are what the next localization waits for: they go first wherever the
-    // queues are shared (LSA_MAP_STREAM_PRIORITY=0: default priority)
+    // the insertion has half a frame before the next localization asks for the map, the ICP kernels it runs beside are
+    // the frame's critical path: they go first (LSA_MAP_STREAM_PRIORITY=1: the other way round)
     int least = 0, greatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
     const char* e = std::getenv("LSA_MAP_STREAM_PRIORITY");
-    const int prio = (e && std::atoi(e) == 0) ? least : greatest;
+    const int prio = (e && std::atoi(e) != 0) ? greatest : least;
     if (const char* k = std::getenv("LSA_MAP_STREAM_SKIP"))  // experiment: shifts the stream's place in the runtime's round robin over hardware queues
       for (int i = 0; i < std::atoi(k); ++i) { hipStream_t pad; (void)hipStreamCreateWithFlags(&pad, hipStreamNonBlocking); }
     ok = ok && hipStreamCreateWithPriority(&g->stream, hipStreamNonBlocking, prio) == hipSuccess;

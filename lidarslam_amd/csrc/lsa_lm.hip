@@ -550,6 +550,13 @@ int lsa_solve_device(lsa_ctx* ctx, unsigned type_mask, const double prior[6], in
     hipLaunchKernelGGL(k_lm_solve, dim3(nb), dim3(256), p.cslots * slot_bytes, ctx->stream, p, ctx->lm_xchg, ctx->lm_mailbox, out_tag,
                        ctx->route_stats && ctx->trace_dev ? reinterpret_cast<unsigned long long*>(ctx->trace_dev) + (size_t)8192 * 12 : nullptr);
   }
+  // host work the caller wants done while the kernel runs (one shot)
+  if (ctx->solve_hook)
+  {
+    void (*fn)(void*) = ctx->solve_hook;
+    ctx->solve_hook = nullptr;
+    fn(ctx->solve_hook_arg);
+  }
   // the result arrives as granules in coherent host memory (as lsa_accumulate's sums do)
   double res[kResCount];
   {
@@ -605,6 +612,14 @@ int lsa_solve_device(lsa_ctx* ctx, unsigned type_mask, const double prior[6], in
 }
 
 int lsa_solve_device_fallbacks(const lsa_ctx* ctx) { return ctx ? ctx->lm_fallbacks : 0; }
+
+int lsa_solve_device_interlude(lsa_ctx* ctx, void (*fn)(void*), void* arg)
+{
+  if (!ctx) return LSA_E_ARG;
+  ctx->solve_hook = fn;
+  ctx->solve_hook_arg = arg;
+  return LSA_OK;
+}
 
 int lsa_solve_device_trace(lsa_ctx* ctx, unsigned long long out[8])
 {

@@ -566,9 +566,9 @@ lsa_ctx* lsa_slam_context(lsa_slam* s);
 /* LidarSlam::RollingGrid ON THE DEVICE (slam_lib/include/LidarSlam/RollingGrid.h:63-212, slam_lib/src/RollingGrid.cxx): the
  * rolling voxel map of one keypoint type as ONE array of voxels sorted by (outer voxel index, leaf voxel index), living
  * in the memory of the context it was created on.  Add / Roll / ClearOldPoints / BuildSubMapKdTree are sequences of
- * kernels on a stream of the grid's own (sort of the batch, one thread per voxel folding the batch's points for it in
- * arrival order through the reference's per-point rule, merge by rank, stable compactions), ordered by events against
- * the context's stream wherever the two share data; the sub-map is written straight into a kNN target of the context.
+ * kernels on the context's look-ahead stream (runs of the batch sorted in LDS and merged by rank, one thread per voxel
+ * folding the batch's points for it in arrival order through the reference's per-point rule, old and new voxels merged
+ * by rank, stable compactions), ordered by events against the context's stream wherever the two share data; the sub-map is written straight into a kNN target of the context.
  * One grid is driven by one host thread at a time (not necessarily the context's).  Points come out in KEY ORDER (outer index, then leaf index) where the reference
  * hands them out in its hash containers' iteration order -- a defined order in place of an accidental one, adopted by
  * the oracle and the host grid as well ("OrderedMaps").  Sampling modes FIRST, LAST, MAX_INTENSITY, CENTER_POINT;

@@ -396,6 +396,7 @@ int SlamCore::ProcessCurrentFrame(uint64_t stampUs)
   CurrentStamp = stampUs;
   CurrentTime = StampToSec(stampUs);
   HaveFrame = true;
+  AheadWorker.Wait();  // it reads the previous frame's keypoint buffers, which the extraction is about to rotate (long done)
   lsa_set_knn_lanes(Ctx, LSA_EDGE, KnnLanesEdges);
   lsa_set_knn_lanes(Ctx, LSA_PLANE, KnnLanesPlanes);
   lsa_set_knn_lanes(Ctx, LSA_BLOB, KnnLanesBlobs);
@@ -548,6 +549,7 @@ lsa_match_params_t SlamCore::LocMatchParams() const
 int SlamCore::ComputeEgoMotion()
 {
   Trelative = Pose::Identity();
+  if (AheadStatus < 0) { const int rc = AheadStatus; AheadStatus = 0; return Fail(rc, "lsa_prepare_previous_targets (look-ahead thread)"); }
   if (LogTrajectory.size() >= 2 &&
       (EgoMotion == EgoMotionMode::MOTION_EXTRAPOLATION || EgoMotion == EgoMotionMode::MOTION_EXTRAPOLATION_AND_REGISTRATION))
   {
@@ -588,17 +590,12 @@ int SlamCore::ComputeEgoMotion()
     // the targets of the NEXT frame's ego-motion, which are this frame's keypoints, are built beside this registration:
     // enqueued (ten launches on the look-ahead stream) while the first iteration's kernels -- the solve's included --
     // are on their way
-    if (icpIter == 0)
+    // (ten launches and two copies on the look-ahead stream: a host thread of their own issues them, this one goes on
+    // to the solve)
+    if (icpIter == 0 && BuildTargetsAhead)
     {
-      InterludeDone = false;
-      InterludeStatus = 0;
-      if (DeviceLM)
-        lsa_solve_device_interlude(Ctx, [](void* self) {
-          SlamCore* core = static_cast<SlamCore*>(self);
-          core->InterludeStatus = core->PrepareNextEgoMotionTargets();
-          core->InterludeDone = true;
-        }, this);
-      else LSA_TRY(PrepareNextEgoMotionTargets());
+      AheadStatus = 0;
+      AheadWorker.Submit([this] { AheadStatus = PrepareNextEgoMotionTargets(); });
     }
     // while the device is busy with this iteration: sub-maps the workers have finished meanwhile go to the device
     if (!SpecPending) LSA_TRY(StageSpeculativeSubMaps());
@@ -616,13 +613,6 @@ int SlamCore::ComputeEgoMotion()
     optimizer.UseDeviceResiduals((1u << LSA_EDGE) | (1u << LSA_PLANE));
     SolveSummary summary;
     LSA_TRY(optimizer.Solve(summary));
-    if (icpIter == 0 && DeviceLM)
-    {
-      // the solve did not get as far as its launch (it fell back to the host loop): the interlude is still due
-      lsa_solve_device_interlude(Ctx, nullptr, nullptr);
-      if (!InterludeDone) InterludeStatus = PrepareNextEgoMotionTargets();
-      if (InterludeStatus < 0) return InterludeStatus;
-    }
     TotalMatchedKeypoints = summary.num_matches;
     if (SpecPending)
     {

@@ -287,11 +287,11 @@ private:
   bool SpecStaged[3] = {false, false, false};
   int StageSpeculativeSubMaps();
   double MapJobSeconds[3] = {0., 0., 0.};  // written by the workers, read after WaitMaps
-  bool InterludeDone = false;
-  int InterludeStatus = 0;                  // result of the work done between a solve's launch and its wait
+  HostWorker AheadWorker;                   // enqueues the next frame's ego-motion targets beside the first solve
+  int AheadStatus = 0;                  // result of the work done between a solve's launch and its wait
   int MapJobFailed[3] = {0, 0, 0};          // a device-map insertion that failed on its worker (read after WaitMaps)
   HostWorker MapWorker[3];                  // one per map: the three rolling grids are independent
-  void WaitMaps() { for (auto& w : MapWorker) w.Wait(); }
+  void WaitMaps() { for (auto& w : MapWorker) w.Wait(); AheadWorker.Wait(); }
 };
 
 }  // namespace host

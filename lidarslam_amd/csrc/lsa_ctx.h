@@ -229,6 +229,8 @@ struct lsa_ctx
   unsigned lm_tag = 0;            // tags handed out so far (every launch takes max evaluations + 2)
   unsigned long long lm_seq = 0;  // launches so far
   int lm_blocks = lsa::kLmBlocks;
+  hipStream_t map_stream = nullptr;     // shared by the device maps of this context (lsa_device_grid.hip), created with the first of them
+  int map_stream_users = 0;
   void (*solve_hook)(void*) = nullptr;  // lsa_solve_device_interlude
   void* solve_hook_arg = nullptr;
   int lm_records = 512;   // residual blocks per workgroup of the solve kernel the launch aims at (LSA_LM_RECORDS)

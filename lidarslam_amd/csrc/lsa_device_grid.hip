@@ -926,10 +926,12 @@ struct lsa_device_grid
   int* st = nullptr;           // device state (16 ints)
   int* host_st = nullptr;      // pinned copy of it, refreshed behind every modification
   hipEvent_t ev_state = nullptr;
-  // Every kernel of the grid runs on its own stream: a keyframe goes into the map beside the next frame's work on the
-  // context's stream (and may be enqueued by another host thread).  Where the two meet -- keypoints read, a target or
+  // The grid's kernels run on a stream beside the context's (by default the context's look-ahead stream, see
+  // lsa_device_grid_create): a keyframe goes into the map beside the next frame's work on the context's stream (and may
+  // be enqueued by another host thread).  Where the two meet -- keypoints read, a target or
   // the scratch buffer written -- events order them: ev_in (context -> grid) before, ev_out (grid -> context) after.
   hipStream_t stream = nullptr;
+  bool own_stream = false, shared_stream = false;
   hipEvent_t ev_in = nullptr, ev_out = nullptr, ev_sub = nullptr;
   u64* host_sub = nullptr;     // coherent host memory: {tag, size} of the sub-map being built, one 8-byte store by the kernel
   unsigned sub_tag = 0;
@@ -1215,15 +1217,26 @@ int lsa_device_grid_create(lsa_ctx* ctx, lsa_device_grid** out)
   ok = ok && hipHostMalloc((void**)&g->host_sub, sizeof(u64), hipHostMallocCoherent | hipHostMallocMapped) == hipSuccess;
   if (ok) *g->host_sub = 0;
   {
-    // the insertion has half a frame before the next localization asks for the map, the ICP kernels it runs beside are
-    // the frame's critical path: they go first (LSA_MAP_STREAM_PRIORITY=1: the other way round)
+    // The maps' kernels go on the context's LOOK-AHEAD stream (next frame's extraction, next ego-motion targets): a
+    // process has four hardware queues, and the registration's stream, the look-ahead stream and the copy stream are
+    // busy beside the insertions -- every further stream shares a queue with one of them, and when that one is the
+    // ICP's the frame pays (one box, alternating runs: ego-motion phase 0.42 ms per frame with the maps on the
+    // look-ahead stream, 0.60 with a stream per map, 0.83 with one new stream for all maps; 890 / 765 / 665 frames/s).
+    // The order on that stream is the order of need: insertions (end of frame f), extraction of frame f + 2 (announced
+    // during frame f + 1), targets of frame f + 2.
+    // LSA_MAP_STREAM=own|shared: a stream per map / one more stream for all maps (the experiments above)
+    const char* e = std::getenv("LSA_MAP_STREAM");
+    const std::string mode = e ? e : "prefetch";
     int least = 0, greatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-    const char* e = std::getenv("LSA_MAP_STREAM_PRIORITY");
-    const int prio = (e && std::atoi(e) != 0) ? greatest : least;
-    if (const char* k = std::getenv("LSA_MAP_STREAM_SKIP"))  // experiment: shifts the stream's place in the runtime's round robin over hardware queues
-      for (int i = 0; i < std::atoi(k); ++i) { hipStream_t pad; (void)hipStreamCreateWithFlags(&pad, hipStreamNonBlocking); }
-    ok = ok && hipStreamCreateWithPriority(&g->stream, hipStreamNonBlocking, prio) == hipSuccess;
+    if (mode == "own") { ok = ok && hipStreamCreateWithPriority(&g->stream, hipStreamNonBlocking, least) == hipSuccess; g->own_stream = true; }
+    else if (mode != "shared" && ctx->prefetch_stream) g->stream = ctx->prefetch_stream;
+    else
+    {
+      if (!ctx->map_stream) ok = ok && hipStreamCreateWithPriority(&ctx->map_stream, hipStreamNonBlocking, least) == hipSuccess;
+      g->stream = ctx->map_stream;
+      if (ok) { ctx->map_stream_users++; g->shared_stream = true; }
+    }
   }
   for (hipEvent_t* e : {&g->ev_state, &g->ev_in, &g->ev_out, &g->ev_sub}) ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
   if (!ok) { lsa_device_grid_destroy(g); return LSA_E_HIP; }
@@ -1245,7 +1258,12 @@ void lsa_device_grid_destroy(lsa_device_grid* g)
   if (g->host_sub) (void)hipHostFree(g->host_sub);
   for (hipEvent_t e : {g->ev_state, g->ev_in, g->ev_out, g->ev_sub})
     if (e) (void)hipEventDestroy(e);
-  if (g->stream) (void)hipStreamDestroy(g->stream);
+  if (g->stream && g->own_stream) (void)hipStreamDestroy(g->stream);
+  if (g->shared_stream && --g->ctx->map_stream_users == 0 && g->ctx->map_stream)
+  {
+    (void)hipStreamDestroy(g->ctx->map_stream);
+    g->ctx->map_stream = nullptr;
+  }
   delete g;
 }
 

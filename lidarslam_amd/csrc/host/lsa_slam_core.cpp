@@ -291,6 +291,28 @@ int SlamCore::TryStartLookahead()
   return LSA_OK;
 }
 
+// The next frame's extraction (a dozen launches on the look-ahead stream once its upload has arrived) is enqueued by this
+// thread between the launch of a solve and the wait for its result, not between the match and the solve: the solve's
+// kernel then follows the model fits at once (it came 56 us late whenever the look-ahead was enqueued in front of it).
+void SlamCore::ArmLookaheadInterlude()
+{
+  InterludeRan = false;
+  InterludeStatus = LSA_OK;
+  if (!DeviceLM) return;  // the host-driven loop has no such gap: FinishLookaheadInterlude does the work
+  lsa_solve_device_interlude(Ctx, [](void* self) {
+    SlamCore* core = static_cast<SlamCore*>(self);
+    core->InterludeStatus = core->TryStartLookahead();
+    core->InterludeRan = true;
+  }, this);
+}
+int SlamCore::FinishLookaheadInterlude()
+{
+  if (DeviceLM) lsa_solve_device_interlude(Ctx, nullptr, nullptr);  // a solve that never got to its launch leaves it armed
+  if (!InterludeRan) InterludeStatus = TryStartLookahead();
+  InterludeRan = true;
+  return InterludeStatus;
+}
+
 // Slam::AddFrames with several frames, one per LiDAR device (Slam.cxx:230-344; CheckFrames :709-743)
 int SlamCore::AddFrames(const InputFrame* frames, int nframes)
 {
@@ -599,7 +621,7 @@ int SlamCore::ComputeEgoMotion()
     }
     // while the device is busy with this iteration: sub-maps the workers have finished meanwhile go to the device
     if (!SpecPending) LSA_TRY(StageSpeculativeSubMaps());
-    LSA_TRY(TryStartLookahead());
+    ArmLookaheadInterlude();
     Stats.ego_icp += ticp.Stop();
     Stats.ego_iters++;
 
@@ -613,6 +635,7 @@ int SlamCore::ComputeEgoMotion()
     optimizer.UseDeviceResiduals((1u << LSA_EDGE) | (1u << LSA_PLANE));
     SolveSummary summary;
     LSA_TRY(optimizer.Solve(summary));
+    LSA_TRY(FinishLookaheadInterlude());
     TotalMatchedKeypoints = summary.num_matches;
     if (SpecPending)
     {
@@ -773,7 +796,7 @@ int SlamCore::Localization()
     LSA_TRY(lsa_match_types(Ctx, LSA_TARGET_MAP, mask, LSA_SET_WORKING, &mp, Tworld.m, nullptr));
     for (int k = 0; k < 3; ++k)
       if ((mask >> k) & 1u) LocMatchSerial[k] = lsa_match_serial(Ctx, k);
-    LSA_TRY(TryStartLookahead());
+    ArmLookaheadInterlude();
     Stats.loc_icp += ticp.Stop();
     Stats.loc_iters++;
 
@@ -787,6 +810,7 @@ int SlamCore::Localization()
     optimizer.UseDeviceResiduals(7u);
     SolveSummary summary;
     LSA_TRY(optimizer.Solve(summary));
+    LSA_TRY(FinishLookaheadInterlude());
     TotalMatchedKeypoints = summary.num_matches;
     if (summary.skipped)
     {

@@ -260,6 +260,10 @@ private:
   float Device0AzimuthalResolution = 0.f;  // parked here while another device's frame is extracted
   int ExtractFrames();
   int PrepareNextEgoMotionTargets();
+  void ArmLookaheadInterlude();
+  int FinishLookaheadInterlude();
+  bool InterludeRan = true;
+  int InterludeStatus = 0;
   int NextStoredSlot = -1;
   bool NextFrameHinted = false;   // a cloud was announced (HintNextFrame) and its look-ahead extraction not started yet
   int TryStartLookahead();        // starts it as soon as the upload has been enqueued

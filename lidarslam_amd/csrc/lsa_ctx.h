@@ -40,7 +40,7 @@ constexpr int kMailboxStride = 64;        // 8-byte granules per block in the ma
 constexpr int kLmBlocksMax = 128;         // grid limit of the one-launch LM solve (k_lm_solve); LSA_LM_BLOCKS tunes the grid
 constexpr int kLmBlocks = 64;
 constexpr int kLmOut = 48;                // doubles the LM kernel hands to the host (96 granules)
-constexpr int kHistRing = 32;
+constexpr int kHistRing = 256;  // half of it is cleared at a time (two fills on the ICP's stream): once in 128 matches
 constexpr int kAccumVals = 29;            // cost, g[6], H upper[21], nvalid
 
 struct GridDesc

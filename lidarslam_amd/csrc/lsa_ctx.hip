@@ -83,7 +83,7 @@ int ensure_target(lsa_ctx* ctx, int ti, int m)
     }
     LSA_HIP(ctx, dev_alloc(&t.desc, kGridLevels));
     LSA_HIP(ctx, dev_alloc(&t.bbox_bits, 8));
-    // armed once here, re-armed by k_grid_setup after every build
+    // armed once here, re-armed by k_grid_scatter after every build
     const int init[8] = {0x7fffffff, 0x7fffffff, 0x7fffffff, (int)0x80000000, (int)0x80000000, (int)0x80000000, 0, 0};
     LSA_HIP(ctx, hipMemcpy(t.bbox_bits, init, sizeof(init), hipMemcpyHostToDevice));
   }

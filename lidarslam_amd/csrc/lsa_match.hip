@@ -104,21 +104,20 @@ __global__ __launch_bounds__(256) void k_target_prep(GridBatch gb)
 }
 
 // desc[0]: cell = hint (grown until the grid fits its cell budget); every further level has cells 4 x
-// larger (grown likewise).  One thread per target; the bounding box is re-armed for the next build.
-__global__ void k_grid_setup(GridBatch gb)
+// larger (grown likewise).  Pure function of the target's bounding box: every workgroup of k_grid_zero works it out for
+// itself (a few dozen operations against a launch of its own); the first one of a (target, level) leaves it in memory
+// for the kernels that follow.
+__device__ __forceinline__ GridDesc grid_desc_of(const GridBatch& gb, int t, int want)
 {
-  const int t = blockIdx.x;
-  if (threadIdx.x != 0) return;
-  int* bbox = gb.bbox[t];
+  const int* bbox = gb.bbox[t];
   float mn[3], mx[3];
   for (int d = 0; d < 3; ++d) { mn[d] = o2f(bbox[d]); mx[d] = o2f(bbox[3 + d]); }
-  for (int d = 0; d < 3; ++d) { bbox[d] = 0x7fffffff; bbox[3 + d] = (int)0x80000000; }
   float cell = gb.cell_hint[t];
-  for (int level = 0; level < kGridLevels; ++level)
+  GridDesc g;
+  for (int level = 0; level <= want; ++level)
   {
     const double cap = (double)grid_level_cells(level);
     if (level > 0) cell *= 4.0f;
-    GridDesc g;
     while (true)
     {
       double total = 1;
@@ -135,14 +134,16 @@ __global__ void k_grid_setup(GridBatch gb)
     g.inv_cell = 1.0f / cell;
     g.ncells = g.dims[0] * g.dims[1] * g.dims[2];
     g.npoints = gb.m[t];
-    gb.desc[t][level] = g;
   }
+  return g;
 }
 
 __global__ __launch_bounds__(256) void k_grid_zero(GridBatch gb)
 {
   const int t = blockIdx.y / kGridLevels, l = blockIdx.y % kGridLevels;
-  const int nc = gb.desc[t][l].ncells;
+  const GridDesc g = grid_desc_of(gb, t, l);
+  if (blockIdx.x == 0 && threadIdx.x == 0) gb.desc[t][l] = g;
+  const int nc = g.ncells;
   const int i0 = blockIdx.x * 1024 + threadIdx.x;
   if (blockIdx.x * 1024 > nc) return;
   uint32_t* cs = gb.cell_start[t][l];
@@ -252,41 +253,23 @@ __global__ __launch_bounds__(256) void k_scan_block(GridBatch gb)
   }
   if (threadIdx.x == 255) gb.block_sums[t][l][blockIdx.x] = s[255];
 }
-__global__ __launch_bounds__(1024) void k_scan_sums(GridBatch gb)
-{
-  __shared__ uint32_t s[1024];
-  const int t = blockIdx.x / kGridLevels, l = blockIdx.x % kGridLevels;
-  uint32_t* sums = gb.block_sums[t][l];
-  const int nb = (gb.desc[t][l].ncells + 1 + 1023) / 1024;
-  const int per = (nb + 1023) / 1024;
-  const int b = min(nb, (int)threadIdx.x * per), e = min(nb, b + per);
-  uint32_t tsum = 0;
-  for (int i = b; i < e; ++i) tsum += sums[i];
-  s[threadIdx.x] = tsum;
-  __syncthreads();
-  for (int o = 1; o < 1024; o <<= 1)
-  {
-    uint32_t a = (threadIdx.x >= (unsigned)o) ? s[threadIdx.x - o] : 0;
-    __syncthreads();
-    s[threadIdx.x] += a;
-    __syncthreads();
-  }
-  uint32_t run = s[threadIdx.x] - tsum;
-  for (int i = b; i < e; ++i)
-  {
-    uint32_t v = sums[i];
-    sums[i] = run;
-    run += v;
-  }
-}
+// third pass fused into the second: every block sums the totals of the blocks in front of it itself (a grid of 4 M
+// cells is 4 096 blocks: sixteen loads per thread)
 __global__ __launch_bounds__(256) void k_scan_add(GridBatch gb)
 {
+  __shared__ uint32_t part[4];
   const int t = blockIdx.y / kGridLevels, l = blockIdx.y % kGridLevels;
   const int total = gb.desc[t][l].ncells + 1;
   const int base = blockIdx.x * 1024;
   if (base >= total) return;
+  const uint32_t* sums = gb.block_sums[t][l];
+  uint32_t mine = 0;
+  for (int j = threadIdx.x; j < (int)blockIdx.x; j += 256) mine += sums[j];
+  for (int o = 32; o > 0; o >>= 1) mine += __shfl_down(mine, o);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = mine;
+  __syncthreads();
+  const uint32_t add = part[0] + part[1] + part[2] + part[3];
   uint32_t* data = gb.cell_start[t][l];
-  const uint32_t add = gb.block_sums[t][l][blockIdx.x];
   for (int q = 0; q < 4; ++q)
   {
     const int i = base + threadIdx.x * 4 + q;
@@ -298,6 +281,12 @@ __global__ __launch_bounds__(256) void k_grid_scatter(GridBatch gb)
 {
   const int t = blockIdx.y;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+  {
+    // the bounding box is re-armed for the next build (its last readers were k_grid_zero's workgroups)
+    int* bbox = gb.bbox[t];
+    for (int d = 0; d < 3; ++d) { bbox[d] = 0x7fffffff; bbox[3 + d] = (int)0x80000000; }
+  }
   if (blockIdx.x * blockDim.x >= gb.m[t]) return;
   const bool active = i < gb.m[t];
   const int lane = threadIdx.x & 63;
@@ -880,11 +869,9 @@ static int build_grids(lsa_ctx* ctx, const int* tis, int count, hipStream_t st)
   const int pb = (max_m + 255) / 256;
   const int cb = (max_cells + 1 + 1023) / 1024;  // the cell passes return at once beyond a grid's own cell count
   hipLaunchKernelGGL(k_target_prep, dim3(pb, nt), dim3(256), 0, st, gb);
-  hipLaunchKernelGGL(k_grid_setup, dim3(nt), dim3(64), 0, st, gb);
   hipLaunchKernelGGL(k_grid_zero, dim3(cb, nt * kGridLevels), dim3(256), 0, st, gb);
   hipLaunchKernelGGL(k_grid_count, dim3(pb, nt), dim3(256), 0, st, gb);
   hipLaunchKernelGGL(k_scan_block, dim3(cb, nt * kGridLevels), dim3(256), 0, st, gb);
-  hipLaunchKernelGGL(k_scan_sums, dim3(nt * kGridLevels), dim3(1024), 0, st, gb);
   hipLaunchKernelGGL(k_scan_add, dim3(cb, nt * kGridLevels), dim3(256), 0, st, gb);
   hipLaunchKernelGGL(k_grid_scatter, dim3(pb, nt), dim3(256), 0, st, gb);
   return LSA_OK;

@@ -236,25 +236,31 @@ def test_concurrent_types_equal_sequential_calls(gpu_ctx, O, L, kps, model):
 
 def test_histograms_of_earlier_matches_stay_readable(gpu_ctx, O, L, kps):
     """lsa_match_serial / lsa_match_histogram (MatchingResults::NbMatches without a read-back on the critical path):
-    the histogram of a match is still there after later matches of the same type, up to 16 of them"""
+    the histogram of a match is still there after later matches of the same type, up to 128 of them (half of the ring:
+    the other half may be being cleared), across the ring's wrap-around"""
     prev, cur = kps[16]
     pose = perturbed()
     for k in (L.EDGE, L.PLANE):
         gpu_ctx.set_keypoints(L.SET_WORKING, k, cur[k])
         gpu_ctx.set_target(k, prev[k], cell=1.0)
     seen = []
-    for i in range(20):
-        mp = L.MatchParams.localization(saturation_distance=2.0 - 0.05 * i)
-        mp.max_neighbors_distance = 5.0 - 0.2 * i  # a different histogram every time
-        hists = gpu_ctx.match_types(3, L.SET_WORKING, mp, pose)
-        seen.append((gpu_ctx.match_serial(L.EDGE), gpu_ctx.match_serial(L.PLANE), hists.copy()))
-    assert seen[-1][0] == seen[0][0] + 19
-    for se, sp, h in seen[-16:]:
+    for i in range(300):
+        mp = L.MatchParams.localization(saturation_distance=2.0 - 0.05 * (i % 20))
+        mp.max_neighbors_distance = 5.0 - 0.2 * (i % 20)  # a different histogram every time
+        hists = gpu_ctx.match_types(3, L.SET_WORKING, mp, pose, histograms=(i % 7 == 0 or i >= 150))
+        seen.append((gpu_ctx.match_serial(L.EDGE), gpu_ctx.match_serial(L.PLANE), None if hists is None else hists.copy()))
+    assert seen[-1][0] == seen[0][0] + 299
+    checked = 0
+    for se, sp, h in seen[-128:]:
+        if h is None:
+            continue
         assert gpu_ctx.match_histogram(L.EDGE, se).tolist() == h[L.EDGE].tolist()
         assert gpu_ctx.match_histogram(L.PLANE, sp).tolist() == h[L.PLANE].tolist()
-    assert len({tuple(h[L.PLANE].tolist()) for _, _, h in seen}) > 5
+        checked += 1
+    assert checked == 128
+    assert len({tuple(h[L.PLANE].tolist()) for _, _, h in seen if h is not None}) > 5
     with pytest.raises(L.LsaError):
-        gpu_ctx.match_histogram(L.EDGE, seen[0][0])  # 19 matches ago: gone
+        gpu_ctx.match_histogram(L.EDGE, seen[-129][0])  # 128 matches ago: gone
     with pytest.raises(L.LsaError):
         gpu_ctx.match_histogram(L.EDGE, seen[-1][0] + 1)  # not enqueued yet
 

@@ -110,8 +110,11 @@ __device__ __forceinline__ bool lm_evaluate(const LmParams& p, unsigned epoch, u
     double acc[kAccumVals];
 #pragma unroll
     for (int v = 0; v < kAccumVals; ++v) acc[v] = 0.;
+    const unsigned long long e0 = trace ? wall_clock64() : 0ull;
     accumulate_records_cached(p.set, c, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x, cache, p.cslots, p.cslots * 256, epoch == 1, acc);
+    const unsigned long long e1 = trace ? wall_clock64() : 0ull;
     wave_reduce_accum(acc);
+    if (trace && threadIdx.x == 0) { sh.lap[4] += e1 - e0; }
     if ((threadIdx.x & 63) == 0)
     {
 #pragma unroll
@@ -467,6 +470,7 @@ __global__ __launch_bounds__(256) void k_lm_solve(LmParams p, u64* __restrict__ 
     trace[4] += (unsigned long long)sh.lm.evaluations;
     trace[5] += wall_clock64() - sh.lap[5];
     trace[6] += 1;
+    trace[7] += sh.lap[4];  // of "evaluate": the residual blocks alone (before the wavefront's reduction)
   }
   // every block holds the same result; block 0's copy goes out as 2 granules per double
   if (threadIdx.x < 2 * kResCount)

@@ -104,20 +104,22 @@ __global__ __launch_bounds__(256) void k_target_prep(GridBatch gb)
 }
 
 // desc[0]: cell = hint (grown until the grid fits its cell budget); every further level has cells 4 x
-// larger (grown likewise).  Pure function of the target's bounding box: every workgroup of k_grid_zero works it out for
-// itself (a few dozen operations against a launch of its own); the first one of a (target, level) leaves it in memory
-// for the kernels that follow.
-__device__ __forceinline__ GridDesc grid_desc_of(const GridBatch& gb, int t, int want)
+// larger (grown likewise).  One thread per target.  (Folded into k_grid_zero -- every workgroup deriving the geometry for
+// itself -- it saved a launch and cost the zeroing 14 us: the launch covers the cell BUDGET, thousands of workgroups
+// that mostly have nothing to zero then all walk the growth loop.)
+__global__ void k_grid_setup(GridBatch gb)
 {
+  const int t = blockIdx.x;
+  if (threadIdx.x != 0) return;
   const int* bbox = gb.bbox[t];
   float mn[3], mx[3];
   for (int d = 0; d < 3; ++d) { mn[d] = o2f(bbox[d]); mx[d] = o2f(bbox[3 + d]); }
   float cell = gb.cell_hint[t];
-  GridDesc g;
-  for (int level = 0; level <= want; ++level)
+  for (int level = 0; level < kGridLevels; ++level)
   {
     const double cap = (double)grid_level_cells(level);
     if (level > 0) cell *= 4.0f;
+    GridDesc g;
     while (true)
     {
       double total = 1;
@@ -134,16 +136,14 @@ __device__ __forceinline__ GridDesc grid_desc_of(const GridBatch& gb, int t, int
     g.inv_cell = 1.0f / cell;
     g.ncells = g.dims[0] * g.dims[1] * g.dims[2];
     g.npoints = gb.m[t];
+    gb.desc[t][level] = g;
   }
-  return g;
 }
 
 __global__ __launch_bounds__(256) void k_grid_zero(GridBatch gb)
 {
   const int t = blockIdx.y / kGridLevels, l = blockIdx.y % kGridLevels;
-  const GridDesc g = grid_desc_of(gb, t, l);
-  if (blockIdx.x == 0 && threadIdx.x == 0) gb.desc[t][l] = g;
-  const int nc = g.ncells;
+  const int nc = gb.desc[t][l].ncells;
   const int i0 = blockIdx.x * 1024 + threadIdx.x;
   if (blockIdx.x * 1024 > nc) return;
   uint32_t* cs = gb.cell_start[t][l];
@@ -869,6 +869,7 @@ static int build_grids(lsa_ctx* ctx, const int* tis, int count, hipStream_t st)
   const int pb = (max_m + 255) / 256;
   const int cb = (max_cells + 1 + 1023) / 1024;  // the cell passes return at once beyond a grid's own cell count
   hipLaunchKernelGGL(k_target_prep, dim3(pb, nt), dim3(256), 0, st, gb);
+  hipLaunchKernelGGL(k_grid_setup, dim3(nt), dim3(64), 0, st, gb);
   hipLaunchKernelGGL(k_grid_zero, dim3(cb, nt * kGridLevels), dim3(256), 0, st, gb);
   hipLaunchKernelGGL(k_grid_count, dim3(pb, nt), dim3(256), 0, st, gb);
   hipLaunchKernelGGL(k_scan_block, dim3(cb, nt * kGridLevels), dim3(256), 0, st, gb);

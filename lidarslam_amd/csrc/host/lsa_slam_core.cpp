@@ -99,7 +99,7 @@ SlamCore::SlamCore(int device)
     for (int k = 0; k < 3; ++k)
     {
       lsa_ctx* ctx = Ctx;
-      if (!std::getenv("LSA_NO_DEVMAPS") && lsa_device_grid_create(ctx, &DevMaps[k]) == LSA_OK)
+      if (lsa_device_grid_create(ctx, &DevMaps[k]) == LSA_OK)
       {
         // the other parameters start from the same defaults as RollingGrid's (RollingGrid.h:170-212) and follow the same
         // setters afterwards (SetVoxelResolution snaps to the leaf size of the moment on both sides, RollingGrid.cxx:73-88)

@@ -301,11 +301,7 @@ int lsa_upload_frame_begin(lsa_ctx* ctx, const lsa_point_t* pts, int n)
   }
   if (slot < 0) return ctx->fail(LSA_E_STATE, "lsa_upload_frame_begin: no free buffer");
   FrameInbox& in = ctx->inbox[slot];
-  if (!ctx->copy_stream)
-  {
-    LSA_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
-    ctx->uploader = std::thread(uploader_main, ctx);
-  }
+  if (!ctx->uploader.joinable()) ctx->uploader = std::thread(uploader_main, ctx);
   if (!in.ev) LSA_HIP(ctx, hipEventCreateWithFlags(&in.ev, hipEventDisableTiming));
   if (in.cap < n)
   {
@@ -394,13 +390,18 @@ int lsa_ctx_create(int device_id, lsa_ctx** out)
   if (hipSetDevice(device_id) != hipSuccess) return LSA_E_HIP;
   lsa_ctx* ctx = new lsa_ctx;
   ctx->device = device_id;
+  // EXACTLY THREE streams per context, created together: the registration's, the look-ahead's, the copies'.  The runtime
+  // deals streams to the process's four hardware queues in creation order (GPU_MAX_HW_QUEUES = 4, round robin), and two
+  // streams on one queue wait for each other's kernels.  Three in a row sit on three different queues, and the next
+  // context's three start one queue further: with four streams per context every context's registration stream landed
+  // on the same queue (8 sequences side by side: 1 200 frames/s against 2 000), and any further stream of a context
+  // shares the registration's queue (a stream for the maps: 765 against 890 frames/s for one sequence).  The side streams
+  // of the staged (non-fused) match are created when that path is first used.
   if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return LSA_E_HIP; }
   bool ok = true;
-  for (int i = 0; i < 2; ++i)
-  {
-    ok &= hipStreamCreateWithFlags(&ctx->side_stream[i], hipStreamNonBlocking) == hipSuccess;
-    ok &= hipEventCreateWithFlags(&ctx->ev_join[i], hipEventDisableTiming) == hipSuccess;
-  }
+  ok &= hipStreamCreateWithFlags(&ctx->prefetch_stream, hipStreamNonBlocking) == hipSuccess;
+  ok &= hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking) == hipSuccess;
+  for (int i = 0; i < 2; ++i) ok &= hipEventCreateWithFlags(&ctx->ev_join[i], hipEventDisableTiming) == hipSuccess;
   ok &= hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) == hipSuccess;
   ok &= hipEventCreateWithFlags(&ctx->ev_bbox, hipEventDisableTiming) == hipSuccess;
   ok &= hipEventCreateWithFlags(&ctx->ev_stage, hipEventDisableTiming) == hipSuccess;
@@ -409,7 +410,6 @@ int lsa_ctx_create(int device_id, lsa_ctx** out)
   ok &= hipMalloc((void**)&ctx->extract_out, 16 * sizeof(int)) == hipSuccess;
   ok &= hipMalloc((void**)&ctx->extract_out_next, 16 * sizeof(int)) == hipSuccess;
   ok &= hipHostMalloc((void**)&ctx->host_next, 16 * sizeof(int), hipHostMallocDefault) == hipSuccess;
-  ok &= hipStreamCreateWithFlags(&ctx->prefetch_stream, hipStreamNonBlocking) == hipSuccess;
   ok &= hipEventCreateWithFlags(&ctx->ev_prefetch, hipEventDisableTiming) == hipSuccess;
   ok &= hipEventCreateWithFlags(&ctx->ev_spare, hipEventDisableTiming) == hipSuccess;
   for (int k = 0; k < 3; ++k) ok &= hipEventCreateWithFlags(&ctx->ev_map_ahead[k], hipEventDisableTiming) == hipSuccess;

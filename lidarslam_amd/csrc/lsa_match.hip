@@ -1338,6 +1338,8 @@ int lsa_match_types(lsa_ctx* ctx, int slot, unsigned type_mask, int query_set, c
   {
     // fork: the first type stays on the context stream, the others run beside it.  A single type's kernels
     // leave most of the 256 CUs idle (a few thousand queries, latency bound), so the types overlap almost fully.
+    for (int i = 0; i + 1 < nt; ++i)
+      if (!ctx->side_stream[i]) LSA_HIP(ctx, hipStreamCreateWithFlags(&ctx->side_stream[i], hipStreamNonBlocking));  // lsa_ctx_create: why not there
     if (nt > 1) LSA_HIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
     for (int i = 0; i < nt; ++i)
     {

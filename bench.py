@@ -421,15 +421,23 @@ def pmc_traffic(family, model):
     if not tabs:
         return None
     tab = json.load(open(tabs[-1]))
-    rows = [v for k, v in tab.items() if any(p in k for p in FAMILY_KERNELS[family])]
-    if not rows:
+    # per step of the algorithm = one launch of every KERNEL of the family; a kernel's template variants (k = 8 / 10 ...)
+    # are alternatives, not further launches: mean over the variants by calls, then the kernels summed, each weighted by
+    # how often it is launched relative to the most frequent one
+    groups = {}
+    for k, v in tab.items():
+        for p in FAMILY_KERNELS[family]:
+            if p in k:
+                g = groups.setdefault(p, [0, 0.0])
+                g[0] += v["calls"]
+                g[1] += (v["fetch_kib"] + v["write_kib"]) * 1024.0 * v["calls"]
+                break
+    if not groups:
         return None
-    # per step of the algorithm = one launch of every kernel of the family: sum of the kernels' per-launch means,
-    # weighted by how often each is launched relative to the most frequent one
-    most = max(r["calls"] for r in rows)
+    most = max(g[0] for g in groups.values())
     if most == 0:
         return None
-    return sum((r["fetch_kib"] + r["write_kib"]) * 1024.0 * r["calls"] for r in rows) / most
+    return sum(g[1] for g in groups.values()) / most
 
 
 def cpu_baseline(args, sequence):

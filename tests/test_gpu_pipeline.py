@@ -430,18 +430,23 @@ def test_sequences_side_by_side_on_one_gpu_reproduce_lone_runs():
 
     frames = 10
     lone = []
-    for seed in (1000, 1001, 1002):
+    for seed in (1000, 1001, 1002, 1003):
         rep = ConcurrentReplay(0, 16, [seed], frames, EgoMotion=3)
         rep.run(2)
         lone.append(rep.poses[0].copy())
         rep.close()
-    rep = ConcurrentReplay(0, 16, [1000, 1001, 1002, 1000], frames, EgoMotion=3)
-    fps = rep.run(2)
-    assert fps > 0
-    for s, ref in enumerate([lone[0], lone[1], lone[2], lone[0]]):
-        assert np.array_equal(rep.poses[s], ref), s
     assert not np.array_equal(lone[0][-1], lone[1][-1])
-    rep.close()
+    # eight sequences side by side, with the rolling maps on the host threads (what ConcurrentReplay picks for several
+    # sequences) and on the device (what it picked for the lone runs above): the same poses, bit for bit
+    seeds = [1000, 1001, 1002, 1003, 1000, 1001, 1002, 1003]
+    for maps_on_device in (0, 1):
+        rep = ConcurrentReplay(0, 16, seeds, frames, EgoMotion=3, MapsOnDevice=maps_on_device)
+        fps = rep.run(2)
+        assert fps > 0
+        assert rep.slams[0].get_param("DeviceMapsInUse") == float(maps_on_device)
+        for s, seed in enumerate(seeds):
+            assert np.array_equal(rep.poses[s], lone[seed - 1000]), (maps_on_device, s)
+        rep.close()
     with pytest.raises(ValueError):
         ConcurrentReplay(0, 16, [1000], 2, EgoMotion=3).run(2)
 

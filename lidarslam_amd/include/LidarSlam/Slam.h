@@ -263,9 +263,11 @@ public:
       for (Keypoint k : KeypointTypes)
       {
         if (!loc && k == BLOB) continue;
-        std::vector<std::uint8_t> st(1 << 20);
-        std::vector<double> w(1 << 20);
-        const int n = lsa_slam_get_match_status(this->Handle, loc, k, st.data(), w.data(), static_cast<int>(st.size()));
+        // size first (null buffers), then exactly that much
+        const int have = lsa_slam_get_match_status(this->Handle, loc, k, nullptr, nullptr, 1 << 30);
+        std::vector<std::uint8_t> st(have > 0 ? have : 0);
+        std::vector<double> w(st.size());
+        const int n = st.empty() ? 0 : lsa_slam_get_match_status(this->Handle, loc, k, st.data(), w.data(), static_cast<int>(st.size()));
         const std::string prefix = std::string(loc ? "Localization: " : "EgoMotion: ") + KeypointTypeNames.at(k);
         map[prefix + " matches"] = std::vector<double>(st.begin(), st.begin() + (n > 0 ? n : 0));
         w.resize(n > 0 ? n : 0);
@@ -457,19 +459,21 @@ public:
   lsa_slam* GetHandle() { return this->Handle; }
 
 private:
+  // one staging buffer per Slam, kept between calls (the wrappers call the getters every frame: no 16 MB allocation per call)
   template <typename F> PointCloud::Ptr Fetch(F f, const std::string& frame)
   {
     PointCloud::Ptr pc(new PointCloud);
-    std::vector<lsa_point_t> tmp(1 << 19);
-    int n = f(tmp.data(), static_cast<int>(tmp.size()));
-    if (n == static_cast<int>(tmp.size()))
+    if (this->Staging.size() < (1u << 19)) this->Staging.resize(1u << 19);
+    int n = f(this->Staging.data(), static_cast<int>(this->Staging.size()));
+    while (n >= static_cast<int>(this->Staging.size()) && this->Staging.size() < (1u << 26))
     {
-      tmp.resize(1 << 23);
-      n = f(tmp.data(), static_cast<int>(tmp.size()));
+      this->Staging.resize(this->Staging.size() * 4);  // it may have been cut short: once more with room
+      n = f(this->Staging.data(), static_cast<int>(this->Staging.size()));
     }
     if (n < 0) n = 0;
+    n = std::min<int>(n, static_cast<int>(this->Staging.size()));
     pc->points.resize(n);
-    if (n > 0) std::memcpy(static_cast<void*>(pc->points.data()), tmp.data(), static_cast<std::size_t>(n) * sizeof(lsa_point_t));
+    if (n > 0) std::memcpy(static_cast<void*>(pc->points.data()), this->Staging.data(), static_cast<std::size_t>(n) * sizeof(lsa_point_t));
     pc->header.stamp = this->CurrentStamp;
     pc->header.frame_id = frame;
     return pc;
@@ -482,6 +486,7 @@ private:
 
   lsa_slam* Handle = nullptr;
   mutable std::set<std::string> Warned;
+  std::vector<lsa_point_t> Staging;  // Fetch
   PointCloudStorageType LoggingStorage = PointCloudStorageType::PCL_CLOUD;
   double WheelOdomWeight = 0., GravityWeight = 0., SensorTimeOffset = 0.;
   std::map<std::uint8_t, KeypointExtractorPtr> KeyPointsExtractors;

@@ -393,7 +393,7 @@ int lsa_solve_device(lsa_ctx* ctx, unsigned type_mask, const double prior[6], in
                      lsa_solve_result_t* out);
 /* Diagnostics (LSA_ROUTE_STATS=1): 100 MHz ticks block 0 spent evaluating, exchanging, folding, stepping, summed over
  * the solves so far; [4] evaluations, [5] ticks inside the kernel, [6] solves. */
-int lsa_solve_device_trace(lsa_ctx* ctx, unsigned long long out[8]);
+int lsa_solve_device_trace(lsa_ctx* ctx, unsigned long long out[12]);
 /* Solves the device gave up on so far (diagnostics; 0 on a healthy run). */
 int lsa_solve_device_fallbacks(const lsa_ctx* ctx);
 /* Host work for the time the next solve runs on the device: `fn(arg)` is called once, on the calling thread, by the

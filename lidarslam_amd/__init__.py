@@ -452,7 +452,7 @@ class Context:
         return r
 
     def solve_device_trace(self):
-        out = np.zeros(8, np.uint64)
+        out = np.zeros(12, np.uint64)
         self.L.lsa_solve_device_trace.argtypes = [C.c_void_p, C.c_void_p]
         self._check(self.L.lsa_solve_device_trace(self.h, ptr(out)), "lsa_solve_device_trace")
         return out

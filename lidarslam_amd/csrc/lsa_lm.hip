@@ -77,6 +77,7 @@ struct Shared
   int failed;
   int stop;
   unsigned long long lap[6], tk;  // diagnostics (block 0): evaluate, exchange, fold, step [100 MHz ticks], evaluations, total
+  unsigned long long sub[4], st0;  // diagnostics: parts of the step -- decision, scaled system, Cholesky solve, candidate
 };
 
 __device__ __forceinline__ double uniform(double v)
@@ -262,17 +263,38 @@ enum LmCode
   kCodeFunctionTolerance
 };
 
-// sh.w = the point to evaluate, sh.rot = its rotation and derivatives (CeresCostFunctions.h:67-79)
+// sh.w = the point to evaluate next (one thread); its rotation and derivatives follow in finish_point
 __device__ __forceinline__ void set_point(Shared& sh, const double w[6])
 {
 #pragma unroll
   for (int a = 0; a < 6; ++a) sh.w[a] = w[a];
-  double R[9], dRx[9], dRy[9], dRz[9];
-  rotation_and_derivatives(lsa_cos(w[3]), lsa_sin(w[3]), lsa_cos(w[4]), lsa_sin(w[4]), lsa_cos(w[5]), lsa_sin(w[5]), R, dRx, dRy, dRz);
+}
+__device__ __forceinline__ double lane_value(double v, int lane)
+{
+  const long long b = __double_as_longlong(v);
+  const int lo = __shfl((int)(b & 0xffffffffll), lane), hi = __shfl((int)(b >> 32), lane);
+  return __longlong_as_double(((long long)hi << 32) | (long long)(unsigned)lo);
+}
+// sh.rot = rotation and derivatives at sh.w (CeresCostFunctions.h:67-79).  The first wavefront runs it, all lanes: the
+// three cosines and three sines -- a few hundred dependent instructions each, the longest part of what lies between two
+// evaluations -- are worked out by six lanes side by side instead of one lane six times.
+__device__ __forceinline__ void finish_point(Shared& sh)
+{
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // sh.w was written by lane 0 of this wavefront
+  const int lane = threadIdx.x & 63;
+  const double angle = sh.w[3 + (lane < 6 ? lane % 3 : 0)];
+  const double v = lane < 3 ? lsa_cos(angle) : lsa_sin(angle);
+  const double cx = lane_value(v, 0), cy = lane_value(v, 1), cz = lane_value(v, 2);
+  const double sx = lane_value(v, 3), sy = lane_value(v, 4), sz = lane_value(v, 5);
+  if (lane == 0)
+  {
+    double R[9], dRx[9], dRy[9], dRz[9];
+    rotation_and_derivatives(cx, sx, cy, sy, cz, sz, R, dRx, dRy, dRz);
 #pragma unroll
-  for (int i = 0; i < 9; ++i) { sh.rot[i] = R[i]; sh.rot[9 + i] = dRx[i]; sh.rot[18 + i] = dRy[i]; sh.rot[27 + i] = dRz[i]; }
+    for (int i = 0; i < 9; ++i) { sh.rot[i] = R[i]; sh.rot[9 + i] = dRx[i]; sh.rot[18 + i] = dRy[i]; sh.rot[27 + i] = dRz[i]; }
 #pragma unroll
-  for (int i = 0; i < 3; ++i) sh.rot[36 + i] = w[i];
+    for (int i = 0; i < 3; ++i) sh.rot[36 + i] = sh.w[i];
+  }
 }
 
 // What the trust-region loop of host/lsa_lm.cpp (LocalOptimizer::Solve) does between two evaluations, N active
@@ -351,6 +373,7 @@ __device__ bool lm_step(const LmParams& p, Shared& sh, bool first)
     }
   }
 
+  if (sh.st0) { const unsigned long long n = wall_clock64(); sh.sub[0] += n - sh.st0; sh.st0 = n; }
   while (true)
   {
     if (lm.iter >= p.max_iter) { lm.code = kCodeMaxIterations; return true; }
@@ -384,7 +407,9 @@ __device__ bool lm_step(const LmParams& p, Shared& sh, bool first)
     for (int a = 0; a < N; ++a) M[a * N + a] += lm.diag[a] / lm.radius;
 #pragma unroll
     for (int a = 0; a < N; ++a) y[a] = 0.;
+    if (sh.st0) { const unsigned long long n = wall_clock64(); sh.sub[1] += n - sh.st0; sh.st0 = n; }
     bool ok = solve_spd<N>(M, gs, y);
+    if (sh.st0) { const unsigned long long n = wall_clock64(); sh.sub[2] += n - sh.st0; sh.st0 = n; }
     lm.reuse_diagonal = 1;
     double model_cost_change = 0;
     if (ok)
@@ -427,6 +452,7 @@ __device__ bool lm_step(const LmParams& p, Shared& sh, bool first)
     lm.delta_norm = __builtin_sqrt(delta_norm);
     set_point(sh, cand);
     ++lm.evaluations;
+    if (sh.st0) { const unsigned long long n = wall_clock64(); sh.sub[3] += n - sh.st0; sh.st0 = n; }
     return false;
   }
 }
@@ -439,6 +465,8 @@ __global__ __launch_bounds__(256) void k_lm_solve(LmParams p, u64* __restrict__ 
   if (threadIdx.x == 0)
   {
     for (int i = 0; i < 6; ++i) sh.lap[i] = 0;
+    for (int i = 0; i < 4; ++i) sh.sub[i] = 0;
+    sh.st0 = 0;
     sh.tk = wall_clock64();
     sh.lap[5] = sh.tk;
     LmState& lm = sh.lm;
@@ -452,13 +480,19 @@ __global__ __launch_bounds__(256) void k_lm_solve(LmParams p, u64* __restrict__ 
     set_point(sh, p.x0);
     sh.stop = 0;
   }
+  if (threadIdx.x < 64) finish_point(sh);
   __syncthreads();
   bool failed = false;
   // every evaluation of the launch has an epoch of its own; all blocks walk through the same sequence of them
   for (unsigned epoch = 1;; ++epoch)
   {
     if (!lm_evaluate(p, epoch, xchg, sh, lm_cache, tr)) { failed = true; break; }
-    if (threadIdx.x == 0) sh.stop = (p.two_d ? lm_step<3>(p, sh, epoch == 1) : lm_step<6>(p, sh, epoch == 1)) ? 1 : 0;
+    if (threadIdx.x < 64)
+    {
+      if (threadIdx.x == 0 && tr) sh.st0 = wall_clock64();
+      if (threadIdx.x == 0) sh.stop = (p.two_d ? lm_step<3>(p, sh, epoch == 1) : lm_step<6>(p, sh, epoch == 1)) ? 1 : 0;
+      finish_point(sh);
+    }
     __syncthreads();
     if (tr) lm_lap(sh, 3);
     if (sh.stop) break;
@@ -471,6 +505,7 @@ __global__ __launch_bounds__(256) void k_lm_solve(LmParams p, u64* __restrict__ 
     trace[5] += wall_clock64() - sh.lap[5];
     trace[6] += 1;
     trace[7] += sh.lap[4];  // of "evaluate": the residual blocks alone (before the wavefront's reduction)
+    for (int i = 0; i < 4; ++i) trace[8 + i] += sh.sub[i];
   }
   // every block holds the same result; block 0's copy goes out as 2 granules per double
   if (threadIdx.x < 2 * kResCount)
@@ -625,11 +660,11 @@ int lsa_solve_device_interlude(lsa_ctx* ctx, void (*fn)(void*), void* arg)
   return LSA_OK;
 }
 
-int lsa_solve_device_trace(lsa_ctx* ctx, unsigned long long out[8])
+int lsa_solve_device_trace(lsa_ctx* ctx, unsigned long long out[12])
 {
   if (!ctx || !out || !ctx->trace_dev) return LSA_E_ARG;
   if (hipStreamSynchronize(ctx->stream) != hipSuccess) return LSA_E_HIP;
-  if (hipMemcpy(out, reinterpret_cast<unsigned long long*>(ctx->trace_dev) + (size_t)8192 * 12, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return LSA_E_HIP;
+  if (hipMemcpy(out, reinterpret_cast<unsigned long long*>(ctx->trace_dev) + (size_t)8192 * 12, 12 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return LSA_E_HIP;
   return LSA_OK;
 }
 

@@ -36,6 +36,7 @@ if lt[6] > 0:
     print("LM solves %d, evaluations/solve %.2f, in-kernel us/solve %.1f; per evaluation us: evaluate %.2f exchange %.2f fold %.2f step %.2f" % (
         lt[6], lt[4] / lt[6], lt[5] / lt[6] / 100, lt[0] / lt[4] / 100, lt[1] / lt[4] / 100, lt[2] / lt[4] / 100, lt[3] / lt[4] / 100))
     print("   of evaluate: residual blocks %.2f us" % (lt[7] / lt[4] / 100))
+    print("   of step: decision %.2f, scaled system %.2f, Cholesky solve %.2f, model change + candidate %.2f us" % tuple(lt[8 + i] / lt[4] / 100 for i in range(4)))
 
 dur = (mid - start)
 idx = np.argsort(-np.where(ok, dur, -1))[:25]

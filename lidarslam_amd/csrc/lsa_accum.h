@@ -210,23 +210,71 @@ __device__ __forceinline__ void accumulate_records_cached(const RecordSet& rs, c
   }
 }
 
-// fixed-order reduction over the wavefront: afterwards lane 0 holds the wavefront's sums.  Across the four rows of
-// 16 lanes: v_permlane32_swap / v_permlane16_swap (gfx950) hand every lane its partner's value in one VALU pass --
-// lower half + upper half, then row 0 + row 1 -- the same pairs, in the same order, as a shuffle-down by 32 and by
-// 16 gives lane 0; inside a row the partner's value comes through a DPP operand (row_shl), not through LDS.  One
-// step for all 29 values at a time: 29 independent exchanges in flight instead of 29 chains of 6 dependent ones.
-__device__ __forceinline__ void wave_reduce_accum(double acc[kAccumVals])
+// Fixed-order reduction of the 29 sums over the wavefront, TRANSPOSED: every step halves the number of values a lane
+// carries instead of carrying all of them through all six steps -- 32 exchanges and additions in place of 174.
+//   halves of the wavefront: v_permlane32_swap on the pair (value i, value 16 + i) hands the lower half both halves'
+//     value i and the upper half both halves' value 16 + i in one VALU pass per word: 16 values left per lane;
+//   rows of 16 lanes: v_permlane16_swap likewise on (i, 8 + i): 8 values left, row r holding values 8 r .. 8 r + 7;
+//   inside a row: partners at lane distance 8 (row_ror:8), then the mirror image inside 8 lanes (row_half_mirror),
+//     then distance 2 and 1 (quad_perm): 4, 2, 1 values left, a lane keeps the half its own bit selects and gets the
+//     partner's part of that half through a DPP operand.
+// Afterwards lane L holds the wavefront's total of value 8 (L >> 4) + ((L >> 1) & 7) (odd lanes duplicate their even
+// neighbours); the summation order is fixed by the lane number alone.
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double x)
 {
+  const long long b = __double_as_longlong(x);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), CTRL, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xF, 0xF, true);
+  return __longlong_as_double(((long long)hi << 32) | (long long)(unsigned)lo);
+}
+// x = value for the lower half / even rows, y = value for the upper half / odd rows: the sum over both halves (rows) of
+// the one this lane's half (row) keeps
+template <int W>
+__device__ __forceinline__ double swap_keep_add(double x, double y)
+{
+  const long long bx = __double_as_longlong(x), by = __double_as_longlong(y);
+  const unsigned xl = (unsigned)(bx & 0xffffffffll), xh = (unsigned)((unsigned long long)bx >> 32);
+  const unsigned yl = (unsigned)(by & 0xffffffffll), yh = (unsigned)((unsigned long long)by >> 32);
+  // swap(a, b): a's upper half (odd rows) <-> b's lower half (even rows); afterwards [0] = {a.lower, b.lower}, [1] = {a.upper, b.upper}
+  const auto lo = W == 32 ? __builtin_amdgcn_permlane32_swap(xl, yl, false, false) : __builtin_amdgcn_permlane16_swap(xl, yl, false, false);
+  const auto hi = W == 32 ? __builtin_amdgcn_permlane32_swap(xh, yh, false, false) : __builtin_amdgcn_permlane16_swap(xh, yh, false, false);
+  const double a = __longlong_as_double((long long)(((unsigned long long)hi[0] << 32) | lo[0]));
+  const double c = __longlong_as_double((long long)(((unsigned long long)hi[1] << 32) | lo[1]));
+  return a + c;
+}
+__device__ __forceinline__ double wave_reduce_accum(const double acc[kAccumVals], int& slot)
+{
+  static_assert(kAccumVals <= 32, "32 slots");
+  const int lane = threadIdx.x & 63;
+  double a[16], b[8], c[4], d[2];
 #pragma unroll
-  for (int v = 0; v < kAccumVals; ++v) acc[v] = swap_add<32>(acc[v]);
+  for (int i = 0; i < 16; ++i) a[i] = swap_keep_add<32>(acc[i], 16 + i < kAccumVals ? acc[16 + i] : 0.);
 #pragma unroll
-  for (int v = 0; v < kAccumVals; ++v) acc[v] = swap_add<16>(acc[v]);
+  for (int i = 0; i < 8; ++i) b[i] = swap_keep_add<16>(a[i], a[8 + i]);
+  const bool b3 = (lane & 8) != 0, b2 = (lane & 4) != 0, b1 = (lane & 2) != 0;
 #pragma unroll
-  for (int o = 8; o > 0; o >>= 1)
+  for (int i = 0; i < 4; ++i)
   {
-#pragma unroll
-    for (int v = 0; v < kAccumVals; ++v) acc[v] += dpp_row_shl(acc[v], o);
+    const double keep = b3 ? b[4 + i] : b[i], send = b3 ? b[i] : b[4 + i];
+    c[i] = keep + dpp_mov<0x128>(send);  // row_ror:8
   }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+  {
+    const double keep = b2 ? c[2 + i] : c[i], send = b2 ? c[i] : c[2 + i];
+    d[i] = keep + dpp_mov<0x141>(send);  // row_half_mirror: lane j <-> 7 - j of its 8, the other value of bit 2
+  }
+  double e;
+  {
+    const double keep = b1 ? d[1] : d[0], send = b1 ? d[0] : d[1];
+    e = keep + dpp_mov<0x4E>(send);      // quad_perm [2, 3, 0, 1]
+  }
+  e = e + dpp_mov<0xB1>(e);              // quad_perm [1, 0, 3, 2]
+  // which value this lane ended up with: the half-mirror step pairs j with 7 - j, so from there on the lane's bits 1 and 0
+  // are those of min(j, 7 - j) in its group of four ... the value index only depends on the bits that SELECTED
+  slot = 8 * (lane >> 4) + (b3 ? 4 : 0) + (b2 ? 2 : 0) + (b1 ? 1 : 0);
+  return e;
 }
 #endif  // __HIPCC__
 

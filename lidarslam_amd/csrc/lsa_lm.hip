@@ -114,13 +114,10 @@ __device__ __forceinline__ bool lm_evaluate(const LmParams& p, unsigned epoch, u
     const unsigned long long e0 = trace ? wall_clock64() : 0ull;
     accumulate_records_cached(p.set, c, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x, cache, p.cslots, p.cslots * 256, epoch == 1, acc);
     const unsigned long long e1 = trace ? wall_clock64() : 0ull;
-    wave_reduce_accum(acc);
+    int slot;
+    const double total = wave_reduce_accum(acc, slot);  // this lane's one value of the 29, summed over the wavefront
     if (trace && threadIdx.x == 0) { sh.lap[4] += e1 - e0; }
-    if ((threadIdx.x & 63) == 0)
-    {
-#pragma unroll
-      for (int v = 0; v < kAccumVals; ++v) sh.wsum[threadIdx.x >> 6][v] = acc[v];
-    }
+    if ((threadIdx.x & 1) == 0 && slot < kAccumVals) sh.wsum[threadIdx.x >> 6][slot] = total;
   }
   if (threadIdx.x == 0) sh.failed = 0;
   __syncthreads();

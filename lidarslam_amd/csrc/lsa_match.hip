@@ -735,14 +735,11 @@ __global__ __launch_bounds__(256) void k_accumulate(AccumConst c, double* __rest
 #pragma unroll
   for (int v = 0; v < kAccumVals; ++v) acc[v] = 0.;
   accumulate_records(c.set, c.rot, c.jac != 0, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x, acc);
-  // fixed-order reduction: wavefront (permlane swaps + DPP), then the 4 waves through LDS
+  // fixed-order reduction: wavefront (transposed: permlane swaps + DPP, lsa_accum.h), then the 4 waves through LDS
   __shared__ double wsum[4][kAccumVals];
-  wave_reduce_accum(acc);
-  if ((threadIdx.x & 63) == 0)
-  {
-#pragma unroll
-    for (int v = 0; v < kAccumVals; ++v) wsum[threadIdx.x >> 6][v] = acc[v];
-  }
+  int slot;
+  const double total = wave_reduce_accum(acc, slot);  // this lane's one value of the 29, summed over the wavefront
+  if ((threadIdx.x & 1) == 0 && slot < kAccumVals) wsum[threadIdx.x >> 6][slot] = total;
   __syncthreads();
   // Zero-copy hand-over: the block's 29 partial sums land in coherent host memory as 58 granules.  A granule is
   // ONE naturally aligned 8-byte word -- the evaluation's tag above, one half of a double below -- written by ONE

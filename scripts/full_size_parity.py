@@ -35,9 +35,12 @@ for f, (pts, stamp) in enumerate(scans):
         for k in (L.EDGE, L.PLANE):
             same_keypoints &= sg.keypoints(k, 2).tobytes() == so.keypoints(k, 2).tobytes()
 print(json.dumps({
-    "model": model, "frames": frames, "points_per_frame": int(np.mean([p.size for p, _ in scans])),
+    "command": "python scripts/full_size_parity.py %d %d" % (frames, model), "model": model, "frames": frames, "points_per_frame": int(np.mean([p.size for p, _ in scans])),
     "max_translation_diff_m": worst_t, "max_rotation_diff_rad": worst_r, "keypoint_sets_identical": bool(same_keypoints),
     "keyframes": [sg.stats()[13], so.stats()[13]], "map_sizes_gpu": [int(sg.map(k).size) for k in (L.EDGE, L.PLANE)],
     "map_sizes_oracle": [int(so.map(k).size) for k in (L.EDGE, L.PLANE)],
+    "maps_on_device": bool(sg.get_param("DeviceMapsInUse")), "maps_identical_byte_for_byte": bool(all(sg.map(k).tobytes() == so.map(k).tobytes() for k in (L.EDGE, L.PLANE))),
+    "sub_maps_identical_byte_for_byte": bool(all(sg.target_submap(k).tobytes() == so.submap(k).tobytes() for k in (L.EDGE, L.PLANE))),
+    "solves_that_fell_back_to_the_host_loop": int(sg.get_param("DeviceSolveFallbacks")),
     "gpu_frames_per_s": frames / t_gpu, "oracle_16_threads_frames_per_s": frames / t_cpu,
     "final_position": sg.world_transform()[:3, 3].round(4).tolist()}))

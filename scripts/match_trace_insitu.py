@@ -49,3 +49,10 @@ for name, col in (("second", 4), ("beyond2", 5), ("cands", 6), ("far", 7), ("she
     print("corr(dur, %s) = %.2f   mean %.1f" % (name, c, tr[sel, col].mean()))
 fast = sel[dur[sel] < np.percentile(dur[sel], 50)]
 print("fast half means:", [round(float(tr[fast, c].mean()), 1) for c in range(4, 10)])
+
+xcc = (tr[:, 3] >> 32).astype(np.int64)
+print("per XCD: blocks, mean duration us, last end us")
+for x in range(8):
+    m = ok & (xcc == x)
+    if m.any():
+        print("  xcd %d: %4d blocks, mean %.1f, p90 %.1f, last end %.1f, candidates %d" % (x, int(m.sum()), dur[m].mean(), np.percentile(dur[m], 90), end[m].max(), int(tr[m, 6].sum())))

@@ -6,7 +6,7 @@ from lidarslam_amd.replay import ConcurrentReplay, sequence_seed
 
 L.bind_host_to_device(0)
 frames, warm = 40, 8
-for params in ({}, {"MapsOnDevice": 0}):
+for params in ({"MapsOnDevice": 1}, {"MapsOnDevice": 0}):
     for S in (1, 2, 4, 8):
         rep = ConcurrentReplay(0, 128, [sequence_seed(s) for s in range(S)], frames, lookahead=True, EgoMotion=3, **params)
         t0 = time.process_time()

@@ -158,7 +158,7 @@ __device__ __forceinline__ void accumulate_records(const RecordSet& rs, const Ro
 }
 
 // The same with the thread's first `cslots` residual blocks kept in LDS between the evaluations of one launch
-// (cache[f * cstride + slot * 256 + thread], f = 0..16: A, P, X, weight, a^2; weight < 0 marks a rejected keypoint):
+// (cache[f * cstride + slot * blockDim.x + thread], f = 0..16: A, P, X, weight, a^2; weight < 0 marks a rejected keypoint):
 // the first evaluation (fill == true) reads global memory and fills the cache, the others read the cache.  Same
 // records, same order, same arithmetic as accumulate_records.
 __device__ __forceinline__ void accumulate_records_cached(const RecordSet& rs, const RotConst& c, int first, int stride, double* __restrict__ cache,
@@ -169,7 +169,7 @@ __device__ __forceinline__ void accumulate_records_cached(const RecordSet& rs, c
   for (int gidx = first; gidx < total; gidx += stride, ++j)
   {
     double A[9], Px, Py, Pz, Xx, Xy, Xz, weight, a2;
-    const int at = j * 256 + (int)threadIdx.x;
+    const int at = j * (int)blockDim.x + (int)threadIdx.x;
     if (j < cslots && !fill)
     {
       weight = cache[15 * cstride + at];

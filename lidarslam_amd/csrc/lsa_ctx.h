@@ -39,6 +39,7 @@ constexpr int kAccumBlocksMax = 256;      // what the buffers hold (the grid siz
 constexpr int kMailboxStride = 64;        // 8-byte granules per block in the mailbox: 2 x 29 used, {tag, half of a double} each
 constexpr int kLmBlocksMax = 128;         // grid limit of the one-launch LM solve (k_lm_solve); LSA_LM_BLOCKS tunes the grid
 constexpr int kLmBlocks = 64;
+constexpr int kLmThreads = 512;           // threads of a workgroup of k_lm_solve (8 wavefronts: two per SIMD)
 constexpr int kLmOut = 48;                // doubles the LM kernel hands to the host (96 granules)
 constexpr int kHistRing = 256;  // half of it is cleared at a time (two fills on the ICP's stream): once in 128 matches
 constexpr int kAccumVals = 29;            // cost, g[6], H upper[21], nvalid

@@ -67,7 +67,7 @@ struct LmState
 
 struct Shared
 {
-  double wsum[4][kAccumVals];
+  double wsum[kLmThreads / 64][kAccumVals];
   unsigned gat[kLmBlocksMax][2 * kAccumVals];  // halves of every block's partial sums
   double part[kAccumVals][8];
   double tot[kAccumVals];   // the sums of the last evaluation over ALL residual blocks
@@ -112,7 +112,7 @@ __device__ __forceinline__ bool lm_evaluate(const LmParams& p, unsigned epoch, u
 #pragma unroll
     for (int v = 0; v < kAccumVals; ++v) acc[v] = 0.;
     const unsigned long long e0 = trace ? wall_clock64() : 0ull;
-    accumulate_records_cached(p.set, c, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x, cache, p.cslots, p.cslots * 256, epoch == 1, acc);
+    accumulate_records_cached(p.set, c, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x, cache, p.cslots, p.cslots * kLmThreads, epoch == 1, acc);
     const unsigned long long e1 = trace ? wall_clock64() : 0ull;
     int slot;
     const double total = wave_reduce_accum(acc, slot);  // this lane's one value of the 29, summed over the wavefront
@@ -128,7 +128,9 @@ __device__ __forceinline__ bool lm_evaluate(const LmParams& p, unsigned epoch, u
   if (threadIdx.x < 2 * kAccumVals)
   {
     const int v = threadIdx.x >> 1, half = threadIdx.x & 1;
-    const double r = ((sh.wsum[0][v] + sh.wsum[1][v]) + sh.wsum[2][v]) + sh.wsum[3][v];
+    double r = sh.wsum[0][v];
+#pragma unroll
+    for (int w = 1; w < kLmThreads / 64; ++w) r += sh.wsum[w][v];  // ((w0 + w1) + w2) + ...
     const u64 bits = (u64)__double_as_longlong(r);
     const unsigned word = half ? (unsigned)(bits >> 32) : (unsigned)(bits & 0xffffffffull);
     __hip_atomic_store(slots + (size_t)blockIdx.x * kMailboxStride + threadIdx.x, ((u64)tag << 32) | word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -139,7 +141,7 @@ __device__ __forceinline__ bool lm_evaluate(const LmParams& p, unsigned epoch, u
   {
     const unsigned long long t0 = wall_clock64();
     unsigned spins = 0;
-    for (int base = threadIdx.x; base < total; base += 8 * 256)
+    for (int base = threadIdx.x; base < total; base += 8 * kLmThreads)
     {
       while (true)
       {
@@ -148,7 +150,7 @@ __device__ __forceinline__ bool lm_evaluate(const LmParams& p, unsigned epoch, u
 #pragma unroll
         for (int k = 0; k < 8; ++k)
         {
-          const int g = base + k * 256;
+          const int g = base + k * kLmThreads;
           if (g < total)
           {
             const int b = g / (2 * kAccumVals), s = g - b * (2 * kAccumVals);
@@ -158,7 +160,7 @@ __device__ __forceinline__ bool lm_evaluate(const LmParams& p, unsigned epoch, u
 #pragma unroll
         for (int k = 0; k < 8; ++k)
         {
-          const int g = base + k * 256;
+          const int g = base + k * kLmThreads;
           if (g < total)
           {
             if ((unsigned)(x[k] >> 32) == tag)
@@ -454,10 +456,10 @@ __device__ bool lm_step(const LmParams& p, Shared& sh, bool first)
   }
 }
 
-__global__ __launch_bounds__(256) void k_lm_solve(LmParams p, u64* __restrict__ xchg, u64* __restrict__ mailbox, unsigned out_tag, unsigned long long* trace)
+__global__ __launch_bounds__(kLmThreads) void k_lm_solve(LmParams p, u64* __restrict__ xchg, u64* __restrict__ mailbox, unsigned out_tag, unsigned long long* trace)
 {
   __shared__ Shared sh;
-  extern __shared__ double lm_cache[];  // [17][cslots * 256]
+  extern __shared__ double lm_cache[];  // [17][cslots * kLmThreads]
   const bool tr = trace != nullptr && blockIdx.x == 0;
   if (threadIdx.x == 0)
   {
@@ -540,7 +542,7 @@ int lm_cache_capacity()
 {
   int slots = 0;
   for (int want = 3; want >= 1 && slots == 0; --want)
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_lm_solve), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(want * 17 * 256 * sizeof(double))) == hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_lm_solve), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(want * 17 * kLmThreads * sizeof(double))) == hipSuccess)
       slots = want;
   (void)hipGetLastError();
   return slots;
@@ -578,12 +580,12 @@ int lsa_solve_device(lsa_ctx* ctx, unsigned type_mask, const double prior[6], in
   const int nb = std::min(std::max((total + ctx->lm_records - 1) / ctx->lm_records, 1), std::min(ctx->lm_blocks, kLmBlocksMax));
   // the thread's first residual blocks stay in LDS between the evaluations (17 doubles each): as many per thread as
   // the block's share needs, as many as the LDS holds beside the kernel's own 34 KB (the rest is read again)
-  const int per_thread = (total + nb * 256 - 1) / (nb * 256);
-  const size_t slot_bytes = (size_t)17 * 256 * sizeof(double);
+  const int per_thread = (total + nb * kLmThreads - 1) / (nb * kLmThreads);
+  const size_t slot_bytes = (size_t)17 * kLmThreads * sizeof(double);
   p.cslots = std::min(per_thread, std::max(ctx->lm_cache_slots, 0));
   {
     ProfScope ps(ctx, "lm_solve", 0.);
-    hipLaunchKernelGGL(k_lm_solve, dim3(nb), dim3(256), p.cslots * slot_bytes, ctx->stream, p, ctx->lm_xchg, ctx->lm_mailbox, out_tag,
+    hipLaunchKernelGGL(k_lm_solve, dim3(nb), dim3(kLmThreads), p.cslots * slot_bytes, ctx->stream, p, ctx->lm_xchg, ctx->lm_mailbox, out_tag,
                        ctx->route_stats && ctx->trace_dev ? reinterpret_cast<unsigned long long*>(ctx->trace_dev) + (size_t)8192 * 12 : nullptr);
   }
   // host work the caller wants done while the kernel runs (one shot)

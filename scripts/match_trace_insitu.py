@@ -56,3 +56,12 @@ for x in range(8):
     m = ok & (xcc == x)
     if m.any():
         print("  xcd %d: %4d blocks, mean %.1f, p90 %.1f, last end %.1f, candidates %d" % (x, int(m.sum()), dur[m].mean(), np.percentile(dur[m], 90), end[m].max(), int(tr[m, 6].sum())))
+
+# which keypoint type a hardware block served (k_search_all: j = block / 8 < ceil(edge blocks / 8) -> edges)
+kp = [slam.keypoints(k).size for k in range(3)]
+se = ((kp[0] + 31) // 32 + 7) // 8
+bidx = np.arange(tr.shape[0])
+is_edge = (bidx // 8) < se
+for name, m in (("edge", ok & is_edge), ("plane", ok & ~is_edge)):
+    if m.any():
+        print("%s blocks %d: duration mean %.1f p90 %.1f max %.1f us, last end %.1f" % (name, int(m.sum()), dur[m].mean(), np.percentile(dur[m], 90), dur[m].max(), end[m].max()))

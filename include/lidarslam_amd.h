@@ -608,6 +608,18 @@ int lsa_device_grid_build_submap_begin(lsa_device_grid* g, const float min_point
 int lsa_device_grid_build_submap_begin_for_keypoints(lsa_device_grid* g, int box_type, int min_nb_points, int slot, int type);
 int lsa_device_grid_build_submap_end(lsa_device_grid* g);
 int lsa_device_grid_submap_valid(lsa_device_grid* g);
+/* Sub-maps AHEAD of time.  The sub-map only depends on the outer voxels the keypoints' box touches, and the predicted pose
+ * gives that box to a voxel long before the localization asks: _ahead_begin (right after lsa_keypoint_bboxes_begin(_interp)
+ * under the PREDICTED pose, no lsa_keypoint_bboxes_end) extracts the sub-map for the box of keypoint type `box_type` into
+ * the context's spare map target, behind the grid's last insertion; _ahead_poll (non-blocking; returns 0 nothing, 1
+ * extraction on its way, 2 search grid enqueued) is called now and then meanwhile (or _ahead_wait from a thread of its own); _ahead_take (right after
+ * lsa_keypoint_bboxes_begin under the ACTUAL pose) compares the two voxel ranges on the device: when they are the same the
+ * spare target becomes target (slot, type), *taken = 1 and the size is returned; otherwise *taken = 0 and the caller
+ * extracts the sub-map as usual.  The same sub-map either way. */
+int lsa_device_grid_submap_ahead_begin(lsa_device_grid* g, int box_type, int min_nb_points, int type);
+int lsa_device_grid_submap_ahead_poll(lsa_device_grid* g);
+int lsa_device_grid_submap_ahead_wait(lsa_device_grid* g); /* blocking form of _poll, for a thread with nothing else to do */
+int lsa_device_grid_submap_ahead_take(lsa_device_grid* g, int box_type, int min_nb_points, int slot, int type, int* taken);
 
 /* ---- the rolling voxel map (host) ---------------------------
  * LidarSlam::RollingGrid -- slam_lib/include/LidarSlam/RollingGrid.h:63-212,

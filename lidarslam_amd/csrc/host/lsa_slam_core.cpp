@@ -302,16 +302,23 @@ void SlamCore::ArmLookaheadInterlude()
   if (!DeviceLM) return;  // the host-driven loop has no such gap: FinishLookaheadInterlude does the work
   lsa_solve_device_interlude(Ctx, [](void* self) {
     SlamCore* core = static_cast<SlamCore*>(self);
-    core->InterludeStatus = core->TryStartLookahead();
+    core->InterludeStatus = core->InterludeWork();
     core->InterludeRan = true;
   }, this);
 }
 int SlamCore::FinishLookaheadInterlude()
 {
   if (DeviceLM) lsa_solve_device_interlude(Ctx, nullptr, nullptr);  // a solve that never got to its launch leaves it armed
-  if (!InterludeRan) InterludeStatus = TryStartLookahead();
+  if (!InterludeRan) InterludeStatus = InterludeWork();
   InterludeRan = true;
   return InterludeStatus;
+}
+// what this thread enqueues while a solve runs: the next frame's extraction once its upload is there, and (once per frame,
+// with the first solve of the ego-motion ICP) the sub-maps for the predicted boxes on the device
+int SlamCore::InterludeWork()
+{
+  LSA_TRY(TryStartLookahead());
+  return LSA_OK;
 }
 
 // Slam::AddFrames with several frames, one per LiDAR device (Slam.cxx:230-344; CheckFrames :709-743)
@@ -585,12 +592,12 @@ int SlamCore::ComputeEgoMotion()
       Trelative = Inverse(Tworld) * next;
     }
   }
+  const bool registers = EgoMotion == EgoMotionMode::REGISTRATION || EgoMotion == EgoMotionMode::MOTION_EXTRAPOLATION_AND_REGISTRATION;
   {
     const int rc = BeginSubMapSpeculation(Tworld * Trelative);
     if (rc < 0) return rc;
   }
-  if (!(EgoMotion == EgoMotionMode::REGISTRATION || EgoMotion == EgoMotionMode::MOTION_EXTRAPOLATION_AND_REGISTRATION))
-    return LSA_OK;
+  if (!registers) return LSA_OK;
 
   // kd-trees on the previous frame's raw keypoints -> device search grids, no PCIe traffic
   for (int k : {LSA_EDGE, LSA_PLANE})
@@ -684,8 +691,9 @@ int SlamCore::Localization()
     // the voxels the box of the current keypoints (at the initial pose guess) touches -- written straight into the
     // target; only the box (read back once for all types) and the sub-maps' sizes cross the bus
     Tick t;
-    WaitMaps();  // the workers have enqueued the previous keyframe's insertions
+    WaitMaps();  // the workers have enqueued the previous keyframe's insertions, and the sub-maps ahead of time
     Stats.maps_wait = t.Stop();
+    if (DevSpecStatus < 0) { const int rc = DevSpecStatus; DevSpecStatus = 0; return Fail(rc, "sub-maps ahead of time (look-ahead thread)"); }
     Stats.maps_async = std::max(MapJobSeconds[0], std::max(MapJobSeconds[1], MapJobSeconds[2]));
     for (int k = 0; k < 3; ++k)
       if (MapJobFailed[k]) { MapJobFailed[k] = 0; return Fail(LSA_E_HIP, "lsa_device_grid_add_staged (map worker)"); }
@@ -704,11 +712,19 @@ int SlamCore::Localization()
       if (MapUpdate == MappingMode::NONE) LSA_TRY(lsa_device_grid_build_submap_begin(DevMaps[k], nullptr, nullptr, -1, LSA_TARGET_MAP, k));
       else
       {
+        if (DevSpec[k])
+        {
+          // extracted ahead of time for the predicted box: stands when the actual box touches the same outer voxels
+          int taken = 0;
+          LSA_TRY(lsa_device_grid_submap_ahead_take(DevMaps[k], k, KeypointCounts[k] / 2, LSA_TARGET_MAP, k, &taken));
+          if (taken) { need[k] = false; Stats.submap_spec_hits++; SubMapSpecHitsTotal++; continue; }
+        }
         if (LocalMaps[k]->IsTimeThreshold()) LSA_TRY(lsa_device_grid_clear_old_points(DevMaps[k], CurrentTime));
         LSA_TRY(lsa_device_grid_build_submap_begin_for_keypoints(DevMaps[k], k, KeypointCounts[k] / 2, LSA_TARGET_MAP, k));
       }
     }
-    for (int k = 0; k < 3; ++k)  // the three extractions run side by side, each on its grid's stream
+    for (bool& b : DevSpec) b = false;
+    for (int k = 0; k < 3; ++k)  // the extractions follow one another on the context's stream, their sizes come back together
       if (need[k]) LSA_TRY(lsa_device_grid_build_submap_end(DevMaps[k]));
     Stats.submap += t.Stop();
   }
@@ -852,15 +868,26 @@ int SlamCore::Localization()
 int SlamCore::BeginSubMapSpeculation(const Pose& predicted)
 {
   SpecPending = false;
-  if (MapUpdate == MappingMode::NONE || DeviceMapsInUse()) return LSA_OK;  // device maps: the sub-map never leaves the device
+  for (bool& b : DevSpec) b = false;
+  if (MapUpdate == MappingMode::NONE) return LSA_OK;
+  const bool onDevice = DeviceMapsInUse();
+  if (onDevice)
+  {
+    // device maps: the sub-maps for the predicted boxes are extracted on the device, beside the ego-motion ICP; decaying
+    // maps are left to the localization (ClearOldPoints comes first there)
+    bool any = false;
+    for (int k = 0; k < 3; ++k) any = any || (UseKeypoints[k] && KeypointCounts[k] > 0);
+    if (!SubMapsAhead || !any || LocalMaps[0]->IsTimeThreshold()) return LSA_OK;
+  }
   // Localization() will look at the keypoints after undistorting them with the motion between the previous pose
   // and the (then known) current one: the prediction does the same with the predicted pose -- the scan poses of
   // InterpolateScanPose at both ends of the keypoints' time range (Slam.cxx:1271-1285, 1288-1352).  Here Tworld
   // still is the previous frame's pose.
   bool interpolated = false;
+  Pose begin = predicted, end = predicted;
+  double t0 = 0., t1 = 0.;
   if (Undistortion && !LogTrajectory.empty())
   {
-    double t0 = 0., t1 = 0.;
     LSA_TRY(lsa_keypoint_time_range(Ctx, LSA_SET_RAW_CURRENT, &t0, &t1));
     const double prevPoseTime = LogTrajectory.back().time;
     const double currPoseTime = StampToSec(CurrentStamp);
@@ -870,12 +897,42 @@ int SlamCore::BeginSubMapSpeculation(const Pose& predicted)
         if (std::abs(time / (currPoseTime - prevPoseTime)) > MaxExtrapolationRatio) return predicted;
         return LinearInterpolation(Tworld, predicted, currPoseTime + time, prevPoseTime, currPoseTime);
       };
-      const Pose begin = scanPose(t0), end = scanPose(t1);
-      LSA_TRY(lsa_keypoint_bboxes_begin_interp(Ctx, LSA_SET_RAW_CURRENT, begin.m, end.m, t0, t1));
+      begin = scanPose(t0);
+      end = scanPose(t1);
       interpolated = true;
     }
   }
-  if (!interpolated) LSA_TRY(lsa_keypoint_bboxes_begin(Ctx, LSA_SET_RAW_CURRENT, predicted.m));
+  if (onDevice)
+  {
+    // Everything else is a dozen calls into the runtime and one wait for the extraction's size: a host thread of its own
+    // does it (the one that enqueues the next frame's ego-motion targets later in the frame), this one goes on to the
+    // first search.  The boxes go onto the context's stream (they only read the raw keypoints), the extractions onto the
+    // grids' stream behind the previous keyframe's insertions, the spare targets' search grids behind the extractions.
+    int minPts[3];
+    bool use[3];
+    for (int k = 0; k < 3; ++k)
+    {
+      use[k] = UseKeypoints[k] && KeypointCounts[k] > 0;
+      minPts[k] = KeypointCounts[k] / 2;
+      if (use[k]) lsa_set_target_cell_size(Ctx, LSA_TARGET_MAP, k, static_cast<float>((k == LSA_EDGE ? KnnCellScaleMapsEdges : KnnCellScaleMaps) * LocalMaps[k]->GetLeafSize()));
+      DevSpec[k] = use[k];
+    }
+    DevSpecStatus = 0;
+    AheadWorker.Submit([this, interpolated, begin, end, t0, t1, use0 = use[0], use1 = use[1], use2 = use[2], m0 = minPts[0], m1 = minPts[1], m2 = minPts[2]] {
+      const bool use[3] = {use0, use1, use2};
+      const int minPts[3] = {m0, m1, m2};
+      for (auto& w : MapWorker) w.Wait();  // the previous keyframe's insertions are on the grids' stream by now
+      int rc = interpolated ? lsa_keypoint_bboxes_begin_interp(Ctx, LSA_SET_RAW_CURRENT, begin.m, end.m, t0, t1) : lsa_keypoint_bboxes_begin(Ctx, LSA_SET_RAW_CURRENT, begin.m);
+      for (int k = 0; k < 3 && rc >= 0; ++k)
+        if (use[k]) rc = lsa_device_grid_submap_ahead_begin(DevMaps[k], k, minPts[k], k);
+      for (int k = 0; k < 3 && rc >= 0; ++k)
+        if (use[k]) rc = lsa_device_grid_submap_ahead_wait(DevMaps[k]);
+      DevSpecStatus = rc < 0 ? rc : 0;
+    });
+    return LSA_OK;
+  }
+  if (interpolated) LSA_TRY(lsa_keypoint_bboxes_begin_interp(Ctx, LSA_SET_RAW_CURRENT, begin.m, end.m, t0, t1));
+  else LSA_TRY(lsa_keypoint_bboxes_begin(Ctx, LSA_SET_RAW_CURRENT, predicted.m));
   SpecPending = true;
   return LSA_OK;
 }
@@ -1240,6 +1297,7 @@ int SlamCore::GetRegisteredFrame(std::vector<lsa_point_t>& out)
   X("BuildTargetsAhead", BuildTargetsAhead, bool)                                                      \
   X("DeviceLM", DeviceLM, bool)                                                                        \
   X("MapsOnDevice", MapsOnDevice, bool)                                                                \
+  X("SubMapsAhead", SubMapsAhead, bool)                                                                \
   X("FusedMatch", FusedMatch, bool)                                                                    \
   X("EgoMotionICPMaxIter", EgoMotionICPMaxIter, unsigned)                                              \
   X("LocalizationICPMaxIter", LocalizationICPMaxIter, unsigned)                                        \

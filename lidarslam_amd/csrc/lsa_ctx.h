@@ -298,6 +298,7 @@ int transform_points_to(lsa_ctx* ctx, const lsa_point_t* src, int n, const doubl
 int time_from_advancement(lsa_ctx* ctx, lsa_point_t* frame, int n, double rpm, int first_packet);  // lsa_extract.hip
 int ensure_capacity(lsa_ctx* ctx, int n);
 int ensure_target(lsa_ctx* ctx, int ti, int m);
+int build_target_grids(lsa_ctx* ctx, const int* tis, int count, hipStream_t st);  // lsa_match.hip: the search grids of these targets, one chain of launches
 int ensure_match(lsa_ctx* ctx, int type, int k);
 int ensure_scratch(lsa_ctx* ctx, size_t bytes);
 int enqueue_time_range(lsa_ctx* ctx, int set, const int* counts_dev);

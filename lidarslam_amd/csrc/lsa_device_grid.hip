@@ -48,7 +48,9 @@ struct GridParams
   unsigned min_frames;
 };
 // state the kernels read and write (device memory, kStInts ints)
-enum { kStN = 0, kStNbPoints = 1, kStUpdated = 2, kStPosX = 3, kStGroups = 6, kStNew = 7, kStOff = 8, kStSub = 11, kStTmp = 12 /* 6 ints */, kStSubFirst = 18, kStCompact = 19, kStInts = 32 };
+enum { kStN = 0, kStNbPoints = 1, kStUpdated = 2, kStPosX = 3, kStGroups = 6, kStNew = 7, kStOff = 8, kStSub = 11, kStTmp = 12 /* 6 ints */, kStSubFirst = 18, kStCompact = 19, kStPred = 20 /* 6 ints: lo[3], hi[3]: outer voxels of the box a sub-map was extracted ahead for */, kStInts = 32 };
+
+__device__ __forceinline__ float ordered_to_float(unsigned u) { return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u); }
 
 __device__ __forceinline__ int round_to_int(float v)
 {
@@ -852,7 +854,6 @@ struct CopyEmit
 // device holds, clamped to the grid.  The box comes from the caller (floats) or from the bounding-box words the context's
 // lsa_keypoint_bboxes_begin left on the device (ordered unsigned, 6 per keypoint type).  Every thread works it out for
 // itself (a handful of operations against a launch of its own).
-__device__ __forceinline__ float ordered_to_float(unsigned u) { return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u); }
 struct BoxArg { float mn[3], mx[3]; };
 struct SubMapPred
 {
@@ -862,6 +863,7 @@ struct SubMapPred
   const int* st;
   BoxArg box;
   const unsigned* ctx_box;
+  const int* range;  // non-null: lo[3], hi[3] in outer voxels, worked out before (the box of a sub-map extracted ahead)
   int grid_size;
   float resolution;
   double resolution_d;
@@ -878,6 +880,13 @@ struct SubMapPred
     const int z = id / (g * g); id -= z * g * g;
     const int y = id / g; const int x = id - y * g;
     const int c[3] = {x, y, z};
+    if (range)
+    {
+#pragma unroll
+      for (int d = 0; d < 3; ++d)
+        if (c[d] < range[d] || c[d] > range[3 + d]) return false;
+    }
+    else
 #pragma unroll
     for (int d = 0; d < 3; ++d)
     {
@@ -905,6 +914,40 @@ struct PointEmit
 };
 __global__ void k_set_int(int* __restrict__ p, int v) { if (threadIdx.x == 0 && blockIdx.x == 0) *p = v; }
 __global__ void k_copy_int(int* __restrict__ dst, const int* __restrict__ src) { if (threadIdx.x == 0 && blockIdx.x == 0) *dst = *src; }
+// the outer voxels the box of `words` (ordered unsigned, lsa_keypoint_bboxes_begin) touches: lo[3], hi[3]
+__device__ __forceinline__ void box_voxels(const unsigned* __restrict__ words, int grid_size, float resolution, double resolution_d, const int* __restrict__ st, int lo[3],
+                                           int hi[3])
+{
+#pragma unroll
+  for (int d = 0; d < 3; ++d)
+  {
+    const float origin = __int_as_float(st[kStPosX + d]) - (float)((double)(grid_size / 2) * resolution_d);
+    const int a = round_to_int((ordered_to_float(words[d]) - origin) / resolution), b = round_to_int((ordered_to_float(words[3 + d]) - origin) / resolution);
+    lo[d] = a > 0 ? a : 0;
+    hi[d] = b < grid_size - 1 ? b : grid_size - 1;
+  }
+}
+// sub-map ahead of time: the voxel range of the PREDICTED box is kept in the state ...
+__global__ void k_pred_box(const unsigned* __restrict__ words, int grid_size, float resolution, double resolution_d, int* __restrict__ st)
+{
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  int lo[3], hi[3];
+  box_voxels(words, grid_size, resolution, resolution_d, st, lo, hi);
+  for (int d = 0; d < 3; ++d) { st[kStPred + d] = lo[d]; st[kStPred + 3 + d] = hi[d]; }
+}
+// ... and compared with that of the ACTUAL box when the localization asks: the sub-map only depends on the range of
+// outer voxels the box touches (RollingGrid.cxx:363-442).  {tag, same} goes to the host in one 8-byte store.
+__global__ void k_box_check(const unsigned* __restrict__ words, int grid_size, float resolution, double resolution_d, int* __restrict__ st, u64* __restrict__ host_out,
+                            unsigned tag)
+{
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  int lo[3], hi[3];
+  box_voxels(words, grid_size, resolution, resolution_d, st, lo, hi);
+  bool same = true;
+  for (int d = 0; d < 3; ++d) same = same && lo[d] == st[kStPred + d] && hi[d] == st[kStPred + 3 + d];
+  if (same) st[kStUpdated] = 0;  // the sub-map that is about to be taken over is of the map as it is now
+  __hip_atomic_store(host_out, ((u64)tag << 32) | (same ? 1u : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 
 }  // namespace
 
@@ -932,11 +975,16 @@ struct lsa_device_grid
   // the scratch buffer written -- events order them: ev_in (context -> grid) before, ev_out (grid -> context) after.
   hipStream_t stream = nullptr;
   bool own_stream = false, shared_stream = false;
-  hipEvent_t ev_in = nullptr, ev_out = nullptr, ev_sub = nullptr;
+  hipEvent_t ev_in = nullptr, ev_out = nullptr, ev_sub = nullptr, ev_ahead = nullptr;
   u64* host_sub = nullptr;     // coherent host memory: {tag, size} of the sub-map being built, one 8-byte store by the kernel
   unsigned sub_tag = 0;
   int sub_target = -1;         // target index (slot * 3 + type) of the sub-map between _begin and _end
   bool sub_pending = false;    // kernels of a sub-map are on their way
+  // a sub-map extracted AHEAD of time for a predicted box, into the context's spare map target (target[9 + type])
+  u64* host_ahead = nullptr;   // coherent host memory: [0] {tag, size} of the extraction, [1] {tag, same box?} of the check
+  unsigned ahead_tag = 0;
+  int ahead_phase = 0;         // 0 none, 1 extraction on its way, 2 search grid on its way / ready
+  int ahead_type = -1, ahead_min = 0, ahead_m = 0;
   int staged = 0;              // keypoints staged in `batch` by lsa_device_grid_stage_keypoints
   bool submap_valid = false;
   int submap_count = 0;
@@ -974,6 +1022,7 @@ void tighten(lsa_device_grid* g)
 int after_submap(lsa_device_grid* g)
 {
   G_HIP(hipStreamWaitEvent(g->stream, g->ev_sub, 0));
+  g->ahead_phase = 0;  // a sub-map extracted ahead of time was of the map before this modification
   return LSA_OK;
 }
 
@@ -1216,6 +1265,8 @@ int lsa_device_grid_create(lsa_ctx* ctx, lsa_device_grid** out)
   ok = ok && hipHostMalloc((void**)&g->host_st, kStInts * sizeof(int), hipHostMallocDefault) == hipSuccess;
   ok = ok && hipHostMalloc((void**)&g->host_sub, sizeof(u64), hipHostMallocCoherent | hipHostMallocMapped) == hipSuccess;
   if (ok) *g->host_sub = 0;
+  ok = ok && hipHostMalloc((void**)&g->host_ahead, 2 * sizeof(u64), hipHostMallocCoherent | hipHostMallocMapped) == hipSuccess;
+  if (ok) g->host_ahead[0] = g->host_ahead[1] = 0;
   {
     // The maps' kernels go on the context's LOOK-AHEAD stream (next frame's extraction, next ego-motion targets): a
     // process has four hardware queues, and the registration's stream, the look-ahead stream and the copy stream are
@@ -1238,7 +1289,7 @@ int lsa_device_grid_create(lsa_ctx* ctx, lsa_device_grid** out)
       if (ok) { ctx->map_stream_users++; g->shared_stream = true; }
     }
   }
-  for (hipEvent_t* e : {&g->ev_state, &g->ev_in, &g->ev_out, &g->ev_sub}) ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
+  for (hipEvent_t* e : {&g->ev_state, &g->ev_in, &g->ev_out, &g->ev_sub, &g->ev_ahead}) ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
   if (!ok) { lsa_device_grid_destroy(g); return LSA_E_HIP; }
   if (const char* e = std::getenv("LSA_MAP_ADD")) g->legacy_add = std::string(e) == "legacy";
   *out = g;
@@ -1256,7 +1307,8 @@ void lsa_device_grid_destroy(lsa_device_grid* g)
   fr(g->st); fr(g->batch); fr(g->bkeys); fr(g->skeys); fr(g->border); fr(g->sorder); fr(g->heads); fr(g->fresh_flag); fr(g->chunks); fr(g->sort_tmp); fr(g->old_local);
   if (g->host_st) (void)hipHostFree(g->host_st);
   if (g->host_sub) (void)hipHostFree(g->host_sub);
-  for (hipEvent_t e : {g->ev_state, g->ev_in, g->ev_out, g->ev_sub})
+  if (g->host_ahead) (void)hipHostFree(g->host_ahead);
+  for (hipEvent_t e : {g->ev_state, g->ev_in, g->ev_out, g->ev_sub, g->ev_ahead})
     if (e) (void)hipEventDestroy(e);
   if (g->stream && g->own_stream) (void)hipStreamDestroy(g->stream);
   if (g->shared_stream && --g->ctx->map_stream_users == 0 && g->ctx->map_stream)
@@ -1469,7 +1521,7 @@ int lsa_device_grid_get(lsa_device_grid* g, int clean, lsa_point_t* out, int cap
   const MapView m = g->buf[g->cur];
   rc = order_after_context(g);  // the scratch buffer is the context's; a sub-map extraction on its stream comes first too
   if (rc) return rc;
-  SubMapPred pred{m.keys, m.pts, m.count, g->st, BoxArg{}, nullptr, g->GridSize, (float)g->VoxelResolution, g->VoxelResolution, 0, g->MinFramesPerVoxel, -1, clean ? 3 : 0};
+  SubMapPred pred{m.keys, m.pts, m.count, g->st, BoxArg{}, nullptr, nullptr, g->GridSize, (float)g->VoxelResolution, g->VoxelResolution, 0, g->MinFramesPerVoxel, -1, clean ? 3 : 0};
   compact(g, pred, PointEmit{m.pts, reinterpret_cast<float4*>(ctx->scratch_out)}, g->st + kStN, g->n_upper, g->st + kStSub);
   int kept = 0;
   G_HIP(hipMemcpyAsync(&kept, g->st + kStSub, sizeof(int), hipMemcpyDeviceToHost, g->stream));
@@ -1505,10 +1557,12 @@ static int build_submap_begin(lsa_device_grid* g, const float mn[3], const float
   // coherent host memory -- no copy, no event, no host call between the kernels.
   hipStream_t st = ctx->stream;
   G_HIP(hipStreamWaitEvent(st, g->ev_out, 0));
+  G_HIP(hipStreamWaitEvent(st, g->ev_ahead, 0));  // an extraction ahead of time that was not taken over shares the scratch
+  g->ahead_phase = 0;
   Target& t = ctx->target[ti];
   const MapView m = g->buf[g->cur];
   const bool boxed = mn || box_type >= 0;
-  SubMapPred pred{m.keys, m.pts, m.count, g->st, BoxArg{}, nullptr, g->GridSize, (float)g->VoxelResolution, g->VoxelResolution, 0, g->MinFramesPerVoxel, min_nb_points, boxed ? 1 : 0};
+  SubMapPred pred{m.keys, m.pts, m.count, g->st, BoxArg{}, nullptr, nullptr, g->GridSize, (float)g->VoxelResolution, g->VoxelResolution, 0, g->MinFramesPerVoxel, min_nb_points, boxed ? 1 : 0};
   bool filtered = false;
   if (boxed)
   {
@@ -1587,6 +1641,149 @@ int lsa_device_grid_build_submap(lsa_device_grid* g, const float mn[3], const fl
 {
   const int rc = lsa_device_grid_build_submap_begin(g, mn, mx, min_nb_points, slot, type);
   return rc ? rc : lsa_device_grid_build_submap_end(g);
+}
+
+// ---- sub-maps ahead of time -------------------------------------------------------------------------------------------
+// The sub-map the next localization will ask for only depends on the outer voxels its keypoints' box touches, and that box
+// is known to a voxel long before the localization: _ahead_begin extracts the sub-map for the box of keypoint type
+// `box_type` as lsa_keypoint_bboxes_begin(_interp) just left it on the device (the PREDICTED pose) into the context's
+// spare map target, on the grid's stream behind the last insertion; _ahead_poll (non-blocking, call it now and then)
+// enqueues the spare target's search grid once the extraction's size has arrived; _ahead_take, after
+// lsa_keypoint_bboxes_begin under the ACTUAL pose, compares the two voxel ranges on the device and, when they are the
+// same, swaps the spare target in as target (slot, type): *taken = 1, the return value is the sub-map's size, and
+// lsa_device_grid_build_submap_begin / _end are not needed.  Anything that does not fit (*taken = 0) leaves everything
+// as it was.  Same sub-map, byte for byte, either way.
+int lsa_device_grid_submap_ahead_begin(lsa_device_grid* g, int box_type, int min_nb_points, int type)
+{
+  if (!g || box_type < 0 || box_type > 2 || type < 0 || type > 2) return g ? g->ctx->fail(LSA_E_ARG, "lsa_device_grid_submap_ahead_begin: bad argument") : LSA_E_ARG;
+  lsa_ctx* ctx = g->ctx;
+  G_HIP(hipSetDevice(ctx->device));
+  g->ahead_phase = 0;
+  ctx->bbox_pending = false;  // the box stays on the device
+  tighten(g);
+  if (g->n_upper == 0 || g->sub_target >= 0) return LSA_OK;
+  int rc = ensure_map(g, g->n_upper);
+  if (rc) return rc;
+  if (ctx->map_ahead_ready[type]) { G_HIP(hipEventSynchronize(ctx->ev_map_ahead[type])); ctx->map_ahead_ready[type] = false; }
+  rc = ensure_target(ctx, 9 + type, g->n_upper);
+  if (rc) return rc;
+  rc = after_submap(g);
+  if (rc) return rc;
+  rc = order_after_context(g);  // the box words; the spare target's last readers
+  if (rc) return rc;
+  hipStream_t st = g->stream;
+  // The predicted box becomes a range of outer voxels on the grid's stream, behind the last insertion (which may move the
+  // grid).  The words are rewritten for the actual box later: should this kernel be so late that it reads those, or a
+  // half-written box, the extraction below is simply for the range it stored, and _ahead_take compares the actual range
+  // with the stored one -- a wrong guess costs the extraction, never the result.
+  const unsigned* words = reinterpret_cast<const unsigned*>(ctx->range_bits + 16) + 6 * box_type;
+  hipLaunchKernelGGL(k_pred_box, dim3(1), dim3(64), 0, st, words, g->GridSize, (float)g->VoxelResolution, g->VoxelResolution, g->st);
+  Target& t = ctx->target[9 + type];
+  const MapView m = g->buf[g->cur];
+  const bool filtered = !(min_nb_points < 0 || g->MinFramesPerVoxel <= 1);
+  SubMapPred pred{m.keys, m.pts, m.count, g->st, BoxArg{}, nullptr, g->st + kStPred, g->GridSize, (float)g->VoxelResolution, g->VoxelResolution, filtered ? 1 : 0,
+                  g->MinFramesPerVoxel, min_nb_points, 1};
+  const unsigned tag = ++g->ahead_tag;
+  {
+    ProfScope ps(ctx, "map_submap_ahead", (double)g->n_upper * 44, st);
+    compact(g, pred, PointEmit{m.pts, reinterpret_cast<float4*>(t.pts)}, g->st + kStN, g->n_upper, g->st + kStSub, false, true, st, filtered ? nullptr : g->host_ahead, tag);
+    if (filtered)
+    {
+      pred.mode = 2;
+      hipLaunchKernelGGL(k_copy_int, dim3(1), dim3(64), 0, st, g->st + kStSubFirst, g->st + kStSub);
+      compact(g, pred, PointEmit{m.pts, reinterpret_cast<float4*>(t.pts)}, g->st + kStN, g->n_upper, g->st + kStSub, true, true, st, g->host_ahead, tag);
+    }
+  }
+  G_HIP(hipEventRecord(g->ev_ahead, st));  // whoever uses the grid's scratch next on another stream comes behind this
+  g->ahead_phase = 1;
+  g->ahead_type = type;
+  g->ahead_min = min_nb_points;
+  return LSA_OK;
+}
+int lsa_device_grid_submap_ahead_poll(lsa_device_grid* g)
+{
+  if (!g) return LSA_E_ARG;
+  if (g->ahead_phase != 1) return g->ahead_phase;
+  const u64 v = __atomic_load_n(g->host_ahead, __ATOMIC_ACQUIRE);
+  if ((unsigned)(v >> 32) != g->ahead_tag) return 1;
+  lsa_ctx* ctx = g->ctx;
+  G_HIP(hipSetDevice(ctx->device));
+  const int type = g->ahead_type;
+  Target& t = ctx->target[9 + type];
+  g->ahead_m = (int)(unsigned)(v & 0xffffffffull);
+  t.m = g->ahead_m;
+  t.cell_hint = ctx->target[LSA_TARGET_MAP * 3 + type].cell_hint;
+  t.dirty = false;
+  if (t.m > 0)
+  {
+    const int tis[1] = {9 + type};
+    const int rc = build_target_grids(ctx, tis, 1, g->stream);
+    if (rc) return rc;
+  }
+  G_HIP(hipEventRecord(ctx->ev_map_ahead[type], g->stream));
+  g->ahead_phase = 2;
+  return 2;
+}
+// ... or waited for (a thread that has nothing else to do): returns once the search grid has been enqueued
+int lsa_device_grid_submap_ahead_wait(lsa_device_grid* g)
+{
+  if (!g) return LSA_E_ARG;
+  const auto t0 = std::chrono::steady_clock::now();
+  unsigned spins = 0;
+  while (g->ahead_phase == 1)
+  {
+    const int rc = lsa_device_grid_submap_ahead_poll(g);
+    if (rc < 0) return rc;
+    if (rc == 1 && (++spins & 255u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(500))
+      return g->ctx->fail(LSA_E_HIP, "lsa_device_grid_submap_ahead_wait: the extraction's size did not arrive");
+#if defined(__x86_64__)
+    __builtin_ia32_pause();
+#endif
+  }
+  return g->ahead_phase;
+}
+int lsa_device_grid_submap_ahead_take(lsa_device_grid* g, int box_type, int min_nb_points, int slot, int type, int* taken)
+{
+  if (!g || !taken || box_type < 0 || box_type > 2 || slot < 0 || slot > 1 || type < 0 || type > 2)
+    return g ? g->ctx->fail(LSA_E_ARG, "lsa_device_grid_submap_ahead_take: bad argument") : LSA_E_ARG;
+  *taken = 0;
+  lsa_ctx* ctx = g->ctx;
+  if (g->ahead_phase == 1)
+  {
+    const int rc = lsa_device_grid_submap_ahead_poll(g);
+    if (rc < 0) return rc;
+  }
+  const bool fits = g->ahead_phase == 2 && g->ahead_type == type && g->ahead_min == min_nb_points && g->sub_target < 0 &&
+                    ctx->target[9 + type].cell_hint == ctx->target[slot * 3 + type].cell_hint;
+  g->ahead_phase = 0;
+  if (!fits) return LSA_OK;
+  G_HIP(hipSetDevice(ctx->device));
+  // the comparison runs on the context's stream, where the actual box was just enqueued, behind the grid's stream (the
+  // predicted range and the state it reads)
+  G_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_map_ahead[type], 0));
+  const unsigned tag = ++g->ahead_tag;
+  const unsigned* words = reinterpret_cast<const unsigned*>(ctx->range_bits + 16) + 6 * box_type;
+  hipLaunchKernelGGL(k_box_check, dim3(1), dim3(64), 0, ctx->stream, words, g->GridSize, (float)g->VoxelResolution, g->VoxelResolution, g->st, g->host_ahead + 1, tag);
+  const auto t0 = std::chrono::steady_clock::now();
+  unsigned spins = 0;
+  u64 v;
+  while ((unsigned)((v = __atomic_load_n(g->host_ahead + 1, __ATOMIC_ACQUIRE)) >> 32) != tag)
+    if ((++spins & 1023u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2))
+    {
+      G_HIP(hipStreamSynchronize(ctx->stream));
+      return ctx->fail(LSA_E_HIP, "lsa_device_grid_submap_ahead_take: the comparison did not arrive");
+    }
+  if (!(v & 1ull)) return LSA_OK;  // another range of voxels: the caller extracts the sub-map now
+  ctx->bbox_pending = false;
+  std::swap(ctx->target[slot * 3 + type], ctx->target[9 + type]);
+  ctx->target[slot * 3 + type].dirty = false;
+  g->submap_valid = true;
+  g->submap_count = g->ahead_m;
+  G_HIP(hipEventSynchronize(g->ev_state));  // the flag's last refresh has landed: it was taken back by the comparison
+  g->host_st[kStUpdated] = 0;
+  G_HIP(hipEventRecord(g->ev_sub, ctx->stream));
+  *taken = 1;
+  return g->ahead_m;
 }
 
 // RollingGrid::IsSubMapKdTreeValid(): an Add that changed a voxel's point has dropped the sub-map (RollingGrid.cxx:315-317);

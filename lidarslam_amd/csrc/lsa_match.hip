@@ -929,6 +929,11 @@ void launch_model(lsa_ctx* ctx, const lsa_point_t* q, int nq, const MatchConst& 
 
 }  // namespace
 
+namespace lsa
+{
+int build_target_grids(lsa_ctx* ctx, const int* tis, int count, hipStream_t st) { return build_grids(ctx, tis, count, st); }
+}  // namespace lsa
+
 extern "C" {
 
 int lsa_set_target(lsa_ctx* ctx, int slot, int type, const lsa_point_t* pts, int m)

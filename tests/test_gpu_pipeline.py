@@ -164,6 +164,8 @@ def test_map_maintenance_beside_the_device_work(L, O, params, on_device):
     centroid = params.get("VoxelGridSamplingMode") == 4
     assert sg.get_param("DeviceMapsInUse") == (1.0 if on_device and not centroid else 0.0)
     if params.get("MapUpdate", 2) != 0:
+        # host maps: sub-maps extracted ahead of time by the map workers for the predicted boxes were kept
+        # (device maps: "SubMapsAhead", off by default, has a test of its own)
         assert (sg.get_param("SubMapSpeculationHits") > 0) == (not on_device or centroid)
     for k in range(3):
         assert sg.map(k).tobytes() == so.map(k).tobytes()
@@ -761,3 +763,21 @@ def test_the_maps_follow_a_setter_that_moves_them_between_device_and_host(L, O):
         dp, da = pose_diff(ref.world_transform(), sw.world_transform())
         assert dp < 2e-2 and da < 2e-3, (f, dp, da)
     ref.close(), sw.close()
+
+
+def test_sub_maps_ahead_of_time_change_nothing_but_the_schedule(L):
+    """"SubMapsAhead": the sub-map for the predicted box, extracted on the device beside the ego-motion ICP and swapped in
+    when the actual box touches the same outer voxels -- the same poses, maps and sub-maps, bit for bit, as extracting it
+    when the localization asks"""
+    a, b = L.Slam(0, EgoMotion=3, SubMapsAhead=1), L.Slam(0, EgoMotion=3, SubMapsAhead=0)
+    for f in range(25):
+        pts, stamp = L.synth_frame(16, 1000, f)
+        for s in (a, b):
+            s.add_frame(pts, stamp, f)
+        assert np.array_equal(a.world_transform(), b.world_transform()), f
+        for k in range(2):
+            assert a.target_submap(k).tobytes() == b.target_submap(k).tobytes(), (f, k)
+    for k in range(2):
+        assert a.map(k).tobytes() == b.map(k).tobytes()
+    assert a.get_param("SubMapSpeculationHits") > 20 and b.get_param("SubMapSpeculationHits") == 0
+    a.close(), b.close()

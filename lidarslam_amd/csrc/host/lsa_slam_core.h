@@ -210,11 +210,11 @@ public:
   // hand their points out in key order ("OrderedMaps"), so the two give the same sub-maps and the same poses.
   lsa_device_grid* DevMaps[3] = {nullptr, nullptr, nullptr};
   bool MapsOnDevice = true;
-  // device maps: sub-maps extracted for the predicted boxes beside the ego-motion ICP ("SubMapsAhead").  Off by default:
-  // the extraction queues on the look-ahead stream behind the previous keyframe's insertions and its search grid is
-  // ready 0.55 ms into the frame, when the localization has been waiting for it for 0.05 ms -- measured 921 against 940
-  // frames/s.  It pays once the insertion is shorter than the ego-motion ICP it runs beside.
-  bool SubMapsAhead = false;
+  // device maps: sub-maps extracted for the predicted boxes beside the ego-motion ICP ("SubMapsAhead"): the extraction and
+  // the spare target's search grid queue on the look-ahead stream behind the previous keyframe's insertions, a host thread
+  // of their own enqueues them, and the localization swaps the target in when the actual box touches the same outer voxels
+  // (980 against 950 frames/s; with the first, slower insertion kernels it lost: the sub-map came 0.05 ms late)
+  bool SubMapsAhead = true;
   bool DevSpec[3] = {false, false, false};
   bool OrderedMaps = true;
   bool DeviceMapsInUse() const { return MapsOnDevice && DevMaps[0] && LocalMaps[0]->GetSampling() != SamplingMode::CENTROID; }

@@ -133,6 +133,7 @@ __device__ __forceinline__ int f2o_i(float f) { const int i = __float_as_int(f);
 __device__ __forceinline__ float o2f_i(int i) { return __int_as_float(i >= 0 ? i : i ^ 0x7fffffff); }
 __global__ __launch_bounds__(256) void k_batch_bbox(const float4* __restrict__ batch, int n, int* __restrict__ st)
 {
+  __shared__ float smn[4][3], smx[4][3];
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
   if (i < n)
@@ -147,11 +148,15 @@ __global__ __launch_bounds__(256) void k_batch_bbox(const float4* __restrict__ b
       mx[d] = fmaxf(mx[d], __shfl_down(mx[d], o));
     }
   if ((threadIdx.x & 63) == 0)
-    for (int d = 0; d < 3; ++d)
-    {
-      atomicMin(&st[kStTmp + d], f2o_i(mn[d]));
-      atomicMax(&st[kStTmp + 3 + d], f2o_i(mx[d]));
-    }
+    for (int d = 0; d < 3; ++d) { smn[threadIdx.x >> 6][d] = mn[d]; smx[threadIdx.x >> 6][d] = mx[d]; }
+  __syncthreads();
+  // six atomics per workgroup (every wavefront aiming at the same six words was 15 us for 27 k points)
+  if (threadIdx.x < 3)
+  {
+    const int d = threadIdx.x;
+    atomicMin(&st[kStTmp + d], f2o_i(fminf(fminf(smn[0][d], smn[1][d]), fminf(smn[2][d], smn[3][d]))));
+    atomicMax(&st[kStTmp + 3 + d], f2o_i(fmaxf(fmaxf(smx[0][d], smx[1][d]), fmaxf(smx[2][d], smx[3][d]))));
+  }
 }
 // how many outer voxels the grid has to move so that the box fits (one thread); explicit box: roll_to != nullptr
 __global__ void k_roll_decide(GridParams p, int* __restrict__ st, int use_box)
@@ -559,41 +564,119 @@ __global__ __launch_bounds__(256) void k_add_keys(const float4* __restrict__ bat
   if (threadIdx.x == 0) old_chunks[chunk] = run;
 }
 
-// launch 3: runs of 4096 (key, arrival index) pairs sorted in LDS (bitonic; the pairs are unique, so the order is the
-// stable order by key)
+// launch 3: runs of 4096 (key, arrival index) pairs sorted by one workgroup (bitonic; the pairs are unique, so the order
+// is the stable order by key).  A thread holds four consecutive pairs in registers: of the 78 steps of the network, the
+// 23 whose partner is one of the thread's own pairs are done in place, the 45 whose partner sits in another lane of the
+// wavefront go through lane exchanges, and only the 10 that cross wavefronts go through LDS (two buffers, one barrier
+// each).  (The first version did all 78 through LDS with a barrier each: 55 us a run.)
 constexpr int kRun = 4096;
+struct SortPair
+{
+  u64 k;
+  unsigned i;
+};
+__device__ __forceinline__ bool pair_gt(const SortPair& a, const SortPair& b) { return a.k > b.k || (a.k == b.k && a.i > b.i); }
+// the value of lane (lane ^ M) for one 32-bit word: DPP operands and gfx950's permlane swaps, no LDS crossbar
+template <int M>
+__device__ __forceinline__ unsigned word_xor(unsigned x, int lane)
+{
+  if (M == 1) return (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xF, 0xF, true);   // quad_perm [1, 0, 3, 2]
+  if (M == 2) return (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E, 0xF, 0xF, true);   // quad_perm [2, 3, 0, 1]
+  if (M == 4)
+  {
+    const unsigned up = (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x104, 0xF, 0xF, true);  // row_shl:4: lane i <- i + 4
+    const unsigned dn = (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, true);  // row_shr:4: lane i <- i - 4
+    return (lane & 4) ? dn : up;
+  }
+  if (M == 8) return (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x128, 0xF, 0xF, true);   // row_ror:8
+  if (M == 16)
+  {
+    const auto r = __builtin_amdgcn_permlane16_swap(x, x, false, false);  // [0]: rows 0 0 2 2, [1]: rows 1 1 3 3
+    return (lane & 16) ? r[0] : r[1];
+  }
+  const auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false);    // [0]: lower half twice, [1]: upper half twice
+  return (lane & 32) ? r[0] : r[1];
+}
+template <int M>
+__device__ __forceinline__ SortPair lane_xor(const SortPair& v, int lane)
+{
+  SortPair o;
+  const unsigned lo = word_xor<M>((unsigned)(v.k & 0xffffffffull), lane), hi = word_xor<M>((unsigned)(v.k >> 32), lane);
+  o.k = ((u64)hi << 32) | lo;
+  o.i = word_xor<M>(v.i, lane);
+  return o;
+}
 __global__ __launch_bounds__(1024) void k_sort_runs(const u64* keys, int n, u64* out_keys, unsigned* __restrict__ out_idx)  // keys == out_keys: in place, run by run
 {
-  __shared__ u64 sk[kRun];
-  __shared__ unsigned si[kRun];
-  const int base = blockIdx.x * kRun;
-  for (int t = threadIdx.x; t < kRun; t += 1024)
+  __shared__ u64 sk[2][kRun];
+  __shared__ unsigned si[2][kRun];
+  const int base = blockIdx.x * kRun, t = threadIdx.x;
+  SortPair v[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
   {
-    const int i = base + t;
-    sk[t] = i < n ? keys[i] : kNoKey;
-    si[t] = i < n ? (unsigned)i : 0xffffffffu;
+    const int i = base + 4 * t + e;
+    v[e].k = i < n ? keys[i] : kNoKey;
+    v[e].i = i < n ? (unsigned)i : 0xffffffffu;
   }
-  __syncthreads();
+  int buf = 0;
   for (int k = 2; k <= kRun; k <<= 1)
     for (int j = k >> 1; j > 0; j >>= 1)
     {
-      for (int t = threadIdx.x; t < kRun / 2; t += 1024)
+      if (j <= 2)
       {
-        // the t-th pair of this step: a = t with a zero inserted at bit log2(j)
-        const int a = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-        const int b = a | j;
-        const bool up = (a & k) == 0;
-        const u64 ka = sk[a], kb = sk[b];
-        const unsigned ia = si[a], ib = si[b];
-        const bool gt = ka > kb || (ka == kb && ia > ib);
-        if (gt == up) { sk[a] = kb; sk[b] = ka; si[a] = ib; si[b] = ia; }
+        // partner = another pair of this thread (constant register indices: j = 1 pairs 0-1 and 2-3, j = 2 pairs 0-2 and 1-3)
+        auto cx = [&](SortPair& a, SortPair& b, int pos) {
+          const bool up = ((pos & k) == 0);
+          if (pair_gt(a, b) == up) { const SortPair x = a; a = b; b = x; }
+        };
+        if (j == 1) { cx(v[0], v[1], 4 * t); cx(v[2], v[3], 4 * t + 2); }
+        else { cx(v[0], v[2], 4 * t); cx(v[1], v[3], 4 * t + 1); }
       }
-      __syncthreads();
+      else
+      {
+        const int tj = j >> 2;                  // the partner thread is t ^ tj, same place inside the thread
+        const bool lower = (t & tj) == 0;
+        SortPair o[4];
+        if (tj < 64)
+        {
+          const int lane = t & 63;
+          // one of six code paths, chosen by a scalar branch (the step is the same for the whole workgroup)
+          switch (__builtin_amdgcn_readfirstlane(tj))
+          {
+            case 1: _Pragma("unroll") for (int e = 0; e < 4; ++e) o[e] = lane_xor<1>(v[e], lane); break;
+            case 2: _Pragma("unroll") for (int e = 0; e < 4; ++e) o[e] = lane_xor<2>(v[e], lane); break;
+            case 4: _Pragma("unroll") for (int e = 0; e < 4; ++e) o[e] = lane_xor<4>(v[e], lane); break;
+            case 8: _Pragma("unroll") for (int e = 0; e < 4; ++e) o[e] = lane_xor<8>(v[e], lane); break;
+            case 16: _Pragma("unroll") for (int e = 0; e < 4; ++e) o[e] = lane_xor<16>(v[e], lane); break;
+            default: _Pragma("unroll") for (int e = 0; e < 4; ++e) o[e] = lane_xor<32>(v[e], lane); break;
+          }
+        }
+        else
+        {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { sk[buf][4 * t + e] = v[e].k; si[buf][4 * t + e] = v[e].i; }
+          __syncthreads();
+          const int pt = t ^ tj;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { o[e].k = sk[buf][4 * pt + e]; o[e].i = si[buf][4 * pt + e]; }
+          buf ^= 1;  // the next step through LDS writes the other buffer: this one may still be read
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+        {
+          const bool up = (((4 * t + e) & k) == 0);
+          const bool take_min = lower == up;
+          const bool mine_gt = pair_gt(v[e], o[e]);
+          if (mine_gt == take_min) v[e] = o[e];
+        }
+      }
     }
-  for (int t = threadIdx.x; t < kRun; t += 1024)
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
   {
-    const int i = base + t;
-    if (i < n) { out_keys[i] = sk[t]; out_idx[i] = si[t]; }
+    const int i = base + 4 * t + e;
+    if (i < n) { out_keys[i] = v[e].k; out_idx[i] = v[e].i; }
   }
 }
 // launch 4 (more than one run): every pair's place is the number of pairs of all runs in front of it

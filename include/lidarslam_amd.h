@@ -594,6 +594,8 @@ int lsa_device_grid_add_keypoints(lsa_device_grid* g, int set, int type, const d
  * context's thread) reads the keypoints -- the set may be rewritten right after --, _add_staged inserts them. */
 int lsa_device_grid_stage_keypoints(lsa_device_grid* g, int set, int type, const double pose[16]);
 int lsa_device_grid_add_staged(lsa_device_grid* g, double time);
+/* ... for up to three maps of one context at once: one launch of every step serves all of them (a block row per map). */
+int lsa_device_grid_add_staged_all(lsa_device_grid* const* grids, int count, double time);
 int lsa_device_grid_roll(lsa_device_grid* g, const float min_point[3], const float max_point[3]);
 int lsa_device_grid_clear_old_points(lsa_device_grid* g, double current_time);
 /* RollingGrid::Get(clean): points written. */

@@ -1041,19 +1041,25 @@ int SlamCore::UpdateMapsUsingTworld()
   {
     // the keyframe's keypoints go into the device maps as they are (WORLD transform, keying, sort, fold, merge: kernels on
     // the context's stream, nothing is waited for)
-    // this thread only hands the keypoints over (one transform kernel per type on the grid's stream); the workers
-    // enqueue the insertions, which run on the grids' streams beside the next frame
+    // this thread only hands the keypoints over (one transform kernel per type); ONE worker enqueues the insertion of all
+    // the types -- seven launches, a block row per map -- which runs on the look-ahead stream beside the next frame
+    lsa_device_grid* grids[3];
+    int ng = 0;
     for (int k = 0; k < 3; ++k)
     {
       if (!UseKeypoints[k]) continue;
       LSA_TRY(lsa_device_grid_stage_keypoints(DevMaps[k], LSA_SET_WORKING, k, Tworld.m));
-      lsa_device_grid* grid = DevMaps[k];
+      grids[ng++] = DevMaps[k];
+    }
+    if (ng > 0)
+    {
       const double time = CurrentTime;
-      int* failed = &MapJobFailed[k];
-      double* spent = &MapJobSeconds[k];
-      MapWorker[k].Submit([grid, time, failed, spent] {
+      int* failed = &MapJobFailed[0];
+      double* spent = &MapJobSeconds[0];
+      MapWorker[0].Submit([g0 = grids[0], g1 = grids[1 % ng], g2 = grids[2 % ng], ng, time, failed, spent] {
+        lsa_device_grid* gs[3] = {g0, g1, g2};
         Tick t;
-        if (lsa_device_grid_add_staged(grid, time) < 0) *failed = 1;
+        if (lsa_device_grid_add_staged_all(gs, ng, time) < 0) *failed = 1;
         *spent += t.Stop();  // host time of the enqueue (the kernels run on behind it)
       });
     }

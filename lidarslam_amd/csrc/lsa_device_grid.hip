@@ -131,10 +131,10 @@ struct MapView
 // bounding box of the batch: ordered-int atomics into st[kStTmp .. +5]
 __device__ __forceinline__ int f2o_i(float f) { const int i = __float_as_int(f); return i >= 0 ? i : i ^ 0x7fffffff; }
 __device__ __forceinline__ float o2f_i(int i) { return __int_as_float(i >= 0 ? i : i ^ 0x7fffffff); }
-__global__ __launch_bounds__(256) void k_batch_bbox(const float4* __restrict__ batch, int n, int* __restrict__ st)
+__device__ __forceinline__ void d_batch_bbox(int bx, const float4* __restrict__ batch, int n, int* __restrict__ st)
 {
   __shared__ float smn[4][3], smx[4][3];
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = bx * blockDim.x + threadIdx.x;
   float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
   if (i < n)
   {
@@ -513,15 +513,15 @@ __device__ __forceinline__ bool shifted_key(u64 k, const Shift& s, int g, u64& o
 
 // launch 2: blocks [0, kblocks): the keys of the batch in the grid after the move; the others: 1024 old voxels each, which
 // of them survive the move -- every voxel's rank among the survivors of its chunk, and the chunk's count
-__global__ __launch_bounds__(256) void k_add_keys(const float4* __restrict__ batch, int n, int kblocks, GridParams p, const int* __restrict__ st, int use_box,
+__device__ __forceinline__ void d_add_keys(int bx, const float4* __restrict__ batch, int n, int kblocks, GridParams p, const int* __restrict__ st, int use_box,
                                                   u64* __restrict__ keys, const u64* __restrict__ old_keys, int* __restrict__ old_local,
-                                                  int* __restrict__ old_chunks)
+                                                  int* __restrict__ old_chunks, int ochunks)
 {
   const Shift s = roll_shift(p, st, use_box);
   const int g = p.grid_size;
-  if ((int)blockIdx.x < kblocks)
+  if ((int)bx < kblocks)
   {
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int i = bx * 256 + threadIdx.x;
     if (i >= n) return;
     const float4 a = batch[2 * (size_t)i];
     const float pt[3] = {a.x, a.y, a.z};
@@ -543,7 +543,8 @@ __global__ __launch_bounds__(256) void k_add_keys(const float4* __restrict__ bat
     return;
   }
   __shared__ int wave_cnt[4];
-  const int chunk = blockIdx.x - kblocks;
+  const int chunk = bx - kblocks;
+  if (chunk >= ochunks) return;  // (a launch shared with a bigger map)
   const int N = st[kStN];
   int run = 0;
   for (int q = 0; q < 4; ++q)
@@ -606,11 +607,12 @@ __device__ __forceinline__ SortPair lane_xor(const SortPair& v, int lane)
   o.i = word_xor<M>(v.i, lane);
   return o;
 }
-__global__ __launch_bounds__(1024) void k_sort_runs(const u64* keys, int n, u64* out_keys, unsigned* __restrict__ out_idx)  // keys == out_keys: in place, run by run
+__device__ __forceinline__ void d_sort_runs(int bx, const u64* keys, int n, u64* out_keys, unsigned* __restrict__ out_idx)  // keys == out_keys: in place, run by run
 {
   __shared__ u64 sk[2][kRun];
   __shared__ unsigned si[2][kRun];
-  const int base = blockIdx.x * kRun, t = threadIdx.x;
+  const int base = bx * kRun, t = threadIdx.x;
+  if (base >= n) return;  // (a launch shared with a bigger batch)
   SortPair v[4];
 #pragma unroll
   for (int e = 0; e < 4; ++e)
@@ -680,10 +682,10 @@ __global__ __launch_bounds__(1024) void k_sort_runs(const u64* keys, int n, u64*
   }
 }
 // launch 4 (more than one run): every pair's place is the number of pairs of all runs in front of it
-__global__ __launch_bounds__(256) void k_merge_runs(const u64* __restrict__ keys, const unsigned* __restrict__ idx, int n, u64* __restrict__ out_keys,
+__device__ __forceinline__ void d_merge_runs(int bx, const u64* __restrict__ keys, const unsigned* __restrict__ idx, int n, u64* __restrict__ out_keys,
                                                     unsigned* __restrict__ out_idx)
 {
-  const int e = blockIdx.x * 256 + threadIdx.x;
+  const int e = bx * 256 + threadIdx.x;
   if (e >= n) return;
   const u64 k = keys[e];
   const unsigned id = idx[e];
@@ -709,14 +711,15 @@ __global__ __launch_bounds__(256) void k_merge_runs(const u64* __restrict__ keys
 // launch 5: one thread per place of the sorted batch; the first of a run of equal keys folds the run's points into the
 // voxel, in arrival order, by the reference's per-point rule.  An existing voxel is updated where it is (the old array);
 // a new one is left at the thread's own place in `fresh`, flagged, with its rank among the new ones of the block.
-__global__ __launch_bounds__(256) void k_add_fold(const float4* __restrict__ batch, int n, const u64* __restrict__ skeys, const unsigned* __restrict__ sorder,
+__device__ __forceinline__ void d_add_fold(int bx, const float4* __restrict__ batch, int n, const u64* __restrict__ skeys, const unsigned* __restrict__ sorder,
                                                   GridParams p, int* __restrict__ st, int use_box, MapView map, MapView fresh, int* __restrict__ fresh_flag,
                                                   int* __restrict__ fresh_chunks, int fixed, double time)
 {
   __shared__ int wave_cnt[4];
+  if (bx * 256 >= n) return;  // (a launch shared with a bigger batch)
   const Shift sft = roll_shift(p, st, use_box);
   const int g = p.grid_size;
-  const int j0 = blockIdx.x * 256 + threadIdx.x;
+  const int j0 = bx * 256 + threadIdx.x;
   const u64 key = j0 < n ? skeys[j0] : kNoKey;
   const bool head = j0 < n && key != kNoKey && (j0 == 0 || skeys[j0 - 1] != key);
   bool is_fresh = false;
@@ -812,19 +815,21 @@ __global__ __launch_bounds__(256) void k_add_fold(const float4* __restrict__ bat
   int before = 0;
   for (int w = 0; w < wv; ++w) before += wave_cnt[w];
   if (j0 < n) fresh_flag[j0] = ((before + __popcll(ballot & ((1ull << lane) - 1ull))) << 1) | (is_fresh ? 1 : 0);
-  if (threadIdx.x == 0) fresh_chunks[blockIdx.x] = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+  if (threadIdx.x == 0) fresh_chunks[bx] = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
 }
 
 // launch 6: the new map.  Blocks [0, oblocks): 1024 old voxels each -- a survivor's place is its rank among the survivors
 // plus the number of new voxels in front of it; the other blocks: 256 places of the sorted batch each -- a new voxel's
 // place is its rank among the new ones plus the number of survivors in front of it.  Every block scans the chunk counts
 // of both arrays for itself (dynamic LDS: ochunks + fchunks + 2 ints).
-__global__ __launch_bounds__(256) void k_add_merge(GridParams p, int* __restrict__ st, int use_box, MapView old, const int* __restrict__ old_local,
+__device__ __forceinline__ void d_add_merge(int bx, GridParams p, int* __restrict__ st, int use_box, MapView old, const int* __restrict__ old_local,
                                                    const int* __restrict__ old_chunks, int ochunks, int oblocks, const u64* __restrict__ skeys, int n, MapView fresh,
                                                    const int* __restrict__ fresh_flag, const int* __restrict__ fresh_chunks, int fchunks, MapView dst)
 {
   extern __shared__ int scan[];  // [ochunks + 1] exclusive scan of the survivors per chunk, then [fchunks + 1] of the new voxels per block
   __shared__ int carry;
+  // oblocks: where the launch's blocks for the sorted batch begin (it may be shared with a bigger map)
+  if (bx < oblocks ? bx >= ochunks : (bx - oblocks) * 256 >= n) return;
   int* const oscan = scan;
   int* const fscan = scan + ochunks + 1;
   const Shift sft = roll_shift(p, st, use_box);
@@ -862,14 +867,14 @@ __global__ __launch_bounds__(256) void k_add_merge(GridParams p, int* __restrict
     __syncthreads();
   }
   const int survivors = oscan[ochunks], created = fscan[fchunks];
-  if (blockIdx.x == 0 && threadIdx.x == 0) { st[kStCompact] = survivors; st[kStNew] = created; }
+  if (bx == 0 && threadIdx.x == 0) { st[kStCompact] = survivors; st[kStNew] = created; }
   auto fresh_before = [&](int j) { return j >= n ? created : fscan[j >> 8] + (fresh_flag[j] >> 1); };
   auto survivors_before = [&](int i) { return i >= N ? survivors : oscan[i >> 10] + old_local[i]; };
-  if ((int)blockIdx.x < oblocks)
+  if ((int)bx < oblocks)
   {
     for (int q = 0; q < 4; ++q)
     {
-      const int i = blockIdx.x * 1024 + q * 256 + threadIdx.x;
+      const int i = bx * 1024 + q * 256 + threadIdx.x;
       if (i >= N) continue;
       u64 nk;
       if (!shifted_key(old.keys[i], sft, g, nk)) continue;
@@ -881,7 +886,7 @@ __global__ __launch_bounds__(256) void k_add_merge(GridParams p, int* __restrict
     }
     return;
   }
-  const int j = (blockIdx.x - oblocks) * 256 + threadIdx.x;
+  const int j = (bx - oblocks) * 256 + threadIdx.x;
   if (j >= n || !(fresh_flag[j] & 1)) return;
   const u64 key = skeys[j];
   const int at = fresh_before(j) + survivors_before(lower_bound_old(old.keys, N, vkey_of_new(key, sft, g), sft.any, g));
@@ -891,9 +896,9 @@ __global__ __launch_bounds__(256) void k_add_merge(GridParams p, int* __restrict
   dst.count[at] = fresh.count[j];
 }
 // launch 7: the move and the counts become the grid's state (Roll recounts the points when the grid moved, :155)
-__global__ void k_add_commit(GridParams p, int* __restrict__ st, int use_box)
+__device__ __forceinline__ void d_add_commit(int bx, GridParams p, int* __restrict__ st, int use_box)
 {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (threadIdx.x != 0 || bx != 0) return;
   const Shift s = roll_shift(p, st, use_box);
   const int survivors = st[kStCompact], created = st[kStNew];
   st[kStNbPoints] = (s.any ? survivors : st[kStNbPoints]) + created;
@@ -906,6 +911,47 @@ __global__ void k_add_commit(GridParams p, int* __restrict__ st, int use_box)
     st[kStTmp + 3 + d] = (int)0x80000000;
   }
 }
+
+// One launch of each step serves all the maps of a keyframe (blockIdx.y = map): the insertions of the keypoint types run
+// side by side instead of one behind the other on the stream they share.
+struct AddOne
+{
+  const float4* batch;
+  int n, use_box, fixed;
+  double time;
+  GridParams p;
+  int* st;
+  u64 *bkeys, *skeys;
+  unsigned *border, *sorder;
+  MapView map, fresh, dst;
+  int *old_local, *old_chunks, *fresh_flag, *fresh_chunks;
+  int ochunks;
+};
+struct AddBatch
+{
+  AddOne a[3];
+  int kblocks, oblocks;  // of the launch: the largest of the maps'
+};
+__global__ __launch_bounds__(256) void k_batch_bbox(AddBatch b) { const AddOne& A = b.a[blockIdx.y]; if (A.use_box) d_batch_bbox(blockIdx.x, A.batch, A.n, A.st); }
+__global__ __launch_bounds__(256) void k_add_keys(AddBatch b)
+{
+  const AddOne& A = b.a[blockIdx.y];
+  d_add_keys(blockIdx.x, A.batch, A.n, b.kblocks, A.p, A.st, A.use_box, A.bkeys, A.map.keys, A.old_local, A.old_chunks, A.ochunks);
+}
+__global__ __launch_bounds__(1024) void k_sort_runs(AddBatch b) { const AddOne& A = b.a[blockIdx.y]; d_sort_runs(blockIdx.x, A.bkeys, A.n, A.bkeys, A.border); }
+__global__ __launch_bounds__(256) void k_merge_runs(AddBatch b) { const AddOne& A = b.a[blockIdx.y]; d_merge_runs(blockIdx.x, A.bkeys, A.border, A.n, A.skeys, A.sorder); }
+__global__ __launch_bounds__(256) void k_add_fold(AddBatch b)
+{
+  const AddOne& A = b.a[blockIdx.y];
+  d_add_fold(blockIdx.x, A.batch, A.n, A.skeys, A.sorder, A.p, A.st, A.use_box, A.map, A.fresh, A.fresh_flag, A.fresh_chunks, A.fixed, A.time);
+}
+__global__ __launch_bounds__(256) void k_add_merge(AddBatch b)
+{
+  const AddOne& A = b.a[blockIdx.y];
+  d_add_merge(blockIdx.x, A.p, A.st, A.use_box, A.map, A.old_local, A.old_chunks, A.ochunks, b.oblocks, A.skeys, A.n, A.fresh, A.fresh_flag, A.fresh_chunks, (A.n + 255) / 256,
+              A.dst);
+}
+__global__ void k_add_commit(AddBatch b) { const AddOne& A = b.a[blockIdx.y]; d_add_commit(blockIdx.x, A.p, A.st, A.use_box); }
 
 // ---- ClearOldPoints (RollingGrid.cxx:325-351) ----------------------------------------------------------------------
 struct DecayPred
@@ -1078,7 +1124,6 @@ struct lsa_device_grid
   unsigned *border = nullptr, *sorder = nullptr;
   int *heads = nullptr, *fresh_flag = nullptr, *chunks = nullptr;
   int* old_local = nullptr;    // [cap] rank of an old voxel among the survivors of its chunk (Add)
-  bool legacy_add = false;     // LSA_MAP_ADD=legacy: the chain of library sort and compactions the seven-launch Add replaced
   MapView fresh = {}, fresh2 = {};
   void* sort_tmp = nullptr;
   size_t sort_tmp_bytes = 0;
@@ -1262,76 +1307,61 @@ int roll(lsa_device_grid* g, bool use_box)
   return LSA_OK;
 }
 
-// Add of the n points in g->batch (device): the first version's chain, kept for comparison (LSA_MAP_ADD=legacy)
-int add_batch_legacy(lsa_device_grid* g, int n, bool fixed, double time, bool do_roll)
+// Add of the ns[i] points in gs[i]->batch (device), for up to three maps of one context at a time: seven launches
+// whatever the number of maps
+int add_batches(lsa_device_grid* const* gs, const int* ns, int count, bool fixed, double time, bool do_roll)
 {
+  lsa_device_grid* g = gs[0];  // (for the error macro; all maps share the context and the stream)
   hipStream_t st = g->stream;
-  tighten(g);
-  int rc = after_submap(g);
-  if (rc) return rc;
-  rc = ensure_map(g, g->n_upper + n);
-  if (rc) return rc;
-  const GridParams p = params_of(g);
-  ProfScope ps(g->ctx, "map_add", (double)n * (32 + 12 + 44) + (double)g->n_upper * 44 * (do_roll ? 2 : 1), g->stream);
-  if (do_roll)
+  AddBatch b{};
+  int kmax = 0, omax = 0, runs = 0;
+  for (int i = 0; i < count; ++i)
   {
-    hipLaunchKernelGGL(k_batch_bbox, dim3((n + 255) / 256), dim3(256), 0, st, g->batch, n, g->st);
-    rc = roll(g, true);
+    lsa_device_grid* gi = gs[i];
+    if (gi->ctx != g->ctx || gi->stream != st) return g->ctx->fail(LSA_E_ARG, "lsa_device_grid: the maps of one insertion share a context");
+    tighten(gi);
+    int rc = after_submap(gi);
+    if (rc) return rc;
+    rc = ensure_map(gi, gi->n_upper + ns[i]);
+    if (rc) return rc;
+    AddOne& A = b.a[i];
+    A.batch = gi->batch; A.n = ns[i]; A.use_box = do_roll ? 1 : 0; A.fixed = fixed ? 1 : 0; A.time = time;
+    A.p = params_of(gi); A.st = gi->st;
+    A.bkeys = gi->bkeys; A.skeys = gi->skeys; A.border = gi->border; A.sorder = gi->sorder;
+    A.map = gi->buf[gi->cur]; A.dst = gi->buf[1 - gi->cur]; A.fresh = gi->fresh;
+    A.old_local = gi->old_local; A.old_chunks = gi->chunks; A.fresh_flag = gi->fresh_flag; A.fresh_chunks = gi->heads;
+    A.ochunks = std::max((gi->n_upper + 1023) / 1024, 1);
+    kmax = std::max(kmax, (ns[i] + 255) / 256);
+    omax = std::max(omax, A.ochunks);
+    runs = std::max(runs, (ns[i] + kRun - 1) / kRun);
+  }
+  b.kblocks = kmax;
+  b.oblocks = omax;
+  const size_t lds = (size_t)(omax + kmax + 2) * sizeof(int);
+  if (lds > 48 * 1024) return g->ctx->fail(LSA_E_CAPACITY, "lsa_device_grid: more than twelve million voxels in a map");
+  double bytes = 0;
+  for (int i = 0; i < count; ++i) bytes += (double)ns[i] * (32 + 12 + 44) + (double)gs[i]->n_upper * 44 * 2;
+  {
+    ProfScope ps(g->ctx, "map_add", bytes, st);
+    const unsigned y = (unsigned)count;
+    if (do_roll) hipLaunchKernelGGL(k_batch_bbox, dim3(kmax, y), dim3(256), 0, st, b);
+    hipLaunchKernelGGL(k_add_keys, dim3(kmax + omax, y), dim3(256), 0, st, b);
+    hipLaunchKernelGGL(k_sort_runs, dim3(runs, y), dim3(1024), 0, st, b);
+    hipLaunchKernelGGL(k_merge_runs, dim3(kmax, y), dim3(256), 0, st, b);
+    hipLaunchKernelGGL(k_add_fold, dim3(kmax, y), dim3(256), 0, st, b);
+    hipLaunchKernelGGL(k_add_merge, dim3(omax + kmax, y), dim3(256), lds, st, b);
+    hipLaunchKernelGGL(k_add_commit, dim3(1, y), dim3(64), 0, st, b);
+  }
+  for (int i = 0; i < count; ++i)
+  {
+    gs[i]->cur = 1 - gs[i]->cur;
+    gs[i]->n_upper += ns[i];
+    const int rc = refresh_state(gs[i]);  // whether a point changed (the kd-tree is only dropped then, :315-317) is read by lsa_device_grid_submap_valid
     if (rc) return rc;
   }
-  hipLaunchKernelGGL(k_batch_keys, dim3((n + 255) / 256), dim3(256), 0, st, g->batch, n, p, g->st, g->bkeys, g->border);
-  size_t bytes = g->sort_tmp_bytes;
-  if (rocprim::radix_sort_pairs(g->sort_tmp, bytes, g->bkeys, g->skeys, g->border, g->sorder, (size_t)n, 0, 64, st) != hipSuccess)
-    return g->ctx->fail(LSA_E_HIP, "lsa_device_grid: radix sort failed");
-  // one group per distinct key (points outside the grid are not grouped)
-  compact(g, HeadPred{g->skeys}, HeadEmit{g->heads}, nullptr, n, g->st + kStGroups);
-  const MapView map = g->buf[g->cur], dst = g->buf[1 - g->cur];
-  hipLaunchKernelGGL(k_fold, dim3((n + 127) / 128), dim3(128), 0, st, g->batch, n, g->skeys, g->sorder, g->heads, p, g->st, map, g->fresh, g->fresh_flag,
-                     fixed ? 1 : 0, time);
-  compact(g, FreshPred{g->fresh_flag}, FreshEmit{g->fresh, g->fresh2}, g->st + kStGroups, n, g->st + kStNew);
-  hipLaunchKernelGGL(k_merge, dim3((g->n_upper + n + 255) / 256), dim3(256), 0, st, map, g->fresh2, dst, g->st, 0);
-  hipLaunchKernelGGL(k_after_merge, dim3(1), dim3(64), 0, st, g->st);
-  g->cur = 1 - g->cur;
-  g->n_upper += n;
-  return refresh_state(g);  // whether a point changed (the kd-tree is only dropped then, :315-317) is read by lsa_device_grid_submap_valid
+  return LSA_OK;
 }
-
-// Add of the n points in g->batch (device)
-int add_batch(lsa_device_grid* g, int n, bool fixed, double time, bool do_roll)
-{
-  hipStream_t st = g->stream;
-  tighten(g);
-  {
-    const int rc = after_submap(g);
-    if (rc) return rc;
-  }
-  const int kblocks = (n + 255) / 256, ochunks = std::max((g->n_upper + 1023) / 1024, 1);
-  const size_t lds = (size_t)(ochunks + kblocks + 2) * sizeof(int);
-  if (g->legacy_add || lds > 48 * 1024) return add_batch_legacy(g, n, fixed, time, do_roll);
-  int rc = ensure_map(g, g->n_upper + n);
-  if (rc) return rc;
-  const GridParams p = params_of(g);
-  const int roll = do_roll ? 1 : 0;
-  ProfScope ps(g->ctx, "map_add", (double)n * (32 + 12 + 44) + (double)g->n_upper * 44 * 2, g->stream);
-  if (do_roll) hipLaunchKernelGGL(k_batch_bbox, dim3(kblocks), dim3(256), 0, st, g->batch, n, g->st);
-  const MapView map = g->buf[g->cur], dst = g->buf[1 - g->cur];
-  hipLaunchKernelGGL(k_add_keys, dim3(kblocks + ochunks), dim3(256), 0, st, g->batch, n, kblocks, p, g->st, roll, g->bkeys, map.keys, g->old_local, g->chunks);
-  const int runs = (n + kRun - 1) / kRun;
-  if (runs == 1) hipLaunchKernelGGL(k_sort_runs, dim3(1), dim3(1024), 0, st, g->bkeys, n, g->skeys, g->sorder);
-  else
-  {
-    hipLaunchKernelGGL(k_sort_runs, dim3(runs), dim3(1024), 0, st, g->bkeys, n, g->bkeys, g->border);
-    hipLaunchKernelGGL(k_merge_runs, dim3(kblocks), dim3(256), 0, st, g->bkeys, g->border, n, g->skeys, g->sorder);
-  }
-  hipLaunchKernelGGL(k_add_fold, dim3(kblocks), dim3(256), 0, st, g->batch, n, g->skeys, g->sorder, p, g->st, roll, map, g->fresh, g->fresh_flag, g->heads,
-                     fixed ? 1 : 0, time);
-  hipLaunchKernelGGL(k_add_merge, dim3(ochunks + kblocks), dim3(256), lds, st, p, g->st, roll, map, g->old_local, g->chunks, ochunks, ochunks, g->skeys, n, g->fresh,
-                     g->fresh_flag, g->heads, kblocks, dst);
-  hipLaunchKernelGGL(k_add_commit, dim3(1), dim3(64), 0, st, p, g->st, roll);
-  g->cur = 1 - g->cur;
-  g->n_upper += n;
-  return refresh_state(g);  // whether a point changed (the kd-tree is only dropped then, :315-317) is read by lsa_device_grid_submap_valid
-}
+int add_batch(lsa_device_grid* g, int n, bool fixed, double time, bool do_roll) { return add_batches(&g, &n, 1, fixed, time, do_roll); }
 
 }  // namespace
 
@@ -1374,7 +1404,6 @@ int lsa_device_grid_create(lsa_ctx* ctx, lsa_device_grid** out)
   }
   for (hipEvent_t* e : {&g->ev_state, &g->ev_in, &g->ev_out, &g->ev_sub, &g->ev_ahead}) ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
   if (!ok) { lsa_device_grid_destroy(g); return LSA_E_HIP; }
-  if (const char* e = std::getenv("LSA_MAP_ADD")) g->legacy_add = std::string(e) == "legacy";
   *out = g;
   return lsa_device_grid_reset(g, nullptr);
 }
@@ -1545,6 +1574,22 @@ int lsa_device_grid_add_staged(lsa_device_grid* g, double time)
   if (n <= 0) return LSA_OK;  // "Pointcloud is empty, voxel grid not updated."
   G_HIP(hipSetDevice(g->ctx->device));
   return add_batch(g, n, false, time, true);
+}
+// ... of several maps of one context at once (the keypoint types of a keyframe): one launch of every step for all of them
+int lsa_device_grid_add_staged_all(lsa_device_grid* const* grids, int count, double time)
+{
+  if (!grids || count < 1 || count > 3) return LSA_E_ARG;
+  lsa_device_grid* gs[3];
+  int ns[3], m = 0;
+  for (int i = 0; i < count; ++i)
+  {
+    if (!grids[i]) return LSA_E_ARG;
+    if (grids[i]->staged > 0) { gs[m] = grids[i]; ns[m] = grids[i]->staged; ++m; }  // "Pointcloud is empty, voxel grid not updated."
+    grids[i]->staged = 0;
+  }
+  if (m == 0) return LSA_OK;
+  if (hipSetDevice(gs[0]->ctx->device) != hipSuccess) return LSA_E_HIP;
+  return add_batches(gs, ns, m, false, time, true);
 }
 int lsa_device_grid_add_keypoints(lsa_device_grid* g, int set, int type, const double pose[16], double time)
 {

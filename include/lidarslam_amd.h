@@ -622,6 +622,10 @@ int lsa_device_grid_submap_ahead_begin(lsa_device_grid* g, int box_type, int min
 int lsa_device_grid_submap_ahead_poll(lsa_device_grid* g);
 int lsa_device_grid_submap_ahead_wait(lsa_device_grid* g); /* blocking form of _poll, for a thread with nothing else to do */
 int lsa_device_grid_submap_ahead_take(lsa_device_grid* g, int box_type, int min_nb_points, int slot, int type, int* taken);
+/* _take in two steps (several maps: every comparison is enqueued before any is waited for): _take_begin returns 1 when a
+ * comparison is on its way, 0 when nothing fits; _take_end waits for it. */
+int lsa_device_grid_submap_ahead_take_begin(lsa_device_grid* g, int box_type, int min_nb_points, int slot, int type);
+int lsa_device_grid_submap_ahead_take_end(lsa_device_grid* g, int* taken);
 
 /* ---- the rolling voxel map (host) ---------------------------
  * LidarSlam::RollingGrid -- slam_lib/include/LidarSlam/RollingGrid.h:63-212,

@@ -691,13 +691,16 @@ int SlamCore::Localization()
     // the voxels the box of the current keypoints (at the initial pose guess) touches -- written straight into the
     // target; only the box (read back once for all types) and the sub-maps' sizes cross the bus
     Tick t;
-    WaitMaps();  // the workers have enqueued the previous keyframe's insertions, and the sub-maps ahead of time
+    // the workers have enqueued the previous keyframe's insertions, and the sub-maps ahead of time (NOT the next frame's
+    // ego-motion targets, which the look-ahead thread may still be enqueueing: nothing here depends on them)
+    for (auto& w : MapWorker) w.Wait();
+    while (DevSpecRunning.load(std::memory_order_acquire)) std::this_thread::yield();
     Stats.maps_wait = t.Stop();
     if (DevSpecStatus < 0) { const int rc = DevSpecStatus; DevSpecStatus = 0; return Fail(rc, "sub-maps ahead of time (look-ahead thread)"); }
     Stats.maps_async = std::max(MapJobSeconds[0], std::max(MapJobSeconds[1], MapJobSeconds[2]));
     for (int k = 0; k < 3; ++k)
       if (MapJobFailed[k]) { MapJobFailed[k] = 0; return Fail(LSA_E_HIP, "lsa_device_grid_add_staged (map worker)"); }
-    bool need[3], any = false;
+    bool need[3], checking[3] = {false, false, false}, any = false;
     for (int k = 0; k < 3; ++k)
     {
       need[k] = UseKeypoints[k] && !lsa_device_grid_submap_valid(DevMaps[k]);
@@ -712,16 +715,21 @@ int SlamCore::Localization()
       if (MapUpdate == MappingMode::NONE) LSA_TRY(lsa_device_grid_build_submap_begin(DevMaps[k], nullptr, nullptr, -1, LSA_TARGET_MAP, k));
       else
       {
-        if (DevSpec[k])
-        {
-          // extracted ahead of time for the predicted box: stands when the actual box touches the same outer voxels
-          int taken = 0;
-          LSA_TRY(lsa_device_grid_submap_ahead_take(DevMaps[k], k, KeypointCounts[k] / 2, LSA_TARGET_MAP, k, &taken));
-          if (taken) { need[k] = false; Stats.submap_spec_hits++; SubMapSpecHitsTotal++; continue; }
-        }
+        // extracted ahead of time for the predicted box: stands when the actual box touches the same outer voxels (the
+        // comparisons of all the maps are enqueued first, then waited for)
+        if (DevSpec[k] && lsa_device_grid_submap_ahead_take_begin(DevMaps[k], k, KeypointCounts[k] / 2, LSA_TARGET_MAP, k) == 1) { checking[k] = true; continue; }
         if (LocalMaps[k]->IsTimeThreshold()) LSA_TRY(lsa_device_grid_clear_old_points(DevMaps[k], CurrentTime));
         LSA_TRY(lsa_device_grid_build_submap_begin_for_keypoints(DevMaps[k], k, KeypointCounts[k] / 2, LSA_TARGET_MAP, k));
       }
+    }
+    for (int k = 0; k < 3; ++k)
+    {
+      if (!checking[k]) continue;
+      int taken = 0;
+      LSA_TRY(lsa_device_grid_submap_ahead_take_end(DevMaps[k], &taken));
+      if (taken) { need[k] = false; Stats.submap_spec_hits++; SubMapSpecHitsTotal++; continue; }
+      if (LocalMaps[k]->IsTimeThreshold()) LSA_TRY(lsa_device_grid_clear_old_points(DevMaps[k], CurrentTime));
+      LSA_TRY(lsa_device_grid_build_submap_begin_for_keypoints(DevMaps[k], k, KeypointCounts[k] / 2, LSA_TARGET_MAP, k));
     }
     for (bool& b : DevSpec) b = false;
     for (int k = 0; k < 3; ++k)  // the extractions follow one another on the context's stream, their sizes come back together
@@ -918,6 +926,7 @@ int SlamCore::BeginSubMapSpeculation(const Pose& predicted)
       DevSpec[k] = use[k];
     }
     DevSpecStatus = 0;
+    DevSpecRunning.store(true, std::memory_order_release);
     AheadWorker.Submit([this, interpolated, begin, end, t0, t1, use0 = use[0], use1 = use[1], use2 = use[2], m0 = minPts[0], m1 = minPts[1], m2 = minPts[2]] {
       const bool use[3] = {use0, use1, use2};
       const int minPts[3] = {m0, m1, m2};
@@ -928,6 +937,7 @@ int SlamCore::BeginSubMapSpeculation(const Pose& predicted)
       for (int k = 0; k < 3 && rc >= 0; ++k)
         if (use[k]) rc = lsa_device_grid_submap_ahead_wait(DevMaps[k]);
       DevSpecStatus = rc < 0 ? rc : 0;
+      DevSpecRunning.store(false, std::memory_order_release);
     });
     return LSA_OK;
   }

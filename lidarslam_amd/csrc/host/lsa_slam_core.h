@@ -268,7 +268,8 @@ private:
   int PrepareNextEgoMotionTargets();
   void ArmLookaheadInterlude();
   int InterludeWork();
-  int DevSpecStatus = 0;   // written by the look-ahead thread, read after WaitMaps
+  int DevSpecStatus = 0;   // written by the look-ahead thread, read once DevSpecRunning is false
+  std::atomic<bool> DevSpecRunning{false};
   int FinishLookaheadInterlude();
   bool InterludeRan = true;
   int InterludeStatus = 0;

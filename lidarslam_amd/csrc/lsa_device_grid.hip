@@ -1114,6 +1114,8 @@ struct lsa_device_grid
   unsigned ahead_tag = 0;
   int ahead_phase = 0;         // 0 none, 1 extraction on its way, 2 search grid on its way / ready
   int ahead_type = -1, ahead_min = 0, ahead_m = 0;
+  bool take_pending = false;   // a comparison of _take_begin is on its way
+  int take_slot = 0;
   int staged = 0;              // keypoints staged in `batch` by lsa_device_grid_stage_keypoints
   bool submap_valid = false;
   int submap_count = 0;
@@ -1870,12 +1872,14 @@ int lsa_device_grid_submap_ahead_wait(lsa_device_grid* g)
   }
   return g->ahead_phase;
 }
-int lsa_device_grid_submap_ahead_take(lsa_device_grid* g, int box_type, int min_nb_points, int slot, int type, int* taken)
+// _take in two steps, so that the comparisons of several maps are enqueued before any of them is waited for: _take_begin
+// returns 1 when a comparison is on its way (0: nothing fits, extract the sub-map as usual), _take_end waits for it.
+int lsa_device_grid_submap_ahead_take_begin(lsa_device_grid* g, int box_type, int min_nb_points, int slot, int type)
 {
-  if (!g || !taken || box_type < 0 || box_type > 2 || slot < 0 || slot > 1 || type < 0 || type > 2)
+  if (!g || box_type < 0 || box_type > 2 || slot < 0 || slot > 1 || type < 0 || type > 2)
     return g ? g->ctx->fail(LSA_E_ARG, "lsa_device_grid_submap_ahead_take: bad argument") : LSA_E_ARG;
-  *taken = 0;
   lsa_ctx* ctx = g->ctx;
+  g->take_pending = false;
   if (g->ahead_phase == 1)
   {
     const int rc = lsa_device_grid_submap_ahead_poll(g);
@@ -1884,7 +1888,7 @@ int lsa_device_grid_submap_ahead_take(lsa_device_grid* g, int box_type, int min_
   const bool fits = g->ahead_phase == 2 && g->ahead_type == type && g->ahead_min == min_nb_points && g->sub_target < 0 &&
                     ctx->target[9 + type].cell_hint == ctx->target[slot * 3 + type].cell_hint;
   g->ahead_phase = 0;
-  if (!fits) return LSA_OK;
+  if (!fits) return 0;
   G_HIP(hipSetDevice(ctx->device));
   // the comparison runs on the context's stream, where the actual box was just enqueued, behind the grid's stream (the
   // predicted range and the state it reads)
@@ -1892,6 +1896,19 @@ int lsa_device_grid_submap_ahead_take(lsa_device_grid* g, int box_type, int min_
   const unsigned tag = ++g->ahead_tag;
   const unsigned* words = reinterpret_cast<const unsigned*>(ctx->range_bits + 16) + 6 * box_type;
   hipLaunchKernelGGL(k_box_check, dim3(1), dim3(64), 0, ctx->stream, words, g->GridSize, (float)g->VoxelResolution, g->VoxelResolution, g->st, g->host_ahead + 1, tag);
+  g->take_pending = true;
+  g->take_slot = slot;
+  return 1;
+}
+int lsa_device_grid_submap_ahead_take_end(lsa_device_grid* g, int* taken)
+{
+  if (!g || !taken) return LSA_E_ARG;
+  *taken = 0;
+  if (!g->take_pending) return LSA_OK;
+  g->take_pending = false;
+  lsa_ctx* ctx = g->ctx;
+  const int type = g->ahead_type, slot = g->take_slot;
+  const unsigned tag = g->ahead_tag;
   const auto t0 = std::chrono::steady_clock::now();
   unsigned spins = 0;
   u64 v;
@@ -1912,6 +1929,13 @@ int lsa_device_grid_submap_ahead_take(lsa_device_grid* g, int box_type, int min_
   G_HIP(hipEventRecord(g->ev_sub, ctx->stream));
   *taken = 1;
   return g->ahead_m;
+}
+int lsa_device_grid_submap_ahead_take(lsa_device_grid* g, int box_type, int min_nb_points, int slot, int type, int* taken)
+{
+  if (!taken) return LSA_E_ARG;
+  *taken = 0;
+  const int rc = lsa_device_grid_submap_ahead_take_begin(g, box_type, min_nb_points, slot, type);
+  return rc <= 0 ? rc : lsa_device_grid_submap_ahead_take_end(g, taken);
 }
 
 // RollingGrid::IsSubMapKdTreeValid(): an Add that changed a voxel's point has dropped the sub-map (RollingGrid.cxx:315-317);

@@ -5,12 +5,14 @@
 // The reference keeps the map as unordered_map<outer voxel, unordered_map<leaf voxel, Voxel>>.  Here the map is ONE
 // array of voxels sorted by the 64-bit key (outer index << 32 | leaf index) -- keys, points and counts in three
 // parallel arrays, double-buffered:
-//   Add      the batch is keyed and sorted by (key, arrival order) (radix sort: rocPRIM); one thread per distinct key
-//            finds the voxel by binary search and folds the batch's points for it IN ARRIVAL ORDER through the
-//            reference's per-point rule (FIRST / LAST / MAX_INTENSITY / CENTER_POINT, fixed points, one count per Add
-//            call), exactly what the sequential loop of RollingGrid.cxx:183-312 does to that voxel; new voxels are
-//            merged in by rank (two binary searches, one scatter) -- no hash table, no atomics on voxels
-//   Roll     a shift of the outer coordinates keeps the key order: transform + stable compaction
+//   Add      the batch is keyed and sorted by (key, arrival order) (runs sorted by a workgroup each, merged by rank); the
+//            first thread of a run of equal keys finds the voxel by binary search and folds the run's points for it IN
+//            ARRIVAL ORDER through the reference's per-point rule (FIRST / LAST / MAX_INTENSITY / CENTER_POINT, fixed
+//            points, one count per Add call), exactly what the sequential loop of RollingGrid.cxx:183-312 does to that
+//            voxel; new voxels are merged in by rank (two binary searches, one scatter) -- no hash table, no atomics on
+//            voxels; seven launches for all the maps of a keyframe together
+//   Roll     a shift of the outer coordinates keeps the key order: folded into Add's merge (on its own: transform + stable
+//            compaction)
 //   decay    ClearOldPoints: stable compaction
 //   sub-map  voxels whose outer index lies in the box, stable compaction straight into the target's point buffer
 // Iteration order.  The reference's Get / BuildSubMapKdTree hand the points out in libstdc++'s hash iteration order,
@@ -26,7 +28,6 @@
 #include <cstring>
 #include <limits>
 #include <string.h>
-#include <rocprim/rocprim.hpp>
 #include "lsa_ctx.h"
 #include "lsa_device_math.h"
 
@@ -228,42 +229,6 @@ __global__ void k_after_roll(int* __restrict__ st)
   }
 }
 
-// ---- Add (RollingGrid.cxx:160-318) ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_batch_keys(const float4* __restrict__ batch, int n, GridParams p, const int* __restrict__ st, u64* __restrict__ keys,
-                                                    unsigned* __restrict__ order)
-{
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const float4 a = batch[2 * (size_t)i];
-  const float pt[3] = {a.x, a.y, a.z};
-  int out[3], in[3];
-  bool inside = true;
-  float center[3];
-  for (int d = 0; d < 3; ++d)
-  {
-    // voxelGridOrigin = VoxelGridPosition - int(GridSize / 2) * VoxelResolution (:177)
-    const float origin = __int_as_float(st[kStPosX + d]) - (float)((double)(p.grid_size / 2) * p.resolution_d);
-    out[d] = round_to_int((pt[d] - origin) / p.resolution);
-    inside = inside && out[d] >= 0 && out[d] < p.grid_size;
-    center[d] = (float)out[d] * p.resolution + origin;
-    in[d] = round_to_int((pt[d] - center[d]) / p.leaf);
-  }
-  const int g = p.grid_size;
-  const unsigned idx_out = (unsigned)(out[2] * g * g + out[1] * g + out[0]);
-  const unsigned idx_in = (unsigned)(in[2] * g * g + in[1] * g + in[0]);  // possibly "negative": the reference's own index (:200-202)
-  keys[i] = inside ? (((u64)idx_out << 32) | idx_in) : kNoKey;
-  order[i] = (unsigned)i;
-}
-struct HeadPred
-{
-  const u64* keys;
-  __device__ bool operator()(int j) const { return keys[j] != kNoKey && (j == 0 || keys[j] != keys[j - 1]); }
-};
-struct HeadEmit
-{
-  int* heads;
-  __device__ void operator()(int j, int at) const { heads[at] = j; }
-};
 __device__ __forceinline__ int lower_bound_u64(const u64* __restrict__ a, int n, u64 key)
 {
   int lo = 0, hi = n;
@@ -274,146 +239,11 @@ __device__ __forceinline__ int lower_bound_u64(const u64* __restrict__ a, int n,
   }
   return lo;
 }
-// One thread per distinct key of the batch: the voxel's state after the sequential loop has seen the batch's points
-// for it, in arrival order.  Existing voxels are updated in place; new ones go to the `fresh` arrays (key order).
-__global__ __launch_bounds__(128) void k_fold(const float4* __restrict__ batch, int nbatch, const u64* __restrict__ skeys, const unsigned* __restrict__ sorder,
-                                              const int* __restrict__ heads, GridParams p, int* __restrict__ st, MapView map, MapView fresh,
-                                              int* __restrict__ fresh_flag, int fixed, double time)
-{
-  const int gidx = blockIdx.x * blockDim.x + threadIdx.x;
-  const int ngroups = st[kStGroups];
-  if (gidx >= ngroups) return;
-  const int j0 = heads[gidx];
-  const u64 key = skeys[j0];
-  const int n = st[kStN];
-  const int at = lower_bound_u64(map.keys, n, key);
-  const bool exists = at < n && map.keys[at] == key;
-  float4 va, vb;      // the voxel's point
-  unsigned count = 0;
-  bool have = exists;
-  bool changed = false;
-  if (exists) { va = map.pts[2 * (size_t)at]; vb = map.pts[2 * (size_t)at + 1]; count = map.count[at]; }
-  else { va = make_float4(0.f, 0.f, 0.f, 0.f); vb = va; }
-  // CENTER_POINT (:253): the centre is that of the leaf voxel of the point at hand, voxelGridCenterIn - VoxelResolution / 2.f
-  // + LeafSize * voxelCoordIn -- two leaf voxels of one outer voxel can share an inner index (To1d of coordinates around
-  // zero), so the points of one group do not all have the same centre
-  float base[3] = {0.f, 0.f, 0.f};  // voxelGridCenterIn: the same for the whole group
-  if (p.sampling == 3)
-  {
-    const int g = p.grid_size;
-    int id = (int)(unsigned)(key >> 32);
-    const int oz = id / (g * g); id -= oz * g * g;
-    const int oy = id / g; const int ox = id - oy * g;
-    const int out[3] = {ox, oy, oz};
-    for (int d = 0; d < 3; ++d)
-    {
-      const float origin = __int_as_float(st[kStPosX + d]) - (float)((double)(g / 2) * p.resolution_d);
-      base[d] = (float)out[d] * p.resolution + origin;
-    }
-  }
-  bool counted = false;
-  for (int j = j0; j < nbatch && skeys[j] == key; ++j)
-  {
-    const unsigned src = sorder[j];
-    const float4 a = batch[2 * (size_t)src], b = batch[2 * (size_t)src + 1];
-    if (!have)
-    {
-      va = a; vb = b; have = true; changed = true;  // new voxel: the point as it is (:206-212)
-    }
-    else
-    {
-      const unsigned label = (__float_as_uint(vb.w) >> 24) & 0xffu;
-      if (label == 1) continue;  // the voxel holds a fixed point: nothing of this point is taken, not even its time (:219-220)
-      if (p.sampling == 1) { va = a; vb = b; changed = true; }                       // LAST
-      else if (p.sampling == 2) { if (b.z > vb.z) { va = a; vb = b; changed = true; } }  // MAX_INTENSITY
-      else if (p.sampling == 3)
-      {
-        const float pt[3] = {a.x, a.y, a.z};
-        float centre[3];
-        for (int d = 0; d < 3; ++d) centre[d] = base[d] - p.resolution / 2.f + p.leaf * (float)round_to_int((pt[d] - base[d]) / p.leaf);
-        const float d1x = a.x - centre[0], d1y = a.y - centre[1], d1z = a.z - centre[2];
-        const float d0x = va.x - centre[0], d0y = va.y - centre[1], d0z = va.z - centre[2];
-        // Eigen's Vector3f norm: sqrt(x^2 + (y^2 + z^2))
-        if (sqrtf(d1x * d1x + (d1y * d1y + d1z * d1z)) < sqrtf(d0x * d0x + (d0y * d0y + d0z * d0z))) { va = a; vb = b; changed = true; }
-      }
-    }
-    // voxel.point.time = currentTime; label = fixed (:300-306); one count per Add call (:307-311)
-    const long long tb = __double_as_longlong(time);
-    vb.x = __int_as_float((int)(tb & 0xffffffffll));
-    vb.y = __int_as_float((int)(tb >> 32));
-    vb.w = __uint_as_float((__float_as_uint(vb.w) & 0x00ffffffu) | ((fixed ? 1u : 0u) << 24));
-    if (!counted) { ++count; counted = true; }
-  }
-  if (exists)
-  {
-    map.pts[2 * (size_t)at] = va;
-    map.pts[2 * (size_t)at + 1] = vb;
-    map.count[at] = count;
-    fresh_flag[gidx] = 0;
-  }
-  else
-  {
-    fresh.keys[gidx] = key;  // compacted to the new voxels' own array below
-    fresh.pts[2 * (size_t)gidx] = va;
-    fresh.pts[2 * (size_t)gidx + 1] = vb;
-    fresh.count[gidx] = count;
-    fresh_flag[gidx] = 1;
-  }
-  if (changed) st[kStUpdated] = 1;
-}
-struct FreshPred
-{
-  const int* flag;
-  __device__ bool operator()(int i) const { return flag[i] != 0; }
-};
-struct FreshEmit
-{
-  MapView src, dst;
-  __device__ void operator()(int i, int at) const
-  {
-    dst.keys[at] = src.keys[i];
-    dst.pts[2 * (size_t)at] = src.pts[2 * (size_t)i];
-    dst.pts[2 * (size_t)at + 1] = src.pts[2 * (size_t)i + 1];
-    dst.count[at] = src.count[i];
-  }
-};
-// merge by rank: a voxel's place is its index plus the number of voxels of the other array in front of it
-__global__ __launch_bounds__(256) void k_merge(MapView map, MapView fresh, MapView dst, const int* __restrict__ st, int capacity_hint)
-{
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const int n = st[kStN], m = st[kStNew];
-  (void)capacity_hint;
-  if (i < n)
-  {
-    const int at = i + lower_bound_u64(fresh.keys, m, map.keys[i]);
-    dst.keys[at] = map.keys[i];
-    dst.pts[2 * (size_t)at] = map.pts[2 * (size_t)i];
-    dst.pts[2 * (size_t)at + 1] = map.pts[2 * (size_t)i + 1];
-    dst.count[at] = map.count[i];
-  }
-  else if (i - n < m)
-  {
-    const int j = i - n;
-    const int at = j + lower_bound_u64(map.keys, n, fresh.keys[j]);
-    dst.keys[at] = fresh.keys[j];
-    dst.pts[2 * (size_t)at] = fresh.pts[2 * (size_t)j];
-    dst.pts[2 * (size_t)at + 1] = fresh.pts[2 * (size_t)j + 1];
-    dst.count[at] = fresh.count[j];
-  }
-}
-__global__ void k_after_merge(int* __restrict__ st)
-{
-  if (threadIdx.x == 0 && blockIdx.x == 0)
-  {
-    st[kStN] += st[kStNew];
-    st[kStNbPoints] += st[kStNew];
-  }
-}
 
-// ---- Add in seven launches ------------------------------------------------------------------------------------------------
-// The chain above (bounding box, roll decision, roll compaction, keys, library sort, heads, fold, fresh compaction, merge,
-// state) is some twenty-five dependent launches; the next localization waits for the last of them.  This one does the same
-// work in seven: box -> keys of the batch + survivors of the roll counted -> runs of 4096 sorted in LDS -> runs merged by
+// ---- Add (RollingGrid.cxx:160-318) in seven launches --------------------------------------------------------------------
+// (The first version -- bounding box, roll decision, roll compaction, keys, library radix sort, heads, fold, compaction of
+// the new voxels, merge, state -- was twenty-five dependent launches, and the next localization waits for the last of
+// them.)  Seven: box -> keys of the batch + survivors of the roll counted -> runs of 4096 sorted in LDS -> runs merged by
 // rank -> fold per voxel (straight off the sorted batch) -> map = surviving old voxels (re-keyed) merged with the new ones
 // by rank -> state.  Nothing is decided in a launch of its own: every kernel works the roll's shift out for itself from the
 // committed grid position and the batch's box, and the last kernel commits position and counts.
@@ -1126,9 +956,7 @@ struct lsa_device_grid
   unsigned *border = nullptr, *sorder = nullptr;
   int *heads = nullptr, *fresh_flag = nullptr, *chunks = nullptr;
   int* old_local = nullptr;    // [cap] rank of an old voxel among the survivors of its chunk (Add)
-  MapView fresh = {}, fresh2 = {};
-  void* sort_tmp = nullptr;
-  size_t sort_tmp_bytes = 0;
+  MapView fresh = {};
   int chunk_cap = 0;
 };
 
@@ -1244,9 +1072,8 @@ int ensure_batch(lsa_device_grid* g, int n)
   const int cap = std::max(n + n / 4, 1 << 14);
   G_HIP(hipStreamSynchronize(g->stream));
   auto fr = [](void* p) { if (p) (void)hipFree(p); };
-  fr(g->batch); fr(g->bkeys); fr(g->skeys); fr(g->border); fr(g->sorder); fr(g->heads); fr(g->fresh_flag); fr(g->sort_tmp);
+  fr(g->batch); fr(g->bkeys); fr(g->skeys); fr(g->border); fr(g->sorder); fr(g->heads); fr(g->fresh_flag);
   free_view(g->fresh);
-  free_view(g->fresh2);
   G_HIP(hipMalloc((void**)&g->batch, (size_t)cap * 2 * sizeof(float4)));
   G_HIP(hipMalloc((void**)&g->bkeys, (size_t)cap * sizeof(u64)));
   G_HIP(hipMalloc((void**)&g->skeys, (size_t)cap * sizeof(u64)));
@@ -1256,13 +1083,6 @@ int ensure_batch(lsa_device_grid* g, int n)
   G_HIP(hipMalloc((void**)&g->fresh_flag, (size_t)cap * sizeof(int)));
   int rc = alloc_view(g, g->fresh, cap);
   if (rc) return rc;
-  rc = alloc_view(g, g->fresh2, cap);
-  if (rc) return rc;
-  size_t bytes = 0;
-  if (rocprim::radix_sort_pairs((void*)nullptr, bytes, g->bkeys, g->skeys, g->border, g->sorder, (size_t)cap, 0, 64, g->stream) != hipSuccess)
-    return g->ctx->fail(LSA_E_HIP, "lsa_device_grid: radix sort sizing failed");
-  G_HIP(hipMalloc(&g->sort_tmp, bytes + 256));
-  g->sort_tmp_bytes = bytes + 256;
   g->bcap = cap;
   return LSA_OK;
 }
@@ -1416,9 +1236,9 @@ void lsa_device_grid_destroy(lsa_device_grid* g)
   (void)hipSetDevice(g->ctx->device);
   if (g->stream) (void)hipStreamSynchronize(g->stream);
   (void)hipStreamSynchronize(g->ctx->stream);  // a match may still read a sub-map: nothing of the grid is in use after this
-  free_view(g->buf[0]); free_view(g->buf[1]); free_view(g->fresh); free_view(g->fresh2);
+  free_view(g->buf[0]); free_view(g->buf[1]); free_view(g->fresh);
   auto fr = [](void* p) { if (p) (void)hipFree(p); };
-  fr(g->st); fr(g->batch); fr(g->bkeys); fr(g->skeys); fr(g->border); fr(g->sorder); fr(g->heads); fr(g->fresh_flag); fr(g->chunks); fr(g->sort_tmp); fr(g->old_local);
+  fr(g->st); fr(g->batch); fr(g->bkeys); fr(g->skeys); fr(g->border); fr(g->sorder); fr(g->heads); fr(g->fresh_flag); fr(g->chunks); fr(g->old_local);
   if (g->host_st) (void)hipHostFree(g->host_st);
   if (g->host_sub) (void)hipHostFree(g->host_sub);
   if (g->host_ahead) (void)hipHostFree(g->host_ahead);

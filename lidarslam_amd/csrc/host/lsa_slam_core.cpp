@@ -694,7 +694,30 @@ int SlamCore::Localization()
     // the workers have enqueued the previous keyframe's insertions, and the sub-maps ahead of time (NOT the next frame's
     // ego-motion targets, which the look-ahead thread may still be enqueueing: nothing here depends on them)
     for (auto& w : MapWorker) w.Wait();
-    while (DevSpecRunning.load(std::memory_order_acquire)) std::this_thread::yield();
+    {
+      // the sub-maps ahead of time: waited for -- and when that took time twice in a row (the ego-motion ICP of this sensor
+      // is shorter than insertion + extraction + grid build), not tried again for a while ("SubMapsAheadAdaptive")
+      Tick tw;
+      while (DevSpecRunning.load(std::memory_order_acquire)) std::this_thread::yield();
+      const bool tried = DevSpec[0] || DevSpec[1] || DevSpec[2];
+      if (tried && SubMapsAheadAdaptive && tw.Stop() > 80e-6)
+      {
+        DevSpecGood = 0;
+        if (++DevSpecLate >= 2)
+        {
+          // not tried for a while; twice as long every time it happens again soon (a sensor whose ego-motion ICP is simply
+          // too short ends up trying once in 64 frames, an occasional hiccup costs four)
+          DevSpecBackoff = DevSpecPenalty;
+          DevSpecPenalty = std::min(2 * DevSpecPenalty, 64);
+          DevSpecLate = 0;
+        }
+      }
+      else if (tried)
+      {
+        DevSpecLate = 0;
+        if (++DevSpecGood >= 8) DevSpecPenalty = 4;
+      }
+    }
     Stats.maps_wait = t.Stop();
     if (DevSpecStatus < 0) { const int rc = DevSpecStatus; DevSpecStatus = 0; return Fail(rc, "sub-maps ahead of time (look-ahead thread)"); }
     Stats.maps_async = std::max(MapJobSeconds[0], std::max(MapJobSeconds[1], MapJobSeconds[2]));
@@ -886,6 +909,9 @@ int SlamCore::BeginSubMapSpeculation(const Pose& predicted)
     bool any = false;
     for (int k = 0; k < 3; ++k) any = any || (UseKeypoints[k] && KeypointCounts[k] > 0);
     if (!SubMapsAhead || !any || LocalMaps[0]->IsTimeThreshold()) return LSA_OK;
+    // it has to be ready when the localization asks: where the ego-motion ICP is shorter than insertion + extraction +
+    // grid build (small sensors) it is not, and is then left alone for a while
+    if (DevSpecBackoff > 0) { --DevSpecBackoff; return LSA_OK; }
   }
   // Localization() will look at the keypoints after undistorting them with the motion between the previous pose
   // and the (then known) current one: the prediction does the same with the predicted pose -- the scan poses of
@@ -912,7 +938,7 @@ int SlamCore::BeginSubMapSpeculation(const Pose& predicted)
   }
   if (onDevice)
   {
-    // Everything else is a dozen calls into the runtime and one wait for the extraction's size: a host thread of its own
+    // Everything else is a dozen calls into the runtime: a host thread of its own
     // does it (the one that enqueues the next frame's ego-motion targets later in the frame), this one goes on to the
     // first search.  The boxes go onto the context's stream (they only read the raw keypoints), the extractions onto the
     // grids' stream behind the previous keyframe's insertions, the spare targets' search grids behind the extractions.
@@ -926,6 +952,7 @@ int SlamCore::BeginSubMapSpeculation(const Pose& predicted)
       DevSpec[k] = use[k];
     }
     DevSpecStatus = 0;
+    DevSpecCancel.store(false, std::memory_order_release);
     DevSpecRunning.store(true, std::memory_order_release);
     AheadWorker.Submit([this, interpolated, begin, end, t0, t1, use0 = use[0], use1 = use[1], use2 = use[2], m0 = minPts[0], m1 = minPts[1], m2 = minPts[2]] {
       const bool use[3] = {use0, use1, use2};
@@ -934,8 +961,15 @@ int SlamCore::BeginSubMapSpeculation(const Pose& predicted)
       int rc = interpolated ? lsa_keypoint_bboxes_begin_interp(Ctx, LSA_SET_RAW_CURRENT, begin.m, end.m, t0, t1) : lsa_keypoint_bboxes_begin(Ctx, LSA_SET_RAW_CURRENT, begin.m);
       for (int k = 0; k < 3 && rc >= 0; ++k)
         if (use[k]) rc = lsa_device_grid_submap_ahead_begin(DevMaps[k], k, minPts[k], k);
+      // ... and waits for the extractions' sizes (this thread has nothing else to do) to enqueue the spare targets' search
+      // grids at once -- unless the localization gets there first and calls it off
       for (int k = 0; k < 3 && rc >= 0; ++k)
-        if (use[k]) rc = lsa_device_grid_submap_ahead_wait(DevMaps[k]);
+        while (use[k] && rc >= 0 && !DevSpecCancel.load(std::memory_order_acquire))
+        {
+          rc = lsa_device_grid_submap_ahead_poll(DevMaps[k]);
+          if (rc != 1) break;
+          std::this_thread::yield();
+        }
       DevSpecStatus = rc < 0 ? rc : 0;
       DevSpecRunning.store(false, std::memory_order_release);
     });
@@ -1314,6 +1348,7 @@ int SlamCore::GetRegisteredFrame(std::vector<lsa_point_t>& out)
   X("DeviceLM", DeviceLM, bool)                                                                        \
   X("MapsOnDevice", MapsOnDevice, bool)                                                                \
   X("SubMapsAhead", SubMapsAhead, bool)                                                                \
+  X("SubMapsAheadAdaptive", SubMapsAheadAdaptive, bool)                                                \
   X("FusedMatch", FusedMatch, bool)                                                                    \
   X("EgoMotionICPMaxIter", EgoMotionICPMaxIter, unsigned)                                              \
   X("LocalizationICPMaxIter", LocalizationICPMaxIter, unsigned)                                        \

@@ -215,6 +215,7 @@ public:
   // of their own enqueues them, and the localization swaps the target in when the actual box touches the same outer voxels
   // (980 against 950 frames/s; with the first, slower insertion kernels it lost: the sub-map came 0.05 ms late)
   bool SubMapsAhead = true;
+  bool SubMapsAheadAdaptive = true;  // give it up for a while when the localization had to wait for it twice in a row
   bool DevSpec[3] = {false, false, false};
   bool OrderedMaps = true;
   bool DeviceMapsInUse() const { return MapsOnDevice && DevMaps[0] && LocalMaps[0]->GetSampling() != SamplingMode::CENTROID; }
@@ -269,7 +270,10 @@ private:
   void ArmLookaheadInterlude();
   int InterludeWork();
   int DevSpecStatus = 0;   // written by the look-ahead thread, read once DevSpecRunning is false
-  std::atomic<bool> DevSpecRunning{false};
+  std::atomic<bool> DevSpecRunning{false}, DevSpecCancel{false};
+  int DevSpecBackoff = 0;  // frames the sub-maps ahead of time are not tried for (they were late)
+  int DevSpecLate = 0;     // frames in a row the localization had to wait for them
+  int DevSpecGood = 0, DevSpecPenalty = 4;
   int FinishLookaheadInterlude();
   bool InterludeRan = true;
   int InterludeStatus = 0;

@@ -770,7 +770,8 @@ def test_sub_maps_ahead_of_time_change_nothing_but_the_schedule(L):
     """"SubMapsAhead": the sub-map for the predicted box, extracted on the device beside the ego-motion ICP and swapped in
     when the actual box touches the same outer voxels -- the same poses, maps and sub-maps, bit for bit, as extracting it
     when the localization asks"""
-    a, b = L.Slam(0, EgoMotion=3, SubMapsAhead=1), L.Slam(0, EgoMotion=3, SubMapsAhead=0)
+    # ("SubMapsAheadAdaptive" = 0: also where it comes late, as on this small sensor, where the pipeline gives it up by itself)
+    a, b = L.Slam(0, EgoMotion=3, SubMapsAhead=1, SubMapsAheadAdaptive=0), L.Slam(0, EgoMotion=3, SubMapsAhead=0)
     for f in range(25):
         pts, stamp = L.synth_frame(16, 1000, f)
         for s in (a, b):

@@ -34,8 +34,14 @@ namespace
 
 constexpr int kPending = -2;  // neighbour count of a query no block of the grid settles
 constexpr int kShells = 7;
-constexpr int kFill = 3;       // a block is scanned first when it holds kFill x k points
-constexpr int kHeavyCandidates = 192;  // a block with more candidates than this is scanned by the whole wavefront
+#ifndef LSA_KFILL
+#define LSA_KFILL 3
+#endif
+#ifndef LSA_KHEAVY
+#define LSA_KHEAVY 192
+#endif
+constexpr int kFill = LSA_KFILL;       // a block is scanned first when it holds kFill x k points
+constexpr int kHeavyCandidates = LSA_KHEAVY;  // a block with more candidates than this is scanned by the whole wavefront
 
 __device__ __forceinline__ constexpr int shell_level(int s) { return s < 2 ? 0 : (s < 4 ? 1 : 2); }
 __device__ __forceinline__ constexpr int shell_r(int s) { return s == 6 ? 3 : ((s & 1) ? 2 : 1); }

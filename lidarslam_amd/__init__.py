@@ -613,6 +613,24 @@ class Slam:
     def add_stored_frame(self, slot, stamp_us, seq=0):
         self._check(self.L.lsa_slam_add_stored_frame(self.h, slot, stamp_us, seq), "lsa_slam_add_stored_frame")
 
+    # replay loops that hold their clouds for the whole run: the pointer of a cloud is taken once (`cloud_pointer`), not per call
+    @staticmethod
+    def cloud_pointer(pts):
+        assert pts.dtype == POINT_DTYPE
+        return ptr(pts), int(pts.size)
+
+    def add_frame_at(self, cloud, stamp_us, seq=0):
+        """add_frame on a (pointer, size) pair from `cloud_pointer`; the array it came from must be alive"""
+        self._n = cloud[1]
+        self._check(self.L.lsa_slam_add_frame(self.h, cloud[0], cloud[1], stamp_us, seq), "lsa_slam_add_frame")
+
+    def hint_next_frame_at(self, cloud):
+        self._check(self.L.lsa_slam_hint_next_frame(self.h, cloud[0], cloud[1]), "lsa_slam_hint_next_frame")
+
+    def stats_into(self, out_ptr):
+        """stats() into an array the caller keeps (out_ptr = ptr(np.zeros(16)))"""
+        self.L.lsa_slam_get_stats(self.h, out_ptr)
+
     def world_transform(self):
         T = np.zeros(16)
         t = C.c_double()

@@ -594,7 +594,7 @@ def test_lookahead_extraction_changes_nothing_but_the_schedule(L):
     ahead = run(lambda f: f + 1 if f + 1 < len(frames) else None)
     wrong = run(lambda f: (f + 3) % len(frames))
     assert plain[3] == 0 and ahead[3] == len(frames) - 1 and wrong[3] == 0
-    for other in (ahead, wrong):
+    for other in (ahead, wrong, ahead_at):
         assert np.array_equal(plain[0], other[0]) and plain[1] == other[1] and plain[2] == other[2]
     plain_c = run(lambda f: None, change_at=6)
     ahead_c = run(lambda f: f + 1 if f + 1 < len(frames) else None, change_at=6)
@@ -642,14 +642,21 @@ def test_host_frames_announced_ahead_change_nothing_but_the_schedule(L):
     for a cloud that is never added, and when the announced cloud is replaced by another one."""
     frames = [L.synth_frame(16, 1000, f) for f in range(12)]
 
-    def run(hint):
+    clouds = [L.Slam.cloud_pointer(pts) for pts, _ in frames]
+
+    def run(hint, by_pointer=False):
         s = L.Slam(0, EgoMotion=3)
         poses, kps, used = [], [], []
         for f, (pts, stamp) in enumerate(frames):
             h = hint(f)
-            if h is not None:
-                s.hint_next_frame(frames[h][0])
-            s.add_frame(pts, stamp, f)
+            if by_pointer:  # the calls bench.py makes: the clouds' pointers taken once, outside the loop
+                if h is not None:
+                    s.hint_next_frame_at(clouds[h])
+                s.add_frame_at(clouds[f], stamp, f)
+            else:
+                if h is not None:
+                    s.hint_next_frame(frames[h][0])
+                s.add_frame(pts, stamp, f)
             poses.append(s.world_transform())
             kps.append([s.keypoints(k, 2).tobytes() for k in (L.EDGE, L.PLANE)])
             used.append(s.get_param("TotalMatchedKeypoints"))
@@ -660,11 +667,13 @@ def test_host_frames_announced_ahead_change_nothing_but_the_schedule(L):
     plain = run(lambda f: None)
     ahead = run(lambda f: f + 1 if f + 1 < len(frames) else None)
     wrong = run(lambda f: (f + 5) % len(frames))
+    ahead_at = run(lambda f: f + 1 if f + 1 < len(frames) else None, by_pointer=True)
+    assert ahead_at[3] == len(frames) - 1
     assert plain[3] == 0 and plain[4] == 0
     assert ahead[3] == len(frames) - 1  # every announced cloud was the one that came
     assert 1 <= ahead[4] <= len(frames) - 1  # the extraction ran ahead whenever the upload was enqueued in time
     assert wrong[3] == 0 and wrong[4] == 0
-    for other in (ahead, wrong):
+    for other in (ahead, wrong, ahead_at):
         assert np.array_equal(plain[0], other[0]) and plain[1] == other[1] and plain[2] == other[2]
 
 

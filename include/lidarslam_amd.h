@@ -290,8 +290,9 @@ int lsa_set_knn_rounds(lsa_ctx* ctx, int type, int rounds);
  * The device keeps the last 16 matches of every type. */
 long long lsa_match_serial(const lsa_ctx* ctx, int type);
 int lsa_match_histogram(lsa_ctx* ctx, int type, long long serial, int histogram[LSA_MATCH_NSTATUS]);
-/* lsa_match_types as ONE launch for all keypoint types, search and model fit in the same kernel (default), or
- * (on = 0) as the staged kernels, types side by side on streams.  Same results either way. */
+/* lsa_match_types as ONE launch for all keypoint types, search and model fit in the same kernel (on = 1, the default),
+ * as two launches (on = 2: the searches of all types, then their model fits), or (on = 0) as the staged kernels, types
+ * side by side on streams.  Same results either way. */
 int lsa_set_fused_match(lsa_ctx* ctx, int on);
 /* Diagnostics: queries of the last lsa_match that the first kNN kernel handed to the second stage. */
 int lsa_match_slow_queries(lsa_ctx* ctx);

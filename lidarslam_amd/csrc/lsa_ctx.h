@@ -249,6 +249,7 @@ struct lsa_ctx
   // lsa_match_types as one launch for all types, search and model fit fused (lsa_match_fused.hip); off: the staged
   // kernels of lsa_match.hip, types side by side on streams (same results, kept for comparison)
   bool fused_match = true;
+  bool fused_model = true;  // ... and the search kernel fits the models of its own keypoints (one launch instead of two)
   void* trace_dev = nullptr;  // LSA_ROUTE_STATS: 4 x 8 bytes per hardware block of the last fused match (lsa_match_trace)
   bool route_stats = false;  // LSA_ROUTE_STATS: the fused search counts the routes it takes (lsa_match_route_stats)  // blocks of 3^3 .. (2 rounds + 1)^3 cells the first kernel tries
   // lsa_match_types: the keypoint types of one ICP iteration are matched concurrently, the first on

@@ -441,6 +441,7 @@ int lsa_ctx_create(int device_id, lsa_ctx** out)
   if (const char* e = std::getenv("LSA_ROUTE_STATS")) ctx->route_stats = std::atoi(e) != 0;
   if (ctx->route_stats) ok &= hipMalloc(&ctx->trace_dev, ((size_t)8192 * 12 + 16) * sizeof(unsigned long long)) == hipSuccess && hipMemset(ctx->trace_dev, 0, ((size_t)8192 * 12 + 16) * sizeof(unsigned long long)) == hipSuccess;
   if (const char* e = std::getenv("LSA_FUSED_MATCH")) ctx->fused_match = std::atoi(e) != 0;
+  if (const char* e = std::getenv("LSA_FUSED_MODEL")) ctx->fused_model = std::atoi(e) != 0;
   if (const char* e = std::getenv("LSA_MAILBOX_CHECK")) ctx->mailbox_check = std::atoi(e) != 0;
   if (!ok) { lsa_ctx_destroy(ctx); return LSA_E_HIP; }
   *out = ctx;

@@ -1130,6 +1130,7 @@ int lsa_set_fused_match(lsa_ctx* ctx, int on)
 {
   if (!ctx) return LSA_E_ARG;
   ctx->fused_match = on != 0;
+  ctx->fused_model = on != 2;
   return LSA_OK;
 }
 

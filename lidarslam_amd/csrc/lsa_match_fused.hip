@@ -601,6 +601,7 @@ struct FusedArgs
 {
   Rigid pose;
   FusedType t[3];
+  int fuse_model;  // the search kernel fits the models of its own keypoints (no second launch)
 };
 
 struct SearchShared
@@ -677,56 +678,26 @@ __device__ __forceinline__ void search_type(const Rigid& pose, const FusedType& 
 // lanes per query
 constexpr int kGE = 8, kGP = 8, kGB = 8;
 
-// The searches of one ICP iteration, all keypoint types in one launch.
-template <int KE, int KP, int KB>
-__global__ __launch_bounds__(256, 4) void k_search_all(FusedArgs a)
-{
-  __shared__ SearchShared sh;
-  // Hardware blocks b, b + 8, ... share an XCD (and its L2).  Every XCD gets one contiguous eighth of EVERY type's
-  // blocks -- neighbouring keypoints (scan order) search a compact region of the target through one L2 -- and the
-  // types with the longest searches (edges: no early out, larger k) first.
-  const int xcd = blockIdx.x % 8, j = blockIdx.x / 8;
-  const int se = (a.t[0].nblocks + 7) / 8, sp = (a.t[1].nblocks + 7) / 8;
-  if (j < se)
-  {
-    const int block = xcd * se + j;
-    if (block < a.t[0].nblocks) search_type<KE, kGE>(a.pose, a.t[0], block, sh);
-  }
-  else if (j < se + sp)
-  {
-    const int block = xcd * sp + (j - se);
-    if (block < a.t[1].nblocks) search_type<KP, kGP>(a.pose, a.t[1], block, sh);
-  }
-  else
-  {
-    if constexpr (KB > 0)
-    {
-      const int sb = (a.t[2].nblocks + 7) / 8;
-      const int block = xcd * sb + (j - se - sp);
-      if (block < a.t[2].nblocks) search_type<KB, kGB>(a.pose, a.t[2], block, sh);
-    }
-  }
-}
-
 // The model fits of one ICP iteration, one thread per keypoint, all types in one launch.  What the search could not
 // settle inside the grid's blocks (kPending) is searched here first: the wavefront of such a keypoint walks the whole
 // target for it, every lane keeping the k best of its share, one merge at the end.
-template <int KE>
+template <int KE, int QPB>
 struct ModelShared
 {
-  float4 nb[KE * kModelBlock];  // edge candidates staged in LDS
-  float nd[KE * kModelBlock];
+  float4 nb[KE * QPB];  // edge candidates staged in LDS
+  float nd[KE * QPB];
   int lh[LSA_MATCH_NSTATUS];
 };
 
-template <int KMAX, int TYPE, typename SH>
+// QPB keypoints per workgroup, one thread each (the first QPB threads; every thread of the workgroup calls)
+template <int KMAX, int TYPE, int QPB, typename SH>
 __device__ __forceinline__ void model_type(const Rigid& pose, const FusedType& t, int block, SH& sh)
 {
   const int tid = threadIdx.x, lane = tid & 63;
   if (tid < LSA_MATCH_NSTATUS) sh.lh[tid] = 0;
   __syncthreads();
-  const int i = block * kModelBlock + tid;
-  const bool have = i < t.nq;
+  const int i = block * QPB + tid;
+  const bool have = tid < QPB && i < t.nq;
   int n = 0;
   if (have && !t.mc.bad_param) n = t.knn_cnt[i];
   unsigned long long pending = __ballot(have && n == kPending);
@@ -734,7 +705,7 @@ __device__ __forceinline__ void model_type(const Rigid& pose, const FusedType& t
   {
     const int src = __ffsll((long long)pending) - 1;
     pending &= pending - 1;
-    const int qi = block * kModelBlock + (tid - lane) + src;
+    const int qi = block * QPB + (tid - lane) + src;
     const float4 q4 = t.queries[2 * (size_t)qi];
     double wx, wy, wz;
     rigid_apply(pose, (double)q4.x, (double)q4.y, (double)q4.z, wx, wy, wz);
@@ -769,7 +740,7 @@ __device__ __forceinline__ void model_type(const Rigid& pose, const FusedType& t
   {
     const int st = fit_model<KMAX, TYPE>(
       t.queries[2 * (size_t)i], t.mc, n, [&](int s) { return t.knn_idx[(size_t)s * t.cap + i]; }, [&](int s) { return t.knn_d2[(size_t)s * t.cap + i]; },
-      t.xyzl, sh.nb, sh.nd, kModelBlock, tid, t.rec, t.cap, i);
+      t.xyzl, sh.nb, sh.nd, QPB, tid, t.rec, t.cap, i);
     t.status[i] = (uint8_t)st;
     atomicAdd(&sh.lh[st], 1);
   }
@@ -777,22 +748,82 @@ __device__ __forceinline__ void model_type(const Rigid& pose, const FusedType& t
   if (tid < LSA_MATCH_NSTATUS && sh.lh[tid]) atomicAdd(&t.hist[tid], sh.lh[tid]);
 }
 
+// The searches of one ICP iteration, all keypoint types in one launch -- and, when a.fuse_model, the model fits of the
+// same keypoints behind them: the first wavefront of a workgroup fits the 32 keypoints its four wavefronts have just
+// searched (their lists come back from the L2 they were written to a moment ago, their neighbours' points are the ones
+// the search has just read), while the other workgroups of the CU go on searching.  No second launch, no kernel
+// boundary with its cold caches, and the slowest search of the launch no longer holds up every model fit.
+template <int KE, int KP, int KB>
+__global__ __launch_bounds__(256, 4) void k_search_all(FusedArgs a)
+{
+  constexpr int QB = 256 / kGE;
+  static_assert(kGE == kGP && kGP == kGB, "one workgroup serves 256 / G keypoints of any type");
+  __shared__ union
+  {
+    SearchShared s;
+    ModelShared<(KE > KB ? KE : KB), QB> m;  // after the workgroup's searches: the tables are dead
+  } sh;
+  // Hardware blocks b, b + 8, ... share an XCD (and its L2).  Every XCD gets one contiguous eighth of EVERY type's
+  // blocks -- neighbouring keypoints (scan order) search a compact region of the target through one L2 -- and the
+  // types with the longest searches (edges: no early out, larger k) first.
+  const int xcd = blockIdx.x % 8, j = blockIdx.x / 8;
+  const int se = (a.t[0].nblocks + 7) / 8, sp = (a.t[1].nblocks + 7) / 8;
+  if (j < se)
+  {
+    const int block = xcd * se + j;
+    if (block >= a.t[0].nblocks) return;
+    search_type<KE, kGE>(a.pose, a.t[0], block, sh.s);
+    if (!a.fuse_model) return;
+    __syncthreads();  // the lists of all four wavefronts are written (and the tables free)
+    model_type<KE, LSA_EDGE, QB>(a.pose, a.t[0], block, sh.m);
+  }
+  else if (j < se + sp)
+  {
+    const int block = xcd * sp + (j - se);
+    if (block >= a.t[1].nblocks) return;
+    search_type<KP, kGP>(a.pose, a.t[1], block, sh.s);
+    if (!a.fuse_model) return;
+    __syncthreads();
+    model_type<KP, LSA_PLANE, QB>(a.pose, a.t[1], block, sh.m);
+  }
+  else
+  {
+    if constexpr (KB > 0)
+    {
+      const int sb = (a.t[2].nblocks + 7) / 8;
+      const int block = xcd * sb + (j - se - sp);
+      if (block >= a.t[2].nblocks) return;
+      search_type<KB, kGB>(a.pose, a.t[2], block, sh.s);
+      if (!a.fuse_model) return;
+      __syncthreads();
+      model_type<KB, LSA_BLOB, QB>(a.pose, a.t[2], block, sh.m);
+    }
+  }
+}
+
 template <int KE, int KP, int KB>
 __global__ __launch_bounds__(kModelBlock) void k_model_all(FusedArgs a)
 {
-  __shared__ ModelShared<KE> sh;
+  __shared__ ModelShared<KE, kModelBlock> sh;
   int b = blockIdx.x;
-  if (b < a.t[0].mblocks) { model_type<KE, LSA_EDGE>(a.pose, a.t[0], b, sh); return; }
+  if (b < a.t[0].mblocks) { model_type<KE, LSA_EDGE, kModelBlock>(a.pose, a.t[0], b, sh); return; }
   b -= a.t[0].mblocks;
-  if (b < a.t[1].mblocks) { model_type<KP, LSA_PLANE>(a.pose, a.t[1], b, sh); return; }
+  if (b < a.t[1].mblocks) { model_type<KP, LSA_PLANE, kModelBlock>(a.pose, a.t[1], b, sh); return; }
   b -= a.t[1].mblocks;
-  if constexpr (KB > 0) model_type<KB, LSA_BLOB>(a.pose, a.t[2], b, sh);
+  if constexpr (KB > 0) model_type<KB, LSA_BLOB, kModelBlock>(a.pose, a.t[2], b, sh);
 }
 
 template <int KE, int KP, int KB>
 void launch_fused(lsa_ctx* ctx, const FusedArgs& a, double search_bytes, double model_bytes, hipStream_t st)
 {
   const int grid = 8 * ((a.t[0].nblocks + 7) / 8 + (a.t[1].nblocks + 7) / 8 + (a.t[2].nblocks + 7) / 8);
+  if (a.fuse_model)
+  {
+    // one launch: every workgroup fits the models of the keypoints it has searched
+    ProfScope ps(ctx, "match_search_model", search_bytes + model_bytes, st);
+    hipLaunchKernelGGL((k_search_all<KE, KP, KB>), dim3(grid), dim3(256), 0, st, a);
+    return;
+  }
   if (grid > 0)
   {
     ProfScope ps(ctx, "match_search", search_bytes, st);
@@ -847,6 +878,11 @@ int enqueue_fused_match(lsa_ctx* ctx, const MatchPrep* preps, int count, const d
     model_bytes += (double)p.nq * (32 + p.mc.k * 8 + p.mc.k * 16 + 136);
   }
   if (a.t[0].mblocks + a.t[1].mblocks + a.t[2].mblocks == 0) return LSA_OK;
+  // the search kernel fits the models too when every type that has keypoints is searched (a type with invalid
+  // parameters is not: its keypoints get their status from the model kernel)
+  a.fuse_model = ctx->fused_model ? 1 : 0;
+  for (int k = 0; k < 3; ++k)
+    if (a.t[k].mblocks > 0 && a.t[k].nblocks == 0) a.fuse_model = 0;
   // the list lengths compiled in: the reference's defaults (edges 8 ego-motion / 10 localization, planes 5, no blobs)
   // get kernels of their own -- one kernel has one register budget, the longest list in it sets it for every type
   const int ke = kmax[0], kp = kmax[1];

@@ -419,9 +419,10 @@ def test_fused_and_staged_matching_agree(O, L, kps, model):
     stage -> second stage -> model fit): histograms, status, weights and records bit for bit, for every keypoint type,
     ego-motion and localization parameters, several cell sizes and neighbour counts"""
     prev, cur = kps[model]
-    a, b = L.Context(0), L.Context(0)
-    a.set_fused_match(1)
+    a, b, c = L.Context(0), L.Context(0), L.Context(0)
+    a.set_fused_match(1)  # one launch: every workgroup fits the models of the keypoints it has searched
     b.set_fused_match(0)
+    c.set_fused_match(2)  # two launches: searches, then model fits
     cases = [
         (L.MatchParams.ego_motion(saturation_distance=5.0), (0.5, 0.25, 0.5)),
         (L.MatchParams.localization(saturation_distance=2.0), (0.75, 0.6, 0.3)),
@@ -432,33 +433,43 @@ def test_fused_and_staged_matching_agree(O, L, kps, model):
     odd.edge_nb_neighbors, odd.plane_nb_neighbors, odd.blob_nb_neighbors = 16, 7, 13
     cases.append((odd, (0.75, 0.6, 0.3)))
     for mp, cells in cases:
-        for ctx in (a, b):
+        for ctx in (a, b, c):
             for k in (L.EDGE, L.PLANE, L.BLOB):
                 n = 20000 if k == L.BLOB else None
                 ctx.set_keypoints(L.SET_WORKING, k, cur[k][:n])
                 ctx.set_target(k, prev[k], cell=cells[k])
         ha = a.match_types(7, L.SET_WORKING, mp, perturbed())
-        hb = b.match_types(7, L.SET_WORKING, mp, perturbed())
-        assert ha.tolist() == hb.tolist()
-        for k in (L.EDGE, L.PLANE, L.BLOB):
-            sa, wa, ra = a.match_results(k, L.SET_WORKING)
-            sb, wb, rb = b.match_results(k, L.SET_WORKING)
-            assert np.array_equal(sa, sb), (k, cells, np.flatnonzero(sa != sb)[:10])
-            assert np.array_equal(bits(wa), bits(wb)) and np.array_equal(bits(ra), bits(rb))
+        for other in (b, c):
+            hb = other.match_types(7, L.SET_WORKING, mp, perturbed())
+            assert ha.tolist() == hb.tolist()
+            for k in (L.EDGE, L.PLANE, L.BLOB):
+                sa, wa, ra = a.match_results(k, L.SET_WORKING)
+                sb, wb, rb = other.match_results(k, L.SET_WORKING)
+                assert np.array_equal(sa, sb), (k, cells, np.flatnonzero(sa != sb)[:10])
+                assert np.array_equal(bits(wa), bits(wb)) and np.array_equal(bits(ra), bits(rb))
     # keypoints far from a sparse target: no block of the grid holds k points -> tail kernel (edges), FAR (planes)
     far = cur[L.EDGE][:500].copy()
     far["x"] += 300.0
-    for ctx in (a, b):
+    for ctx in (a, b, c):
         ctx.set_keypoints(L.SET_WORKING, L.EDGE, np.concatenate([cur[L.EDGE][:500], far]))
         ctx.set_target(L.EDGE, prev[L.EDGE][::7], cell=0.3)
         ctx.set_keypoints(L.SET_WORKING, L.PLANE, np.concatenate([cur[L.PLANE][:500], far]))
         ctx.set_target(L.PLANE, prev[L.PLANE][::50], cell=0.3)
     mp = L.MatchParams.localization(saturation_distance=2.0)
-    ha, hb = a.match_types(3, L.SET_WORKING, mp, np.eye(4)), b.match_types(3, L.SET_WORKING, mp, np.eye(4))
-    assert ha.tolist() == hb.tolist()
-    for k in (L.EDGE, L.PLANE):
-        sa, wa, ra = a.match_results(k, L.SET_WORKING)
-        sb, wb, rb = b.match_results(k, L.SET_WORKING)
-        assert np.array_equal(sa, sb) and np.array_equal(bits(ra), bits(rb))
-    a.close()
-    b.close()
+    ha = a.match_types(3, L.SET_WORKING, mp, np.eye(4))
+    for other in (b, c):
+        hb = other.match_types(3, L.SET_WORKING, mp, np.eye(4))
+        assert ha.tolist() == hb.tolist()
+        for k in (L.EDGE, L.PLANE):
+            sa, wa, ra = a.match_results(k, L.SET_WORKING)
+            sb, wb, rb = other.match_results(k, L.SET_WORKING)
+            assert np.array_equal(sa, sb) and np.array_equal(bits(ra), bits(rb))
+    # invalid parameters for one type: its keypoints are not searched, their status comes from the model kernel (the
+    # one-launch form steps aside for that match)
+    bad = L.MatchParams.localization(saturation_distance=2.0)
+    bad.plane_nb_neighbors = 2
+    ha = a.match_types(3, L.SET_WORKING, bad, np.eye(4))
+    hb = b.match_types(3, L.SET_WORKING, bad, np.eye(4))
+    assert ha.tolist() == hb.tolist() and ha[L.PLANE][1] > 0  # LSA_MATCH_BAD_MODEL_PARAMETRIZATION
+    for ctx in (a, b, c):
+        ctx.close()

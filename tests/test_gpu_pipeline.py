@@ -594,7 +594,7 @@ def test_lookahead_extraction_changes_nothing_but_the_schedule(L):
     ahead = run(lambda f: f + 1 if f + 1 < len(frames) else None)
     wrong = run(lambda f: (f + 3) % len(frames))
     assert plain[3] == 0 and ahead[3] == len(frames) - 1 and wrong[3] == 0
-    for other in (ahead, wrong, ahead_at):
+    for other in (ahead, wrong):
         assert np.array_equal(plain[0], other[0]) and plain[1] == other[1] and plain[2] == other[2]
     plain_c = run(lambda f: None, change_at=6)
     ahead_c = run(lambda f: f + 1 if f + 1 < len(frames) else None, change_at=6)

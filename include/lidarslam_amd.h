@@ -419,6 +419,16 @@ int lsa_reset_working_keypoints(lsa_ctx* ctx);
  * H0 is applied to every point, as in the reference. */
 int lsa_undistort(lsa_ctx* ctx, const double H0[16], const double H1[16], double t0, double t1);
 
+/* What Slam::Localization starts with (Slam.cxx:980-999, 1026-1029) as ONE launch: lsa_reset_working_keypoints, then
+ * lsa_undistort(H0, H1, t0, t1) unless H0 is NULL, then -- unless box_pose is NULL -- the bounding boxes of the three
+ * types under box_pose as lsa_keypoint_bboxes_begin(LSA_SET_WORKING, box_pose) leaves them on the device for the
+ * device maps (lsa_device_grid_build_submap_begin_for_keypoints, lsa_device_grid_submap_ahead_take); they only travel
+ * to the host if lsa_keypoint_bboxes_end asks for them.  Same working keypoints and boxes as the separate calls.
+ * lsa_arm_localization_boxes prepares the boxes' words for that launch (one tiny launch): called while the device is
+ * idle -- between two frames -- it is off the frame's critical path; lsa_localization_begin does it itself otherwise. */
+int lsa_localization_begin(lsa_ctx* ctx, const double H0[16], const double H1[16], double t0, double t1, const double box_pose[16]);
+int lsa_arm_localization_boxes(lsa_ctx* ctx);
+
 /* min/max of the `time` field over the working keypoints (Slam::InitUndistortion,
  * Slam.cxx:1291-1300) and bounding box of pose * working keypoints of one type
  * (Slam.cxx:1026-1029). */

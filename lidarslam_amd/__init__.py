@@ -57,7 +57,7 @@ ABI_SYMBOLS = [
     "lsa_download_debug", "lsa_nb_laser_rings", "lsa_transform_keypoints", "lsa_set_target", "lsa_set_target_from_set", "lsa_prepare_previous_targets", "lsa_prepared_targets_adopted", "lsa_target_staging", "lsa_set_target_staged", "lsa_stage_target_ahead", "lsa_drop_target_ahead", "lsa_staged_targets_adopted",
     "lsa_target_size", "lsa_download_target", "lsa_set_target_cell_size", "lsa_set_knn_lanes", "lsa_set_fused_match", "lsa_set_knn_rounds", "lsa_match_slow_queries", "lsa_match_exhaustive_queries", "lsa_match_route_stats", "lsa_match_trace", "lsa_set_keypoints", "lsa_match", "lsa_match_types",
     "lsa_download_match", "lsa_overlap", "lsa_accumulate", "lsa_mailbox_active", "lsa_solve", "lsa_solve_device", "lsa_solve_device_fallbacks", "lsa_solve_device_trace", "lsa_registration_error", "lsa_selftest_math", "lsa_reset_working_keypoints", "lsa_undistort", "lsa_working_time_range",
-    "lsa_working_bbox", "lsa_working_bboxes", "lsa_keypoint_bboxes_begin", "lsa_keypoint_bboxes_begin_interp", "lsa_keypoint_time_range", "lsa_keypoint_bboxes_end", "lsa_download_transformed", "lsa_stage_transformed", "lsa_staged_transformed", "lsa_transform_frame", "lsa_profile_enable", "lsa_profile_select", "lsa_profile_reset",
+    "lsa_working_bbox", "lsa_working_bboxes", "lsa_localization_begin", "lsa_arm_localization_boxes", "lsa_keypoint_bboxes_begin", "lsa_keypoint_bboxes_begin_interp", "lsa_keypoint_time_range", "lsa_keypoint_bboxes_end", "lsa_download_transformed", "lsa_stage_transformed", "lsa_staged_transformed", "lsa_transform_frame", "lsa_profile_enable", "lsa_profile_select", "lsa_profile_reset",
     "lsa_profile_get", "lsa_slam_create", "lsa_slam_destroy", "lsa_slam_last_error", "lsa_slam_set_param",
     "lsa_slam_get_param", "lsa_slam_reset", "lsa_slam_clear_maps", "lsa_slam_add_frame", "lsa_slam_store_frame", "lsa_slam_add_stored_frame", "lsa_slam_hint_next_stored_frame", "lsa_slam_hint_next_frame", "lsa_upload_frame_begin", "lsa_upload_frame_ready", "lsa_upload_frame_adopt", "lsa_uploads_adopted", "lsa_extract_prefetch_uploaded",
     "lsa_slam_get_world_transform", "lsa_slam_get_covariance", "lsa_slam_get_keypoints", "lsa_slam_get_registered_frame",
@@ -146,6 +146,8 @@ def lib():
     L.lsa_working_time_range.argtypes = [vp, vp, vp]
     L.lsa_keypoint_time_range.argtypes = [vp, i32, vp, vp]
     L.lsa_keypoint_bboxes_begin.argtypes = [vp, i32, vp]
+    L.lsa_localization_begin.argtypes = [vp, vp, vp, f64, f64, vp]
+    L.lsa_arm_localization_boxes.argtypes = [vp]
     L.lsa_keypoint_bboxes_begin_interp.argtypes = [vp, i32, vp, vp, f64, f64]
     L.lsa_keypoint_bboxes_end.argtypes = [vp, vp, vp]
     L.lsa_working_bbox.argtypes = [vp, i32, vp, vp, vp]
@@ -480,6 +482,19 @@ class Context:
 
     def undistort(self, H0, H1, t0, t1):
         self._check(self.L.lsa_undistort(self.h, ptr(pose16(H0)), ptr(pose16(H1)), t0, t1), "lsa_undistort")
+
+    def localization_begin(self, H0=None, H1=None, t0=0.0, t1=0.0, box_pose=None, arm=False):
+        """lsa_localization_begin: reset + undistort (unless H0 is None) + boxes under box_pose (unless None), one launch;
+        the boxes are read with keypoint_bboxes_end"""
+        if arm:
+            self._check(self.L.lsa_arm_localization_boxes(self.h), "lsa_arm_localization_boxes")
+        self._check(self.L.lsa_localization_begin(self.h, ptr(pose16(H0)) if H0 is not None else None, ptr(pose16(H1)) if H1 is not None else None,
+                                                  C.c_double(t0), C.c_double(t1), ptr(pose16(box_pose)) if box_pose is not None else None), "lsa_localization_begin")
+
+    def keypoint_bboxes_end(self):
+        mn, mx = np.zeros(9, np.float32), np.zeros(9, np.float32)
+        self._check(self.L.lsa_keypoint_bboxes_end(self.h, ptr(mn), ptr(mx)), "lsa_keypoint_bboxes_end")
+        return mn.reshape(3, 3), mx.reshape(3, 3)
 
     def working_time_range(self):
         a, b = C.c_double(), C.c_double()

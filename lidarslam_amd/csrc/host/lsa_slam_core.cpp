@@ -458,6 +458,8 @@ int SlamCore::ProcessCurrentFrame(uint64_t stampUs)
     if (rc < 0) return rc;
     Stats.maps = t.Stop();
   }
+  // the words the next frame's localization reduces its keypoints' boxes into, armed while the device has nothing to do
+  if (LocalizationStartFused && DeviceMapsInUse() && MapUpdate != MappingMode::NONE) LSA_TRY(lsa_arm_localization_boxes(Ctx));
   LogCurrentFrameState(CurrentTime);
   NbrFrameProcessed++;
   return LSA_OK;
@@ -673,16 +675,37 @@ int SlamCore::Localization()
 {
   PreviousTworld = Tworld;
   Tworld = PreviousTworld * Trelative;
-  LSA_TRY(lsa_reset_working_keypoints(Ctx));  // CurrentUndistortedKeypoints = CurrentRawKeypoints
-
-  if (Undistortion)
+  // With the maps on the device the reset, the first undistortion and the keypoints' boxes under the pose guess (which the
+  // grids read on the device) are one launch; otherwise the three steps as the reference lists them.
+  const bool oneLaunch = LocalizationStartFused && DeviceMapsInUse() && MapUpdate != MappingMode::NONE;
+  bool boxesEnqueued = false;
+  if (oneLaunch)
   {
     Tick t;
-    int rc = InitUndistortion();
-    if (rc < 0) return rc;
-    rc = RefineUndistortion();
-    if (rc < 0) return rc;
+    Pose d0 = Pose::Identity(), d1 = Pose::Identity();
+    if (Undistortion)
+    {
+      double t0, t1;
+      LSA_TRY(lsa_keypoint_time_range(Ctx, LSA_SET_RAW_CURRENT, &t0, &t1));  // what the working keypoints are about to be
+      InitUndistortion(t0, t1);
+      RefineUndistortion(&d0, &d1);
+    }
+    LSA_TRY(lsa_localization_begin(Ctx, Undistortion ? d0.m : nullptr, Undistortion ? d1.m : nullptr, Motion.Time0, Motion.Time1, Tworld.m));
+    boxesEnqueued = true;
     Stats.undistort += t.Stop();
+  }
+  else
+  {
+    LSA_TRY(lsa_reset_working_keypoints(Ctx));  // CurrentUndistortedKeypoints = CurrentRawKeypoints
+    if (Undistortion)
+    {
+      Tick t;
+      int rc = InitUndistortion();
+      if (rc < 0) return rc;
+      rc = RefineUndistortion();
+      if (rc < 0) return rc;
+      Stats.undistort += t.Stop();
+    }
   }
 
   if (DeviceMapsInUse())
@@ -730,7 +753,7 @@ int SlamCore::Localization()
       any = any || need[k];
     }
     // the boxes of the current keypoints under the pose guess stay on the device: the grids read them there
-    if (any && MapUpdate != MappingMode::NONE) LSA_TRY(lsa_keypoint_bboxes_begin(Ctx, LSA_SET_WORKING, Tworld.m));
+    if (any && MapUpdate != MappingMode::NONE && !boxesEnqueued) LSA_TRY(lsa_keypoint_bboxes_begin(Ctx, LSA_SET_WORKING, Tworld.m));
     for (int k = 0; k < 3; ++k)
     {
       if (!need[k]) continue;
@@ -1212,14 +1235,18 @@ int SlamCore::InitUndistortion()
 {
   double t0, t1;
   LSA_TRY(lsa_working_time_range(Ctx, &t0, &t1));
+  InitUndistortion(t0, t1);
+  return LSA_OK;
+}
+void SlamCore::InitUndistortion(double t0, double t1)
+{
   Motion.SetTimes(t0, t1);
   Motion.SetTransforms(Pose::Identity(), Pose::Identity());
   if (Motion.GetTimeRange() < 1e-6) Motion.SetTimes(0., 0.);
-  return LSA_OK;
 }
 
-// Slam::RefineUndistortion (Slam.cxx:1322-1352)
-int SlamCore::RefineUndistortion()
+// Slam::RefineUndistortion (Slam.cxx:1322-1352); with d0 / d1 the two transforms are handed back instead of applied
+int SlamCore::RefineUndistortion(Pose* outD0, Pose* outD1)
 {
   const Pose previousBaseBegin = Motion.GetH0();
   const Pose previousBaseEnd = Motion.GetH1();
@@ -1231,6 +1258,7 @@ int SlamCore::RefineUndistortion()
   Motion.SetTransforms(newBaseBegin, newBaseEnd);
   const Pose d0 = newBaseBegin * Inverse(previousBaseBegin);
   const Pose d1 = newBaseEnd * Inverse(previousBaseEnd);
+  if (outD0 && outD1) { *outD0 = d0; *outD1 = d1; return LSA_OK; }
   LSA_TRY(lsa_undistort(Ctx, d0.m, d1.m, Motion.Time0, Motion.Time1));
   return LSA_OK;
 }
@@ -1349,6 +1377,7 @@ int SlamCore::GetRegisteredFrame(std::vector<lsa_point_t>& out)
   X("MapsOnDevice", MapsOnDevice, bool)                                                                \
   X("SubMapsAhead", SubMapsAhead, bool)                                                                \
   X("SubMapsAheadAdaptive", SubMapsAheadAdaptive, bool)                                                \
+  X("LocalizationStartFused", LocalizationStartFused, bool)                                            \
   X("FusedMatch", FusedMatch, bool)                                                                    \
   X("EgoMotionICPMaxIter", EgoMotionICPMaxIter, unsigned)                                              \
   X("LocalizationICPMaxIter", LocalizationICPMaxIter, unsigned)                                        \

@@ -216,6 +216,7 @@ public:
   // (980 against 950 frames/s; with the first, slower insertion kernels it lost: the sub-map came 0.05 ms late)
   bool SubMapsAhead = true;
   bool SubMapsAheadAdaptive = true;  // give it up for a while when the localization had to wait for it twice in a row
+  bool LocalizationStartFused = true;  // reset + first undistortion + keypoint boxes of the localization as one launch (device maps)
   bool DevSpec[3] = {false, false, false};
   bool OrderedMaps = true;
   bool DeviceMapsInUse() const { return MapsOnDevice && DevMaps[0] && LocalMaps[0]->GetSampling() != SamplingMode::CENTROID; }
@@ -249,7 +250,8 @@ private:
   void LogCurrentFrameState(double time);
   Pose InterpolateScanPose(double time) const;
   int InitUndistortion();
-  int RefineUndistortion();
+  void InitUndistortion(double t0, double t1);
+  int RefineUndistortion(Pose* outD0 = nullptr, Pose* outD1 = nullptr);
   int Fail(int rc, const char* where);
   lsa_match_params_t EgoMatchParams() const;
   lsa_match_params_t LocMatchParams() const;

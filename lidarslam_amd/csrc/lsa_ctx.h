@@ -258,7 +258,7 @@ struct lsa_ctx
   hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
   void* scratch_out = nullptr;    // device staging for transformed downloads
   size_t scratch_cap = 0;
-  unsigned long long* range_bits = nullptr;  // [0..1] time range, [16..24] bounding boxes (ordered bits)
+  unsigned long long* range_bits = nullptr;  // [0..1] time range, [16..24] and [32..40] bounding boxes (ordered bits)
   hipEvent_t ev_bbox = nullptr;
   // lsa_stage_transformed: pinned host buffers the device writes the transformed keypoints into directly
   lsa_point_t* stage[3] = {nullptr, nullptr, nullptr};
@@ -266,6 +266,9 @@ struct lsa_ctx
   hipEvent_t ev_stage = nullptr;
   bool stage_pending = false;
   bool bbox_pending = false;
+  bool bbox_copied = true;   // the boxes of the last lsa_keypoint_bboxes_begin / lsa_localization_begin are on their way to the host
+  bool loc_boxes = false;    // the boxes the grids read are the ones lsa_localization_begin made (words of their own)
+  bool loc_armed = false;    // ... whose words are armed for the next launch
   std::mutex prof_mutex;  // stats / pending / event_pool of the profiling scopes
   int bbox_n[3] = {0, 0, 0};
 
@@ -295,6 +298,10 @@ namespace lsa
   } while (0)
 
 int lm_cache_capacity();
+// the 18 words of the keypoints' bounding boxes: [16..24] of range_bits for lsa_keypoint_bboxes_begin, [32..40] for lsa_localization_begin
+inline unsigned* box_words(lsa_ctx* ctx) { return reinterpret_cast<unsigned*>(ctx->range_bits + 16); }
+inline unsigned* loc_box_words(lsa_ctx* ctx) { return reinterpret_cast<unsigned*>(ctx->range_bits + 32); }
+inline const unsigned* current_box_words(lsa_ctx* ctx) { return ctx->loc_boxes ? loc_box_words(ctx) : box_words(ctx); }
 int transform_points_to(lsa_ctx* ctx, const lsa_point_t* src, int n, const double pose[16], lsa_point_t* dst, hipStream_t stream = nullptr);  // lsa_transform.hip
 int time_from_advancement(lsa_ctx* ctx, lsa_point_t* frame, int n, double rpm, int first_packet);  // lsa_extract.hip
 int ensure_capacity(lsa_ctx* ctx, int n);

@@ -421,7 +421,7 @@ int lsa_ctx_create(int device_id, lsa_ctx** out)
   if (ok) ok &= hipMemset(ctx->reduce_out, 0, 64 * sizeof(double)) == hipSuccess;  // [32] holds the arrival ticket of k_accumulate
   ok &= hipMalloc((void**)&ctx->hist_dev, 3 * kHistRing * 16 * sizeof(int)) == hipSuccess;
   if (ok) ok &= hipMemset(ctx->hist_dev, 0, 3 * kHistRing * 16 * sizeof(int)) == hipSuccess;
-  ok &= hipMalloc((void**)&ctx->range_bits, 32 * sizeof(unsigned long long)) == hipSuccess;
+  ok &= hipMalloc((void**)&ctx->range_bits, 48 * sizeof(unsigned long long)) == hipSuccess;
   ok &= hipHostMalloc((void**)&ctx->host_pinned, 512 * sizeof(double), hipHostMallocDefault) == hipSuccess;
   if (hipHostMalloc((void**)&ctx->mailbox, (size_t)kAccumBlocksMax * kMailboxStride * sizeof(unsigned long long), hipHostMallocCoherent | hipHostMallocMapped) == hipSuccess)
     std::memset(ctx->mailbox, 0, (size_t)kAccumBlocksMax * kMailboxStride * sizeof(unsigned long long));

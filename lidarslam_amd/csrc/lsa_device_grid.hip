@@ -1517,7 +1517,7 @@ static int build_submap_begin(lsa_device_grid* g, const float mn[3], const float
   if (boxed)
   {
     if (mn) for (int d = 0; d < 3; ++d) { pred.box.mn[d] = mn[d]; pred.box.mx[d] = mx[d]; }
-    pred.ctx_box = mn ? nullptr : reinterpret_cast<const unsigned*>(ctx->range_bits + 16) + 6 * box_type;
+    pred.ctx_box = mn ? nullptr : lsa::current_box_words(ctx) + 6 * box_type;
     filtered = !(min_nb_points < 0 || g->MinFramesPerVoxel <= 1);
     pred.mode = filtered ? 1 : 0;
   }
@@ -1714,7 +1714,7 @@ int lsa_device_grid_submap_ahead_take_begin(lsa_device_grid* g, int box_type, in
   // predicted range and the state it reads)
   G_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_map_ahead[type], 0));
   const unsigned tag = ++g->ahead_tag;
-  const unsigned* words = reinterpret_cast<const unsigned*>(ctx->range_bits + 16) + 6 * box_type;
+  const unsigned* words = lsa::current_box_words(ctx) + 6 * box_type;
   hipLaunchKernelGGL(k_box_check, dim3(1), dim3(64), 0, ctx->stream, words, g->GridSize, (float)g->VoxelResolution, g->VoxelResolution, g->st, g->host_ahead + 1, tag);
   g->take_pending = true;
   g->take_slot = slot;

@@ -246,6 +246,62 @@ __global__ __launch_bounds__(256) void k_bbox3(KpSets sets, Rigid T0, int interp
   }
 }
 
+// What the localization starts with, in ONE launch: working = the raw keypoints, undistorted (the reset and the first
+// RefineUndistortion of Slam::Localization, Slam.cxx:980-999), and the bounding boxes of the three types under the pose
+// guess (pcl::getMinMax3D of the transformed keypoints, Slam.cxx:1027-1029).  The boxes' words must be armed (k_bbox_init)
+// before the launch: the blocks reduce into them with atomics.
+__global__ __launch_bounds__(256) void k_loc_start(StageOut s, int undistort, InterpConst c, int boxes, Rigid T0, unsigned* __restrict__ bits)
+{
+  __shared__ unsigned slo[4][3], shi[4][3];
+  const int t = blockIdx.y;
+  const int n = s.n[t];
+  if ((int)(blockIdx.x * blockDim.x) >= n) return;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned lo[3] = {~0u, ~0u, ~0u}, hi[3] = {0u, 0u, 0u};
+  if (i < n)
+  {
+    float4 a = s.in[t][2 * (size_t)i];
+    const float4 b = s.in[t][2 * (size_t)i + 1];
+    if (undistort)
+    {
+      Rigid U;
+      interp_eval(c, point_time(b), U);
+      double ox, oy, oz;
+      rigid_apply(U, (double)a.x, (double)a.y, (double)a.z, ox, oy, oz);
+      a.x = (float)ox; a.y = (float)oy; a.z = (float)oz;
+    }
+    s.out[t][2 * (size_t)i] = a;
+    s.out[t][2 * (size_t)i + 1] = b;
+    if (boxes)
+    {
+      double ox, oy, oz;
+      rigid_apply(T0, (double)a.x, (double)a.y, (double)a.z, ox, oy, oz);
+      const float v[3] = {(float)ox, (float)oy, (float)oz};
+      for (int d = 0; d < 3; ++d)
+        if (v[d] == v[d]) lo[d] = hi[d] = f2ou(v[d]);
+    }
+  }
+  if (!boxes) return;
+  for (int d = 0; d < 3; ++d)
+    for (int sft = 32; sft > 0; sft >>= 1)
+    {
+      const unsigned l2 = __shfl_down(lo[d], sft), h2 = __shfl_down(hi[d], sft);
+      lo[d] = l2 < lo[d] ? l2 : lo[d];
+      hi[d] = h2 > hi[d] ? h2 : hi[d];
+    }
+  if ((threadIdx.x & 63) == 0)
+    for (int d = 0; d < 3; ++d) { slo[threadIdx.x >> 6][d] = lo[d]; shi[threadIdx.x >> 6][d] = hi[d]; }
+  __syncthreads();
+  if (threadIdx.x < 3)
+  {
+    const int d = threadIdx.x;
+    unsigned l = slo[0][d], h = shi[0][d];
+    for (int w = 1; w < 4; ++w) { l = slo[w][d] < l ? slo[w][d] : l; h = shi[w][d] > h ? shi[w][d] : h; }
+    atomicMin(&bits[6 * t + d], l);
+    atomicMax(&bits[6 * t + 3 + d], h);
+  }
+}
+
 // host-side quaternion helpers (Eigen::Quaternion(Matrix3d), slam_lib/include/LidarSlam/MotionModel.h:64-76)
 void quat_from_matrix(const double R[9], double q[4])
 {
@@ -369,6 +425,7 @@ int lsa_reset_working_keypoints(lsa_ctx* ctx)
     nmax = std::max(nmax, n);
   }
   if (nmax > 0) hipLaunchKernelGGL(k_copy_sets, dim3((nmax + 255) / 256, 3), dim3(256), 0, ctx->stream, so);  // one launch instead of three copies
+  ctx->loc_boxes = false;
   ctx->kp_time_valid[LSA_SET_WORKING] = ctx->kp_time_valid[LSA_SET_RAW_CURRENT];
   ctx->kp_time[LSA_SET_WORKING][0] = ctx->kp_time[LSA_SET_RAW_CURRENT][0];
   ctx->kp_time[LSA_SET_WORKING][1] = ctx->kp_time[LSA_SET_RAW_CURRENT][1];
@@ -392,6 +449,56 @@ int lsa_undistort(lsa_ctx* ctx, const double H0[16], const double H1[16], double
   if (nmax <= 0) return LSA_OK;
   ProfScope ps(ctx, "undistort", (double)total * 48);
   hipLaunchKernelGGL(k_undistort, dim3((nmax + 255) / 256, 3), dim3(256), 0, ctx->stream, sets, c);
+  return LSA_OK;
+}
+
+int lsa_arm_localization_boxes(lsa_ctx* ctx)
+{
+  if (!ctx) return LSA_E_ARG;
+  if (ctx->loc_armed) return LSA_OK;
+  LSA_HIP(ctx, hipSetDevice(ctx->device));
+  hipLaunchKernelGGL(k_bbox_init, dim3(1), dim3(64), 0, ctx->stream, lsa::loc_box_words(ctx));
+  ctx->loc_armed = true;
+  return LSA_OK;
+}
+
+int lsa_localization_begin(lsa_ctx* ctx, const double H0[16], const double H1[16], double t0, double t1, const double box_pose[16])
+{
+  if (!ctx || (H0 && !H1)) return ctx ? ctx->fail(LSA_E_ARG, "lsa_localization_begin: bad argument") : LSA_E_ARG;
+  LSA_HIP(ctx, hipSetDevice(ctx->device));
+  StageOut so;
+  int nmax = 0, total = 0;
+  for (int k = 0; k < 3; ++k)
+  {
+    const int n = ctx->kp_n[LSA_SET_RAW_CURRENT][k];
+    ctx->kp_n[LSA_SET_WORKING][k] = n;
+    so.in[k] = reinterpret_cast<const float4*>(ctx->kp[LSA_SET_RAW_CURRENT][k]);
+    so.out[k] = reinterpret_cast<float4*>(ctx->kp[LSA_SET_WORKING][k]);
+    so.n[k] = n;
+    if (box_pose) ctx->bbox_n[k] = n;
+    nmax = std::max(nmax, n);
+    total += std::max(n, 0);
+  }
+  ctx->kp_time_valid[LSA_SET_WORKING] = ctx->kp_time_valid[LSA_SET_RAW_CURRENT];
+  ctx->kp_time[LSA_SET_WORKING][0] = ctx->kp_time[LSA_SET_RAW_CURRENT][0];
+  ctx->kp_time[LSA_SET_WORKING][1] = ctx->kp_time[LSA_SET_RAW_CURRENT][1];
+  ctx->loc_boxes = box_pose != nullptr;
+  if (box_pose)
+  {
+    // the words are armed while the device is idle between two frames (lsa_arm_localization_boxes); here only when nobody did
+    const int rc = lsa_arm_localization_boxes(ctx);
+    if (rc) return rc;
+    ctx->loc_armed = false;
+    ctx->bbox_pending = true;
+    ctx->bbox_copied = false;
+  }
+  if (nmax <= 0) return LSA_OK;
+  InterpConst c{};
+  if (H0) c = make_interp(H0, H1, t0, t1);
+  Rigid T{};
+  if (box_pose) row_major_to_rt(box_pose, T.R, T.t);
+  ProfScope ps(ctx, "undistort", (double)total * (H0 ? 64 : 64));
+  hipLaunchKernelGGL(k_loc_start, dim3((nmax + 255) / 256, 3), dim3(256), 0, ctx->stream, so, H0 ? 1 : 0, c, box_pose ? 1 : 0, T, lsa::loc_box_words(ctx));
   return LSA_OK;
 }
 
@@ -439,6 +546,7 @@ static int bboxes_begin(lsa_ctx* ctx, int set, const double pose[16], const doub
   hipLaunchKernelGGL(k_bbox3, dim3((nmax + 255) / 256, 3), dim3(256), 0, ctx->stream, sets, T, pose_end ? 1 : 0, ic, bits);
   LSA_HIP(ctx, hipMemcpyAsync(ctx->host_pinned + 160, bits, 18 * sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
   LSA_HIP(ctx, hipEventRecord(ctx->ev_bbox, ctx->stream));
+  ctx->bbox_copied = true;
   return LSA_OK;
 }
 int lsa_keypoint_bboxes_begin(lsa_ctx* ctx, int set, const double pose[16]) { return bboxes_begin(ctx, set, pose, nullptr, 0., 0.); }
@@ -454,6 +562,14 @@ int lsa_keypoint_bboxes_end(lsa_ctx* ctx, float mn[9], float mx[9])
   ctx->bbox_pending = false;
   for (int i = 0; i < 9; ++i) { mn[i] = FLT_MAX; mx[i] = -FLT_MAX; }
   if (ctx->bbox_n[0] <= 0 && ctx->bbox_n[1] <= 0 && ctx->bbox_n[2] <= 0) return LSA_OK;
+  if (!ctx->bbox_copied)
+  {
+    // the boxes lsa_localization_begin left on the device: nobody needs them on the host in the pipeline, so they only
+    // come over when they are asked for
+    LSA_HIP(ctx, hipMemcpyAsync(ctx->host_pinned + 160, lsa::loc_box_words(ctx), 18 * sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
+    LSA_HIP(ctx, hipEventRecord(ctx->ev_bbox, ctx->stream));
+    ctx->bbox_copied = true;
+  }
   LSA_HIP(ctx, hipEventSynchronize(ctx->ev_bbox));
   const unsigned* hp = reinterpret_cast<const unsigned*>(ctx->host_pinned + 160);
   for (int k = 0; k < 3; ++k)

@@ -44,6 +44,23 @@ def test_undistortion_bit_exact(gpu_ctx, O, L, scan):
         for k in range(3):
             assert gpu_ctx.keypoints(L.SET_WORKING, k).tobytes() == O.undistort(kp[k], A, B, t0, t1).tobytes(), (case, k)
             assert gpu_ctx.keypoints(L.SET_RAW_CURRENT, k).tobytes() == kp[k].tobytes()  # raw keypoints untouched
+        # lsa_localization_begin: the same reset + undistortion, and the boxes under the pose guess, in one launch
+        Tw = se3(12.5, -3.25, 0.75, 0.02, -0.01, 0.6)
+        boxes = gpu_ctx.keypoint_bboxes(L.SET_WORKING, Tw)
+        for arm in (True, False):  # the words armed ahead (between two frames), or by the call itself
+            gpu_ctx.localization_begin(A, B, t0, t1, box_pose=Tw, arm=arm)
+            for k in range(3):
+                assert gpu_ctx.keypoints(L.SET_WORKING, k).tobytes() == O.undistort(kp[k], A, B, t0, t1).tobytes(), (case, k)
+            got = gpu_ctx.keypoint_bboxes_end()
+            assert got[0].tobytes() == boxes[0].tobytes() and got[1].tobytes() == boxes[1].tobytes(), case
+        gpu_ctx.localization_begin(box_pose=Tw)  # no undistortion: working = raw
+        plain = gpu_ctx.keypoint_bboxes_end()
+        for k in range(3):
+            assert gpu_ctx.keypoints(L.SET_WORKING, k).tobytes() == kp[k].tobytes()
+        want = gpu_ctx.keypoint_bboxes(L.SET_RAW_CURRENT, Tw)
+        assert plain[0].tobytes() == want[0].tobytes() and plain[1].tobytes() == want[1].tobytes()
+        gpu_ctx.localization_begin(A, B, t0, t1)  # no boxes
+        assert gpu_ctx.keypoints(L.SET_WORKING, 0).tobytes() == O.undistort(kp[0], A, B, t0, t1).tobytes()
     tr = gpu_ctx.working_time_range()
     allk = np.concatenate(kp)
     assert tr == (allk["time"].min(), allk["time"].max())

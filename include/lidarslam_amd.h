@@ -290,6 +290,12 @@ int lsa_set_knn_rounds(lsa_ctx* ctx, int type, int rounds);
  * The device keeps the last 16 matches of every type. */
 long long lsa_match_serial(const lsa_ctx* ctx, int type);
 int lsa_match_histogram(lsa_ctx* ctx, int type, long long serial, int histogram[LSA_MATCH_NSTATUS]);
+/* lsa_undistort(H0, H1, t0, t1) followed by lsa_match_types on LSA_SET_WORKING -- what comes between two iterations of
+ * the localization ICP (Slam.cxx:1140-1147, 1074-1091) -- with the undistortion inside the search kernel when that kernel
+ * reaches every keypoint of the working set (one-launch form, every type that has keypoints asked for, with a target and
+ * valid parameters); as the two calls otherwise.  Same keypoints, same matches either way. */
+int lsa_match_types_undistorted(lsa_ctx* ctx, int slot, unsigned type_mask, const lsa_match_params_t* p, const double pose[16], int* histograms,
+                                const double H0[16], const double H1[16], double t0, double t1);
 /* lsa_match_types as ONE launch for all keypoint types, search and model fit in the same kernel (on = 1, the default),
  * as two launches (on = 2: the searches of all types, then their model fits), or (on = 0) as the staged kernels, types
  * side by side on streams.  Same results either way. */

@@ -55,7 +55,7 @@ ABI_SYMBOLS = [
     "lsa_frame_store_put", "lsa_frame_store_use", "lsa_frame_size", "lsa_get_azimuthal_resolution",
     "lsa_set_azimuthal_resolution", "lsa_extract_keypoints", "lsa_extract_keypoints_more", "lsa_extract_prefetch", "lsa_extract_prefetch_adopted", "lsa_transform_frame_at", "lsa_set_keypoint_types", "lsa_download_keypoints", "lsa_keypoint_count",
     "lsa_download_debug", "lsa_nb_laser_rings", "lsa_transform_keypoints", "lsa_set_target", "lsa_set_target_from_set", "lsa_prepare_previous_targets", "lsa_prepared_targets_adopted", "lsa_target_staging", "lsa_set_target_staged", "lsa_stage_target_ahead", "lsa_drop_target_ahead", "lsa_staged_targets_adopted",
-    "lsa_target_size", "lsa_download_target", "lsa_set_target_cell_size", "lsa_set_knn_lanes", "lsa_set_fused_match", "lsa_set_knn_rounds", "lsa_match_slow_queries", "lsa_match_exhaustive_queries", "lsa_match_route_stats", "lsa_match_trace", "lsa_set_keypoints", "lsa_match", "lsa_match_types",
+    "lsa_target_size", "lsa_download_target", "lsa_set_target_cell_size", "lsa_set_knn_lanes", "lsa_set_fused_match", "lsa_set_knn_rounds", "lsa_match_slow_queries", "lsa_match_exhaustive_queries", "lsa_match_route_stats", "lsa_match_trace", "lsa_set_keypoints", "lsa_match", "lsa_match_types", "lsa_match_types_undistorted",
     "lsa_download_match", "lsa_overlap", "lsa_accumulate", "lsa_mailbox_active", "lsa_solve", "lsa_solve_device", "lsa_solve_device_fallbacks", "lsa_solve_device_trace", "lsa_registration_error", "lsa_selftest_math", "lsa_reset_working_keypoints", "lsa_undistort", "lsa_working_time_range",
     "lsa_working_bbox", "lsa_working_bboxes", "lsa_localization_begin", "lsa_arm_localization_boxes", "lsa_keypoint_bboxes_begin", "lsa_keypoint_bboxes_begin_interp", "lsa_keypoint_time_range", "lsa_keypoint_bboxes_end", "lsa_download_transformed", "lsa_stage_transformed", "lsa_staged_transformed", "lsa_transform_frame", "lsa_profile_enable", "lsa_profile_select", "lsa_profile_reset",
     "lsa_profile_get", "lsa_slam_create", "lsa_slam_destroy", "lsa_slam_last_error", "lsa_slam_set_param",
@@ -134,6 +134,7 @@ def lib():
     L.lsa_overlap.argtypes = [vp, C.c_uint, i32, vp, vp, C.c_double, C.c_double, C.c_float, vp, vp]
     L.lsa_upload_wire_frame.argtypes = [vp, vp, i32, vp, vp, i32, i32, C.c_double, i32]
     L.lsa_match_types.argtypes = [vp, i32, C.c_uint, i32, C.POINTER(MatchParams), vp, vp]
+    L.lsa_match_types_undistorted.argtypes = [vp, i32, C.c_uint, C.POINTER(MatchParams), vp, vp, vp, vp, f64, f64]
     L.lsa_download_match.argtypes = [vp, i32, vp, vp, vp, i32]
     L.lsa_accumulate.argtypes = [vp, C.c_uint, vp, i32, vp, vp, vp, vp]
     L.lsa_solve.argtypes = [vp, C.c_uint, vp, i32, i32, vp, vp, vp]
@@ -391,6 +392,14 @@ class Context:
         hist = np.zeros((3, 8), np.int32) if histograms else None
         self._check(self.L.lsa_match_types(self.h, slot, type_mask, query_set, C.byref(params), ptr(pose16(pose)),
                                            ptr(hist) if histograms else None), "lsa_match_types")
+        return hist
+
+    def match_types_undistorted(self, type_mask, params, pose, H0, H1, t0, t1, slot=TARGET_MAP):
+        """lsa_match_types_undistorted: lsa_undistort + lsa_match_types on the working set, the undistortion inside the search
+        kernel where it can be; returns [3][NSTATUS]"""
+        hist = np.zeros((3, 8), np.int32)
+        self._check(self.L.lsa_match_types_undistorted(self.h, slot, type_mask, C.byref(params), ptr(pose16(pose)), ptr(hist), ptr(pose16(H0)), ptr(pose16(H1)),
+                                                       C.c_double(t0), C.c_double(t1)), "lsa_match_types_undistorted")
         return hist
 
     def overlap(self, type_mask, ratio, leaves, H0, H1=None, t0=0.0, t1=0.0):

@@ -856,6 +856,8 @@ int SlamCore::Localization()
 
   TotalMatchedKeypoints = 0;
   lsa_match_params_t mp = LocMatchParams();
+  Pose pendingD0 = Pose::Identity(), pendingD1 = Pose::Identity();
+  bool pendingUndistort = false;
   for (unsigned icpIter = 0; icpIter < LocalizationICPMaxIter; ++icpIter)
   {
     Tick ticp;
@@ -864,7 +866,12 @@ int SlamCore::Localization()
     unsigned mask = 0;
     for (int k = 0; k < 3; ++k)
       if (UseKeypoints[k]) mask |= 1u << k;
-    LSA_TRY(lsa_match_types(Ctx, LSA_TARGET_MAP, mask, LSA_SET_WORKING, &mp, Tworld.m, nullptr));
+    // the undistortion the previous iteration ended with rides in this iteration's search kernel (same keypoints, one launch less)
+    if (pendingUndistort)
+      LSA_TRY(lsa_match_types_undistorted(Ctx, LSA_TARGET_MAP, mask, &mp, Tworld.m, nullptr, pendingD0.m, pendingD1.m, Motion.Time0, Motion.Time1));
+    else
+      LSA_TRY(lsa_match_types(Ctx, LSA_TARGET_MAP, mask, LSA_SET_WORKING, &mp, Tworld.m, nullptr));
+    pendingUndistort = false;
     for (int k = 0; k < 3; ++k)
       if ((mask >> k) & 1u) LocMatchSerial[k] = lsa_match_serial(Ctx, k);
     ArmLookaheadInterlude();
@@ -896,13 +903,22 @@ int SlamCore::Localization()
     Stats.lm_evals += summary.num_evaluations;
     Tworld = optimizer.GetOptimizedPose();
     Trelative = Inverse(PreviousTworld) * Tworld;
+    const bool lastIteration = (summary.num_successful_steps == 1) || (icpIter == LocalizationICPMaxIter - 1);
     if (Undistortion == UNDISTORTION_REFINED)
     {
-      int rc = RefineUndistortion();
-      if (rc < 0) return rc;
+      if (UndistortInSearch && !lastIteration)
+      {
+        RefineUndistortion(&pendingD0, &pendingD1);
+        pendingUndistort = true;
+      }
+      else
+      {
+        int rc = RefineUndistortion();
+        if (rc < 0) return rc;
+      }
     }
     Stats.loc_lm += tlm.Stop();
-    if ((summary.num_successful_steps == 1) || (icpIter == LocalizationICPMaxIter - 1))
+    if (lastIteration)
     {
       LSA_TRY(optimizer.EstimateRegistrationError(LocalizationUncertainty));
       break;
@@ -1378,6 +1394,7 @@ int SlamCore::GetRegisteredFrame(std::vector<lsa_point_t>& out)
   X("SubMapsAhead", SubMapsAhead, bool)                                                                \
   X("SubMapsAheadAdaptive", SubMapsAheadAdaptive, bool)                                                \
   X("LocalizationStartFused", LocalizationStartFused, bool)                                            \
+  X("UndistortInSearch", UndistortInSearch, bool)                                                      \
   X("FusedMatch", FusedMatch, bool)                                                                    \
   X("EgoMotionICPMaxIter", EgoMotionICPMaxIter, unsigned)                                              \
   X("LocalizationICPMaxIter", LocalizationICPMaxIter, unsigned)                                        \

@@ -217,6 +217,7 @@ public:
   bool SubMapsAhead = true;
   bool SubMapsAheadAdaptive = true;  // give it up for a while when the localization had to wait for it twice in a row
   bool LocalizationStartFused = true;  // reset + first undistortion + keypoint boxes of the localization as one launch (device maps)
+  bool UndistortInSearch = true;  // RefineUndistortion between two localization iterations inside the next iteration's search kernel
   bool DevSpec[3] = {false, false, false};
   bool OrderedMaps = true;
   bool DeviceMapsInUse() const { return MapsOnDevice && DevMaps[0] && LocalMaps[0]->GetSampling() != SamplingMode::CENTROID; }

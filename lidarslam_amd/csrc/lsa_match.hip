@@ -1299,7 +1299,8 @@ int lsa_match(lsa_ctx* ctx, int slot, int type, int query_set, const lsa_match_p
   return rc;
 }
 
-int lsa_match_types(lsa_ctx* ctx, int slot, unsigned type_mask, int query_set, const lsa_match_params_t* p, const double pose[16], int* histograms)
+static int match_types_impl(lsa_ctx* ctx, int slot, unsigned type_mask, int query_set, const lsa_match_params_t* p, const double pose[16], int* histograms,
+                            const InterpConst* undistort)
 {
   if (!ctx || !p || !pose || slot < 0 || slot > 1 || (type_mask & ~7u) || query_set < 0 || query_set > 2)
     return ctx ? ctx->fail(LSA_E_ARG, "lsa_match_types: bad argument") : LSA_E_ARG;
@@ -1333,7 +1334,7 @@ int lsa_match_types(lsa_ctx* ctx, int slot, unsigned type_mask, int query_set, c
     }
     if (np > 0)
     {
-      const int rc = enqueue_fused_match(ctx, preps, np, pose, ctx->stream);
+      const int rc = enqueue_fused_match(ctx, preps, np, pose, ctx->stream, undistort);
       if (rc) return rc;
     }
   }
@@ -1367,6 +1368,35 @@ int lsa_match_types(lsa_ctx* ctx, int slot, unsigned type_mask, int query_set, c
       for (int s = 0; s < LSA_MATCH_NSTATUS; ++s) histograms[types[i] * LSA_MATCH_NSTATUS + s] = hp[types[i] * 16 + s];
   }
   return LSA_OK;
+}
+
+int lsa_match_types(lsa_ctx* ctx, int slot, unsigned type_mask, int query_set, const lsa_match_params_t* p, const double pose[16], int* histograms)
+{
+  return match_types_impl(ctx, slot, type_mask, query_set, p, pose, histograms, nullptr);
+}
+
+int lsa_match_types_undistorted(lsa_ctx* ctx, int slot, unsigned type_mask, const lsa_match_params_t* p, const double pose[16], int* histograms, const double H0[16],
+                                const double H1[16], double t0, double t1)
+{
+  if (!ctx || !p || !pose || !H0 || !H1 || slot < 0 || slot > 1 || (type_mask & ~7u))
+    return ctx ? ctx->fail(LSA_E_ARG, "lsa_match_types_undistorted: bad argument") : LSA_E_ARG;
+  // one launch when the search kernel reaches every keypoint of the working set: the one-launch form, every type that has
+  // keypoints asked for, with a target and with valid parameters (a type that is not searched would keep its distortion)
+  bool reach = ctx->fused_match;
+  for (int k = 0; k < 3 && reach; ++k)
+  {
+    if (ctx->kp_n[LSA_SET_WORKING][k] <= 0) continue;
+    const int nb = k == LSA_EDGE ? p->edge_nb_neighbors : k == LSA_PLANE ? p->plane_nb_neighbors : p->blob_nb_neighbors;
+    const bool bad = k == LSA_EDGE ? (nb < 2 || p->edge_min_nb_neighbors < 2) : k == LSA_PLANE ? nb < 3 : nb < 4;
+    reach = ((type_mask >> k) & 1u) && ctx->target[slot * 3 + k].m > 0 && !bad && nb <= kKnnMax;
+  }
+  if (!reach)
+  {
+    const int rc = lsa_undistort(ctx, H0, H1, t0, t1);
+    return rc ? rc : match_types_impl(ctx, slot, type_mask, LSA_SET_WORKING, p, pose, histograms, nullptr);
+  }
+  const InterpConst ic = make_interp_const(H0, H1, t0, t1);
+  return match_types_impl(ctx, slot, type_mask, LSA_SET_WORKING, p, pose, histograms, &ic);
 }
 
 int lsa_overlap(lsa_ctx* ctx, unsigned type_mask, int interpolate, const double H0[16], const double H1[16], double t0, double t1, float sampling_ratio,

@@ -602,6 +602,8 @@ struct FusedArgs
   Rigid pose;
   FusedType t[3];
   int fuse_model;  // the search kernel fits the models of its own keypoints (no second launch)
+  int undistort;   // ... and first moves every keypoint by the motion `ic` interpolated at its own time (lsa_undistort), in place
+  InterpConst ic;
 };
 
 struct SearchShared
@@ -612,7 +614,7 @@ struct SearchShared
 };
 
 template <int KMAX, int G>
-__device__ __forceinline__ void search_type(const Rigid& pose, const FusedType& t, int block, SearchShared& sh)
+__device__ __forceinline__ void search_type(const Rigid& pose, const FusedType& t, int block, SearchShared& sh, const InterpConst* ic = nullptr)
 {
   constexpr int QB = 256 / G;
   const int tid = threadIdx.x, gl = tid % G, ql = tid / G;
@@ -628,7 +630,19 @@ __device__ __forceinline__ void search_type(const Rigid& pose, const FusedType& 
   {
     // KeypointsMatcher: worldPoint = PosePrior * basePoint in double, narrowed to float for the search
     // (KeypointsMatcher.cxx:117-118, KDTreePCLAdaptor.h:96-100)
-    const float4 q4 = t.queries[2 * (size_t)q];
+    float4 q4 = t.queries[2 * (size_t)q];
+    if (ic)
+    {
+      // Slam::RefineUndistortion's step for this keypoint (k_undistort of lsa_transform.hip, same arithmetic): the lanes
+      // of the group all work it out, the first one stores it for the model fit and everything after this match
+      const float4 b4 = t.queries[2 * (size_t)q + 1];
+      Rigid U;
+      interp_eval(*ic, __hiloint2double(__float_as_int(b4.y), __float_as_int(b4.x)), U);
+      double ux, uy, uz;
+      rigid_apply(U, (double)q4.x, (double)q4.y, (double)q4.z, ux, uy, uz);
+      q4.x = (float)ux; q4.y = (float)uy; q4.z = (float)uz;
+      if (gl == 0) const_cast<float4*>(t.queries)[2 * (size_t)q] = q4;
+    }
     double wx, wy, wz;
     rigid_apply(pose, (double)q4.x, (double)q4.y, (double)q4.z, wx, wy, wz);
     qx = (float)wx; qy = (float)wy; qz = (float)wz;
@@ -772,7 +786,7 @@ __global__ __launch_bounds__(256, 4) void k_search_all(FusedArgs a)
   {
     const int block = xcd * se + j;
     if (block >= a.t[0].nblocks) return;
-    search_type<KE, kGE>(a.pose, a.t[0], block, sh.s);
+    search_type<KE, kGE>(a.pose, a.t[0], block, sh.s, a.undistort ? &a.ic : nullptr);
     if (!a.fuse_model) return;
     __syncthreads();  // the lists of all four wavefronts are written (and the tables free)
     model_type<KE, LSA_EDGE, QB>(a.pose, a.t[0], block, sh.m);
@@ -781,7 +795,7 @@ __global__ __launch_bounds__(256, 4) void k_search_all(FusedArgs a)
   {
     const int block = xcd * sp + (j - se);
     if (block >= a.t[1].nblocks) return;
-    search_type<KP, kGP>(a.pose, a.t[1], block, sh.s);
+    search_type<KP, kGP>(a.pose, a.t[1], block, sh.s, a.undistort ? &a.ic : nullptr);
     if (!a.fuse_model) return;
     __syncthreads();
     model_type<KP, LSA_PLANE, QB>(a.pose, a.t[1], block, sh.m);
@@ -793,7 +807,7 @@ __global__ __launch_bounds__(256, 4) void k_search_all(FusedArgs a)
       const int sb = (a.t[2].nblocks + 7) / 8;
       const int block = xcd * sb + (j - se - sp);
       if (block >= a.t[2].nblocks) return;
-      search_type<KB, kGB>(a.pose, a.t[2], block, sh.s);
+      search_type<KB, kGB>(a.pose, a.t[2], block, sh.s, a.undistort ? &a.ic : nullptr);
       if (!a.fuse_model) return;
       __syncthreads();
       model_type<KB, LSA_BLOB, QB>(a.pose, a.t[2], block, sh.m);
@@ -840,7 +854,7 @@ namespace lsa
 
 // Enqueues the matches `preps` describes (at most one per keypoint type, every one with a non-empty target and at
 // least one keypoint) as two launches on `st`: the searches of all types, then their model fits.
-int enqueue_fused_match(lsa_ctx* ctx, const MatchPrep* preps, int count, const double pose[16], hipStream_t st)
+int enqueue_fused_match(lsa_ctx* ctx, const MatchPrep* preps, int count, const double pose[16], hipStream_t st, const InterpConst* undistort)
 {
   FusedArgs a;
   std::memset(&a, 0, sizeof(a));
@@ -880,6 +894,12 @@ int enqueue_fused_match(lsa_ctx* ctx, const MatchPrep* preps, int count, const d
   if (a.t[0].mblocks + a.t[1].mblocks + a.t[2].mblocks == 0) return LSA_OK;
   // the search kernel fits the models too when every type that has keypoints is searched (a type with invalid
   // parameters is not: its keypoints get their status from the model kernel)
+  if (undistort)
+  {
+    // lsa_match_types_undistorted has checked that every keypoint of the set is searched by this launch
+    a.undistort = 1;
+    a.ic = *undistort;
+  }
   a.fuse_model = ctx->fused_model ? 1 : 0;
   for (int k = 0; k < 3; ++k)
     if (a.t[k].mblocks > 0 && a.t[k].nblocks == 0) a.fuse_model = 0;

@@ -18,6 +18,9 @@ struct MatchPrep
   int* hist;                    // device, 16 ints: [8] rejection histogram, [8], [9] hand-over counters
 };
 
-int enqueue_fused_match(lsa_ctx* ctx, const MatchPrep* preps, int count, const double pose[16], hipStream_t st);
+struct InterpConst;
+// undistort: every keypoint is first moved by that motion interpolated at its own time, in place (lsa_undistort's step, folded
+// into the search kernel); only when every keypoint of the set is among `preps` and is searched
+int enqueue_fused_match(lsa_ctx* ctx, const MatchPrep* preps, int count, const double pose[16], hipStream_t st, const InterpConst* undistort = nullptr);
 
 }  // namespace lsa

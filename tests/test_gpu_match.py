@@ -19,6 +19,14 @@ def perturbed(dx=0.45, yaw=0.01, dz=0.0):
     return T
 
 
+def se3(dx, dy, dz, rx, ry, rz):
+    cx, sx, cy, sy, cz, sz = np.cos(rx), np.sin(rx), np.cos(ry), np.sin(ry), np.cos(rz), np.sin(rz)
+    T = np.eye(4)
+    T[:3, :3] = [[cy * cz, sx * sy * cz - cx * sz, cx * sy * cz + sx * sz], [cy * sz, sx * sy * sz + cx * cz, cx * sy * sz - sx * cz], [-sy, sx * cy, cx * cy]]
+    T[:3, 3] = [dx, dy, dz]
+    return T
+
+
 def assert_match_equal(ctx, O, L, k, cur, tgt, mp, pose, cell=None):
     ctx.set_keypoints(L.SET_WORKING, k, cur)
     ctx.set_target(k, tgt, cell=cell)
@@ -410,6 +418,38 @@ def test_targets_prepared_ahead_give_the_same_matches(O, L, kps):
     ctx.set_target_from_set(L.PLANE, L.SET_RAW_PREVIOUS, cell=0.25)
     assert taken() == 1 and ctx.target(L.PLANE, L.TARGET_PREVIOUS).tobytes() == first[:100].tobytes()
     ctx.close()
+
+
+def test_undistortion_inside_the_search_kernel(L, kps):
+    """lsa_match_types_undistorted against lsa_undistort + lsa_match_types: working keypoints, histograms, status, weights
+    and records bit for bit -- with the undistortion inside the search kernel (every keypoint reached), and in the cases
+    where it has to step aside (a type not asked for, a type with invalid parameters, the staged kernels)"""
+    prev, cur = kps[128]
+    H0 = se3(0.01, -0.02, 0.0, 0.001, 0.0, -0.003)
+    H1 = se3(0.32, 0.03, -0.01, -0.004, 0.002, 0.011)
+    bad = L.MatchParams.localization(saturation_distance=2.0)
+    bad.plane_nb_neighbors = 2
+    cases = [(7, L.MatchParams.localization(saturation_distance=2.0), 1), (3, L.MatchParams.localization(saturation_distance=2.0), 1),
+             (7, bad, 1), (7, L.MatchParams.localization(saturation_distance=1.0), 0), (7, L.MatchParams.localization(saturation_distance=1.0), 2)]
+    a, b = L.Context(0), L.Context(0)
+    for mask, mp, fused in cases:
+        for ctx in (a, b):
+            ctx.set_fused_match(fused)
+            for k in (L.EDGE, L.PLANE, L.BLOB):
+                ctx.set_keypoints(L.SET_WORKING, k, cur[k][:20000])
+                ctx.set_target(k, prev[k], cell=(0.75, 0.6, 0.3)[k])
+        ha = a.match_types_undistorted(mask, mp, perturbed(), H0, H1, -0.1, 0.0)
+        b.undistort(H0, H1, -0.1, 0.0)
+        hb = b.match_types(mask, L.SET_WORKING, mp, perturbed())
+        assert ha.tolist() == hb.tolist()
+        for k in (L.EDGE, L.PLANE, L.BLOB):
+            assert a.keypoints(L.SET_WORKING, k).tobytes() == b.keypoints(L.SET_WORKING, k).tobytes(), (mask, fused, k)
+            if (mask >> k) & 1:
+                sa, wa, ra = a.match_results(k, L.SET_WORKING)
+                sb, wb, rb = b.match_results(k, L.SET_WORKING)
+                assert np.array_equal(sa, sb) and np.array_equal(bits(wa), bits(wb)) and np.array_equal(bits(ra), bits(rb))
+    a.close()
+    b.close()
 
 
 @pytest.mark.parametrize("model", [16, 128])

@@ -452,6 +452,13 @@ int lsa_keypoint_bboxes_begin(lsa_ctx* ctx, int set, const double pose[16]);
  * the box the keypoints will have once they are undistorted with that motion. */
 int lsa_keypoint_bboxes_begin_interp(lsa_ctx* ctx, int set, const double H0[16], const double H1[16], double t0, double t1);
 int lsa_keypoint_bboxes_end(lsa_ctx* ctx, float mn[9], float mx[9]);
+/* The boxes of a prediction, for lsa_device_grid_submap_ahead_begin only: as lsa_keypoint_bboxes_begin(_interp when H1 is
+ * given) but enqueued on the context's look-ahead stream (where the device maps work) and never copied to the host, so that
+ * nothing of the speculation sits on the context's own stream.  _mark, called by the thread that drives the context once
+ * the set's keypoints are enqueued, names the point from which they exist; lsa_keypoint_boxes_predicted may then be
+ * called from any thread. */
+int lsa_keypoint_boxes_predicted_mark(lsa_ctx* ctx);
+int lsa_keypoint_boxes_predicted(lsa_ctx* ctx, int set, const double H0[16], const double H1[16], double t0, double t1);
 
 /* Slam::TransformPointCloud (Slam.cxx:1491-1509) on a device keypoint set:
  * writes pose * set to `out` on the host. */

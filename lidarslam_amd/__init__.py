@@ -57,7 +57,7 @@ ABI_SYMBOLS = [
     "lsa_download_debug", "lsa_nb_laser_rings", "lsa_transform_keypoints", "lsa_set_target", "lsa_set_target_from_set", "lsa_prepare_previous_targets", "lsa_prepared_targets_adopted", "lsa_target_staging", "lsa_set_target_staged", "lsa_stage_target_ahead", "lsa_drop_target_ahead", "lsa_staged_targets_adopted",
     "lsa_target_size", "lsa_download_target", "lsa_set_target_cell_size", "lsa_set_knn_lanes", "lsa_set_fused_match", "lsa_set_knn_rounds", "lsa_match_slow_queries", "lsa_match_exhaustive_queries", "lsa_match_route_stats", "lsa_match_trace", "lsa_set_keypoints", "lsa_match", "lsa_match_types", "lsa_match_types_undistorted",
     "lsa_download_match", "lsa_overlap", "lsa_accumulate", "lsa_mailbox_active", "lsa_solve", "lsa_solve_device", "lsa_solve_device_fallbacks", "lsa_solve_device_trace", "lsa_registration_error", "lsa_selftest_math", "lsa_reset_working_keypoints", "lsa_undistort", "lsa_working_time_range",
-    "lsa_working_bbox", "lsa_working_bboxes", "lsa_localization_begin", "lsa_arm_localization_boxes", "lsa_keypoint_bboxes_begin", "lsa_keypoint_bboxes_begin_interp", "lsa_keypoint_time_range", "lsa_keypoint_bboxes_end", "lsa_download_transformed", "lsa_stage_transformed", "lsa_staged_transformed", "lsa_transform_frame", "lsa_profile_enable", "lsa_profile_select", "lsa_profile_reset",
+    "lsa_working_bbox", "lsa_working_bboxes", "lsa_localization_begin", "lsa_arm_localization_boxes", "lsa_keypoint_bboxes_begin", "lsa_keypoint_bboxes_begin_interp", "lsa_keypoint_boxes_predicted_mark", "lsa_keypoint_boxes_predicted", "lsa_keypoint_time_range", "lsa_keypoint_bboxes_end", "lsa_download_transformed", "lsa_stage_transformed", "lsa_staged_transformed", "lsa_transform_frame", "lsa_profile_enable", "lsa_profile_select", "lsa_profile_reset",
     "lsa_profile_get", "lsa_slam_create", "lsa_slam_destroy", "lsa_slam_last_error", "lsa_slam_set_param",
     "lsa_slam_get_param", "lsa_slam_reset", "lsa_slam_clear_maps", "lsa_slam_add_frame", "lsa_slam_store_frame", "lsa_slam_add_stored_frame", "lsa_slam_hint_next_stored_frame", "lsa_slam_hint_next_frame", "lsa_upload_frame_begin", "lsa_upload_frame_ready", "lsa_upload_frame_adopt", "lsa_uploads_adopted", "lsa_extract_prefetch_uploaded",
     "lsa_slam_get_world_transform", "lsa_slam_get_covariance", "lsa_slam_get_keypoints", "lsa_slam_get_registered_frame",
@@ -151,6 +151,8 @@ def lib():
     L.lsa_arm_localization_boxes.argtypes = [vp]
     L.lsa_keypoint_bboxes_begin_interp.argtypes = [vp, i32, vp, vp, f64, f64]
     L.lsa_keypoint_bboxes_end.argtypes = [vp, vp, vp]
+    L.lsa_keypoint_boxes_predicted_mark.argtypes = [vp]
+    L.lsa_keypoint_boxes_predicted.argtypes = [vp, i32, vp, vp, f64, f64]
     L.lsa_working_bbox.argtypes = [vp, i32, vp, vp, vp]
     L.lsa_download_transformed.argtypes = [vp, i32, i32, vp, vp, i32]
     L.lsa_transform_frame.argtypes = [vp, i32, vp, vp, f64, f64, vp, i32]

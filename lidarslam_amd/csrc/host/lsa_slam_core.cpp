@@ -979,8 +979,8 @@ int SlamCore::BeginSubMapSpeculation(const Pose& predicted)
   {
     // Everything else is a dozen calls into the runtime: a host thread of its own
     // does it (the one that enqueues the next frame's ego-motion targets later in the frame), this one goes on to the
-    // first search.  The boxes go onto the context's stream (they only read the raw keypoints), the extractions onto the
-    // grids' stream behind the previous keyframe's insertions, the spare targets' search grids behind the extractions.
+    // first search.  The boxes and the extractions go onto the grids' (look-ahead) stream, behind the previous keyframe's
+    // insertions, the spare targets' search grids behind the extractions: nothing of it on the context's stream.
     int minPts[3];
     bool use[3];
     for (int k = 0; k < 3; ++k)
@@ -991,13 +991,17 @@ int SlamCore::BeginSubMapSpeculation(const Pose& predicted)
       DevSpec[k] = use[k];
     }
     DevSpecStatus = 0;
+    LSA_TRY(lsa_keypoint_boxes_predicted_mark(Ctx));  // the raw keypoints exist from here on the context's stream
     DevSpecCancel.store(false, std::memory_order_release);
     DevSpecRunning.store(true, std::memory_order_release);
     AheadWorker.Submit([this, interpolated, begin, end, t0, t1, use0 = use[0], use1 = use[1], use2 = use[2], m0 = minPts[0], m1 = minPts[1], m2 = minPts[2]] {
       const bool use[3] = {use0, use1, use2};
       const int minPts[3] = {m0, m1, m2};
       for (auto& w : MapWorker) w.Wait();  // the previous keyframe's insertions are on the grids' stream by now
-      int rc = interpolated ? lsa_keypoint_bboxes_begin_interp(Ctx, LSA_SET_RAW_CURRENT, begin.m, end.m, t0, t1) : lsa_keypoint_bboxes_begin(Ctx, LSA_SET_RAW_CURRENT, begin.m);
+      // the predicted boxes on the look-ahead stream, where the grids read them: nothing of this on the context's stream
+      int rc = SpecBoxesOnLookahead ? lsa_keypoint_boxes_predicted(Ctx, LSA_SET_RAW_CURRENT, begin.m, interpolated ? end.m : nullptr, t0, t1)
+                                    : (interpolated ? lsa_keypoint_bboxes_begin_interp(Ctx, LSA_SET_RAW_CURRENT, begin.m, end.m, t0, t1)
+                                                    : lsa_keypoint_bboxes_begin(Ctx, LSA_SET_RAW_CURRENT, begin.m));
       for (int k = 0; k < 3 && rc >= 0; ++k)
         if (use[k]) rc = lsa_device_grid_submap_ahead_begin(DevMaps[k], k, minPts[k], k);
       // ... and waits for the extractions' sizes (this thread has nothing else to do) to enqueue the spare targets' search
@@ -1395,6 +1399,7 @@ int SlamCore::GetRegisteredFrame(std::vector<lsa_point_t>& out)
   X("SubMapsAheadAdaptive", SubMapsAheadAdaptive, bool)                                                \
   X("LocalizationStartFused", LocalizationStartFused, bool)                                            \
   X("UndistortInSearch", UndistortInSearch, bool)                                                      \
+  X("SpecBoxesOnLookahead", SpecBoxesOnLookahead, bool)                                                \
   X("FusedMatch", FusedMatch, bool)                                                                    \
   X("EgoMotionICPMaxIter", EgoMotionICPMaxIter, unsigned)                                              \
   X("LocalizationICPMaxIter", LocalizationICPMaxIter, unsigned)                                        \

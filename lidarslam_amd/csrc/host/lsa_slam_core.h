@@ -218,6 +218,7 @@ public:
   bool SubMapsAheadAdaptive = true;  // give it up for a while when the localization had to wait for it twice in a row
   bool LocalizationStartFused = true;  // reset + first undistortion + keypoint boxes of the localization as one launch (device maps)
   bool UndistortInSearch = true;  // RefineUndistortion between two localization iterations inside the next iteration's search kernel
+  bool SpecBoxesOnLookahead = true;  // the predicted boxes of the sub-maps ahead of time on the look-ahead stream, not the context's
   bool DevSpec[3] = {false, false, false};
   bool OrderedMaps = true;
   bool DeviceMapsInUse() const { return MapsOnDevice && DevMaps[0] && LocalMaps[0]->GetSampling() != SamplingMode::CENTROID; }

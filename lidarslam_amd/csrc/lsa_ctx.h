@@ -260,6 +260,7 @@ struct lsa_ctx
   size_t scratch_cap = 0;
   unsigned long long* range_bits = nullptr;  // [0..1] time range, [16..24] and [32..40] bounding boxes (ordered bits)
   hipEvent_t ev_bbox = nullptr;
+  hipEvent_t ev_pred = nullptr;  // the keypoints the predicted boxes are taken of exist (lsa_keypoint_boxes_predicted_mark)
   // lsa_stage_transformed: pinned host buffers the device writes the transformed keypoints into directly
   lsa_point_t* stage[3] = {nullptr, nullptr, nullptr};
   int stage_cap[3] = {0, 0, 0}, stage_n[3] = {0, 0, 0};
@@ -269,6 +270,7 @@ struct lsa_ctx
   bool bbox_copied = true;   // the boxes of the last lsa_keypoint_bboxes_begin / lsa_localization_begin are on their way to the host
   bool loc_boxes = false;    // the boxes the grids read are the ones lsa_localization_begin made (words of their own)
   bool loc_armed = false;    // ... whose words are armed for the next launch
+  bool pred_on_lookahead = false;  // the boxes in the first words were enqueued on the look-ahead stream (lsa_keypoint_boxes_predicted)
   std::mutex prof_mutex;  // stats / pending / event_pool of the profiling scopes
   int bbox_n[3] = {0, 0, 0};
 

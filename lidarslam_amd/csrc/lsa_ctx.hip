@@ -404,6 +404,7 @@ int lsa_ctx_create(int device_id, lsa_ctx** out)
   for (int i = 0; i < 2; ++i) ok &= hipEventCreateWithFlags(&ctx->ev_join[i], hipEventDisableTiming) == hipSuccess;
   ok &= hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) == hipSuccess;
   ok &= hipEventCreateWithFlags(&ctx->ev_bbox, hipEventDisableTiming) == hipSuccess;
+  ok &= hipEventCreateWithFlags(&ctx->ev_pred, hipEventDisableTiming) == hipSuccess;
   ok &= hipEventCreateWithFlags(&ctx->ev_stage, hipEventDisableTiming) == hipSuccess;
   ok &= hipMalloc((void**)&ctx->ring_start, (kMaxRings + 1) * sizeof(int)) == hipSuccess;
   ok &= hipMalloc((void**)&ctx->ring_len, kMaxRings * sizeof(int)) == hipSuccess;
@@ -512,6 +513,7 @@ void lsa_ctx_destroy(lsa_ctx* ctx)
   }
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
   if (ctx->ev_bbox) (void)hipEventDestroy(ctx->ev_bbox);
+  if (ctx->ev_pred) (void)hipEventDestroy(ctx->ev_pred);
   if (ctx->ev_stage) (void)hipEventDestroy(ctx->ev_stage);
   for (int k = 0; k < 3; ++k)
     if (ctx->stage[k]) (void)hipHostFree(ctx->stage[k]);

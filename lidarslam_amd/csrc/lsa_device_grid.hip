@@ -1619,8 +1619,14 @@ int lsa_device_grid_submap_ahead_begin(lsa_device_grid* g, int box_type, int min
   if (rc) return rc;
   rc = after_submap(g);
   if (rc) return rc;
-  rc = order_after_context(g);  // the box words; the spare target's last readers
-  if (rc) return rc;
+  // The box words: enqueued on this very stream by lsa_keypoint_boxes_predicted, or on the context's by
+  // lsa_keypoint_bboxes_begin -- then this stream comes behind the context's.  (The spare target's last readers, searches of an
+  // earlier frame, have long finished: every frame ends with the host reading its last solve's result.)
+  if (!(ctx->pred_on_lookahead && g->stream == ctx->prefetch_stream))
+  {
+    rc = order_after_context(g);
+    if (rc) return rc;
+  }
   hipStream_t st = g->stream;
   // The predicted box becomes a range of outer voxels on the grid's stream, behind the last insertion (which may move the
   // grid).  The words are rewritten for the actual box later: should this kernel be so late that it reads those, or a

@@ -536,6 +536,7 @@ static int bboxes_begin(lsa_ctx* ctx, int set, const double pose[16], const doub
     nmax = std::max(nmax, sets.n[k]);
   }
   ctx->bbox_pending = true;
+  ctx->pred_on_lookahead = false;
   if (nmax <= 0) return LSA_OK;
   Rigid T;
   row_major_to_rt(pose, T.R, T.t);
@@ -555,6 +556,44 @@ int lsa_keypoint_bboxes_begin_interp(lsa_ctx* ctx, int set, const double H0[16],
   if (!H1) return ctx ? ctx->fail(LSA_E_ARG, "lsa_keypoint_bboxes_begin_interp: bad argument") : LSA_E_ARG;
   return bboxes_begin(ctx, set, H0, H1, t0, t1);
 }
+// The boxes of a PREDICTION (the sub-maps extracted ahead of time, lsa_device_grid_submap_ahead_begin): same words, same
+// kernels, but on the look-ahead stream -- where the grids that read them work -- and never copied to the host: nothing of it
+// touches the context's stream, whose next search would otherwise queue behind it.  _mark (the thread that owns the
+// context's stream, once the keypoints are enqueued) says from where on the keypoints exist; the boxes may then be
+// enqueued by any thread.
+int lsa_keypoint_boxes_predicted_mark(lsa_ctx* ctx)
+{
+  if (!ctx) return LSA_E_ARG;
+  LSA_HIP(ctx, hipSetDevice(ctx->device));
+  LSA_HIP(ctx, hipEventRecord(ctx->ev_pred, ctx->stream));
+  return LSA_OK;
+}
+int lsa_keypoint_boxes_predicted(lsa_ctx* ctx, int set, const double H0[16], const double H1[16], double t0, double t1)
+{
+  if (!ctx || !H0 || set < 0 || set > 2) return ctx ? ctx->fail(LSA_E_ARG, "lsa_keypoint_boxes_predicted: bad argument") : LSA_E_ARG;
+  LSA_HIP(ctx, hipSetDevice(ctx->device));
+  KpSets sets;
+  int nmax = 0;
+  for (int k = 0; k < 3; ++k)
+  {
+    sets.pts[k] = reinterpret_cast<const float4*>(ctx->kp[set][k]);
+    sets.n[k] = ctx->kp_n[set][k];
+    nmax = std::max(nmax, sets.n[k]);
+  }
+  if (nmax <= 0) return LSA_OK;
+  Rigid T;
+  row_major_to_rt(H0, T.R, T.t);
+  InterpConst ic{};
+  if (H1) ic = make_interp(H0, H1, t0, t1);
+  hipStream_t st = ctx->prefetch_stream;
+  LSA_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_pred, 0));
+  unsigned* bits = lsa::box_words(ctx);
+  hipLaunchKernelGGL(k_bbox_init, dim3(1), dim3(64), 0, st, bits);
+  hipLaunchKernelGGL(k_bbox3, dim3((nmax + 255) / 256, 3), dim3(256), 0, st, sets, T, H1 ? 1 : 0, ic, bits);
+  ctx->pred_on_lookahead = true;
+  return LSA_OK;
+}
+
 int lsa_keypoint_bboxes_end(lsa_ctx* ctx, float mn[9], float mx[9])
 {
   if (!ctx || !mn || !mx) return ctx ? ctx->fail(LSA_E_ARG, "lsa_keypoint_bboxes_end: bad argument") : LSA_E_ARG;

@@ -644,6 +644,9 @@ int lsa_device_grid_submap_valid(lsa_device_grid* g);
  * extracts the sub-map as usual.  The same sub-map either way. */
 int lsa_device_grid_submap_ahead_begin(lsa_device_grid* g, int box_type, int min_nb_points, int type);
 int lsa_device_grid_submap_ahead_poll(lsa_device_grid* g);
+/* ... of several maps of one context: when all their sizes have arrived, their search grids are built by one sequence of
+ * launches (1 while a size is missing, 2 when done). */
+int lsa_device_grid_submap_ahead_poll_all(lsa_device_grid* const* grids, int count);
 int lsa_device_grid_submap_ahead_wait(lsa_device_grid* g); /* blocking form of _poll, for a thread with nothing else to do */
 int lsa_device_grid_submap_ahead_take(lsa_device_grid* g, int box_type, int min_nb_points, int slot, int type, int* taken);
 /* _take in two steps (several maps: every comparison is enqueued before any is waited for): _take_begin returns 1 when a

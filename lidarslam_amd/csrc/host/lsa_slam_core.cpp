@@ -1006,10 +1006,21 @@ int SlamCore::BeginSubMapSpeculation(const Pose& predicted)
         if (use[k]) rc = lsa_device_grid_submap_ahead_begin(DevMaps[k], k, minPts[k], k);
       // ... and waits for the extractions' sizes (this thread has nothing else to do) to enqueue the spare targets' search
       // grids at once -- unless the localization gets there first and calls it off
-      for (int k = 0; k < 3 && rc >= 0; ++k)
-        while (use[k] && rc >= 0 && !DevSpecCancel.load(std::memory_order_acquire))
+      // (all the maps' grids in one sequence of launches, once the last size is there)
+      lsa_device_grid* grids[3];
+      int ng = 0;
+      for (int k = 0; k < 3; ++k)
+        if (use[k]) grids[ng++] = DevMaps[k];
+      while (SpecGridsTogether && ng > 0 && rc >= 0 && !DevSpecCancel.load(std::memory_order_acquire))
+      {
+        rc = lsa_device_grid_submap_ahead_poll_all(grids, ng);
+        if (rc != 1) break;
+        std::this_thread::yield();
+      }
+      for (int i = 0; i < ng && !SpecGridsTogether && rc >= 0; ++i)
+        while (rc >= 0 && !DevSpecCancel.load(std::memory_order_acquire))
         {
-          rc = lsa_device_grid_submap_ahead_poll(DevMaps[k]);
+          rc = lsa_device_grid_submap_ahead_poll(grids[i]);
           if (rc != 1) break;
           std::this_thread::yield();
         }
@@ -1400,6 +1411,7 @@ int SlamCore::GetRegisteredFrame(std::vector<lsa_point_t>& out)
   X("LocalizationStartFused", LocalizationStartFused, bool)                                            \
   X("UndistortInSearch", UndistortInSearch, bool)                                                      \
   X("SpecBoxesOnLookahead", SpecBoxesOnLookahead, bool)                                                \
+  X("SpecGridsTogether", SpecGridsTogether, bool)                                                      \
   X("FusedMatch", FusedMatch, bool)                                                                    \
   X("EgoMotionICPMaxIter", EgoMotionICPMaxIter, unsigned)                                              \
   X("LocalizationICPMaxIter", LocalizationICPMaxIter, unsigned)                                        \

@@ -219,6 +219,7 @@ public:
   bool LocalizationStartFused = true;  // reset + first undistortion + keypoint boxes of the localization as one launch (device maps)
   bool UndistortInSearch = true;  // RefineUndistortion between two localization iterations inside the next iteration's search kernel
   bool SpecBoxesOnLookahead = true;  // the predicted boxes of the sub-maps ahead of time on the look-ahead stream, not the context's
+  bool SpecGridsTogether = true;  // the search grids of the sub-maps extracted ahead of time built by one sequence of launches
   bool DevSpec[3] = {false, false, false};
   bool OrderedMaps = true;
   bool DeviceMapsInUse() const { return MapsOnDevice && DevMaps[0] && LocalMaps[0]->GetSampling() != SamplingMode::CENTROID; }

@@ -1680,6 +1680,56 @@ int lsa_device_grid_submap_ahead_poll(lsa_device_grid* g)
   g->ahead_phase = 2;
   return 2;
 }
+// The same for several maps of one context at once: once ALL their sizes have arrived their search grids are built by ONE
+// sequence of launches (a block row per target) instead of one sequence each.  Returns 1 while a size is missing, 2 when the
+// grids are enqueued (or nothing was pending).
+int lsa_device_grid_submap_ahead_poll_all(lsa_device_grid* const* grids, int count)
+{
+  if (!grids || count < 1 || count > 3) return LSA_E_ARG;
+  lsa_ctx* ctx = nullptr;
+  hipStream_t st = nullptr;
+  u64 v[3];
+  bool pending[3] = {false, false, false}, any = false;
+  for (int i = 0; i < count; ++i)
+  {
+    lsa_device_grid* g = grids[i];
+    if (!g) return LSA_E_ARG;
+    if (g->ahead_phase != 1) continue;
+    if (ctx && (g->ctx != ctx || g->stream != st)) return g->ctx->fail(LSA_E_ARG, "lsa_device_grid_submap_ahead_poll_all: maps of different contexts or streams");
+    ctx = g->ctx;
+    st = g->stream;
+    v[i] = __atomic_load_n(g->host_ahead, __ATOMIC_ACQUIRE);
+    if ((unsigned)(v[i] >> 32) != g->ahead_tag) return 1;
+    pending[i] = any = true;
+  }
+  if (!any) return 2;
+  LSA_HIP(ctx, hipSetDevice(ctx->device));
+  int tis[3], nt = 0;
+  for (int i = 0; i < count; ++i)
+  {
+    if (!pending[i]) continue;
+    lsa_device_grid* g = grids[i];
+    const int type = g->ahead_type;
+    Target& t = ctx->target[9 + type];
+    g->ahead_m = (int)(unsigned)(v[i] & 0xffffffffull);
+    t.m = g->ahead_m;
+    t.cell_hint = ctx->target[LSA_TARGET_MAP * 3 + type].cell_hint;
+    t.dirty = false;
+    if (t.m > 0) tis[nt++] = 9 + type;
+  }
+  if (nt > 0)
+  {
+    const int rc = build_target_grids(ctx, tis, nt, st);
+    if (rc) return rc;
+  }
+  for (int i = 0; i < count; ++i)
+  {
+    if (!pending[i]) continue;
+    LSA_HIP(ctx, hipEventRecord(ctx->ev_map_ahead[grids[i]->ahead_type], st));
+    grids[i]->ahead_phase = 2;
+  }
+  return 2;
+}
 // ... or waited for (a thread that has nothing else to do): returns once the search grid has been enqueued
 int lsa_device_grid_submap_ahead_wait(lsa_device_grid* g)
 {

@@ -327,6 +327,37 @@ __device__ __forceinline__ int lower_bound_old(const u64* __restrict__ keys, int
   }
   return lo;
 }
+// The same within [lo, hi) -- the answer is known to lie in [lo, hi].
+__device__ __forceinline__ int lower_bound_old_in(const u64* __restrict__ keys, int lo, int hi, const VKey& t, bool any, int g)
+{
+  while (lo < hi)
+  {
+    const int mid = (lo + hi) >> 1;
+    if (vless(vkey_of_old(keys[mid], any, g), t)) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+// ... and by a whole wavefront for ONE key (the same in every lane): 64 probes per round trip instead of one, three or four
+// dependent loads for a map of a million voxels instead of twenty.  Every lane returns the answer.
+__device__ __forceinline__ int lower_bound_old_wave(const u64* __restrict__ keys, int n, const VKey& t, bool any, int g)
+{
+  const int lane = threadIdx.x & 63;
+  int lo = 0, hi = n;  // the answer lies in [lo, hi]
+  while (hi - lo > 64)
+  {
+    const int step = (hi - lo + 64) / 65;  // >= 1; probes at lo + step * (lane + 1) - 1, clamped: non-decreasing along the lanes
+    const int pos = min(hi - 1, lo + step * (lane + 1) - 1);
+    const bool less = vless(vkey_of_old(keys[pos], any, g), t);
+    const int c = __popcll(__ballot(less));  // the keys ascend: the probes below the target are the first c lanes'
+    // the answer is beyond probe c - 1 and not beyond probe c
+    const int nlo = c == 0 ? lo : min(hi - 1, lo + step * c - 1) + 1;
+    const int nhi = c == 64 ? hi : min(hi - 1, lo + step * (c + 1) - 1);
+    lo = nlo; hi = nhi;
+  }
+  const int pos = lo + lane;
+  const bool less = pos < hi && vless(vkey_of_old(keys[pos], any, g), t);
+  return lo + __popcll(__ballot(less));
+}
 // does the voxel survive the move, and under which key
 __device__ __forceinline__ bool shifted_key(u64 k, const Shift& s, int g, u64& out)
 {
@@ -553,11 +584,30 @@ __device__ __forceinline__ void d_add_fold(int bx, const float4* __restrict__ ba
   const u64 key = j0 < n ? skeys[j0] : kNoKey;
   const bool head = j0 < n && key != kNoKey && (j0 == 0 || skeys[j0 - 1] != key);
   bool is_fresh = false;
+  // Where the block's 256 sorted keys lie in the old array: the places of its first and of its last valid key, found by a
+  // wavefront each (64 probes per round trip); every thread then searches between the two -- a few hundred voxels, a
+  // handful of cache lines the block shares -- instead of the whole map.
+  __shared__ int bound[2];
+  const int N = st[kStN];
+  {
+    const int wv = threadIdx.x >> 6;
+    if (wv < 2)
+    {
+      // the last valid key of the block: the keys ascend and the invalid ones (kNoKey) sort last
+      int jl = min(n, bx * 256 + 256) - 1;
+      const u64 kf = skeys[bx * 256];
+      u64 kl = skeys[jl];
+      int res = wv == 0 ? 0 : N;
+      if (wv == 0 && kf != kNoKey) res = lower_bound_old_wave(map.keys, N, vkey_of_new(kf, sft, g), sft.any, g);
+      if (wv == 1 && kl != kNoKey) res = lower_bound_old_wave(map.keys, N, vkey_of_new(kl, sft, g), sft.any, g);
+      if ((threadIdx.x & 63) == 0) bound[wv] = res;
+    }
+    __syncthreads();
+  }
   if (head)
   {
-    const int N = st[kStN];
     const VKey target = vkey_of_new(key, sft, g);
-    const int at = lower_bound_old(map.keys, N, target, sft.any, g);
+    const int at = lower_bound_old_in(map.keys, bound[0], min(N, max(bound[1], bound[0])), target, sft.any, g);
     bool exists = false;
     if (at < N)
     {

@@ -122,9 +122,9 @@ class ConcurrentReplay:
 
         # Where the rolling maps live ("MapsOnDevice", the caller's choice when given).  One sequence: on the device --
         # nothing of the map crosses the bus and the frame does not wait for host threads (measured on MI355X, VLS-128:
-        # 1 119 against 676 frames/s).  Several sequences side by side: on the host -- a process has 4 hardware queues,
+        # 1 124 against 707 frames/s).  Several sequences side by side: on the host -- a process has 4 hardware queues,
         # the maps' chains of small kernels compete for them with the ICP kernels of the other sequences (8 sequences:
-        # 1910 against 2010 frames/s), where the host cores are there (2.6 per sequence against 1.4).
+        # 1810 against 2210 frames/s), where the host cores are there (2.6 per sequence against 1.4).
         params.setdefault("MapsOnDevice", 1 if len(seeds) == 1 else 0)
         self.frames = frames
         self.lookahead = lookahead  # extract frame f + 1 beside the registration of frame f (same results)

@@ -790,6 +790,7 @@ __global__ __launch_bounds__(256, 4) void k_search_all(FusedArgs a)
     if (!a.fuse_model) return;
     __syncthreads();  // the lists of all four wavefronts are written (and the tables free)
     model_type<KE, LSA_EDGE, QB>(a.pose, a.t[0], block, sh.m);
+    if (a.t[0].trace && threadIdx.x == 0) a.t[0].trace[(size_t)blockIdx.x * 12 + 2] = wall_clock64();  // diagnostics: end of the model fits
   }
   else if (j < se + sp)
   {
@@ -799,6 +800,7 @@ __global__ __launch_bounds__(256, 4) void k_search_all(FusedArgs a)
     if (!a.fuse_model) return;
     __syncthreads();
     model_type<KP, LSA_PLANE, QB>(a.pose, a.t[1], block, sh.m);
+    if (a.t[1].trace && threadIdx.x == 0) a.t[1].trace[(size_t)blockIdx.x * 12 + 2] = wall_clock64();  // diagnostics: end of the model fits
   }
   else
   {
@@ -811,6 +813,7 @@ __global__ __launch_bounds__(256, 4) void k_search_all(FusedArgs a)
       if (!a.fuse_model) return;
       __syncthreads();
       model_type<KB, LSA_BLOB, QB>(a.pose, a.t[2], block, sh.m);
+    if (a.t[2].trace && threadIdx.x == 0) a.t[2].trace[(size_t)blockIdx.x * 12 + 2] = wall_clock64();  // diagnostics: end of the model fits
     }
   }
 }

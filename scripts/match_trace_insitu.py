@@ -65,3 +65,5 @@ is_edge = (bidx // 8) < se
 for name, m in (("edge", ok & is_edge), ("plane", ok & ~is_edge)):
     if m.any():
         print("%s blocks %d: duration mean %.1f p90 %.1f max %.1f us, last end %.1f" % (name, int(m.sum()), dur[m].mean(), np.percentile(dur[m], 90), dur[m].max(), end[m].max()))
+        md = (end - mid)[m]
+        print("   model fits behind the search: mean %.1f p50 %.1f p90 %.1f max %.1f us; search + fits max %.1f" % (md.mean(), np.median(md), np.percentile(md, 90), md.max(), (end - start)[m].max()))

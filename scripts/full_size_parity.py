@@ -2,7 +2,7 @@
 through the HIP pipeline -- replayed from the frame store with the look-ahead on, as bench.py does -- and through the
 CPU oracle; prints the largest pose difference (reference protocol: translation norm [m] and rotation angle [rad] of
 ref^-1 * cur), whether the keypoint sets were identical in every frame, and the keyframe / map sizes at the end.
-    python scripts/full_size_parity.py [frames] [model]"""
+    python scripts/full_size_parity.py [frames] [model] [seed]"""
 import json
 import sys
 import time
@@ -15,9 +15,10 @@ from oracle import oracle as O  # noqa: E402
 
 frames = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 model = int(sys.argv[2]) if len(sys.argv) > 2 else 128
+seed = int(sys.argv[3]) if len(sys.argv) > 3 else 1000
 L.bind_host_to_device(0)
 sg, so = L.Slam(0, EgoMotion=3), O.Slam(EgoMotion=3, NbThreads=16)
-scans = [L.synth_frame(model, 1000, f) for f in range(frames)]
+scans = [L.synth_frame(model, seed, f) for f in range(frames)]
 for f, (pts, _) in enumerate(scans):
     sg.store_frame(f, pts)
 worst_t = worst_r = 0.0
@@ -35,7 +36,7 @@ for f, (pts, stamp) in enumerate(scans):
         for k in (L.EDGE, L.PLANE):
             same_keypoints &= sg.keypoints(k, 2).tobytes() == so.keypoints(k, 2).tobytes()
 print(json.dumps({
-    "command": "python scripts/full_size_parity.py %d %d" % (frames, model), "model": model, "frames": frames, "points_per_frame": int(np.mean([p.size for p, _ in scans])),
+    "command": "python scripts/full_size_parity.py %d %d %d" % (frames, model, seed), "model": model, "frames": frames, "points_per_frame": int(np.mean([p.size for p, _ in scans])),
     "max_translation_diff_m": worst_t, "max_rotation_diff_rad": worst_r, "keypoint_sets_identical": bool(same_keypoints),
     "keyframes": [sg.stats()[13], so.stats()[13]], "map_sizes_gpu": [int(sg.map(k).size) for k in (L.EDGE, L.PLANE)],
     "map_sizes_oracle": [int(so.map(k).size) for k in (L.EDGE, L.PLANE)],

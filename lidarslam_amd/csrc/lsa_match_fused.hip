@@ -613,8 +613,252 @@ struct SearchShared
   int route[6];  // diagnostics: [0] second scans, [1] first block beyond shell 2, [2] candidates walked, [3] far, [4] first block = shell 0, [5] longest lane walk
 };
 
-template <int KMAX, int G>
-__device__ __forceinline__ void search_type(const Rigid& pose, const FusedType& t, int block, SearchShared& sh, const InterpConst* ic = nullptr)
+// What the searching lanes leave in LDS for the lane that finishes a keypoint's match (one-launch form): the running
+// sums of pcl::computeMeanAndCovarianceMatrix over the neighbours the model keeps, and what was decided on the way.
+constexpr int kStagePending = -2;  // no block of the grid settled the query: the finishing wavefront searches the whole target
+template <int QB, int KC>
+struct FitStage
+{
+  double acc[9][QB];     // xx xy xz yy yz zz x y z
+  float4 q4[QB];         // the keypoint in BASE coordinates (undistorted when the launch undistorts)
+  float4 cand[KC][QB];   // the neighbours' points (x, y, z, laser id), ascending (distance, index)
+  float last_d2[QB];     // squared distance of the last neighbour kept
+  int nsel[QB];          // neighbours kept
+  int pre[QB];           // status decided before the PCA (LSA_MATCH_SUCCESS: go on), or kStagePending
+  int lh[LSA_MATCH_NSTATUS];
+};
+
+// The part of KeypointsMatcher::BuildLineMatch / BuildPlaneMatch / BuildBlobMatch (KeypointsMatcher.cxx:106-346) in front of
+// the PCA, by the G lanes that searched the keypoint: the k neighbours' points gathered side by side (one lane each),
+// the neighbourhood filter -- GetPerRingLineNeighbors `:349-405` one candidate per lane, GetRansacLineNeighbors
+// `:408-480` one line hypothesis per lane -- and the running sums of the covariance, one SUM per lane, every sum over
+// the kept neighbours in ascending order as the reference adds them.  best[0 .. n): the neighbours, uniform across the
+// group; n: their number (kKnnFar: the k-th lies beyond the rejection distance).  write: this group's lanes store.
+template <int KMAX, int TYPE, int G, int QB, int KC>
+__device__ __forceinline__ void group_stage(const knn_key (&best)[KMAX], int n, const MatchConst& c, const float4* __restrict__ xyzl, int gl, int slot,
+                                            bool live, bool write, FitStage<QB, KC>& fs)
+{
+  static_assert(KMAX <= KC && KMAX <= 2 * G, "two candidates per lane at most");
+  constexpr int E = (KMAX + G - 1) / G;
+  const int nn = n > 0 ? n : 0;
+  // gather: lane gl fetches neighbours gl, gl + G
+#pragma unroll
+  for (int e = 0; e < E; ++e)
+  {
+    knn_key key = kKeyEmpty;
+#pragma unroll
+    for (int j = 0; j < G; ++j)
+      if (e * G + j < KMAX && gl == j) key = best[e * G + j];
+    const int s = e * G + gl;
+    if (live && write && s < nn && s < KMAX) fs.cand[s][slot] = xyzl[key_idx(key)];
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // the group's own lanes wrote them: same wavefront, in order
+  unsigned mask = 0;  // neighbours kept, uniform across the group
+  int pre = LSA_MATCH_SUCCESS;
+  const int gbase = (threadIdx.x & 63) - gl;  // first lane of the group in its wavefront
+  auto group_bits = [&](bool v) { return (unsigned)((__ballot(v) >> gbase) & ((1ull << G) - 1ull)); };
+  if (TYPE == LSA_EDGE)
+  {
+    if (c.single_edge_per_ring)
+    {
+      // GetPerRingLineNeighbors: drop the closest point's own ring and rings more than 4 away, keep the nearest point of
+      // every remaining ring (a candidate whose ring showed up earlier is out, whatever became of the earlier one)
+      const int closest = nn > 0 ? (int)__float_as_uint(fs.cand[0][slot].w) : 0;
+#pragma unroll
+      for (int e = 0; e < E; ++e)
+      {
+        const int t = e * G + gl;
+        bool keep = false;
+        if (t < nn && t < KMAX)
+        {
+          const int lid = (int)__float_as_uint(fs.cand[t][slot].w);
+          keep = (lid != closest) && (abs(closest - lid) <= 4);
+#pragma unroll
+          for (int s = 0; s < KMAX - 1; ++s)
+            if (s < t && (int)__float_as_uint(fs.cand[s][slot].w) == lid) keep = false;
+        }
+        mask |= group_bits(keep) << (e * G);
+      }
+    }
+    else if (nn >= 2)
+    {
+      // GetRansacLineNeighbors: the line through the closest point and candidate pi, for every pi at once
+      const float4 p1 = fs.cand[0][slot];
+      const Vec3<float> P1 = {p1.x, p1.y, p1.z};
+      auto inlier = [&](int ci, const Vec3<float>& dir) {
+        const float4 pc = fs.cand[ci][slot];
+        return vsqnorm(vcross(vsub(Vec3<float>{pc.x, pc.y, pc.z}, P1), dir)) < c.ransac_sq_inlier;
+      };
+      unsigned vote = 0;  // (inliers << 8) | (255 - pi): the maximum is the first hypothesis with the most inliers
+#pragma unroll
+      for (int e = 0; e < E; ++e)
+      {
+        const int pi = e * G + gl;
+        if (pi >= 1 && pi < nn && pi < KMAX)
+        {
+          const float4 p2 = fs.cand[pi][slot];
+          const Vec3<float> dir = normalized3(vsub(Vec3<float>{p2.x, p2.y, p2.z}, P1));
+          int cnt = 0;
+#pragma unroll
+          for (int ci = 1; ci < KMAX; ++ci)
+            if (ci < nn && (ci == pi || inlier(ci, dir))) ++cnt;
+          const unsigned v = ((unsigned)cnt << 8) | (unsigned)(255 - pi);
+          vote = v > vote ? v : vote;
+        }
+      }
+      vote = group_max<G>(vote);
+      const int bestpi = 255 - (int)(vote & 0xffu);
+      const float4 pb = fs.cand[bestpi][slot];
+      const Vec3<float> dir = normalized3(vsub(Vec3<float>{pb.x, pb.y, pb.z}, P1));
+#pragma unroll
+      for (int e = 0; e < E; ++e)
+      {
+        const int ci = e * G + gl;
+        const bool in = ci < nn && ci < KMAX && (ci == 0 || ci == bestpi || inlier(ci, dir));
+        mask |= group_bits(in) << (e * G);
+      }
+    }
+  }
+  else
+  {
+    // n == kKnnFar: the target holds >= k points but the k-th nearest is beyond MaxNeighborsDistance
+    if (n == kKnnFar) pre = LSA_MATCH_NEIGHBORS_TOO_FAR;
+    else if (n < c.k) pre = LSA_MATCH_NOT_ENOUGH_NEIGHBORS;
+    else mask = (1u << c.k) - 1u;
+  }
+  const int nsel = __popc(mask);
+  float last_d2 = 0.f;
+#pragma unroll
+  for (int s = 0; s < KMAX; ++s)
+    if ((mask >> s) & 1u) last_d2 = key_d2(best[s]);
+  if (TYPE == LSA_EDGE && nsel < c.min_neighbors) pre = LSA_MATCH_NOT_ENOUGH_NEIGHBORS;
+  if (pre == LSA_MATCH_SUCCESS && (double)last_d2 > c.max_dist2) pre = LSA_MATCH_NEIGHBORS_TOO_FAR;
+  // the nine sums, lane j < 6 the product j, lanes 6 and 7 the sums of x and y, every lane the sum of z (lane 0's is kept)
+  const int j = gl & 7;
+  const int iu = j < 3 ? 0 : (j < 5 ? 1 : (j == 5 ? 2 : j - 6));
+  const int iv = j < 3 ? j : (j < 5 ? j - 2 : (j == 5 ? 2 : 3));
+  double a = 0., az = 0.;
+  if (pre == LSA_MATCH_SUCCESS)
+  {
+#pragma unroll
+    for (int s = 0; s < KMAX; ++s)
+      if ((mask >> s) & 1u)
+      {
+        const float4 p = fs.cand[s][slot];
+        const float u = iu == 0 ? p.x : (iu == 1 ? p.y : p.z);
+        const float v = iv == 0 ? p.x : (iv == 1 ? p.y : (iv == 2 ? p.z : 1.f));
+        a += (double)(u * v);  // float product, double sum (PCL 1.10 dense branch); x * 1.f is x
+        az += (double)p.z;
+      }
+  }
+  if (live && write && gl < 8)
+  {
+    fs.acc[j][slot] = a;
+    if (gl == 0)
+    {
+      fs.acc[8][slot] = az;
+      fs.nsel[slot] = nsel;
+      fs.last_d2[slot] = last_d2;
+      fs.pre[slot] = pre;
+    }
+  }
+}
+
+// The rest of the match, one lane per keypoint: mean and covariance from the sums, pcl::eigen33 in double, the validity
+// tests, the residual record (KeypointsMatcher.cxx:149-186, 229-272, 315-345).  Returns the status.
+template <int TYPE, int QB, int KC>
+__device__ __forceinline__ int finish_model(const FitStage<QB, KC>& fs, int slot, const MatchConst& c, double* __restrict__ rec, int cap, int i)
+{
+  int st = fs.pre[slot];
+  double w = 0.;
+  if (st == LSA_MATCH_SUCCESS)
+  {
+    const float4 q4 = fs.q4[slot];
+    CovAccum<double> acc;
+    acc.a0 = fs.acc[0][slot]; acc.a1 = fs.acc[1][slot]; acc.a2 = fs.acc[2][slot]; acc.a3 = fs.acc[3][slot]; acc.a4 = fs.acc[4][slot];
+    acc.a5 = fs.acc[5][slot]; acc.a6 = fs.acc[6][slot]; acc.a7 = fs.acc[7][slot]; acc.a8 = fs.acc[8][slot];
+    Vec3<double> mean, e0, e1, e2;
+    double l0 = 0, l1 = 0, l2 = 0;
+    Sym3<double> cov;
+    acc.finish(fs.nsel[slot], mean, cov);
+    eigen33<double>(cov, e0, e1, e2, l0, l1, l2);
+    double A[9];
+    if (TYPE == LSA_EDGE)
+    {
+      const double nn[3] = {e2.x, e2.y, e2.z};
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) A[a * 3 + b] = (a == b ? 1. : 0.) - nn[a] * nn[b];
+      if (!isfinite(A[0])) st = LSA_MATCH_INVALID_NUMERICAL;
+      else
+      {
+        const double mse = l0 + l1;
+        if (mse >= c.max_model_err * c.max_model_err) st = LSA_MATCH_MSE_TOO_LARGE;
+        else w = (mse <= 1e-6) ? 1. : 1. - __builtin_sqrt(mse) / c.max_model_err;
+      }
+    }
+    else if (TYPE == LSA_PLANE)
+    {
+      if (l1 / l2 < c.planarity) st = LSA_MATCH_BAD_PCA_STRUCTURE;
+      else
+      {
+        const double nn[3] = {e0.x, e0.y, e0.z};
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+          for (int b = 0; b < 3; ++b) A[a * 3 + b] = nn[a] * nn[b];
+        if (!isfinite(A[0])) st = LSA_MATCH_INVALID_NUMERICAL;
+        else
+        {
+          const double mse = l0;
+          if (mse >= c.max_model_err * c.max_model_err) st = LSA_MATCH_MSE_TOO_LARGE;
+          else w = (mse <= 1e-6) ? 1. : 1. - __builtin_sqrt(mse) / c.max_model_err;
+        }
+      }
+    }
+    else
+    {
+      if (l0 <= 0. || l1 <= 0.) st = LSA_MATCH_BAD_PCA_STRUCTURE;
+      else
+      {
+        const double d0 = 1. / __builtin_sqrt(l0), d1 = 1. / __builtin_sqrt(l1), d2 = 1. / __builtin_sqrt(l2);
+        const double V[3][3] = {{e0.x, e1.x, e2.x}, {e0.y, e1.y, e2.y}, {e0.z, e1.z, e2.z}};
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+          for (int b = 0; b < 3; ++b) A[a * 3 + b] = ((V[a][0] * d0) * V[b][0] + (V[a][1] * d1) * V[b][1]) + (V[a][2] * d2) * V[b][2];
+        if (!isfinite(A[0]) || !isfinite(d0 * d1 * d2)) st = LSA_MATCH_INVALID_NUMERICAL;
+        else w = 1.0;
+      }
+    }
+    if (st == LSA_MATCH_SUCCESS) write_record(rec, cap, i, A, mean, (double)q4.x, (double)q4.y, (double)q4.z, w);
+  }
+  if (st != LSA_MATCH_SUCCESS) rec[(size_t)15 * cap + i] = 0.;  // Weights[i] = 0 for rejected keypoints
+  return st;
+}
+
+// the whole target for one query, by the whole wavefront: best[0 .. k) uniform across it
+template <int KMAX>
+__device__ __forceinline__ void search_whole_target(const float4* __restrict__ sorted, int npoints, float qx, float qy, float qz, int k, knn_key (&best)[KMAX])
+{
+  const int lane = threadIdx.x & 63;
+  LaneList<KMAX> L;
+  L.reset();
+  for (int c = lane; c < npoints; c += 64)
+  {
+    const float4 p = sorted[c];
+    const float dx = qx - p.x, dy = qy - p.y, dz = qz - p.z;
+    L.insert(make_key((dx * dx + dy * dy) + dz * dz, __float_as_int(p.w)));
+  }
+  merge_lists<KMAX, 64>(L, k, best);
+}
+
+// One workgroup's share of a type: 256 / G keypoints searched by G lanes each.  FUSE: the groups go on to the front
+// part of the model fit (group_stage) and the workgroup's first wavefront finishes the 256 / G matches; otherwise the
+// neighbour lists go to memory for the model kernel.
+template <int KMAX, int G, int TYPE, bool FUSE, int KC>
+__device__ __forceinline__ void search_type(const Rigid& pose, const FusedType& t, int block, SearchShared& sh, FitStage<256 / G, KC>& fs, const InterpConst* ic = nullptr)
 {
   constexpr int QB = 256 / G;
   const int tid = threadIdx.x, gl = tid % G, ql = tid / G;
@@ -634,7 +878,7 @@ __device__ __forceinline__ void search_type(const Rigid& pose, const FusedType& 
     if (ic)
     {
       // Slam::RefineUndistortion's step for this keypoint (k_undistort of lsa_transform.hip, same arithmetic): the lanes
-      // of the group all work it out, the first one stores it for the model fit and everything after this match
+      // of the group all work it out, the first one stores it for everything after this match
       const float4 b4 = t.queries[2 * (size_t)q + 1];
       Rigid U;
       interp_eval(*ic, __hiloint2double(__float_as_int(b4.y), __float_as_int(b4.x)), U);
@@ -643,6 +887,7 @@ __device__ __forceinline__ void search_type(const Rigid& pose, const FusedType& 
       q4.x = (float)ux; q4.y = (float)uy; q4.z = (float)uz;
       if (gl == 0) const_cast<float4*>(t.queries)[2 * (size_t)q] = q4;
     }
+    if constexpr (FUSE) { if (gl == 0) fs.q4[ql] = q4; }
     double wx, wy, wz;
     rigid_apply(pose, (double)q4.x, (double)q4.y, (double)q4.z, wx, wy, wz);
     qx = (float)wx; qy = (float)wy; qz = (float)wz;
@@ -654,31 +899,74 @@ __device__ __forceinline__ void search_type(const Rigid& pose, const FusedType& 
   const unsigned long long tick0 = t.trace ? wall_clock64() : 0ull;
   const RowTable tb = {sh.b, sh.e, sh.p};
   const int outcome = group_search<KMAX, G>(t.desc, t.gp, qx, qy, qz, t.k, t.far_d2, active, gl, tid, tb, sh.save, best, ub, t.route_stats ? sh.route : nullptr);
-  if (gl == 0 && active)
+  int cnt = 0;
+#pragma unroll
+  for (int s = 0; s < KMAX; ++s)
+    if (s < t.k && best[s] != kKeyEmpty) ++cnt;
+  const unsigned long long tick1 = t.trace ? wall_clock64() : 0ull;
+  if constexpr (FUSE)
   {
-    int cnt = 0;
+    // kStagePending: no block of the grid settles it -- the finishing wavefront searches the whole target for it
+    const bool tail = active && outcome == kOutTail;
+    if (tail && gl == 0) fs.pre[ql] = kStagePending;
+    group_stage<KMAX, TYPE, G, QB, KC>(best, outcome == kOutFar ? kKnnFar : cnt, t.mc, t.xyzl, gl, ql, active && !tail, true, fs);
+    __syncthreads();  // the workgroup's QB keypoints are staged (and the tables free)
+    if (tid >= 64) return;
+    // the first wavefront finishes them, one lane each
+    const int lane = tid;
+    if (lane < LSA_MATCH_NSTATUS) fs.lh[lane] = 0;
+    const int i = block * QB + lane;
+    const bool have = lane < QB && i < t.nq;
+    unsigned long long pending = __ballot(have && fs.pre[lane < QB ? lane : 0] == kStagePending);
+    while (pending)
+    {
+      const int src = __ffsll((long long)pending) - 1;
+      pending &= pending - 1;
+      const float4 b4 = fs.q4[src];
+      double wx, wy, wz;
+      rigid_apply(pose, (double)b4.x, (double)b4.y, (double)b4.z, wx, wy, wz);
+      search_whole_target<KMAX>(t.gp.sorted[0], t.npoints, (float)wx, (float)wy, (float)wz, t.k, best);
+      int c2 = 0;
+#pragma unroll
+      for (int s = 0; s < KMAX; ++s)
+        if (s < t.k && best[s] != kKeyEmpty) ++c2;
+      // every group of the wavefront holds the same lists: all take part, the first one stores
+      group_stage<KMAX, TYPE, G, QB, KC>(best, c2, t.mc, t.xyzl, gl, src, true, lane < G, fs);
+      if (lane == 0) atomicAdd(t.hist + LSA_MATCH_NSTATUS, 1);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    if (have)
+    {
+      const int st = finish_model<TYPE, QB, KC>(fs, lane, t.mc, t.rec, t.cap, i);
+      t.status[i] = (uint8_t)st;
+      atomicAdd(&fs.lh[st], 1);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // one wavefront: its LDS atomics are done, in order
+    if (lane < LSA_MATCH_NSTATUS && fs.lh[lane]) atomicAdd(&t.hist[lane], fs.lh[lane]);
+  }
+  if (!FUSE && gl == 0 && active)
+  {
 #pragma unroll
     for (int s = 0; s < KMAX; ++s)
       if (s < t.k)
       {
         t.knn_idx[(size_t)s * t.cap + q] = key_idx(best[s]);
         t.knn_d2[(size_t)s * t.cap + q] = key_d2(best[s]);
-        if (best[s] != kKeyEmpty) ++cnt;
       }
     // kPending: no block of the grid settles it -- the model kernel's wavefront searches the whole target for it
     t.knn_cnt[q] = outcome == kOutTail ? kPending : (outcome == kOutFar ? kKnnFar : cnt);
   }
   if (t.route_stats)
   {
-    __syncthreads();
+    if (!FUSE) __syncthreads();  // (FUSE: only the first wavefront is left, behind the workgroup's barrier)
     if (t.trace && tid == 0)
     {
-      const unsigned long long tick1 = wall_clock64();
+      const unsigned long long tick2 = wall_clock64();
       unsigned xcc = 0, hwid = 0;
       asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
       asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
       unsigned long long* tr = t.trace + (size_t)blockIdx.x * 12;
-      tr[0] = tick0; tr[1] = tick1; tr[2] = tick1; tr[3] = ((unsigned long long)xcc << 32) | hwid;
+      tr[0] = tick0; tr[1] = tick1; tr[2] = tick2; tr[3] = ((unsigned long long)xcc << 32) | hwid;
       for (int i = 0; i < 6; ++i) tr[4 + i] = (unsigned long long)sh.route[i];
     }
     if (tid < 6 && sh.route[tid])
@@ -692,9 +980,10 @@ __device__ __forceinline__ void search_type(const Rigid& pose, const FusedType& 
 // lanes per query
 constexpr int kGE = 8, kGP = 8, kGB = 8;
 
-// The model fits of one ICP iteration, one thread per keypoint, all types in one launch.  What the search could not
-// settle inside the grid's blocks (kPending) is searched here first: the wavefront of such a keypoint walks the whole
-// target for it, every lane keeping the k best of its share, one merge at the end.
+// The model fits of one ICP iteration as a launch of their own (two-launch form), one thread per keypoint, all types in
+// one launch.  What the search could not settle inside the grid's blocks (kPending) is searched here first: the
+// wavefront of such a keypoint walks the whole target for it, every lane keeping the k best of its share, one merge at
+// the end.
 template <int KE, int QPB>
 struct ModelShared
 {
@@ -723,18 +1012,8 @@ __device__ __forceinline__ void model_type(const Rigid& pose, const FusedType& t
     const float4 q4 = t.queries[2 * (size_t)qi];
     double wx, wy, wz;
     rigid_apply(pose, (double)q4.x, (double)q4.y, (double)q4.z, wx, wy, wz);
-    const float qx = (float)wx, qy = (float)wy, qz = (float)wz;
-    LaneList<KMAX> L;
-    L.reset();
-    const float4* __restrict__ sorted = t.gp.sorted[0];
-    for (int c = lane; c < t.npoints; c += 64)
-    {
-      const float4 p = sorted[c];
-      const float dx = qx - p.x, dy = qy - p.y, dz = qz - p.z;
-      L.insert(make_key((dx * dx + dy * dy) + dz * dz, __float_as_int(p.w)));
-    }
     knn_key best[KMAX];
-    merge_lists<KMAX, 64>(L, t.k, best);
+    search_whole_target<KMAX>(t.gp.sorted[0], t.npoints, (float)wx, (float)wy, (float)wz, t.k, best);
     if (lane == src)
     {
       int cnt = 0;
@@ -762,21 +1041,18 @@ __device__ __forceinline__ void model_type(const Rigid& pose, const FusedType& t
   if (tid < LSA_MATCH_NSTATUS && sh.lh[tid]) atomicAdd(&t.hist[tid], sh.lh[tid]);
 }
 
-// The searches of one ICP iteration, all keypoint types in one launch -- and, when a.fuse_model, the model fits of the
-// same keypoints behind them: the first wavefront of a workgroup fits the 32 keypoints its four wavefronts have just
-// searched (their lists come back from the L2 they were written to a moment ago, their neighbours' points are the ones
-// the search has just read), while the other workgroups of the CU go on searching.  No second launch, no kernel
-// boundary with its cold caches, and the slowest search of the launch no longer holds up every model fit.
-template <int KE, int KP, int KB>
+// The searches of one ICP iteration, all keypoint types in one launch -- and, when FUSE, the model fits of the same
+// keypoints: the lanes that searched a keypoint gather its neighbours, filter them and sum up their covariance
+// (group_stage: nothing of it leaves the chip), the workgroup's first wavefront does the eigen-decompositions and writes
+// the records (finish_model).  No second launch, no neighbour lists in memory.
+template <int KE, int KP, int KB, bool FUSE>
 __global__ __launch_bounds__(256, 4) void k_search_all(FusedArgs a)
 {
   constexpr int QB = 256 / kGE;
+  constexpr int KC = FUSE ? (KE > KP ? (KE > KB ? KE : KB) : (KP > KB ? KP : KB)) : 1;
   static_assert(kGE == kGP && kGP == kGB, "one workgroup serves 256 / G keypoints of any type");
-  __shared__ union
-  {
-    SearchShared s;
-    ModelShared<(KE > KB ? KE : KB), QB> m;  // after the workgroup's searches: the tables are dead
-  } sh;
+  __shared__ SearchShared sh;
+  __shared__ FitStage<QB, KC> fs;
   // Hardware blocks b, b + 8, ... share an XCD (and its L2).  Every XCD gets one contiguous eighth of EVERY type's
   // blocks -- neighbouring keypoints (scan order) search a compact region of the target through one L2 -- and the
   // types with the longest searches (edges: no early out, larger k) first.
@@ -786,21 +1062,13 @@ __global__ __launch_bounds__(256, 4) void k_search_all(FusedArgs a)
   {
     const int block = xcd * se + j;
     if (block >= a.t[0].nblocks) return;
-    search_type<KE, kGE>(a.pose, a.t[0], block, sh.s, a.undistort ? &a.ic : nullptr);
-    if (!a.fuse_model) return;
-    __syncthreads();  // the lists of all four wavefronts are written (and the tables free)
-    model_type<KE, LSA_EDGE, QB>(a.pose, a.t[0], block, sh.m);
-    if (a.t[0].trace && threadIdx.x == 0) a.t[0].trace[(size_t)blockIdx.x * 12 + 2] = wall_clock64();  // diagnostics: end of the model fits
+    search_type<KE, kGE, LSA_EDGE, FUSE, KC>(a.pose, a.t[0], block, sh, fs, a.undistort ? &a.ic : nullptr);
   }
   else if (j < se + sp)
   {
     const int block = xcd * sp + (j - se);
     if (block >= a.t[1].nblocks) return;
-    search_type<KP, kGP>(a.pose, a.t[1], block, sh.s, a.undistort ? &a.ic : nullptr);
-    if (!a.fuse_model) return;
-    __syncthreads();
-    model_type<KP, LSA_PLANE, QB>(a.pose, a.t[1], block, sh.m);
-    if (a.t[1].trace && threadIdx.x == 0) a.t[1].trace[(size_t)blockIdx.x * 12 + 2] = wall_clock64();  // diagnostics: end of the model fits
+    search_type<KP, kGP, LSA_PLANE, FUSE, KC>(a.pose, a.t[1], block, sh, fs, a.undistort ? &a.ic : nullptr);
   }
   else
   {
@@ -809,11 +1077,7 @@ __global__ __launch_bounds__(256, 4) void k_search_all(FusedArgs a)
       const int sb = (a.t[2].nblocks + 7) / 8;
       const int block = xcd * sb + (j - se - sp);
       if (block >= a.t[2].nblocks) return;
-      search_type<KB, kGB>(a.pose, a.t[2], block, sh.s, a.undistort ? &a.ic : nullptr);
-      if (!a.fuse_model) return;
-      __syncthreads();
-      model_type<KB, LSA_BLOB, QB>(a.pose, a.t[2], block, sh.m);
-    if (a.t[2].trace && threadIdx.x == 0) a.t[2].trace[(size_t)blockIdx.x * 12 + 2] = wall_clock64();  // diagnostics: end of the model fits
+      search_type<KB, kGB, LSA_BLOB, FUSE, KC>(a.pose, a.t[2], block, sh, fs, a.undistort ? &a.ic : nullptr);
     }
   }
 }
@@ -838,13 +1102,13 @@ void launch_fused(lsa_ctx* ctx, const FusedArgs& a, double search_bytes, double 
   {
     // one launch: every workgroup fits the models of the keypoints it has searched
     ProfScope ps(ctx, "match_search_model", search_bytes + model_bytes, st);
-    hipLaunchKernelGGL((k_search_all<KE, KP, KB>), dim3(grid), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((k_search_all<KE, KP, KB, true>), dim3(grid), dim3(256), 0, st, a);
     return;
   }
   if (grid > 0)
   {
     ProfScope ps(ctx, "match_search", search_bytes, st);
-    hipLaunchKernelGGL((k_search_all<KE, KP, KB>), dim3(grid), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((k_search_all<KE, KP, KB, false>), dim3(grid), dim3(256), 0, st, a);
   }
   ProfScope ps(ctx, "match_model", model_bytes, st);
   hipLaunchKernelGGL((k_model_all<KE, KP, KB>), dim3(a.t[0].mblocks + a.t[1].mblocks + a.t[2].mblocks), dim3(kModelBlock), 0, st, a);
@@ -889,10 +1153,11 @@ int enqueue_fused_match(lsa_ctx* ctx, const MatchPrep* preps, int count, const d
     // a type whose parameters are invalid is not searched (BAD_MODEL_PARAMETRIZATION for every keypoint)
     t.nblocks = p.mc.bad_param ? 0 : (int)(((size_t)p.nq * lanes[p.type] + 255) / 256);
     t.mblocks = (p.nq + kModelBlock - 1) / kModelBlock;
-    // algorithmic bytes (B_icp = K (32 + 32 k + 136)): keypoint in, k candidate points examined at
-    // least, k (index, distance) pairs out | keypoint and neighbour lists in, k gathered target points, record out
-    search_bytes += (double)p.nq * (32 + p.mc.k * 16 + p.mc.k * 8);
-    model_bytes += (double)p.nq * (32 + p.mc.k * 8 + p.mc.k * 16 + 136);
+    // algorithmic bytes (B_icp = K (32 + 32 k + 136)): keypoint in, k gathered target points (32 B each in
+    // the reference's layout), residual record + status out -- counted ONCE per keypoint for the one-launch form.  The
+    // two-launch form splits the same total: the search takes the keypoint and the k points, the model fit the record.
+    search_bytes += (double)p.nq * (32 + p.mc.k * 32);
+    model_bytes += (double)p.nq * 136;
   }
   if (a.t[0].mblocks + a.t[1].mblocks + a.t[2].mblocks == 0) return LSA_OK;
   // the search kernel fits the models too when every type that has keypoints is searched (a type with invalid

@@ -31,6 +31,7 @@ extern "C" {
 #define LSA_E_ARG (-3)
 #define LSA_E_STATE (-4)
 #define LSA_E_CAPACITY (-5)
+#define LSA_E_GATE (-6) /* an ICP iteration enqueued ahead did not run: its gate gave up waiting for the host (lsa_icp_gate) */
 
 /* Keypoint types -- slam_lib/include/LidarSlam/Enums.h:30-36 */
 #define LSA_EDGE 0
@@ -196,6 +197,14 @@ int lsa_extract_keypoints_more(lsa_ctx* ctx, const lsa_extract_params_t* params,
 int lsa_upload_frame_begin(lsa_ctx* ctx, const lsa_point_t* pts, int n);
 int lsa_upload_frame_ready(const lsa_ctx* ctx);
 int lsa_upload_frame_adopt(lsa_ctx* ctx, const lsa_point_t* pts, int n);
+/* Gives up every cloud announced with lsa_upload_frame_begin and not adopted yet (Slam::Reset: nothing announced before a
+ * reset is taken over after it).  A cloud whose buffer was rewritten since it was announced is never adopted either: a
+ * sample of its contents is compared (lsa_upload_frame_adopt then returns 0 and the caller uploads). */
+int lsa_upload_frame_forget(lsa_ctx* ctx);
+/* Frees the buffers the context has outgrown since the last call.  Growth never frees on the spot: hipFree waits for the
+ * whole device, also for an ICP iteration that waits on the device for this very process (lsa_icp_gate).  Call it where
+ * nothing of the context waits on the device for the host -- the pipeline does at the start of every AddFrame. */
+int lsa_collect_garbage(lsa_ctx* ctx);
 int lsa_uploads_adopted(const lsa_ctx* ctx);
 int lsa_extract_prefetch_uploaded(lsa_ctx* ctx, const lsa_extract_params_t* params);
 /* Look-ahead for replay from the frame store: extracts the keypoints of the frame in `slot` on a stream of its own,
@@ -398,9 +407,40 @@ typedef struct lsa_solve_result
 } lsa_solve_result_t;
 int lsa_solve_device(lsa_ctx* ctx, unsigned type_mask, const double prior[6], int two_d_mode, int lm_max_iter, int min_matches,
                      lsa_solve_result_t* out);
+/* lsa_solve_device in two halves: _begin enqueues the solve (prior == NULL: the start point is the one the gate in
+ * front of it will hand over, see lsa_icp_gate), _end waits for the result of the oldest solve begun and not ended.
+ * _drop forgets the solve begun last without waiting (its gate was called off: it will never run). */
+int lsa_solve_device_begin(lsa_ctx* ctx, unsigned type_mask, const double prior[6], int two_d_mode, int lm_max_iter, int min_matches);
+int lsa_solve_device_end(lsa_ctx* ctx, lsa_solve_result_t* out);
+int lsa_solve_device_drop(lsa_ctx* ctx);
+
+/* ICP iterations enqueued AHEAD of their inputs (the `for icpIter` loops of Slam::ComputeEgoMotion / Localization,
+ * slam_lib/src/Slam.cxx:892-950, 1071-1145: iteration i + 1 needs the pose iteration i ends with).
+ *   ticket = lsa_icp_gate(ctx)              a gate on the context's stream; the launches enqueued next with
+ *   lsa_match_types_gated(...)              gated inputs -- this match and lsa_solve_device_begin(prior = NULL) -- wait
+ *   lsa_solve_device_begin(ctx, .., NULL)   behind it ON THE DEVICE
+ *   lsa_icp_post(ctx, ticket, pose, prior, H0, H1, t0, t1)   hands over the pose to search under, the optimiser's start
+ *                                           point and (H0 / H1 not NULL) the undistortion the match starts with: they run
+ *   lsa_icp_cancel(ctx, ticket)             or calls them off: they do nothing, nobody waits for them
+ * so that the kernel-launch path is not between the end of a solve and the next search.  A gate waits 50 ms at most; after
+ * that the launches behind it do nothing and lsa_solve_device_end reports LSA_E_GATE.  At most 8 gates in flight.
+ * lsa_icp_abandon calls off every gate still waiting and forgets the solves begun behind them (error paths, Reset).
+ * lsa_match_types_gated returns 1 (and enqueues nothing) when this match cannot wait behind a gate: the two-launch or
+ * staged forms, an empty target, an undistortion that would not reach every keypoint. */
+int lsa_icp_gate(lsa_ctx* ctx);
+int lsa_icp_post(lsa_ctx* ctx, int ticket, const double pose[16], const double prior[6], const double H0[16], const double H1[16], double t0, double t1);
+int lsa_icp_cancel(lsa_ctx* ctx, int ticket);
+int lsa_icp_abandon(lsa_ctx* ctx);
+int lsa_match_types_gated(lsa_ctx* ctx, int slot, unsigned type_mask, int query_set, const lsa_match_params_t* p, int undistort);
+
 /* Diagnostics (LSA_ROUTE_STATS=1): 100 MHz ticks block 0 spent evaluating, exchanging, folding, stepping, summed over
  * the solves so far; [4] evaluations, [5] ticks inside the kernel, [6] solves. */
 int lsa_solve_device_trace(lsa_ctx* ctx, unsigned long long out[12]);
+/* Test hooks for the two bounded waits on the device, so that the callers' fall-backs can be exercised:
+ *   "gate_give_up_every" n   every n-th gate (lsa_icp_gate) gives up at once, as if the host had not answered in 50 ms
+ *   "lm_give_up_block" b     workgroup b of the NEXT one-launch solve abandons the exchange (the others then wait their
+ *                            20 ms and give up too: lsa_solve_device reports LSA_E_STATE); one shot, -1 = none */
+int lsa_debug_set(lsa_ctx* ctx, const char* name, int value);
 /* Solves the device gave up on so far (diagnostics; 0 on a healthy run). */
 int lsa_solve_device_fallbacks(const lsa_ctx* ctx);
 /* Host work for the time the next solve runs on the device: `fn(arg)` is called once, on the calling thread, by the

@@ -56,10 +56,10 @@ ABI_SYMBOLS = [
     "lsa_set_azimuthal_resolution", "lsa_extract_keypoints", "lsa_extract_keypoints_more", "lsa_extract_prefetch", "lsa_extract_prefetch_adopted", "lsa_transform_frame_at", "lsa_set_keypoint_types", "lsa_download_keypoints", "lsa_keypoint_count",
     "lsa_download_debug", "lsa_nb_laser_rings", "lsa_transform_keypoints", "lsa_set_target", "lsa_set_target_from_set", "lsa_prepare_previous_targets", "lsa_prepared_targets_adopted", "lsa_target_staging", "lsa_set_target_staged", "lsa_stage_target_ahead", "lsa_drop_target_ahead", "lsa_staged_targets_adopted",
     "lsa_target_size", "lsa_download_target", "lsa_set_target_cell_size", "lsa_set_knn_lanes", "lsa_set_fused_match", "lsa_set_knn_rounds", "lsa_match_slow_queries", "lsa_match_exhaustive_queries", "lsa_match_route_stats", "lsa_match_trace", "lsa_set_keypoints", "lsa_match", "lsa_match_types", "lsa_match_types_undistorted",
-    "lsa_download_match", "lsa_overlap", "lsa_accumulate", "lsa_mailbox_active", "lsa_solve", "lsa_solve_device", "lsa_solve_device_fallbacks", "lsa_solve_device_trace", "lsa_registration_error", "lsa_selftest_math", "lsa_reset_working_keypoints", "lsa_undistort", "lsa_working_time_range",
+    "lsa_download_match", "lsa_overlap", "lsa_accumulate", "lsa_mailbox_active", "lsa_solve", "lsa_solve_device", "lsa_solve_device_fallbacks", "lsa_solve_device_begin", "lsa_solve_device_end", "lsa_solve_device_drop", "lsa_icp_gate", "lsa_icp_post", "lsa_icp_cancel", "lsa_icp_abandon", "lsa_debug_set", "lsa_match_types_gated", "lsa_solve_device_trace", "lsa_registration_error", "lsa_selftest_math", "lsa_reset_working_keypoints", "lsa_undistort", "lsa_working_time_range",
     "lsa_working_bbox", "lsa_working_bboxes", "lsa_localization_begin", "lsa_arm_localization_boxes", "lsa_keypoint_bboxes_begin", "lsa_keypoint_bboxes_begin_interp", "lsa_keypoint_boxes_predicted_mark", "lsa_keypoint_boxes_predicted", "lsa_keypoint_time_range", "lsa_keypoint_bboxes_end", "lsa_download_transformed", "lsa_stage_transformed", "lsa_staged_transformed", "lsa_transform_frame", "lsa_profile_enable", "lsa_profile_select", "lsa_profile_reset",
     "lsa_profile_get", "lsa_slam_create", "lsa_slam_destroy", "lsa_slam_last_error", "lsa_slam_set_param",
-    "lsa_slam_get_param", "lsa_slam_reset", "lsa_slam_clear_maps", "lsa_slam_add_frame", "lsa_slam_store_frame", "lsa_slam_add_stored_frame", "lsa_slam_hint_next_stored_frame", "lsa_slam_hint_next_frame", "lsa_upload_frame_begin", "lsa_upload_frame_ready", "lsa_upload_frame_adopt", "lsa_uploads_adopted", "lsa_extract_prefetch_uploaded",
+    "lsa_slam_get_param", "lsa_slam_reset", "lsa_slam_clear_maps", "lsa_slam_add_frame", "lsa_slam_store_frame", "lsa_slam_add_stored_frame", "lsa_slam_hint_next_stored_frame", "lsa_slam_hint_next_frame", "lsa_upload_frame_begin", "lsa_upload_frame_ready", "lsa_upload_frame_adopt", "lsa_upload_frame_forget", "lsa_collect_garbage", "lsa_uploads_adopted", "lsa_extract_prefetch_uploaded",
     "lsa_slam_get_world_transform", "lsa_slam_get_covariance", "lsa_slam_get_keypoints", "lsa_slam_get_registered_frame",
     "lsa_slam_get_match_status", "lsa_slam_get_stats", "lsa_slam_context", "lsa_slam_get_latency_compensated_world_transform",
     "lsa_slam_set_world_transform_from_guess", "lsa_slam_get_trajectory", "lsa_slam_get_debug_information", "lsa_slam_get_map",
@@ -464,6 +464,49 @@ class Context:
         w = np.ascontiguousarray(prior6, np.float64)
         self._check(self.L.lsa_solve_device(self.h, type_mask, ptr(w), int(two_d), max_iter, min_matches, C.byref(r)), "lsa_solve_device")
         return r
+
+    def solve_device_begin(self, type_mask, prior6=None, max_iter=15, two_d=False, min_matches=0):
+        """lsa_solve_device_begin; prior6 None: the start point comes from the gate enqueued last (icp_gate)"""
+        w = None if prior6 is None else np.ascontiguousarray(prior6, np.float64)
+        self.L.lsa_solve_device_begin.argtypes = [C.c_void_p, C.c_uint, C.c_void_p, C.c_int, C.c_int, C.c_int]
+        self._check(self.L.lsa_solve_device_begin(self.h, type_mask, None if w is None else ptr(w), int(two_d), max_iter, min_matches), "lsa_solve_device_begin")
+
+    def solve_device_end(self):
+        """lsa_solve_device_end -> SolveResult, or the negative code (LSA_E_GATE ...) when there is none"""
+        r = SolveResult()
+        self.L.lsa_solve_device_end.argtypes = [C.c_void_p, C.c_void_p]
+        rc = self.L.lsa_solve_device_end(self.h, C.byref(r))
+        return r if rc == 0 else rc
+
+    def solve_device_drop(self):
+        self.L.lsa_solve_device_drop.argtypes = [C.c_void_p]
+        self._check(self.L.lsa_solve_device_drop(self.h), "lsa_solve_device_drop")
+
+    def icp_gate(self):
+        self.L.lsa_icp_gate.argtypes = [C.c_void_p]
+        return self._check(self.L.lsa_icp_gate(self.h), "lsa_icp_gate")
+
+    def icp_post(self, ticket, pose, prior6, H0=None, H1=None, t0=0.0, t1=0.0):
+        w = np.ascontiguousarray(prior6, np.float64)
+        self.L.lsa_icp_post.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double]
+        self._check(self.L.lsa_icp_post(self.h, ticket, ptr(pose16(pose)), ptr(w), None if H0 is None else ptr(pose16(H0)), None if H1 is None else ptr(pose16(H1)), t0, t1), "lsa_icp_post")
+
+    def icp_cancel(self, ticket):
+        self.L.lsa_icp_cancel.argtypes = [C.c_void_p, C.c_int]
+        self._check(self.L.lsa_icp_cancel(self.h, ticket), "lsa_icp_cancel")
+
+    def icp_abandon(self):
+        self.L.lsa_icp_abandon.argtypes = [C.c_void_p]
+        self._check(self.L.lsa_icp_abandon(self.h), "lsa_icp_abandon")
+
+    def match_types_gated(self, type_mask, query_set, params, undistort=False, slot=TARGET_MAP):
+        """lsa_match_types_gated: 0 enqueued behind the gate, 1 this match cannot wait behind a gate"""
+        self.L.lsa_match_types_gated.argtypes = [C.c_void_p, C.c_int, C.c_uint, C.c_int, C.c_void_p, C.c_int]
+        return self._check(self.L.lsa_match_types_gated(self.h, slot, type_mask, query_set, C.byref(params), int(undistort)), "lsa_match_types_gated")
+
+    def debug_set(self, name, value):
+        self.L.lsa_debug_set.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+        self._check(self.L.lsa_debug_set(self.h, name.encode(), int(value)), "lsa_debug_set")
 
     def solve_device_trace(self):
         out = np.zeros(12, np.uint64)

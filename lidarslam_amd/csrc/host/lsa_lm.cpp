@@ -107,6 +107,26 @@ void SymEigen(int n, const double* Ain, double* evals, double* evecs)
 
 }  // namespace
 
+void LocalOptimizer::TakeResult(const lsa_solve_result_t& r, SolveSummary& sum)
+{
+  sum = SolveSummary();
+  sum.num_successful_steps = r.num_successful_steps;
+  sum.num_unsuccessful_steps = r.num_unsuccessful_steps;
+  sum.num_iterations = r.num_iterations;
+  sum.num_evaluations = r.num_evaluations;
+  sum.initial_cost = r.initial_cost;
+  sum.final_cost = r.final_cost;
+  sum.num_matches = r.num_matches;
+  sum.skipped = r.skipped != 0;
+  sum.message = r.message;
+  if (!sum.skipped)
+  {
+    std::memcpy(PoseArray, r.pose, sizeof(PoseArray));
+    std::memcpy(FinalH, r.H, sizeof(FinalH));
+    HaveFinal = true;
+  }
+}
+
 int LocalOptimizer::Solve(SolveSummary& sum)
 {
   HaveFinal = false;
@@ -116,27 +136,35 @@ int LocalOptimizer::Solve(SolveSummary& sum)
     const int rc = lsa_solve_device(Ctx, TypeMask, PoseArray, TwoDMode ? 1 : 0, static_cast<int>(LMMaxIter), static_cast<int>(MinMatches), &r);
     if (rc == LSA_OK)
     {
-      sum = SolveSummary();
-      sum.num_successful_steps = r.num_successful_steps;
-      sum.num_unsuccessful_steps = r.num_unsuccessful_steps;
-      sum.num_iterations = r.num_iterations;
-      sum.num_evaluations = r.num_evaluations;
-      sum.initial_cost = r.initial_cost;
-      sum.final_cost = r.final_cost;
-      sum.num_matches = r.num_matches;
-      sum.skipped = r.skipped != 0;
-      sum.message = r.message;
-      if (!sum.skipped)
-      {
-        std::memcpy(PoseArray, r.pose, sizeof(PoseArray));
-        std::memcpy(FinalH, r.H, sizeof(FinalH));
-        HaveFinal = true;
-      }
+      TakeResult(r, sum);
       return LSA_OK;
     }
     if (rc != LSA_E_STATE) return rc;  // LSA_E_STATE: the device gave up, nothing was changed
   }
   return SolveOnHost(sum);
+}
+
+int LocalOptimizer::Begin(bool gated)
+{
+  HaveFinal = false;
+  return lsa_solve_device_begin(Ctx, TypeMask, gated ? nullptr : PoseArray, TwoDMode ? 1 : 0, static_cast<int>(LMMaxIter), static_cast<int>(MinMatches));
+}
+
+int LocalOptimizer::End(SolveSummary& sum)
+{
+  HaveFinal = false;
+  lsa_solve_result_t r;
+  const int rc = lsa_solve_device_end(Ctx, &r);
+  if (rc == LSA_OK)
+  {
+    TakeResult(r, sum);
+    return LSA_OK;
+  }
+  if (rc != LSA_E_STATE) return rc;  // LSA_E_GATE: neither the match nor the solve ran, the caller redoes both
+  // the solve gave up: the residual blocks are there, the loop runs here.  Whatever was enqueued ahead has been called off
+  // (lsa_solve_device_end): 1 tells the caller
+  const int hrc = SolveOnHost(sum);
+  return hrc < 0 ? hrc : 1;
 }
 
 int LocalOptimizer::SolveOnHost(SolveSummary& sum)

@@ -55,6 +55,13 @@ public:
   // up, the loop runs here with one launch per evaluation.  Same decisions from the same sums either way.
   void SetDeviceLoop(bool b) { DeviceLoop = b; }
   int Solve(SolveSummary& summary);
+  // Solve in two halves (device loop only): Begin enqueues the solve -- gated: behind the gate enqueued last (lsa_icp_gate),
+  // which will hand over the start point; SetPosePrior must then have been called with that very pose before End --, End
+  // waits for the result of the oldest solve begun on this context (by this object or an earlier one with the same
+  // settings).  End returns LSA_E_GATE when the gate gave up (nothing ran); a device solve that gave up itself is redone
+  // on the host -- End then returns 1: the iterations enqueued ahead have been called off.
+  int Begin(bool gated);
+  int End(SolveSummary& summary);
   Pose GetOptimizedPose() const { return FromXYZRPY(PoseArray); }
   int EstimateRegistrationError(RegistrationError& err);
 
@@ -70,6 +77,7 @@ private:
   bool HaveFinal = false;
   double FinalH[36];
   int SolveOnHost(SolveSummary& summary);
+  void TakeResult(const lsa_solve_result_t& r, SolveSummary& summary);
 };
 
 }  // namespace host

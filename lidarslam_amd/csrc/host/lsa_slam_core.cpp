@@ -81,6 +81,7 @@ SlamCore::SlamCore(int device)
   ExtractParams.edge_saliency_threshold = 1.5f;
   ExtractParams.edge_intensity_gap_threshold = 50.f;
   for (int k = 0; k < 3; ++k) LocalMaps[k] = std::make_shared<RollingGrid>();
+  if (const char* e = std::getenv("LSA_ICP_AHEAD")) ICPAhead = std::atoi(e) != 0;  // default of the parameter (A/B runs)
   // the plane map takes the largest insertions (tens of thousands of keypoints per keyframe): four host threads
   // keep them shorter than the ego-motion ICP they run beside ("MapAddThreads"; the map is the same for any value)
   LocalMaps[LSA_PLANE]->SetAddThreads(4);
@@ -151,6 +152,13 @@ void SlamCore::Reset(bool resetLog)
   LocalizationUncertainty = RegistrationError();
   CurrentStamp = 0;  // the "previous frame" after a reset is an empty cloud with stamp 0
   HaveFrame = false;
+  // nothing announced ahead of the reset (HintNextFrame) is taken over after it, no ICP iteration stays enqueued
+  NextFrameHinted = false;
+  if (Ctx)
+  {
+    (void)lsa_upload_frame_forget(Ctx);
+    (void)lsa_icp_abandon(Ctx);
+  }
   if (Ctx)
     for (int s = 0; s < 3; ++s)
       for (int k = 0; k < 3; ++k) lsa_set_keypoints(Ctx, s, k, nullptr, 0);
@@ -238,6 +246,7 @@ int SlamCore::AddFrame(const lsa_point_t* pts, int n, uint64_t stampUs, uint32_t
   if (!Ctx) return LSA_E_NO_DEVICE;
   Tick total;
   Stats = FrameStats();
+  (void)lsa_collect_garbage(Ctx);  // buffers outgrown during the last frame (nothing on the device waits for the host here)
   if (!pts || n <= 0) { LastError = "SLAM input only contains empty pointclouds : exiting."; return LSA_OK; }
   if (stampUs == CurrentStamp) { LastError = "SLAM frames have the same timestamp as previous ones : frames ignored."; return LSA_OK; }
   if (pts[0].device_id != 0 && (!OtherExtractors.empty() || !OtherBaseToLidarOffsets.empty()))
@@ -332,6 +341,7 @@ int SlamCore::AddFrames(const InputFrame* frames, int nframes)
     return AddFrame(frames[0].pts, frames[0].n, frames[0].stampUs, frames[0].seq);
   Tick total;
   Stats = FrameStats();
+  (void)lsa_collect_garbage(Ctx);
   bool allEmpty = true;
   for (int i = 0; i < nframes; ++i)
     if (frames[i].pts && frames[i].n > 0) allEmpty = false;
@@ -609,21 +619,87 @@ int SlamCore::ComputeEgoMotion()
   }
   TotalMatchedKeypoints = 0;
   lsa_match_params_t mp = EgoMatchParams();
+  const unsigned mask = (1u << LSA_EDGE) | (1u << LSA_PLANE);
+  auto saturation = [&](unsigned icpIter) {
+    const double iterRatio = icpIter / static_cast<double>(EgoMotionICPMaxIter - 1);
+    return (1 - iterRatio) * EgoMotionInitSaturationDistance + iterRatio * EgoMotionFinalSaturationDistance;
+  };
+  auto configure = [&](LocalOptimizer& optimizer) {
+    optimizer.SetDeviceLoop(DeviceLM);
+    optimizer.SetTwoDMode(TwoDMode);
+    optimizer.SetLMMaxIter(EgoMotionLMMaxIter);
+    optimizer.SetMinMatches(MinNbMatchedKeypoints);
+    optimizer.UseDeviceResiduals(mask);
+  };
+  // Iteration i + 1 is enqueued behind a gate (lsa_icp_gate) while iteration i runs: when the solve's result arrives its
+  // launches are in the queue already, and all that is between the solve and the next search is one store the gate polls
+  // for (or the call that calls them off: Slam.cxx:919-923, 950).
+  // (With the maps on the HOST this loop stays as it was: between its iterations this thread stages sub-maps the map workers
+  // have extracted and reads boxes back, and the frame then came out 1.5e-5 m beside the oracle in some schedules -- the
+  // statuses of the last iteration and all the counts equal, no gate timing out; not understood yet)
+  bool ahead = ICPAhead && DeviceLM && FusedMatch && (DeviceMapsInUse() || MapUpdate == MappingMode::NONE);
+  if (const char* e = std::getenv("LSA_ICP_AHEAD_LOOPS")) ahead = ahead && (std::atoi(e) & 1);  // (diagnostics: 1 ego-motion only, 2 localization only)
+  if (ahead) lsa_icp_abandon(Ctx);
+  bool enqueued = false;           // this iteration's launches are in the queue (their gate has been answered)
+  long long aheadSerial[3] = {0, 0, 0};
+  auto callOff = [&](int& ticket) {
+    if (ticket < 0) return;
+    lsa_icp_cancel(Ctx, ticket);
+    lsa_solve_device_drop(Ctx);
+    ticket = -1;
+  };
 
   for (unsigned icpIter = 0; icpIter < EgoMotionICPMaxIter; ++icpIter)
   {
     Tick ticp;
-    const double iterRatio = icpIter / static_cast<double>(EgoMotionICPMaxIter - 1);
-    mp.saturation_distance = (1 - iterRatio) * EgoMotionInitSaturationDistance + iterRatio * EgoMotionFinalSaturationDistance;
-    // both keypoint types are matched concurrently and nothing is read back: the number of matches
-    // arrives with the optimizer's first evaluation
-    LSA_TRY(lsa_match_types(Ctx, LSA_TARGET_PREVIOUS, (1u << LSA_EDGE) | (1u << LSA_PLANE), LSA_SET_RAW_CURRENT, &mp, Trelative.m, nullptr));
-    for (int k : {LSA_EDGE, LSA_PLANE}) EgoMatchSerial[k] = lsa_match_serial(Ctx, k);
+    mp.saturation_distance = saturation(icpIter);
+    LocalOptimizer optimizer(Ctx);
+    configure(optimizer);
+    optimizer.SetPosePrior(Trelative);
+    bool begun = enqueued;  // the solve of this iteration is in flight
+    if (!enqueued)
+    {
+      // both keypoint types are matched concurrently and nothing is read back: the number of matches
+      // arrives with the optimizer's first evaluation
+      LSA_TRY(lsa_match_types(Ctx, LSA_TARGET_PREVIOUS, mask, LSA_SET_RAW_CURRENT, &mp, Trelative.m, nullptr));
+      for (int k : {LSA_EDGE, LSA_PLANE}) EgoMatchSerial[k] = lsa_match_serial(Ctx, k);
+      if (ahead)
+      {
+        LSA_TRY(optimizer.Begin(false));
+        begun = true;
+      }
+    }
+    else
+      for (int k : {LSA_EDGE, LSA_PLANE}) EgoMatchSerial[k] = aheadSerial[k];
+    enqueued = false;
+    int ticket = -1;
+    if (ahead && begun && icpIter + 1 < EgoMotionICPMaxIter)
+    {
+      ticket = lsa_icp_gate(Ctx);
+      if (ticket < 0) { ticket = -1; ahead = false; }
+      else
+      {
+        lsa_match_params_t next = mp;
+        next.saturation_distance = saturation(icpIter + 1);
+        int rc = lsa_match_types_gated(Ctx, LSA_TARGET_PREVIOUS, mask, LSA_SET_RAW_CURRENT, &next, 0);
+        if (rc == 0)
+        {
+          for (int k : {LSA_EDGE, LSA_PLANE}) aheadSerial[k] = lsa_match_serial(Ctx, k);
+          rc = lsa_solve_device_begin(Ctx, mask, nullptr, TwoDMode ? 1 : 0, static_cast<int>(EgoMotionLMMaxIter), static_cast<int>(MinNbMatchedKeypoints));
+          if (rc < 0) { lsa_icp_cancel(Ctx, ticket); return Fail(rc, "lsa_solve_device_begin"); }
+        }
+        else
+        {
+          lsa_icp_cancel(Ctx, ticket);
+          ticket = -1;
+          ahead = false;
+          if (rc < 0) return Fail(rc, "lsa_match_types_gated");
+        }
+      }
+    }
     // the targets of the NEXT frame's ego-motion, which are this frame's keypoints, are built beside this registration:
-    // enqueued (ten launches on the look-ahead stream) while the first iteration's kernels -- the solve's included --
-    // are on their way
-    // (ten launches and two copies on the look-ahead stream: a host thread of their own issues them, this one goes on
-    // to the solve)
+    // enqueued (ten launches and two copies on the look-ahead stream: a host thread of their own issues them, this one
+    // goes on to the solve) while the first iteration's kernels -- the solve's included -- are on their way
     if (icpIter == 0 && BuildTargetsAhead)
     {
       AheadStatus = 0;
@@ -631,33 +707,61 @@ int SlamCore::ComputeEgoMotion()
     }
     // while the device is busy with this iteration: sub-maps the workers have finished meanwhile go to the device
     if (!SpecPending) LSA_TRY(StageSpeculativeSubMaps());
-    ArmLookaheadInterlude();
+    if (!begun) ArmLookaheadInterlude();
     Stats.ego_icp += ticp.Stop();
     Stats.ego_iters++;
 
     Tick tlm;
-    LocalOptimizer optimizer(Ctx);
-    optimizer.SetDeviceLoop(DeviceLM);
-    optimizer.SetTwoDMode(TwoDMode);
-    optimizer.SetPosePrior(Trelative);
-    optimizer.SetLMMaxIter(EgoMotionLMMaxIter);
-    optimizer.SetMinMatches(MinNbMatchedKeypoints);
-    optimizer.UseDeviceResiduals((1u << LSA_EDGE) | (1u << LSA_PLANE));
     SolveSummary summary;
-    LSA_TRY(optimizer.Solve(summary));
-    LSA_TRY(FinishLookaheadInterlude());
+    if (begun)
+    {
+      Tick tdbg;
+      const int irc = InterludeWork();
+      const double dbgInterlude = tdbg.Stop();
+      int rc = optimizer.End(summary);
+      if (std::getenv("LSA_GATE_DEBUG") && tdbg.Stop() > 0.01)
+        std::fprintf(stderr, "[gate debug] ego iteration %u: enqueue %.3f ms, interlude %.3f ms, until the result %.3f ms, rc %d\n", icpIter, 1e3 * Stats.ego_icp, 1e3 * dbgInterlude, 1e3 * tdbg.Stop(), rc);
+      if (rc == LSA_E_GATE)
+      {
+        // the gate gave up waiting for this thread (it was held up for 50 ms): nothing of the iteration ran.  Whatever
+        // waits behind it is called off, the iteration is done again in line, the rest of the loop without gates.
+        callOff(ticket);
+        lsa_icp_abandon(Ctx);
+        ahead = false;
+        IcpGateTimeouts++;
+        LSA_TRY(lsa_match_types(Ctx, LSA_TARGET_PREVIOUS, mask, LSA_SET_RAW_CURRENT, &mp, Trelative.m, nullptr));
+        for (int k : {LSA_EDGE, LSA_PLANE}) EgoMatchSerial[k] = lsa_match_serial(Ctx, k);
+        rc = optimizer.Solve(summary);
+      }
+      if (rc < 0) { callOff(ticket); return Fail(rc, "LocalOptimizer::Solve (ego-motion)"); }
+      if (rc == 1) { ticket = -1; ahead = false; }  // solved on the host: what was enqueued ahead has been called off
+      if (irc < 0) { callOff(ticket); return irc; }
+    }
+    else
+    {
+      LSA_TRY(optimizer.Solve(summary));
+      LSA_TRY(FinishLookaheadInterlude());
+    }
     TotalMatchedKeypoints = summary.num_matches;
     if (SpecPending)
     {
       // the predicted bounding boxes have long arrived: the map workers extract the sub-maps from here on
       const int rc = FinishSubMapSpeculation();
-      if (rc < 0) return rc;
+      if (rc < 0) { callOff(ticket); return rc; }
     }
     Stats.ego_lm += tlm.Stop();
     Stats.lm_evals += summary.num_evaluations;
-    if (summary.skipped) break;  // "Not enough keypoints, EgoMotion skipped for this frame."
+    if (summary.skipped) { callOff(ticket); break; }  // "Not enough keypoints, EgoMotion skipped for this frame."
     Trelative = optimizer.GetOptimizedPose();
-    if (summary.num_successful_steps == 1) break;
+    if (summary.num_successful_steps == 1) { callOff(ticket); break; }
+    if (ticket >= 0)
+    {
+      double prior[6];
+      ToXYZRPY(Trelative, prior);  // LocalOptimizer::SetPosePrior of the next iteration
+      const int rc = lsa_icp_post(Ctx, ticket, Trelative.m, prior, nullptr, nullptr, 0., 0.);
+      if (rc < 0) return Fail(rc, "lsa_icp_post");
+      enqueued = true;
+    }
   }
   if (KeepMatchDebug)
     for (int k : {LSA_EDGE, LSA_PLANE})
@@ -857,15 +961,38 @@ int SlamCore::Localization()
   TotalMatchedKeypoints = 0;
   lsa_match_params_t mp = LocMatchParams();
   Pose pendingD0 = Pose::Identity(), pendingD1 = Pose::Identity();
-  bool pendingUndistort = false;
-  for (unsigned icpIter = 0; icpIter < LocalizationICPMaxIter; ++icpIter)
-  {
-    Tick ticp;
+  bool pendingUndistort = false;  // the undistortion the last iteration ended with has not been applied yet
+  bool postedUndistort = false;   // ... it was handed to the gate of the iteration enqueued ahead
+  unsigned mask = 0;
+  for (int k = 0; k < 3; ++k)
+    if (UseKeypoints[k]) mask |= 1u << k;
+  auto saturation = [&](unsigned icpIter) {
     const double iterRatio = icpIter / static_cast<double>(LocalizationICPMaxIter - 1);
-    mp.saturation_distance = (1 - iterRatio) * LocalizationInitSaturationDistance + iterRatio * LocalizationFinalSaturationDistance;
-    unsigned mask = 0;
-    for (int k = 0; k < 3; ++k)
-      if (UseKeypoints[k]) mask |= 1u << k;
+    return (1 - iterRatio) * LocalizationInitSaturationDistance + iterRatio * LocalizationFinalSaturationDistance;
+  };
+  auto configure = [&](LocalOptimizer& optimizer) {
+    optimizer.SetDeviceLoop(DeviceLM);
+    optimizer.SetTwoDMode(TwoDMode);
+    optimizer.SetLMMaxIter(LocalizationLMMaxIter);
+    optimizer.SetMinMatches(MinNbMatchedKeypoints);
+    optimizer.UseDeviceResiduals(7u);
+  };
+  // as in the ego-motion loop: iteration i + 1 behind a gate while iteration i runs.  The undistortion between two
+  // iterations has to ride in the next search kernel for that (a launch of its own would have to be enqueued between
+  // the two, when the motion is known).
+  const bool undistortAhead = Undistortion == UNDISTORTION_REFINED;
+  bool ahead = ICPAhead && DeviceLM && FusedMatch && (!undistortAhead || UndistortInSearch);
+  if (const char* e = std::getenv("LSA_ICP_AHEAD_LOOPS")) ahead = ahead && (std::atoi(e) & 2);
+  if (ahead) lsa_icp_abandon(Ctx);
+  bool enqueued = false;
+  long long aheadSerial[3] = {0, 0, 0};
+  auto callOff = [&](int& ticket) {
+    if (ticket < 0) return;
+    lsa_icp_cancel(Ctx, ticket);
+    lsa_solve_device_drop(Ctx);
+    ticket = -1;
+  };
+  auto matchInLine = [&]() -> int {
     // the undistortion the previous iteration ended with rides in this iteration's search kernel (same keypoints, one launch less)
     if (pendingUndistort)
       LSA_TRY(lsa_match_types_undistorted(Ctx, LSA_TARGET_MAP, mask, &mp, Tworld.m, nullptr, pendingD0.m, pendingD1.m, Motion.Time0, Motion.Time1));
@@ -874,25 +1001,91 @@ int SlamCore::Localization()
     pendingUndistort = false;
     for (int k = 0; k < 3; ++k)
       if ((mask >> k) & 1u) LocMatchSerial[k] = lsa_match_serial(Ctx, k);
-    ArmLookaheadInterlude();
+    return LSA_OK;
+  };
+
+  for (unsigned icpIter = 0; icpIter < LocalizationICPMaxIter; ++icpIter)
+  {
+    Tick ticp;
+    mp.saturation_distance = saturation(icpIter);
+    LocalOptimizer optimizer(Ctx);
+    configure(optimizer);
+    optimizer.SetPosePrior(Tworld);
+    bool begun = enqueued;
+    if (!enqueued)
+    {
+      LSA_TRY(matchInLine());
+      if (ahead)
+      {
+        LSA_TRY(optimizer.Begin(false));
+        begun = true;
+      }
+    }
+    else
+      for (int k = 0; k < 3; ++k)
+        if ((mask >> k) & 1u) LocMatchSerial[k] = aheadSerial[k];
+    enqueued = false;
+    int ticket = -1;
+    if (ahead && begun && icpIter + 1 < LocalizationICPMaxIter)
+    {
+      ticket = lsa_icp_gate(Ctx);
+      if (ticket < 0) { ticket = -1; ahead = false; }
+      else
+      {
+        lsa_match_params_t next = mp;
+        next.saturation_distance = saturation(icpIter + 1);
+        int rc = lsa_match_types_gated(Ctx, LSA_TARGET_MAP, mask, LSA_SET_WORKING, &next, undistortAhead ? 1 : 0);
+        if (rc == 0)
+        {
+          for (int k = 0; k < 3; ++k)
+            if ((mask >> k) & 1u) aheadSerial[k] = lsa_match_serial(Ctx, k);
+          rc = lsa_solve_device_begin(Ctx, 7u, nullptr, TwoDMode ? 1 : 0, static_cast<int>(LocalizationLMMaxIter), static_cast<int>(MinNbMatchedKeypoints));
+          if (rc < 0) { lsa_icp_cancel(Ctx, ticket); return Fail(rc, "lsa_solve_device_begin"); }
+        }
+        else
+        {
+          lsa_icp_cancel(Ctx, ticket);
+          ticket = -1;
+          ahead = false;
+          if (rc < 0) return Fail(rc, "lsa_match_types_gated");
+        }
+      }
+    }
+    if (!begun) ArmLookaheadInterlude();
     Stats.loc_icp += ticp.Stop();
     Stats.loc_iters++;
 
     Tick tlm;
-    LocalOptimizer optimizer(Ctx);
-    optimizer.SetDeviceLoop(DeviceLM);
-    optimizer.SetTwoDMode(TwoDMode);
-    optimizer.SetPosePrior(Tworld);
-    optimizer.SetLMMaxIter(LocalizationLMMaxIter);
-    optimizer.SetMinMatches(MinNbMatchedKeypoints);
-    optimizer.UseDeviceResiduals(7u);
     SolveSummary summary;
-    LSA_TRY(optimizer.Solve(summary));
-    LSA_TRY(FinishLookaheadInterlude());
+    if (begun)
+    {
+      const int irc = InterludeWork();
+      int rc = optimizer.End(summary);
+      if (rc == LSA_E_GATE)
+      {
+        // (see the ego-motion loop) nothing of the iteration ran: done again in line, the rest of the loop without gates
+        callOff(ticket);
+        lsa_icp_abandon(Ctx);
+        ahead = false;
+        IcpGateTimeouts++;
+        pendingUndistort = postedUndistort;  // (it was to ride in the search that did not run)
+        rc = matchInLine();
+        if (rc == LSA_OK) rc = optimizer.Solve(summary);
+      }
+      if (rc < 0) { callOff(ticket); return Fail(rc, "LocalOptimizer::Solve (localization)"); }
+      if (rc == 1) { ticket = -1; ahead = false; }
+      if (irc < 0) { callOff(ticket); return irc; }
+    }
+    else
+    {
+      LSA_TRY(optimizer.Solve(summary));
+      LSA_TRY(FinishLookaheadInterlude());
+    }
     TotalMatchedKeypoints = summary.num_matches;
     if (summary.skipped)
     {
       // reset state to previous one to avoid instability (Slam.cxx:1098-1107)
+      callOff(ticket);
       Trelative = Pose::Identity();
       Tworld = PreviousTworld;
       if (Undistortion) Motion.SetTransforms(Pose::Identity(), Pose::Identity());
@@ -904,6 +1097,7 @@ int SlamCore::Localization()
     Tworld = optimizer.GetOptimizedPose();
     Trelative = Inverse(PreviousTworld) * Tworld;
     const bool lastIteration = (summary.num_successful_steps == 1) || (icpIter == LocalizationICPMaxIter - 1);
+    if (lastIteration) callOff(ticket);  // nothing more to search: what follows on the stream does not wait behind the gate
     if (Undistortion == UNDISTORTION_REFINED)
     {
       if (UndistortInSearch && !lastIteration)
@@ -914,7 +1108,7 @@ int SlamCore::Localization()
       else
       {
         int rc = RefineUndistortion();
-        if (rc < 0) return rc;
+        if (rc < 0) { callOff(ticket); return rc; }
       }
     }
     Stats.loc_lm += tlm.Stop();
@@ -922,6 +1116,16 @@ int SlamCore::Localization()
     {
       LSA_TRY(optimizer.EstimateRegistrationError(LocalizationUncertainty));
       break;
+    }
+    if (ticket >= 0)
+    {
+      double prior[6];
+      ToXYZRPY(Tworld, prior);  // LocalOptimizer::SetPosePrior of the next iteration
+      const int rc = lsa_icp_post(Ctx, ticket, Tworld.m, prior, pendingUndistort ? pendingD0.m : nullptr, pendingUndistort ? pendingD1.m : nullptr, Motion.Time0, Motion.Time1);
+      if (rc < 0) return Fail(rc, "lsa_icp_post");
+      postedUndistort = pendingUndistort;
+      pendingUndistort = false;
+      enqueued = true;
     }
   }
   if (KeepMatchDebug)
@@ -1409,6 +1613,7 @@ int SlamCore::GetRegisteredFrame(std::vector<lsa_point_t>& out)
   X("SubMapsAhead", SubMapsAhead, bool)                                                                \
   X("SubMapsAheadAdaptive", SubMapsAheadAdaptive, bool)                                                \
   X("LocalizationStartFused", LocalizationStartFused, bool)                                            \
+  X("ICPAhead", ICPAhead, bool)                                                                        \
   X("UndistortInSearch", UndistortInSearch, bool)                                                      \
   X("SpecBoxesOnLookahead", SpecBoxesOnLookahead, bool)                                                \
   X("SpecGridsTogether", SpecGridsTogether, bool)                                                      \
@@ -1567,6 +1772,7 @@ int SlamCore::GetParam(const std::string& name, double* v) const
   if (name == "DeviceMapsInUse") { *v = DeviceMapsInUse() ? 1. : 0.; return LSA_OK; }
   if (name == "UploadsAdopted") { *v = Ctx ? lsa_uploads_adopted(Ctx) : 0; return LSA_OK; }
   if (name == "DeviceSolveFallbacks") { *v = Ctx ? lsa_solve_device_fallbacks(Ctx) : 0; return LSA_OK; }
+  if (name == "IcpGateTimeouts") { *v = IcpGateTimeouts; return LSA_OK; }
   if (name == "TargetsBuiltAheadAdopted") { *v = Ctx ? lsa_prepared_targets_adopted(Ctx) : 0; return LSA_OK; }
   if (name == "SubMapsStagedAheadAdopted") { *v = Ctx ? lsa_staged_targets_adopted(Ctx) : 0; return LSA_OK; }
   if (name == "MapAddThreads") { *v = LocalMaps[LSA_PLANE]->GetAddThreads(); return LSA_OK; }

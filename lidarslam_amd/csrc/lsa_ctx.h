@@ -43,6 +43,8 @@ constexpr int kLmThreads = 512;           // threads of a workgroup of k_lm_solv
 constexpr int kLmOut = 48;                // doubles the LM kernel hands to the host (96 granules)
 constexpr int kHistRing = 256;  // half of it is cleared at a time (two fills on the ICP's stream): once in 128 matches
 constexpr int kAccumVals = 29;            // cost, g[6], H upper[21], nvalid
+constexpr int kGateRing = 8;              // gates (ICP iterations enqueued ahead of their inputs) a context can have in flight
+constexpr int kGateWords = 64;            // 8-byte words of a gate block
 
 struct GridDesc
 {
@@ -106,6 +108,7 @@ struct FrameInbox
   int cap = 0;
   int n = 0;
   const lsa_point_t* src = nullptr;  // the caller's buffer (identity of the frame; read by the uploader thread only)
+  unsigned long long fingerprint = 0;  // of the cloud's contents when it was copied (a sample of its points): a buffer rewritten in place is not adopted
   hipEvent_t ev = nullptr;           // recorded on the copy stream behind the DMA
   std::atomic<int> state{0};         // 0 free, 1 posted to the uploader, 2 DMA enqueued and event recorded, -1 failed
 };
@@ -230,6 +233,16 @@ struct lsa_ctx
   unsigned lm_tag = 0;            // tags handed out so far (every launch takes max evaluations + 2)
   unsigned long long lm_seq = 0;  // launches so far
   int lm_blocks = lsa::kLmBlocks;
+  // lsa_icp_gate: ICP iterations enqueued ahead of their inputs.  [kGateRing][kGateWords] words each: the host's side in
+  // coherent host memory (word 0 = sequence number << 8 | go, written last), the device's side the launches read
+  unsigned long long* gate_host = nullptr;
+  unsigned long long* gate_dev = nullptr;
+  unsigned gate_seq = 0;                 // gates enqueued so far
+  int gate_current = -1;                 // ticket the launches enqueued next wait behind (lsa_match_types_gated, lsa_solve_device_begin)
+  struct GateSaved { double sat[3]; int hist_pos[3]; long long hist_serial[3]; int k[3]; bool valid[3]; unsigned mask; bool used; } gate_saved[lsa::kGateRing] = {};
+  int debug_gate_give_up_every = 0;      // lsa_debug_set: every n-th gate gives up at once (exercises the callers' fall-back)
+  int debug_lm_give_up_block = -1;       // lsa_debug_set: that workgroup of the NEXT solve abandons the exchange (one shot)
+  std::deque<unsigned> lm_pending;       // result tags of the solves begun and not ended yet, oldest first
   hipStream_t map_stream = nullptr;     // shared by the device maps of this context (lsa_device_grid.hip), created with the first of them
   int map_stream_users = 0;
   void (*solve_hook)(void*) = nullptr;  // lsa_solve_device_interlude
@@ -272,6 +285,12 @@ struct lsa_ctx
   bool loc_armed = false;    // ... whose words are armed for the next launch
   bool pred_on_lookahead = false;  // the boxes in the first words were enqueued on the look-ahead stream (lsa_keypoint_boxes_predicted)
   std::mutex prof_mutex;  // stats / pending / event_pool of the profiling scopes
+  // Buffers that were outgrown.  hipFree / hipHostFree wait for the whole device -- also for a gate that waits for THIS
+  // process (lsa_icp_gate), with the runtime's lock held: a free on a worker thread at the wrong moment stalls the frame
+  // until the gate gives up.  Outgrown buffers are therefore only noted here and freed at the start of the next frame
+  // (lsa_collect_garbage), when nothing on the device waits for the host; kernels in flight keep the old buffer valid.
+  std::mutex grave_mutex;
+  std::vector<void*> grave_dev, grave_host;
   int bbox_n[3] = {0, 0, 0};
 
   // profiling
@@ -300,6 +319,18 @@ namespace lsa
   } while (0)
 
 int lm_cache_capacity();
+inline void retire_dev(lsa_ctx* ctx, void* p)
+{
+  if (!p) return;
+  std::lock_guard<std::mutex> l(ctx->grave_mutex);
+  ctx->grave_dev.push_back(p);
+}
+inline void retire_host(lsa_ctx* ctx, void* p)
+{
+  if (!p) return;
+  std::lock_guard<std::mutex> l(ctx->grave_mutex);
+  ctx->grave_host.push_back(p);
+}
 // the 18 words of the keypoints' bounding boxes: [16..24] of range_bits for lsa_keypoint_bboxes_begin, [32..40] for lsa_localization_begin
 inline unsigned* box_words(lsa_ctx* ctx) { return reinterpret_cast<unsigned*>(ctx->range_bits + 16); }
 inline unsigned* loc_box_words(lsa_ctx* ctx) { return reinterpret_cast<unsigned*>(ctx->range_bits + 32); }

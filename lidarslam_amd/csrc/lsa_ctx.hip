@@ -15,9 +15,10 @@ using namespace lsa;
 namespace lsa
 {
 
-template <typename T> static hipError_t dev_alloc(T** p, size_t count)
+// (re)allocation of a device buffer of the context: what it held is retired, not freed (lsa_ctx.h: grave_dev)
+template <typename T> static hipError_t dev_alloc(lsa_ctx* ctx, T** p, size_t count)
 {
-  if (*p) { (void)hipFree(*p); *p = nullptr; }
+  if (*p) { retire_dev(ctx, *p); *p = nullptr; }
   return hipMalloc((void**)p, std::max<size_t>(count, 1) * sizeof(T));
 }
 
@@ -30,7 +31,7 @@ int ensure_capacity(lsa_ctx* ctx, int n)
   // a look-ahead extraction in flight writes into buffers that are about to move: let it finish and forget it
   if (ctx->prefetch_stream) LSA_HIP(ctx, hipStreamSynchronize(ctx->prefetch_stream));
   ctx->prefetch_pending = false;
-  for (int k = 0; k < 3; ++k) LSA_HIP(ctx, dev_alloc(&ctx->kp_next[k], (size_t)cap));
+  for (int k = 0; k < 3; ++k) LSA_HIP(ctx, dev_alloc(ctx, &ctx->kp_next[k], (size_t)cap));
   // keypoint sets must survive a growth (raw previous is still needed): copy them over
   lsa_point_t* old_kp[3][3];
   for (int s = 0; s < 3; ++s)
@@ -38,32 +39,32 @@ int ensure_capacity(lsa_ctx* ctx, int n)
   for (int s = 0; s < 3; ++s)
     for (int k = 0; k < 3; ++k)
     {
-      LSA_HIP(ctx, dev_alloc(&ctx->kp[s][k], (size_t)cap));
+      LSA_HIP(ctx, dev_alloc(ctx, &ctx->kp[s][k], (size_t)cap));
       if (old_kp[s][k] && ctx->kp_n[s][k] > 0)
         LSA_HIP(ctx, hipMemcpy(ctx->kp[s][k], old_kp[s][k], (size_t)ctx->kp_n[s][k] * sizeof(lsa_point_t), hipMemcpyDeviceToDevice));
-      if (old_kp[s][k]) (void)hipFree(old_kp[s][k]);
+      retire_dev(ctx, old_kp[s][k]);
     }
   {
     // an uploaded frame must survive too (a further device frame may need more room for the merged keypoints)
     lsa_point_t* old_frame = ctx->frame_own;
     const bool current = old_frame && ctx->frame == old_frame && ctx->frame_n > 0;
     ctx->frame_own = nullptr;
-    LSA_HIP(ctx, dev_alloc(&ctx->frame_own, (size_t)cap));
+    LSA_HIP(ctx, dev_alloc(ctx, &ctx->frame_own, (size_t)cap));
     if (current)
     {
       LSA_HIP(ctx, hipMemcpy(ctx->frame_own, old_frame, (size_t)ctx->frame_n * sizeof(lsa_point_t), hipMemcpyDeviceToDevice));
       ctx->frame = ctx->frame_own;
     }
-    if (old_frame) (void)hipFree(old_frame);
+    retire_dev(ctx, old_frame);
   }
-  LSA_HIP(ctx, dev_alloc(&ctx->xyzi, (size_t)cap));
-  LSA_HIP(ctx, dev_alloc(&ctx->orig, (size_t)cap));
-  LSA_HIP(ctx, dev_alloc(&ctx->ring_of, (size_t)cap));
+  LSA_HIP(ctx, dev_alloc(ctx, &ctx->xyzi, (size_t)cap));
+  LSA_HIP(ctx, dev_alloc(ctx, &ctx->orig, (size_t)cap));
+  LSA_HIP(ctx, dev_alloc(ctx, &ctx->ring_of, (size_t)cap));
   int nblocks = (cap + kBucketChunk - 1) / kBucketChunk;
-  LSA_HIP(ctx, dev_alloc(&ctx->block_hist, (size_t)nblocks * kMaxRings));
-  for (int i = 0; i < 4; ++i) LSA_HIP(ctx, dev_alloc(&ctx->score[i], (size_t)cap));
-  LSA_HIP(ctx, dev_alloc(&ctx->valid, (size_t)cap));
-  LSA_HIP(ctx, dev_alloc(&ctx->label, (size_t)cap));
+  LSA_HIP(ctx, dev_alloc(ctx, &ctx->block_hist, (size_t)nblocks * kMaxRings));
+  for (int i = 0; i < 4; ++i) LSA_HIP(ctx, dev_alloc(ctx, &ctx->score[i], (size_t)cap));
+  LSA_HIP(ctx, dev_alloc(ctx, &ctx->valid, (size_t)cap));
+  LSA_HIP(ctx, dev_alloc(ctx, &ctx->label, (size_t)cap));
   ctx->cap_n = cap;
   return LSA_OK;
 }
@@ -77,26 +78,26 @@ int ensure_target(lsa_ctx* ctx, int ti, int m)
     {
       GridLevel& g = t.lv[l];
       g.max_cells = grid_level_cells(l);
-      LSA_HIP(ctx, dev_alloc(&g.cell_start, (size_t)g.max_cells + 1));
-      LSA_HIP(ctx, dev_alloc(&g.cell_fill, (size_t)g.max_cells));
-      LSA_HIP(ctx, dev_alloc(&g.block_sums, (size_t)g.max_cells / 1024 + 2));
+      LSA_HIP(ctx, dev_alloc(ctx, &g.cell_start, (size_t)g.max_cells + 1));
+      LSA_HIP(ctx, dev_alloc(ctx, &g.cell_fill, (size_t)g.max_cells));
+      LSA_HIP(ctx, dev_alloc(ctx, &g.block_sums, (size_t)g.max_cells / 1024 + 2));
     }
-    LSA_HIP(ctx, dev_alloc(&t.desc, kGridLevels));
-    LSA_HIP(ctx, dev_alloc(&t.bbox_bits, 8));
+    LSA_HIP(ctx, dev_alloc(ctx, &t.desc, kGridLevels));
+    LSA_HIP(ctx, dev_alloc(ctx, &t.bbox_bits, 8));
     // armed once here, re-armed by k_grid_scatter after every build
     const int init[8] = {0x7fffffff, 0x7fffffff, 0x7fffffff, (int)0x80000000, (int)0x80000000, (int)0x80000000, 0, 0};
     LSA_HIP(ctx, hipMemcpy(t.bbox_bits, init, sizeof(init), hipMemcpyHostToDevice));
   }
   if (m <= t.cap) return LSA_OK;
-  int cap = std::max(2 * m, 16384);  // doubling: a growing sub-map re-allocates (and synchronises) a handful of times
-  LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  if (ctx->prefetch_stream) LSA_HIP(ctx, hipStreamSynchronize(ctx->prefetch_stream));  // targets built ahead live there
-  LSA_HIP(ctx, dev_alloc(&t.pts, (size_t)cap));
-  LSA_HIP(ctx, dev_alloc(&t.xyzl, (size_t)cap));
+  int cap = std::max(2 * m, 16384);  // doubling: a growing sub-map re-allocates a handful of times
+  // (no synchronisation: the outgrown buffers are retired, launches in flight keep them; the new ones are filled before
+  // they are read.  This runs on worker threads too, beside ICP iterations that wait behind a gate)
+  LSA_HIP(ctx, dev_alloc(ctx, &t.pts, (size_t)cap));
+  LSA_HIP(ctx, dev_alloc(ctx, &t.xyzl, (size_t)cap));
   for (int l = 0; l < kGridLevels; ++l)
   {
-    LSA_HIP(ctx, dev_alloc(&t.lv[l].sorted, (size_t)cap));
-    LSA_HIP(ctx, dev_alloc(&t.lv[l].cell_of, (size_t)cap));
+    LSA_HIP(ctx, dev_alloc(ctx, &t.lv[l].sorted, (size_t)cap));
+    LSA_HIP(ctx, dev_alloc(ctx, &t.lv[l].cell_of, (size_t)cap));
   }
   t.cap = cap;
   return LSA_OK;
@@ -107,14 +108,13 @@ int ensure_match(lsa_ctx* ctx, int type, int k)
   MatchBuf& b = ctx->match[type];
   if (k <= b.cap) return LSA_OK;
   int cap = std::max(k + k / 4, 4096);
-  LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  LSA_HIP(ctx, dev_alloc(&b.rec, (size_t)cap * 16));
-  LSA_HIP(ctx, dev_alloc(&b.status, (size_t)cap));
-  LSA_HIP(ctx, dev_alloc(&b.knn_idx, (size_t)cap * kKnnMax));
-  LSA_HIP(ctx, dev_alloc(&b.knn_d2, (size_t)cap * kKnnMax));
-  LSA_HIP(ctx, dev_alloc(&b.knn_cnt, (size_t)cap));
-  LSA_HIP(ctx, dev_alloc(&b.slow_list, (size_t)cap));
-  LSA_HIP(ctx, dev_alloc(&b.slow_pts, (size_t)cap));
+  LSA_HIP(ctx, dev_alloc(ctx, &b.rec, (size_t)cap * 16));
+  LSA_HIP(ctx, dev_alloc(ctx, &b.status, (size_t)cap));
+  LSA_HIP(ctx, dev_alloc(ctx, &b.knn_idx, (size_t)cap * kKnnMax));
+  LSA_HIP(ctx, dev_alloc(ctx, &b.knn_d2, (size_t)cap * kKnnMax));
+  LSA_HIP(ctx, dev_alloc(ctx, &b.knn_cnt, (size_t)cap));
+  LSA_HIP(ctx, dev_alloc(ctx, &b.slow_list, (size_t)cap));
+  LSA_HIP(ctx, dev_alloc(ctx, &b.slow_pts, (size_t)cap));
   b.cap = cap;
   return LSA_OK;
 }
@@ -122,8 +122,7 @@ int ensure_match(lsa_ctx* ctx, int type, int k)
 int ensure_scratch(lsa_ctx* ctx, size_t bytes)
 {
   if (bytes <= ctx->scratch_cap) return LSA_OK;
-  LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  if (ctx->scratch_out) (void)hipFree(ctx->scratch_out);
+  retire_dev(ctx, ctx->scratch_out);
   ctx->scratch_out = nullptr;
   LSA_HIP(ctx, hipMalloc(&ctx->scratch_out, bytes + bytes / 4));
   ctx->scratch_cap = bytes + bytes / 4;
@@ -237,6 +236,22 @@ static void maybe_estimate_resolution(lsa_ctx* ctx, const lsa_point_t* pts, int 
   }
 }
 
+// FNV-1a over 256 points spread evenly over the cloud (and its size): tells a buffer that was rewritten in place from the
+// one that was announced, at the cost of 8 KB of reads
+static unsigned long long cloud_fingerprint(const lsa_point_t* pts, int n)
+{
+  unsigned long long h = 1469598103934665603ull ^ (unsigned long long)n;
+  const int samples = std::min(n, 256);
+  for (int i = 0; i < samples; ++i)
+  {
+    const size_t at = (size_t)i * (size_t)n / (size_t)samples;
+    unsigned long long w[sizeof(lsa_point_t) / 8];
+    std::memcpy(w, pts + at, sizeof(w));
+    for (unsigned long long v : w) { h ^= v; h *= 1099511628211ull; }
+  }
+  return h;
+}
+
 // the uploader thread of a context: pageable cloud -> pinned staging -> DMA on the copy stream -> event
 static void uploader_main(lsa_ctx* ctx)
 {
@@ -245,12 +260,13 @@ static void uploader_main(lsa_ctx* ctx)
   while (true)
   {
     ctx->up_cv.wait(l, [ctx] { return ctx->up_quit || !ctx->up_jobs.empty(); });
-    if (ctx->up_jobs.empty()) return;
+    if (ctx->up_quit || ctx->up_jobs.empty()) return;  // on the way out the queued clouds are not touched: their owner may have freed them
     const int slot = ctx->up_jobs.front();
     ctx->up_jobs.pop_front();
     l.unlock();
     FrameInbox& in = ctx->inbox[slot];
     std::memcpy(in.pinned, in.src, (size_t)in.n * sizeof(lsa_point_t));
+    in.fingerprint = cloud_fingerprint(in.pinned, in.n);
     bool ok = hipMemcpyAsync(in.dev, in.pinned, (size_t)in.n * sizeof(lsa_point_t), hipMemcpyHostToDevice, ctx->copy_stream) == hipSuccess;
     ok = ok && hipEventRecord(in.ev, ctx->copy_stream) == hipSuccess;
     l.lock();
@@ -306,9 +322,8 @@ int lsa_upload_frame_begin(lsa_ctx* ctx, const lsa_point_t* pts, int n)
   if (in.cap < n)
   {
     // (this slot's last frame is at least two AddFrame calls old: nothing reads it any more)
-    LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (in.dev) (void)hipFree(in.dev);
-    if (in.pinned) (void)hipHostFree(in.pinned);
+    retire_dev(ctx, in.dev);
+    retire_host(ctx, in.pinned);
     in.dev = nullptr; in.pinned = nullptr; in.cap = 0;
     const int cap = n + n / 8;
     LSA_HIP(ctx, hipMalloc((void**)&in.dev, (size_t)cap * sizeof(lsa_point_t)));
@@ -359,6 +374,19 @@ int lsa_upload_frame_adopt(lsa_ctx* ctx, const lsa_point_t* pts, int n)
     in.state.store(0);
     return ctx->fail(LSA_E_HIP, "lsa_upload_frame_adopt: the upload failed");
   }
+  if (in.fingerprint != cloud_fingerprint(pts, n))
+  {
+    // same address and size, other contents: the buffer was reused for another scan since it was announced (a driver's
+    // ring buffer, an allocator handing the same block out again) -- the copy made then is stale, the caller uploads
+    LSA_HIP(ctx, hipEventSynchronize(in.ev));
+    if (ctx->prefetch_pending && ctx->prefetch_frame == in.dev)
+    {
+      LSA_HIP(ctx, hipStreamSynchronize(ctx->prefetch_stream));
+      ctx->prefetch_pending = false;
+    }
+    in.state.store(0);
+    return 0;
+  }
   int rc = ensure_capacity(ctx, n);
   if (rc) return rc;
   maybe_estimate_resolution(ctx, pts, n);
@@ -369,6 +397,33 @@ int lsa_upload_frame_adopt(lsa_ctx* ctx, const lsa_point_t* pts, int n)
   in.state.store(0);
   ctx->uploads_adopted++;
   return 1;
+}
+
+int lsa_upload_frame_forget(lsa_ctx* ctx)
+{
+  if (!ctx) return LSA_E_ARG;
+  while (!ctx->inbox_queue.empty())
+  {
+    const int rc = inbox_drop_front(ctx);
+    if (rc) return rc;
+  }
+  return LSA_OK;
+}
+
+int lsa_collect_garbage(lsa_ctx* ctx)
+{
+  if (!ctx) return LSA_E_ARG;
+  std::vector<void*> dev, host;
+  {
+    std::lock_guard<std::mutex> l(ctx->grave_mutex);
+    dev.swap(ctx->grave_dev);
+    host.swap(ctx->grave_host);
+  }
+  if (dev.empty() && host.empty()) return LSA_OK;
+  LSA_HIP(ctx, hipSetDevice(ctx->device));
+  for (void* p : dev) (void)hipFree(p);       // (waits for the device: every launch that could still read them is over)
+  for (void* p : host) (void)hipHostFree(p);
+  return LSA_OK;
 }
 
 int lsa_uploads_adopted(const lsa_ctx* ctx) { return ctx ? ctx->uploads_adopted : 0; }
@@ -432,6 +487,20 @@ int lsa_ctx_create(int device_id, lsa_ctx** out)
     std::memset(ctx->lm_mailbox, 0, (size_t)2 * kLmOut * sizeof(unsigned long long));
   else
     ctx->lm_mailbox = nullptr;  // optional: lsa_solve_device then reports LSA_E_STATE and the host-driven loop is used
+  // gates of ICP iterations enqueued ahead (lsa_icp_gate): optional like the result mailbox
+  if (ctx->lm_mailbox && hipHostMalloc((void**)&ctx->gate_host, (size_t)kGateRing * kGateWords * sizeof(unsigned long long), hipHostMallocCoherent | hipHostMallocMapped) == hipSuccess)
+  {
+    std::memset(ctx->gate_host, 0, (size_t)kGateRing * kGateWords * sizeof(unsigned long long));
+    if (hipMalloc((void**)&ctx->gate_dev, (size_t)kGateRing * kGateWords * sizeof(unsigned long long)) != hipSuccess ||
+        hipMemset(ctx->gate_dev, 0, (size_t)kGateRing * kGateWords * sizeof(unsigned long long)) != hipSuccess)
+    {
+      (void)hipHostFree(ctx->gate_host);
+      ctx->gate_host = nullptr;
+      ctx->gate_dev = nullptr;
+    }
+  }
+  else
+    ctx->gate_host = nullptr;
   ok &= hipMalloc((void**)&ctx->lm_xchg, (size_t)2 * kLmBlocksMax * kMailboxStride * sizeof(unsigned long long)) == hipSuccess;
   if (ok) ok &= hipMemset(ctx->lm_xchg, 0, (size_t)2 * kLmBlocksMax * kMailboxStride * sizeof(unsigned long long)) == hipSuccess;
   if (const char* e = std::getenv("LSA_ACCUM_BLOCKS")) ctx->accum_blocks = std::min(std::max(std::atoi(e), 1), kAccumBlocksMax);
@@ -466,6 +535,7 @@ void lsa_ctx_destroy(lsa_ctx* ctx)
     ctx->up_cv.notify_all();
     ctx->uploader.join();
   }
+  (void)lsa_collect_garbage(ctx);
   if (ctx->copy_stream) { (void)hipStreamSynchronize(ctx->copy_stream); (void)hipStreamDestroy(ctx->copy_stream); }
   for (auto& in : ctx->inbox)
   {
@@ -504,6 +574,8 @@ void lsa_ctx_destroy(lsa_ctx* ctx)
   if (ctx->host_pinned) (void)hipHostFree(ctx->host_pinned);
   if (ctx->mailbox) (void)hipHostFree(ctx->mailbox);
   if (ctx->lm_mailbox) (void)hipHostFree(ctx->lm_mailbox);
+  if (ctx->gate_host) (void)hipHostFree(ctx->gate_host);
+  fr(ctx->gate_dev);
   fr(ctx->lm_xchg);
   fr(ctx->trace_dev);
   for (int i = 0; i < 2; ++i)
@@ -903,7 +975,7 @@ int lsa_frame_store_put(lsa_ctx* ctx, int slot, const lsa_point_t* pts, int n)
   {
     // the frame in use may be this very slot: nothing may still read it
     LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (d) { if (ctx->frame == d) { ctx->frame = nullptr; ctx->frame_n = 0; } (void)hipFree(d); ctx->store[slot] = {nullptr, 0}; ctx->store_cap[slot] = 0; }
+    if (d) { if (ctx->frame == d) { ctx->frame = nullptr; ctx->frame_n = 0; } retire_dev(ctx, d); ctx->store[slot] = {nullptr, 0}; ctx->store_cap[slot] = 0; }
     d = nullptr;
     LSA_HIP(ctx, hipMalloc((void**)&d, (size_t)n * sizeof(lsa_point_t)));
     ctx->store_cap[slot] = n;

@@ -1074,6 +1074,14 @@ void free_view(MapView& v)
   if (v.count) (void)hipFree(v.count);
   v = MapView{};
 }
+// an outgrown view while the grid lives: retired with its context (lsa_ctx.h: grave_dev), freed at the next frame's start
+void retire_view(lsa_device_grid* g, MapView& v)
+{
+  retire_dev(g->ctx, v.keys);
+  retire_dev(g->ctx, v.pts);
+  retire_dev(g->ctx, v.count);
+  v = MapView{};
+}
 
 // room for `want` voxels in both buffers of the map (contents kept) and for the chunk counters of a compaction over them
 int ensure_map(lsa_device_grid* g, int want)
@@ -1094,22 +1102,22 @@ int ensure_map(lsa_device_grid* g, int want)
       G_HIP(hipMemcpy(nb[0].keys, o.keys, (size_t)g->cap * sizeof(u64), hipMemcpyDeviceToDevice));
       G_HIP(hipMemcpy(nb[0].pts, o.pts, (size_t)g->cap * 2 * sizeof(float4), hipMemcpyDeviceToDevice));
       G_HIP(hipMemcpy(nb[0].count, o.count, (size_t)g->cap * sizeof(unsigned), hipMemcpyDeviceToDevice));
-      free_view(g->buf[0]);
-      free_view(g->buf[1]);
+      retire_view(g, g->buf[0]);
+      retire_view(g, g->buf[1]);
     }
     g->buf[0] = nb[0];
     g->buf[1] = nb[1];
     g->cur = 0;
     g->cap = cap;
-    if (g->old_local) (void)hipFree(g->old_local);
+    retire_dev(g->ctx, g->old_local);
     g->old_local = nullptr;
     G_HIP(hipMalloc((void**)&g->old_local, (size_t)cap * sizeof(int)));
   }
   const int nchunks = (std::max(g->cap, g->bcap) + 1023) / 1024 + 1;
   if (nchunks > g->chunk_cap)
   {
-    G_HIP(hipStreamSynchronize(g->stream));
-    if (g->chunks) (void)hipFree(g->chunks);
+    retire_dev(g->ctx, g->chunks);
+    g->chunks = nullptr;
     G_HIP(hipMalloc((void**)&g->chunks, (size_t)nchunks * sizeof(int)));
     g->chunk_cap = nchunks;
   }
@@ -1120,10 +1128,9 @@ int ensure_batch(lsa_device_grid* g, int n)
 {
   if (n <= g->bcap) return LSA_OK;
   const int cap = std::max(n + n / 4, 1 << 14);
-  G_HIP(hipStreamSynchronize(g->stream));
-  auto fr = [](void* p) { if (p) (void)hipFree(p); };
+  auto fr = [g](void* p) { retire_dev(g->ctx, p); };
   fr(g->batch); fr(g->bkeys); fr(g->skeys); fr(g->border); fr(g->sorder); fr(g->heads); fr(g->fresh_flag);
-  free_view(g->fresh);
+  retire_view(g, g->fresh);
   G_HIP(hipMalloc((void**)&g->batch, (size_t)cap * 2 * sizeof(float4)));
   G_HIP(hipMalloc((void**)&g->bkeys, (size_t)cap * sizeof(u64)));
   G_HIP(hipMalloc((void**)&g->skeys, (size_t)cap * sizeof(u64)));

@@ -254,6 +254,22 @@ struct InterpConst
   int invalid;           // Time0 == Time1 or H0 ~ H1
 };
 
+// What an ICP iteration that was enqueued ahead of its inputs (lsa_icp_gate) reads on the device once the host has
+// handed them over: the pose the keypoints are searched under, the optimiser's start point, the undistortion of the
+// iteration before.  `go` comes first: 1 = run, anything else = the launch does nothing (0 called off, 2 the gate gave up).
+struct IcpInputs
+{
+  Rigid pose;
+  double x0[6];
+  InterpConst ic;
+};
+struct IcpGate
+{
+  unsigned long long go;
+  IcpInputs in;
+};
+static_assert(sizeof(IcpGate) % 8 == 0 && sizeof(IcpGate) <= 64 * 8, "a gate block is at most 64 words");
+
 LSA_DEV void interp_eval(const InterpConst& c, double t, Rigid& out)
 {
   if (c.invalid)

@@ -23,6 +23,7 @@
 #include <chrono>
 #include <cmath>
 #include "lsa_accum.h"
+#include "lsa_device_math.h"
 #include "../../include/lsa_pmath.h"
 
 using namespace lsa;
@@ -41,6 +42,8 @@ struct LmParams
   int min_matches;
   unsigned tag_base;
   int cslots;  // residual blocks per thread kept in LDS between the evaluations
+  int give_up_block;    // test hook: this workgroup abandons the exchange at its first evaluation (-1: none)
+  const IcpGate* gate;  // not null: the launch was enqueued ahead of its start point (lsa_icp_gate) -- x0 comes from there, or nothing is done
 };
 
 // result layout (doubles): [0..5] pose, [6] initial cost, [7] final cost, [8..36] the 29 sums at the final
@@ -137,11 +140,11 @@ __device__ __forceinline__ bool lm_evaluate(const LmParams& p, unsigned epoch, u
   }
   // gather: every thread sweeps its granules, a batch of loads in flight together, until every tag matches
   const int total = nb * 2 * kAccumVals;
-  bool failed = false;
+  bool failed = (int)blockIdx.x == p.give_up_block;  // (test hook: as if this workgroup had waited too long)
   {
     const unsigned long long t0 = wall_clock64();
     unsigned spins = 0;
-    for (int base = threadIdx.x; base < total; base += 8 * kLmThreads)
+    for (int base = threadIdx.x; base < total && !failed; base += 8 * kLmThreads)
     {
       while (true)
       {
@@ -461,6 +464,25 @@ __global__ __launch_bounds__(kLmThreads) void k_lm_solve(LmParams p, u64* __rest
   __shared__ Shared sh;
   extern __shared__ double lm_cache[];  // [17][cslots * kLmThreads]
   const bool tr = trace != nullptr && blockIdx.x == 0;
+  if (p.gate)
+  {
+    // enqueued ahead of its start point: the gate in front of this launch has left it (go == 1), or the iteration was
+    // called off (0: nobody waits for a result) or the gate gave up waiting for the host (2: the host is told)
+    const unsigned long long go = p.gate->go;
+    if (go != 1ull)
+    {
+      if (go == 2ull && blockIdx.x == 0 && threadIdx.x < 2 * kResCount)
+      {
+        const double r = (threadIdx.x >> 1) == kResFailed ? 2. : 0.;
+        const u64 bits = (u64)__double_as_longlong(r);
+        const unsigned word = (threadIdx.x & 1) ? (unsigned)(bits >> 32) : (unsigned)(bits & 0xffffffffull);
+        __hip_atomic_store(mailbox + threadIdx.x, ((u64)out_tag << 32) | word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+      return;
+    }
+#pragma unroll
+    for (int a = 0; a < 6; ++a) p.x0[a] = p.gate->in.x0[a];
+  }
   if (threadIdx.x == 0)
   {
     for (int i = 0; i < 6; ++i) sh.lap[i] = 0;
@@ -530,6 +552,32 @@ __global__ __launch_bounds__(kLmThreads) void k_lm_solve(LmParams p, u64* __rest
   }
 }
 
+// Waits for the host to release gate `seq` (word 0 of its block in coherent host memory = seq << 8 | go), then brings the
+// inputs the host posted over to the device block the launches behind the gate read.  One wavefront; the wait is bounded
+// (50 ms of the 100 MHz clock): a host that does not answer makes the launches behind it do nothing and say so.
+__global__ __launch_bounds__(64) void k_icp_gate(const u64* __restrict__ host_words, u64* __restrict__ dev_words, unsigned seq, int give_up)
+{
+  const int lane = threadIdx.x;
+  unsigned long long w = 0;
+  if (lane == 0)
+  {
+    const unsigned long long t0 = wall_clock64();
+    bool timed_out = give_up != 0;  // (test hook: as if the host had not answered in time)
+    while (!timed_out)
+    {
+      w = __hip_atomic_load(host_words, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      if ((unsigned)(w >> 8) == seq) break;
+      if (wall_clock64() - t0 > 5000000ull) { timed_out = true; break; }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    w = timed_out ? 2ull : (w & 1ull);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");  // system scope: what the host stored before the word is seen
+  const unsigned go = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)w);
+  if (go == 1u && lane >= 1 && lane < kGateWords) dev_words[lane] = __hip_atomic_load(host_words + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (lane == 0) dev_words[0] = (u64)go;
+}
+
 const char* const kMessages[] = {"", "not enough matches", "gradient tolerance (iteration 0)", "max iterations", "gradient tolerance",
                                  "min trust region radius", "too many invalid steps", "parameter tolerance", "function tolerance"};
 
@@ -537,6 +585,7 @@ const char* const kMessages[] = {"", "not enough matches", "gradient tolerance (
 
 namespace lsa
 {
+InterpConst make_interp_const(const double H0[16], const double H1[16], double t0, double t1);  // lsa_transform.hip
 // how many 256-thread layers of residual blocks (34 KB each) the solve kernel may keep in LDS beside its own data
 int lm_cache_capacity()
 {
@@ -551,9 +600,10 @@ int lm_cache_capacity()
 
 extern "C" {
 
-int lsa_solve_device(lsa_ctx* ctx, unsigned type_mask, const double prior[6], int two_d_mode, int lm_max_iter, int min_matches, lsa_solve_result_t* out)
+int lsa_solve_device_begin(lsa_ctx* ctx, unsigned type_mask, const double prior[6], int two_d_mode, int lm_max_iter, int min_matches)
 {
-  if (!ctx || !prior || !out) return ctx ? ctx->fail(LSA_E_ARG, "lsa_solve_device: bad argument") : LSA_E_ARG;
+  if (!ctx) return LSA_E_ARG;
+  if (!prior && ctx->gate_current < 0) return ctx->fail(LSA_E_ARG, "lsa_solve_device_begin: no start point and no gate to wait behind");
   if (!ctx->lm_mailbox) return ctx->fail(LSA_E_STATE, "lsa_solve_device: no coherent host memory for the result");
   LSA_HIP(ctx, hipSetDevice(ctx->device));
   LmParams p;
@@ -567,7 +617,10 @@ int lsa_solve_device(lsa_ctx* ctx, unsigned type_mask, const double prior[6], in
     p.set.sat2[k] = mb.sat * mb.sat;
     total += p.set.count[k];
   }
-  for (int a = 0; a < 6; ++a) p.x0[a] = prior[a];
+  for (int a = 0; a < 6; ++a) p.x0[a] = prior ? prior[a] : 0.;
+  p.give_up_block = ctx->debug_lm_give_up_block;
+  ctx->debug_lm_give_up_block = -1;
+  p.gate = prior ? nullptr : reinterpret_cast<const IcpGate*>(ctx->gate_dev + (size_t)ctx->gate_current * kGateWords);
   p.two_d = two_d_mode ? 1 : 0;
   p.max_iter = lm_max_iter < 0 ? 0 : lm_max_iter;
   p.min_matches = min_matches;
@@ -588,13 +641,23 @@ int lsa_solve_device(lsa_ctx* ctx, unsigned type_mask, const double prior[6], in
     hipLaunchKernelGGL(k_lm_solve, dim3(nb), dim3(kLmThreads), p.cslots * slot_bytes, ctx->stream, p, ctx->lm_xchg, ctx->lm_mailbox, out_tag,
                        ctx->route_stats && ctx->trace_dev ? reinterpret_cast<unsigned long long*>(ctx->trace_dev) + (size_t)8192 * 12 : nullptr);
   }
-  // host work the caller wants done while the kernel runs (one shot)
-  if (ctx->solve_hook)
-  {
-    void (*fn)(void*) = ctx->solve_hook;
-    ctx->solve_hook = nullptr;
-    fn(ctx->solve_hook_arg);
-  }
+  ctx->lm_pending.push_back(out_tag);
+  return LSA_OK;
+}
+
+int lsa_solve_device_drop(lsa_ctx* ctx)
+{
+  if (!ctx || ctx->lm_pending.empty()) return LSA_E_ARG;
+  ctx->lm_pending.pop_back();  // the solve begun last will never run (its gate was called off): nobody waits for it
+  return LSA_OK;
+}
+
+int lsa_solve_device_end(lsa_ctx* ctx, lsa_solve_result_t* out)
+{
+  if (!ctx || !out) return ctx ? ctx->fail(LSA_E_ARG, "lsa_solve_device_end: bad argument") : LSA_E_ARG;
+  if (ctx->lm_pending.empty()) return ctx->fail(LSA_E_STATE, "lsa_solve_device_end: no solve in flight");
+  const unsigned out_tag = ctx->lm_pending.front();
+  ctx->lm_pending.pop_front();
   // the result arrives as granules in coherent host memory (as lsa_accumulate's sums do)
   double res[kResCount];
   {
@@ -619,8 +682,12 @@ int lsa_solve_device(lsa_ctx* ctx, unsigned type_mask, const double prior[6], in
       std::memcpy(&res[v], &bits, sizeof(double));
     }
   }
+  // (the gate's case first and without waiting for the stream: the next iteration's gate may be waiting there for this thread)
+  if (res[kResFailed] == 2.) return ctx->fail(LSA_E_GATE, "lsa_solve_device: the gate in front of the solve gave up waiting for the host");
   if (res[kResFailed] != 0.)
   {
+    // iterations enqueued ahead are called off first (their gates wait for this thread, the stream would not drain)
+    (void)lsa_icp_abandon(ctx);
     LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));  // every block has given up or finished: the slots are quiet again
     ctx->lm_fallbacks++;
     return ctx->fail(LSA_E_STATE, "lsa_solve_device: a block waited too long for the others");
@@ -646,6 +713,115 @@ int lsa_solve_device(lsa_ctx* ctx, unsigned type_mask, const double prior[6], in
   out->message = kMessages[std::min(std::max(out->termination, 0), 8)];
   // algorithmic bytes: every evaluation reads the record of every residual block (128 B + status)
   profile_add_bytes(ctx, "lm_solve", (double)out->num_evaluations * out->num_matches * 129);
+  return LSA_OK;
+}
+
+int lsa_solve_device(lsa_ctx* ctx, unsigned type_mask, const double prior[6], int two_d_mode, int lm_max_iter, int min_matches, lsa_solve_result_t* out)
+{
+  if (!ctx || !prior || !out) return ctx ? ctx->fail(LSA_E_ARG, "lsa_solve_device: bad argument") : LSA_E_ARG;
+  if (!ctx->lm_pending.empty()) return ctx->fail(LSA_E_STATE, "lsa_solve_device: another solve is in flight (lsa_solve_device_begin)");
+  const int rc = lsa_solve_device_begin(ctx, type_mask, prior, two_d_mode, lm_max_iter, min_matches);
+  if (rc) return rc;
+  // host work the caller wants done while the kernel runs (one shot)
+  if (ctx->solve_hook)
+  {
+    void (*fn)(void*) = ctx->solve_hook;
+    ctx->solve_hook = nullptr;
+    fn(ctx->solve_hook_arg);
+  }
+  return lsa_solve_device_end(ctx, out);
+}
+
+// ---- ICP iterations enqueued ahead of their inputs ------------------------------------------------------------------
+// A gate is one small launch that waits, on the device, for the host to post what the launches behind it need (the pose
+// the solve before it ended with: slam_lib/src/Slam.cxx:907, 940-946 and 1086, 1134-1142), or to call them off.  The
+// kernel-launch path (a dozen microseconds a launch) is then not between the end of a solve and the next search: the
+// launches are in the queue already and what remains is one store to coherent host memory and the gate's poll.
+int lsa_icp_gate(lsa_ctx* ctx)
+{
+  if (!ctx) return LSA_E_ARG;
+  if (!ctx->gate_host || !ctx->gate_dev) return ctx->fail(LSA_E_STATE, "lsa_icp_gate: no coherent host memory for the gates");
+  LSA_HIP(ctx, hipSetDevice(ctx->device));
+  const unsigned seq = ++ctx->gate_seq;
+  const int ticket = (int)(seq % kGateRing);
+  lsa_ctx::GateSaved& sv = ctx->gate_saved[ticket];
+  sv = lsa_ctx::GateSaved();
+  sv.used = true;
+  hipLaunchKernelGGL(k_icp_gate, dim3(1), dim3(64), 0, ctx->stream, ctx->gate_host + (size_t)ticket * kGateWords, ctx->gate_dev + (size_t)ticket * kGateWords, seq,
+                     (ctx->debug_gate_give_up_every > 0 && seq % (unsigned)ctx->debug_gate_give_up_every == 0) ? 1 : 0);
+  ctx->gate_current = ticket;
+  return ticket;
+}
+
+static int gate_release(lsa_ctx* ctx, int ticket, const IcpGate* block)
+{
+  if (!ctx || ticket < 0 || ticket >= kGateRing || !ctx->gate_host || !ctx->gate_saved[ticket].used)
+    return ctx ? ctx->fail(LSA_E_ARG, "lsa_icp_post / lsa_icp_cancel: no such gate") : LSA_E_ARG;
+  unsigned long long* w = ctx->gate_host + (size_t)ticket * kGateWords;
+  // which gate this slot serves now: the newest one enqueued with this ticket
+  unsigned seq = ctx->gate_seq;
+  while ((int)(seq % kGateRing) != ticket) --seq;
+  if (block)
+  {
+    unsigned long long words[kGateWords] = {};
+    std::memcpy(words, block, sizeof(IcpGate));
+    for (int i = 1; i < kGateWords; ++i) __atomic_store_n(w + i, words[i], __ATOMIC_RELAXED);
+  }
+  // the payload first, then the word the gate polls
+  __atomic_store_n(w, ((unsigned long long)seq << 8) | (block ? 1ull : 0ull), __ATOMIC_RELEASE);
+  ctx->gate_saved[ticket].used = false;
+  if (ctx->gate_current == ticket) ctx->gate_current = -1;
+  return LSA_OK;
+}
+
+int lsa_icp_post(lsa_ctx* ctx, int ticket, const double pose[16], const double prior[6], const double H0[16], const double H1[16], double t0, double t1)
+{
+  if (!ctx || !pose || !prior || ((H0 == nullptr) != (H1 == nullptr))) return ctx ? ctx->fail(LSA_E_ARG, "lsa_icp_post: bad argument") : LSA_E_ARG;
+  IcpGate g;
+  std::memset(&g, 0, sizeof(g));
+  g.go = 1;
+  row_major_to_rt(pose, g.in.pose.R, g.in.pose.t);
+  for (int a = 0; a < 6; ++a) g.in.x0[a] = prior[a];
+  if (H0) g.in.ic = make_interp_const(H0, H1, t0, t1);
+  return gate_release(ctx, ticket, &g);
+}
+
+int lsa_icp_cancel(lsa_ctx* ctx, int ticket)
+{
+  if (!ctx || ticket < 0 || ticket >= kGateRing) return LSA_E_ARG;
+  // what the launches behind the gate had announced on the host is taken back: they will not run
+  const lsa_ctx::GateSaved sv = ctx->gate_saved[ticket];
+  const int rc = gate_release(ctx, ticket, nullptr);
+  if (rc) return rc;
+  for (int k = 0; k < 3; ++k)
+    if ((sv.mask >> k) & 1u)
+    {
+      ctx->match[k].sat = sv.sat[k];
+      ctx->match[k].k = sv.k[k];
+      ctx->match[k].valid = sv.valid[k];
+      ctx->hist_pos[k] = sv.hist_pos[k];
+      ctx->hist_serial[k] = sv.hist_serial[k];
+    }
+  return LSA_OK;
+}
+
+int lsa_icp_abandon(lsa_ctx* ctx)
+{
+  if (!ctx) return LSA_E_ARG;
+  for (int t = 0; t < kGateRing; ++t)
+    if (ctx->gate_saved[t].used) (void)lsa_icp_cancel(ctx, t);
+  ctx->lm_pending.clear();
+  ctx->gate_current = -1;
+  return LSA_OK;
+}
+
+int lsa_debug_set(lsa_ctx* ctx, const char* name, int value)
+{
+  if (!ctx || !name) return LSA_E_ARG;
+  const std::string n(name);
+  if (n == "gate_give_up_every") ctx->debug_gate_give_up_every = value;
+  else if (n == "lm_give_up_block") ctx->debug_lm_give_up_block = value;
+  else return ctx->fail(LSA_E_ARG, "lsa_debug_set: no such knob");
   return LSA_OK;
 }
 

@@ -962,7 +962,7 @@ lsa_point_t* lsa_target_staging(lsa_ctx* ctx, int slot, int type, int capacity)
   if (capacity > ctx->tstage_cap[ti])
   {
     if (hipSetDevice(ctx->device) != hipSuccess) return nullptr;
-    if (ctx->tstage[ti]) (void)hipHostFree(ctx->tstage[ti]);  // waits for a copy still reading it
+    retire_host(ctx, ctx->tstage[ti]);  // (a copy may still be reading it: freed at the next frame's start)
     ctx->tstage[ti] = nullptr;
     ctx->tstage_cap[ti] = 0;
     // the map grows keyframe after keyframe at the start of a sequence: doubling keeps the (slow) pinned
@@ -1300,9 +1300,9 @@ int lsa_match(lsa_ctx* ctx, int slot, int type, int query_set, const lsa_match_p
 }
 
 static int match_types_impl(lsa_ctx* ctx, int slot, unsigned type_mask, int query_set, const lsa_match_params_t* p, const double pose[16], int* histograms,
-                            const InterpConst* undistort)
+                            const InterpConst* undistort, int gate = -1, bool gate_undistorts = false)
 {
-  if (!ctx || !p || !pose || slot < 0 || slot > 1 || (type_mask & ~7u) || query_set < 0 || query_set > 2)
+  if (!ctx || !p || (!pose && gate < 0) || slot < 0 || slot > 1 || (type_mask & ~7u) || query_set < 0 || query_set > 2)
     return ctx ? ctx->fail(LSA_E_ARG, "lsa_match_types: bad argument") : LSA_E_ARG;
   LSA_HIP(ctx, hipSetDevice(ctx->device));
   if (histograms) std::memset(histograms, 0, 3 * LSA_MATCH_NSTATUS * sizeof(int));
@@ -1328,13 +1328,22 @@ static int match_types_impl(lsa_ctx* ctx, int slot, unsigned type_mask, int quer
     int np = 0;
     for (int i = 0; i < nt; ++i)
     {
+      if (gate >= 0)
+      {
+        // should the iteration be called off, what it announces here is taken back (lsa_icp_cancel)
+        lsa_ctx::GateSaved& sv = ctx->gate_saved[gate];
+        const int k = types[i];
+        sv.mask |= 1u << k;
+        sv.sat[k] = ctx->match[k].sat; sv.k[k] = ctx->match[k].k; sv.valid[k] = ctx->match[k].valid;
+        sv.hist_pos[k] = ctx->hist_pos[k]; sv.hist_serial[k] = ctx->hist_serial[k];
+      }
       const int rc = match_prepare(ctx, slot, types[i], query_set, p, ctx->stream, preps[np]);
       if (rc < 0) return rc;
       if (rc > 0) ++np;
     }
     if (np > 0)
     {
-      const int rc = enqueue_fused_match(ctx, preps, np, pose, ctx->stream, undistort);
+      const int rc = enqueue_fused_match(ctx, preps, np, pose, ctx->stream, undistort, gate, gate_undistorts);
       if (rc) return rc;
     }
   }
@@ -1397,6 +1406,35 @@ int lsa_match_types_undistorted(lsa_ctx* ctx, int slot, unsigned type_mask, cons
   }
   const InterpConst ic = make_interp_const(H0, H1, t0, t1);
   return match_types_impl(ctx, slot, type_mask, LSA_SET_WORKING, p, pose, histograms, &ic);
+}
+
+// Whether lsa_match_types_undistorted would do the undistortion inside the search kernel: the one-launch form, every type
+// that has keypoints asked for, with a target and with valid parameters
+static bool search_reaches_every_keypoint(lsa_ctx* ctx, int slot, unsigned type_mask, const lsa_match_params_t* p)
+{
+  bool reach = ctx->fused_match;
+  for (int k = 0; k < 3 && reach; ++k)
+  {
+    if (ctx->kp_n[LSA_SET_WORKING][k] <= 0) continue;
+    const int nb = k == LSA_EDGE ? p->edge_nb_neighbors : k == LSA_PLANE ? p->plane_nb_neighbors : p->blob_nb_neighbors;
+    const bool bad = k == LSA_EDGE ? (nb < 2 || p->edge_min_nb_neighbors < 2) : k == LSA_PLANE ? nb < 3 : nb < 4;
+    reach = ((type_mask >> k) & 1u) && ctx->target[slot * 3 + k].m > 0 && !bad && nb <= kKnnMax;
+  }
+  return reach;
+}
+
+int lsa_match_types_gated(lsa_ctx* ctx, int slot, unsigned type_mask, int query_set, const lsa_match_params_t* p, int undistort)
+{
+  if (!ctx || !p || slot < 0 || slot > 1 || (type_mask & ~7u) || query_set < 0 || query_set > 2)
+    return ctx ? ctx->fail(LSA_E_ARG, "lsa_match_types_gated: bad argument") : LSA_E_ARG;
+  if (ctx->gate_current < 0) return ctx->fail(LSA_E_STATE, "lsa_match_types_gated: no gate to wait behind (lsa_icp_gate)");
+  // only the one-launch form reads a gate; an undistortion must reach every keypoint of the working set (otherwise it is a
+  // launch of its own, which the caller has to enqueue once the motion is known)
+  if (!ctx->fused_match || !ctx->fused_model) return 1;
+  if (undistort && (query_set != LSA_SET_WORKING || !search_reaches_every_keypoint(ctx, slot, type_mask, p))) return 1;
+  for (int k = 0; k < 3; ++k)
+    if (((type_mask >> k) & 1u) && ctx->kp_n[query_set][k] > 0 && ctx->target[slot * 3 + k].m <= 0) return 1;  // (an empty target is answered by a fill, not by the search)
+  return match_types_impl(ctx, slot, type_mask, query_set, p, nullptr, nullptr, nullptr, ctx->gate_current, undistort != 0);
 }
 
 int lsa_overlap(lsa_ctx* ctx, unsigned type_mask, int interpolate, const double H0[16], const double H1[16], double t0, double t1, float sampling_ratio,

@@ -71,6 +71,10 @@ struct LaneList
   }
   __device__ __forceinline__ void insert(knn_key key)
   {
+#ifdef LSA_ABLATE_INSERT
+    if (key < v[0]) v[0] = key;  // (timing experiment only: wrong results)
+    return;
+#endif
     if (key < v[KMAX - 1])
     {
       v[KMAX - 1] = key;
@@ -249,60 +253,43 @@ __device__ __forceinline__ unsigned store_rows(const RowTable& tb, int base, int
   return total;
 }
 
-// The scan of a block: its `total` candidates are dealt EVENLY to the G lanes of the group, whatever the rows'
-// lengths (lane gl takes the flattened range [gl total / G, (gl + 1) total / G)), every lane walks its range four
-// candidates at a time -- the loads of the next four in flight while the current four are compared, the bounds of
-// the next run fetched from LDS while the current run is walked -- and keeps its k best in a sorted list in
-// registers.  base: the group's table of the block, nent: its entries.
+// The scan of a block: its `total` candidates, in the order of the table, are dealt to the G lanes of the group ROUND
+// ROBIN (candidate c -> lane c mod G): the lanes of a group read neighbouring addresses of the cell-sorted array -- one
+// or two cache lines per load instruction and group where contiguous per-lane runs touched G (the kernel is bound by
+// the gathers' cache-line throughput in the vector memory pipeline, not by arithmetic) -- and the k nearest spread over
+// the lanes.  Every lane walks U candidates per turn, the loads of the next turn in flight while the current one is
+// compared, and follows the table's runs by itself (one entry = start, end, candidates in front; all rows non-empty, a
+// (0, 0, total) sentinel behind them).  It keeps its k best in a sorted list in registers.  base: the group's table of
+// the block, nent: its entries.
 template <int KMAX, int G>
 __device__ __forceinline__ void scan_rows(LaneList<KMAX>& L, const RowTable& tb, int base, int nent, unsigned total, int gl,
                                           const float4* __restrict__ sorted, float qx, float qy, float qz, int* route)
 {
   constexpr int U = KMAX > 8 ? 2 : 4;  // long lists: fewer candidates in flight, fewer registers
-  const unsigned S = (gl * total) / G;                // G is a power of two, total < 2^20
-  unsigned n = ((gl + 1) * total) / G - S;            // candidates of this lane
-  int f = base;
-  uint32_t c = 0, cend = 0, nb = 0, nen = 0;
-  {
-    // the entry that holds candidate S: the last one whose prefix is <= S (prefixes increase strictly)
-    int lo = 0, hi = nent - 1;
-    if (n == 0) hi = 0;
-    while (__any(lo < hi))
-    {
-      const int mid = (lo + hi + 1) >> 1;
-      const uint32_t pm = tb.p[base + mid];
-      if (lo < hi) { if (pm <= S) lo = mid; else hi = mid - 1; }
-    }
-    if (n > 0)
-    {
-      f = base + lo;
-      c = tb.b[f] + (S - tb.p[f]);
-      cend = tb.e[f];
-      nb = tb.b[f + 1];
-      nen = tb.e[f + 1];
-    }
-  }
-  // the next U candidates of the range: addresses (0 = none)
+  int f = base;                 // next entry of the table
+  uint32_t pend = 0, roff = 0;  // the current run: candidates [.., pend) of the block, candidate c at address roff + c
+  uint32_t cnext = (uint32_t)gl;
+  // the next U candidates of this lane: addresses (0 = none)
   auto gen = [&](uint32_t (&addr)[U], bool (&ok)[U]) {
 #pragma unroll
     for (int u = 0; u < U; ++u)
     {
-      ok[u] = n > 0;
+      const uint32_t c = cnext + (uint32_t)(u * G);
+      ok[u] = c < total;
       addr[u] = 0;
       if (ok[u])
       {
-        if (c >= cend)
+        while (c >= pend)
         {
-          // next run: its bounds are in registers already, those of the one after it are on their way
-          c = nb; cend = nen;
+          const uint32_t rb = tb.b[f], re = tb.e[f], rp = tb.p[f];
+          roff = rb - rp;
+          pend = rp + (re - rb);
           ++f;
-          nb = tb.b[f + 1];
-          nen = tb.e[f + 1];
         }
-        addr[u] = c++;
-        --n;
+        addr[u] = roff + c;
       }
     }
+    cnext += (uint32_t)(U * G);
   };
   uint32_t addr[U];
   bool ok[U];
@@ -390,8 +377,10 @@ enum { kOutNone = 0, kOutFound = 1, kOutFar = 2, kOutTail = 3 };
 // the group.  Every lane of the wavefront calls it; groups without a query (active == false) come back with kOutNone.
 template <int KMAX, int G>
 __device__ __forceinline__ int group_search(const GridDesc* __restrict__ desc, const GridPtrs& gp, float qx, float qy, float qz, int k, float far_d2,
-                                            bool active, int gl, int tid, const RowTable& tb, knn_key* save, knn_key (&best)[KMAX], float& ub_out, int* route)
+                                            bool active, int gl, int tid, const RowTable& tb, knn_key* save, knn_key (&best)[KMAX], float& ub_out, int* route,
+                                            unsigned long long* phase = nullptr)
 {
+  auto stamp = [&](int i) { if (phase && (tid & 63) == 0) phase[(tid >> 6) * 8 + i] = wall_clock64(); };
   constexpr int E1 = (9 + G - 1) / G, E2 = (25 + G - 1) / G, E3 = (49 + G - 1) / G;
   constexpr int CAP = table_capacity<G>();
   static_assert((256 / G) * CAP <= kTableEntries, "row tables");
@@ -480,6 +469,7 @@ __device__ __forceinline__ int group_search(const GridDesc* __restrict__ desc, c
     }
   }
   if (need) outcome = kOutTail;  // not even the largest block holds k points
+  stamp(0);
   if (route && gl == 0 && active)
   {
     if (sh >= 3) atomicAdd(&route[1], 1);
@@ -501,6 +491,7 @@ __device__ __forceinline__ int group_search(const GridDesc* __restrict__ desc, c
     L.reset();
     const float4* sorted = sh < 2 ? gp.sorted[0] : (sh < 4 ? gp.sorted[1] : gp.sorted[2]);
     scan_rows<KMAX, G>(L, tb, base, heavy ? 0 : nent, heavy ? 0u : cand, gl, sorted, qx, qy, qz, route);
+    stamp(1);
     merge_lists<KMAX, G>(L, k, best, !heavy);
     if (heavy)
     {
@@ -532,6 +523,7 @@ __device__ __forceinline__ int group_search(const GridDesc* __restrict__ desc, c
       }
     }
   }
+  stamp(2);
   // second scan, certain
   if (__any(sh2 >= 0))
   {
@@ -571,6 +563,7 @@ __device__ __forceinline__ int group_search(const GridDesc* __restrict__ desc, c
     }
     if (sh2 >= 0) outcome = kOutFound;
   }
+  stamp(3);
   return outcome;
 }
 
@@ -604,6 +597,7 @@ struct FusedArgs
   int fuse_model;  // the search kernel fits the models of its own keypoints (no second launch)
   int undistort;   // ... and first moves every keypoint by the motion `ic` interpolated at its own time (lsa_undistort), in place
   InterpConst ic;
+  const IcpGate* gate;  // not null: enqueued ahead of its inputs (lsa_icp_gate) -- pose and `ic` come from there, or nothing is done
 };
 
 struct SearchShared
@@ -611,6 +605,7 @@ struct SearchShared
   uint32_t b[kTableEntries], e[kTableEntries], p[kTableEntries];  // the groups' row tables
   knn_key save[(256 / 8) * 16];  // the groups' lists while the wavefront scans a heavy block for one of them
   int route[6];  // diagnostics: [0] second scans, [1] first block beyond shell 2, [2] candidates walked, [3] far, [4] first block = shell 0, [5] longest lane walk
+  unsigned long long phase[32];  // diagnostics (first lane of every wavefront, 8 each): clock after the rows, the first scan, its merge, the second scan | the staging, the barrier, the finish
 };
 
 // What the searching lanes leave in LDS for the lane that finishes a keypoint's match (one-launch form): the running
@@ -867,6 +862,7 @@ __device__ __forceinline__ void search_type(const Rigid& pose, const FusedType& 
   if (t.route_stats)
   {
     if (tid < 6) sh.route[tid] = 0;
+    if (tid < 32) sh.phase[tid] = 0;
     __syncthreads();
   }
   float qx = 0.f, qy = 0.f, qz = 0.f;
@@ -898,7 +894,7 @@ __device__ __forceinline__ void search_type(const Rigid& pose, const FusedType& 
   float ub = INFINITY;
   const unsigned long long tick0 = t.trace ? wall_clock64() : 0ull;
   const RowTable tb = {sh.b, sh.e, sh.p};
-  const int outcome = group_search<KMAX, G>(t.desc, t.gp, qx, qy, qz, t.k, t.far_d2, active, gl, tid, tb, sh.save, best, ub, t.route_stats ? sh.route : nullptr);
+  const int outcome = group_search<KMAX, G>(t.desc, t.gp, qx, qy, qz, t.k, t.far_d2, active, gl, tid, tb, sh.save, best, ub, t.route_stats ? sh.route : nullptr, t.trace ? sh.phase : nullptr);
   int cnt = 0;
 #pragma unroll
   for (int s = 0; s < KMAX; ++s)
@@ -910,8 +906,10 @@ __device__ __forceinline__ void search_type(const Rigid& pose, const FusedType& 
     const bool tail = active && outcome == kOutTail;
     if (tail && gl == 0) fs.pre[ql] = kStagePending;
     group_stage<KMAX, TYPE, G, QB, KC>(best, outcome == kOutFar ? kKnnFar : cnt, t.mc, t.xyzl, gl, ql, active && !tail, true, fs);
+    if (t.trace && (tid & 63) == 0) sh.phase[(tid >> 6) * 8 + 4] = wall_clock64();
     __syncthreads();  // the workgroup's QB keypoints are staged (and the tables free)
     if (tid >= 64) return;
+    if (t.trace && tid == 0) sh.phase[5] = wall_clock64();
     // the first wavefront finishes them, one lane each
     const int lane = tid;
     if (lane < LSA_MATCH_NSTATUS) fs.lh[lane] = 0;
@@ -937,7 +935,11 @@ __device__ __forceinline__ void search_type(const Rigid& pose, const FusedType& 
     }
     if (have)
     {
+#ifdef LSA_ABLATE_FINISH
+      const int st = fs.pre[lane] == LSA_MATCH_SUCCESS ? LSA_MATCH_MSE_TOO_LARGE : fs.pre[lane];  // (timing experiment only)
+#else
       const int st = finish_model<TYPE, QB, KC>(fs, lane, t.mc, t.rec, t.cap, i);
+#endif
       t.status[i] = (uint8_t)st;
       atomicAdd(&fs.lh[st], 1);
     }
@@ -968,6 +970,14 @@ __device__ __forceinline__ void search_type(const Rigid& pose, const FusedType& 
       unsigned long long* tr = t.trace + (size_t)blockIdx.x * 12;
       tr[0] = tick0; tr[1] = tick1; tr[2] = tick2; tr[3] = ((unsigned long long)xcc << 32) | hwid;
       for (int i = 0; i < 6; ++i) tr[4 + i] = (unsigned long long)sh.route[i];
+      // clocks of the phases, 16 bits each, relative to the start of the search
+      // (of the wavefront that was staged last: the one the workgroup waited for)
+      int w = 0;
+      for (int v = 1; v < 4; ++v)
+        if (sh.phase[v * 8 + 4] > sh.phase[w * 8 + 4]) w = v;
+      auto rel = [&](int i) { return sh.phase[i] > tick0 ? ((sh.phase[i] - tick0) & 0xffffull) : 0ull; };
+      tr[10] = rel(w * 8 + 0) | (rel(w * 8 + 1) << 16) | (rel(w * 8 + 2) << 32) | (rel(w * 8 + 3) << 48);
+      tr[11] = rel(w * 8 + 4) | (rel(5) << 16);
     }
     if (tid < 6 && sh.route[tid])
     {
@@ -1053,6 +1063,13 @@ __global__ __launch_bounds__(256, 4) void k_search_all(FusedArgs a)
   static_assert(kGE == kGP && kGP == kGB, "one workgroup serves 256 / G keypoints of any type");
   __shared__ SearchShared sh;
   __shared__ FitStage<QB, KC> fs;
+  if (a.gate)
+  {
+    // the gate in front of this launch has left the inputs of the iteration (go == 1) or the iteration was called off
+    if (a.gate->go != 1ull) return;
+    a.pose = a.gate->in.pose;
+    if (a.undistort) a.ic = a.gate->in.ic;
+  }
   // Hardware blocks b, b + 8, ... share an XCD (and its L2).  Every XCD gets one contiguous eighth of EVERY type's
   // blocks -- neighbouring keypoints (scan order) search a compact region of the target through one L2 -- and the
   // types with the longest searches (edges: no early out, larger k) first.
@@ -1086,6 +1103,11 @@ template <int KE, int KP, int KB>
 __global__ __launch_bounds__(kModelBlock) void k_model_all(FusedArgs a)
 {
   __shared__ ModelShared<KE, kModelBlock> sh;
+  if (a.gate)
+  {
+    if (a.gate->go != 1ull) return;
+    a.pose = a.gate->in.pose;
+  }
   int b = blockIdx.x;
   if (b < a.t[0].mblocks) { model_type<KE, LSA_EDGE, kModelBlock>(a.pose, a.t[0], b, sh); return; }
   b -= a.t[0].mblocks;
@@ -1121,11 +1143,12 @@ namespace lsa
 
 // Enqueues the matches `preps` describes (at most one per keypoint type, every one with a non-empty target and at
 // least one keypoint) as two launches on `st`: the searches of all types, then their model fits.
-int enqueue_fused_match(lsa_ctx* ctx, const MatchPrep* preps, int count, const double pose[16], hipStream_t st, const InterpConst* undistort)
+int enqueue_fused_match(lsa_ctx* ctx, const MatchPrep* preps, int count, const double pose[16], hipStream_t st, const InterpConst* undistort, int gate, bool gate_undistorts)
 {
   FusedArgs a;
   std::memset(&a, 0, sizeof(a));
-  row_major_to_rt(pose, a.pose.R, a.pose.t);
+  if (gate >= 0) a.gate = reinterpret_cast<const IcpGate*>(ctx->gate_dev + (size_t)gate * kGateWords);
+  else row_major_to_rt(pose, a.pose.R, a.pose.t);
   int kmax[3] = {1, 1, 1};
   const int lanes[3] = {kGE, kGP, kGB};
   double search_bytes = 0, model_bytes = 0;
@@ -1168,6 +1191,7 @@ int enqueue_fused_match(lsa_ctx* ctx, const MatchPrep* preps, int count, const d
     a.undistort = 1;
     a.ic = *undistort;
   }
+  if (gate >= 0 && gate_undistorts) a.undistort = 1;
   a.fuse_model = ctx->fused_model ? 1 : 0;
   for (int k = 0; k < 3; ++k)
     if (a.t[k].mblocks > 0 && a.t[k].nblocks == 0) a.fuse_model = 0;

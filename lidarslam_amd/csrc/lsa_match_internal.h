@@ -21,6 +21,8 @@ struct MatchPrep
 struct InterpConst;
 // undistort: every keypoint is first moved by that motion interpolated at its own time, in place (lsa_undistort's step, folded
 // into the search kernel); only when every keypoint of the set is among `preps` and is searched
-int enqueue_fused_match(lsa_ctx* ctx, const MatchPrep* preps, int count, const double pose[16], hipStream_t st, const InterpConst* undistort = nullptr);
+// gate >= 0: the launch waits behind that gate (lsa_icp_gate) and takes pose -- and, gate_undistorts, the undistortion -- from it
+int enqueue_fused_match(lsa_ctx* ctx, const MatchPrep* preps, int count, const double pose[16], hipStream_t st, const InterpConst* undistort = nullptr,
+                        int gate = -1, bool gate_undistorts = false);
 
 }  // namespace lsa

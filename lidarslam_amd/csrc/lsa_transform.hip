@@ -643,8 +643,7 @@ int lsa_stage_transformed(lsa_ctx* ctx, int set, const double pose[16])
     const int n = ctx->kp_n[set][k];
     if (n > ctx->stage_cap[k])
     {
-      LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
-      if (ctx->stage[k]) (void)hipHostFree(ctx->stage[k]);
+      retire_host(ctx, ctx->stage[k]);
       ctx->stage[k] = nullptr;
       const int cap = std::max(n + n / 4, 4096);
       LSA_HIP(ctx, hipHostMalloc((void**)&ctx->stage[k], (size_t)cap * sizeof(lsa_point_t), hipHostMallocDefault));

@@ -67,3 +67,10 @@ for name, m in (("edge", ok & is_edge), ("plane", ok & ~is_edge)):
         print("%s blocks %d: duration mean %.1f p90 %.1f max %.1f us, last end %.1f" % (name, int(m.sum()), dur[m].mean(), np.percentile(dur[m], 90), dur[m].max(), end[m].max()))
         md = (end - mid)[m]
         print("   model fits behind the search: mean %.1f p50 %.1f p90 %.1f max %.1f us; search + fits max %.1f" % (md.mean(), np.median(md), np.percentile(md, 90), md.max(), (end - start)[m].max()))
+
+# phases of the search inside a block (thread 0's wavefront): rows known, first scan, its merge, second scan | staged, barrier passed
+ph = np.stack([(tr[:, 10] >> (16 * i)) & 0xffff for i in range(4)] + [(tr[:, 11] >> (16 * i)) & 0xffff for i in range(2)], 1).astype(np.float64) / 100.0
+tot = (end - start)
+names = ["rows", "scan1", "merge1", "scan2", "staged", "barrier"]
+for label, m in (("all", ok), ("slowest 5 %", ok & (tot >= np.percentile(tot[ok], 95))), ("median band", ok & (tot >= np.percentile(tot[ok], 40)) & (tot <= np.percentile(tot[ok], 60)))):
+    print("%-12s n=%4d  " % (label, int(m.sum())) + "  ".join("%s %.1f" % (n, ph[m, i].mean()) for i, n in enumerate(names)) + "  end %.1f" % tot[m].mean())

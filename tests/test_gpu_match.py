@@ -3,6 +3,8 @@ LocalOptimizer evaluation / solve through the C ABI against the CPU oracle.
 Bar: match status, weights and residual records bit-exact (integer / decision work and the float and
 double arithmetic behind it); normal equations within 1e-12 relative (the GPU tree reduction sums in
 another order than the reference's sequential loop); solved poses within 1e-9 (north star: 1e-4)."""
+import time
+
 import numpy as np
 import pytest
 
@@ -513,3 +515,80 @@ def test_fused_and_staged_matching_agree(O, L, kps, model):
     assert ha.tolist() == hb.tolist() and ha[L.PLANE][1] > 0  # LSA_MATCH_BAD_MODEL_PARAMETRIZATION
     for ctx in (a, b, c):
         ctx.close()
+
+
+def test_an_iteration_enqueued_behind_a_gate_equals_the_one_enqueued_in_line(gpu_ctx, O, L, kps):
+    """lsa_icp_gate: a match and a solve enqueued BEFORE their pose exists wait on the device; posted, they compute what the
+    same calls compute when they are enqueued with the pose; called off, they leave no trace."""
+    prev, cur = kps[16]
+    mp = L.MatchParams.ego_motion(saturation_distance=5.0)
+    mp2 = L.MatchParams.ego_motion(saturation_distance=3.0)
+    for k in (0, 1):
+        gpu_ctx.set_keypoints(L.SET_WORKING, k, cur[k])
+        gpu_ctx.set_target(k, prev[k])
+    gpu_ctx.set_keypoints(L.SET_WORKING, 2, cur[2][:0])
+    pose, w0 = perturbed(0.45, 0.01), np.array([0.45, 0.02, 0.0, 0.0, 0.0, 0.01])
+    # in line
+    gpu_ctx.match_types(3, L.SET_WORKING, mp, pose, histograms=False)
+    want = gpu_ctx.solve_device(3, w0)
+    want_match = [gpu_ctx.match_results(k, L.SET_WORKING) for k in (0, 1)]
+    serial = [gpu_ctx.match_serial(k) for k in (0, 1)]
+    # behind a gate, released after a while
+    t = gpu_ctx.icp_gate()
+    assert gpu_ctx.match_types_gated(3, L.SET_WORKING, mp) == 0
+    gpu_ctx.solve_device_begin(3, None)
+    time.sleep(0.005)
+    gpu_ctx.icp_post(t, pose, w0)
+    got = gpu_ctx.solve_device_end()
+    assert list(got.pose) == list(want.pose) and got.final_cost == want.final_cost and got.num_evaluations == want.num_evaluations
+    assert list(got.H) == list(want.H) and got.num_matches == want.num_matches
+    for k in (0, 1):
+        for a, b in zip(want_match[k], gpu_ctx.match_results(k, L.SET_WORKING)):
+            assert a.tobytes() == b.tobytes()
+    # called off: the launches do nothing, what they had announced is taken back
+    serial = [gpu_ctx.match_serial(k) for k in (0, 1)]
+    t = gpu_ctx.icp_gate()
+    assert gpu_ctx.match_types_gated(3, L.SET_WORKING, mp2) == 0
+    gpu_ctx.solve_device_begin(3, None)
+    gpu_ctx.icp_cancel(t)
+    gpu_ctx.solve_device_drop()
+    gpu_ctx.sync()
+    assert [gpu_ctx.match_serial(k) for k in (0, 1)] == serial
+    for k in (0, 1):
+        for a, b in zip(want_match[k], gpu_ctx.match_results(k, L.SET_WORKING)):
+            assert a.tobytes() == b.tobytes()
+    again = gpu_ctx.solve_device(3, w0)  # (the saturation distance of the match that did run is still in force)
+    assert list(again.pose) == list(want.pose) and again.final_cost == want.final_cost
+    # two iterations in the queue at once, the second one behind its gate while the first runs
+    gpu_ctx.match_types(3, L.SET_WORKING, mp, pose, histograms=False)
+    gpu_ctx.solve_device_begin(3, w0)
+    t = gpu_ctx.icp_gate()
+    assert gpu_ctx.match_types_gated(3, L.SET_WORKING, mp2) == 0
+    gpu_ctx.solve_device_begin(3, None)
+    first = gpu_ctx.solve_device_end()
+    assert list(first.pose) == list(want.pose)
+    pose2 = se3(*first.pose)
+    gpu_ctx.icp_post(t, pose2, np.array(first.pose))
+    second = gpu_ctx.solve_device_end()
+    gpu_ctx.match_types(3, L.SET_WORKING, mp2, pose2, histograms=False)
+    ref2 = gpu_ctx.solve_device(3, np.array(first.pose))
+    assert list(second.pose) == list(ref2.pose) and second.final_cost == ref2.final_cost
+    assert gpu_ctx.solve_device_fallbacks() == 0
+
+
+def test_a_solve_abandoned_on_the_device_says_so(gpu_ctx, O, L, kps):
+    """lsa_debug_set("lm_give_up_block"): the workgroup stops exchanging sums, the others run into their 20 ms limit, the
+    launch drains and lsa_solve_device reports LSA_E_STATE (never a wrong pose); the next solve is healthy again."""
+    rec, st = setup_residuals(gpu_ctx, O, L, kps, 128)
+    w0 = np.array([0.45, 0.02, 0.0, 0.0, 0.0, 0.01])
+    want = gpu_ctx.solve_device(7, w0)
+    before = gpu_ctx.solve_device_fallbacks()
+    gpu_ctx.debug_set("lm_give_up_block", 3)
+    with pytest.raises(L.LsaError, match="-4"):
+        gpu_ctx.solve_device(7, w0)
+    assert gpu_ctx.solve_device_fallbacks() == before + 1
+    again = gpu_ctx.solve_device(7, w0)
+    assert list(again.pose) == list(want.pose) and again.final_cost == want.final_cost
+    # the host-driven loop the caller falls back to takes the same decisions (test_one_launch_solve_equals_the_host_driven_loop)
+    pose, summ, costs = gpu_ctx.solve(7, perturbed(0.45, 0.01))
+    assert (want.num_successful_steps, want.num_iterations) == (summ[0], summ[2])

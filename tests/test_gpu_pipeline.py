@@ -3,6 +3,8 @@ oracle.  Bar: float outputs of the transforms bit-exact (double math, one roundi
 operation order); keypoint sets bit-exact; poses within the north-star tolerance 1e-4 m / 1e-4 rad
 measured with the reference's own regression protocol (LidarSlamTestNode.cxx:297-305) -- in practice
 they agree to ~1e-12, the test keeps 1e-7 so that a real regression cannot hide."""
+import time
+
 import numpy as np
 import pytest
 
@@ -106,7 +108,7 @@ def run_both(L, O, model, nframes, seed=1000, check_keypoints=True, **params):
         dp, da = pose_diff(To, Tg)
         worst = (max(worst[0], dp), max(worst[1], da))
         assert dp < 1e-4 and da < 1e-4, f"frame {f}: north-star tolerance exceeded ({dp} m, {da} rad)"
-        assert dp < 1e-7 and da < 1e-6, f"frame {f}: poses drift apart ({dp} m, {da} rad)"
+        assert dp < 1e-7 and da < 1e-6, f"frame {f}: poses drift apart ({dp} m, {da} rad; gates that gave up: {sg.get_param('IcpGateTimeouts')}, solves redone on the host: {sg.get_param('DeviceSolveFallbacks')})"
         if check_keypoints:
             for k in range(3):
                 assert sg.keypoints(k, which=2).tobytes() == so.keypoints(k, which=2).tobytes(), f"frame {f}: raw keypoints {k}"
@@ -809,3 +811,127 @@ def test_sub_maps_ahead_of_time_change_nothing_but_the_schedule(L):
         assert a.map(k).tobytes() == b.map(k).tobytes()
     assert a.get_param("SubMapSpeculationHits") > 20 and b.get_param("SubMapSpeculationHits") == 0
     a.close(), b.close()
+
+
+@pytest.mark.gpu
+def test_a_cloud_rewritten_after_it_was_announced_is_not_taken_over(L):
+    """HintNextFrame identifies the announced cloud by address and size.  A buffer that is reused for another scan (a
+    driver's ring buffer, an allocator handing the block out again) must not be answered with the copy made when it was
+    announced: nothing announced survives Reset(), and a sample of the contents is compared when the cloud is adopted."""
+    frames = [L.synth_frame(16, 1000, f) for f in range(4)]
+    ref = L.Slam(0, EgoMotion=3)
+    for f in (2, 3):
+        ref.add_frame(frames[f][0], frames[f][1], f)
+    want = ref.world_transform()
+    want_kp = [ref.keypoints(k, 2).tobytes() for k in (L.EDGE, L.PLANE)]
+    ref.close()
+
+    # hint(A), reset, rewrite A in place, add_frame(A) must see the new contents
+    s = L.Slam(0, EgoMotion=3)
+    buf = frames[0][0].copy()
+    s.add_frame(frames[1][0], frames[1][1], 0)
+    s.hint_next_frame(buf)
+    s.reset()
+    for f in (2, 3):
+        buf[:] = 0
+        n = frames[f][0].size
+        cloud = buf[:n] if n <= buf.size else frames[f][0].copy()
+        cloud[:] = frames[f][0]
+        s.add_frame(cloud, frames[f][1], f)
+    assert np.array_equal(s.world_transform(), want)
+    assert [s.keypoints(k, 2).tobytes() for k in (L.EDGE, L.PLANE)] == want_kp
+    s.close()
+
+    # the same without a reset in between: announced, rewritten in place (same address, same size), added
+    s = L.Slam(0, EgoMotion=3)
+    n = min(frames[2][0].size, frames[3][0].size)
+    a, b = frames[2][0][:n].copy(), frames[3][0][:n].copy()
+    plain = L.Slam(0, EgoMotion=3)
+    plain.add_frame(a.copy(), frames[2][1], 0)
+    plain.add_frame(b.copy(), frames[3][1], 1)
+    buf = a.copy()
+    s.hint_next_frame(buf)          # announces the contents of frame 2 ...
+    s.add_frame(buf, frames[2][1], 0)  # ... which is the cloud that comes: taken over
+    s.hint_next_frame(buf)          # announced again with the old contents,
+    s.context().sync()
+    time.sleep(0.05)                # (the uploader thread has copied it by now)
+    buf[:] = b                      # rewritten in place,
+    s.add_frame(buf, frames[3][1], 1)  # and added: the copy made when it was announced is stale
+    assert np.array_equal(s.world_transform(), plain.world_transform())
+    assert s.get_param("UploadsAdopted") == 1
+    s.close()
+    plain.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model,nframes", [(16, 14), (64, 6)])
+def test_icp_iterations_enqueued_ahead_change_nothing_but_the_schedule(L, model, nframes):
+    """ICPAhead: iteration i + 1 of both ICP loops waits behind a gate on the device while iteration i runs
+    (lsa_icp_gate / lsa_icp_post / lsa_icp_cancel).  Same launches, same inputs, same order: poses, match counts and
+    match statuses are those of the loop that enqueues every iteration when its pose is known, bit for bit."""
+    frames = [L.synth_frame(model, 1000, f) for f in range(nframes)]
+
+    def run(**params):
+        s = L.Slam(0, EgoMotion=3, **params)
+        poses, used, status = [], [], []
+        for f, (pts, stamp) in enumerate(frames):
+            s.add_frame(pts, stamp, f)
+            poses.append(s.world_transform())
+            used.append(s.get_param("TotalMatchedKeypoints"))
+            status.append([s.match_status(loc, k)[0].tobytes() for loc in (0, 1) for k in (L.EDGE, L.PLANE)])
+        fb, gt = s.get_param("DeviceSolveFallbacks"), s.get_param("IcpGateTimeouts")
+        cov = s.covariance()
+        s.close()
+        return np.array(poses), used, status, cov, fb, gt
+
+    inline = run(ICPAhead=0)
+    ahead = run(ICPAhead=1)
+    assert ahead[4] == 0 and ahead[5] == 0
+    assert np.array_equal(inline[0], ahead[0]) and inline[1] == ahead[1] and inline[2] == ahead[2]
+    assert np.array_equal(inline[3], ahead[3])
+    # ... also without the refined undistortion (nothing rides in the search kernel) and with a single LM iteration allowed
+    for extra in ({"Undistortion": 1}, {"Undistortion": 0}, {"LocalizationICPMaxIter": 1, "EgoMotionICPMaxIter": 2}):
+        a, b = run(ICPAhead=0, **extra), run(ICPAhead=1, **extra)
+        assert np.array_equal(a[0], b[0]) and a[1] == b[1] and a[2] == b[2], extra
+
+
+@pytest.mark.gpu
+def test_the_fall_backs_of_the_bounded_device_waits_are_exercised(L, O):
+    """Two waits on the device are bounded and have a fall-back on the host that a healthy run never takes:
+    (a) the gate of an ICP iteration enqueued ahead gives up after 50 ms without an answer -- nothing of the iteration ran,
+        the caller does it again in line (LSA_E_GATE);
+    (b) a workgroup of the one-launch solve that waits 20 ms for the others' sums abandons the exchange, all give up, the
+        trust-region loop runs on the host (LSA_E_STATE, DeviceSolveFallbacks).
+    lsa_debug_set provokes both; the results must be those of the undisturbed run / of the oracle."""
+    frames = [L.synth_frame(16, 1000, f) for f in range(8)]
+
+    def run(prepare=None, **params):
+        s = L.Slam(0, EgoMotion=3, **params)
+        poses = []
+        for f, (pts, stamp) in enumerate(frames):
+            if prepare:
+                prepare(s, f)
+            s.add_frame(pts, stamp, f)
+            poses.append(s.world_transform())
+        out = np.array(poses), s.get_param("IcpGateTimeouts"), s.get_param("DeviceSolveFallbacks"), s.get_param("TotalMatchedKeypoints")
+        s.close()
+        return out
+
+    plain = run()
+    assert plain[1] == 0 and plain[2] == 0
+    # (a) every third gate gives up
+    gates = run(lambda s, f: s.context().debug_set("gate_give_up_every", 3) if f == 0 else None)
+    assert gates[1] >= 4 and gates[2] == 0
+    assert np.array_equal(plain[0], gates[0]) and plain[3] == gates[3]
+    # (b) one solve of frames 2 and 5 is abandoned by its second workgroup (or by its only one)
+    so = O.Slam(EgoMotion=3)
+    ref = []
+    for f, (pts, stamp) in enumerate(frames):
+        so.add_frame(pts, stamp, f)
+        ref.append(so.world_transform())
+    for block in (1, 0):
+        lm = run(lambda s, f: s.context().debug_set("lm_give_up_block", block) if f in (2, 5) else None)
+        assert lm[2] == 2 and lm[1] == 0
+        for f in range(len(frames)):
+            dp, da = pose_diff(ref[f], lm[0][f])
+            assert dp < 1e-7 and da < 1e-6, (block, f, dp, da)

@@ -78,13 +78,28 @@ def spawn_ranks(args):
     for r in range(args.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
-    rcs = [p.wait() for p in procs]
-    sys.stdout.write(out.decode())
+        # rank 0's stdout is THE line; what the other ranks print goes to stderr, labelled, so that a rank that fails is seen
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE if r else None))
+    outs = [None] * len(procs)
+
+    def drain(r):
+        outs[r] = procs[r].communicate()
+
+    readers = [threading.Thread(target=drain, args=(r,)) for r in range(len(procs))]
+    for t in readers:
+        t.start()
+    for t in readers:
+        t.join()
+    rcs = [p.returncode for p in procs]
+    for r in range(1, len(procs)):
+        for stream in outs[r]:
+            text = (stream or b"").decode(errors="replace").strip()
+            if text and (rcs[r] != 0 or os.environ.get("LSA_BENCH_VERBOSE")):
+                sys.stderr.write("".join(f"[rank {r}] {line}\n" for line in text.splitlines()[-40:]))
+    sys.stdout.write(outs[0][0].decode())
     sys.stdout.flush()
     if any(rcs):
-        raise SystemExit(f"ranks exited with {rcs}")
+        raise SystemExit(f"ranks exited with {rcs} (rank r's output above, prefixed [rank r])")
 
 
 def family_of(scope):
@@ -170,9 +185,9 @@ def main():
                 for f, (pts, _) in enumerate(frames):
                     self.slam.store_frame(f, pts)
 
-        def step(self, f):
+        def step(self, f, announce=True):
             pts, stamp = self.frames[f]
-            nxt = f + 1 < len(self.frames)
+            nxt = announce and f + 1 < len(self.frames)
             if self.mode == "resident":
                 if nxt:
                     self.slam.hint_next_stored_frame(f + 1)
@@ -202,7 +217,7 @@ def main():
             for f in range(total):
                 if f == args.warmup:
                     gate.wait()
-                rp.step(f)
+                rp.step(f, announce=f != args.warmup - 1)
                 publish(s, rp.slam, rp.frames[f][1])
             rp.slam.context().sync()
         except BaseException:
@@ -216,7 +231,10 @@ def main():
     exchange = PoseExchange(world, device="cuda" if args.backend == "nccl" else "cpu", per_rank=per_gpu)
 
     def step(f):
-        main_replay.step(f)
+        # the last warm-up frame announces nothing: the first timed frame's upload and extraction are inside the timed
+        # region like every other's (the last timed frame announces the frame behind it when there is one -- K uploads
+        # and K extractions are timed either way)
+        main_replay.step(f, announce=f != args.warmup - 1)
         if not distributed:
             return None
         publish(0, slam, main_replay.frames[f][1])
@@ -276,17 +294,29 @@ def main():
     elapsed = time.perf_counter() - t0
     for t in followers:
         t.join()
-    for rp in others:
-        rp.slam.close()
+    others_alive = others  # closed once their counters have been read
+    per_rank = None
     if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+        dev = "cuda" if args.backend == "nccl" else "cpu"
+        mine = torch.tensor([elapsed, float(slam.get_param("DeviceSolveFallbacks")), float(slam.get_param("IcpGateTimeouts"))], dtype=torch.float64, device=dev)
+        table = torch.zeros(world * 3, dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(table, mine)  # every rank's own clock and fall-back counters: rank 0 reports them
+        per_rank = table.cpu().numpy().reshape(world, 3)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
     kernels = [] if args.no_profile else ctx.profile_stats()
     ctx.profile(False)
     extra = {"uploads_taken_over": slam.get_param("UploadsAdopted"), "extractions_taken_over": slam.get_param("LookaheadAdopted"),
-             "device_solve_fallbacks": slam.get_param("DeviceSolveFallbacks")}
+             "device_solve_fallbacks": slam.get_param("DeviceSolveFallbacks") + sum(rp.slam.get_param("DeviceSolveFallbacks") for rp in others_alive),
+             "icp_gate_timeouts": slam.get_param("IcpGateTimeouts") + sum(rp.slam.get_param("IcpGateTimeouts") for rp in others_alive)}
+    for rp in others_alive:
+        rp.slam.close()
+    if per_rank is not None:
+        extra["ranks"] = {"backend": args.backend, "world_size": world,
+                          "frames_per_s_per_rank": [per_gpu * args.steps / float(r[0]) for r in per_rank],
+                          "device_solve_fallbacks_per_rank": [int(r[1]) for r in per_rank], "icp_gate_timeouts_per_rank": [int(r[2]) for r in per_rank]}
 
     if rank == 0:
         name = {128: "VLS-128", 64: "HDL-64", 16: "VLP-16"}.get(args.model, str(args.model))
@@ -375,7 +405,7 @@ def main():
 def extra_leg(rp, args):
     """Not the headline: the same frames through another way of handing them over, timed like the headline."""
     for f in range(args.warmup):
-        rp.step(f)
+        rp.step(f, announce=f != args.warmup - 1)
     rp.slam.context().sync()
     t0 = time.perf_counter()
     for f in range(args.warmup, args.warmup + args.steps):
@@ -399,8 +429,10 @@ def batch_replay(args, device):
             s.set_param(name, float(value))
     fps = rep.run(args.warmup)
     maps = "device" if rep.slams and rep.slams[0].get_param("DeviceMapsInUse") else "host"
+    fallbacks = [int(s.get_param("DeviceSolveFallbacks")) for s in rep.slams]  # of EVERY sequence: solves side by side compete for the CUs
+    timeouts = [int(s.get_param("IcpGateTimeouts")) for s in rep.slams]
     rep.close()
-    return {"sequences_on_one_gpu": n, "value": fps, "unit": "frames/s", "per_sequence": fps / n, "steps": args.steps, "warmup": args.warmup,
+    return {"sequences_on_one_gpu": n, "value": fps, "device_solve_fallbacks": fallbacks, "icp_gate_timeouts": timeouts, "unit": "frames/s", "per_sequence": fps / n, "steps": args.steps, "warmup": args.warmup,
             "frames_from": "frame store in HBM, look-ahead extraction", "rolling_maps": maps}
 
 
@@ -447,28 +479,50 @@ def pmc_traffic(family, model):
 def cpu_baseline(args, sequence):
     """The CPU oracle (restatement of the reference algorithm, OpenMP over rings / keypoints like the reference) on the
     frames of the timed region: it registers the warm-up frames too (the maps have to exist) but only the timed ones
-    count, exactly as on the GPU."""
+    count, exactly as on the GPU.  SURVEY.md 8d asks for NbThreads = 1, 4 (the reference's recommended setting,
+    ros_wrapping/lidar_slam/params/slam_config_outdoor.yaml:93) and all cores: the headline figure is the all-cores run over
+    the whole timed region; 1 and 4 threads run a bounded sample of it (the first frames of the timed region, ~10 s each)."""
     import numpy as np
 
     from oracle import oracle as O
 
     seed, frames = sequence
     # the GPU box gives one GPU job a share of 16 host cores, whatever the affinity mask says
-    threads = args.cpu_threads or min(16, len(os.sched_getaffinity(0)))
-    s = O.Slam(EgoMotion=3, NbThreads=threads)
-    times = []
-    for f, (pts, stamp) in enumerate(frames):
-        t = time.perf_counter()
-        s.add_frame(pts, stamp, f)
-        times.append(time.perf_counter() - t)
-    t = np.array(times[args.warmup:])
-    return {
+    cores = min(16, len(os.sched_getaffinity(0)))
+    threads = args.cpu_threads or cores
+
+    def run(nthreads, timed):
+        s = O.Slam(EgoMotion=3, NbThreads=nthreads)
+        times = []
+        # the warm-up frames build the maps: always with all the cores (what is timed is the frames behind them)
+        s.set_param("NbThreads", threads)
+        for f, (pts, stamp) in enumerate(frames[: args.warmup + timed]):
+            if f == args.warmup:
+                s.set_param("NbThreads", nthreads)
+            t = time.perf_counter()
+            s.add_frame(pts, stamp, f)
+            times.append(time.perf_counter() - t)
+        return np.array(times[args.warmup:])
+
+    t = run(threads, args.steps)
+    out = {
         "value": float(len(t) / t.sum()),
         "unit": "frames/s",
         "cores": threads,
         "kind": "port",
         "sample": f"frames {args.warmup}..{args.warmup + len(t) - 1} of the same sequence (seed {seed}): the frames of the timed region, after the same {args.warmup} warm-up frames; median {1e3 * float(np.median(t)):.1f} ms/frame",
     }
+    per_frame = float(np.median(t))
+    by_threads = {str(threads): {"value": out["value"], "cores": threads, "frames": int(len(t))}}
+    for n in (1, 4):
+        if n >= threads or args.model != 128 and args.steps > 60:
+            continue
+        # a bounded sample: about 10 s of CPU work at this thread count (perfect scaling assumed for the estimate)
+        k = int(max(3, min(args.steps, 10.0 / max(per_frame * threads / n * 0.6, 1e-3))))
+        tn = run(n, k)
+        by_threads[str(n)] = {"value": float(len(tn) / tn.sum()), "cores": n, "frames": int(len(tn))}
+    out["by_threads"] = by_threads
+    return out
 
 
 if __name__ == "__main__":

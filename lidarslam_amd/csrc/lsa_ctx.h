@@ -44,7 +44,8 @@ constexpr int kLmOut = 48;                // doubles the LM kernel hands to the 
 constexpr int kHistRing = 256;  // half of it is cleared at a time (two fills on the ICP's stream): once in 128 matches
 constexpr int kAccumVals = 29;            // cost, g[6], H upper[21], nvalid
 constexpr int kGateRing = 8;              // gates (ICP iterations enqueued ahead of their inputs) a context can have in flight
-constexpr int kGateWords = 64;            // 8-byte words of a gate block
+constexpr int kGateWords = 64;            // 8-byte words of a gate block on the device
+constexpr int kGateGranules = 128;        // 8-byte granules {sequence number, half a word} of a gate block in host memory
 
 struct GridDesc
 {
@@ -233,8 +234,10 @@ struct lsa_ctx
   unsigned lm_tag = 0;            // tags handed out so far (every launch takes max evaluations + 2)
   unsigned long long lm_seq = 0;  // launches so far
   int lm_blocks = lsa::kLmBlocks;
-  // lsa_icp_gate: ICP iterations enqueued ahead of their inputs.  [kGateRing][kGateWords] words each: the host's side in
-  // coherent host memory (word 0 = sequence number << 8 | go, written last), the device's side the launches read
+  // lsa_icp_gate: ICP iterations enqueued ahead of their inputs.  The host's side, in coherent host memory:
+  // [kGateRing][kGateGranules] granules {sequence number of the gate, half of word i / 2} -- every 8-byte granule carries
+  // its own tag, so ONE sweep of loads over the bus that finds all the tags in place has the whole block, whatever order
+  // the reads were served in.  The device's side, which the launches read: [kGateRing][kGateWords] words, word 0 = go
   unsigned long long* gate_host = nullptr;
   unsigned long long* gate_dev = nullptr;
   unsigned gate_seq = 0;                 // gates enqueued so far

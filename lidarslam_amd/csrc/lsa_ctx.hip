@@ -488,9 +488,9 @@ int lsa_ctx_create(int device_id, lsa_ctx** out)
   else
     ctx->lm_mailbox = nullptr;  // optional: lsa_solve_device then reports LSA_E_STATE and the host-driven loop is used
   // gates of ICP iterations enqueued ahead (lsa_icp_gate): optional like the result mailbox
-  if (ctx->lm_mailbox && hipHostMalloc((void**)&ctx->gate_host, (size_t)kGateRing * kGateWords * sizeof(unsigned long long), hipHostMallocCoherent | hipHostMallocMapped) == hipSuccess)
+  if (ctx->lm_mailbox && hipHostMalloc((void**)&ctx->gate_host, (size_t)kGateRing * kGateGranules * sizeof(unsigned long long), hipHostMallocCoherent | hipHostMallocMapped) == hipSuccess)
   {
-    std::memset(ctx->gate_host, 0, (size_t)kGateRing * kGateWords * sizeof(unsigned long long));
+    std::memset(ctx->gate_host, 0, (size_t)kGateRing * kGateGranules * sizeof(unsigned long long));
     if (hipMalloc((void**)&ctx->gate_dev, (size_t)kGateRing * kGateWords * sizeof(unsigned long long)) != hipSuccess ||
         hipMemset(ctx->gate_dev, 0, (size_t)kGateRing * kGateWords * sizeof(unsigned long long)) != hipSuccess)
     {

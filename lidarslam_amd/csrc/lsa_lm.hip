@@ -215,7 +215,9 @@ __device__ __forceinline__ bool lm_evaluate(const LmParams& p, unsigned epoch, u
 template <int N>
 __device__ __forceinline__ bool solve_spd(const double A[N * N], const double b[N], double x[N])
 {
-  double L[N * N];
+  // (every division by a diagonal element is a multiplication by its reciprocal, taken once: 6 divisions instead of 27
+  // on the one thread that runs the step; host/lsa_lm.cpp and the oracle do the same, operation for operation)
+  double L[N * N], rinv[N];
 #pragma unroll
   for (int i = 0; i < N * N; ++i) L[i] = 0.;
   bool ok = true;
@@ -231,9 +233,10 @@ __device__ __forceinline__ bool solve_spd(const double A[N * N], const double b[
       {
         if (!(s > 0.0) || !isfinite(s)) ok = false;
         L[i * N + i] = __builtin_sqrt(s);
+        rinv[i] = 1.0 / L[i * N + i];
       }
       else
-        L[i * N + j] = s / L[j * N + j];
+        L[i * N + j] = s * rinv[j];
     }
   if (!ok) return false;
   double y[N];
@@ -243,7 +246,7 @@ __device__ __forceinline__ bool solve_spd(const double A[N * N], const double b[
     double s = b[i];
 #pragma unroll
     for (int k = 0; k < i; ++k) s -= L[i * N + k] * y[k];
-    y[i] = s / L[i * N + i];
+    y[i] = s * rinv[i];
   }
 #pragma unroll
   for (int i = N - 1; i >= 0; --i)
@@ -251,7 +254,7 @@ __device__ __forceinline__ bool solve_spd(const double A[N * N], const double b[
     double s = y[i];
 #pragma unroll
     for (int k = i + 1; k < N; ++k) s -= L[k * N + i] * x[k];
-    x[i] = s / L[i * N + i];
+    x[i] = s * rinv[i];
   }
 #pragma unroll
   for (int i = 0; i < N; ++i)
@@ -480,8 +483,6 @@ __global__ __launch_bounds__(kLmThreads) void k_lm_solve(LmParams p, u64* __rest
       }
       return;
     }
-#pragma unroll
-    for (int a = 0; a < 6; ++a) p.x0[a] = p.gate->in.x0[a];
   }
   if (threadIdx.x == 0)
   {
@@ -493,12 +494,21 @@ __global__ __launch_bounds__(kLmThreads) void k_lm_solve(LmParams p, u64* __rest
     LmState& lm = sh.lm;
 #pragma unroll
     for (int v = 0; v < kAccumVals; ++v) lm.cur[v] = 0.;
+    // the start point: the launch's own argument, or what the gate brought over (read into LDS, the arguments stay untouched)
+    double x0[6];
 #pragma unroll
-    for (int a = 0; a < 6; ++a) { lm.x[a] = p.x0[a]; lm.scale[a] = 1.; lm.diag[a] = 0.; }
+    for (int a = 0; a < 6; ++a) x0[a] = p.x0[a];
+    if (p.gate)
+    {
+#pragma unroll
+      for (int a = 0; a < 6; ++a) x0[a] = p.gate->in.x0[a];
+    }
+#pragma unroll
+    for (int a = 0; a < 6; ++a) { lm.x[a] = x0[a]; lm.scale[a] = 1.; lm.diag[a] = 0.; }
     lm.radius = 1e4; lm.decrease_factor = 2.0; lm.x_norm = 0.; lm.model_cost_change = 0.; lm.delta_norm = 0.; lm.initial_cost = 0.;
     lm.reuse_diagonal = 0; lm.consecutive_invalid = 0; lm.iter = 0;
     lm.evaluations = 1; lm.successful = 0; lm.unsuccessful = 0; lm.iterations = 0; lm.code = kCodeNone; lm.skipped = 0; lm.matches = 0;
-    set_point(sh, p.x0);
+    set_point(sh, x0);
     sh.stop = 0;
   }
   if (threadIdx.x < 64) finish_point(sh);
@@ -552,30 +562,44 @@ __global__ __launch_bounds__(kLmThreads) void k_lm_solve(LmParams p, u64* __rest
   }
 }
 
-// Waits for the host to release gate `seq` (word 0 of its block in coherent host memory = seq << 8 | go), then brings the
-// inputs the host posted over to the device block the launches behind the gate read.  One wavefront; the wait is bounded
-// (50 ms of the 100 MHz clock): a host that does not answer makes the launches behind it do nothing and say so.
-__global__ __launch_bounds__(64) void k_icp_gate(const u64* __restrict__ host_words, u64* __restrict__ dev_words, unsigned seq, int give_up)
+// Waits for the host to release gate `seq`, then leaves what the host posted in the device block the launches behind the
+// gate read.  The host's block is 128 granules {seq, half of word i / 2}; the two wavefronts sweep all of them with one
+// load each, again and again, until every tag is `seq`: one trip over the bus after the host's last store, and no
+// assumption on the order the reads are served in.  Word 0 of the block is go (1 run, 0 called off); the wait is bounded
+// (50 ms of the 100 MHz clock): a host that does not answer makes the launches behind it do nothing and say so (go = 2).
+__global__ __launch_bounds__(kGateGranules) void k_icp_gate(const u64* __restrict__ host_granules, u64* __restrict__ dev_words, unsigned seq, int give_up)
 {
-  const int lane = threadIdx.x;
-  unsigned long long w = 0;
-  if (lane == 0)
+  __shared__ unsigned halves[kGateGranules];
+  __shared__ int state;  // 0 waiting, 1 all there, 2 gave up
+  const int t = threadIdx.x;
+  if (t == 0) state = give_up ? 2 : 0;  // (test hook: as if the host had not answered in time)
+  __syncthreads();
+  const unsigned long long t0 = wall_clock64();
+  while (state == 0)
   {
-    const unsigned long long t0 = wall_clock64();
-    bool timed_out = give_up != 0;  // (test hook: as if the host had not answered in time)
-    while (!timed_out)
+    const u64 g = __hip_atomic_load(host_granules + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    const bool mine = (unsigned)(g >> 32) == seq;
+    if (mine) halves[t] = (unsigned)(g & 0xffffffffull);
+    const int all = __syncthreads_and(mine ? 1 : 0);
+    if (t == 0)
     {
-      w = __hip_atomic_load(host_words, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      if ((unsigned)(w >> 8) == seq) break;
-      if (wall_clock64() - t0 > 5000000ull) { timed_out = true; break; }
-      __builtin_amdgcn_s_sleep(1);
+      if (all) state = 1;
+      else if (wall_clock64() - t0 > 5000000ull) state = 2;
     }
-    w = timed_out ? 2ull : (w & 1ull);
+    __syncthreads();
+    if (state == 0) __builtin_amdgcn_s_sleep(1);
   }
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");  // system scope: what the host stored before the word is seen
-  const unsigned go = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)w);
-  if (go == 1u && lane >= 1 && lane < kGateWords) dev_words[lane] = __hip_atomic_load(host_words + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  if (lane == 0) dev_words[0] = (u64)go;
+  if (state == 1)
+  {
+    if (t < kGateWords)
+    {
+      const u64 w = ((u64)halves[2 * t + 1] << 32) | halves[2 * t];
+      // called off (go == 0): only the first word matters
+      if (t == 0 || (halves[0] | halves[1]) != 0u) dev_words[t] = w;
+    }
+  }
+  else if (t == 0)
+    dev_words[0] = 2ull;
 }
 
 const char* const kMessages[] = {"", "not enough matches", "gradient tolerance (iteration 0)", "max iterations", "gradient tolerance",
@@ -747,7 +771,7 @@ int lsa_icp_gate(lsa_ctx* ctx)
   lsa_ctx::GateSaved& sv = ctx->gate_saved[ticket];
   sv = lsa_ctx::GateSaved();
   sv.used = true;
-  hipLaunchKernelGGL(k_icp_gate, dim3(1), dim3(64), 0, ctx->stream, ctx->gate_host + (size_t)ticket * kGateWords, ctx->gate_dev + (size_t)ticket * kGateWords, seq,
+  hipLaunchKernelGGL(k_icp_gate, dim3(1), dim3(kGateGranules), 0, ctx->stream, ctx->gate_host + (size_t)ticket * kGateGranules, ctx->gate_dev + (size_t)ticket * kGateWords, seq,
                      (ctx->debug_gate_give_up_every > 0 && seq % (unsigned)ctx->debug_gate_give_up_every == 0) ? 1 : 0);
   ctx->gate_current = ticket;
   return ticket;
@@ -757,18 +781,18 @@ static int gate_release(lsa_ctx* ctx, int ticket, const IcpGate* block)
 {
   if (!ctx || ticket < 0 || ticket >= kGateRing || !ctx->gate_host || !ctx->gate_saved[ticket].used)
     return ctx ? ctx->fail(LSA_E_ARG, "lsa_icp_post / lsa_icp_cancel: no such gate") : LSA_E_ARG;
-  unsigned long long* w = ctx->gate_host + (size_t)ticket * kGateWords;
+  unsigned long long* g = ctx->gate_host + (size_t)ticket * kGateGranules;
   // which gate this slot serves now: the newest one enqueued with this ticket
   unsigned seq = ctx->gate_seq;
   while ((int)(seq % kGateRing) != ticket) --seq;
-  if (block)
+  unsigned long long words[kGateWords] = {};
+  if (block) std::memcpy(words, block, sizeof(IcpGate));  // (word 0 = go = 1; called off: all zero)
+  // every granule carries the gate's number: the device has the block once it has seen it in all of them
+  for (int i = 0; i < kGateWords; ++i)
   {
-    unsigned long long words[kGateWords] = {};
-    std::memcpy(words, block, sizeof(IcpGate));
-    for (int i = 1; i < kGateWords; ++i) __atomic_store_n(w + i, words[i], __ATOMIC_RELAXED);
+    __atomic_store_n(g + 2 * i, ((unsigned long long)seq << 32) | (words[i] & 0xffffffffull), __ATOMIC_RELAXED);
+    __atomic_store_n(g + 2 * i + 1, ((unsigned long long)seq << 32) | (words[i] >> 32), __ATOMIC_RELAXED);
   }
-  // the payload first, then the word the gate polls
-  __atomic_store_n(w, ((unsigned long long)seq << 8) | (block ? 1ull : 0ull), __ATOMIC_RELEASE);
   ctx->gate_saved[ticket].used = false;
   if (ctx->gate_current == ticket) ctx->gate_current = -1;
   return LSA_OK;

@@ -868,25 +868,28 @@ __device__ __forceinline__ void search_type(const Rigid& pose, const FusedType& 
   float qx = 0.f, qy = 0.f, qz = 0.f;
   if (active)
   {
+    float4 q4 = t.queries[2 * (size_t)q];
     // KeypointsMatcher: worldPoint = PosePrior * basePoint in double, narrowed to float for the search
     // (KeypointsMatcher.cxx:117-118, KDTreePCLAdaptor.h:96-100)
-    float4 q4 = t.queries[2 * (size_t)q];
-    if (ic)
-    {
-      // Slam::RefineUndistortion's step for this keypoint (k_undistort of lsa_transform.hip, same arithmetic): the lanes
-      // of the group all work it out, the first one stores it for everything after this match
-      const float4 b4 = t.queries[2 * (size_t)q + 1];
-      Rigid U;
-      interp_eval(*ic, __hiloint2double(__float_as_int(b4.y), __float_as_int(b4.x)), U);
-      double ux, uy, uz;
-      rigid_apply(U, (double)q4.x, (double)q4.y, (double)q4.z, ux, uy, uz);
-      q4.x = (float)ux; q4.y = (float)uy; q4.z = (float)uz;
-      if (gl == 0) const_cast<float4*>(t.queries)[2 * (size_t)q] = q4;
-    }
+    auto place = [&](const Rigid& P, const InterpConst* C) {
+      if (C)
+      {
+        // Slam::RefineUndistortion's step for this keypoint (k_undistort of lsa_transform.hip, same arithmetic): the lanes
+        // of the group all work it out, the first one stores it for everything after this match
+        const float4 b4 = t.queries[2 * (size_t)q + 1];
+        Rigid U;
+        interp_eval(*C, __hiloint2double(__float_as_int(b4.y), __float_as_int(b4.x)), U);
+        double ux, uy, uz;
+        rigid_apply(U, (double)q4.x, (double)q4.y, (double)q4.z, ux, uy, uz);
+        q4.x = (float)ux; q4.y = (float)uy; q4.z = (float)uz;
+        if (gl == 0) const_cast<float4*>(t.queries)[2 * (size_t)q] = q4;
+      }
+      double wx, wy, wz;
+      rigid_apply(P, (double)q4.x, (double)q4.y, (double)q4.z, wx, wy, wz);
+      qx = (float)wx; qy = (float)wy; qz = (float)wz;
+    };
+    place(pose, ic);
     if constexpr (FUSE) { if (gl == 0) fs.q4[ql] = q4; }
-    double wx, wy, wz;
-    rigid_apply(pose, (double)q4.x, (double)q4.y, (double)q4.z, wx, wy, wz);
-    qx = (float)wx; qy = (float)wy; qz = (float)wz;
   }
   knn_key best[KMAX];
 #pragma unroll
@@ -1063,13 +1066,27 @@ __global__ __launch_bounds__(256, 4) void k_search_all(FusedArgs a)
   static_assert(kGE == kGP && kGP == kGB, "one workgroup serves 256 / G keypoints of any type");
   __shared__ SearchShared sh;
   __shared__ FitStage<QB, KC> fs;
+  // enqueued ahead of its inputs: the gate in front of this launch has left them (go == 1) or the iteration was called off.
+  // (The arguments themselves are never written: a kernel argument that is modified lives in scratch memory.)
+  if (a.gate && a.gate->go != 1ull) return;
+  // Pose and motion always go through ONE copy in LDS, whichever source they have -- the launch's own arguments or what
+  // the gate brought over: a pointer that may lead into the kernel's arguments or elsewhere, and even a choice between the
+  // two value by value, makes the compiler move pose and motion (or all 1.4 KB of arguments) into scratch memory.
+  __shared__ IcpInputs gin;
   if (a.gate)
   {
-    // the gate in front of this launch has left the inputs of the iteration (go == 1) or the iteration was called off
-    if (a.gate->go != 1ull) return;
-    a.pose = a.gate->in.pose;
-    if (a.undistort) a.ic = a.gate->in.ic;
+    constexpr int words = (int)(sizeof(IcpInputs) / 8);
+    static_assert(words <= 256, "one word per thread");
+    if ((int)threadIdx.x < words)
+      reinterpret_cast<unsigned long long*>(&gin)[threadIdx.x] = reinterpret_cast<const unsigned long long*>(&a.gate->in)[threadIdx.x];
   }
+  else if (threadIdx.x == 0)
+  {
+    gin.pose = a.pose;
+    if (a.undistort) gin.ic = a.ic;
+  }
+  __syncthreads();
+  const InterpConst* const ic = a.undistort ? &gin.ic : nullptr;
   // Hardware blocks b, b + 8, ... share an XCD (and its L2).  Every XCD gets one contiguous eighth of EVERY type's
   // blocks -- neighbouring keypoints (scan order) search a compact region of the target through one L2 -- and the
   // types with the longest searches (edges: no early out, larger k) first.
@@ -1079,13 +1096,13 @@ __global__ __launch_bounds__(256, 4) void k_search_all(FusedArgs a)
   {
     const int block = xcd * se + j;
     if (block >= a.t[0].nblocks) return;
-    search_type<KE, kGE, LSA_EDGE, FUSE, KC>(a.pose, a.t[0], block, sh, fs, a.undistort ? &a.ic : nullptr);
+    search_type<KE, kGE, LSA_EDGE, FUSE, KC>(gin.pose, a.t[0], block, sh, fs, ic);
   }
   else if (j < se + sp)
   {
     const int block = xcd * sp + (j - se);
     if (block >= a.t[1].nblocks) return;
-    search_type<KP, kGP, LSA_PLANE, FUSE, KC>(a.pose, a.t[1], block, sh, fs, a.undistort ? &a.ic : nullptr);
+    search_type<KP, kGP, LSA_PLANE, FUSE, KC>(gin.pose, a.t[1], block, sh, fs, ic);
   }
   else
   {
@@ -1094,7 +1111,7 @@ __global__ __launch_bounds__(256, 4) void k_search_all(FusedArgs a)
       const int sb = (a.t[2].nblocks + 7) / 8;
       const int block = xcd * sb + (j - se - sp);
       if (block >= a.t[2].nblocks) return;
-      search_type<KB, kGB, LSA_BLOB, FUSE, KC>(a.pose, a.t[2], block, sh, fs, a.undistort ? &a.ic : nullptr);
+      search_type<KB, kGB, LSA_BLOB, FUSE, KC>(gin.pose, a.t[2], block, sh, fs, ic);
     }
   }
 }
@@ -1103,11 +1120,7 @@ template <int KE, int KP, int KB>
 __global__ __launch_bounds__(kModelBlock) void k_model_all(FusedArgs a)
 {
   __shared__ ModelShared<KE, kModelBlock> sh;
-  if (a.gate)
-  {
-    if (a.gate->go != 1ull) return;
-    a.pose = a.gate->in.pose;
-  }
+  if (a.gate && a.gate->go != 1ull) return;  // (only reached with a gate when a type's parameters are invalid: nothing is searched for it)
   int b = blockIdx.x;
   if (b < a.t[0].mblocks) { model_type<KE, LSA_EDGE, kModelBlock>(a.pose, a.t[0], b, sh); return; }
   b -= a.t[0].mblocks;

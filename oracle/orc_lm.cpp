@@ -132,7 +132,9 @@ void EvaluateResiduals(const Residual* res, size_t n, const double w[6], bool ja
 
 bool CholeskySolve(int n, const double* A, const double* b, double* x)
 {
-  double L[36];
+  // L L^T = A, forward and backward substitution; every division by a diagonal element is a multiplication by its
+  // reciprocal, taken once (the product's device and host loops do the same: operation for operation)
+  double L[36], rinv[6];
   for (int i = 0; i < n; ++i)
     for (int j = 0; j <= i; ++j)
     {
@@ -142,22 +144,23 @@ bool CholeskySolve(int n, const double* A, const double* b, double* x)
       {
         if (!(s > 0.0) || !std::isfinite(s)) return false;
         L[i * n + i] = std::sqrt(s);
+        rinv[i] = 1.0 / L[i * n + i];
       }
       else
-        L[i * n + j] = s / L[j * n + j];
+        L[i * n + j] = s * rinv[j];
     }
   double y[6];
   for (int i = 0; i < n; ++i)
   {
     double s = b[i];
     for (int k = 0; k < i; ++k) s -= L[i * n + k] * y[k];
-    y[i] = s / L[i * n + i];
+    y[i] = s * rinv[i];
   }
   for (int i = n - 1; i >= 0; --i)
   {
     double s = y[i];
     for (int k = i + 1; k < n; ++k) s -= L[k * n + i] * x[k];
-    x[i] = s / L[i * n + i];
+    x[i] = s * rinv[i];
   }
   for (int i = 0; i < n; ++i) if (!std::isfinite(x[i])) return false;
   return true;

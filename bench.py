@@ -392,6 +392,14 @@ def main():
             for key, m in (("replay_resident", "resident"), ("causal_no_lookahead", "causal"), ("replay_announced", "announced")):
                 if m != mode:
                     out[key] = extra_leg(Replay(sequences[0][1], m), args)
+            # the causal leg again with the clouds in page-locked buffers, as a driver that registers its ring of scan
+            # buffers once would hand them over (lsa_pin_host_memory): the upload is then one DMA at the bus rate
+            for pts, _ in sequences[0][1]:
+                L.Slam.pin_cloud(pts)
+            out["causal_pinned_buffers"] = extra_leg(Replay(sequences[0][1], "causal"), args)
+            out["causal_pinned_buffers"]["frames_from"] = "host clouds in page-locked buffers (registered once, outside the timed region), nothing announced ahead"
+            for pts, _ in sequences[0][1]:
+                L.Slam.unpin_cloud(pts)
             if args.batch_sequences > 1:
                 out["batch_replay"] = batch_replay(args, local_rank)
         if world == 1 and not args.no_cpu_baseline:

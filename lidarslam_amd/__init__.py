@@ -59,7 +59,7 @@ ABI_SYMBOLS = [
     "lsa_download_match", "lsa_overlap", "lsa_accumulate", "lsa_mailbox_active", "lsa_solve", "lsa_solve_device", "lsa_solve_device_fallbacks", "lsa_solve_device_begin", "lsa_solve_device_end", "lsa_solve_device_drop", "lsa_icp_gate", "lsa_icp_post", "lsa_icp_cancel", "lsa_icp_abandon", "lsa_debug_set", "lsa_match_types_gated", "lsa_solve_device_trace", "lsa_registration_error", "lsa_selftest_math", "lsa_reset_working_keypoints", "lsa_undistort", "lsa_working_time_range",
     "lsa_working_bbox", "lsa_working_bboxes", "lsa_localization_begin", "lsa_arm_localization_boxes", "lsa_keypoint_bboxes_begin", "lsa_keypoint_bboxes_begin_interp", "lsa_keypoint_boxes_predicted_mark", "lsa_keypoint_boxes_predicted", "lsa_keypoint_time_range", "lsa_keypoint_bboxes_end", "lsa_download_transformed", "lsa_stage_transformed", "lsa_staged_transformed", "lsa_transform_frame", "lsa_profile_enable", "lsa_profile_select", "lsa_profile_reset",
     "lsa_profile_get", "lsa_slam_create", "lsa_slam_destroy", "lsa_slam_last_error", "lsa_slam_set_param",
-    "lsa_slam_get_param", "lsa_slam_reset", "lsa_slam_clear_maps", "lsa_slam_add_frame", "lsa_slam_store_frame", "lsa_slam_add_stored_frame", "lsa_slam_hint_next_stored_frame", "lsa_slam_hint_next_frame", "lsa_upload_frame_begin", "lsa_upload_frame_ready", "lsa_upload_frame_adopt", "lsa_upload_frame_forget", "lsa_collect_garbage", "lsa_uploads_adopted", "lsa_extract_prefetch_uploaded",
+    "lsa_slam_get_param", "lsa_slam_reset", "lsa_slam_clear_maps", "lsa_slam_add_frame", "lsa_slam_store_frame", "lsa_slam_add_stored_frame", "lsa_slam_hint_next_stored_frame", "lsa_slam_hint_next_frame", "lsa_upload_frame_begin", "lsa_upload_frame_ready", "lsa_upload_frame_adopt", "lsa_upload_frame_forget", "lsa_upload_robosense_frame", "lsa_pin_host_memory", "lsa_unpin_host_memory", "lsa_collect_garbage", "lsa_uploads_adopted", "lsa_extract_prefetch_uploaded",
     "lsa_slam_get_world_transform", "lsa_slam_get_covariance", "lsa_slam_get_keypoints", "lsa_slam_get_registered_frame",
     "lsa_slam_get_match_status", "lsa_slam_get_stats", "lsa_slam_context", "lsa_slam_get_latency_compensated_world_transform",
     "lsa_slam_set_world_transform_from_guess", "lsa_slam_get_trajectory", "lsa_slam_get_debug_information", "lsa_slam_get_map",
@@ -295,6 +295,18 @@ class Context:
         self._check(self.L.lsa_upload_wire_frame(self.h, rec.ctypes.data_as(C.c_void_p), n, lay, ptr(mp) if mp is not None else None,
                                                  0 if mp is None else mp.size, device_id, C.c_double(rpm), int(timestamp_first_packet)),
                     "lsa_upload_wire_frame")
+
+    def upload_robosense_frame(self, records, width, height, layout, mapping=None, device_id=0, rpm=600.0):
+        """lsa_upload_robosense_frame: the RoboSense driver's organized cloud (height lasers x width points) of records with
+        float x, y, z, intensity; layout = (point_step, off_x, off_y, off_z, off_intensity).  Returns the points kept."""
+        rec = np.ascontiguousarray(records)
+        lay = (C.c_int32 * 7)(*([int(v) for v in layout] + [0, 0]))
+        mp = np.ascontiguousarray(mapping, np.uint16) if mapping is not None else None
+        kept = C.c_int()
+        self.L.lsa_upload_robosense_frame.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_void_p]
+        self._check(self.L.lsa_upload_robosense_frame(self.h, rec.ctypes.data_as(C.c_void_p), width, height, lay, ptr(mp) if mp is not None else None,
+                                                      0 if mp is None else mp.size, device_id, rpm, C.byref(kept)), "lsa_upload_robosense_frame")
+        return kept.value
 
     def upload_polydata_frame(self, xyz, time, laser_id, intensity, mapping=None, time_to_seconds=1.0):
         """lsa_upload_polydata_frame: the arrays of a vtkPolyData frame (xyz (n, 3) float32 / float64, the others any of
@@ -683,6 +695,20 @@ class Slam:
         self._check(self.L.lsa_slam_add_stored_frame(self.h, slot, stamp_us, seq), "lsa_slam_add_stored_frame")
 
     # replay loops that hold their clouds for the whole run: the pointer of a cloud is taken once (`cloud_pointer`), not per call
+    @staticmethod
+    def pin_cloud(pts):
+        """lsa_pin_host_memory on the array's buffer (a driver's scan buffer that is handed over again and again)"""
+        L = lib()
+        L.lsa_pin_host_memory.argtypes = [C.c_void_p, C.c_size_t]
+        if L.lsa_pin_host_memory(ptr(pts), pts.nbytes) != 0:
+            raise LsaError("lsa_pin_host_memory failed")
+
+    @staticmethod
+    def unpin_cloud(pts):
+        L = lib()
+        L.lsa_unpin_host_memory.argtypes = [C.c_void_p]
+        L.lsa_unpin_host_memory(ptr(pts))
+
     @staticmethod
     def cloud_pointer(pts):
         assert pts.dtype == POINT_DTYPE

@@ -410,6 +410,17 @@ int lsa_upload_frame_forget(lsa_ctx* ctx)
   return LSA_OK;
 }
 
+int lsa_pin_host_memory(void* ptr, size_t bytes)
+{
+  if (!ptr || bytes == 0) return LSA_E_ARG;
+  return hipHostRegister(ptr, bytes, hipHostRegisterPortable) == hipSuccess ? LSA_OK : LSA_E_HIP;
+}
+int lsa_unpin_host_memory(void* ptr)
+{
+  if (!ptr) return LSA_E_ARG;
+  return hipHostUnregister(ptr) == hipSuccess ? LSA_OK : LSA_E_HIP;
+}
+
 int lsa_collect_garbage(lsa_ctx* ctx)
 {
   if (!ctx) return LSA_E_ARG;
@@ -955,6 +966,195 @@ int lsa_upload_polydata_frame(lsa_ctx* ctx, int n, const void* xyz, int xyz_type
     maybe_estimate_resolution(ctx, pts.data(), kept);
   }
   return kept == n ? 1 : 0;  // allPointsAreValid
+}
+
+// ---- RobosenseToLidarNode::Callback (ros_wrapping/lidar_conversions/src/RobosenseToLidarNode.cxx:58-125) on the device ----
+namespace
+{
+struct RsFrame
+{
+  const unsigned char* raw;
+  int step, off_x, off_y, off_z, off_i;
+  int n, width, points_per_ring, nlasers;
+  int mapping_len, device_id;
+  double rpm;
+  uint16_t mapping[kMaxRings];
+};
+__device__ __forceinline__ float rs_f32(const RsFrame& f, int i, int off) { return *reinterpret_cast<const float*>(f.raw + (size_t)i * f.step + off); }
+__device__ __forceinline__ bool rs_finite(const RsFrame& f, int i) { return isfinite(rs_f32(f, i, f.off_x)) && isfinite(rs_f32(f, i, f.off_y)) && isfinite(rs_f32(f, i, f.off_z)); }
+// the last record with finite coordinates of every chunk of 1024 (-1: none)
+__global__ __launch_bounds__(256) void k_rs_last_finite(RsFrame f, int* __restrict__ chunk_last)
+{
+  __shared__ int last;
+  if (threadIdx.x == 0) last = -1;
+  __syncthreads();
+  int mine = -1;
+  for (int q = 0; q < 4; ++q)
+  {
+    const int i = blockIdx.x * 1024 + q * 256 + threadIdx.x;
+    if (i < f.n && rs_finite(f, i)) mine = i;
+  }
+  if (mine >= 0) atomicMax(&last, mine);
+  __syncthreads();
+  if (threadIdx.x == 0) chunk_last[blockIdx.x] = last;
+}
+// chunk_last -> the last finite record IN FRONT of every chunk (exclusive running maximum; one block)
+__global__ __launch_bounds__(1024) void k_rs_carry(int* __restrict__ chunk_last, int nchunks)
+{
+  __shared__ int s[1024];
+  int run = -1;
+  for (int base = 0; base < nchunks; base += 1024)
+  {
+    const int i = base + threadIdx.x;
+    const int v = i < nchunks ? chunk_last[i] : -1;
+    s[threadIdx.x] = v;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1)
+    {
+      const int a = threadIdx.x >= (unsigned)o ? s[threadIdx.x - o] : -1;
+      __syncthreads();
+      s[threadIdx.x] = max(s[threadIdx.x], a);
+      __syncthreads();
+    }
+    const int before = threadIdx.x > 0 ? s[threadIdx.x - 1] : -1;
+    if (i < nchunks) chunk_last[i] = max(run, before);
+    run = max(run, s[1023]);
+    __syncthreads();
+  }
+}
+// A record stays when its coordinates are finite and differ from those of the last point KEPT.  A record skipped as a
+// duplicate has the coordinates of the point kept before it, so "the last point kept" and "the nearest finite record in
+// front" have the same coordinates: no sequential pass is needed.  keep[i], and how many stay per chunk.
+__global__ __launch_bounds__(256) void k_rs_keep(RsFrame f, const int* __restrict__ chunk_carry, uint8_t* __restrict__ keep, int* __restrict__ chunk_count)
+{
+  __shared__ uint8_t fin[1024];
+  __shared__ int cnt;
+  if (threadIdx.x == 0) cnt = 0;
+  const int c0 = blockIdx.x * 1024;
+  for (int q = 0; q < 4; ++q)
+  {
+    const int l = q * 256 + threadIdx.x, i = c0 + l;
+    fin[l] = (i < f.n && rs_finite(f, i)) ? 1 : 0;
+  }
+  __syncthreads();
+  int mine = 0;
+  for (int q = 0; q < 4; ++q)
+  {
+    const int l = q * 256 + threadIdx.x, i = c0 + l;
+    if (i >= f.n) continue;
+    bool k = false;
+    if (fin[l])
+    {
+      int j = l - 1;
+      while (j >= 0 && !fin[j]) --j;
+      const int prev = j >= 0 ? c0 + j : chunk_carry[blockIdx.x];
+      k = prev < 0 || !(rs_f32(f, i, f.off_x) == rs_f32(f, prev, f.off_x) && rs_f32(f, i, f.off_y) == rs_f32(f, prev, f.off_y) &&
+                        rs_f32(f, i, f.off_z) == rs_f32(f, prev, f.off_z));
+    }
+    keep[i] = k ? 1 : 0;
+    mine += k ? 1 : 0;
+  }
+  for (int o = 32; o > 0; o >>= 1) mine += __shfl_down(mine, o);
+  if ((threadIdx.x & 63) == 0 && mine) atomicAdd(&cnt, mine);
+  __syncthreads();
+  if (threadIdx.x == 0) chunk_count[blockIdx.x] = cnt;
+}
+// the points that stay, in order, as LidarPoints
+__global__ __launch_bounds__(256) void k_rs_to_points(RsFrame f, const uint8_t* __restrict__ keep, const int* __restrict__ chunk_start, float4* __restrict__ out)
+{
+  __shared__ int wave_base[4];
+  int run = chunk_start[blockIdx.x];
+  for (int q = 0; q < 4; ++q)
+  {
+    const int i = blockIdx.x * 1024 + q * 256 + threadIdx.x;
+    const bool k = i < f.n && keep[i];
+    const unsigned long long ballot = __ballot(k);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) wave_base[wv] = __popcll(ballot);
+    __syncthreads();
+    int base = run;
+    for (int w = 0; w < wv; ++w) base += wave_base[w];
+    const int batch = wave_base[0] + wave_base[1] + wave_base[2] + wave_base[3];
+    if (k)
+    {
+      const int at = base + __popcll(ballot & ((1ull << lane) - 1ull));
+      const unsigned ring = (unsigned)i / (unsigned)f.width;
+      // LaserIdMapping if given, RS16's when the input has 16 rings, otherwise the ring itself (:106-109)
+      const unsigned rs16 = ring < 8u ? ring : 23u - ring;  // {0..7, 15, 14, ..., 8}
+      const unsigned id = f.mapping_len > 0 ? (ring < (unsigned)f.mapping_len ? f.mapping[ring] : 0xffffu) : (f.nlasers == 16 ? rs16 : ring);
+      const double adv = (double)((unsigned)i % (unsigned)f.points_per_ring) / (double)f.points_per_ring;
+      const double t = (adv - 1) / f.rpm * 60.;
+      const long long bits = __double_as_longlong(t);
+      float4 a = make_float4(rs_f32(f, i, f.off_x), rs_f32(f, i, f.off_y), rs_f32(f, i, f.off_z), 1.f), b;
+      b.x = __int_as_float((int)(bits & 0xffffffffll));
+      b.y = __int_as_float((int)(bits >> 32));
+      b.z = rs_f32(f, i, f.off_i);
+      b.w = __uint_as_float((id & 0xffffu) | ((unsigned)(f.device_id & 0xff) << 16));  // laser_id, device_id, label 0
+      out[2 * (size_t)at] = a;
+      out[2 * (size_t)at + 1] = b;
+    }
+    run += batch;
+    __syncthreads();
+  }
+}
+}  // namespace
+
+int lsa_upload_robosense_frame(lsa_ctx* ctx, const void* records, int width, int height, const lsa_wire_layout_t* lay, const uint16_t* laser_id_mapping,
+                               int mapping_len, int device_id, double rpm, int* n_valid)
+{
+  if (!ctx || !records || !lay || width <= 0 || height <= 0 || lay->point_step <= 0 || mapping_len < 0 || (mapping_len > 0 && !laser_id_mapping) || !(rpm > 0.) ||
+      (long long)width * height > (1ll << 30))
+    return ctx ? ctx->fail(LSA_E_ARG, "lsa_upload_robosense_frame: empty frame or bad layout") : LSA_E_ARG;
+  if (mapping_len > kMaxRings) return ctx->fail(LSA_E_CAPACITY, "lsa_upload_robosense_frame: more than 512 entries in the laser id mapping");
+  if (mapping_len > 0 && mapping_len < height) return ctx->fail(LSA_E_ARG, "lsa_upload_robosense_frame: the laser id mapping is shorter than the cloud is high");
+  const int offs[4] = {lay->off_x, lay->off_y, lay->off_z, lay->off_intensity};
+  for (int o : offs)
+    if (o < 0 || o + 4 > lay->point_step || (o & 3)) return ctx->fail(LSA_E_ARG, "lsa_upload_robosense_frame: field outside the record or not aligned");
+  if (lay->point_step & 3) return ctx->fail(LSA_E_ARG, "lsa_upload_robosense_frame: records must be a multiple of 4 bytes");
+  LSA_HIP(ctx, hipSetDevice(ctx->device));
+  const int n = width * height;
+  int rc = ensure_capacity(ctx, n);
+  if (rc) return rc;
+  const size_t bytes = (size_t)n * lay->point_step;
+  const int nchunks = (n + 1023) / 1024;
+  const size_t off_keep = (bytes + 255) / 256 * 256, off_last = off_keep + ((size_t)n + 255) / 256 * 256,
+               off_counts = off_last + ((size_t)nchunks * sizeof(int) + 255) / 256 * 256;
+  rc = ensure_scratch(ctx, off_counts + (size_t)(nchunks + 1) * sizeof(int) + 64);
+  if (rc) return rc;
+  char* base = static_cast<char*>(ctx->scratch_out);
+  LSA_HIP(ctx, hipMemcpyAsync(base, records, bytes, hipMemcpyHostToDevice, ctx->stream));
+  RsFrame f;
+  f.raw = reinterpret_cast<const unsigned char*>(base);
+  f.step = lay->point_step; f.off_x = lay->off_x; f.off_y = lay->off_y; f.off_z = lay->off_z; f.off_i = lay->off_intensity;
+  f.n = n; f.width = width; f.nlasers = height; f.points_per_ring = n / height;
+  f.mapping_len = mapping_len; f.device_id = device_id; f.rpm = rpm;
+  if (mapping_len > 0) std::memcpy(f.mapping, laser_id_mapping, (size_t)mapping_len * sizeof(uint16_t));
+  uint8_t* keep = reinterpret_cast<uint8_t*>(base + off_keep);
+  int* last = reinterpret_cast<int*>(base + off_last);
+  int* counts = reinterpret_cast<int*>(base + off_counts);
+  {
+    ProfScope ps(ctx, "robosense_to_points", (double)bytes + (double)n * 32);
+    hipLaunchKernelGGL(k_rs_last_finite, dim3(nchunks), dim3(256), 0, ctx->stream, f, last);
+    hipLaunchKernelGGL(k_rs_carry, dim3(1), dim3(1024), 0, ctx->stream, last, nchunks);
+    hipLaunchKernelGGL(k_rs_keep, dim3(nchunks), dim3(256), 0, ctx->stream, f, last, keep, counts);
+    hipLaunchKernelGGL(k_soa_scan_counts, dim3(1), dim3(1024), 0, ctx->stream, counts, nchunks, counts + nchunks);
+    hipLaunchKernelGGL(k_rs_to_points, dim3(nchunks), dim3(256), 0, ctx->stream, f, keep, counts, reinterpret_cast<float4*>(ctx->frame_own));
+  }
+  int kept = 0;
+  LSA_HIP(ctx, hipMemcpyAsync(&kept, counts + nchunks, sizeof(kept), hipMemcpyDeviceToHost, ctx->stream));
+  LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the caller's records may go away; the size is needed now
+  if (n_valid) *n_valid = kept;
+  ctx->frame = kept > 0 ? ctx->frame_own : nullptr;
+  ctx->frame_n = kept;
+  ctx->inbox_current = -1;
+  if (kept > 0 && (ctx->az_res < 1e-6 || M_PI / 4. < ctx->az_res))
+  {
+    // first usable frame: the azimuthal resolution is estimated on the host from the converted points (SSKE.cxx:593-637)
+    std::vector<lsa_point_t> pts(kept);
+    LSA_HIP(ctx, hipMemcpy(pts.data(), ctx->frame_own, (size_t)kept * sizeof(lsa_point_t), hipMemcpyDeviceToHost));
+    maybe_estimate_resolution(ctx, pts.data(), kept);
+  }
+  return LSA_OK;
 }
 
 int lsa_frame_store_put(lsa_ctx* ctx, int slot, const lsa_point_t* pts, int n)

@@ -265,7 +265,7 @@ template <int KMAX, int G>
 __device__ __forceinline__ void scan_rows(LaneList<KMAX>& L, const RowTable& tb, int base, int nent, unsigned total, int gl,
                                           const float4* __restrict__ sorted, float qx, float qy, float qz, int* route)
 {
-  constexpr int U = KMAX > 8 ? 2 : 4;  // long lists: fewer candidates in flight, fewer registers
+  constexpr int U = KMAX >= 8 ? 2 : 4;  // edge lists (k = 8, 10, 16): fewer candidates in flight, fewer registers (with 4 the k = 8 kernel spilled 57)
   int f = base;                 // next entry of the table
   uint32_t pend = 0, roff = 0;  // the current run: candidates [.., pend) of the block, candidate c at address roff + c
   uint32_t cnext = (uint32_t)gl;
@@ -330,10 +330,10 @@ __device__ __forceinline__ void scan_rows(LaneList<KMAX>& L, const RowTable& tb,
 // as long as its longest walk.  Such a block is scanned by the WHOLE wavefront, one heavy group's after the other: the
 // group's table is in LDS, its query travels by lane reads, every lane keeps its k best and the 64 lists merge into the
 // group's slot in LDS -- where the lists all groups hold so far wait meanwhile (the caller puts them there and takes
-// them back: the registers go to the wavefront's lists).  Rare, and kept out of line: its registers are not the
-// kernel's.
+// them back: the registers go to the wavefront's lists).  Inlined: as a function of its own it saved and restored fifty
+// registers through scratch memory on every call -- 5 of the 11 MB a launch wrote (PMC WRITE_SIZE, scripts/pmc_microbench.sh).
 template <int KMAX>
-__device__ __noinline__ void scan_heavy_blocks(unsigned long long pending, int G, const RowTable tb, knn_key* save, const float4* s0, const float4* s1,
+__device__ __forceinline__ void scan_heavy_blocks(unsigned long long pending, int G, const RowTable tb, knn_key* save, const float4* s0, const float4* s1,
                                                const float4* s2, int cur, int cbase, int nent, unsigned cand, float qx, float qy, float qz, int k, int* route)
 {
   const int tid = threadIdx.x, lane = tid & 63;

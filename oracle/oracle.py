@@ -251,6 +251,20 @@ def velodyne_to_lidar(records, layout, mapping=None, device_id=0, rpm=600.0, tim
     return out, rc == 1
 
 
+def robosense_to_lidar(records, width, height, layout, mapping=None, device_id=0, rpm=600.0):
+    """RobosenseToLidarNode::Callback on the driver's organized cloud (height lasers x width points, pcl::PointXYZI records);
+    returns the LidarPoint array of the points kept."""
+    rec = np.ascontiguousarray(records)
+    out = np.zeros(max(width * height, 1), POINT_DTYPE)
+    lay = (C.c_int32 * 5)(*[int(v) for v in layout])
+    mp = np.ascontiguousarray(mapping, np.uint16) if mapping is not None else None
+    f = lib().orc_robosense_to_lidar
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_void_p]
+    n = f(rec.ctypes.data_as(C.c_void_p), width, height, lay, ptr(mp) if mp is not None else None, 0 if mp is None else mp.size, device_id, rpm, ptr(out))
+    return out[: max(n, 0)].copy()
+
+
 def polydata_to_point_cloud(xyz, time, laser_id, intensity, mapping=None, time_to_seconds=1.0):
     """vtkSlam::PolyDataToPointCloud (paraview_wrapping/Plugin/vtkLidarSlam/vtkSlam.cxx:668-707), numpy restatement:
     frame end = max of the time array (:682), stamp = end * (factor * 1e6) as an integer (:683), points with all-zero

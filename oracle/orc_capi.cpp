@@ -348,6 +348,44 @@ int orc_velodyne_to_lidar(const void* records, int n, const int32_t layout[7], c
   return isTimeValid ? 1 : 0;
 }
 
+// RobosenseToLidarNode::Callback (ros_wrapping/lidar_conversions/src/RobosenseToLidarNode.cxx:58-125) on the driver's
+// organized cloud of pcl::PointXYZI records (height = lasers, width = points per laser, row after row): records with a
+// NaN coordinate are skipped (:82-83), a record whose coordinates equal those of the last point KEPT is skipped (dual
+// return mode, :87-88), laser_id = i / width through the given mapping, or RS16's when there are 16 lasers (:106-109),
+// time from the position inside the ring (:118-119).  layout = {point_step, off_x, off_y, off_z, off_intensity}.
+// Returns the number of points kept, -1 for an empty cloud.
+int orc_robosense_to_lidar(const void* records, int width, int height, const int32_t layout[5], const uint16_t* mapping, int mapping_len, int device_id, double rpm,
+                           lsa_point_t* out)
+{
+  static const uint16_t LASER_ID_MAPPING_RS16[16] = {0, 1, 2, 3, 4, 5, 6, 7, 15, 14, 13, 12, 11, 10, 9, 8};  // (:32)
+  const long long size = (long long)width * height;
+  if (size <= 0) return -1;  // "Input RSLidar pointcloud is empty : frame ignored." (:61-65)
+  const unsigned char* raw = (const unsigned char*)records;
+  const int step = layout[0];
+  auto f32 = [&](long long i, int off) { float v; std::memcpy(&v, raw + (size_t)i * step + off, 4); return v; };
+  const unsigned int nLasers = (unsigned)height;
+  const unsigned int pointsPerRing = (unsigned)(size / nLasers);
+  const bool useLaserIdMapping = mapping_len > 0;
+  int kept = 0;
+  for (unsigned int i = 0; i < (unsigned)size; ++i)
+  {
+    const float x = f32(i, layout[1]), y = f32(i, layout[2]), z = f32(i, layout[3]);
+    if (!(std::isfinite(x) && std::isfinite(y) && std::isfinite(z))) continue;
+    if (kept > 0 && x == out[kept - 1].x && y == out[kept - 1].y && z == out[kept - 1].z) continue;  // std::equal on data[0..3)
+    lsa_point_t p;
+    std::memset(&p, 0, sizeof(p));
+    p.x = x; p.y = y; p.z = z; p.w = 1.f;
+    p.intensity = f32(i, layout[4]);
+    p.device_id = (uint8_t)device_id;
+    const uint16_t laser_id = (uint16_t)(i / (unsigned)width);
+    p.laser_id = useLaserIdMapping ? mapping[laser_id] : (nLasers == 16) ? LASER_ID_MAPPING_RS16[laser_id] : laser_id;
+    const double frameAdvancement = static_cast<double>(i % pointsPerRing) / pointsPerRing;
+    p.time = (frameAdvancement - 1) / rpm * 60.;
+    out[kept++] = p;
+  }
+  return kept;
+}
+
 // ---- full pipeline ---------------------------------------------------------------------
 void* orc_slam_create() { return new SlamHandle; }
 void orc_slam_destroy(void* h) { delete (SlamHandle*)h; }

@@ -2,7 +2,7 @@
 profiles/ (tracked): kernel stats of the rocprofv3 --kernel-trace --stats run, the PMC per-kernel
 traffic table, the bench JSON lines and the CPU sweep logs.  usage: collect_profiles.py r01"""
 import glob, json, os, shutil, subprocess, sys
-rnd = sys.argv[1] if len(sys.argv) > 1 else "r02"
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r03"
 src, dst = os.path.join("gpurun_out", rnd), "profiles"
 os.makedirs(dst, exist_ok=True)
 newest = lambda pattern: sorted(glob.glob(pattern), key=os.path.getmtime, reverse=True)  # gpurun_out keeps earlier runs too

@@ -2,7 +2,7 @@
 # End-of-round measurement on one MI355X box: bench lines for the three sensor configs, CPU baseline
 # sweeps, rocprofv3 kernel-trace summary and the two PMC passes (FETCH_SIZE / WRITE_SIZE separately).
 # usage: scripts/round_measure.sh r02   (writes gpurun_out/r02/, then run scripts/collect_profiles.py r02 here)
-R=${1:-r02}
+R=${1:-r03}
 set -o pipefail
 mkdir -p gpurun_out/$R
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT

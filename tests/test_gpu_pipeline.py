@@ -935,3 +935,69 @@ def test_the_fall_backs_of_the_bounded_device_waits_are_exercised(L, O):
         for f in range(len(frames)):
             dp, da = pose_diff(ref[f], lm[0][f])
             assert dp < 1e-7 and da < 1e-6, (block, f, dp, da)
+
+
+@pytest.mark.gpu
+def test_robosense_clouds_are_converted_as_the_driver_node_does(O, L):
+    """RobosenseToLidarNode::Callback (lidar_conversions/src/RobosenseToLidarNode.cxx:58-125) on the device: the frame the
+    context holds after lsa_upload_robosense_frame is the LidarPoint cloud the node would publish, byte for byte -- NaN
+    records dropped, the second of two identical returns dropped (also across runs of NaN and across chunk borders of
+    the kernels), RS16's own laser id mapping / a given mapping / none, the time from the position inside the ring."""
+    ctx = L.Context(0)
+    eye = np.eye(4)
+    rng = np.random.default_rng(11)
+    RS_DTYPE = np.dtype({"names": ["x", "y", "z", "intensity"], "formats": ["<f4"] * 4, "offsets": [0, 4, 8, 16], "itemsize": 32})  # pcl::PointXYZI
+    RS_LAYOUT = (32, 0, 4, 8, 16)
+
+    def organized(model, f, height, width, nan_share, dup_share):
+        """a synthetic scan arranged as the driver publishes it: one row per laser, NaN where a ray gave nothing"""
+        pts, _ = L.synth_frame(model, 1000, f)
+        cloud = np.zeros((height, width), RS_DTYPE)
+        for c in "xyz":
+            cloud[c] = np.nan
+        for r in range(height):
+            row = pts[pts["laser_id"] == (r % model)][:width]
+            for c in ("x", "y", "z", "intensity"):
+                cloud[c][r, : row.size] = row[c]
+        flat = cloud.reshape(-1)
+        n = flat.size
+        holes = rng.random(n) < nan_share
+        flat["x"][holes] = np.nan
+        runs = rng.integers(0, n - 3000, 3)
+        for s in runs:
+            flat["y"][s : s + 2500] = np.inf  # long runs without a return (they span the kernels' chunks of 1024)
+        dup = np.nonzero(rng.random(n) < dup_share)[0]
+        dup = dup[dup > 0]
+        for c in "xyz":
+            flat[c][dup] = flat[c][dup - 1]  # dual return mode: the second return equals the first
+        return flat
+
+    try:
+        mapping = rng.permutation(40).astype(np.uint16)
+        cases = [(16, 16, 1800, None, 0), (16, 16, 1800, None, 3), (16, 32, 1500, None, 0), (64, 40, 2048, mapping, 1), (16, 16, 1800, mapping[:16], 0)]
+        for f, (model, height, width, mp, dev) in enumerate(cases):
+            rec = organized(model, f, height, width, 0.05, 0.1)
+            want = O.robosense_to_lidar(rec, width, height, RS_LAYOUT, mp, dev, 600.0)
+            kept = ctx.upload_robosense_frame(rec, width, height, RS_LAYOUT, mp, dev, 600.0)
+            assert kept == want.size and 0.5 * rec.size < kept < rec.size
+            assert same_points(ctx.transform_frame(eye), want)
+        # nothing but duplicates and NaN after the first point; a cloud without a single finite point
+        rec = organized(16, 0, 16, 1800, 0.0, 0.0)
+        for c in "xyz":
+            rec[c][1:] = rec[c][0]
+        rec["x"][5::7] = np.nan
+        assert ctx.upload_robosense_frame(rec, 1800, 16, RS_LAYOUT) == 1 == O.robosense_to_lidar(rec, 1800, 16, RS_LAYOUT).size
+        rec["z"][:] = np.nan
+        assert ctx.upload_robosense_frame(rec, 1800, 16, RS_LAYOUT) == 0 == O.robosense_to_lidar(rec, 1800, 16, RS_LAYOUT).size
+        # keypoints from the driver's cloud == keypoints from the converted cloud
+        rec = organized(16, 1, 16, 1800, 0.02, 0.05)
+        want = O.robosense_to_lidar(rec, 1800, 16, RS_LAYOUT)
+        ctx.upload_robosense_frame(rec, 1800, 16, RS_LAYOUT)
+        counts = ctx.extract_keypoints()
+        ctx2 = L.Context(0)
+        ctx2.azimuthal_resolution = ctx.azimuthal_resolution
+        ctx2.upload_frame(want)
+        assert counts.tolist() == ctx2.extract_keypoints().tolist() and counts[:2].min() > 100
+        ctx2.close()
+    finally:
+        ctx.close()

@@ -460,3 +460,36 @@ def test_libm_instead_of_the_portable_trigonometry(O, L, golden, capsys):
         print("\nlibm vs lsa_pmath in the oracle:", report)
     assert report["label_or_validity_flips"] <= 2 and report["match_status_flips"] <= 2
     assert dp < 1e-6 and da < 1e-6
+
+
+def test_robosense_conversion_follows_the_driver_nodes_loop(O):
+    """orc_robosense_to_lidar against the reference's loop written out in Python, rule by rule
+    (ros_wrapping/lidar_conversions/src/RobosenseToLidarNode.cxx:78-121): NaN records skipped, a record equal to the last
+    point KEPT skipped, laser_id = i / width through RS16's mapping when the cloud has 16 rows, time from i mod (size / rows)"""
+    RS = np.dtype({"names": ["x", "y", "z", "intensity"], "formats": ["<f4"] * 4, "offsets": [0, 4, 8, 16], "itemsize": 32})
+    rng = np.random.default_rng(0)
+    RS16 = [0, 1, 2, 3, 4, 5, 6, 7, 15, 14, 13, 12, 11, 10, 9, 8]
+    for h, w, mapping in ((16, 50, None), (12, 40, None), (16, 30, list(range(15, -1, -1)))):
+        rec = np.zeros(h * w, RS)
+        for c in ("x", "y", "z", "intensity"):
+            rec[c] = rng.normal(size=h * w).astype(np.float32)
+        rec["x"][rng.random(h * w) < 0.1] = np.nan
+        d = np.nonzero(rng.random(h * w) < 0.2)[0]
+        d = d[d > 0]
+        for c in "xyz":
+            rec[c][d] = rec[c][d - 1]
+        out = O.robosense_to_lidar(rec, w, h, (32, 0, 4, 8, 16), mapping, 2, 600.0)
+        kept = []
+        for i in range(h * w):
+            p = rec[i]
+            if not (np.isfinite(p["x"]) and np.isfinite(p["y"]) and np.isfinite(p["z"])):
+                continue
+            if kept and kept[-1][0] == p["x"] and kept[-1][1] == p["y"] and kept[-1][2] == p["z"]:
+                continue
+            ring = i // w
+            lid = mapping[ring] if mapping is not None else (RS16[ring] if h == 16 else ring)
+            kept.append((p["x"], p["y"], p["z"], lid, ((i % w) / w - 1) / 600.0 * 60.0, p["intensity"]))
+        assert len(kept) == out.size
+        for k, (x, y, z, lid, t, inten) in enumerate(kept):
+            assert out["x"][k] == x and out["y"][k] == y and out["z"][k] == z and out["laser_id"][k] == lid and out["time"][k] == t
+            assert out["intensity"][k] == inten and out["device_id"][k] == 2 and out["w"][k] == 1.0

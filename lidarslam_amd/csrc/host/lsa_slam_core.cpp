@@ -1666,7 +1666,7 @@ int SlamCore::GetRegisteredFrame(std::vector<lsa_point_t>& out)
   X("EdgeSaliencyThreshold", ExtractParams.edge_saliency_threshold, float)                             \
   X("EdgeIntensityGapThreshold", ExtractParams.edge_intensity_gap_threshold, float)
 
-// The maps live either in the device grids or in the host grids (CENTROID sampling, "MapsOnDevice" = 0): a setter that
+// The maps live either in the device grids or in the host grids ("MapsOnDevice" = 0): a setter that
 // moves them from one side to the other takes the points along, the way RollingGrid's own geometry setters do
 // (prevMap = Get(); Clear(); Add(prevMap), RollingGrid.cxx:59-88: counts start again, the points keep their place).
 int SlamCore::MigrateMaps(bool fromDevice)

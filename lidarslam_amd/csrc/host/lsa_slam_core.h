@@ -206,7 +206,7 @@ public:
   std::shared_ptr<RollingGrid> LocalMaps[3];
   // The same three maps resident on the device (lsa_device_grid: SURVEY.md 8f-1).  "MapsOnDevice" (default): keyframes
   // are inserted and sub-maps extracted without leaving the device -- no staging of the keypoints in host memory, no map
-  // threads, no sub-map upload.  Off, or with CENTROID sampling (kept on the host): the host containers above.  Both
+  // threads, no sub-map upload.  Off: the host containers above.  Both
   // hand their points out in key order ("OrderedMaps"), so the two give the same sub-maps and the same poses.
   lsa_device_grid* DevMaps[3] = {nullptr, nullptr, nullptr};
   bool MapsOnDevice = true;
@@ -224,7 +224,7 @@ public:
   bool SpecGridsTogether = true;  // the search grids of the sub-maps extracted ahead of time built by one sequence of launches
   bool DevSpec[3] = {false, false, false};
   bool OrderedMaps = true;
-  bool DeviceMapsInUse() const { return MapsOnDevice && DevMaps[0] && LocalMaps[0]->GetSampling() != SamplingMode::CENTROID; }
+  bool DeviceMapsInUse() const { return MapsOnDevice && DevMaps[0]; }  // (every sampling mode: CENTROID since round 3)
   int MigrateMaps(bool fromDevice);
   int SetParamValue(const std::string& name, double v);
   int GetMap(int k, bool clean, std::vector<lsa_point_t>& out);

@@ -322,6 +322,8 @@ namespace lsa
   } while (0)
 
 int lm_cache_capacity();
+extern std::atomic<int> g_live_contexts;  // contexts of this process (lsa_lm.hip: a solve's share of the chip)
+int lm_blocks_share();
 inline void retire_dev(lsa_ctx* ctx, void* p)
 {
   if (!p) return;

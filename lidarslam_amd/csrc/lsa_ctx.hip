@@ -456,6 +456,7 @@ int lsa_ctx_create(int device_id, lsa_ctx** out)
   if (hipSetDevice(device_id) != hipSuccess) return LSA_E_HIP;
   lsa_ctx* ctx = new lsa_ctx;
   ctx->device = device_id;
+  g_live_contexts.fetch_add(1, std::memory_order_relaxed);
   // EXACTLY THREE streams per context, created together: the registration's, the look-ahead's, the copies'.  The runtime
   // deals streams to the process's four hardware queues in creation order (GPU_MAX_HW_QUEUES = 4, round robin), and two
   // streams on one queue wait for each other's kernels.  Three in a row sit on three different queues, and the next
@@ -463,7 +464,7 @@ int lsa_ctx_create(int device_id, lsa_ctx** out)
   // on the same queue (8 sequences side by side: 1 200 frames/s against 2 000), and any further stream of a context
   // shares the registration's queue (a stream for the maps: 765 against 890 frames/s for one sequence).  The side streams
   // of the staged (non-fused) match are created when that path is first used.
-  if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return LSA_E_HIP; }
+  if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { g_live_contexts.fetch_sub(1, std::memory_order_relaxed); delete ctx; return LSA_E_HIP; }
   bool ok = true;
   ok &= hipStreamCreateWithFlags(&ctx->prefetch_stream, hipStreamNonBlocking) == hipSuccess;
   ok &= hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking) == hipSuccess;
@@ -603,6 +604,7 @@ void lsa_ctx_destroy(lsa_ctx* ctx)
   for (int k = 0; k < 6; ++k)
     if (ctx->tstage[k]) (void)hipHostFree(ctx->tstage[k]);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  g_live_contexts.fetch_sub(1, std::memory_order_relaxed);
   delete ctx;
 }
 

@@ -574,7 +574,7 @@ __device__ __forceinline__ void d_merge_runs(int bx, const u64* __restrict__ key
 // a new one is left at the thread's own place in `fresh`, flagged, with its rank among the new ones of the block.
 __device__ __forceinline__ void d_add_fold(int bx, const float4* __restrict__ batch, int n, const u64* __restrict__ skeys, const unsigned* __restrict__ sorder,
                                                   GridParams p, int* __restrict__ st, int use_box, MapView map, MapView fresh, int* __restrict__ fresh_flag,
-                                                  int* __restrict__ fresh_chunks, int fixed, double time)
+                                                  int* __restrict__ fresh_chunks, int fixed, double time, int* __restrict__ vrank = nullptr, bool only_flags = false)
 {
   __shared__ int wave_cnt[4];
   if (bx * 256 >= n) return;  // (a launch shared with a bigger batch)
@@ -638,10 +638,38 @@ __device__ __forceinline__ void d_add_fold(int bx, const float4* __restrict__ ba
       }
     }
     bool counted = false;
+    // CENTROID (:263-297).  The reference keeps, per voxel that an earlier point of this Add fell into, the running mean of
+    // those points -- and, INSIDE its loop over the points, pulls EVERY such voxel's point towards its mean once per point
+    // of the whole cloud that gets as far as the end of the loop body ((point * count + mean) / (count + 1), :282-297).  A
+    // voxel's point therefore depends on how many such points lie between and behind its own in arrival order: vrank.
+    float mean[3] = {0.f, 0.f, 0.f};
+    unsigned mean_count = 0;
+    bool in_mean = false;
+    int prev_rank = -1;
+    auto pull = [&](int times) {
+      const float c = (float)count, c1 = (float)(count + 1);
+      for (int it = 0; it < times; ++it)
+      {
+        const float nx = (va.x * c + mean[0]) / c1, ny = (va.y * c + mean[1]) / c1, nz = (va.z * c + mean[2]) / c1;
+        if (nx == va.x && ny == va.y && nz == va.z) break;  // a fixed point of the step: nothing moves any more
+        va.x = nx; va.y = ny; va.z = nz;
+      }
+    };
     for (int j = j0; j < n && skeys[j] == key; ++j)
     {
       const unsigned src = sorder[j];
       const float4 a = batch[2 * (size_t)src], b = batch[2 * (size_t)src + 1];
+      if (only_flags)
+      {
+        // (first of the CENTROID launches) does this point get to the end of the loop body?  Not when its voxel holds a
+        // fixed point (:219-220) -- from before, or because an earlier point of this very call made it one
+        bool through = true;
+        if (!have) { have = true; vb.w = __uint_as_float((fixed ? 1u : 0u) << 24); }
+        else if (((__float_as_uint(vb.w) >> 24) & 0xffu) == 1) through = false;
+        else vb.w = __uint_as_float((__float_as_uint(vb.w) & 0x00ffffffu) | ((fixed ? 1u : 0u) << 24));
+        vrank[src] = through ? 1 : 0;
+        continue;
+      }
       if (!have)
       {
         va = a; vb = b; have = true; changed = true;  // new voxel: the point as it is (:206-212)
@@ -650,6 +678,15 @@ __device__ __forceinline__ void d_add_fold(int bx, const float4* __restrict__ ba
       {
         const unsigned label = (__float_as_uint(vb.w) >> 24) & 0xffu;
         if (label == 1) continue;  // the voxel holds a fixed point: nothing of this point is taken, not even its time (:219-220)
+        if (p.sampling == 4)
+        {
+          // the pulls of the points of other voxels since this voxel's last one, then this point into the mean
+          if (in_mean) pull(vrank[src] - prev_rank - 1);
+          const float mc = (float)mean_count, mc1 = (float)(mean_count + 1);
+          mean[0] = (mean[0] * mc + a.x) / mc1; mean[1] = (mean[1] * mc + a.y) / mc1; mean[2] = (mean[2] * mc + a.z) / mc1;
+          ++mean_count;
+          in_mean = true;
+        }
         if (p.sampling == 1) { va = a; vb = b; changed = true; }                       // LAST
         else if (p.sampling == 2) { if (b.z > vb.z) { va = a; vb = b; changed = true; } }  // MAX_INTENSITY
         else if (p.sampling == 3)
@@ -664,6 +701,11 @@ __device__ __forceinline__ void d_add_fold(int bx, const float4* __restrict__ ba
           if (sqrtf(d1x * d1x + (d1y * d1y + d1z * d1z)) < sqrtf(d0x * d0x + (d0y * d0y + d0z * d0z))) { va = a; vb = b; changed = true; }
         }
       }
+      if (p.sampling == 4)
+      {
+        if (in_mean) pull(1);  // this point's own turn of the loop at :282-297
+        prev_rank = vrank[src];
+      }
       // voxel.point.time = currentTime; label = fixed (:300-306); one count per Add call (:307-311)
       const long long tb = __double_as_longlong(time);
       vb.x = __int_as_float((int)(tb & 0xffffffffll));
@@ -671,6 +713,9 @@ __device__ __forceinline__ void d_add_fold(int bx, const float4* __restrict__ ba
       vb.w = __uint_as_float((__float_as_uint(vb.w) & 0x00ffffffu) | ((fixed ? 1u : 0u) << 24));
       if (!counted) { ++count; counted = true; }
     }
+    if (!only_flags)
+    {
+    if (p.sampling == 4 && in_mean) pull(vrank[n] - prev_rank - 1);  // the points of the cloud behind this voxel's last one
     if (exists)
     {
       map.pts[2 * (size_t)at] = va;
@@ -686,6 +731,13 @@ __device__ __forceinline__ void d_add_fold(int bx, const float4* __restrict__ ba
       fresh.count[j0] = count;
     }
     if (changed) st[kStUpdated] = 1;
+    }
+  }
+  if (only_flags)
+  {
+    // points outside the grid (no key) never enter the loop body
+    if (j0 < n && key == kNoKey) vrank[sorder[j0]] = 0;
+    return;
   }
   // rank of every place among the block's new voxels (the places that hold none get the rank the next one would)
   const u64 ballot = __ballot(is_fresh);
@@ -805,6 +857,7 @@ struct AddOne
   unsigned *border, *sorder;
   MapView map, fresh, dst;
   int *old_local, *old_chunks, *fresh_flag, *fresh_chunks;
+  int* vrank;
   int ochunks;
 };
 struct AddBatch
@@ -823,7 +876,41 @@ __global__ __launch_bounds__(256) void k_merge_runs(AddBatch b) { const AddOne& 
 __global__ __launch_bounds__(256) void k_add_fold(AddBatch b)
 {
   const AddOne& A = b.a[blockIdx.y];
-  d_add_fold(blockIdx.x, A.batch, A.n, A.skeys, A.sorder, A.p, A.st, A.use_box, A.map, A.fresh, A.fresh_flag, A.fresh_chunks, A.fixed, A.time);
+  d_add_fold(blockIdx.x, A.batch, A.n, A.skeys, A.sorder, A.p, A.st, A.use_box, A.map, A.fresh, A.fresh_flag, A.fresh_chunks, A.fixed, A.time, A.vrank, false);
+}
+// CENTROID sampling only, in front of the fold: which points of the batch get to the end of the loop body (k_add_flags: the
+// fold's own walk over the runs, nothing written but the flags), and how many of them lie in front of every point in
+// ARRIVAL order (k_add_vscan: exclusive scan in place, one workgroup per map; [n] = all of them)
+__global__ __launch_bounds__(256) void k_add_flags(AddBatch b)
+{
+  const AddOne& A = b.a[blockIdx.y];
+  if (A.p.sampling != 4) return;
+  d_add_fold(blockIdx.x, A.batch, A.n, A.skeys, A.sorder, A.p, A.st, A.use_box, A.map, A.fresh, A.fresh_flag, A.fresh_chunks, A.fixed, A.time, A.vrank, true);
+}
+__global__ __launch_bounds__(1024) void k_add_vscan(AddBatch b)
+{
+  const AddOne& A = b.a[blockIdx.y];
+  if (A.p.sampling != 4) return;
+  __shared__ int s[1024];
+  int run = 0;
+  for (int base = 0; base < A.n; base += 1024)
+  {
+    const int i = base + threadIdx.x;
+    const int v = i < A.n ? A.vrank[i] : 0;
+    s[threadIdx.x] = v;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1)
+    {
+      const int a = threadIdx.x >= (unsigned)o ? s[threadIdx.x - o] : 0;
+      __syncthreads();
+      s[threadIdx.x] += a;
+      __syncthreads();
+    }
+    if (i < A.n) A.vrank[i] = run + s[threadIdx.x] - v;
+    run += s[1023];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) A.vrank[A.n] = run;
 }
 __global__ __launch_bounds__(256) void k_add_merge(AddBatch b)
 {
@@ -1005,6 +1092,7 @@ struct lsa_device_grid
   u64 *bkeys = nullptr, *skeys = nullptr;
   unsigned *border = nullptr, *sorder = nullptr;
   int *heads = nullptr, *fresh_flag = nullptr, *chunks = nullptr;
+  int* vrank = nullptr;  // CENTROID sampling: how many points of the batch that take part in the loop body lie in front of every point (arrival order), [n] = all
   int* old_local = nullptr;    // [cap] rank of an old voxel among the survivors of its chunk (Add)
   MapView fresh = {};
   int chunk_cap = 0;
@@ -1129,7 +1217,7 @@ int ensure_batch(lsa_device_grid* g, int n)
   if (n <= g->bcap) return LSA_OK;
   const int cap = std::max(n + n / 4, 1 << 14);
   auto fr = [g](void* p) { retire_dev(g->ctx, p); };
-  fr(g->batch); fr(g->bkeys); fr(g->skeys); fr(g->border); fr(g->sorder); fr(g->heads); fr(g->fresh_flag);
+  fr(g->batch); fr(g->bkeys); fr(g->skeys); fr(g->border); fr(g->sorder); fr(g->heads); fr(g->fresh_flag); fr(g->vrank);
   retire_view(g, g->fresh);
   G_HIP(hipMalloc((void**)&g->batch, (size_t)cap * 2 * sizeof(float4)));
   G_HIP(hipMalloc((void**)&g->bkeys, (size_t)cap * sizeof(u64)));
@@ -1138,6 +1226,7 @@ int ensure_batch(lsa_device_grid* g, int n)
   G_HIP(hipMalloc((void**)&g->sorder, (size_t)cap * sizeof(unsigned)));
   G_HIP(hipMalloc((void**)&g->heads, (size_t)cap * sizeof(int)));
   G_HIP(hipMalloc((void**)&g->fresh_flag, (size_t)cap * sizeof(int)));
+  G_HIP(hipMalloc((void**)&g->vrank, ((size_t)cap + 1) * sizeof(int)));
   int rc = alloc_view(g, g->fresh, cap);
   if (rc) return rc;
   g->bcap = cap;
@@ -1208,7 +1297,7 @@ int add_batches(lsa_device_grid* const* gs, const int* ns, int count, bool fixed
     A.p = params_of(gi); A.st = gi->st;
     A.bkeys = gi->bkeys; A.skeys = gi->skeys; A.border = gi->border; A.sorder = gi->sorder;
     A.map = gi->buf[gi->cur]; A.dst = gi->buf[1 - gi->cur]; A.fresh = gi->fresh;
-    A.old_local = gi->old_local; A.old_chunks = gi->chunks; A.fresh_flag = gi->fresh_flag; A.fresh_chunks = gi->heads;
+    A.old_local = gi->old_local; A.old_chunks = gi->chunks; A.fresh_flag = gi->fresh_flag; A.fresh_chunks = gi->heads; A.vrank = gi->vrank;
     A.ochunks = std::max((gi->n_upper + 1023) / 1024, 1);
     kmax = std::max(kmax, (ns[i] + 255) / 256);
     omax = std::max(omax, A.ochunks);
@@ -1227,6 +1316,13 @@ int add_batches(lsa_device_grid* const* gs, const int* ns, int count, bool fixed
     hipLaunchKernelGGL(k_add_keys, dim3(kmax + omax, y), dim3(256), 0, st, b);
     hipLaunchKernelGGL(k_sort_runs, dim3(runs, y), dim3(1024), 0, st, b);
     hipLaunchKernelGGL(k_merge_runs, dim3(kmax, y), dim3(256), 0, st, b);
+    bool centroid = false;
+    for (int i = 0; i < count; ++i) centroid = centroid || b.a[i].p.sampling == 4;
+    if (centroid)
+    {
+      hipLaunchKernelGGL(k_add_flags, dim3(kmax, y), dim3(256), 0, st, b);
+      hipLaunchKernelGGL(k_add_vscan, dim3(1, y), dim3(1024), 0, st, b);
+    }
     hipLaunchKernelGGL(k_add_fold, dim3(kmax, y), dim3(256), 0, st, b);
     hipLaunchKernelGGL(k_add_merge, dim3(omax + kmax, y), dim3(256), lds, st, b);
     hipLaunchKernelGGL(k_add_commit, dim3(1, y), dim3(64), 0, st, b);
@@ -1295,7 +1391,7 @@ void lsa_device_grid_destroy(lsa_device_grid* g)
   (void)hipStreamSynchronize(g->ctx->stream);  // a match may still read a sub-map: nothing of the grid is in use after this
   free_view(g->buf[0]); free_view(g->buf[1]); free_view(g->fresh);
   auto fr = [](void* p) { if (p) (void)hipFree(p); };
-  fr(g->st); fr(g->batch); fr(g->bkeys); fr(g->skeys); fr(g->border); fr(g->sorder); fr(g->heads); fr(g->fresh_flag); fr(g->chunks); fr(g->old_local);
+  fr(g->st); fr(g->batch); fr(g->bkeys); fr(g->skeys); fr(g->border); fr(g->sorder); fr(g->heads); fr(g->fresh_flag); fr(g->vrank); fr(g->chunks); fr(g->old_local);
   if (g->host_st) (void)hipHostFree(g->host_st);
   if (g->host_sub) (void)hipHostFree(g->host_sub);
   if (g->host_ahead) (void)hipHostFree(g->host_ahead);
@@ -1412,7 +1508,6 @@ int lsa_device_grid_add(lsa_device_grid* g, const lsa_point_t* pts, int n, int f
 {
   if (!g || n < 0 || (!pts && n > 0)) return g ? g->ctx->fail(LSA_E_ARG, "lsa_device_grid_add: bad argument") : LSA_E_ARG;
   if (n == 0) return LSA_OK;  // "Pointcloud is empty, voxel grid not updated."
-  if (g->Sampling == 4) return g->ctx->fail(LSA_E_STATE, "lsa_device_grid_add: CENTROID sampling is kept on the host grid");
   G_HIP(hipSetDevice(g->ctx->device));
   int rc = ensure_batch(g, n);
   if (rc) return rc;
@@ -1428,7 +1523,6 @@ int lsa_device_grid_add(lsa_device_grid* g, const lsa_point_t* pts, int n, int f
 int lsa_device_grid_stage_keypoints(lsa_device_grid* g, int set, int type, const double pose[16])
 {
   if (!g || !pose || set < 0 || set > 2 || type < 0 || type > 2) return g ? g->ctx->fail(LSA_E_ARG, "lsa_device_grid_stage_keypoints: bad argument") : LSA_E_ARG;
-  if (g->Sampling == 4) return g->ctx->fail(LSA_E_STATE, "lsa_device_grid_stage_keypoints: CENTROID sampling is kept on the host grid");
   lsa_ctx* ctx = g->ctx;
   const int n = ctx->kp_n[set][type];
   g->staged = 0;

@@ -609,6 +609,24 @@ const char* const kMessages[] = {"", "not enough matches", "gradient tolerance (
 
 namespace lsa
 {
+std::atomic<int> g_live_contexts{0};
+// workgroups one solve may use so that the solves that can run at once all fit on the chip
+int lm_blocks_share()
+{
+  static const int cus = [] {
+    hipDeviceProp_t prop;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
+    return std::max(prop.multiProcessorCount, 8);
+  }();
+  static const int queues = [] {
+    const char* e = std::getenv("GPU_MAX_HW_QUEUES");
+    const int q = e ? std::atoi(e) : 4;  // the runtime's default
+    return std::max(q, 1);
+  }();
+  const int side_by_side = std::max(1, std::min(g_live_contexts.load(std::memory_order_relaxed), queues));
+  return std::max(cus / side_by_side, 8);
+}
 InterpConst make_interp_const(const double H0[16], const double H1[16], double t0, double t1);  // lsa_transform.hip
 // how many 256-thread layers of residual blocks (34 KB each) the solve kernel may keep in LDS beside its own data
 int lm_cache_capacity()
@@ -654,7 +672,10 @@ int lsa_solve_device_begin(lsa_ctx* ctx, unsigned type_mask, const double prior[
   const unsigned out_tag = (unsigned)(++ctx->lm_seq);
   // about two residual blocks per thread (measured: 1024 per workgroup 63 us a solve, 512: 56, 256: 58 -- fewer blocks per thread
   // shorten the evaluation, more workgroups lengthen the exchange), never more workgroups than the exchange has slots for
-  const int nb = std::min(std::max((total + ctx->lm_records - 1) / ctx->lm_records, 1), std::min(ctx->lm_blocks, kLmBlocksMax));
+  // ... and never more than this solve's share of the chip: the workgroups exchange their sums by waiting for each other,
+  // so ALL of them have to be resident (512 threads of 250 registers: one workgroup per CU), also when the solves of
+  // other contexts of this process run beside this one -- as many at once as the process has hardware queues
+  const int nb = std::min(std::max((total + ctx->lm_records - 1) / ctx->lm_records, 1), std::min(std::min(ctx->lm_blocks, kLmBlocksMax), lm_blocks_share()));
   // the thread's first residual blocks stay in LDS between the evaluations (17 doubles each): as many per thread as
   // the block's share needs, as many as the LDS holds beside the kernel's own 34 KB (the rest is read again)
   const int per_thread = (total + nb * kLmThreads - 1) / (nb * kLmThreads);

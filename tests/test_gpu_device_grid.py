@@ -38,7 +38,7 @@ def same_submap(g, o, mn=None, mx=None, min_nb=-1):
     return na
 
 
-@pytest.mark.parametrize("sampling", [0, 1, 2, 3])
+@pytest.mark.parametrize("sampling", [0, 1, 2, 3, 4])  # FIRST, LAST, MAX_INTENSITY, CENTER_POINT, CENTROID
 @pytest.mark.parametrize("min_frames", [0, 3])
 def test_add_roll_and_submaps_follow_the_oracle(ctx, sampling, min_frames):
     rng = np.random.default_rng(100 + sampling * 7 + min_frames)
@@ -182,8 +182,28 @@ def test_changing_the_geometry_puts_the_points_back(ctx):
     assert g.size() == o.size() == 0
     with pytest.raises(L.LsaError):
         g.set("NoSuchParameter", 1.0)
-    with pytest.raises(L.LsaError):
-        L.DeviceGrid(ctx, Sampling=4).add(pts)  # CENTROID stays on the host grid
+    g.close()
+
+
+def test_centroid_sampling_with_the_reference_loop_quirk(ctx):
+    """CENTROID (RollingGrid.cxx:263-297): the block that pulls every touched voxel towards the mean of its new points sits
+    INSIDE the loop over the cloud, so a voxel's point depends on how many points of the cloud follow its own -- in arrival
+    order, whatever voxel they fall into.  Dense batches (many points per leaf voxel, thousands of points behind a voxel's
+    last one), fixed keyframes, points outside the grid, a batch that only revisits old voxels: byte for byte."""
+    rng = np.random.default_rng(21)
+    g, o = pair(ctx, GridSize=10, VoxelResolution=6.0, LeafSize=0.8, Sampling=4)
+    centre = np.zeros(3)
+    for step in range(10):
+        n = (300, 5000, 20000, 257, 4097, 1)[step % 6]
+        pts = cloud(rng, n, centre, spread=6.0 if step % 3 else 40.0, t=step * 0.1, labels=True)  # spread 40: most points outside the grid
+        for m in (g, o):
+            m.add(pts, fixed=(step == 4), time=step * 0.1, roll=(step in (0, 7)))
+        same_state(g, o)
+    # the same cloud again: no new voxel, every point pulls
+    for m in (g, o):
+        m.add(pts, time=1.5, roll=False)
+    same_state(g, o)
+    assert g.size() > 500
     g.close()
 
 

@@ -176,16 +176,15 @@ def test_pipeline_modes(L, O, params):
 def test_map_maintenance_beside_the_device_work(L, O, params, on_device):
     """30 frames against the oracle's maps.  Maps on the device (the default): keyframes are keyed, sorted, folded and
     merged into the sorted voxel arrays by kernels, the sub-maps are compacted straight into the kNN target.  Maps on
-    the host ("MapsOnDevice" = 0, and CENTROID sampling always): the insertions run on worker threads beside the next
+    the host ("MapsOnDevice" = 0): the insertions run on worker threads beside the next
     frame, the sub-maps are extracted ahead of time under the predicted pose.  Either way the trajectory must not
     know (same maps, same sub-map order), and map and sub-map are the oracle's, byte for byte."""
     sg, so, poses, _ = run_both(L, O, 8, 30, check_keypoints=False, MapsOnDevice=on_device, **params)
-    centroid = params.get("VoxelGridSamplingMode") == 4
-    assert sg.get_param("DeviceMapsInUse") == (1.0 if on_device and not centroid else 0.0)
+    assert sg.get_param("DeviceMapsInUse") == (1.0 if on_device else 0.0)  # every sampling mode, CENTROID too (round 3)
     if params.get("MapUpdate", 2) != 0:
         # sub-maps extracted ahead of time for the predicted boxes were kept (host maps: by the map workers; device maps:
         # on the look-ahead stream -- not for decaying maps, whose ClearOldPoints comes first in the localization)
-        decaying_on_device = on_device and not centroid and "VoxelGridDecayingThreshold" in params
+        decaying_on_device = on_device and "VoxelGridDecayingThreshold" in params
         assert (sg.get_param("SubMapSpeculationHits") > 0) == (not decaying_on_device)
     for k in range(3):
         assert sg.map(k).tobytes() == so.map(k).tobytes()
@@ -770,7 +769,7 @@ def test_polydata_arrays_upload_follows_the_paraview_filter(O, L):
 
 
 def test_the_maps_follow_a_setter_that_moves_them_between_device_and_host(L, O):
-    """"MapsOnDevice" or CENTROID sampling set in the middle of a sequence: the points change sides (as RollingGrid's own
+    """"MapsOnDevice" set in the middle of a sequence: the points change sides (as RollingGrid's own
     geometry setters put them back, counts start again) and the sequence goes on -- close to the trajectory that never
     switched, with the same number of map points right after the move"""
     ref = L.Slam(0, EgoMotion=3)

@@ -306,6 +306,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    ctx_event_overhead = ctx.profile_event_overhead_us()
     kernels = [] if args.no_profile else ctx.profile_stats()
     ctx.profile(False)
     extra = {"uploads_taken_over": slam.get_param("UploadsAdopted"), "extractions_taken_over": slam.get_param("LookaheadAdopted"),
@@ -375,6 +376,7 @@ def main():
                 "algorithmic_bytes_per_launch": dom["bytes"] / max(dom["launches"], 1),
                 "launches_per_frame": dom["launches"] / n,
                 "chosen_by": "largest summed launch time by kernel family over the warm-up frames",
+                "event_overhead_us": ctx_event_overhead,  # what a pair of events measures around nothing: taken off every launch
             }
             out["kernels_from"] = "timed region" if table is kernels else "warm-up frames (every scope timed)"
             out["kernels"] = {

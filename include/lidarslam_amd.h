@@ -556,6 +556,9 @@ typedef struct lsa_kernel_stat_t
   double bytes;   /* algorithmic bytes summed over the launches */
 } lsa_kernel_stat_t;
 int lsa_profile_enable(lsa_ctx* ctx, int on);
+/* What a pair of HIP events measures around nothing on the context's stream [us] (calibrated when profiling is switched
+ * on; every scope's time is what its events measure minus this). */
+double lsa_profile_event_overhead_us(const lsa_ctx* ctx);
 /* Events cost a few microseconds per scope on a path that is launch bound: time only the scope `scope`,
  * and only one launch in `every` of it (all launches are counted; total_ms is scaled to all of them). */
 int lsa_profile_select(lsa_ctx* ctx, const char* scope, int every);

@@ -24,7 +24,7 @@
 #ifndef LSA_PMATH_H
 #define LSA_PMATH_H
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define LSA_HD __host__ __device__ inline
 #else
 #define LSA_HD static inline

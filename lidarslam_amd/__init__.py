@@ -59,7 +59,7 @@ ABI_SYMBOLS = [
     "lsa_download_match", "lsa_overlap", "lsa_accumulate", "lsa_mailbox_active", "lsa_solve", "lsa_solve_device", "lsa_solve_device_fallbacks", "lsa_solve_device_begin", "lsa_solve_device_end", "lsa_solve_device_drop", "lsa_icp_gate", "lsa_icp_post", "lsa_icp_cancel", "lsa_icp_abandon", "lsa_debug_set", "lsa_match_types_gated", "lsa_solve_device_trace", "lsa_registration_error", "lsa_selftest_math", "lsa_reset_working_keypoints", "lsa_undistort", "lsa_working_time_range",
     "lsa_working_bbox", "lsa_working_bboxes", "lsa_localization_begin", "lsa_arm_localization_boxes", "lsa_keypoint_bboxes_begin", "lsa_keypoint_bboxes_begin_interp", "lsa_keypoint_boxes_predicted_mark", "lsa_keypoint_boxes_predicted", "lsa_keypoint_time_range", "lsa_keypoint_bboxes_end", "lsa_download_transformed", "lsa_stage_transformed", "lsa_staged_transformed", "lsa_transform_frame", "lsa_profile_enable", "lsa_profile_select", "lsa_profile_reset",
     "lsa_profile_get", "lsa_slam_create", "lsa_slam_destroy", "lsa_slam_last_error", "lsa_slam_set_param",
-    "lsa_slam_get_param", "lsa_slam_reset", "lsa_slam_clear_maps", "lsa_slam_add_frame", "lsa_slam_store_frame", "lsa_slam_add_stored_frame", "lsa_slam_hint_next_stored_frame", "lsa_slam_hint_next_frame", "lsa_upload_frame_begin", "lsa_upload_frame_ready", "lsa_upload_frame_adopt", "lsa_upload_frame_forget", "lsa_upload_robosense_frame", "lsa_pin_host_memory", "lsa_unpin_host_memory", "lsa_collect_garbage", "lsa_uploads_adopted", "lsa_extract_prefetch_uploaded",
+    "lsa_slam_get_param", "lsa_slam_reset", "lsa_slam_clear_maps", "lsa_slam_add_frame", "lsa_slam_store_frame", "lsa_slam_add_stored_frame", "lsa_slam_hint_next_stored_frame", "lsa_slam_hint_next_frame", "lsa_upload_frame_begin", "lsa_upload_frame_ready", "lsa_upload_frame_adopt", "lsa_upload_frame_forget", "lsa_profile_event_overhead_us", "lsa_upload_robosense_frame", "lsa_pin_host_memory", "lsa_unpin_host_memory", "lsa_collect_garbage", "lsa_uploads_adopted", "lsa_extract_prefetch_uploaded",
     "lsa_slam_get_world_transform", "lsa_slam_get_covariance", "lsa_slam_get_keypoints", "lsa_slam_get_registered_frame",
     "lsa_slam_get_match_status", "lsa_slam_get_stats", "lsa_slam_context", "lsa_slam_get_latency_compensated_world_transform",
     "lsa_slam_set_world_transform_from_guess", "lsa_slam_get_trajectory", "lsa_slam_get_debug_information", "lsa_slam_get_map",
@@ -515,6 +515,11 @@ class Context:
         """lsa_match_types_gated: 0 enqueued behind the gate, 1 this match cannot wait behind a gate"""
         self.L.lsa_match_types_gated.argtypes = [C.c_void_p, C.c_int, C.c_uint, C.c_int, C.c_void_p, C.c_int]
         return self._check(self.L.lsa_match_types_gated(self.h, slot, type_mask, query_set, C.byref(params), int(undistort)), "lsa_match_types_gated")
+
+    def profile_event_overhead_us(self):
+        self.L.lsa_profile_event_overhead_us.restype = C.c_double
+        self.L.lsa_profile_event_overhead_us.argtypes = [C.c_void_p]
+        return float(self.L.lsa_profile_event_overhead_us(self.h))
 
     def debug_set(self, name, value):
         self.L.lsa_debug_set.argtypes = [C.c_void_p, C.c_char_p, C.c_int]

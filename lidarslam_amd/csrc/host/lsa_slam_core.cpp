@@ -1196,7 +1196,6 @@ int SlamCore::BeginSubMapSpeculation(const Pose& predicted)
     }
     DevSpecStatus = 0;
     LSA_TRY(lsa_keypoint_boxes_predicted_mark(Ctx));  // the raw keypoints exist from here on the context's stream
-    DevSpecCancel.store(false, std::memory_order_release);
     DevSpecRunning.store(true, std::memory_order_release);
     AheadWorker.Submit([this, interpolated, begin, end, t0, t1, use0 = use[0], use1 = use[1], use2 = use[2], m0 = minPts[0], m1 = minPts[1], m2 = minPts[2]] {
       const bool use[3] = {use0, use1, use2};
@@ -1209,20 +1208,22 @@ int SlamCore::BeginSubMapSpeculation(const Pose& predicted)
       for (int k = 0; k < 3 && rc >= 0; ++k)
         if (use[k]) rc = lsa_device_grid_submap_ahead_begin(DevMaps[k], k, minPts[k], k);
       // ... and waits for the extractions' sizes (this thread has nothing else to do) to enqueue the spare targets' search
-      // grids at once -- unless the localization gets there first and calls it off
+      // grids at once.  The localization waits for this job to END (DevSpecRunning) before it touches the boxes' words or
+      // the spare targets: nothing calls the job off half-way (the predicted boxes' kernels on the look-ahead stream have
+      // to be over before lsa_keypoint_bboxes_begin rewrites those words on the context's stream)
       // (all the maps' grids in one sequence of launches, once the last size is there)
       lsa_device_grid* grids[3];
       int ng = 0;
       for (int k = 0; k < 3; ++k)
         if (use[k]) grids[ng++] = DevMaps[k];
-      while (SpecGridsTogether && ng > 0 && rc >= 0 && !DevSpecCancel.load(std::memory_order_acquire))
+      while (SpecGridsTogether && ng > 0 && rc >= 0)
       {
         rc = lsa_device_grid_submap_ahead_poll_all(grids, ng);
         if (rc != 1) break;
         std::this_thread::yield();
       }
       for (int i = 0; i < ng && !SpecGridsTogether && rc >= 0; ++i)
-        while (rc >= 0 && !DevSpecCancel.load(std::memory_order_acquire))
+        while (rc >= 0)
         {
           rc = lsa_device_grid_submap_ahead_poll(grids[i]);
           if (rc != 1) break;

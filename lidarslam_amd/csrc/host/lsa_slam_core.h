@@ -277,7 +277,7 @@ private:
   void ArmLookaheadInterlude();
   int InterludeWork();
   int DevSpecStatus = 0;   // written by the look-ahead thread, read once DevSpecRunning is false
-  std::atomic<bool> DevSpecRunning{false}, DevSpecCancel{false};
+  std::atomic<bool> DevSpecRunning{false};
   int DevSpecBackoff = 0;  // frames the sub-maps ahead of time are not tried for (they were late)
   int DevSpecLate = 0;     // frames in a row the localization had to wait for them
   int DevSpecGood = 0, DevSpecPenalty = 4;

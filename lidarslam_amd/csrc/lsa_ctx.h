@@ -300,12 +300,15 @@ struct lsa_ctx
   bool profiling = false;
   std::string prof_only;   // when not empty: only the scope of this name is timed ...
   int prof_every = 1;      // ... and only one launch in prof_every of it (the others are counted)
+  double prof_overhead_ms = 0;  // what a pair of events measures around NOTHING on this stream (calibrated when profiling is switched on): taken off every scope
   std::vector<lsa::KernelStat> stats;
   std::vector<lsa::PendingEvent> pending;
   std::vector<hipEvent_t> event_pool;
 
+  mutable std::mutex error_mutex;  // worker threads of the pipeline report through fail() too
   int fail(int code, const std::string& msg)
   {
+    std::lock_guard<std::mutex> l(error_mutex);
     error = msg;
     return code;
   }

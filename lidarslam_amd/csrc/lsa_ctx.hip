@@ -180,7 +180,7 @@ void profile_collect(lsa_ctx* ctx)
   {
     (void)hipEventSynchronize(p.b);
     float ms = 0;
-    if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) ctx->stats[p.stat].total_ms += ms;
+    if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) ctx->stats[p.stat].total_ms += std::max(0.0, (double)ms - ctx->prof_overhead_ms);
     ctx->event_pool.push_back(p.a);
     ctx->event_pool.push_back(p.b);
   }
@@ -608,7 +608,17 @@ void lsa_ctx_destroy(lsa_ctx* ctx)
   delete ctx;
 }
 
-const char* lsa_last_error(const lsa_ctx* ctx) { return ctx ? ctx->error.c_str() : "null context"; }
+const char* lsa_last_error(const lsa_ctx* ctx)
+{
+  if (!ctx) return "null context";
+  // a copy of the calling thread's own: another thread of the pipeline may report an error meanwhile
+  thread_local std::string copy;
+  {
+    std::lock_guard<std::mutex> l(ctx->error_mutex);
+    copy = ctx->error;
+  }
+  return copy.c_str();
+}
 
 int lsa_sync(lsa_ctx* ctx)
 {
@@ -1246,9 +1256,37 @@ float lsa_get_azimuthal_resolution(const lsa_ctx* ctx) { return ctx ? ctx->az_re
 void lsa_set_azimuthal_resolution(lsa_ctx* ctx, float rad) { if (ctx) ctx->az_res = rad; }
 int lsa_nb_laser_rings(const lsa_ctx* ctx) { return ctx ? ctx->nb_rings_seen : 0; }
 
+// what two events measure with nothing between them (the markers' own way through the queue): the median of 15 pairs on the
+// idle stream.  A scope's time is what its events measure minus this, so that it can be held against a profiler's figure
+// for the kernel alone.
+static void calibrate_event_overhead(lsa_ctx* ctx)
+{
+  if (ctx->prof_overhead_ms > 0.) return;
+  hipEvent_t a = nullptr, b = nullptr;
+  if (hipSetDevice(ctx->device) != hipSuccess || hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+  (void)hipStreamSynchronize(ctx->stream);
+  std::vector<float> ms;
+  for (int i = 0; i < 15; ++i)
+  {
+    (void)hipEventRecord(a, ctx->stream);
+    (void)hipEventRecord(b, ctx->stream);
+    (void)hipEventSynchronize(b);
+    float t = 0;
+    if (hipEventElapsedTime(&t, a, b) == hipSuccess) ms.push_back(t);
+  }
+  (void)hipEventDestroy(a);
+  (void)hipEventDestroy(b);
+  if (ms.empty()) return;
+  std::sort(ms.begin(), ms.end());
+  ctx->prof_overhead_ms = ms[ms.size() / 2];
+}
+
+double lsa_profile_event_overhead_us(const lsa_ctx* ctx) { return ctx ? 1e3 * ctx->prof_overhead_ms : 0.; }
+
 int lsa_profile_enable(lsa_ctx* ctx, int on)
 {
   if (!ctx) return LSA_E_ARG;
+  if (on) calibrate_event_overhead(ctx);
   ctx->profiling = on != 0;
   ctx->prof_only.clear();
   ctx->prof_every = 1;
@@ -1257,6 +1295,7 @@ int lsa_profile_enable(lsa_ctx* ctx, int on)
 int lsa_profile_select(lsa_ctx* ctx, const char* scope, int every)
 {
   if (!ctx || !scope || every < 1) return LSA_E_ARG;
+  calibrate_event_overhead(ctx);
   ctx->profiling = true;
   ctx->prof_only = scope;
   ctx->prof_every = every;

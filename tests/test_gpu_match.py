@@ -48,7 +48,7 @@ def assert_match_equal(ctx, O, L, k, cur, tgt, mp, pose, cell=None):
 def kps(O, L):
     """keypoints of two consecutive scans per sensor model, extracted by the oracle"""
     out = {}
-    for model in (8, 16, 128):
+    for model in (8, 16, 64, 128):
         ex = O.Extractor()
         per = []
         for f in range(2):
@@ -59,7 +59,7 @@ def kps(O, L):
     return out
 
 
-@pytest.mark.parametrize("model", [8, 16, 128])
+@pytest.mark.parametrize("model", [8, 16, 64, 128])  # fixtures, VLP-16, HDL-64 (BASELINE config 3), VLS-128
 def test_ego_motion_matching_bit_exact(gpu_ctx, O, L, kps, model):
     """per-ring edge neighbourhoods + plane fits, current scan on the previous scan (Slam.cxx:877-911)"""
     prev, cur = kps[model]
@@ -69,7 +69,7 @@ def test_ego_motion_matching_bit_exact(gpu_ctx, O, L, kps, model):
         assert (st == 0).sum() > 20
 
 
-@pytest.mark.parametrize("model", [8, 16, 128])
+@pytest.mark.parametrize("model", [8, 16, 64, 128])
 def test_localization_matching_bit_exact(gpu_ctx, O, L, kps, model):
     """RANSAC line neighbourhoods, planes and blobs (Slam.cxx:1055-1090)"""
     prev, cur = kps[model]

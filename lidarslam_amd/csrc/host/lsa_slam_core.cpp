@@ -12,6 +12,7 @@ namespace host
 {
 namespace
 {
+#define ICP_TRACE(...) do { if (std::getenv("LSA_ICP_TRACE")) std::fprintf(stderr, __VA_ARGS__); } while (0)
 struct Tick
 {
   std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
@@ -634,10 +635,14 @@ int SlamCore::ComputeEgoMotion()
   // Iteration i + 1 is enqueued behind a gate (lsa_icp_gate) while iteration i runs: when the solve's result arrives its
   // launches are in the queue already, and all that is between the solve and the next search is one store the gate polls
   // for (or the call that calls them off: Slam.cxx:919-923, 950).
-  // (With the maps on the HOST this loop stays as it was: between its iterations this thread stages sub-maps the map workers
-  // have extracted and reads boxes back, and the frame then came out 1.5e-5 m beside the oracle in some schedules -- the
-  // statuses of the last iteration and all the counts equal, no gate timing out; not understood yet)
-  bool ahead = ICPAhead && DeviceLM && FusedMatch && (DeviceMapsInUse() || MapUpdate == MappingMode::NONE);
+  // (With the maps on the HOST this loop stays as it was.  Between its iterations this thread then hands sub-maps the map
+  // workers have extracted to the look-ahead stream (StageSpeculativeSubMaps: a copy out of pinned memory and a grid build).
+  // With a gate waiting on the registration's stream at that moment the device delivered no result for two seconds in some
+  // assignments of the streams to the hardware queues (seen with a second context alive in the process), the solve was then
+  // redone on the host with the NEXT iteration's saturation distance already in force: 1.5e-5 m beside the oracle.  The
+  // hang is not understood (LSA_ICP_AHEAD_HOSTMAPS=1 + LSA_ICP_TRACE=1 reproduce it); the fall-back's wrong distance is
+  // fixed (the solve on the host takes the distances the device solve was enqueued with).)
+  bool ahead = ICPAhead && DeviceLM && FusedMatch && (DeviceMapsInUse() || MapUpdate == MappingMode::NONE || std::getenv("LSA_ICP_AHEAD_HOSTMAPS") != nullptr);
   if (const char* e = std::getenv("LSA_ICP_AHEAD_LOOPS")) ahead = ahead && (std::atoi(e) & 1);  // (diagnostics: 1 ego-motion only, 2 localization only)
   if (ahead) lsa_icp_abandon(Ctx);
   bool enqueued = false;           // this iteration's launches are in the queue (their gate has been answered)
@@ -671,11 +676,13 @@ int SlamCore::ComputeEgoMotion()
     }
     else
       for (int k : {LSA_EDGE, LSA_PLANE}) EgoMatchSerial[k] = aheadSerial[k];
+    ICP_TRACE("[ego %u] top: ahead %d begun %d enqueued %d\n", icpIter, (int)ahead, (int)begun, (int)enqueued);
     enqueued = false;
     int ticket = -1;
     if (ahead && begun && icpIter + 1 < EgoMotionICPMaxIter)
     {
       ticket = lsa_icp_gate(Ctx);
+      ICP_TRACE("[ego %u] gate ticket %d\n", icpIter, ticket);
       if (ticket < 0) { ticket = -1; ahead = false; }
       else
       {
@@ -719,6 +726,7 @@ int SlamCore::ComputeEgoMotion()
       const int irc = InterludeWork();
       const double dbgInterlude = tdbg.Stop();
       int rc = optimizer.End(summary);
+      ICP_TRACE("[ego %u] End rc %d irc %d ticket %d\n", icpIter, rc, irc, ticket);
       if (std::getenv("LSA_GATE_DEBUG") && tdbg.Stop() > 0.01)
         std::fprintf(stderr, "[gate debug] ego iteration %u: enqueue %.3f ms, interlude %.3f ms, until the result %.3f ms, rc %d\n", icpIter, 1e3 * Stats.ego_icp, 1e3 * dbgInterlude, 1e3 * tdbg.Stop(), rc);
       if (rc == LSA_E_GATE)
@@ -743,6 +751,9 @@ int SlamCore::ComputeEgoMotion()
       LSA_TRY(FinishLookaheadInterlude());
     }
     TotalMatchedKeypoints = summary.num_matches;
+    if (std::getenv("LSA_ICP_TRACE"))
+      std::fprintf(stderr, "[icp] frame %u ego %u: matches %d evals %d steps %d cost %.17g -> %.17g%s\n", NbrFrameProcessed, icpIter, summary.num_matches, summary.num_evaluations,
+                   summary.num_successful_steps, summary.initial_cost, summary.final_cost, summary.skipped ? " skipped" : "");
     if (SpecPending)
     {
       // the predicted bounding boxes have long arrived: the map workers extract the sub-maps from here on
@@ -1082,6 +1093,9 @@ int SlamCore::Localization()
       LSA_TRY(FinishLookaheadInterlude());
     }
     TotalMatchedKeypoints = summary.num_matches;
+    if (std::getenv("LSA_ICP_TRACE"))
+      std::fprintf(stderr, "[icp] frame %u loc %u: matches %d evals %d steps %d cost %.17g -> %.17g%s\n", NbrFrameProcessed, icpIter, summary.num_matches, summary.num_evaluations,
+                   summary.num_successful_steps, summary.initial_cost, summary.final_cost, summary.skipped ? " skipped" : "");
     if (summary.skipped)
     {
       // reset state to previous one to avoid instability (Slam.cxx:1098-1107)

@@ -159,7 +159,7 @@ int LocalOptimizer::End(SolveSummary& sum)
   HaveFinal = false;
   lsa_solve_result_t r;
   const int rc = lsa_solve_device_end(Ctx, &r);
-  if (std::getenv("LSA_ICP_TRACE")) std::fprintf(stderr, "[optimizer end] rc %d (%s)\n", rc, rc ? lsa_last_error(Ctx) : "");
+  if (lsa_icp_trace_on()) std::fprintf(stderr, "[optimizer end] rc %d (%s)\n", rc, rc ? lsa_last_error(Ctx) : "");
   if (rc == LSA_OK)
   {
     TakeResult(r, sum);

@@ -12,7 +12,7 @@ namespace host
 {
 namespace
 {
-#define ICP_TRACE(...) do { if (std::getenv("LSA_ICP_TRACE")) std::fprintf(stderr, __VA_ARGS__); } while (0)
+#define ICP_TRACE(...) do { if (lsa_icp_trace_on()) std::fprintf(stderr, __VA_ARGS__); } while (0)
 struct Tick
 {
   std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
@@ -642,8 +642,9 @@ int SlamCore::ComputeEgoMotion()
   // redone on the host with the NEXT iteration's saturation distance already in force: 1.5e-5 m beside the oracle.  The
   // hang is not understood (LSA_ICP_AHEAD_HOSTMAPS=1 + LSA_ICP_TRACE=1 reproduce it); the fall-back's wrong distance is
   // fixed (the solve on the host takes the distances the device solve was enqueued with).)
-  bool ahead = ICPAhead && DeviceLM && FusedMatch && (DeviceMapsInUse() || MapUpdate == MappingMode::NONE || std::getenv("LSA_ICP_AHEAD_HOSTMAPS") != nullptr);
-  if (const char* e = std::getenv("LSA_ICP_AHEAD_LOOPS")) ahead = ahead && (std::atoi(e) & 1);  // (diagnostics: 1 ego-motion only, 2 localization only)
+  static const bool aheadWithHostMaps = std::getenv("LSA_ICP_AHEAD_HOSTMAPS") != nullptr;  // (diagnostics)
+  static const int aheadLoops = std::getenv("LSA_ICP_AHEAD_LOOPS") ? std::atoi(std::getenv("LSA_ICP_AHEAD_LOOPS")) : 3;  // (diagnostics: 1 ego-motion only, 2 localization only)
+  bool ahead = ICPAhead && DeviceLM && FusedMatch && (DeviceMapsInUse() || MapUpdate == MappingMode::NONE || aheadWithHostMaps) && (aheadLoops & 1);
   if (ahead) lsa_icp_abandon(Ctx);
   bool enqueued = false;           // this iteration's launches are in the queue (their gate has been answered)
   long long aheadSerial[3] = {0, 0, 0};
@@ -727,7 +728,8 @@ int SlamCore::ComputeEgoMotion()
       const double dbgInterlude = tdbg.Stop();
       int rc = optimizer.End(summary);
       ICP_TRACE("[ego %u] End rc %d irc %d ticket %d\n", icpIter, rc, irc, ticket);
-      if (std::getenv("LSA_GATE_DEBUG") && tdbg.Stop() > 0.01)
+      static const bool gateDebug = std::getenv("LSA_GATE_DEBUG") != nullptr;
+      if (gateDebug && tdbg.Stop() > 0.01)
         std::fprintf(stderr, "[gate debug] ego iteration %u: enqueue %.3f ms, interlude %.3f ms, until the result %.3f ms, rc %d\n", icpIter, 1e3 * Stats.ego_icp, 1e3 * dbgInterlude, 1e3 * tdbg.Stop(), rc);
       if (rc == LSA_E_GATE)
       {
@@ -751,7 +753,7 @@ int SlamCore::ComputeEgoMotion()
       LSA_TRY(FinishLookaheadInterlude());
     }
     TotalMatchedKeypoints = summary.num_matches;
-    if (std::getenv("LSA_ICP_TRACE"))
+    if (lsa_icp_trace_on())
       std::fprintf(stderr, "[icp] frame %u ego %u: matches %d evals %d steps %d cost %.17g -> %.17g%s\n", NbrFrameProcessed, icpIter, summary.num_matches, summary.num_evaluations,
                    summary.num_successful_steps, summary.initial_cost, summary.final_cost, summary.skipped ? " skipped" : "");
     if (SpecPending)
@@ -993,7 +995,8 @@ int SlamCore::Localization()
   // the two, when the motion is known).
   const bool undistortAhead = Undistortion == UNDISTORTION_REFINED;
   bool ahead = ICPAhead && DeviceLM && FusedMatch && (!undistortAhead || UndistortInSearch);
-  if (const char* e = std::getenv("LSA_ICP_AHEAD_LOOPS")) ahead = ahead && (std::atoi(e) & 2);
+  static const int aheadLoops = std::getenv("LSA_ICP_AHEAD_LOOPS") ? std::atoi(std::getenv("LSA_ICP_AHEAD_LOOPS")) : 3;
+  ahead = ahead && (aheadLoops & 2);
   if (ahead) lsa_icp_abandon(Ctx);
   bool enqueued = false;
   long long aheadSerial[3] = {0, 0, 0};
@@ -1093,7 +1096,7 @@ int SlamCore::Localization()
       LSA_TRY(FinishLookaheadInterlude());
     }
     TotalMatchedKeypoints = summary.num_matches;
-    if (std::getenv("LSA_ICP_TRACE"))
+    if (lsa_icp_trace_on())
       std::fprintf(stderr, "[icp] frame %u loc %u: matches %d evals %d steps %d cost %.17g -> %.17g%s\n", NbrFrameProcessed, icpIter, summary.num_matches, summary.num_evaluations,
                    summary.num_successful_steps, summary.initial_cost, summary.final_cost, summary.skipped ? " skipped" : "");
     if (summary.skipped)

@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <atomic>
@@ -313,6 +314,13 @@ struct lsa_ctx
     return code;
   }
 };
+
+// LSA_ICP_TRACE=1: every step of the gated ICP loops on stderr (diagnostics; read once)
+inline bool lsa_icp_trace_on()
+{
+  static const bool on = std::getenv("LSA_ICP_TRACE") != nullptr;
+  return on;
+}
 
 namespace lsa
 {

@@ -19,7 +19,10 @@ using namespace lsa;
 namespace
 {
 
-constexpr int kLabelThreads = 1024;  // one block per ring
+#ifndef LSA_LABEL_THREADS
+#define LSA_LABEL_THREADS 1024
+#endif
+constexpr int kLabelThreads = LSA_LABEL_THREADS;  // one block per ring
 
 struct ExtractConst
 {

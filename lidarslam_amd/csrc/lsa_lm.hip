@@ -687,7 +687,7 @@ int lsa_solve_device_begin(lsa_ctx* ctx, unsigned type_mask, const double prior[
                        ctx->route_stats && ctx->trace_dev ? reinterpret_cast<unsigned long long*>(ctx->trace_dev) + (size_t)8192 * 12 : nullptr);
   }
   ctx->lm_pending.push_back(out_tag);
-  if (std::getenv("LSA_ICP_TRACE")) std::fprintf(stderr, "[lm begin] tag %u gated %d sat2 %.6g %.6g counts %d %d\n", out_tag, prior ? 0 : 1, p.set.sat2[0], p.set.sat2[1], p.set.count[0], p.set.count[1]);
+  if (lsa_icp_trace_on()) std::fprintf(stderr, "[lm begin] tag %u gated %d sat2 %.6g %.6g counts %d %d\n", out_tag, prior ? 0 : 1, p.set.sat2[0], p.set.sat2[1], p.set.count[0], p.set.count[1]);
   return LSA_OK;
 }
 
@@ -704,7 +704,7 @@ int lsa_solve_device_end(lsa_ctx* ctx, lsa_solve_result_t* out)
   if (ctx->lm_pending.empty()) return ctx->fail(LSA_E_STATE, "lsa_solve_device_end: no solve in flight");
   const unsigned out_tag = ctx->lm_pending.front();
   ctx->lm_pending.pop_front();
-  if (std::getenv("LSA_ICP_TRACE")) std::fprintf(stderr, "[lm end] waits for tag %u (%zu more in flight)\n", out_tag, ctx->lm_pending.size());
+  if (lsa_icp_trace_on()) std::fprintf(stderr, "[lm end] waits for tag %u (%zu more in flight)\n", out_tag, ctx->lm_pending.size());
   // the result arrives as granules in coherent host memory (as lsa_accumulate's sums do)
   double res[kResCount];
   {
@@ -733,7 +733,7 @@ int lsa_solve_device_end(lsa_ctx* ctx, lsa_solve_result_t* out)
       std::memcpy(&res[v], &bits, sizeof(double));
     }
   }
-  if (std::getenv("LSA_ICP_TRACE")) std::fprintf(stderr, "[lm end] tag %u: failed %g code %g evals %g matches %g\n", out_tag, res[kResFailed], res[kResCode], res[kResEvaluations], res[kResMatches]);
+  if (lsa_icp_trace_on()) std::fprintf(stderr, "[lm end] tag %u: failed %g code %g evals %g matches %g\n", out_tag, res[kResFailed], res[kResCode], res[kResEvaluations], res[kResMatches]);
   // (the gate's case first and without waiting for the stream: the next iteration's gate may be waiting there for this thread)
   if (res[kResFailed] == 2.) return ctx->fail(LSA_E_GATE, "lsa_solve_device: the gate in front of the solve gave up waiting for the host");
   if (res[kResFailed] != 0.)
@@ -821,7 +821,7 @@ static int gate_release(lsa_ctx* ctx, int ticket, const IcpGate* block)
     __atomic_store_n(g + 2 * i, ((unsigned long long)seq << 32) | (words[i] & 0xffffffffull), __ATOMIC_RELAXED);
     __atomic_store_n(g + 2 * i + 1, ((unsigned long long)seq << 32) | (words[i] >> 32), __ATOMIC_RELAXED);
   }
-  if (std::getenv("LSA_ICP_TRACE")) std::fprintf(stderr, "[gate] ticket %d seq %u %s\n", ticket, seq, block ? "posted" : "called off");
+  if (lsa_icp_trace_on()) std::fprintf(stderr, "[gate] ticket %d seq %u %s\n", ticket, seq, block ? "posted" : "called off");
   ctx->gate_saved[ticket].used = false;
   if (ctx->gate_current == ticket) ctx->gate_current = -1;
   return LSA_OK;

@@ -160,4 +160,94 @@ LSA_HD double lsa_atan2(double y, double x)
   return (y < 0.0) ? -z : z;
 }
 
+/* asin / acos: the rational approximation R(x^2) of fdlibm's e_asin.c / e_acos.c.  They serve the pose algebra
+ * between two ICP iterations (roll-pitch-yaw of a rotation matrix, the angle of a slerp), which the device evaluates
+ * behind a solve (lsa_lm.hip) and the host and the oracle evaluate with the same routine.  sqrt is the IEEE one on
+ * both sides (__builtin_sqrt). */
+LSA_HD double lsa_asin_r(double t)
+{
+  const double pS0 = 1.66666666666666657415e-01, pS1 = -3.25565818622400915405e-01, pS2 = 2.01212532134862925881e-01,
+               pS3 = -4.00555345006794114027e-02, pS4 = 7.91534994289814532176e-04, pS5 = 3.47933107596021167570e-05,
+               qS1 = -2.40339491173441421878e+00, qS2 = 2.02094576023350569471e+00, qS3 = -6.88283971605453293030e-01,
+               qS4 = 7.70381505559019352791e-02;
+  const double p = t * (pS0 + t * (pS1 + t * (pS2 + t * (pS3 + t * (pS4 + t * pS5)))));
+  const double q = 1.0 + t * (qS1 + t * (qS2 + t * (qS3 + t * qS4)));
+  return p / q;
+}
+/* v with the low 32 bits of its mantissa cleared */
+LSA_HD double lsa_high_part(double v)
+{
+  unsigned long long b;
+  __builtin_memcpy(&b, &v, sizeof(b));
+  b &= 0xffffffff00000000ULL;
+  __builtin_memcpy(&v, &b, sizeof(b));
+  return v;
+}
+
+LSA_HD double lsa_asin(double x)
+{
+  const double PIO2_HI = 1.57079632679489655800e+00, PIO2_LO = 6.12323399573676603587e-17, PIO4_HI = 7.85398163397448278999e-01;
+  if (x != x) return x;
+  const double ax = x < 0.0 ? -x : x;
+  if (ax >= 1.0)
+  {
+    if (ax == 1.0) return x * PIO2_HI + x * PIO2_LO;
+    return (x - x) / (x - x); /* NaN */
+  }
+  if (ax < 0.5)
+  {
+    if (ax < 7.450580596923828125e-09) return x; /* 2^-27 */
+    return x + x * lsa_asin_r(x * x);
+  }
+  const double w = 1.0 - ax;
+  const double t = w * 0.5;
+  const double r = lsa_asin_r(t);
+  const double s = __builtin_sqrt(t);
+  double res;
+  if (ax >= 0.974999904632568359375) /* high word 0x3FEF3333 */
+    res = PIO2_HI - (2.0 * (s + s * r) - PIO2_LO);
+  else
+  {
+    const double sh = lsa_high_part(s);
+    const double c = (t - sh * sh) / (s + sh);
+    const double p = 2.0 * s * r - (PIO2_LO - 2.0 * c);
+    const double q = PIO4_HI - 2.0 * sh;
+    res = PIO4_HI - (p - q);
+  }
+  return x > 0.0 ? res : -res;
+}
+
+LSA_HD double lsa_acos(double x)
+{
+  const double PI = 3.14159265358979311600e+00, PIO2_HI = 1.57079632679489655800e+00, PIO2_LO = 6.12323399573676603587e-17;
+  if (x != x) return x;
+  const double ax = x < 0.0 ? -x : x;
+  if (ax >= 1.0)
+  {
+    if (ax == 1.0) return x > 0.0 ? 0.0 : PI + 2.0 * PIO2_LO;
+    return (x - x) / (x - x); /* NaN */
+  }
+  if (ax < 0.5)
+  {
+    if (ax <= 6.938893903907228377647697925567626953125e-18) return PIO2_HI + PIO2_LO; /* 2^-57 */
+    const double r = lsa_asin_r(x * x);
+    return PIO2_HI - (x - (PIO2_LO - r * x));
+  }
+  if (x < 0.0)
+  {
+    const double z = (1.0 + x) * 0.5;
+    const double r = lsa_asin_r(z);
+    const double s = __builtin_sqrt(z);
+    const double w = r * s - PIO2_LO;
+    return PI - 2.0 * (s + w);
+  }
+  const double z = (1.0 - x) * 0.5;
+  const double s = __builtin_sqrt(z);
+  const double df = lsa_high_part(s);
+  const double c = (z - df * df) / (s + df);
+  const double r = lsa_asin_r(z);
+  const double w = r * s + c;
+  return 2.0 * (df + w);
+}
+
 #endif /* LSA_PMATH_H */

@@ -17,6 +17,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "../../include/lsa_pmath.h"
+#include "lsa_posemath.h"
 
 #define LSA_DEV __device__ __forceinline__
 
@@ -226,49 +227,13 @@ template <typename T> struct CovAccum
   }
 };
 
-// ---------------------------------------------------------------------------
-// double-precision rigid transform: row-major R + t, applied as
-// ((R0 x + R1 y) + R2 z) + t  (Eigen 4x4 * 4x1, column-major packet order)
-struct Rigid
-{
-  double R[9];
-  double t[3];
-};
+// (Rigid, InterpConst, IcpGate: lsa_posemath.h)
 LSA_DEV void rigid_apply(const Rigid& a, double x, double y, double z, double& ox, double& oy, double& oz)
 {
   ox = ((a.R[0] * x + a.R[1] * y) + a.R[2] * z) + a.t[0];
   oy = ((a.R[3] * x + a.R[4] * y) + a.R[5] * z) + a.t[1];
   oz = ((a.R[6] * x + a.R[7] * y) + a.R[8] * z) + a.t[2];
 }
-
-// Everything of LinearTransformInterpolator::operator() that does not depend on
-// the point's time; prepared on the host (acos there), evaluated per point here.
-struct InterpConst
-{
-  double qa[4], qb[4];   // w x y z
-  double d, theta, sin_theta;
-  double trans0[3], trans1[3];
-  double time0, time1;
-  Rigid h0;              // applied to every point when invalid
-  int linear;            // |d| >= 1 - eps
-  int invalid;           // Time0 == Time1 or H0 ~ H1
-};
-
-// What an ICP iteration that was enqueued ahead of its inputs (lsa_icp_gate) reads on the device once the host has
-// handed them over: the pose the keypoints are searched under, the optimiser's start point, the undistortion of the
-// iteration before.  `go` comes first: 1 = run, anything else = the launch does nothing (0 called off, 2 the gate gave up).
-struct IcpInputs
-{
-  Rigid pose;
-  double x0[6];
-  InterpConst ic;
-};
-struct IcpGate
-{
-  unsigned long long go;
-  IcpInputs in;
-};
-static_assert(sizeof(IcpGate) % 8 == 0 && sizeof(IcpGate) <= 64 * 8, "a gate block is at most 64 words");
 
 LSA_DEV void interp_eval(const InterpConst& c, double t, Rigid& out)
 {

@@ -1584,7 +1584,7 @@ int lsa_accumulate(lsa_ctx* ctx, unsigned type_mask, const double w[6], int want
   LSA_HIP(ctx, hipSetDevice(ctx->device));
   AccumConst c;
   // R = Rz Ry Rx and its partial derivatives (CeresCostFunctions.h:67-79), once per evaluation on the host
-  rotation_and_derivatives(std::cos(w[3]), std::sin(w[3]), std::cos(w[4]), std::sin(w[4]), std::cos(w[5]), std::sin(w[5]), c.rot.R, c.rot.dRx, c.rot.dRy, c.rot.dRz);
+  rotation_and_derivatives(lsa_cos(w[3]), lsa_sin(w[3]), lsa_cos(w[4]), lsa_sin(w[4]), lsa_cos(w[5]), lsa_sin(w[5]), c.rot.R, c.rot.dRx, c.rot.dRy, c.rot.dRz);
   c.rot.t[0] = w[0]; c.rot.t[1] = w[1]; c.rot.t[2] = w[2];
   int total = 0;
   for (int k = 0; k < 3; ++k)

@@ -1,5 +1,5 @@
 // lsa_selftest.hip -- lsa_selftest_math: evaluates on the device the elementary operations the
-// bit-exact CPU/GPU parity rests on (portable sin/cos/atan2 of include/lsa_pmath.h, IEEE sqrt and
+// bit-exact CPU/GPU parity rests on (portable sin/cos/atan2/asin/acos of include/lsa_pmath.h, IEEE sqrt and
 // division in float and double), so that a test can compare them bit for bit with the host.
 #include "lsa_ctx.h"
 #include "lsa_device_math.h"
@@ -22,6 +22,8 @@ __global__ void k_selftest(int fn, const double* __restrict__ x, const double* _
     case 4: r = (double)((float)x[i] / (float)y[i]); break;
     case 5: r = sqrt_t(x[i]); break;
     case 6: r = x[i] / y[i]; break;
+    case 7: r = lsa_asin(x[i]); break;
+    case 8: r = lsa_acos(x[i]); break;
   }
   out[i] = r;
 }
@@ -29,7 +31,7 @@ __global__ void k_selftest(int fn, const double* __restrict__ x, const double* _
 
 extern "C" int lsa_selftest_math(lsa_ctx* ctx, int fn, const double* x, const double* y, int n, double* out)
 {
-  if (!ctx || !x || !y || !out || n <= 0 || fn < 0 || fn > 6) return ctx ? ctx->fail(LSA_E_ARG, "lsa_selftest_math: bad argument") : LSA_E_ARG;
+  if (!ctx || !x || !y || !out || n <= 0 || fn < 0 || fn > 8) return ctx ? ctx->fail(LSA_E_ARG, "lsa_selftest_math: bad argument") : LSA_E_ARG;
   LSA_HIP(ctx, hipSetDevice(ctx->device));
   int rc = ensure_scratch(ctx, (size_t)n * 3 * sizeof(double));
   if (rc) return rc;

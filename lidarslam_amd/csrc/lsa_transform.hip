@@ -302,76 +302,14 @@ __global__ __launch_bounds__(256) void k_loc_start(StageOut s, int undistort, In
   }
 }
 
-// host-side quaternion helpers (Eigen::Quaternion(Matrix3d), slam_lib/include/LidarSlam/MotionModel.h:64-76)
-void quat_from_matrix(const double R[9], double q[4])
-{
-  double t = R[0] + R[4] + R[8];
-  if (t > 0.0)
-  {
-    t = std::sqrt(t + 1.0);
-    q[0] = 0.5 * t;
-    t = 0.5 / t;
-    q[1] = (R[7] - R[5]) * t;
-    q[2] = (R[2] - R[6]) * t;
-    q[3] = (R[3] - R[1]) * t;
-  }
-  else
-  {
-    int i = 0;
-    if (R[4] > R[0]) i = 1;
-    if (R[8] > R[i * 3 + i]) i = 2;
-    const int j = (i + 1) % 3, k = (j + 1) % 3;
-    t = std::sqrt(R[i * 3 + i] - R[j * 3 + j] - R[k * 3 + k] + 1.0);
-    double v[3];
-    v[i] = 0.5 * t;
-    t = 0.5 / t;
-    q[0] = (R[k * 3 + j] - R[j * 3 + k]) * t;
-    v[j] = (R[j * 3 + i] + R[i * 3 + j]) * t;
-    v[k] = (R[k * 3 + i] + R[i * 3 + k]) * t;
-    q[1] = v[0]; q[2] = v[1]; q[3] = v[2];
-  }
-}
-void quat_to_matrix(const double q[4], double R[9])
-{
-  const double w = q[0], x = q[1], y = q[2], z = q[3];
-  const double tx = 2.0 * x, ty = 2.0 * y, tz = 2.0 * z;
-  const double twx = tx * w, twy = ty * w, twz = tz * w;
-  const double txx = tx * x, txy = ty * x, txz = tz * x;
-  const double tyy = ty * y, tyz = tz * y, tzz = tz * z;
-  R[0] = 1.0 - (tyy + tzz); R[1] = txy - twz;         R[2] = txz + twy;
-  R[3] = txy + twz;         R[4] = 1.0 - (txx + tzz); R[5] = tyz - twx;
-  R[6] = txz - twy;         R[7] = tyz + twx;         R[8] = 1.0 - (txx + tyy);
-}
-
-// Everything of LinearTransformInterpolator that is independent of the point: SetTransforms
-// (quaternion round trip), IsInterpolatorValid (isApprox, prec 1e-12), slerp constants.
+// Everything of LinearTransformInterpolator that is independent of the point (lsa_posemath.h: one source for the host
+// and for the device, which prepares the same constants behind a solve)
 InterpConst make_interp(const double H0[16], const double H1[16], double t0, double t1)
 {
-  InterpConst c;
-  double R0[9], R1[9];
-  row_major_to_rt(H0, R0, c.trans0);
-  row_major_to_rt(H1, R1, c.trans1);
-  quat_from_matrix(R0, c.qa);
-  quat_from_matrix(R1, c.qb);
-  c.time0 = t0; c.time1 = t1;
-  // GetH0 / GetH1 go through the quaternions
-  double G0[9], G1[9];
-  quat_to_matrix(c.qa, G0);
-  quat_to_matrix(c.qb, G1);
-  std::memcpy(c.h0.R, G0, sizeof(G0));
-  std::memcpy(c.h0.t, c.trans0, sizeof(c.trans0));
-  double d = 0, na = 1, nb = 1;
-  for (int i = 0; i < 9; ++i) { double e = G0[i] - G1[i]; d += e * e; na += G0[i] * G0[i]; nb += G1[i] * G1[i]; }
-  for (int i = 0; i < 3; ++i) { double e = c.trans0[i] - c.trans1[i]; d += e * e; na += c.trans0[i] * c.trans0[i]; nb += c.trans1[i] * c.trans1[i]; }
-  const bool approx = d <= 1e-12 * 1e-12 * std::min(na, nb);
-  c.invalid = (t0 == t1 || approx) ? 1 : 0;
-  c.d = (c.qa[1] * c.qb[1] + c.qa[3] * c.qb[3]) + (c.qa[2] * c.qb[2] + c.qa[0] * c.qb[0]);
-  const double one = 1.0 - std::numeric_limits<double>::epsilon();
-  const double absD = std::abs(c.d);
-  c.linear = absD >= one ? 1 : 0;
-  c.theta = c.linear ? 0.0 : std::acos(absD);
-  c.sin_theta = c.linear ? 1.0 : lsa_sin(c.theta);
-  return c;
+  posemath::Pose a, b;
+  std::memcpy(a.m, H0, sizeof(a.m));
+  std::memcpy(b.m, H1, sizeof(b.m));
+  return posemath::MakeInterpConst(a, b, t0, t1);
 }
 
 }  // namespace

@@ -240,6 +240,8 @@ int orc_math(int fn, const double* x, const double* y, int n, double* out)
       case 4: out[i] = (double)((float)x[i] / (float)y[i]); break;
       case 5: out[i] = std::sqrt(x[i]); break;
       case 6: out[i] = x[i] / y[i]; break;
+      case 7: out[i] = lsa_asin(x[i]); break;
+      case 8: out[i] = lsa_acos(x[i]); break;
       default: return -1;
     }
   }

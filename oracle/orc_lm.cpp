@@ -19,9 +19,9 @@ namespace
 struct RotAndDerivs { double R[9], dRx[9], dRy[9], dRz[9]; };
 RotAndDerivs MakeRot(double rx, double ry, double rz)
 {
-  const double cx = std::cos(rx), sx = std::sin(rx);
-  const double cy = std::cos(ry), sy = std::sin(ry);
-  const double cz = std::cos(rz), sz = std::sin(rz);
+  const double cx = t_cos(rx), sx = t_sin(rx);
+  const double cy = t_cos(ry), sy = t_sin(ry);
+  const double cz = t_cos(rz), sz = t_sin(rz);
   RotAndDerivs o;
   double R[9] = {cy * cz, sx * sy * cz - cx * sz, cx * sy * cz + sx * sz,
                  cy * sz, sx * sy * sz + cx * cz, cx * sy * sz - sx * cz,

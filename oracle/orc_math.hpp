@@ -25,7 +25,8 @@
 //        slam_lib/include/LidarSlam/MotionModel.h:36-136
 // Transcendentals that the GPU path also evaluates (atan2/cos/sin inside
 // eigen33, sin inside slerp) come from include/lsa_pmath.h so that CPU and GPU
-// agree bit for bit; host-only ones (RPY conversion, acos in slerp) use libm.
+// agree bit for bit -- since round 3 also the pose algebra between two ICP iterations (RPY conversion, acos in slerp),
+// which the device evaluates behind a solve when the next iteration is enqueued ahead (lsa_posemath.h).
 #pragma once
 #include <cmath>
 #include <cstdint>
@@ -36,7 +37,7 @@
 
 namespace orc
 {
-// The trigonometry inside the analytic eigen-solver and the slerp: lsa_pmath.h (what the device evaluates, bit for bit)
+// The trigonometry inside the analytic eigen-solver, the slerp and the RPY conversions: lsa_pmath.h (what the device evaluates, bit for bit)
 // by default; libm (what the reference's PCL / Eigen call: std::atan2 / cos / sin of glibc) when asked for.  The
 // switch exists for ONE purpose: tests/test_oracle_properties.py counts how many decisions (keypoint labels, match
 // status) and how many low bits change between the two, i.e. what the shared header could hide.
@@ -44,6 +45,8 @@ inline int& libm_trig() { static int on = 0; return on; }
 inline double t_sin(double x) { return libm_trig() ? std::sin(x) : lsa_sin(x); }
 inline double t_cos(double x) { return libm_trig() ? std::cos(x) : lsa_cos(x); }
 inline double t_atan2(double y, double x) { return libm_trig() ? std::atan2(y, x) : lsa_atan2(y, x); }
+inline double t_asin(double x) { return libm_trig() ? std::asin(x) : lsa_asin(x); }
+inline double t_acos(double x) { return libm_trig() ? std::acos(x) : lsa_acos(x); }
 
 
 // ---------------------------------------------------------------------------
@@ -385,8 +388,7 @@ inline Quat quat_mul(const Quat& a, const Quat& b)
           a.w * b.z + a.z * b.w + a.x * b.y - a.y * b.x};
 }
 // Constants of a slerp between two fixed quaternions (everything that does not
-// depend on t).  theta uses libm acos (host only); the sines use lsa_sin
-// because the GPU evaluates the per-point part.
+// depend on t), in the portable functions the GPU evaluates them with.
 struct SlerpConst { Quat a, b; double d, theta, sin_theta; bool linear; };
 inline SlerpConst slerp_prepare(const Quat& a, const Quat& b)
 {
@@ -396,7 +398,7 @@ inline SlerpConst slerp_prepare(const Quat& a, const Quat& b)
   const double one = 1.0 - std::numeric_limits<double>::epsilon();
   double absD = std::abs(c.d);
   c.linear = absD >= one;
-  c.theta = c.linear ? 0.0 : std::acos(absD);
+  c.theta = c.linear ? 0.0 : t_acos(absD);
   c.sin_theta = c.linear ? 1.0 : t_sin(c.theta);
   return c;
 }
@@ -414,19 +416,19 @@ inline Quat slerp_eval(const SlerpConst& c, double t)
 }
 
 // ---------------------------------------------------------------------------
-// RPY <-> matrix (slam_lib/src/Utilities.cxx:33-77), host only -> libm
+// RPY <-> matrix (slam_lib/src/Utilities.cxx:33-77)
 inline void rpy_to_matrix(double roll, double pitch, double yaw, double R[9])
 {
-  Quat qz = {std::cos(yaw * 0.5), 0, 0, std::sin(yaw * 0.5)};
-  Quat qy = {std::cos(pitch * 0.5), 0, std::sin(pitch * 0.5), 0};
-  Quat qx = {std::cos(roll * 0.5), std::sin(roll * 0.5), 0, 0};
+  Quat qz = {t_cos(yaw * 0.5), 0, 0, t_sin(yaw * 0.5)};
+  Quat qy = {t_cos(pitch * 0.5), 0, t_sin(pitch * 0.5), 0};
+  Quat qx = {t_cos(roll * 0.5), t_sin(roll * 0.5), 0, 0};
   quat_to_matrix(quat_mul(quat_mul(qz, qy), qx), R);
 }
 inline void matrix_to_rpy(const double R[9], double rpy[3])
 {
-  rpy[0] = std::atan2(R[7], R[8]);
-  rpy[1] = -std::asin(R[6]);
-  rpy[2] = std::atan2(R[3], R[0]);
+  rpy[0] = t_atan2(R[7], R[8]);
+  rpy[1] = -t_asin(R[6]);
+  rpy[2] = t_atan2(R[3], R[0]);
 }
 inline Iso xyzrpy_to_iso(const double w[6])
 {

@@ -420,7 +420,7 @@ void Slam::UpdateMapsUsingTworld()
   // Eigen::AngleAxisd(R).angle(): 2 atan2(|q.vec|, |q.w|)
   Quat q = quat_from_matrix(motionSinceLastKf.R);
   double n = std::sqrt((q.x * q.x + q.y * q.y) + q.z * q.z);
-  double rotSinceLastKf = (n != 0.) ? 2. * std::atan2(n, std::abs(q.w)) : 0.;
+  double rotSinceLastKf = (n != 0.) ? 2. * t_atan2(n, std::abs(q.w)) : 0.;
 
   constexpr double MIN_KF_NB = 10.;
   double thresholdCoef = std::min(KfCounter / MIN_KF_NB, 1.);
@@ -530,7 +530,7 @@ void Slam::CheckMotionLimits()
   // Eigen::AngleAxisd(R).angle(): 2 atan2(|q.vec|, |q.w|)
   Quat q = quat_from_matrix(TWindow.R);
   double qn = std::sqrt((q.x * q.x + q.y * q.y) + q.z * q.z);
-  float angle = (float)((qn != 0.) ? 2. * std::atan2(qn, std::abs(q.w)) : 0.);
+  float angle = (float)((qn != 0.) ? 2. * t_atan2(qn, std::abs(q.w)) : 0.);
   if (angle > M_PI)
     angle = (float)(2 * M_PI - angle);
   angle = (float)(angle / M_PI * 180.);  // Utils::Rad2Deg (Utilities.h:150-153)

@@ -133,8 +133,10 @@ def test_device_arithmetic_is_bit_identical_to_the_host(gpu_ctx, O):
     rng = np.random.default_rng(1)
     x = np.concatenate([rng.uniform(-4, 4, 100000), rng.uniform(0, np.pi / 3, 100000), 10.0 ** rng.uniform(-30, 30, 50000)])
     y = np.concatenate([rng.uniform(-4, 4, 100000), rng.uniform(0, 1, 100000), 10.0 ** rng.uniform(-30, 30, 50000)])
-    for fn in range(7):
+    for fn in range(9):
         xs, ys = (np.abs(x) if fn in (3, 5) else x), y
+        if fn in (7, 8):  # lsa_asin / lsa_acos: [-1, 1] with both ends, the neighbourhood of +-1 / 0.5 / 0 densely
+            xs = np.concatenate([rng.uniform(-1, 1, 200000), 1 - 10.0 ** rng.uniform(-17, 0, 25000), -1 + 10.0 ** rng.uniform(-17, 0, 24996), [1., -1., 0., 0.5]])
         if fn in (0, 1):  # lsa_sin / lsa_cos are specified for |x| < 1e5 (angles here are <= pi)
             xs = np.where(np.abs(xs) < 1e4, xs, np.fmod(xs, 1e4))
         if fn in (3, 4):  # float: stay inside the normal range (no denormal results)

@@ -23,6 +23,11 @@ def test_portable_trig_is_within_one_ulp_of_libm(O):
     assert ulp_err(O.math(1, x), np.cos(x)).max() <= 1.0
     y, xx = rng.uniform(-10, 10, 200000), rng.uniform(-10, 10, 200000)
     assert ulp_err(O.math(2, xx, y), np.arctan2(y, xx)).max() <= 1.0
+    # asin / acos (the pose algebra between two ICP iterations): the whole domain, both ends densely
+    u = np.concatenate([rng.uniform(-1, 1, 200000), 1 - 10.0 ** rng.uniform(-17, 0, 20000), -1 + 10.0 ** rng.uniform(-17, 0, 20000), [1., -1., 0., 0.5, -0.5]])
+    assert ulp_err(O.math(7, u), np.arcsin(u)).max() <= 1.0
+    assert ulp_err(O.math(8, u), np.arccos(u)).max() <= 1.0
+    assert np.isnan(O.math(7, np.array([1.5, -2.0, np.nan]))).all() and np.isnan(O.math(8, np.array([1.5, -2.0, np.nan]))).all()
     # the quadrant cases the analytic eigen-solver reaches: y >= 0
     assert O.math(2, np.array([1.0, 0.0, -1.0]), np.array([0.0, 1.0, 0.0])).tolist() == [0.0, np.pi / 2, np.pi]
 

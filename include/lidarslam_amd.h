@@ -451,6 +451,42 @@ int lsa_icp_cancel(lsa_ctx* ctx, int ticket);
 int lsa_icp_abandon(lsa_ctx* ctx);
 int lsa_match_types_gated(lsa_ctx* ctx, int slot, unsigned type_mask, int query_set, const lsa_match_params_t* p, int undistort);
 
+/* The same loops WITHOUT the host between two iterations: a LINK is a gate's block on the device that the solve in front
+ * of it fills in itself -- whether the next iteration runs (Slam.cxx:919-923, 950 / 1098-1107, 1151: the solve was not
+ * skipped and made a step), the pose from the solve's parameters (Utils::XYZRPYtoIsometry), the next start point
+ * (LocalOptimizer::SetPosePrior's IsometryToXYZRPY of that pose) and, localization, Slam::RefineUndistortion under the new
+ * pose (Slam.cxx:1322-1352) -- with the arithmetic the host uses on the same result when it arrives (lsa_posemath.h over
+ * lsa_pmath.h: the same bits).  A whole loop is enqueued at once:
+ *   lsa_match_types(...)                                       iteration 0, pose from the host
+ *   t1 = lsa_icp_link(ctx)                                     reserves a block (at most 7 at a time)
+ *   lsa_solve_device_begin_linked(.., prior, .., t1, &link)    solve 0 leaves block t1; what is enqueued next waits behind it
+ *   lsa_match_types_gated(...)                                 iteration 1: searches under the pose in t1, or does nothing
+ *   t2 = lsa_icp_link(ctx); lsa_solve_device_begin_linked(.., NULL, .., t2, &link); ...
+ *   lsa_solve_device_begin_linked(.., NULL, .., -1, NULL)      the last one leaves nothing
+ * then lsa_solve_device_end once per iteration, in order; the host takes the same decision from every result and, where
+ * the device stopped, forgets the rest with lsa_icp_abandon.  Between two iterations there is one kernel boundary. */
+typedef struct lsa_icp_link
+{
+  int refine_undistortion;         /* localization: Slam::RefineUndistortion between two iterations (Undistortion = REFINED) */
+  int first;                       /* first solve of the loop: the motion within the frame is `motion` (later solves go on
+                                      from what the solve before them left on the device) */
+  int have_log;                    /* Slam::InterpolateScanPose (Slam.cxx:1271-1285): LogTrajectory is not empty, */
+  double prev_time, cur_time;      /*   its last time and the current frame's [s], */
+  double max_extrapolation_ratio;  /*   MaxExtrapolationRatio */
+  double previous_world[16];       /* PreviousTworld */
+  double motion[16];               /* LinearTransformInterpolator: Time0, Time1, Rot0 (w x y z), Rot1, Trans0[3], Trans1[3] */
+} lsa_icp_link_t;
+int lsa_icp_link(lsa_ctx* ctx);
+int lsa_solve_device_begin_linked(lsa_ctx* ctx, unsigned type_mask, const double prior[6], int two_d_mode, int lm_max_iter, int min_matches,
+                                  int leave_ticket, const lsa_icp_link_t* link);
+/* Test hook: the block of `ticket` as the device holds it now (waits for the context's stream): words[0] = go, then pose
+ * R[9] t[3], start point [6], and the undistortion's constants (64 words in all, doubles unless stated in lsa_posemath.h). */
+int lsa_icp_link_peek(lsa_ctx* ctx, int ticket, unsigned long long words[64]);
+/* ... and the block the HOST's arithmetic gives for a solve that ended at `x` (its result's skipped / successful steps decide
+ * whether the next iteration runs): what lsa_icp_link_peek must show, word for word wherever go == 1 (with go == 0 only
+ * word 0 counts).  motion_after (may be NULL): the LinearTransformInterpolator state after the refinement. */
+int lsa_icp_link_expected(const double x[6], int skipped, int successful_steps, const lsa_icp_link_t* link, unsigned long long words[64], double motion_after[16]);
+
 /* Diagnostics (LSA_ROUTE_STATS=1): 100 MHz ticks block 0 spent evaluating, exchanging, folding, stepping, summed over
  * the solves so far; [4] evaluations, [5] ticks inside the kernel, [6] solves. */
 int lsa_solve_device_trace(lsa_ctx* ctx, unsigned long long out[12]);

@@ -56,7 +56,7 @@ ABI_SYMBOLS = [
     "lsa_set_azimuthal_resolution", "lsa_extract_keypoints", "lsa_extract_keypoints_more", "lsa_extract_prefetch", "lsa_extract_prefetch_adopted", "lsa_transform_frame_at", "lsa_set_keypoint_types", "lsa_download_keypoints", "lsa_keypoint_count",
     "lsa_download_debug", "lsa_nb_laser_rings", "lsa_transform_keypoints", "lsa_set_target", "lsa_set_target_from_set", "lsa_prepare_previous_targets", "lsa_prepared_targets_adopted", "lsa_target_staging", "lsa_set_target_staged", "lsa_stage_target_ahead", "lsa_drop_target_ahead", "lsa_staged_targets_adopted",
     "lsa_target_size", "lsa_download_target", "lsa_set_target_cell_size", "lsa_set_knn_lanes", "lsa_set_fused_match", "lsa_set_knn_rounds", "lsa_match_slow_queries", "lsa_match_exhaustive_queries", "lsa_match_route_stats", "lsa_match_trace", "lsa_set_keypoints", "lsa_match", "lsa_match_types", "lsa_match_types_undistorted",
-    "lsa_download_match", "lsa_overlap", "lsa_accumulate", "lsa_mailbox_active", "lsa_solve", "lsa_solve_device", "lsa_solve_device_fallbacks", "lsa_solve_device_begin", "lsa_solve_device_end", "lsa_solve_device_drop", "lsa_icp_gate", "lsa_icp_post", "lsa_icp_cancel", "lsa_icp_abandon", "lsa_debug_set", "lsa_match_types_gated", "lsa_solve_device_trace", "lsa_registration_error", "lsa_selftest_math", "lsa_reset_working_keypoints", "lsa_undistort", "lsa_working_time_range",
+    "lsa_download_match", "lsa_overlap", "lsa_accumulate", "lsa_mailbox_active", "lsa_solve", "lsa_solve_device", "lsa_solve_device_fallbacks", "lsa_solve_device_begin", "lsa_solve_device_end", "lsa_solve_device_drop", "lsa_icp_gate", "lsa_icp_link", "lsa_solve_device_begin_linked", "lsa_icp_link_peek", "lsa_icp_link_expected", "lsa_icp_post", "lsa_icp_cancel", "lsa_icp_abandon", "lsa_debug_set", "lsa_match_types_gated", "lsa_solve_device_trace", "lsa_registration_error", "lsa_selftest_math", "lsa_reset_working_keypoints", "lsa_undistort", "lsa_working_time_range",
     "lsa_working_bbox", "lsa_working_bboxes", "lsa_localization_begin", "lsa_arm_localization_boxes", "lsa_keypoint_bboxes_begin", "lsa_keypoint_bboxes_begin_interp", "lsa_keypoint_boxes_predicted_mark", "lsa_keypoint_boxes_predicted", "lsa_keypoint_time_range", "lsa_keypoint_bboxes_end", "lsa_download_transformed", "lsa_stage_transformed", "lsa_staged_transformed", "lsa_transform_frame", "lsa_profile_enable", "lsa_profile_select", "lsa_profile_reset",
     "lsa_profile_get", "lsa_slam_create", "lsa_slam_destroy", "lsa_slam_last_error", "lsa_slam_set_param",
     "lsa_slam_get_param", "lsa_slam_reset", "lsa_slam_clear_maps", "lsa_slam_add_frame", "lsa_slam_store_frame", "lsa_slam_add_stored_frame", "lsa_slam_hint_next_stored_frame", "lsa_slam_hint_next_frame", "lsa_upload_frame_begin", "lsa_upload_frame_ready", "lsa_upload_frame_adopt", "lsa_upload_frame_forget", "lsa_profile_event_overhead_us", "lsa_upload_robosense_frame", "lsa_pin_host_memory", "lsa_unpin_host_memory", "lsa_collect_garbage", "lsa_uploads_adopted", "lsa_extract_prefetch_uploaded",
@@ -80,6 +80,16 @@ class LsaError(RuntimeError):
     pass
 
 
+class IcpLink(C.Structure):
+    """lsa_icp_link_t (include/lidarslam_amd.h): what a solve needs to prepare the ICP iteration enqueued behind it."""
+
+    _fields_ = [
+        ("refine_undistortion", C.c_int), ("first", C.c_int), ("have_log", C.c_int),
+        ("prev_time", C.c_double), ("cur_time", C.c_double), ("max_extrapolation_ratio", C.c_double),
+        ("previous_world", C.c_double * 16), ("motion", C.c_double * 16),
+    ]
+
+
 class SolveResult(C.Structure):
     """lsa_solve_result_t (include/lidarslam_amd.h)."""
 
@@ -90,6 +100,17 @@ class SolveResult(C.Structure):
         ("num_evaluations", C.c_int), ("num_matches", C.c_int), ("skipped", C.c_int), ("termination", C.c_int),
         ("message", C.c_char_p),
     ]
+
+
+def icp_link_expected(x6, skipped, successful_steps, link):
+    """lsa_icp_link_expected: (the 64 words of the block, the motion afterwards) as the host's arithmetic gives them"""
+    words, motion = np.zeros(64, np.uint64), np.zeros(16, np.float64)
+    x = np.ascontiguousarray(x6, np.float64)
+    L = lib()
+    L.lsa_icp_link_expected.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    if L.lsa_icp_link_expected(ptr(x), int(skipped), int(successful_steps), C.byref(link), ptr(words), ptr(motion)) != 0:
+        raise LsaError("lsa_icp_link_expected")
+    return words, motion
 
 
 _lib = None
@@ -497,6 +518,23 @@ class Context:
     def icp_gate(self):
         self.L.lsa_icp_gate.argtypes = [C.c_void_p]
         return self._check(self.L.lsa_icp_gate(self.h), "lsa_icp_gate")
+
+    def icp_link(self):
+        """lsa_icp_link: reserves the block the next linked solve leaves for the iteration behind it -> ticket"""
+        self.L.lsa_icp_link.argtypes = [C.c_void_p]
+        return self._check(self.L.lsa_icp_link(self.h), "lsa_icp_link")
+
+    def solve_device_begin_linked(self, type_mask, prior6, leave_ticket, link, max_iter=15, two_d=False, min_matches=0):
+        w = None if prior6 is None else np.ascontiguousarray(prior6, np.float64)
+        self.L.lsa_solve_device_begin_linked.argtypes = [C.c_void_p, C.c_uint, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        self._check(self.L.lsa_solve_device_begin_linked(self.h, type_mask, None if w is None else ptr(w), int(two_d), max_iter, min_matches, leave_ticket,
+                                                         None if link is None else C.byref(link)), "lsa_solve_device_begin_linked")
+
+    def icp_link_peek(self, ticket):
+        out = np.zeros(64, np.uint64)
+        self.L.lsa_icp_link_peek.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        self._check(self.L.lsa_icp_link_peek(self.h, ticket, ptr(out)), "lsa_icp_link_peek")
+        return out
 
     def icp_post(self, ticket, pose, prior6, H0=None, H1=None, t0=0.0, t1=0.0):
         w = np.ascontiguousarray(prior6, np.float64)

@@ -10,6 +10,7 @@ namespace lsa
 {
 namespace host
 {
+constexpr unsigned kChainMax = 6;  // ICP iterations of one loop enqueued at once behind links (lsa_icp_link: 7 blocks, 7 mailboxes)
 namespace
 {
 #define ICP_TRACE(...) do { if (lsa_icp_trace_on()) std::fprintf(stderr, __VA_ARGS__); } while (0)
@@ -82,7 +83,7 @@ SlamCore::SlamCore(int device)
   ExtractParams.edge_saliency_threshold = 1.5f;
   ExtractParams.edge_intensity_gap_threshold = 50.f;
   for (int k = 0; k < 3; ++k) LocalMaps[k] = std::make_shared<RollingGrid>();
-  if (const char* e = std::getenv("LSA_ICP_AHEAD")) ICPAhead = std::atoi(e) != 0;  // default of the parameter (A/B runs)
+  if (const char* e = std::getenv("LSA_ICP_AHEAD")) ICPAhead = std::atoi(e);  // default of the parameter (A/B runs)
   // the plane map takes the largest insertions (tens of thousands of keypoints per keyframe): four host threads
   // keep them shorter than the ego-motion ICP they run beside ("MapAddThreads"; the map is the same for any value)
   LocalMaps[LSA_PLANE]->SetAddThreads(4);
@@ -644,8 +645,14 @@ int SlamCore::ComputeEgoMotion()
   // fixed (the solve on the host takes the distances the device solve was enqueued with).)
   static const bool aheadWithHostMaps = std::getenv("LSA_ICP_AHEAD_HOSTMAPS") != nullptr;  // (diagnostics)
   static const int aheadLoops = std::getenv("LSA_ICP_AHEAD_LOOPS") ? std::atoi(std::getenv("LSA_ICP_AHEAD_LOOPS")) : 3;  // (diagnostics: 1 ego-motion only, 2 localization only)
-  bool ahead = ICPAhead && DeviceLM && FusedMatch && (DeviceMapsInUse() || MapUpdate == MappingMode::NONE || aheadWithHostMaps) && (aheadLoops & 1);
-  if (ahead) lsa_icp_abandon(Ctx);
+  // ICPAhead = 2: the WHOLE loop is enqueued at once, every solve leaving pose and start point for the iteration behind it
+  // on the device (lsa_icp_link) -- no gate, no host between two iterations, nothing spins; this thread reads the results as
+  // they arrive, takes the decisions the device has taken already and does its own pose algebra beside the running device.
+  bool chain = ICPAhead >= 2 && DeviceLM && FusedMatch && EgoMotionICPMaxIter <= kChainMax && (aheadLoops & 1);
+  bool ahead = !chain && ICPAhead >= 1 && DeviceLM && FusedMatch && (DeviceMapsInUse() || MapUpdate == MappingMode::NONE || aheadWithHostMaps) && (aheadLoops & 1);
+  if (ahead || chain) lsa_icp_abandon(Ctx);
+  unsigned chained = 0;            // iterations 0 .. chained - 1 are in the queue (links)
+  long long chainSerial[kChainMax][3] = {};
   bool enqueued = false;           // this iteration's launches are in the queue (their gate has been answered)
   long long aheadSerial[3] = {0, 0, 0};
   auto callOff = [&](int& ticket) {
@@ -663,13 +670,45 @@ int SlamCore::ComputeEgoMotion()
     configure(optimizer);
     optimizer.SetPosePrior(Trelative);
     bool begun = enqueued;  // the solve of this iteration is in flight
-    if (!enqueued)
+    if (icpIter < chained)
+    {
+      begun = true;
+      for (int k : {LSA_EDGE, LSA_PLANE}) EgoMatchSerial[k] = chainSerial[icpIter][k];
+    }
+    else if (!enqueued)
     {
       // both keypoint types are matched concurrently and nothing is read back: the number of matches
       // arrives with the optimizer's first evaluation
       LSA_TRY(lsa_match_types(Ctx, LSA_TARGET_PREVIOUS, mask, LSA_SET_RAW_CURRENT, &mp, Trelative.m, nullptr));
       for (int k : {LSA_EDGE, LSA_PLANE}) EgoMatchSerial[k] = lsa_match_serial(Ctx, k);
-      if (ahead)
+      if (chain)
+      {
+        // this iteration's solve and every iteration behind it, as far as they can ride behind links
+        double prior[6];
+        ToXYZRPY(Trelative, prior);
+        lsa_icp_link_t link;
+        std::memset(&link, 0, sizeof(link));
+        for (unsigned j = icpIter; j < EgoMotionICPMaxIter; ++j)
+        {
+          int leave = j + 1 < EgoMotionICPMaxIter ? lsa_icp_link(Ctx) : -1;
+          if (leave < 0) leave = -1;
+          link.first = j == icpIter ? 1 : 0;
+          const int rc = lsa_solve_device_begin_linked(Ctx, mask, j == icpIter ? prior : nullptr, TwoDMode ? 1 : 0, static_cast<int>(EgoMotionLMMaxIter), static_cast<int>(MinNbMatchedKeypoints), leave,
+                                                       leave >= 0 ? &link : nullptr);
+          if (rc < 0) { lsa_icp_abandon(Ctx); return Fail(rc, "lsa_solve_device_begin_linked"); }
+          chained = j + 1;
+          if (leave < 0) break;
+          lsa_match_params_t next = mp;
+          next.saturation_distance = saturation(j + 1);
+          const int mrc = lsa_match_types_gated(Ctx, LSA_TARGET_PREVIOUS, mask, LSA_SET_RAW_CURRENT, &next, 0);
+          if (mrc < 0) { lsa_icp_abandon(Ctx); return Fail(mrc, "lsa_match_types_gated"); }
+          if (mrc != 0) { lsa_icp_cancel(Ctx, leave); break; }  // this match cannot wait behind a link: the loop goes on in line from there
+          for (int k : {LSA_EDGE, LSA_PLANE}) chainSerial[j + 1][k] = lsa_match_serial(Ctx, k);
+        }
+        chain = false;  // (enqueued once; whatever is not in the queue now runs in line)
+        begun = true;
+      }
+      else if (ahead)
       {
         LSA_TRY(optimizer.Begin(false));
         begun = true;
@@ -743,8 +782,8 @@ int SlamCore::ComputeEgoMotion()
         for (int k : {LSA_EDGE, LSA_PLANE}) EgoMatchSerial[k] = lsa_match_serial(Ctx, k);
         rc = optimizer.Solve(summary);
       }
-      if (rc < 0) { callOff(ticket); return Fail(rc, "LocalOptimizer::Solve (ego-motion)"); }
-      if (rc == 1) { ticket = -1; ahead = false; }  // solved on the host: what was enqueued ahead has been called off
+      if (rc < 0) { callOff(ticket); lsa_icp_abandon(Ctx); return Fail(rc, "LocalOptimizer::Solve (ego-motion)"); }
+      if (rc == 1) { ticket = -1; ahead = false; chained = 0; }  // solved on the host: what was enqueued ahead has been called off
       if (irc < 0) { callOff(ticket); return irc; }
     }
     else
@@ -764,9 +803,12 @@ int SlamCore::ComputeEgoMotion()
     }
     Stats.ego_lm += tlm.Stop();
     Stats.lm_evals += summary.num_evaluations;
-    if (summary.skipped) { callOff(ticket); break; }  // "Not enough keypoints, EgoMotion skipped for this frame."
+    // (links: the device has taken the same decision from the same result -- the iterations behind this one do nothing;
+    //  what their matches announced on the host is taken back)
+    const bool more = icpIter + 1 < chained;
+    if (summary.skipped) { callOff(ticket); if (more) lsa_icp_abandon(Ctx); break; }  // "Not enough keypoints, EgoMotion skipped for this frame."
     Trelative = optimizer.GetOptimizedPose();
-    if (summary.num_successful_steps == 1) { callOff(ticket); break; }
+    if (summary.num_successful_steps == 1) { callOff(ticket); if (more) lsa_icp_abandon(Ctx); break; }
     if (ticket >= 0)
     {
       double prior[6];
@@ -997,7 +1039,12 @@ int SlamCore::Localization()
   bool ahead = ICPAhead && DeviceLM && FusedMatch && (!undistortAhead || UndistortInSearch);
   static const int aheadLoops = std::getenv("LSA_ICP_AHEAD_LOOPS") ? std::atoi(std::getenv("LSA_ICP_AHEAD_LOOPS")) : 3;
   ahead = ahead && (aheadLoops & 2);
-  if (ahead) lsa_icp_abandon(Ctx);
+  // (ICPAhead = 2: the whole loop behind links, see ComputeEgoMotion; the device then also refines the undistortion)
+  bool chain = ahead && ICPAhead >= 2 && LocalizationICPMaxIter <= kChainMax;
+  if (chain) ahead = false;
+  if (ahead || chain) lsa_icp_abandon(Ctx);
+  unsigned chained = 0;
+  long long chainSerial[kChainMax][3] = {};
   bool enqueued = false;
   long long aheadSerial[3] = {0, 0, 0};
   auto callOff = [&](int& ticket) {
@@ -1026,10 +1073,56 @@ int SlamCore::Localization()
     configure(optimizer);
     optimizer.SetPosePrior(Tworld);
     bool begun = enqueued;
-    if (!enqueued)
+    if (icpIter < chained)
+    {
+      begun = true;
+      for (int k = 0; k < 3; ++k)
+        if ((mask >> k) & 1u) LocMatchSerial[k] = chainSerial[icpIter][k];
+    }
+    else if (!enqueued)
     {
       LSA_TRY(matchInLine());
-      if (ahead)
+      if (chain)
+      {
+        double prior[6];
+        ToXYZRPY(Tworld, prior);
+        lsa_icp_link_t link;
+        std::memset(&link, 0, sizeof(link));
+        link.refine_undistortion = undistortAhead ? 1 : 0;
+        link.have_log = LogTrajectory.empty() ? 0 : 1;
+        link.prev_time = LogTrajectory.empty() ? 0. : LogTrajectory.back().time;
+        link.cur_time = StampToSec(CurrentStamp);
+        link.max_extrapolation_ratio = MaxExtrapolationRatio;
+        std::memcpy(link.previous_world, PreviousTworld.m, sizeof(link.previous_world));
+        {
+          double* m = link.motion;
+          m[0] = Motion.Time0; m[1] = Motion.Time1;
+          m[2] = Motion.Rot0.w; m[3] = Motion.Rot0.x; m[4] = Motion.Rot0.y; m[5] = Motion.Rot0.z;
+          m[6] = Motion.Rot1.w; m[7] = Motion.Rot1.x; m[8] = Motion.Rot1.y; m[9] = Motion.Rot1.z;
+          for (int i = 0; i < 3; ++i) { m[10 + i] = Motion.Trans0[i]; m[13 + i] = Motion.Trans1[i]; }
+        }
+        for (unsigned j = icpIter; j < LocalizationICPMaxIter; ++j)
+        {
+          int leave = j + 1 < LocalizationICPMaxIter ? lsa_icp_link(Ctx) : -1;
+          if (leave < 0) leave = -1;
+          link.first = j == icpIter ? 1 : 0;
+          const int rc = lsa_solve_device_begin_linked(Ctx, 7u, j == icpIter ? prior : nullptr, TwoDMode ? 1 : 0, static_cast<int>(LocalizationLMMaxIter), static_cast<int>(MinNbMatchedKeypoints), leave,
+                                                       leave >= 0 ? &link : nullptr);
+          if (rc < 0) { lsa_icp_abandon(Ctx); return Fail(rc, "lsa_solve_device_begin_linked"); }
+          chained = j + 1;
+          if (leave < 0) break;
+          lsa_match_params_t next = mp;
+          next.saturation_distance = saturation(j + 1);
+          const int mrc = lsa_match_types_gated(Ctx, LSA_TARGET_MAP, mask, LSA_SET_WORKING, &next, undistortAhead ? 1 : 0);
+          if (mrc < 0) { lsa_icp_abandon(Ctx); return Fail(mrc, "lsa_match_types_gated"); }
+          if (mrc != 0) { lsa_icp_cancel(Ctx, leave); break; }
+          for (int k = 0; k < 3; ++k)
+            if ((mask >> k) & 1u) chainSerial[j + 1][k] = lsa_match_serial(Ctx, k);
+        }
+        chain = false;
+        begun = true;
+      }
+      else if (ahead)
       {
         LSA_TRY(optimizer.Begin(false));
         begun = true;
@@ -1086,8 +1179,8 @@ int SlamCore::Localization()
         rc = matchInLine();
         if (rc == LSA_OK) rc = optimizer.Solve(summary);
       }
-      if (rc < 0) { callOff(ticket); return Fail(rc, "LocalOptimizer::Solve (localization)"); }
-      if (rc == 1) { ticket = -1; ahead = false; }
+      if (rc < 0) { callOff(ticket); lsa_icp_abandon(Ctx); return Fail(rc, "LocalOptimizer::Solve (localization)"); }
+      if (rc == 1) { ticket = -1; ahead = false; chained = 0; }
       if (irc < 0) { callOff(ticket); return irc; }
     }
     else
@@ -1103,6 +1196,7 @@ int SlamCore::Localization()
     {
       // reset state to previous one to avoid instability (Slam.cxx:1098-1107)
       callOff(ticket);
+      if (icpIter + 1 < chained) lsa_icp_abandon(Ctx);  // (the device has left go = 0 for them)
       Trelative = Pose::Identity();
       Tworld = PreviousTworld;
       if (Undistortion) Motion.SetTransforms(Pose::Identity(), Pose::Identity());
@@ -1115,6 +1209,7 @@ int SlamCore::Localization()
     Trelative = Inverse(PreviousTworld) * Tworld;
     const bool lastIteration = (summary.num_successful_steps == 1) || (icpIter == LocalizationICPMaxIter - 1);
     if (lastIteration) callOff(ticket);  // nothing more to search: what follows on the stream does not wait behind the gate
+    if (lastIteration && icpIter + 1 < chained) lsa_icp_abandon(Ctx);  // (links: the device has decided the same)
     if (Undistortion == UNDISTORTION_REFINED)
     {
       if (UndistortInSearch && !lastIteration)
@@ -1144,6 +1239,8 @@ int SlamCore::Localization()
       pendingUndistort = false;
       enqueued = true;
     }
+    else if (icpIter + 1 < chained)
+      pendingUndistort = false;  // the next search is in the queue and undistorts with what the device worked out (the same)
   }
   if (KeepMatchDebug)
     for (int k = 0; k < 3; ++k)
@@ -1631,7 +1728,7 @@ int SlamCore::GetRegisteredFrame(std::vector<lsa_point_t>& out)
   X("SubMapsAhead", SubMapsAhead, bool)                                                                \
   X("SubMapsAheadAdaptive", SubMapsAheadAdaptive, bool)                                                \
   X("LocalizationStartFused", LocalizationStartFused, bool)                                            \
-  X("ICPAhead", ICPAhead, bool)                                                                        \
+  X("ICPAhead", ICPAhead, int)                                                                         \
   X("UndistortInSearch", UndistortInSearch, bool)                                                      \
   X("SpecBoxesOnLookahead", SpecBoxesOnLookahead, bool)                                                \
   X("SpecGridsTogether", SpecGridsTogether, bool)                                                      \

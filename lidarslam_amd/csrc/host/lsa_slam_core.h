@@ -218,7 +218,7 @@ public:
   bool SubMapsAheadAdaptive = true;  // give it up for a while when the localization had to wait for it twice in a row
   bool LocalizationStartFused = true;  // reset + first undistortion + keypoint boxes of the localization as one launch (device maps)
   int IcpGateTimeouts = 0;        // ICP iterations enqueued ahead whose gate gave up (diagnostics; 0 on a healthy run)
-  bool ICPAhead = true;           // ICP iteration i + 1 enqueued behind a gate while iteration i runs (lsa_icp_gate): no kernel launch between a solve and the next search
+  int ICPAhead = 2;               // ICP iterations enqueued ahead of their inputs.  2: the whole loop at once, every solve leaving the next iteration's pose on the device (lsa_icp_link); 1: iteration i + 1 behind a gate the host answers (lsa_icp_gate); 0: off
   bool UndistortInSearch = true;  // RefineUndistortion between two localization iterations inside the next iteration's search kernel
   bool SpecBoxesOnLookahead = true;  // the predicted boxes of the sub-maps ahead of time on the look-ahead stream, not the context's
   bool SpecGridsTogether = true;  // the search grids of the sub-maps extracted ahead of time built by one sequence of launches

@@ -42,6 +42,7 @@ constexpr int kLmBlocksMax = 128;         // grid limit of the one-launch LM sol
 constexpr int kLmBlocks = 64;
 constexpr int kLmThreads = 512;           // threads of a workgroup of k_lm_solve (8 wavefronts: two per SIMD)
 constexpr int kLmOut = 48;                // doubles the LM kernel hands to the host (96 granules)
+constexpr int kLmMailRing = 8;            // result mailboxes: solves enqueued one behind the other (lsa_icp_link) each write their own
 constexpr int kHistRing = 256;  // half of it is cleared at a time (two fills on the ICP's stream): once in 128 matches
 constexpr int kAccumVals = 29;            // cost, g[6], H upper[21], nvalid
 constexpr int kGateRing = 8;              // gates (ICP iterations enqueued ahead of their inputs) a context can have in flight
@@ -231,7 +232,7 @@ struct lsa_ctx
   // one-launch LM solve (lsa_solve_device): granules the blocks exchange their partial sums through
   // ([2 parities][kLmBlocksMax][kMailboxStride], device memory) and the result granules in coherent host memory
   unsigned long long* lm_xchg = nullptr;
-  unsigned long long* lm_mailbox = nullptr;  // [2 * kLmOut]
+  unsigned long long* lm_mailbox = nullptr;  // [kLmMailRing][2 * kLmOut]
   unsigned lm_tag = 0;            // tags handed out so far (every launch takes max evaluations + 2)
   unsigned long long lm_seq = 0;  // launches so far
   int lm_blocks = lsa::kLmBlocks;
@@ -243,7 +244,8 @@ struct lsa_ctx
   unsigned long long* gate_dev = nullptr;
   unsigned gate_seq = 0;                 // gates enqueued so far
   int gate_current = -1;                 // ticket the launches enqueued next wait behind (lsa_match_types_gated, lsa_solve_device_begin)
-  struct GateSaved { double sat[3]; int hist_pos[3]; long long hist_serial[3]; int k[3]; bool valid[3]; unsigned mask; bool used; } gate_saved[lsa::kGateRing] = {};
+  struct GateSaved { double sat[3]; int hist_pos[3]; long long hist_serial[3]; int k[3]; bool valid[3]; unsigned mask; bool used; bool link; unsigned seq; } gate_saved[lsa::kGateRing] = {};
+  double* motion_dev = nullptr;          // [16] the motion within the frame (LinearTransformInterpolator) between the linked solves of one localization loop
   int debug_gate_give_up_every = 0;      // lsa_debug_set: every n-th gate gives up at once (exercises the callers' fall-back)
   int debug_lm_give_up_block = -1;       // lsa_debug_set: that workgroup of the NEXT solve abandons the exchange (one shot)
   std::deque<unsigned> lm_pending;       // result tags of the solves begun and not ended yet, oldest first

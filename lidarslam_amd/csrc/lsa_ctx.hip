@@ -495,8 +495,8 @@ int lsa_ctx_create(int device_id, lsa_ctx** out)
     std::memset(ctx->mailbox, 0, (size_t)kAccumBlocksMax * kMailboxStride * sizeof(unsigned long long));
   else
     ctx->mailbox = nullptr;  // optional: lsa_accumulate falls back to a copy + synchronise
-  if (hipHostMalloc((void**)&ctx->lm_mailbox, (size_t)2 * kLmOut * sizeof(unsigned long long), hipHostMallocCoherent | hipHostMallocMapped) == hipSuccess)
-    std::memset(ctx->lm_mailbox, 0, (size_t)2 * kLmOut * sizeof(unsigned long long));
+  if (hipHostMalloc((void**)&ctx->lm_mailbox, (size_t)kLmMailRing * 2 * kLmOut * sizeof(unsigned long long), hipHostMallocCoherent | hipHostMallocMapped) == hipSuccess)
+    std::memset(ctx->lm_mailbox, 0, (size_t)kLmMailRing * 2 * kLmOut * sizeof(unsigned long long));
   else
     ctx->lm_mailbox = nullptr;  // optional: lsa_solve_device then reports LSA_E_STATE and the host-driven loop is used
   // gates of ICP iterations enqueued ahead (lsa_icp_gate): optional like the result mailbox
@@ -513,6 +513,8 @@ int lsa_ctx_create(int device_id, lsa_ctx** out)
   }
   else
     ctx->gate_host = nullptr;
+  if (ctx->gate_dev && (hipMalloc((void**)&ctx->motion_dev, 16 * sizeof(double)) != hipSuccess || hipMemset(ctx->motion_dev, 0, 16 * sizeof(double)) != hipSuccess))
+    ctx->motion_dev = nullptr;  // optional: no links then (lsa_icp_link says so)
   ok &= hipMalloc((void**)&ctx->lm_xchg, (size_t)2 * kLmBlocksMax * kMailboxStride * sizeof(unsigned long long)) == hipSuccess;
   if (ok) ok &= hipMemset(ctx->lm_xchg, 0, (size_t)2 * kLmBlocksMax * kMailboxStride * sizeof(unsigned long long)) == hipSuccess;
   if (const char* e = std::getenv("LSA_ACCUM_BLOCKS")) ctx->accum_blocks = std::min(std::max(std::atoi(e), 1), kAccumBlocksMax);
@@ -588,6 +590,7 @@ void lsa_ctx_destroy(lsa_ctx* ctx)
   if (ctx->lm_mailbox) (void)hipHostFree(ctx->lm_mailbox);
   if (ctx->gate_host) (void)hipHostFree(ctx->gate_host);
   fr(ctx->gate_dev);
+  fr(ctx->motion_dev);
   fr(ctx->lm_xchg);
   fr(ctx->trace_dev);
   for (int i = 0; i < 2; ++i)

@@ -43,7 +43,16 @@ struct LmParams
   unsigned tag_base;
   int cslots;  // residual blocks per thread kept in LDS between the evaluations
   int give_up_block;    // test hook: this workgroup abandons the exchange at its first evaluation (-1: none)
-  const IcpGate* gate;  // not null: the launch was enqueued ahead of its start point (lsa_icp_gate) -- x0 comes from there, or nothing is done
+  const IcpGate* gate;  // not null: the launch was enqueued ahead of its start point (lsa_icp_gate / lsa_icp_link) -- x0 comes from there, or nothing is done
+  // What this solve leaves for the ICP iteration enqueued behind it (lsa_icp_link; Slam.cxx:907, 940-950 and 1086, 1134-1151):
+  // whether it runs at all, the pose its keypoints are searched under, its start point and -- localization -- the undistortion.
+  IcpGate* leave;             // null: nothing is left (no iteration behind this one)
+  int link_refine;            // localization with Slam::RefineUndistortion between two iterations
+  int motion_from_args;       // the motion within the frame as the loop starts with it: motion0 (first solve of the loop) or motion_dev
+  posemath::ScanPoseClock clock;
+  Rigid previous_world;       // PreviousTworld
+  double motion0[16];         // Time0, Time1, Rot0 (w x y z), Rot1, Trans0, Trans1
+  double* motion_dev;         // the same 16 values between the solves of one loop
 };
 
 // result layout (doubles): [0..5] pose, [6] initial cost, [7] final cost, [8..36] the 29 sums at the final
@@ -462,6 +471,66 @@ __device__ bool lm_step(const LmParams& p, Shared& sh, bool first)
   }
 }
 
+// What the host's loop does between two ICP iterations (host/lsa_slam_core.cpp, Slam.cxx:940-950 / 1134-1151), for the
+// iteration enqueued behind this solve: does it run (the solve was not skipped and made a step), the pose from the solve's
+// parameters, the next start point (the round trip through the matrix, as LocalOptimizer::SetPosePrior makes it) and,
+// localization, Slam::RefineUndistortion under the new pose.  lsa_posemath.h is the host's arithmetic: the host works
+// the same values out from the same result when it arrives, bit for bit.  One wavefront: the six half-angle
+// cosines / sines side by side, the rest on lane 0.
+__device__ void leave_link(const LmParams& p, const LmState& lm, bool failed)
+{
+  using namespace posemath;
+  IcpGate* g = p.leave;
+  const int lane = threadIdx.x & 63;
+  const bool go = !failed && !lm.skipped && lm.successful != 1;
+  if (!go)
+  {
+    if (lane == 0) g->go = 0ull;
+    return;
+  }
+  const double half = lm.x[3 + (lane < 6 ? lane % 3 : 0)] * 0.5;
+  const double v = lane < 3 ? lsa_cos(half) : lsa_sin(half);
+  const double cx = lane_value(v, 0), cy = lane_value(v, 1), cz = lane_value(v, 2);
+  const double sx = lane_value(v, 3), sy = lane_value(v, 4), sz = lane_value(v, 5);
+  if (lane != 0) return;
+  double x[6];
+#pragma unroll
+  for (int a = 0; a < 6; ++a) x[a] = lm.x[a];
+  const Pose T = FromXYZRPYTrig(x, cx, sx, cy, sy, cz, sz);
+  double x0[6];
+  ToXYZRPY(T, x0);
+  g->in.pose = ToRigid(T);
+#pragma unroll
+  for (int a = 0; a < 6; ++a) g->in.x0[a] = x0[a];
+  if (p.link_refine)
+  {
+    WithinFrameMotion m;
+    double mv[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) mv[i] = p.motion0[i];
+    if (!p.motion_from_args)
+    {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) mv[i] = p.motion_dev[i];
+    }
+    m.Time0 = mv[0]; m.Time1 = mv[1];
+    m.Rot0 = {mv[2], mv[3], mv[4], mv[5]};
+    m.Rot1 = {mv[6], mv[7], mv[8], mv[9]};
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { m.Trans0[i] = mv[10 + i]; m.Trans1[i] = mv[13 + i]; }
+    Pose d0, d1;
+    RefineUndistortion(m, p.clock, FromRigid(p.previous_world), T, d0, d1);
+    g->in.ic = MakeInterpConst(d0, d1, m.Time0, m.Time1);
+    double* o = p.motion_dev;
+    o[0] = m.Time0; o[1] = m.Time1;
+    o[2] = m.Rot0.w; o[3] = m.Rot0.x; o[4] = m.Rot0.y; o[5] = m.Rot0.z;
+    o[6] = m.Rot1.w; o[7] = m.Rot1.x; o[8] = m.Rot1.y; o[9] = m.Rot1.z;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { o[10 + i] = m.Trans0[i]; o[13 + i] = m.Trans1[i]; }
+  }
+  g->go = 1ull;
+}
+
 __global__ __launch_bounds__(kLmThreads) void k_lm_solve(LmParams p, u64* __restrict__ xchg, u64* __restrict__ mailbox, unsigned out_tag, unsigned long long* trace)
 {
   __shared__ Shared sh;
@@ -481,6 +550,8 @@ __global__ __launch_bounds__(kLmThreads) void k_lm_solve(LmParams p, u64* __rest
         const unsigned word = (threadIdx.x & 1) ? (unsigned)(bits >> 32) : (unsigned)(bits & 0xffffffffull);
         __hip_atomic_store(mailbox + threadIdx.x, ((u64)out_tag << 32) | word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       }
+      // an iteration that does not run leaves the same for the one behind it
+      if (p.leave && blockIdx.x == 0 && threadIdx.x == 0) p.leave->go = 0ull;
       return;
     }
   }
@@ -538,6 +609,8 @@ __global__ __launch_bounds__(kLmThreads) void k_lm_solve(LmParams p, u64* __rest
     trace[7] += sh.lap[4];  // of "evaluate": the residual blocks alone (before the wavefront's reduction)
     for (int i = 0; i < 4; ++i) trace[8 + i] += sh.sub[i];
   }
+  // the iteration enqueued behind this solve: the second wavefront prepares what it reads while the first sends the result
+  if (p.leave && threadIdx.x >= 64 && threadIdx.x < 128) leave_link(p, sh.lm, failed);
   // every block holds the same result; block 0's copy goes out as 2 granules per double
   if (threadIdx.x < 2 * kResCount)
   {
@@ -642,9 +715,11 @@ int lm_cache_capacity()
 
 extern "C" {
 
-int lsa_solve_device_begin(lsa_ctx* ctx, unsigned type_mask, const double prior[6], int two_d_mode, int lm_max_iter, int min_matches)
+static int solve_device_begin(lsa_ctx* ctx, unsigned type_mask, const double prior[6], int two_d_mode, int lm_max_iter, int min_matches, int leave_ticket, const lsa_icp_link_t* link)
 {
   if (!ctx) return LSA_E_ARG;
+  if (leave_ticket >= 0 && (leave_ticket >= kGateRing || !link || !ctx->gate_dev || !ctx->gate_saved[leave_ticket].used || !ctx->gate_saved[leave_ticket].link))
+    return ctx->fail(LSA_E_ARG, "lsa_solve_device_begin_linked: no such link (lsa_icp_link)");
   if (!prior && ctx->gate_current < 0) return ctx->fail(LSA_E_ARG, "lsa_solve_device_begin: no start point and no gate to wait behind");
   if (!ctx->lm_mailbox) return ctx->fail(LSA_E_STATE, "lsa_solve_device: no coherent host memory for the result");
   LSA_HIP(ctx, hipSetDevice(ctx->device));
@@ -663,6 +738,25 @@ int lsa_solve_device_begin(lsa_ctx* ctx, unsigned type_mask, const double prior[
   p.give_up_block = ctx->debug_lm_give_up_block;
   ctx->debug_lm_give_up_block = -1;
   p.gate = prior ? nullptr : reinterpret_cast<const IcpGate*>(ctx->gate_dev + (size_t)ctx->gate_current * kGateWords);
+  p.leave = nullptr;
+  p.link_refine = 0;
+  p.motion_from_args = 0;
+  p.motion_dev = ctx->motion_dev;
+  std::memset(&p.clock, 0, sizeof(p.clock));
+  std::memset(&p.previous_world, 0, sizeof(p.previous_world));
+  std::memset(p.motion0, 0, sizeof(p.motion0));
+  if (leave_ticket >= 0)
+  {
+    p.leave = reinterpret_cast<IcpGate*>(ctx->gate_dev + (size_t)leave_ticket * kGateWords);
+    p.link_refine = link->refine_undistortion ? 1 : 0;
+    p.motion_from_args = link->first ? 1 : 0;
+    p.clock.have_log = link->have_log ? 1 : 0;
+    p.clock.prev_time = link->prev_time;
+    p.clock.cur_time = link->cur_time;
+    p.clock.max_ratio = link->max_extrapolation_ratio;
+    row_major_to_rt(link->previous_world, p.previous_world.R, p.previous_world.t);
+    std::memcpy(p.motion0, link->motion, sizeof(p.motion0));
+  }
   p.two_d = two_d_mode ? 1 : 0;
   p.max_iter = lm_max_iter < 0 ? 0 : lm_max_iter;
   p.min_matches = min_matches;
@@ -683,12 +777,25 @@ int lsa_solve_device_begin(lsa_ctx* ctx, unsigned type_mask, const double prior[
   p.cslots = std::min(per_thread, std::max(ctx->lm_cache_slots, 0));
   {
     ProfScope ps(ctx, "lm_solve", 0.);
-    hipLaunchKernelGGL(k_lm_solve, dim3(nb), dim3(kLmThreads), p.cslots * slot_bytes, ctx->stream, p, ctx->lm_xchg, ctx->lm_mailbox, out_tag,
+    hipLaunchKernelGGL(k_lm_solve, dim3(nb), dim3(kLmThreads), p.cslots * slot_bytes, ctx->stream, p, ctx->lm_xchg, ctx->lm_mailbox + (size_t)(out_tag % kLmMailRing) * 2 * kLmOut, out_tag,
                        ctx->route_stats && ctx->trace_dev ? reinterpret_cast<unsigned long long*>(ctx->trace_dev) + (size_t)8192 * 12 : nullptr);
   }
   ctx->lm_pending.push_back(out_tag);
-  if (lsa_icp_trace_on()) std::fprintf(stderr, "[lm begin] tag %u gated %d sat2 %.6g %.6g counts %d %d\n", out_tag, prior ? 0 : 1, p.set.sat2[0], p.set.sat2[1], p.set.count[0], p.set.count[1]);
+  // what is enqueued next waits behind the link this solve leaves
+  if (leave_ticket >= 0) ctx->gate_current = leave_ticket;
+  if (lsa_icp_trace_on()) std::fprintf(stderr, "[lm begin] tag %u gated %d leaves %d sat2 %.6g %.6g counts %d %d\n", out_tag, prior ? 0 : 1, leave_ticket, p.set.sat2[0], p.set.sat2[1], p.set.count[0], p.set.count[1]);
   return LSA_OK;
+}
+
+int lsa_solve_device_begin(lsa_ctx* ctx, unsigned type_mask, const double prior[6], int two_d_mode, int lm_max_iter, int min_matches)
+{
+  return solve_device_begin(ctx, type_mask, prior, two_d_mode, lm_max_iter, min_matches, -1, nullptr);
+}
+
+int lsa_solve_device_begin_linked(lsa_ctx* ctx, unsigned type_mask, const double prior[6], int two_d_mode, int lm_max_iter, int min_matches, int leave_ticket, const lsa_icp_link_t* link)
+{
+  if (ctx && (int)ctx->lm_pending.size() >= kLmMailRing - 1) return ctx->fail(LSA_E_STATE, "lsa_solve_device_begin_linked: too many solves in flight");
+  return solve_device_begin(ctx, type_mask, prior, two_d_mode, lm_max_iter, min_matches, leave_ticket, link);
 }
 
 int lsa_solve_device_drop(lsa_ctx* ctx)
@@ -707,6 +814,7 @@ int lsa_solve_device_end(lsa_ctx* ctx, lsa_solve_result_t* out)
   if (lsa_icp_trace_on()) std::fprintf(stderr, "[lm end] waits for tag %u (%zu more in flight)\n", out_tag, ctx->lm_pending.size());
   // the result arrives as granules in coherent host memory (as lsa_accumulate's sums do)
   double res[kResCount];
+  const unsigned long long* box = ctx->lm_mailbox + (size_t)(out_tag % kLmMailRing) * 2 * kLmOut;  // (solves in flight do not share a mailbox)
   {
     const auto t0 = std::chrono::steady_clock::now();
     unsigned spins = 0;
@@ -714,7 +822,7 @@ int lsa_solve_device_end(lsa_ctx* ctx, lsa_solve_result_t* out)
     {
       unsigned long long g[2];
       for (int h = 0; h < 2; ++h)
-        while (((g[h] = __atomic_load_n(ctx->lm_mailbox + 2 * v + h, __ATOMIC_RELAXED)) >> 32) != out_tag)
+        while (((g[h] = __atomic_load_n(box + 2 * v + h, __ATOMIC_RELAXED)) >> 32) != out_tag)
         {
           if ((++spins & 0x3ff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2000))
           {
@@ -799,10 +907,89 @@ int lsa_icp_gate(lsa_ctx* ctx)
   lsa_ctx::GateSaved& sv = ctx->gate_saved[ticket];
   sv = lsa_ctx::GateSaved();
   sv.used = true;
+  sv.seq = seq;
   hipLaunchKernelGGL(k_icp_gate, dim3(1), dim3(kGateGranules), 0, ctx->stream, ctx->gate_host + (size_t)ticket * kGateGranules, ctx->gate_dev + (size_t)ticket * kGateWords, seq,
                      (ctx->debug_gate_give_up_every > 0 && seq % (unsigned)ctx->debug_gate_give_up_every == 0) ? 1 : 0);
   ctx->gate_current = ticket;
   return ticket;
+}
+
+// A link is a gate without the kernel and without the host: the block on the device is written by the SOLVE in front of it
+// (k_lm_solve's leave_link: lsa_posemath.h's arithmetic, which the host repeats on the same result when it arrives), so that
+// between two iterations there is one kernel boundary -- no trip over the bus, no host thread on the path.  The ticket is
+// reserved here, handed to lsa_solve_device_begin_linked as the block to leave, and what is enqueued after that solve
+// (lsa_match_types_gated, the next solve) waits behind it.
+int lsa_icp_link(lsa_ctx* ctx)
+{
+  if (!ctx) return LSA_E_ARG;
+  if (!ctx->gate_dev || !ctx->motion_dev) return ctx->fail(LSA_E_STATE, "lsa_icp_link: no device memory for the links");
+  const unsigned seq = ctx->gate_seq + 1;
+  const int ticket = (int)(seq % kGateRing);
+  if (ctx->gate_saved[ticket].used) return ctx->fail(LSA_E_STATE, "lsa_icp_link: too many iterations enqueued ahead");
+  ctx->gate_seq = seq;
+  lsa_ctx::GateSaved& sv = ctx->gate_saved[ticket];
+  sv = lsa_ctx::GateSaved();
+  sv.used = true;
+  sv.link = true;
+  sv.seq = seq;
+  return ticket;
+}
+
+// What the HOST works out between two iterations from a solve's result (lsa_posemath.h compiled for this side: the loops
+// of host/lsa_slam_core.cpp call the same functions), laid out as the device's block: a test holds lsa_icp_link_peek
+// against it, word for word.
+int lsa_icp_link_expected(const double x[6], int skipped, int successful_steps, const lsa_icp_link_t* link, unsigned long long words[64], double motion_after[16])
+{
+  if (!x || !link || !words) return LSA_E_ARG;
+  using namespace posemath;
+  IcpGate g;
+  std::memset(&g, 0, sizeof(g));
+  std::memset(words, 0, kGateWords * sizeof(unsigned long long));
+  if (motion_after) std::memcpy(motion_after, link->motion, 16 * sizeof(double));
+  if (skipped || successful_steps == 1) return LSA_OK;  // go = 0: nothing else of the block means anything
+  const Pose T = FromXYZRPY(x);
+  ToXYZRPY(T, g.in.x0);
+  g.in.pose = ToRigid(T);
+  if (link->refine_undistortion)
+  {
+    WithinFrameMotion m;
+    const double* mv = link->motion;
+    m.Time0 = mv[0]; m.Time1 = mv[1];
+    m.Rot0 = {mv[2], mv[3], mv[4], mv[5]};
+    m.Rot1 = {mv[6], mv[7], mv[8], mv[9]};
+    for (int i = 0; i < 3; ++i) { m.Trans0[i] = mv[10 + i]; m.Trans1[i] = mv[13 + i]; }
+    ScanPoseClock clock;
+    clock.have_log = link->have_log ? 1 : 0;
+    clock.prev_time = link->prev_time;
+    clock.cur_time = link->cur_time;
+    clock.max_ratio = link->max_extrapolation_ratio;
+    Pose previous, d0, d1;
+    std::memcpy(previous.m, link->previous_world, sizeof(previous.m));
+    // (the device keeps R and t of PreviousTworld: the last row is (0, 0, 0, 1) by construction)
+    previous = FromRigid(ToRigid(previous));
+    RefineUndistortion(m, clock, previous, T, d0, d1);
+    g.in.ic = MakeInterpConst(d0, d1, m.Time0, m.Time1);
+    if (motion_after)
+    {
+      double* o = motion_after;
+      o[0] = m.Time0; o[1] = m.Time1;
+      o[2] = m.Rot0.w; o[3] = m.Rot0.x; o[4] = m.Rot0.y; o[5] = m.Rot0.z;
+      o[6] = m.Rot1.w; o[7] = m.Rot1.x; o[8] = m.Rot1.y; o[9] = m.Rot1.z;
+      for (int i = 0; i < 3; ++i) { o[10 + i] = m.Trans0[i]; o[13 + i] = m.Trans1[i]; }
+    }
+  }
+  g.go = 1ull;
+  std::memcpy(words, &g, sizeof(g));
+  return LSA_OK;
+}
+
+int lsa_icp_link_peek(lsa_ctx* ctx, int ticket, unsigned long long words[64])
+{
+  if (!ctx || !words || ticket < 0 || ticket >= kGateRing || !ctx->gate_dev) return ctx ? ctx->fail(LSA_E_ARG, "lsa_icp_link_peek: bad argument") : LSA_E_ARG;
+  LSA_HIP(ctx, hipSetDevice(ctx->device));
+  LSA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  LSA_HIP(ctx, hipMemcpy(words, ctx->gate_dev + (size_t)ticket * kGateWords, kGateWords * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  return LSA_OK;
 }
 
 static int gate_release(lsa_ctx* ctx, int ticket, const IcpGate* block)
@@ -844,8 +1031,18 @@ int lsa_icp_cancel(lsa_ctx* ctx, int ticket)
   if (!ctx || ticket < 0 || ticket >= kGateRing) return LSA_E_ARG;
   // what the launches behind the gate had announced on the host is taken back: they will not run
   const lsa_ctx::GateSaved sv = ctx->gate_saved[ticket];
-  const int rc = gate_release(ctx, ticket, nullptr);
-  if (rc) return rc;
+  if (sv.link)
+  {
+    // (the device has called it off itself -- the solve in front left go = 0 -- or will never reach it)
+    if (!sv.used) return ctx->fail(LSA_E_ARG, "lsa_icp_cancel: no such link");
+    ctx->gate_saved[ticket].used = false;
+    if (ctx->gate_current == ticket) ctx->gate_current = -1;
+  }
+  else
+  {
+    const int rc = gate_release(ctx, ticket, nullptr);
+    if (rc) return rc;
+  }
   for (int k = 0; k < 3; ++k)
     if ((sv.mask >> k) & 1u)
     {
@@ -861,8 +1058,15 @@ int lsa_icp_cancel(lsa_ctx* ctx, int ticket)
 int lsa_icp_abandon(lsa_ctx* ctx)
 {
   if (!ctx) return LSA_E_ARG;
-  for (int t = 0; t < kGateRing; ++t)
-    if (ctx->gate_saved[t].used) (void)lsa_icp_cancel(ctx, t);
+  // the youngest first: each takes back what ITS match announced, the oldest one's "before" is what remains
+  while (true)
+  {
+    int youngest = -1;
+    for (int t = 0; t < kGateRing; ++t)
+      if (ctx->gate_saved[t].used && (youngest < 0 || (int)(ctx->gate_saved[t].seq - ctx->gate_saved[youngest].seq) > 0)) youngest = t;
+    if (youngest < 0) break;
+    if (lsa_icp_cancel(ctx, youngest) != LSA_OK) ctx->gate_saved[youngest].used = false;
+  }
   ctx->lm_pending.clear();
   ctx->gate_current = -1;
   return LSA_OK;

@@ -128,6 +128,23 @@ struct Quaternion
 {
   double w, x, y, z;
 };
+// Eigen::Quaternion(Matrix3d), the branch for a trace <= 0 with I the largest diagonal element (constant indices only:
+// nothing of a pose is addressed by a run-time index, which on the device would put it in scratch memory)
+template <int I> LSA_HD Quaternion ToQuaternionLargest(const Pose& p)
+{
+  constexpr int J = (I + 1) % 3, K = (J + 1) % 3;
+  Quaternion q;
+  double t = __builtin_sqrt(p(I, I) - p(J, J) - p(K, K) + 1.0);
+  const double vi = 0.5 * t;
+  t = 0.5 / t;
+  q.w = (p(K, J) - p(J, K)) * t;
+  const double vj = (p(J, I) + p(I, J)) * t;
+  const double vk = (p(K, I) + p(I, K)) * t;
+  q.x = I == 0 ? vi : (J == 0 ? vj : vk);
+  q.y = I == 1 ? vi : (J == 1 ? vj : vk);
+  q.z = I == 2 ? vi : (J == 2 ? vj : vk);
+  return q;
+}
 LSA_HD Quaternion ToQuaternion(const Pose& p)
 {
   Quaternion q;
@@ -140,25 +157,12 @@ LSA_HD Quaternion ToQuaternion(const Pose& p)
     q.x = (p(2, 1) - p(1, 2)) * t;
     q.y = (p(0, 2) - p(2, 0)) * t;
     q.z = (p(1, 0) - p(0, 1)) * t;
+    return q;
   }
-  else
-  {
-    int i = 0;
-    if (p(1, 1) > p(0, 0)) i = 1;
-    if (p(2, 2) > p(i, i)) i = 2;
-    const int j = (i + 1) % 3, k = (j + 1) % 3;
-    t = __builtin_sqrt(p(i, i) - p(j, j) - p(k, k) + 1.0);
-    // (the three components by comparison, not by a run-time index: no array in scratch memory on the device)
-    const double vi = 0.5 * t;
-    t = 0.5 / t;
-    q.w = (p(k, j) - p(j, k)) * t;
-    const double vj = (p(j, i) + p(i, j)) * t;
-    const double vk = (p(k, i) + p(i, k)) * t;
-    q.x = i == 0 ? vi : (j == 0 ? vj : vk);
-    q.y = i == 1 ? vi : (j == 1 ? vj : vk);
-    q.z = i == 2 ? vi : (j == 2 ? vj : vk);
-  }
-  return q;
+  int i = 0;
+  if (p(1, 1) > p(0, 0)) i = 1;
+  if (p(2, 2) > (i == 0 ? p(0, 0) : p(1, 1))) i = 2;
+  return i == 0 ? ToQuaternionLargest<0>(p) : (i == 1 ? ToQuaternionLargest<1>(p) : ToQuaternionLargest<2>(p));
 }
 LSA_HD void SetRotation(Pose& p, const Quaternion& q)
 {

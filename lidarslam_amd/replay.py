@@ -126,10 +126,9 @@ class ConcurrentReplay:
         # the maps' chains of small kernels compete for them with the ICP kernels of the other sequences (8 sequences:
         # 1810 against 2210 frames/s), where the host cores are there (2.6 per sequence against 1.4).
         params.setdefault("MapsOnDevice", 1 if len(seeds) == 1 else 0)
-        # ICP iterations enqueued ahead wait behind a gate that spins on its hardware queue: alone on the GPU that is the
-        # shortest hand-over, side by side it holds up the other sequences' kernels on the same queue (8 sequences: 1 980
-        # against 2 030 frames/s)
-        params.setdefault("ICPAhead", 1 if len(seeds) == 1 else 0)
+        # ICP loops enqueued whole, every solve leaving the next iteration's pose on the device (links: nothing spins on a
+        # hardware queue, unlike the gates of ICPAhead = 1, which side by side held up the other sequences' kernels)
+        params.setdefault("ICPAhead", 2)
         self.frames = frames
         self.lookahead = lookahead  # extract frame f + 1 beside the registration of frame f (same results)
         self.slams, self.stamps = [], []

@@ -576,6 +576,93 @@ def test_an_iteration_enqueued_behind_a_gate_equals_the_one_enqueued_in_line(gpu
     assert gpu_ctx.solve_device_fallbacks() == 0
 
 
+def test_links_left_by_the_device_equal_the_host_algebra(gpu_ctx, O, L, kps):
+    """lsa_icp_link: the solve itself leaves, on the device, what the iteration enqueued behind it reads -- run or not, the
+    pose from its parameters, the next start point, the refined undistortion (Slam.cxx:940-950, 1134-1151, 1322-1352).
+    (a) The block equals what lsa_posemath.h gives on the HOST from the same result, word for word (one source, two
+    compilers), for ego-motion and localization links, with and without a trajectory to interpolate, when the solve made no
+    step (go = 0) and when it was skipped.  (b) A whole loop enqueued at once -- three iterations behind links, the host only
+    reading results -- computes what the same iterations compute one by one with the host in between."""
+    prev, cur = kps[16]
+    mp = L.MatchParams.ego_motion(saturation_distance=5.0)
+    mp2 = L.MatchParams.ego_motion(saturation_distance=3.0)
+    mp3 = L.MatchParams.ego_motion(saturation_distance=1.5)
+    for k in (0, 1):
+        gpu_ctx.set_keypoints(L.SET_WORKING, k, cur[k])
+        gpu_ctx.set_target(k, prev[k])
+    gpu_ctx.set_keypoints(L.SET_WORKING, 2, cur[2][:0])
+    pose, w0 = perturbed(0.45, 0.01), np.array([0.45, 0.02, 0.0, 0.0, 0.0, 0.01])
+    rng = np.random.default_rng(5)
+
+    def link_for(refine, have_log, first=1, ratio=3.0):
+        ln = L.IcpLink()
+        ln.refine_undistortion, ln.first, ln.have_log = refine, first, have_log
+        ln.prev_time, ln.cur_time, ln.max_extrapolation_ratio = 10.0, 10.1, ratio
+        pw = se3(*(np.array([-0.5, 0.03, 0.01, 0.002, -0.004, 0.02]) + 1e-3 * rng.standard_normal(6)))
+        ln.previous_world[:] = list(pw.reshape(-1))
+        # a motion within the frame as an earlier refinement would have left it: two unit quaternions, two translations
+        q0, q1 = rng.standard_normal(4) * 1e-3 + [1, 0, 0, 0], rng.standard_normal(4) * 1e-3 + [1, 0, 0, 0]
+        q0, q1 = q0 / np.linalg.norm(q0), q1 / np.linalg.norm(q1)
+        ln.motion[:] = [-0.1, 0.0] + list(q0) + list(q1) + list(1e-2 * rng.standard_normal(3)) + list(1e-2 * rng.standard_normal(3))
+        return ln
+
+    # (a) one solve, one link, the block read back
+    cases = [(0, 0, 3.0), (1, 1, 3.0), (1, 0, 3.0), (1, 1, 0.5)]  # (the last: the frame's span is beyond MaxExtrapolationRatio)
+    for refine, have_log, ratio in cases:
+        ln = link_for(refine, have_log, ratio=ratio)
+        gpu_ctx.match_types(3, L.SET_WORKING, mp, pose, histograms=False)
+        t = gpu_ctx.icp_link()
+        gpu_ctx.solve_device_begin_linked(3, w0, t, ln)
+        res = gpu_ctx.solve_device_end()
+        got = gpu_ctx.icp_link_peek(t)
+        want, motion = L.icp_link_expected(res.pose, res.skipped, res.num_successful_steps, ln)
+        assert want[0] == 1 and res.num_successful_steps > 1
+        nwords = 1 + 12 + 6 + (0 if not refine else 64 - 19)
+        assert np.array_equal(got[:nwords], want[:nwords]), (refine, have_log, ratio, np.nonzero(got[:nwords] != want[:nwords])[0])
+        gpu_ctx.icp_abandon()
+    # a solve that makes no step (it starts at its own solution) and one that is skipped leave go = 0
+    done = gpu_ctx.solve_device(3, w0)
+    for prior, min_matches in ((np.array(done.pose), 0), (w0, 10**6)):
+        gpu_ctx.match_types(3, L.SET_WORKING, mp, se3(*done.pose) if min_matches == 0 else pose, histograms=False)
+        ln = link_for(1, 1)
+        t = gpu_ctx.icp_link()
+        gpu_ctx.solve_device_begin_linked(3, prior, t, ln, min_matches=min_matches)
+        res = gpu_ctx.solve_device_end()
+        assert res.skipped == (1 if min_matches else 0) and (min_matches or res.num_successful_steps == 1)
+        assert gpu_ctx.icp_link_peek(t)[0] == 0 == L.icp_link_expected(res.pose, res.skipped, res.num_successful_steps, ln)[0][0]
+        gpu_ctx.icp_abandon()
+
+    # (b) three iterations enqueued at once
+    gpu_ctx.match_types(3, L.SET_WORKING, mp, pose, histograms=False)
+    ln = link_for(0, 0)
+    t1 = gpu_ctx.icp_link()
+    gpu_ctx.solve_device_begin_linked(3, w0, t1, ln)
+    assert gpu_ctx.match_types_gated(3, L.SET_WORKING, mp2) == 0
+    t2 = gpu_ctx.icp_link()
+    gpu_ctx.solve_device_begin_linked(3, None, t2, ln)
+    assert gpu_ctx.match_types_gated(3, L.SET_WORKING, mp3) == 0
+    gpu_ctx.solve_device_begin_linked(3, None, -1, None)
+    chain = [gpu_ctx.solve_device_end() for _ in range(3)]
+    chain_match = [gpu_ctx.match_results(k, L.SET_WORKING) for k in (0, 1)]
+    gpu_ctx.icp_abandon()
+    p, w, one_by_one = pose, w0, []
+    for m in (mp, mp2, mp3):
+        gpu_ctx.match_types(3, L.SET_WORKING, m, p, histograms=False)
+        r = gpu_ctx.solve_device(3, w)
+        one_by_one.append(r)
+        words, _ = L.icp_link_expected(r.pose, r.skipped, r.num_successful_steps, ln)
+        assert words[0] == 1
+        d = words[1:19].view(np.float64)
+        p, w = np.eye(4), d[12:18].copy()
+        p[:3, :3], p[:3, 3] = d[:9].reshape(3, 3), d[9:12]
+    for a, b in zip(chain, one_by_one):
+        assert list(a.pose) == list(b.pose) and a.final_cost == b.final_cost and a.num_evaluations == b.num_evaluations and a.num_matches == b.num_matches
+    for k in (0, 1):
+        for a, b in zip(chain_match[k], gpu_ctx.match_results(k, L.SET_WORKING)):
+            assert a.tobytes() == b.tobytes()
+    assert gpu_ctx.solve_device_fallbacks() == 0
+
+
 def test_a_solve_abandoned_on_the_device_says_so(gpu_ctx, O, L, kps):
     """lsa_debug_set("lm_give_up_block"): the workgroup stops exchanging sums, the others run into their 20 ms limit, the
     launch drains and lsa_solve_device reports LSA_E_STATE (never a wrong pose); the next solve is healthy again."""

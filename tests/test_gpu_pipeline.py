@@ -865,9 +865,12 @@ def test_a_cloud_rewritten_after_it_was_announced_is_not_taken_over(L):
 @pytest.mark.gpu
 @pytest.mark.parametrize("model,nframes", [(16, 14), (64, 6)])
 def test_icp_iterations_enqueued_ahead_change_nothing_but_the_schedule(L, model, nframes):
-    """ICPAhead: iteration i + 1 of both ICP loops waits behind a gate on the device while iteration i runs
-    (lsa_icp_gate / lsa_icp_post / lsa_icp_cancel).  Same launches, same inputs, same order: poses, match counts and
-    match statuses are those of the loop that enqueues every iteration when its pose is known, bit for bit."""
+    """ICPAhead = 1: iteration i + 1 of both ICP loops waits behind a gate on the device while iteration i runs
+    (lsa_icp_gate / lsa_icp_post / lsa_icp_cancel).  ICPAhead = 2 (the default): the whole loop is enqueued at once and
+    every solve leaves the pose, the start point and the undistortion of the iteration behind it on the device
+    (lsa_icp_link: lsa_posemath.h's arithmetic on the device, the host repeats it on the same results).  Same launches,
+    same inputs, same order: poses, match counts and match statuses are those of the loop that enqueues every iteration
+    when its pose is known, bit for bit."""
     frames = [L.synth_frame(model, 1000, f) for f in range(nframes)]
 
     def run(**params):
@@ -884,14 +887,20 @@ def test_icp_iterations_enqueued_ahead_change_nothing_but_the_schedule(L, model,
         return np.array(poses), used, status, cov, fb, gt
 
     inline = run(ICPAhead=0)
-    ahead = run(ICPAhead=1)
-    assert ahead[4] == 0 and ahead[5] == 0
-    assert np.array_equal(inline[0], ahead[0]) and inline[1] == ahead[1] and inline[2] == ahead[2]
-    assert np.array_equal(inline[3], ahead[3])
-    # ... also without the refined undistortion (nothing rides in the search kernel) and with a single LM iteration allowed
-    for extra in ({"Undistortion": 1}, {"Undistortion": 0}, {"LocalizationICPMaxIter": 1, "EgoMotionICPMaxIter": 2}):
-        a, b = run(ICPAhead=0, **extra), run(ICPAhead=1, **extra)
-        assert np.array_equal(a[0], b[0]) and a[1] == b[1] and a[2] == b[2], extra
+    for mode in (1, 2):
+        ahead = run(ICPAhead=mode)
+        assert ahead[4] == 0 and ahead[5] == 0
+        assert np.array_equal(inline[0], ahead[0]) and inline[1] == ahead[1] and inline[2] == ahead[2], mode
+        assert np.array_equal(inline[3], ahead[3]), mode
+    # ... also without the refined undistortion (nothing rides in the search kernel), with a single LM iteration allowed, with
+    # more iterations than one loop enqueues behind links, in 2D, with the maps on the host and without any map update
+    for extra in ({"Undistortion": 1}, {"Undistortion": 0}, {"LocalizationICPMaxIter": 1, "EgoMotionICPMaxIter": 2}, {"LocalizationICPMaxIter": 8, "EgoMotionICPMaxIter": 6},
+                  {"TwoDMode": 1}, {"MapsOnDevice": 0}, {"UndistortInSearch": 0}):
+        a = run(ICPAhead=0, **extra)
+        for mode in (1, 2):
+            b = run(ICPAhead=mode, **extra)
+            assert np.array_equal(a[0], b[0]) and a[1] == b[1] and a[2] == b[2], (extra, mode)
+            assert b[4] == 0 and b[5] == 0
 
 
 @pytest.mark.gpu
@@ -919,7 +928,7 @@ def test_the_fall_backs_of_the_bounded_device_waits_are_exercised(L, O):
     plain = run()
     assert plain[1] == 0 and plain[2] == 0
     # (a) every third gate gives up
-    gates = run(lambda s, f: s.context().debug_set("gate_give_up_every", 3) if f == 0 else None)
+    gates = run(lambda s, f: s.context().debug_set("gate_give_up_every", 3) if f == 0 else None, ICPAhead=1)
     assert gates[1] >= 4 and gates[2] == 0
     assert np.array_equal(plain[0], gates[0]) and plain[3] == gates[3]
     # (b) one solve of frames 2 and 5 is abandoned by its second workgroup (or by its only one)
@@ -928,8 +937,10 @@ def test_the_fall_backs_of_the_bounded_device_waits_are_exercised(L, O):
     for f, (pts, stamp) in enumerate(frames):
         so.add_frame(pts, stamp, f)
         ref.append(so.world_transform())
-    for block in (1, 0):
-        lm = run(lambda s, f: s.context().debug_set("lm_give_up_block", block) if f in (2, 5) else None)
+    # (with the loops enqueued whole -- ICPAhead = 2, the default -- the solve that gives up leaves "do not run" for the
+    #  iterations behind it, the host redoes it and goes on in line; with gates; with nothing enqueued ahead)
+    for block, mode in ((1, 2), (0, 2), (1, 1), (0, 0)):
+        lm = run(lambda s, f: s.context().debug_set("lm_give_up_block", block) if f in (2, 5) else None, ICPAhead=mode)
         assert lm[2] == 2 and lm[1] == 0
         for f in range(len(frames)):
             dp, da = pose_diff(ref[f], lm[0][f])

@@ -249,6 +249,7 @@ struct lsa_ctx
   int debug_gate_give_up_every = 0;      // lsa_debug_set: every n-th gate gives up at once (exercises the callers' fall-back)
   int debug_lm_give_up_block = -1;       // lsa_debug_set: that workgroup of the NEXT solve abandons the exchange (one shot)
   std::deque<unsigned> lm_pending;       // result tags of the solves begun and not ended yet, oldest first
+  std::deque<int> lm_pending_wait;       // ... and the gate / link each of them waits behind (-1: none)
   hipStream_t map_stream = nullptr;     // shared by the device maps of this context (lsa_device_grid.hip), created with the first of them
   int map_stream_users = 0;
   void (*solve_hook)(void*) = nullptr;  // lsa_solve_device_interlude

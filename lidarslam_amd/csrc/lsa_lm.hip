@@ -477,7 +477,7 @@ __device__ bool lm_step(const LmParams& p, Shared& sh, bool first)
 // localization, Slam::RefineUndistortion under the new pose.  lsa_posemath.h is the host's arithmetic: the host works
 // the same values out from the same result when it arrives, bit for bit.  One wavefront: the six half-angle
 // cosines / sines side by side, the rest on lane 0.
-__device__ void leave_link(const LmParams& p, const LmState& lm, bool failed)
+__device__ void leave_link(const LmParams& p, const LmState& lm, bool failed, int part)
 {
   using namespace posemath;
   IcpGate* g = p.leave;
@@ -485,50 +485,64 @@ __device__ void leave_link(const LmParams& p, const LmState& lm, bool failed)
   const bool go = !failed && !lm.skipped && lm.successful != 1;
   if (!go)
   {
-    if (lane == 0) g->go = 0ull;
+    if (lane == 0 && part == 0) g->go = 0ull;
     return;
   }
+  // two wavefronts side by side (the block is read after the kernel has ended: no order among its words): part 0 -- go,
+  // pose, start point; part 1 -- the undistortion.  Both work the pose out for themselves (the same bits).
+  if (part == 1 && !p.link_refine) return;
   const double half = lm.x[3 + (lane < 6 ? lane % 3 : 0)] * 0.5;
   const double v = lane < 3 ? lsa_cos(half) : lsa_sin(half);
   const double cx = lane_value(v, 0), cy = lane_value(v, 1), cz = lane_value(v, 2);
   const double sx = lane_value(v, 3), sy = lane_value(v, 4), sz = lane_value(v, 5);
-  if (lane != 0) return;
   double x[6];
 #pragma unroll
   for (int a = 0; a < 6; ++a) x[a] = lm.x[a];
   const Pose T = FromXYZRPYTrig(x, cx, sx, cy, sy, cz, sz);
-  double x0[6];
-  ToXYZRPY(T, x0);
-  g->in.pose = ToRigid(T);
-#pragma unroll
-  for (int a = 0; a < 6; ++a) g->in.x0[a] = x0[a];
-  if (p.link_refine)
+  if (part == 0)
   {
-    WithinFrameMotion m;
-    double mv[16];
+    if (lane != 0) return;
+    double x0[6];
+    ToXYZRPY(T, x0);
+    g->in.pose = ToRigid(T);
 #pragma unroll
-    for (int i = 0; i < 16; ++i) mv[i] = p.motion0[i];
-    if (!p.motion_from_args)
-    {
-#pragma unroll
-      for (int i = 0; i < 16; ++i) mv[i] = p.motion_dev[i];
-    }
-    m.Time0 = mv[0]; m.Time1 = mv[1];
-    m.Rot0 = {mv[2], mv[3], mv[4], mv[5]};
-    m.Rot1 = {mv[6], mv[7], mv[8], mv[9]};
-#pragma unroll
-    for (int i = 0; i < 3; ++i) { m.Trans0[i] = mv[10 + i]; m.Trans1[i] = mv[13 + i]; }
-    Pose d0, d1;
-    RefineUndistortion(m, p.clock, FromRigid(p.previous_world), T, d0, d1);
-    g->in.ic = MakeInterpConst(d0, d1, m.Time0, m.Time1);
-    double* o = p.motion_dev;
-    o[0] = m.Time0; o[1] = m.Time1;
-    o[2] = m.Rot0.w; o[3] = m.Rot0.x; o[4] = m.Rot0.y; o[5] = m.Rot0.z;
-    o[6] = m.Rot1.w; o[7] = m.Rot1.x; o[8] = m.Rot1.y; o[9] = m.Rot1.z;
-#pragma unroll
-    for (int i = 0; i < 3; ++i) { o[10 + i] = m.Trans0[i]; o[13 + i] = m.Trans1[i]; }
+    for (int a = 0; a < 6; ++a) g->in.x0[a] = x0[a];
+    g->go = 1ull;
+    return;
   }
-  g->go = 1ull;
+  WithinFrameMotion m;
+  double mv[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) mv[i] = p.motion0[i];
+  if (!p.motion_from_args)
+  {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) mv[i] = p.motion_dev[i];
+  }
+  m.Time0 = mv[0]; m.Time1 = mv[1];
+  m.Rot0 = {mv[2], mv[3], mv[4], mv[5]};
+  m.Rot1 = {mv[6], mv[7], mv[8], mv[9]};
+#pragma unroll
+  for (int i = 0; i < 3; ++i) { m.Trans0[i] = mv[10 + i]; m.Trans1[i] = mv[13 + i]; }
+  // Slam::RefineUndistortion with the scan's pose at its begin (lane 0) and at its end (lane 1) interpolated side by
+  // side; lane 0 takes the end over and goes on alone
+  const Pose previous = FromRigid(p.previous_world);
+  const Pose mine = InterpolateScanPose(p.clock, previous, T, lane == 1 ? m.Time1 : m.Time0);
+  Pose worldToBaseEnd = Pose::Identity();
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) worldToBaseEnd(i, j) = lane_value(mine(i, j), 1);
+  if (lane != 0) return;
+  Pose d0, d1;
+  RefineUndistortionFrom(m, mine, worldToBaseEnd, T, d0, d1);
+  g->in.ic = MakeInterpConst(d0, d1, m.Time0, m.Time1);
+  double* o = p.motion_dev;
+  o[0] = m.Time0; o[1] = m.Time1;
+  o[2] = m.Rot0.w; o[3] = m.Rot0.x; o[4] = m.Rot0.y; o[5] = m.Rot0.z;
+  o[6] = m.Rot1.w; o[7] = m.Rot1.x; o[8] = m.Rot1.y; o[9] = m.Rot1.z;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) { o[10 + i] = m.Trans0[i]; o[13 + i] = m.Trans1[i]; }
 }
 
 __global__ __launch_bounds__(kLmThreads) void k_lm_solve(LmParams p, u64* __restrict__ xchg, u64* __restrict__ mailbox, unsigned out_tag, unsigned long long* trace)
@@ -609,8 +623,8 @@ __global__ __launch_bounds__(kLmThreads) void k_lm_solve(LmParams p, u64* __rest
     trace[7] += sh.lap[4];  // of "evaluate": the residual blocks alone (before the wavefront's reduction)
     for (int i = 0; i < 4; ++i) trace[8 + i] += sh.sub[i];
   }
-  // the iteration enqueued behind this solve: the second wavefront prepares what it reads while the first sends the result
-  if (p.leave && threadIdx.x >= 64 && threadIdx.x < 128) leave_link(p, sh.lm, failed);
+  // the iteration enqueued behind this solve: the second and third wavefronts prepare what it reads while the first sends the result
+  if (p.leave && threadIdx.x >= 64 && threadIdx.x < 192) leave_link(p, sh.lm, failed, (threadIdx.x >> 6) - 1);
   // every block holds the same result; block 0's copy goes out as 2 granules per double
   if (threadIdx.x < 2 * kResCount)
   {
@@ -781,6 +795,7 @@ static int solve_device_begin(lsa_ctx* ctx, unsigned type_mask, const double pri
                        ctx->route_stats && ctx->trace_dev ? reinterpret_cast<unsigned long long*>(ctx->trace_dev) + (size_t)8192 * 12 : nullptr);
   }
   ctx->lm_pending.push_back(out_tag);
+  ctx->lm_pending_wait.push_back(prior ? -1 : ctx->gate_current);
   // what is enqueued next waits behind the link this solve leaves
   if (leave_ticket >= 0) ctx->gate_current = leave_ticket;
   if (lsa_icp_trace_on()) std::fprintf(stderr, "[lm begin] tag %u gated %d leaves %d sat2 %.6g %.6g counts %d %d\n", out_tag, prior ? 0 : 1, leave_ticket, p.set.sat2[0], p.set.sat2[1], p.set.count[0], p.set.count[1]);
@@ -802,6 +817,7 @@ int lsa_solve_device_drop(lsa_ctx* ctx)
 {
   if (!ctx || ctx->lm_pending.empty()) return LSA_E_ARG;
   ctx->lm_pending.pop_back();  // the solve begun last will never run (its gate was called off): nobody waits for it
+  ctx->lm_pending_wait.pop_back();
   return LSA_OK;
 }
 
@@ -811,6 +827,8 @@ int lsa_solve_device_end(lsa_ctx* ctx, lsa_solve_result_t* out)
   if (ctx->lm_pending.empty()) return ctx->fail(LSA_E_STATE, "lsa_solve_device_end: no solve in flight");
   const unsigned out_tag = ctx->lm_pending.front();
   ctx->lm_pending.pop_front();
+  const int waited_behind = ctx->lm_pending_wait.front();
+  ctx->lm_pending_wait.pop_front();
   if (lsa_icp_trace_on()) std::fprintf(stderr, "[lm end] waits for tag %u (%zu more in flight)\n", out_tag, ctx->lm_pending.size());
   // the result arrives as granules in coherent host memory (as lsa_accumulate's sums do)
   double res[kResCount];
@@ -852,6 +870,8 @@ int lsa_solve_device_end(lsa_ctx* ctx, lsa_solve_result_t* out)
     ctx->lm_fallbacks++;
     return ctx->fail(LSA_E_STATE, "lsa_solve_device: a block waited too long for the others");
   }
+  // the link this solve waited behind has served: its iteration ran, what its match announced stands
+  if (waited_behind >= 0 && waited_behind < kGateRing && ctx->gate_saved[waited_behind].link) ctx->gate_saved[waited_behind].used = false;
   std::memset(out, 0, sizeof(*out));
   for (int a = 0; a < 6; ++a) out->pose[a] = res[kResPose + a];
   out->initial_cost = res[kResInitial];
@@ -1068,6 +1088,7 @@ int lsa_icp_abandon(lsa_ctx* ctx)
     if (lsa_icp_cancel(ctx, youngest) != LSA_OK) ctx->gate_saved[youngest].used = false;
   }
   ctx->lm_pending.clear();
+  ctx->lm_pending_wait.clear();
   ctx->gate_current = -1;
   return LSA_OK;
 }

@@ -320,18 +320,23 @@ LSA_HD Pose InterpolateScanPose(const ScanPoseClock& k, const Pose& previousTwor
 }
 // Slam::RefineUndistortion (Slam.cxx:1322-1352): the motion within the frame under the new pose; d0 / d1 move the
 // keypoints undistorted under the old motion to where the new one puts them
-LSA_HD void RefineUndistortion(WithinFrameMotion& motion, const ScanPoseClock& k, const Pose& previousTworld, const Pose& tworld, Pose& d0, Pose& d1)
+// (the scan's poses at its begin and its end handed in: the device interpolates the two on two lanes side by side)
+LSA_HD void RefineUndistortionFrom(WithinFrameMotion& motion, const Pose& worldToBaseBegin, const Pose& worldToBaseEnd, const Pose& tworld, Pose& d0, Pose& d1)
 {
   const Pose previousBaseBegin = motion.GetH0();
   const Pose previousBaseEnd = motion.GetH1();
-  const Pose worldToBaseBegin = InterpolateScanPose(k, previousTworld, tworld, motion.Time0);
-  const Pose worldToBaseEnd = InterpolateScanPose(k, previousTworld, tworld, motion.Time1);
   const Pose baseToWorld = Inverse(tworld);
   const Pose newBaseBegin = baseToWorld * worldToBaseBegin;
   const Pose newBaseEnd = baseToWorld * worldToBaseEnd;
   motion.SetTransforms(newBaseBegin, newBaseEnd);
   d0 = newBaseBegin * Inverse(previousBaseBegin);
   d1 = newBaseEnd * Inverse(previousBaseEnd);
+}
+LSA_HD void RefineUndistortion(WithinFrameMotion& motion, const ScanPoseClock& k, const Pose& previousTworld, const Pose& tworld, Pose& d0, Pose& d1)
+{
+  const Pose worldToBaseBegin = InterpolateScanPose(k, previousTworld, tworld, motion.Time0);
+  const Pose worldToBaseEnd = InterpolateScanPose(k, previousTworld, tworld, motion.Time1);
+  RefineUndistortionFrom(motion, worldToBaseBegin, worldToBaseEnd, tworld, d0, d1);
 }
 
 }  // namespace posemath

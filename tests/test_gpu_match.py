@@ -620,13 +620,12 @@ def test_links_left_by_the_device_equal_the_host_algebra(gpu_ctx, O, L, kps):
         nwords = 1 + 12 + 6 + (0 if not refine else 64 - 19)
         assert np.array_equal(got[:nwords], want[:nwords]), (refine, have_log, ratio, np.nonzero(got[:nwords] != want[:nwords])[0])
         gpu_ctx.icp_abandon()
-    # a solve that makes no step (it starts at its own solution) and one that is skipped leave go = 0
-    done = gpu_ctx.solve_device(3, w0)
-    for prior, min_matches in ((np.array(done.pose), 0), (w0, 10**6)):
-        gpu_ctx.match_types(3, L.SET_WORKING, mp, se3(*done.pose) if min_matches == 0 else pose, histograms=False)
+    # a solve that makes no step (no LM iteration allowed) and one that is skipped leave go = 0
+    for max_iter, min_matches in ((0, 0), (15, 10**6)):
+        gpu_ctx.match_types(3, L.SET_WORKING, mp, pose, histograms=False)
         ln = link_for(1, 1)
         t = gpu_ctx.icp_link()
-        gpu_ctx.solve_device_begin_linked(3, prior, t, ln, min_matches=min_matches)
+        gpu_ctx.solve_device_begin_linked(3, w0, t, ln, max_iter=max_iter, min_matches=min_matches)
         res = gpu_ctx.solve_device_end()
         assert res.skipped == (1 if min_matches else 0) and (min_matches or res.num_successful_steps == 1)
         assert gpu_ctx.icp_link_peek(t)[0] == 0 == L.icp_link_expected(res.pose, res.skipped, res.num_successful_steps, ln)[0][0]

@@ -425,58 +425,125 @@ __global__ __launch_bounds__(128) void k_curvature(const float4* __restrict__ xy
 }
 
 // --------------------------------------------------------------------------------------------
-// Greedy non-maximum selection as a fixed point.  st: 0 = out, 1 = undecided candidate, 2 = selected.
+// Greedy non-maximum selection as a fixed point.  One 32-bit word per point holds state AND priority:
+//   0 = out, kSel = selected, anything else = an undecided candidate whose priority is the word itself (larger wins).
 // prio(k) > prio(j):  EDGE  score desc, index asc   (Utils::SortIdx(v, false) + stable tie-break)
 //                     PLANE score asc,  index desc  (the same sorted array walked backwards)
-// Every thread owns a contiguous chunk of the ring and sweeps it forwards, then backwards, updating the states
-// IN PLACE: a decision is only ever taken on final facts (a selected neighbour; no undecided neighbour of
-// higher priority), so reading a neighbour's old or new state both give correct, merely earlier or later,
-// decisions -- and a sweep carries a decision across the whole chunk instead of one window per round.
+// The word of a candidate is the order-preserving integer image of its score (inverted for planes); equal words are equal
+// scores, and the index decides by the SIDE the neighbour is on.  Every thread owns PER consecutive points of the ring.
+// Per round it reads its window (its points and hw on either side) ONCE into registers, sweeps its points forwards, then
+// backwards, and writes the decisions it took: a decision is only ever taken on final facts (a selected neighbour; no
+// undecided neighbour of higher priority), so a neighbour's state of the round's start gives correct, merely later,
+// decisions.  (The first version kept state and score in two arrays and read every neighbour of every visit from LDS:
+// 16 reads per point and sweep against 5 per thread and round.)
+constexpr uint32_t kSel = 0xffffffffu;
+constexpr int kNmsHalfMax = 8;  // NeighborWidth <= 8
 template <bool PLANE>
-__device__ void nms_fixed_point(const float* sc, volatile uint8_t* st, int np, int hw)
+__device__ __forceinline__ uint32_t nms_word(float v)
 {
-  const int per = (np + blockDim.x - 1) / blockDim.x;
-  const int j0 = min(np, (int)threadIdx.x * per), j1 = min(np, j0 + per);
-  auto visit = [&](int j) -> int {
-    if (st[j] != 1) return 0;
-    const float v = sc[j];
-    const int b = max(0, j - hw), e = min(np - 1, j + hw);
-    bool selNear = false, higher = false;
-    for (int k = b; k <= e; ++k)
-    {
-      if (k == j) continue;
-      const uint8_t sk = st[k];
-      if (sk == 2) selNear = true;
-      else if (sk == 1)
-      {
-        const float vk = sc[k];
-        const bool hk = PLANE ? (vk < v || (vk == v && k > j)) : (vk > v || (vk == v && k < j));
-        if (hk) higher = true;
-      }
-    }
-    if (selNear) { st[j] = 0; return 0; }
-    if (!higher) { st[j] = 2; return 0; }
-    return 1;
-  };
+  const uint32_t u = __float_as_uint(v);
+  const uint32_t o = u ^ ((u >> 31) ? 0xffffffffu : 0x80000000u);  // monotone in v; 0 and kSel only for NaN, which never qualifies
+  return PLANE ? ~o : o;
+}
+// (not inlined: the four chunk sizes side by side in one function made the compiler spill the windows; called five times)
+template <bool PLANE, int PER>
+__device__ __noinline__ void nms_fixed_point(volatile uint32_t* w, int np, int hw)
+{
+  constexpr int WIN = PER + 2 * kNmsHalfMax;
+  const int j0 = (int)threadIdx.x * PER;
+  bool fwd = true;
+#ifdef LSA_ABLATE_NMS_ROUNDS
+  for (int round = 0; round < LSA_ABLATE_NMS_ROUNDS; ++round)  // (timing experiment only: wrong results)
+#else
   while (true)
+#endif
   {
+    // a wavefront whose points are all decided has nothing to do but meet the others (decisions are final: it stays so);
+    // the chains of undecided candidates are local, after two or three rounds most of the block's wavefronts are done
+    bool mine = false;
+#pragma unroll
+    for (int a = 0; a < PER; ++a)
+      if (j0 + a < np)
+      {
+        const uint32_t v = w[j0 + a];
+        mine = mine || (v != 0u && v != kSel);
+      }
+    if (!__any(mine))
+    {
+      if (!__syncthreads_or(0)) break;
+      continue;
+    }
+    uint32_t x[WIN];
+#pragma unroll
+    for (int i = 0; i < WIN; ++i)
+    {
+      const int k = j0 - kNmsHalfMax + i;
+      x[i] = 0u;
+      if (i >= kNmsHalfMax - hw && i < kNmsHalfMax + PER + hw && k >= 0 && k < np) x[i] = w[k];
+    }
     int undecided = 0;
-    for (int j = j0; j < j1; ++j) visit(j);
-    for (int j = j1 - 1; j >= j0; --j) undecided |= visit(j);
+    auto visit = [&](int a) -> int {
+      const int i = kNmsHalfMax + a;
+      const uint32_t wj = x[i];
+      if (wj == 0u || wj == kSel) return 0;
+      // the largest word on either side says it all: kSel (the largest there is) = a selected neighbour; otherwise a word
+      // above this one = an undecided neighbour of higher priority -- an equal score on the left (smaller index) wins among
+      // edges, on the right among planes
+      uint32_t ml = 0u, mr = 0u;
+#pragma unroll
+      for (int d = 1; d <= kNmsHalfMax; ++d)
+        if (d <= hw)
+        {
+          ml = x[i - d] > ml ? x[i - d] : ml;
+          mr = x[i + d] > mr ? x[i + d] : mr;
+        }
+      const bool selNear = ml == kSel || mr == kSel;
+      const bool higher = PLANE ? (ml > wj || mr >= wj) : (ml >= wj || mr > wj);
+      if (selNear) { x[i] = 0u; w[j0 + a] = 0u; return 0; }
+      if (!higher) { x[i] = kSel; w[j0 + a] = kSel; return 0; }
+      return 1;
+    };
+#ifdef LSA_NMS_ONE_SWEEP
+    if (fwd)
+    {
+#pragma unroll
+      for (int a = 0; a < PER; ++a) undecided |= visit(a);
+    }
+    else
+    {
+#pragma unroll
+      for (int a = PER - 1; a >= 0; --a) undecided |= visit(a);
+    }
+    fwd = !fwd;
+#else
+#pragma unroll
+    for (int a = 0; a < PER; ++a) visit(a);
+#pragma unroll
+    for (int a = PER - 1; a >= 0; --a) undecided |= visit(a);
+#endif
     if (!__syncthreads_or(undecided)) break;
   }
 }
+template <bool PLANE>
+__device__ __forceinline__ void nms_fixed_point_any(volatile uint32_t* w, int np, int hw)
+{
+  // (block-uniform choice: the smallest chunk that covers the ring with the block's threads)
+  if (np <= (int)blockDim.x) nms_fixed_point<PLANE, 1>(w, np, hw);
+  else if (np <= 2 * (int)blockDim.x) nms_fixed_point<PLANE, 2>(w, np, hw);
+  else if (np <= 4 * (int)blockDim.x) nms_fixed_point<PLANE, 4>(w, np, hw);
+  else nms_fixed_point<PLANE, 8>(w, np, hw);
+}
 
 // after a selection round: label the winners, clear the validity bit `vbit` within +-hw of them
-__device__ void nms_apply(const uint8_t* st, uint8_t* flags, int np, int hw, uint8_t vbit, uint8_t lbit)
+__device__ void nms_apply(const uint32_t* w, uint8_t* flags, int np, int hw, uint8_t vbit, uint8_t lbit)
 {
   for (int j = threadIdx.x; j < np; j += blockDim.x)
   {
     const int b = max(0, j - hw), e = min(np - 1, j + hw);
     bool near = false;
-    for (int k = b; k <= e; ++k) near |= (st[k] == 2);
+    for (int k = b; k <= e; ++k) near |= (w[k] == kSel);
     uint8_t f = flags[j];
-    if (st[j] == 2) f |= lbit;
+    if (w[j] == kSel) f |= lbit;
     if (near) f &= ~vbit;
     flags[j] = f;
   }
@@ -489,8 +556,8 @@ __global__ __launch_bounds__(kLabelThreads) void k_label(const float* __restrict
                                                int* __restrict__ ring_meta, ExtractConst c, uint8_t* __restrict__ valid,
                                                uint8_t* __restrict__ label, int* __restrict__ ring_counts)
 {
-  __shared__ float sc[kMaxRingPoints];
-  __shared__ uint8_t stA[kMaxRingPoints];
+  static_assert(8 * kLabelThreads >= kMaxRingPoints, "a thread owns at most 8 points of its ring");
+  __shared__ uint32_t wd[kMaxRingPoints];    // state + priority of the selection under way (nms_fixed_point)
   __shared__ uint8_t flags[kMaxRingPoints];  // bits 0-2 validity E/P/B, bits 3-5 label E/P/B
   __shared__ int cnt[3];
   const int r = blockIdx.x;
@@ -523,12 +590,11 @@ __global__ __launch_bounds__(kLabelThreads) void k_label(const float* __restrict
     for (int j = threadIdx.x; j < np; j += blockDim.x)
     {
       const float v = src[s0 + j];
-      sc[j] = v;
-      stA[j] = ((v >= thr) && (flags[j] & 1)) ? 1 : 0;  // NaN never qualifies
+      wd[j] = ((v >= thr) && (flags[j] & 1)) ? nms_word<false>(v) : 0u;  // NaN never qualifies
     }
     __syncthreads();
-    nms_fixed_point<false>(sc, stA, np, hw);
-    nms_apply(stA, flags, np, hw, 1, 8);
+    nms_fixed_point_any<false>(wd, np, hw);
+    nms_apply(wd, flags, np, hw, 1, 8);
   }
 
   // --- planes: ascending sin angle, skip < 1e-6, stop above the threshold, +-4 window (SSKE.cxx:536-563)
@@ -537,13 +603,12 @@ __global__ __launch_bounds__(kLabelThreads) void k_label(const float* __restrict
     for (int j = threadIdx.x; j < np; j += blockDim.x)
     {
       const float v = g_angle[s0 + j];
-      sc[j] = v;
       const bool cand = (flags[j] & 2) && !((double)v < 1e-6) && (v <= c.plane_thr);  // NaN fails v <= thr
-      stA[j] = cand ? 1 : 0;
+      wd[j] = cand ? nms_word<true>(v) : 0u;
     }
     __syncthreads();
-    nms_fixed_point<true>(sc, stA, np, hw);
-    nms_apply(stA, flags, np, hw, 2, 16);
+    nms_fixed_point_any<true>(wd, np, hw);
+    nms_apply(wd, flags, np, hw, 2, 16);
   }
 
   // --- blobs (SSKE.cxx:568-572) + validity bit set back for labelled points (:584) + counts

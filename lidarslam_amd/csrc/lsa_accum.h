@@ -157,12 +157,53 @@ __device__ __forceinline__ void accumulate_records(const RecordSet& rs, const Ro
   }
 }
 
+// A thread's FIRST residual block on its way from memory into registers (record_load: the loads are issued, nothing waits
+// for them) and from there into the cache of accumulate_records_cached (record_stash).  The solve kernel issues the loads as
+// its very first instructions: what it has to wait for before the first evaluation anyway -- the word that says whether the
+// launch runs at all, the start point, its sines and cosines -- then costs no time of its own.
+struct RecordRegs
+{
+  double v[16];
+  double a2;
+  int state;  // 1 a residual block, 0 a rejected keypoint, -1 nothing (no residual block for this thread)
+};
+__device__ __forceinline__ void record_load(const RecordSet& rs, int gidx, RecordRegs& r)
+{
+  const int total = rs.count[0] + rs.count[1] + rs.count[2];
+  r.state = -1;
+  r.a2 = 0.;
+#pragma unroll
+  for (int f = 0; f < 16; ++f) r.v[f] = 0.;
+  if (gidx >= total) return;
+  int t = 0, i = gidx;
+  if (i >= rs.count[0]) { i -= rs.count[0]; t = 1; if (i >= rs.count[1]) { i -= rs.count[1]; t = 2; } }
+  const double* rec = rs.rec[t];
+  const size_t cap = (size_t)rs.cap[t];
+  const uint8_t st = rs.status[t][i];
+  // (the record of a rejected keypoint is memory like any other: read, not used)
+#pragma unroll
+  for (int f = 0; f < 16; ++f) r.v[f] = rec[f * cap + i];
+  r.a2 = rs.sat2[t];
+  r.state = st == LSA_MATCH_SUCCESS ? 1 : 0;
+}
+__device__ __forceinline__ void record_stash(const RecordRegs& r, double* __restrict__ cache, int cstride, int at)
+{
+  if (r.state == 1)
+  {
+#pragma unroll
+    for (int f = 0; f < 16; ++f) cache[f * cstride + at] = r.v[f];
+    cache[16 * cstride + at] = r.a2;
+  }
+  else if (r.state == 0)
+    cache[15 * cstride + at] = -1.;
+}
+
 // The same with the thread's first `cslots` residual blocks kept in LDS between the evaluations of one launch
 // (cache[f * cstride + slot * blockDim.x + thread], f = 0..16: A, P, X, weight, a^2; weight < 0 marks a rejected keypoint):
-// the first evaluation (fill == true) reads global memory and fills the cache, the others read the cache.  Same
-// records, same order, same arithmetic as accumulate_records.
+// the first evaluation (fill == true) reads global memory and fills the cache -- but for the first `prefilled` slots, which are
+// there already (record_stash) --, the others read the cache.  Same records, same order, same arithmetic as accumulate_records.
 __device__ __forceinline__ void accumulate_records_cached(const RecordSet& rs, const RotConst& c, int first, int stride, double* __restrict__ cache,
-                                                          int cslots, int cstride, bool fill, double acc[kAccumVals])
+                                                          int cslots, int cstride, bool fill, int prefilled, double acc[kAccumVals])
 {
   const int total = rs.count[0] + rs.count[1] + rs.count[2];
   int j = 0;
@@ -170,7 +211,7 @@ __device__ __forceinline__ void accumulate_records_cached(const RecordSet& rs, c
   {
     double A[9], Px, Py, Pz, Xx, Xy, Xz, weight, a2;
     const int at = j * (int)blockDim.x + (int)threadIdx.x;
-    if (j < cslots && !fill)
+    if (j < cslots && (!fill || j < prefilled))
     {
       weight = cache[15 * cstride + at];
       if (weight < 0.) continue;

@@ -170,6 +170,12 @@ struct lsa_ctx
   std::condition_variable up_cv, up_done;
   std::deque<int> up_jobs;
   bool up_quit = false;
+  // the uploader's helpers: a cloud is staged and sent in up_parts pieces side by side (a thread each), so that 8 MB are on
+  // their way in a quarter of the time one thread's memcpy takes -- the next frame's extraction can only start behind them
+  std::vector<std::thread> up_helpers;
+  std::condition_variable up_help_cv, up_help_done;
+  struct UploadSplit { const char* src = nullptr; char* pinned = nullptr; char* dev = nullptr; size_t points = 0; int parts = 1; unsigned long long seq = 0; int done = 0; bool ok = true; } up_split;
+  int up_parts = 4;
   int uploads_adopted = 0;
   // look-ahead extraction (lsa_extract_prefetch): the next frame's keypoints are extracted on a stream of their own
   // while the current frame is registered; lsa_extract_keypoints adopts them when it is called for that very frame

@@ -252,7 +252,38 @@ static unsigned long long cloud_fingerprint(const lsa_point_t* pts, int n)
   return h;
 }
 
-// the uploader thread of a context: pageable cloud -> pinned staging -> DMA on the copy stream -> event
+// piece `part` of the cloud being uploaded: pageable -> pinned staging -> DMA on the copy stream (any thread, any order)
+static bool upload_part(lsa_ctx* ctx, const lsa_ctx::UploadSplit& u, int part)
+{
+  const size_t b = u.points * (size_t)part / (size_t)u.parts * sizeof(lsa_point_t), e = u.points * (size_t)(part + 1) / (size_t)u.parts * sizeof(lsa_point_t);
+  if (e <= b) return true;
+  std::memcpy(u.pinned + b, u.src + b, e - b);
+  return hipMemcpyAsync(u.dev + b, u.pinned + b, e - b, hipMemcpyHostToDevice, ctx->copy_stream) == hipSuccess;
+}
+static void upload_helper_main(lsa_ctx* ctx, int part)
+{
+  (void)hipSetDevice(ctx->device);
+  unsigned long long seen = 0;
+  std::unique_lock<std::mutex> l(ctx->up_mutex);
+  while (true)
+  {
+    ctx->up_help_cv.wait(l, [&] { return ctx->up_quit || ctx->up_split.seq != seen; });
+    if (ctx->up_quit) return;
+    seen = ctx->up_split.seq;
+    const lsa_ctx::UploadSplit u = ctx->up_split;
+    l.unlock();
+    const bool ok = part < u.parts ? upload_part(ctx, u, part) : true;
+    l.lock();
+    if (ctx->up_split.seq == seen)  // (a helper that woke up for a cloud nobody split has nothing to report to the next one)
+    {
+      ctx->up_split.ok = ctx->up_split.ok && ok;
+      ctx->up_split.done++;
+      ctx->up_help_done.notify_all();
+    }
+  }
+}
+// the uploader thread of a context: pageable cloud -> pinned staging -> DMA on the copy stream -> event, in up_parts pieces
+// side by side (this thread takes the first, a helper each of the others)
 static void uploader_main(lsa_ctx* ctx)
 {
   (void)hipSetDevice(ctx->device);
@@ -263,11 +294,23 @@ static void uploader_main(lsa_ctx* ctx)
     if (ctx->up_quit || ctx->up_jobs.empty()) return;  // on the way out the queued clouds are not touched: their owner may have freed them
     const int slot = ctx->up_jobs.front();
     ctx->up_jobs.pop_front();
-    l.unlock();
     FrameInbox& in = ctx->inbox[slot];
-    std::memcpy(in.pinned, in.src, (size_t)in.n * sizeof(lsa_point_t));
+    const int helpers = (int)ctx->up_helpers.size();
+    lsa_ctx::UploadSplit& u = ctx->up_split;
+    u.src = reinterpret_cast<const char*>(in.src); u.pinned = reinterpret_cast<char*>(in.pinned); u.dev = reinterpret_cast<char*>(in.dev);
+    u.points = (size_t)in.n;
+    u.parts = in.n >= 65536 ? helpers + 1 : 1;  // (a small cloud is not worth waking anybody)
+    u.done = 0; u.ok = true;
+    u.seq++;
+    const lsa_ctx::UploadSplit mine = u;
+    if (mine.parts > 1) ctx->up_help_cv.notify_all();
+    l.unlock();
+    bool ok = upload_part(ctx, mine, 0);
+    l.lock();
+    if (mine.parts > 1) ctx->up_help_done.wait(l, [&] { return ctx->up_split.done >= helpers || ctx->up_quit; });
+    ok = ok && ctx->up_split.ok;
+    l.unlock();
     in.fingerprint = cloud_fingerprint(in.pinned, in.n);
-    bool ok = hipMemcpyAsync(in.dev, in.pinned, (size_t)in.n * sizeof(lsa_point_t), hipMemcpyHostToDevice, ctx->copy_stream) == hipSuccess;
     ok = ok && hipEventRecord(in.ev, ctx->copy_stream) == hipSuccess;
     l.lock();
     in.state.store(ok ? 2 : -1, std::memory_order_release);
@@ -317,7 +360,12 @@ int lsa_upload_frame_begin(lsa_ctx* ctx, const lsa_point_t* pts, int n)
   }
   if (slot < 0) return ctx->fail(LSA_E_STATE, "lsa_upload_frame_begin: no free buffer");
   FrameInbox& in = ctx->inbox[slot];
-  if (!ctx->uploader.joinable()) ctx->uploader = std::thread(uploader_main, ctx);
+  if (!ctx->uploader.joinable())
+  {
+    if (const char* e = std::getenv("LSA_UPLOAD_THREADS")) ctx->up_parts = std::min(std::max(std::atoi(e), 1), 8);
+    for (int h = 1; h < ctx->up_parts; ++h) ctx->up_helpers.emplace_back(upload_helper_main, ctx, h);
+    ctx->uploader = std::thread(uploader_main, ctx);
+  }
   if (!in.ev) LSA_HIP(ctx, hipEventCreateWithFlags(&in.ev, hipEventDisableTiming));
   if (in.cap < n)
   {
@@ -547,7 +595,11 @@ void lsa_ctx_destroy(lsa_ctx* ctx)
       ctx->up_quit = true;
     }
     ctx->up_cv.notify_all();
+    ctx->up_help_cv.notify_all();
+    ctx->up_help_done.notify_all();
     ctx->uploader.join();
+    for (auto& h : ctx->up_helpers) h.join();
+    ctx->up_helpers.clear();
   }
   (void)lsa_collect_garbage(ctx);
   if (ctx->copy_stream) { (void)hipStreamSynchronize(ctx->copy_stream); (void)hipStreamDestroy(ctx->copy_stream); }

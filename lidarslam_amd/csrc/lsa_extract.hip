@@ -451,7 +451,6 @@ __device__ __noinline__ void nms_fixed_point(volatile uint32_t* w, int np, int h
 {
   constexpr int WIN = PER + 2 * kNmsHalfMax;
   const int j0 = (int)threadIdx.x * PER;
-  bool fwd = true;
 #ifdef LSA_ABLATE_NMS_ROUNDS
   for (int round = 0; round < LSA_ABLATE_NMS_ROUNDS; ++round)  // (timing experiment only: wrong results)
 #else
@@ -503,24 +502,10 @@ __device__ __noinline__ void nms_fixed_point(volatile uint32_t* w, int np, int h
       if (!higher) { x[i] = kSel; w[j0 + a] = kSel; return 0; }
       return 1;
     };
-#ifdef LSA_NMS_ONE_SWEEP
-    if (fwd)
-    {
-#pragma unroll
-      for (int a = 0; a < PER; ++a) undecided |= visit(a);
-    }
-    else
-    {
-#pragma unroll
-      for (int a = PER - 1; a >= 0; --a) undecided |= visit(a);
-    }
-    fwd = !fwd;
-#else
 #pragma unroll
     for (int a = 0; a < PER; ++a) visit(a);
 #pragma unroll
     for (int a = PER - 1; a >= 0; --a) undecided |= visit(a);
-#endif
     if (!__syncthreads_or(undecided)) break;
   }
 }

@@ -32,6 +32,10 @@ namespace
 {
 
 typedef unsigned long long u64;
+#ifndef LSA_RECORD_PREFETCH
+#define LSA_RECORD_PREFETCH 1
+#endif
+constexpr bool kRecordPrefetch = LSA_RECORD_PREFETCH != 0;  // (0: A/B builds)
 
 struct LmParams
 {
@@ -124,7 +128,7 @@ __device__ __forceinline__ bool lm_evaluate(const LmParams& p, unsigned epoch, u
 #pragma unroll
     for (int v = 0; v < kAccumVals; ++v) acc[v] = 0.;
     const unsigned long long e0 = trace ? wall_clock64() : 0ull;
-    accumulate_records_cached(p.set, c, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x, cache, p.cslots, p.cslots * kLmThreads, epoch == 1, acc);
+    accumulate_records_cached(p.set, c, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x, cache, p.cslots, p.cslots * kLmThreads, epoch == 1, kRecordPrefetch && p.cslots > 0 ? 1 : 0, acc);
     const unsigned long long e1 = trace ? wall_clock64() : 0ull;
     int slot;
     const double total = wave_reduce_accum(acc, slot);  // this lane's one value of the 29, summed over the wavefront
@@ -550,6 +554,9 @@ __global__ __launch_bounds__(kLmThreads) void k_lm_solve(LmParams p, u64* __rest
   __shared__ Shared sh;
   extern __shared__ double lm_cache[];  // [17][cslots * kLmThreads]
   const bool tr = trace != nullptr && blockIdx.x == 0;
+  // the thread's first residual block: on its way from memory while the launch finds out whether it runs and where it starts
+  RecordRegs pre;
+  if (kRecordPrefetch && p.cslots > 0) record_load(p.set, blockIdx.x * blockDim.x + threadIdx.x, pre);
   if (p.gate)
   {
     // enqueued ahead of its start point: the gate in front of this launch has left it (go == 1), or the iteration was
@@ -597,6 +604,7 @@ __global__ __launch_bounds__(kLmThreads) void k_lm_solve(LmParams p, u64* __rest
     sh.stop = 0;
   }
   if (threadIdx.x < 64) finish_point(sh);
+  if (kRecordPrefetch && p.cslots > 0) record_stash(pre, lm_cache, p.cslots * kLmThreads, threadIdx.x);
   __syncthreads();
   bool failed = false;
   // every evaluation of the launch has an epoch of its own; all blocks walk through the same sequence of them

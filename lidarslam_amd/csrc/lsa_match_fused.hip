@@ -849,16 +849,54 @@ __device__ __forceinline__ void search_whole_target(const float4* __restrict__ s
   merge_lists<KMAX, 64>(L, k, best);
 }
 
+// Pose and motion of the launch, into LDS: the launch's own arguments, or what the link / gate in front of it left on the
+// device (enqueued ahead of its inputs: go == 1, or the iteration was called off and the workgroup returns false).  They
+// always go through ONE copy in LDS, whichever source they have: a pointer that may lead into the kernel's arguments or
+// elsewhere, and even a choice between the two value by value, makes the compiler move pose and motion (or all 1.4 KB of
+// arguments) into scratch memory.  (The arguments themselves are never written: a kernel argument that is modified lives in
+// scratch memory.)  One trip to memory: go travels with the block.
+__device__ __forceinline__ bool load_inputs(const FusedArgs& a, IcpInputs& gin)
+{
+  __shared__ unsigned long long go;
+  if (a.gate)
+  {
+    constexpr int words = (int)(sizeof(IcpInputs) / 8);
+    static_assert(words + 1 <= 256 && offsetof(IcpGate, in) == 8, "one word per thread, go in front");
+    const unsigned long long* src = reinterpret_cast<const unsigned long long*>(a.gate);
+    if ((int)threadIdx.x < words) reinterpret_cast<unsigned long long*>(&gin)[threadIdx.x] = src[1 + threadIdx.x];
+    else if ((int)threadIdx.x == words) go = src[0];
+  }
+  else if (threadIdx.x == 0)
+  {
+    go = 1ull;
+    gin.pose = a.pose;
+    if (a.undistort) gin.ic = a.ic;
+  }
+  __syncthreads();
+  return go == 1ull;
+}
+
 // One workgroup's share of a type: 256 / G keypoints searched by G lanes each.  FUSE: the groups go on to the front
 // part of the model fit (group_stage) and the workgroup's first wavefront finishes the 256 / G matches; otherwise the
 // neighbour lists go to memory for the model kernel.
 template <int KMAX, int G, int TYPE, bool FUSE, int KC>
-__device__ __forceinline__ void search_type(const Rigid& pose, const FusedType& t, int block, SearchShared& sh, FitStage<256 / G, KC>& fs, const InterpConst* ic = nullptr)
+__device__ __forceinline__ void search_type(const FusedArgs& a, IcpInputs& gin, const FusedType& t, int block, SearchShared& sh, FitStage<256 / G, KC>& fs)
 {
   constexpr int QB = 256 / G;
   const int tid = threadIdx.x, gl = tid % G, ql = tid / G;
   const int q = block * QB + ql;
   const bool active = q < t.nq;
+  // the keypoint first, on its way while the launch's inputs arrive: they do not depend on each other, and behind a link or a
+  // gate the inputs are a trip to memory of their own
+  float4 q4 = {0.f, 0.f, 0.f, 0.f}, b4 = {0.f, 0.f, 0.f, 0.f};
+  if (active)
+  {
+    q4 = t.queries[2 * (size_t)q];
+    if (a.undistort) b4 = t.queries[2 * (size_t)q + 1];
+  }
+  if (!load_inputs(a, gin)) return;
+  const Rigid& pose = gin.pose;
+  const InterpConst* const ic = a.undistort ? &gin.ic : nullptr;
   if (t.route_stats)
   {
     if (tid < 6) sh.route[tid] = 0;
@@ -868,7 +906,6 @@ __device__ __forceinline__ void search_type(const Rigid& pose, const FusedType& 
   float qx = 0.f, qy = 0.f, qz = 0.f;
   if (active)
   {
-    float4 q4 = t.queries[2 * (size_t)q];
     // KeypointsMatcher: worldPoint = PosePrior * basePoint in double, narrowed to float for the search
     // (KeypointsMatcher.cxx:117-118, KDTreePCLAdaptor.h:96-100)
     auto place = [&](const Rigid& P, const InterpConst* C) {
@@ -876,7 +913,6 @@ __device__ __forceinline__ void search_type(const Rigid& pose, const FusedType& 
       {
         // Slam::RefineUndistortion's step for this keypoint (k_undistort of lsa_transform.hip, same arithmetic): the lanes
         // of the group all work it out, the first one stores it for everything after this match
-        const float4 b4 = t.queries[2 * (size_t)q + 1];
         Rigid U;
         interp_eval(*C, __hiloint2double(__float_as_int(b4.y), __float_as_int(b4.x)), U);
         double ux, uy, uz;
@@ -1066,27 +1102,7 @@ __global__ __launch_bounds__(256, 4) void k_search_all(FusedArgs a)
   static_assert(kGE == kGP && kGP == kGB, "one workgroup serves 256 / G keypoints of any type");
   __shared__ SearchShared sh;
   __shared__ FitStage<QB, KC> fs;
-  // enqueued ahead of its inputs: the gate in front of this launch has left them (go == 1) or the iteration was called off.
-  // (The arguments themselves are never written: a kernel argument that is modified lives in scratch memory.)
-  if (a.gate && a.gate->go != 1ull) return;
-  // Pose and motion always go through ONE copy in LDS, whichever source they have -- the launch's own arguments or what
-  // the gate brought over: a pointer that may lead into the kernel's arguments or elsewhere, and even a choice between the
-  // two value by value, makes the compiler move pose and motion (or all 1.4 KB of arguments) into scratch memory.
-  __shared__ IcpInputs gin;
-  if (a.gate)
-  {
-    constexpr int words = (int)(sizeof(IcpInputs) / 8);
-    static_assert(words <= 256, "one word per thread");
-    if ((int)threadIdx.x < words)
-      reinterpret_cast<unsigned long long*>(&gin)[threadIdx.x] = reinterpret_cast<const unsigned long long*>(&a.gate->in)[threadIdx.x];
-  }
-  else if (threadIdx.x == 0)
-  {
-    gin.pose = a.pose;
-    if (a.undistort) gin.ic = a.ic;
-  }
-  __syncthreads();
-  const InterpConst* const ic = a.undistort ? &gin.ic : nullptr;
+  __shared__ IcpInputs gin;  // pose and motion of the launch (load_inputs, from inside search_type: behind the keypoints' loads)
   // Hardware blocks b, b + 8, ... share an XCD (and its L2).  Every XCD gets one contiguous eighth of EVERY type's
   // blocks -- neighbouring keypoints (scan order) search a compact region of the target through one L2 -- and the
   // types with the longest searches (edges: no early out, larger k) first.
@@ -1096,13 +1112,13 @@ __global__ __launch_bounds__(256, 4) void k_search_all(FusedArgs a)
   {
     const int block = xcd * se + j;
     if (block >= a.t[0].nblocks) return;
-    search_type<KE, kGE, LSA_EDGE, FUSE, KC>(gin.pose, a.t[0], block, sh, fs, ic);
+    search_type<KE, kGE, LSA_EDGE, FUSE, KC>(a, gin, a.t[0], block, sh, fs);
   }
   else if (j < se + sp)
   {
     const int block = xcd * sp + (j - se);
     if (block >= a.t[1].nblocks) return;
-    search_type<KP, kGP, LSA_PLANE, FUSE, KC>(gin.pose, a.t[1], block, sh, fs, ic);
+    search_type<KP, kGP, LSA_PLANE, FUSE, KC>(a, gin, a.t[1], block, sh, fs);
   }
   else
   {
@@ -1111,7 +1127,7 @@ __global__ __launch_bounds__(256, 4) void k_search_all(FusedArgs a)
       const int sb = (a.t[2].nblocks + 7) / 8;
       const int block = xcd * sb + (j - se - sp);
       if (block >= a.t[2].nblocks) return;
-      search_type<KB, kGB, LSA_BLOB, FUSE, KC>(gin.pose, a.t[2], block, sh, fs, ic);
+      search_type<KB, kGB, LSA_BLOB, FUSE, KC>(a, gin, a.t[2], block, sh, fs);
     }
   }
 }

@@ -116,6 +116,9 @@ SlamCore::SlamCore(int device)
 
 SlamCore::~SlamCore()
 {
+  if (std::getenv("LSA_STAGE_DEBUG") && DbgFrames > 0)
+    std::fprintf(stderr, "[stage debug] per frame, us: garbage+adopt %.1f | wait for the look-ahead thread %.1f | ego-motion before its loop %.1f | after the maps %.1f | localization after its loop %.1f | between ego-motion and localization %.1f (%ld frames)\n",
+                 1e6 * DbgAcc[0] / DbgFrames, 1e6 * DbgAcc[1] / DbgFrames, 1e6 * DbgAcc[2] / DbgFrames, 1e6 * DbgAcc[3] / DbgFrames, 1e6 * DbgAcc[4] / DbgFrames, 1e6 * DbgAcc[5] / DbgFrames, DbgFrames);
   WaitMaps();
   for (auto* g : DevMaps)
     if (g) lsa_device_grid_destroy(g);
@@ -264,6 +267,9 @@ int SlamCore::AddFrame(const lsa_point_t* pts, int n, uint64_t stampUs, uint32_t
     if (adopted < 0) return Fail(adopted, "lsa_upload_frame_adopt");
     if (adopted == 0) LSA_TRY(lsa_upload_frame(Ctx, pts, n));
   }
+  if (NbrFrameProcessed == 8) { for (double& d : DbgAcc) d = 0.; DbgFrames = 0; }  // (the first frames allocate)
+  DbgAcc[0] += total.Stop();
+  DbgFrames++;
   int rc = ProcessCurrentFrame(stampUs);
   Latency = Stats.total = total.Stop();
   return rc;
@@ -297,7 +303,8 @@ int SlamCore::HintNextFrame(const lsa_point_t* pts, int n)
 // the steps of the ICP loops.
 int SlamCore::TryStartLookahead()
 {
-  if (!NextFrameHinted || !lsa_upload_frame_ready(Ctx)) return LSA_OK;
+  // (not while the sub-maps ahead of time are still being enqueued on the same stream: ProcessCurrentFrame)
+  if (!NextFrameHinted || HoldLookahead || DevSpecRunning.load(std::memory_order_acquire) || !lsa_upload_frame_ready(Ctx)) return LSA_OK;
   NextFrameHinted = false;
   if (lsa_extract_prefetch_uploaded(Ctx, &ExtractParams) != LSA_OK) LastError = std::string("look-ahead ignored: ") + lsa_last_error(Ctx);
   return LSA_OK;
@@ -438,7 +445,17 @@ int SlamCore::ProcessCurrentFrame(uint64_t stampUs)
   CurrentStamp = stampUs;
   CurrentTime = StampToSec(stampUs);
   HaveFrame = true;
-  AheadWorker.Wait();  // it reads the previous frame's keypoint buffers, which the extraction is about to rotate (long done)
+  {
+    Tick t;
+    AheadWorker.Wait();  // it reads the previous frame's keypoint buffers, which the extraction is about to rotate (long done)
+    DbgAcc[1] += t.Stop();
+  }
+  // The look-ahead stream carries, in this order of urgency: the previous keyframe's insertion and the sub-maps extracted
+  // ahead of time (this frame's localization waits for them), the next frame's ego-motion targets, the next frame's
+  // extraction (nobody waits for it before the next AddFrame).  An upload that is there early must not put the extraction in
+  // front: with the cloud staged by four threads the sub-map stage went from 0.02 to 0.12 ms per frame (1 250 -> 1 100 frames/s).
+  // Held back until the speculation has been enqueued (BeginSubMapSpeculation, DevSpecRunning).
+  HoldLookahead = DeviceMapsInUse() && SubMapsAhead && MapUpdate != MappingMode::NONE;
   lsa_set_knn_lanes(Ctx, LSA_EDGE, KnnLanesEdges);
   lsa_set_knn_lanes(Ctx, LSA_PLANE, KnnLanesPlanes);
   lsa_set_knn_lanes(Ctx, LSA_BLOB, KnnLanesBlobs);
@@ -456,6 +473,7 @@ int SlamCore::ProcessCurrentFrame(uint64_t stampUs)
   if (rc < 0) return rc;
   rc = Localization();
   if (rc < 0) return rc;
+  Tick tail;
   // confidence estimators: before the maps update, which invalidates the sub-maps (Slam.cxx:269-280)
   if (OverlapSamplingRatio > 0)
   {
@@ -474,6 +492,7 @@ int SlamCore::ProcessCurrentFrame(uint64_t stampUs)
   if (LocalizationStartFused && DeviceMapsInUse() && MapUpdate != MappingMode::NONE) LSA_TRY(lsa_arm_localization_boxes(Ctx));
   LogCurrentFrameState(CurrentTime);
   NbrFrameProcessed++;
+  DbgAcc[3] += tail.Stop() - Stats.maps;
   return LSA_OK;
 }
 
@@ -592,6 +611,7 @@ lsa_match_params_t SlamCore::LocMatchParams() const
 // Slam::ComputeEgoMotion (Slam.cxx:813-972)
 int SlamCore::ComputeEgoMotion()
 {
+  Tick tpre;
   Trelative = Pose::Identity();
   if (AheadStatus < 0) { const int rc = AheadStatus; AheadStatus = 0; return Fail(rc, "lsa_prepare_previous_targets (look-ahead thread)"); }
   if (LogTrajectory.size() >= 2 &&
@@ -610,6 +630,7 @@ int SlamCore::ComputeEgoMotion()
   {
     const int rc = BeginSubMapSpeculation(Tworld * Trelative);
     if (rc < 0) return rc;
+    HoldLookahead = false;  // (from here on DevSpecRunning says whether the speculation is still being enqueued)
   }
   if (!registers) return LSA_OK;
 
@@ -662,6 +683,7 @@ int SlamCore::ComputeEgoMotion()
     ticket = -1;
   };
 
+  DbgAcc[2] += tpre.Stop();
   for (unsigned icpIter = 0; icpIter < EgoMotionICPMaxIter; ++icpIter)
   {
     Tick ticp;
@@ -940,6 +962,8 @@ int SlamCore::Localization()
     for (int k = 0; k < 3; ++k)  // the extractions follow one another on the context's stream, their sizes come back together
       if (need[k]) LSA_TRY(lsa_device_grid_build_submap_end(DevMaps[k]));
     Stats.submap += t.Stop();
+    HoldLookahead = false;
+    LSA_TRY(TryStartLookahead());
   }
   else
   {

@@ -286,6 +286,9 @@ private:
   int InterludeStatus = 0;
   int NextStoredSlot = -1;
   bool NextFrameHinted = false;   // a cloud was announced (HintNextFrame) and its look-ahead extraction not started yet
+  double DbgAcc[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // (diagnostics, LSA_STAGE_DEBUG=1: seconds outside the stage timers, printed when the object goes)
+  long DbgFrames = 0;
+  bool HoldLookahead = false;     // ... and must not start yet: the sub-maps extracted ahead of time for THIS frame's localization go onto the look-ahead stream first
   int TryStartLookahead();        // starts it as soon as the upload has been enqueued
   lsa_ctx* Ctx = nullptr;
   std::string LastError;

@@ -74,7 +74,7 @@ __device__ __forceinline__ constexpr int hsym(int a, int b) { return a <= b ? hi
 // live in registers while the residual blocks are evaluated)
 struct LmState
 {
-  double cur[kAccumVals];  // sums at the current point x
+  int cur_buf;             // which of Shared::sums holds the sums at the current point x (the other one takes the next evaluation's)
   double x[6], scale[6], diag[6];
   double radius, decrease_factor, x_norm, model_cost_change, delta_norm, initial_cost;
   int reuse_diagonal, consecutive_invalid, iter;
@@ -86,7 +86,10 @@ struct Shared
   double wsum[kLmThreads / 64][kAccumVals];
   unsigned gat[kLmBlocksMax][2 * kAccumVals];  // halves of every block's partial sums
   double part[kAccumVals][8];
-  double tot[kAccumVals];   // the sums of the last evaluation over ALL residual blocks
+  // The sums over ALL residual blocks, twice: at the current point, and of the evaluation under way / just done.  A step that
+  // is accepted makes the second the first by flipping LmState::cur_buf (29 values that one thread no longer copies).
+  double sums[2][kAccumVals];
+  double Hs[36], gs[6];     // the scaled system of the step under way (lm_scale_system: a lane per entry)
   double w[6];              // the point to evaluate next
   double rot[39];           // R, dR/drx, dR/dry, dR/drz, t at w
   LmState lm;
@@ -103,7 +106,7 @@ __device__ __forceinline__ double uniform(double v)
   return __longlong_as_double(((long long)hi << 32) | (long long)(unsigned)lo);
 }
 
-// One evaluation at sh.w / sh.rot: sh.tot[] = the 29 sums over ALL residual blocks, identical in every block.
+// One evaluation at sh.w / sh.rot: sh.sums[1 - cur_buf][] = the 29 sums over ALL residual blocks, identical in every block.
 // Returns false when a spin ran out (uniform over the block).
 __device__ __forceinline__ void lm_lap(Shared& sh, int slot)
 {
@@ -217,7 +220,7 @@ __device__ __forceinline__ bool lm_evaluate(const LmParams& p, unsigned epoch, u
     double s = sh.part[threadIdx.x][0];
 #pragma unroll
     for (int j = 1; j < 8; ++j) s += sh.part[threadIdx.x][j];
-    sh.tot[threadIdx.x] = s;
+    sh.sums[1 - sh.lm.cur_buf][threadIdx.x] = s;
   }
   __syncthreads();
   if (trace) lm_lap(sh, 2);
@@ -317,54 +320,58 @@ __device__ __forceinline__ void finish_point(Shared& sh)
 
 // What the trust-region loop of host/lsa_lm.cpp (LocalOptimizer::Solve) does between two evaluations, N active
 // parameters: all 6, or (x, y, rz) in 2D mode (SubsetParameterization(6, {2, 3, 4}), LocalOptimizer.cxx:89-90).
-// In: sh.tot = the sums at sh.w (the start point when first, a candidate afterwards).  Out: sh.w / sh.rot = the next
-// candidate, or the return value true = the solve is over.  One thread runs it.
+// In: sh.sums[1 - cur_buf] = the sums at sh.w (the start point when first, a candidate afterwards).  Out: sh.w / sh.rot =
+// the next candidate, or true = the solve is over.  Three parts, the first wavefront runs them: lm_decide (one lane: what
+// became of the candidate), lm_scale_system (a lane per entry of the Jacobi-scaled normal equations), lm_take_step (one lane:
+// the damped solve and the next candidate).  The arithmetic of every value is the host loop's, operation for operation.
+template <int N> __device__ __forceinline__ constexpr int lm_act(int a) { return N == 6 ? a : (a == 2 ? 5 : a); }
 template <int N>
-__device__ bool lm_step(const LmParams& p, Shared& sh, bool first)
+__device__ __forceinline__ double lm_grad_max(const double* cur)
 {
-  auto act = [](int a) constexpr { return N == 6 ? a : (a == 2 ? 5 : a); };
-  const double function_tolerance = 1e-6, gradient_tolerance = 1e-10, parameter_tolerance = 1e-8;
-  const double min_relative_decrease = 1e-3, min_trust_region_radius = 1e-32, max_radius = 1e16;
-  const double min_diagonal = 1e-6, max_diagonal = 1e32;
-  const int max_consecutive_invalid = 5;
-  LmState& lm = sh.lm;
-  auto grad_max = [&]() {
-    double m = 0;
+  double m = 0;
 #pragma unroll
-    for (int a = 0; a < N; ++a) { const double v = __builtin_fabs(lm.cur[1 + act(a)]); m = m > v ? m : v; }  // std::max(m, v)
-    return m;
-  };
+  for (int a = 0; a < N; ++a) { const double v = __builtin_fabs(cur[1 + lm_act<N>(a)]); m = m > v ? m : v; }  // std::max(m, v)
+  return m;
+}
+template <int N>
+__device__ bool lm_decide(const LmParams& p, Shared& sh, bool first)
+{
+  const double function_tolerance = 1e-6, gradient_tolerance = 1e-10, parameter_tolerance = 1e-8;
+  const double min_relative_decrease = 1e-3, max_radius = 1e16;
+  LmState& lm = sh.lm;
+  const double* cur = sh.sums[lm.cur_buf];
+  const double* tot = sh.sums[1 - lm.cur_buf];
   auto xnorm = [&]() {
     double s = 0;
 #pragma unroll
-    for (int a = 0; a < N; ++a) s += lm.x[act(a)] * lm.x[act(a)];
+    for (int a = 0; a < N; ++a) s += lm.x[lm_act<N>(a)] * lm.x[lm_act<N>(a)];
     return __builtin_sqrt(s);
   };
 
   if (first)
   {
-    lm.matches = (int)sh.tot[28];
+    lm.matches = (int)tot[28];
     if (lm.matches < p.min_matches)
     {
       lm.skipped = 1;
       lm.code = kCodeNotEnoughMatches;
       return true;
     }
-#pragma unroll
-    for (int v = 0; v < kAccumVals; ++v) lm.cur[v] = sh.tot[v];
-    lm.initial_cost = lm.cur[0];
+    lm.cur_buf ^= 1;  // the sums at the start point are the current ones
+    cur = tot;
+    lm.initial_cost = cur[0];
     lm.successful = 1;  // iteration 0 is reported as a successful step by Ceres
 #pragma unroll
-    for (int a = 0; a < N; ++a) lm.scale[a] = 1.0 / (1.0 + __builtin_sqrt(lm.cur[hidx(act(a), act(a))]));  // Jacobi scaling, once
-    if (grad_max() <= gradient_tolerance) { lm.code = kCodeGradient0; return true; }
+    for (int a = 0; a < N; ++a) lm.scale[a] = 1.0 / (1.0 + __builtin_sqrt(cur[hidx(lm_act<N>(a), lm_act<N>(a))]));  // Jacobi scaling, once
+    if (lm_grad_max<N>(cur) <= gradient_tolerance) { lm.code = kCodeGradient0; return true; }
     lm.x_norm = xnorm();
   }
   else
   {
     // parameter / function tolerance terminate WITHOUT taking the candidate step
     if (lm.delta_norm <= parameter_tolerance * (lm.x_norm + parameter_tolerance)) { lm.code = kCodeParameterTolerance; return true; }
-    const double cost_change = lm.cur[0] - sh.tot[0];
-    if (__builtin_fabs(cost_change) <= function_tolerance * lm.cur[0]) { lm.code = kCodeFunctionTolerance; return true; }
+    const double cost_change = cur[0] - tot[0];
+    if (__builtin_fabs(cost_change) <= function_tolerance * cur[0]) { lm.code = kCodeFunctionTolerance; return true; }
     const double relative_decrease = cost_change / lm.model_cost_change;
     if (relative_decrease > min_relative_decrease)
     {
@@ -372,9 +379,8 @@ __device__ bool lm_step(const LmParams& p, Shared& sh, bool first)
       for (int a = 0; a < 6; ++a) lm.x[a] = sh.w[a];
       lm.x_norm = xnorm();
       // cost AND Jacobian were evaluated at the candidate (Ceres evaluates the Jacobian again on acceptance, at the
-      // same point: same arithmetic, one evaluation less)
-#pragma unroll
-      for (int v = 0; v < kAccumVals; ++v) lm.cur[v] = sh.tot[v];
+      // same point: same arithmetic, one evaluation less): its sums become the current ones
+      lm.cur_buf ^= 1;
       ++lm.successful;
       const double t = 2.0 * relative_decrease - 1.0;
       const double q = 1.0 - t * t * t;
@@ -390,24 +396,49 @@ __device__ bool lm_step(const LmParams& p, Shared& sh, bool first)
       lm.radius /= lm.decrease_factor; lm.decrease_factor *= 2.0; lm.reuse_diagonal = 1;
     }
   }
-
   if (sh.st0) { const unsigned long long n = wall_clock64(); sh.sub[0] += n - sh.st0; sh.st0 = n; }
+  return false;
+}
+// sh.Hs / sh.gs = the normal equations at the current point, scaled: lane l < N * N the entry l, the next N lanes the gradient
+template <int N>
+__device__ __forceinline__ void lm_scale_system(Shared& sh)
+{
+  const int l = threadIdx.x & 63;
+  const LmState& lm = sh.lm;
+  const double* cur = sh.sums[lm.cur_buf];
+  if (l < N * N)
+  {
+    const int a = l / N, b = l - a * N;
+    const int fa = lm_act<N>(a), fb = lm_act<N>(b);
+    const int lo = fa <= fb ? fa : fb, hi = fa <= fb ? fb : fa;
+    sh.Hs[l] = cur[7 + lo * 6 - (lo * (lo - 1)) / 2 + (hi - lo)] * lm.scale[a] * lm.scale[b];  // hsym(fa, fb)
+  }
+  else if (l < N * N + N)
+  {
+    const int a = l - N * N;
+    sh.gs[a] = cur[1 + lm_act<N>(a)] * lm.scale[a];
+  }
+}
+template <int N>
+__device__ bool lm_take_step(const LmParams& p, Shared& sh)
+{
+  const double gradient_tolerance = 1e-10, min_trust_region_radius = 1e-32;
+  const double min_diagonal = 1e-6, max_diagonal = 1e32;
+  const int max_consecutive_invalid = 5;
+  LmState& lm = sh.lm;
+  const double* cur = sh.sums[lm.cur_buf];
+  double Hs[N * N], gs[N];
+#pragma unroll
+  for (int i = 0; i < N * N; ++i) Hs[i] = sh.Hs[i];
+#pragma unroll
+  for (int a = 0; a < N; ++a) gs[a] = sh.gs[a];
   while (true)
   {
     if (lm.iter >= p.max_iter) { lm.code = kCodeMaxIterations; return true; }
-    if (grad_max() <= gradient_tolerance) { lm.code = kCodeGradient; return true; }
+    if (lm_grad_max<N>(cur) <= gradient_tolerance) { lm.code = kCodeGradient; return true; }
     if (lm.radius < min_trust_region_radius) { lm.code = kCodeMinRadius; return true; }
     ++lm.iter;
     lm.iterations = lm.iter;
-
-    double Hs[N * N], gs[N];
-#pragma unroll
-    for (int a = 0; a < N; ++a)
-    {
-      gs[a] = lm.cur[1 + act(a)] * lm.scale[a];
-#pragma unroll
-      for (int b = 0; b < N; ++b) Hs[a * N + b] = lm.cur[hsym(act(a), act(b))] * lm.scale[a] * lm.scale[b];
-    }
     if (!lm.reuse_diagonal)
     {
 #pragma unroll
@@ -463,8 +494,8 @@ __device__ bool lm_step(const LmParams& p, Shared& sh, bool first)
 #pragma unroll
     for (int a = 0; a < N; ++a)
     {
-      cand[act(a)] = lm.x[act(a)] + step[a] * lm.scale[a];
-      const double e = lm.x[act(a)] - cand[act(a)];
+      cand[lm_act<N>(a)] = lm.x[lm_act<N>(a)] + step[a] * lm.scale[a];
+      const double e = lm.x[lm_act<N>(a)] - cand[lm_act<N>(a)];
       delta_norm += e * e;
     }
     lm.delta_norm = __builtin_sqrt(delta_norm);
@@ -473,6 +504,17 @@ __device__ bool lm_step(const LmParams& p, Shared& sh, bool first)
     if (sh.st0) { const unsigned long long n = wall_clock64(); sh.sub[3] += n - sh.st0; sh.st0 = n; }
     return false;
   }
+}
+// the three parts, by the first wavefront (all its lanes call); sh.stop = the solve is over
+template <int N>
+__device__ __forceinline__ void lm_step(const LmParams& p, Shared& sh, bool first)
+{
+  if (threadIdx.x == 0) sh.stop = lm_decide<N>(p, sh, first) ? 1 : 0;
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // one wavefront: its LDS operations are served in order
+  if (sh.stop) return;
+  lm_scale_system<N>(sh);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  if (threadIdx.x == 0) sh.stop = lm_take_step<N>(p, sh) ? 1 : 0;
 }
 
 // What the host's loop does between two ICP iterations (host/lsa_slam_core.cpp, Slam.cxx:940-950 / 1134-1151), for the
@@ -585,7 +627,8 @@ __global__ __launch_bounds__(kLmThreads) void k_lm_solve(LmParams p, u64* __rest
     sh.lap[5] = sh.tk;
     LmState& lm = sh.lm;
 #pragma unroll
-    for (int v = 0; v < kAccumVals; ++v) lm.cur[v] = 0.;
+    for (int v = 0; v < kAccumVals; ++v) sh.sums[0][v] = 0.;
+    lm.cur_buf = 0;
     // the start point: the launch's own argument, or what the gate brought over (read into LDS, the arguments stay untouched)
     double x0[6];
 #pragma unroll
@@ -614,7 +657,8 @@ __global__ __launch_bounds__(kLmThreads) void k_lm_solve(LmParams p, u64* __rest
     if (threadIdx.x < 64)
     {
       if (threadIdx.x == 0 && tr) sh.st0 = wall_clock64();
-      if (threadIdx.x == 0) sh.stop = (p.two_d ? lm_step<3>(p, sh, epoch == 1) : lm_step<6>(p, sh, epoch == 1)) ? 1 : 0;
+      if (p.two_d) lm_step<3>(p, sh, epoch == 1);
+      else lm_step<6>(p, sh, epoch == 1);
       finish_point(sh);
     }
     __syncthreads();
@@ -641,8 +685,8 @@ __global__ __launch_bounds__(kLmThreads) void k_lm_solve(LmParams p, u64* __rest
     double r = 0.;
     if (v < kResInitial) r = lm.x[v - kResPose];
     else if (v == kResInitial) r = lm.initial_cost;
-    else if (v == kResFinal) r = lm.cur[0];
-    else if (v < kResSums + kAccumVals) r = lm.cur[v - kResSums];
+    else if (v == kResFinal) r = sh.sums[lm.cur_buf][0];
+    else if (v < kResSums + kAccumVals) r = sh.sums[lm.cur_buf][v - kResSums];
     else if (v == kResSuccessful) r = lm.successful;
     else if (v == kResUnsuccessful) r = lm.unsuccessful;
     else if (v == kResIterations) r = lm.iterations;

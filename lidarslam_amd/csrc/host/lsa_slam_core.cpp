@@ -22,12 +22,14 @@ struct Tick
 inline double StampToSec(uint64_t us) { return us * 1e-6; }  // Utils::PclStampToSec
 }  // namespace
 
+static long long SteadyNs() { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 HostWorker::HostWorker() : T([this] { Run(); }) {}
 HostWorker::~HostWorker()
 {
   {
     std::lock_guard<std::mutex> l(M);
     Quit = true;
+    Leaving.store(true);
   }
   Cv.notify_all();
   T.join();
@@ -37,7 +39,13 @@ void HostWorker::Submit(std::function<void()> job)
   {
     std::lock_guard<std::mutex> l(M);
     Jobs.push_back(std::move(job));
+    Posted.fetch_add(1, std::memory_order_release);
   }
+  Cv.notify_one();
+}
+void HostWorker::Expect(double seconds)
+{
+  PollUntil.store(SteadyNs() + static_cast<long long>(seconds * 1e9), std::memory_order_release);
   Cv.notify_one();
 }
 void HostWorker::Wait()
@@ -50,10 +58,25 @@ void HostWorker::Run()
   std::unique_lock<std::mutex> l(M);
   while (true)
   {
-    Cv.wait(l, [this] { return Quit || !Jobs.empty(); });
-    if (Jobs.empty()) return;  // Quit with nothing left to do
+    Cv.wait(l, [this] { return Quit || !Jobs.empty() || SteadyNs() < PollUntil.load(std::memory_order_acquire); });
+    if (Jobs.empty())
+    {
+      if (Quit) return;  // nothing left to do
+      // woken ahead of a job (Expect): poll for it, without the lock, until it is there or the time is up
+      l.unlock();
+      while (Posted.load(std::memory_order_acquire) == 0 && !Leaving.load() && SteadyNs() < PollUntil.load(std::memory_order_acquire))
+      {
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
+      }
+      PollUntil.store(0, std::memory_order_release);
+      l.lock();
+      continue;
+    }
     std::function<void()> job = std::move(Jobs.front());
     Jobs.pop_front();
+    Posted.fetch_sub(1, std::memory_order_release);
     Busy = true;
     l.unlock();
     job();
@@ -491,6 +514,9 @@ int SlamCore::ProcessCurrentFrame(uint64_t stampUs)
   // the words the next frame's localization reduces its keypoints' boxes into, armed while the device has nothing to do
   if (LocalizationStartFused && DeviceMapsInUse() && MapUpdate != MappingMode::NONE) LSA_TRY(lsa_arm_localization_boxes(Ctx));
   LogCurrentFrameState(CurrentTime);
+  // the next frame's first jobs for the look-ahead thread (the sub-maps under the predicted pose, the ego-motion targets) come
+  // within a fraction of a millisecond when the caller replays: the thread is awake for them
+  if (WorkerPrewake && DeviceMapsInUse()) AheadWorker.Expect(300e-6);
   NbrFrameProcessed++;
   DbgAcc[3] += tail.Stop() - Stats.maps;
   return LSA_OK;
@@ -1092,6 +1118,8 @@ int SlamCore::Localization()
   for (unsigned icpIter = 0; icpIter < LocalizationICPMaxIter; ++icpIter)
   {
     Tick ticp;
+    // the keyframe's insertion is handed to the maps' thread right after this loop: awake by then (last iteration: ~0.1 ms ahead)
+    if (WorkerPrewake && DeviceMapsInUse() && icpIter + 1 == LocalizationICPMaxIter && MapUpdate != MappingMode::NONE) MapWorker[0].Expect(300e-6);
     mp.saturation_distance = saturation(icpIter);
     LocalOptimizer optimizer(Ctx);
     configure(optimizer);
@@ -1752,6 +1780,7 @@ int SlamCore::GetRegisteredFrame(std::vector<lsa_point_t>& out)
   X("SubMapsAhead", SubMapsAhead, bool)                                                                \
   X("SubMapsAheadAdaptive", SubMapsAheadAdaptive, bool)                                                \
   X("LocalizationStartFused", LocalizationStartFused, bool)                                            \
+  X("WorkerPrewake", WorkerPrewake, bool)                                                              \
   X("ICPAhead", ICPAhead, int)                                                                         \
   X("UndistortInSearch", UndistortInSearch, bool)                                                      \
   X("SpecBoxesOnLookahead", SpecBoxesOnLookahead, bool)                                                \

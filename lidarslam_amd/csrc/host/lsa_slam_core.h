@@ -66,6 +66,11 @@ public:
   ~HostWorker();
   void Submit(std::function<void()> job);
   void Wait();
+  // A job is about to be submitted (within `seconds`): the thread wakes up now and polls for it instead of sleeping, so that
+  // the job starts within a microsecond of Submit instead of a scheduler's wake-up later (tens of microseconds on an idle
+  // host, a fifth of a frame and more on a busy one: a map insertion enqueued late runs INTO the next frame's ICP kernels
+  // instead of in front of them).  Costs the polling time on one core, bounded by `seconds`.
+  void Expect(double seconds);
 
 private:
   void Run();
@@ -73,6 +78,9 @@ private:
   std::condition_variable Cv, Idle;
   std::deque<std::function<void()>> Jobs;
   bool Busy = false, Quit = false;
+  std::atomic<int> Posted{0};           // jobs in the queue (read without the lock by the polling thread)
+  std::atomic<long long> PollUntil{0};  // steady-clock nanoseconds
+  std::atomic<bool> Leaving{false};
   std::thread T;
 };
 
@@ -288,6 +296,7 @@ private:
   bool NextFrameHinted = false;   // a cloud was announced (HintNextFrame) and its look-ahead extraction not started yet
   double DbgAcc[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // (diagnostics, LSA_STAGE_DEBUG=1: seconds outside the stage timers, printed when the object goes)
   long DbgFrames = 0;
+  bool WorkerPrewake = true;      // the worker threads are woken ahead of the jobs whose time is known (HostWorker::Expect)
   bool HoldLookahead = false;     // ... and must not start yet: the sub-maps extracted ahead of time for THIS frame's localization go onto the look-ahead stream first
   int TryStartLookahead();        // starts it as soon as the upload has been enqueued
   lsa_ctx* Ctx = nullptr;

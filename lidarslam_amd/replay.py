@@ -129,6 +129,8 @@ class ConcurrentReplay:
         # ICP loops enqueued whole, every solve leaving the next iteration's pose on the device (links: nothing spins on a
         # hardware queue, unlike the gates of ICPAhead = 1, which side by side held up the other sequences' kernels)
         params.setdefault("ICPAhead", 2)
+        # worker threads woken ahead of their jobs poll for them: worth a core for one or two sequences, not for eight
+        params.setdefault("WorkerPrewake", 1 if len(seeds) <= 2 else 0)
         self.frames = frames
         self.lookahead = lookahead  # extract frame f + 1 beside the registration of frame f (same results)
         self.slams, self.stamps = [], []

@@ -55,6 +55,7 @@ def lib():
         L.orc_covariance.argtypes = [vp, vp, i32, f64, vp, vp, vp]
         L.orc_math.argtypes = [i32, vp, vp, i32, vp]
         L.orc_undistort.argtypes = [vp, i32, vp, vp, f64, f64]
+        L.orc_icp_link.argtypes = [vp, i32, i32, f64, f64, f64, vp, vp, vp, vp]
         L.orc_transform.argtypes = [vp, i32, vp]
         L.orc_slam_create.restype = vp
         L.orc_slam_destroy.argtypes = [vp]
@@ -228,6 +229,15 @@ def undistort(pts, H0, H1, t0, t1):
     out = np.ascontiguousarray(pts).copy()
     lib().orc_undistort(ptr(out), out.size, ptr(pose16(H0)), ptr(pose16(H1)), t0, t1)
     return out
+
+
+def icp_link(x6, refine, have_log, prev_time, cur_time, max_ratio, previous_world, motion):
+    """orc_icp_link: the pose algebra between two ICP iterations by the restatement's own functions, laid out as the
+    product's link block -> (64 words, the motion within the frame afterwards)"""
+    words, after = np.zeros(64, np.uint64), np.zeros(16, np.float64)
+    x, m = np.ascontiguousarray(x6, np.float64), np.ascontiguousarray(motion, np.float64)
+    lib().orc_icp_link(ptr(x), int(refine), int(have_log), prev_time, cur_time, max_ratio, ptr(pose16(previous_world)), ptr(m), ptr(words), ptr(after))
+    return words, after
 
 
 def transform(pts, T):

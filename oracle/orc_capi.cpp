@@ -258,6 +258,71 @@ int orc_undistort(lsa_point_t* pts, int n, const double H0[16], const double H1[
   for (int i = 0; i < n; ++i) transform_point(p[i], it(p[i].time));
   return 0;
 }
+// ---- the pose algebra between two ICP iterations ------------------------------------------------------------------
+// What Slam::ComputeEgoMotion / Localization do with a solve's parameters before the next iteration (Slam.cxx:940-950,
+// 1134-1151): Utils::XYZRPYtoIsometry, the next start point (LocalOptimizer::SetPosePrior: IsometryToXYZRPY of that pose),
+// and -- refine -- Slam::RefineUndistortion (Slam.cxx:1271-1285, 1322-1352) with its LinearTransformInterpolator, by THIS
+// restatement's own functions (xyzrpy_to_iso, iso_to_xyzrpy, linear_interpolation, Interpolator, slerp_prepare).  Laid out
+// as the block the product's solve leaves on the device for the next iteration (words: go | pose R[9] t[3] | start point
+// [6] | qa[4] qb[4] d theta sin_theta trans0[3] trans1[3] time0 time1 | h0 R[9] t[3] | {linear, invalid}), so that a test
+// can hold the product's arithmetic (lsa_posemath.h, host and device) against this one word for word.
+// motion: Time0, Time1, Rot0 (w x y z), Rot1, Trans0[3], Trans1[3] of WithinFrameMotion before; motion_after: afterwards.
+int orc_icp_link(const double x[6], int refine, int have_log, double prev_time, double cur_time, double max_ratio, const double previous_world[16],
+                 const double motion[16], unsigned long long words[64], double motion_after[16])
+{
+  std::memset(words, 0, 64 * sizeof(unsigned long long));
+  std::memcpy(motion_after, motion, 16 * sizeof(double));
+  const Iso Tworld = xyzrpy_to_iso(x);
+  double x0[6];
+  iso_to_xyzrpy(Tworld, x0);
+  double* w = reinterpret_cast<double*>(words);
+  words[0] = 1ull;
+  std::memcpy(w + 1, Tworld.R, sizeof(Tworld.R));
+  std::memcpy(w + 10, Tworld.t, sizeof(Tworld.t));
+  std::memcpy(w + 13, x0, sizeof(x0));
+  if (!refine) return 0;
+  Interpolator within;
+  within.Time0 = motion[0]; within.Time1 = motion[1];
+  within.Rot0 = {motion[2], motion[3], motion[4], motion[5]};
+  within.Rot1 = {motion[6], motion[7], motion[8], motion[9]};
+  std::memcpy(within.Trans0, motion + 10, sizeof(within.Trans0));
+  std::memcpy(within.Trans1, motion + 13, sizeof(within.Trans1));
+  const Iso PreviousTworld = IsoFromRowMajor(previous_world);
+  auto InterpolateScanPose = [&](double time) -> Iso {  // Slam.cxx:1271-1285
+    if (!have_log) return Tworld;
+    if (std::abs(time / (cur_time - prev_time)) > max_ratio) return Tworld;
+    return linear_interpolation(PreviousTworld, Tworld, cur_time + time, prev_time, cur_time);
+  };
+  // Slam.cxx:1322-1352
+  const Iso previousBaseBegin = within.GetH0();
+  const Iso previousBaseEnd = within.GetH1();
+  const Iso worldToBaseBegin = InterpolateScanPose(within.Time0);
+  const Iso worldToBaseEnd = InterpolateScanPose(within.Time1);
+  const Iso baseToWorld = iso_inverse(Tworld);
+  const Iso newBaseBegin = iso_mul(baseToWorld, worldToBaseBegin);
+  const Iso newBaseEnd = iso_mul(baseToWorld, worldToBaseEnd);
+  within.SetTransforms(newBaseBegin, newBaseEnd);
+  Interpolator interp = within;
+  interp.SetTransforms(iso_mul(newBaseBegin, iso_inverse(previousBaseBegin)), iso_mul(newBaseEnd, iso_inverse(previousBaseEnd)));
+  const SlerpConst sc = slerp_prepare(interp.Rot0, interp.Rot1);
+  const Iso h0 = interp.GetH0();
+  double* c = w + 19;
+  const double qa[4] = {interp.Rot0.w, interp.Rot0.x, interp.Rot0.y, interp.Rot0.z}, qb[4] = {interp.Rot1.w, interp.Rot1.x, interp.Rot1.y, interp.Rot1.z};
+  std::memcpy(c, qa, sizeof(qa)); std::memcpy(c + 4, qb, sizeof(qb));
+  c[8] = sc.d; c[9] = sc.theta; c[10] = sc.sin_theta;
+  std::memcpy(c + 11, interp.Trans0, 3 * sizeof(double)); std::memcpy(c + 14, interp.Trans1, 3 * sizeof(double));
+  c[17] = interp.Time0; c[18] = interp.Time1;
+  std::memcpy(c + 19, h0.R, sizeof(h0.R)); std::memcpy(c + 28, h0.t, sizeof(h0.t));
+  const int flags[2] = {sc.linear ? 1 : 0, interp.IsInvalid ? 1 : 0};
+  std::memcpy(c + 31, flags, sizeof(flags));
+  double* o = motion_after;
+  o[0] = within.Time0; o[1] = within.Time1;
+  o[2] = within.Rot0.w; o[3] = within.Rot0.x; o[4] = within.Rot0.y; o[5] = within.Rot0.z;
+  o[6] = within.Rot1.w; o[7] = within.Rot1.x; o[8] = within.Rot1.y; o[9] = within.Rot1.z;
+  std::memcpy(o + 10, within.Trans0, 3 * sizeof(double)); std::memcpy(o + 13, within.Trans1, 3 * sizeof(double));
+  return 0;
+}
+
 int orc_transform(lsa_point_t* pts, int n, const double T[16])
 {
   Iso a = IsoFromRowMajor(T);

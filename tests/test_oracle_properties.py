@@ -498,3 +498,57 @@ def test_robosense_conversion_follows_the_driver_nodes_loop(O):
         for k, (x, y, z, lid, t, inten) in enumerate(kept):
             assert out["x"][k] == x and out["y"][k] == y and out["z"][k] == z and out["laser_id"][k] == lid and out["time"][k] == t
             assert out["intensity"][k] == inten and out["device_id"][k] == 2 and out["w"][k] == 1.0
+
+
+# ---------------------------------------------------------------- pose algebra between two ICP iterations
+def test_the_products_pose_algebra_is_the_restatements_bit_for_bit(O, L):
+    """What the product does between two ICP iterations -- on the host (lsa_posemath.h) and, from the same source, on the
+    device behind a solve (lsa_icp_link) -- against the oracle's own restatement of Utils::XYZRPYtoIsometry /
+    IsometryToXYZRPY (Utilities.cxx:33-77), Slam::InterpolateScanPose / RefineUndistortion (Slam.cxx:1271-1285, 1322-1352),
+    LinearInterpolation (MotionModel.cxx:26-34) and LinearTransformInterpolator (MotionModel.h:36-136): two independent
+    write-ups of the same arithmetic must give the same bits.  (tests/test_gpu_match.py holds the device's block against
+    the host's.)  No GPU needed: lsa_icp_link_expected is host code."""
+    rng = np.random.default_rng(17)
+
+    def se3(w):
+        cx, cy, cz = np.cos(w[3:]); sx, sy, sz = np.sin(w[3:])
+        T = np.eye(4)
+        T[:3, :3] = np.array([[cy * cz, sx * sy * cz - cx * sz, cx * sy * cz + sx * sz], [cy * sz, sx * sy * sz + cx * cz, cx * sy * sz - sx * cz], [-sy, sx * cy, cx * cy]])
+        T[:3, 3] = w[:3]
+        return T
+
+    def unit(q):
+        return q / np.linalg.norm(q)
+
+    cases = 0
+    for trial in range(400):
+        big = trial % 5 == 4  # every fifth case: rotations of any size (the quaternion conversion's trace <= 0 branches, yaw near pi)
+        x = np.concatenate([rng.normal(0, 30, 3), rng.uniform(-np.pi, np.pi, 3) if big else rng.normal(0, 0.05, 3)])
+        if big:
+            x[4] = rng.uniform(-1.5, 1.5)  # pitch inside (-pi / 2, pi / 2), as the reference's conversion assumes
+        prev = se3(np.concatenate([x[:3] + rng.normal(0, 0.5, 3), x[3:] + rng.normal(0, 0.02 if not big else 1.0, 3)]))
+        have_log = trial % 7 != 0
+        ratio = 0.5 if trial % 11 == 0 else 3.0
+        t0, t1 = (0.0, 0.0) if trial % 13 == 0 else (-0.1, -1e-4 * (trial % 3))
+        if trial % 17 == 0:
+            q0 = q1 = np.array([1.0, 0.0, 0.0, 0.0])  # the motion as InitUndistortion leaves it
+            tr0 = tr1 = np.zeros(3)
+        else:
+            q0, q1 = unit(rng.normal(0, 1e-2 if not big else 1.0, 4) + [1, 0, 0, 0]), unit(rng.normal(0, 1e-2 if not big else 1.0, 4) + [1, 0, 0, 0])
+            tr0, tr1 = rng.normal(0, 0.05, 3), rng.normal(0, 0.05, 3)
+        motion = np.concatenate([[t0, t1], q0, q1, tr0, tr1])
+        for refine in (0, 1):
+            ln = L.IcpLink()
+            ln.refine_undistortion, ln.first, ln.have_log = refine, 1, int(have_log)
+            ln.prev_time, ln.cur_time, ln.max_extrapolation_ratio = 10.0, 10.1, ratio
+            ln.previous_world[:] = list(prev.reshape(-1))
+            ln.motion[:] = list(motion)
+            got, got_motion = L.icp_link_expected(x, 0, 2, ln)
+            want, want_motion = O.icp_link(x, refine, have_log, 10.0, 10.1, ratio, prev, motion)
+            n = 19 if not refine else 51
+            assert np.array_equal(got[:n], want[:n]), (trial, refine, np.nonzero(got[:n] != want[:n])[0])
+            assert np.array_equal(got_motion.view(np.uint64), want_motion.view(np.uint64)), (trial, refine)
+            cases += 1
+    assert cases == 800
+    # a solve that was skipped, or made no step, leaves "do not run"
+    assert L.icp_link_expected(x, 1, 3, ln)[0][0] == 0 and L.icp_link_expected(x, 0, 1, ln)[0][0] == 0

@@ -988,8 +988,7 @@ int SlamCore::Localization()
     for (int k = 0; k < 3; ++k)  // the extractions follow one another on the context's stream, their sizes come back together
       if (need[k]) LSA_TRY(lsa_device_grid_build_submap_end(DevMaps[k]));
     Stats.submap += t.Stop();
-    HoldLookahead = false;
-    LSA_TRY(TryStartLookahead());
+    HoldLookahead = false;  // (the extraction is enqueued from the loop's interlude, behind this frame's first search: not here, in front of it)
   }
   else
   {

@@ -8,5 +8,5 @@ for i in $(seq $N); do
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); s=d['stage_ms_per_frame']
 acc=sum(v for k,v in s.items() if k not in ('total','maps_async','maps_wait'))
-print('${ENVS[*]} fps', round(d['value'],1), 'ms/icp', round(d['ms_per_icp_iter'],4), 'total', round(s['total'],3), 'outside the loops', round(s['total']-s['ego_lm']-s['loc_lm']-s['ego_icp']-s['loc_icp'],3), 'extract', round(s['extract'],3), 'unaccounted', round(s['total']-acc,3), 'adopted', d['config'].get('extractions_taken_over'), d['config'].get('uploads_taken_over'), {k:round(v,3) for k,v in s.items() if k in ('undistort','submap','maps','maps_wait','maps_async','extract')})"
+print('${ENVS[*]} fps', round(d['value'],1), 'ms/icp', round(d['ms_per_icp_iter'],4), 'total', round(s['total'],3), 'outside the loops', round(s['total']-s['ego_lm']-s['loc_lm']-s['ego_icp']-s['loc_icp'],3), 'extract', round(s['extract'],3), 'unaccounted', round(s['total']-acc,3), 'adopted', d['config'].get('extractions_taken_over'), 'fallbacks', d['config'].get('device_solve_fallbacks'), {k:round(v,3) for k,v in s.items() if k in ('undistort','submap','maps','maps_wait','maps_async','extract')})"
 done

@@ -715,6 +715,8 @@ int lsa_device_grid_add_keypoints(lsa_device_grid* g, int set, int type, const d
  * context's thread) reads the keypoints -- the set may be rewritten right after --, _add_staged inserts them. */
 int lsa_device_grid_stage_keypoints(lsa_device_grid* g, int set, int type, const double pose[16]);
 int lsa_device_grid_add_staged(lsa_device_grid* g, double time);
+/* _stage_keypoints for the keypoint types of a keyframe together (grids[i] takes type types[i] of the set): one launch */
+int lsa_device_grid_stage_keypoints_all(lsa_device_grid* const* grids, const int* types, int count, int set, const double pose[16]);
 /* ... for up to three maps of one context at once: one launch of every step serves all of them (a block row per map). */
 int lsa_device_grid_add_staged_all(lsa_device_grid* const* grids, int count, double time);
 int lsa_device_grid_roll(lsa_device_grid* g, const float min_point[3], const float max_point[3]);

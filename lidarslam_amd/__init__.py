@@ -67,7 +67,7 @@ ABI_SYMBOLS = [
     "lsa_synth_pose",
     "lsa_selftest_keep_busy", "lsa_solve_device_interlude", "lsa_device_grid_create", "lsa_device_grid_destroy", "lsa_device_grid_set", "lsa_device_grid_get_param", "lsa_device_grid_reset", "lsa_device_grid_clear",
     "lsa_device_grid_size", "lsa_device_grid_add", "lsa_device_grid_add_keypoints", "lsa_device_grid_roll", "lsa_device_grid_clear_old_points",
-    "lsa_device_grid_get", "lsa_device_grid_build_submap", "lsa_device_grid_submap_valid", "lsa_device_grid_stage_keypoints", "lsa_device_grid_add_staged", "lsa_device_grid_add_staged_all",
+    "lsa_device_grid_get", "lsa_device_grid_build_submap", "lsa_device_grid_submap_valid", "lsa_device_grid_stage_keypoints", "lsa_device_grid_stage_keypoints_all", "lsa_device_grid_add_staged", "lsa_device_grid_add_staged_all",
     "lsa_device_grid_build_submap_begin", "lsa_device_grid_build_submap_begin_for_keypoints", "lsa_device_grid_build_submap_end",
     "lsa_device_grid_submap_ahead_begin", "lsa_device_grid_submap_ahead_poll", "lsa_device_grid_submap_ahead_poll_all", "lsa_device_grid_submap_ahead_wait", "lsa_device_grid_submap_ahead_take", "lsa_device_grid_submap_ahead_take_begin", "lsa_device_grid_submap_ahead_take_end",
     "lsa_rolling_grid_create", "lsa_rolling_grid_destroy", "lsa_rolling_grid_set", "lsa_rolling_grid_reset", "lsa_rolling_grid_clear",

@@ -1512,15 +1512,16 @@ int SlamCore::UpdateMapsUsingTworld()
     // this thread only hands the keypoints over (one transform kernel per type); ONE worker enqueues the insertion of all
     // the types -- seven launches, a block row per map -- which runs on the look-ahead stream beside the next frame
     lsa_device_grid* grids[3];
-    int ng = 0;
+    int types[3], ng = 0;
     for (int k = 0; k < 3; ++k)
     {
       if (!UseKeypoints[k]) continue;
-      LSA_TRY(lsa_device_grid_stage_keypoints(DevMaps[k], LSA_SET_WORKING, k, Tworld.m));
+      types[ng] = k;
       grids[ng++] = DevMaps[k];
     }
     if (ng > 0)
     {
+      LSA_TRY(lsa_device_grid_stage_keypoints_all(grids, types, ng, LSA_SET_WORKING, Tworld.m));  // one transform launch for all the types
       const double time = CurrentTime;
       int* failed = &MapJobFailed[0];
       double* spent = &MapJobSeconds[0];

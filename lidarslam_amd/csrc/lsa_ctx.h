@@ -361,6 +361,7 @@ inline unsigned* box_words(lsa_ctx* ctx) { return reinterpret_cast<unsigned*>(ct
 inline unsigned* loc_box_words(lsa_ctx* ctx) { return reinterpret_cast<unsigned*>(ctx->range_bits + 32); }
 inline const unsigned* current_box_words(lsa_ctx* ctx) { return ctx->loc_boxes ? loc_box_words(ctx) : box_words(ctx); }
 int transform_points_to(lsa_ctx* ctx, const lsa_point_t* src, int n, const double pose[16], lsa_point_t* dst, hipStream_t stream = nullptr);  // lsa_transform.hip
+int transform_sets_to(lsa_ctx* ctx, const lsa_point_t* const src[3], const int n[3], const double pose[16], lsa_point_t* const dst[3], hipStream_t stream = nullptr);  // lsa_transform.hip
 int time_from_advancement(lsa_ctx* ctx, lsa_point_t* frame, int n, double rpm, int first_packet);  // lsa_extract.hip
 int ensure_capacity(lsa_ctx* ctx, int n);
 int ensure_target(lsa_ctx* ctx, int ti, int m);

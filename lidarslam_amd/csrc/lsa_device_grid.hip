@@ -1539,6 +1539,45 @@ int lsa_device_grid_stage_keypoints(lsa_device_grid* g, int set, int type, const
   g->staged = n;
   return order_after_context(g);
 }
+// ... of the keypoint types of a keyframe together: ONE transform launch for all the maps (a block row each), one event
+int lsa_device_grid_stage_keypoints_all(lsa_device_grid* const* grids, const int* types, int count, int set, const double pose[16])
+{
+  if (!grids || !types || !pose || count < 1 || count > 3 || set < 0 || set > 2) return LSA_E_ARG;
+  for (int i = 0; i < count; ++i)
+    if (!grids[i] || types[i] < 0 || types[i] > 2 || grids[i]->ctx != grids[0]->ctx) return LSA_E_ARG;
+  lsa_device_grid* g = grids[0];
+  lsa_ctx* ctx = g->ctx;
+  G_HIP(hipSetDevice(ctx->device));
+  const lsa_point_t* src[3] = {nullptr, nullptr, nullptr};
+  lsa_point_t* dst[3] = {nullptr, nullptr, nullptr};
+  int ns[3] = {0, 0, 0};
+  bool any = false;
+  for (int i = 0; i < count; ++i)
+  {
+    lsa_device_grid* gi = grids[i];
+    const int n = ctx->kp_n[set][types[i]];
+    gi->staged = 0;
+    if (n <= 0) continue;
+    const int rc = ensure_batch(gi, n);
+    if (rc) return rc;
+    // (the batch buffer is free once the last insertion that read it is over: ev_out)
+    G_HIP(hipStreamWaitEvent(ctx->stream, gi->ev_out, 0));
+    src[i] = ctx->kp[set][types[i]];
+    dst[i] = reinterpret_cast<lsa_point_t*>(gi->batch);
+    ns[i] = n;
+    any = true;
+  }
+  if (!any) return LSA_OK;
+  const int rc = transform_sets_to(ctx, src, ns, pose, dst, ctx->stream);
+  if (rc) return rc;
+  G_HIP(hipEventRecord(g->ev_in, ctx->stream));
+  for (int i = 0; i < count; ++i)
+  {
+    grids[i]->staged = ns[i];
+    if (ns[i] > 0) G_HIP(hipStreamWaitEvent(grids[i]->stream, g->ev_in, 0));
+  }
+  return LSA_OK;
+}
 int lsa_device_grid_add_staged(lsa_device_grid* g, double time)
 {
   if (!g) return LSA_E_ARG;

@@ -620,6 +620,24 @@ int transform_points_to(lsa_ctx* ctx, const lsa_point_t* src, int n, const doubl
   hipLaunchKernelGGL(k_transform_stage, dim3((n + 255) / 256, 1), dim3(256), 0, stream ? stream : ctx->stream, so, T);
   return LSA_OK;
 }
+// ... up to three sets at once (one launch, a block row per set; n <= 0: nothing for that row)
+int transform_sets_to(lsa_ctx* ctx, const lsa_point_t* const src[3], const int n[3], const double pose[16], lsa_point_t* const dst[3], hipStream_t stream)
+{
+  StageOut so{};
+  int nmax = 0;
+  for (int k = 0; k < 3; ++k)
+  {
+    so.in[k] = reinterpret_cast<const float4*>(src[k]);
+    so.out[k] = reinterpret_cast<float4*>(dst[k]);
+    so.n[k] = n[k] > 0 ? n[k] : 0;
+    nmax = std::max(nmax, so.n[k]);
+  }
+  if (nmax <= 0) return LSA_OK;
+  Rigid T;
+  row_major_to_rt(pose, T.R, T.t);
+  hipLaunchKernelGGL(k_transform_stage, dim3((nmax + 255) / 256, 3), dim3(256), 0, stream ? stream : ctx->stream, so, T);
+  return LSA_OK;
+}
 }  // namespace lsa
 
 extern "C" {

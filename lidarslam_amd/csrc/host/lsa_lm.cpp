@@ -65,12 +65,16 @@ void SymEigen(int n, const double* Ain, double* evals, double* evecs)
   for (int i = 0; i < n * n; ++i) A[i] = Ain[i];
   for (int i = 0; i < n; ++i)
     for (int j = 0; j < n; ++j) V[i * n + j] = (i == j);
+  // squared Frobenius norm: what the off-diagonal part is held against.  (The first version swept until that part was below
+  // 1e-300 -- in practice until it had underflowed: twenty microseconds per frame for digits nobody can see.)
+  double scale = 0;
+  for (int i = 0; i < n * n; ++i) scale += A[i] * A[i];
   for (int sweep = 0; sweep < 100; ++sweep)
   {
     double off = 0;
     for (int i = 0; i < n; ++i)
       for (int j = i + 1; j < n; ++j) off += A[i * n + j] * A[i * n + j];
-    if (off < 1e-300) break;
+    if (off <= 1e-36 * scale) break;  // (machine precision is 5e-32 of the squared norm; Jacobi converges quadratically: one more sweep past it)
     for (int p = 0; p < n; ++p)
       for (int q = p + 1; q < n; ++q)
       {

@@ -140,8 +140,8 @@ SlamCore::SlamCore(int device)
 SlamCore::~SlamCore()
 {
   if (std::getenv("LSA_STAGE_DEBUG") && DbgFrames > 0)
-    std::fprintf(stderr, "[stage debug] per frame, us: garbage+adopt %.1f | wait for the look-ahead thread %.1f | ego-motion before its loop %.1f | after the maps %.1f | localization after its loop %.1f | between ego-motion and localization %.1f (%ld frames)\n",
-                 1e6 * DbgAcc[0] / DbgFrames, 1e6 * DbgAcc[1] / DbgFrames, 1e6 * DbgAcc[2] / DbgFrames, 1e6 * DbgAcc[3] / DbgFrames, 1e6 * DbgAcc[4] / DbgFrames, 1e6 * DbgAcc[5] / DbgFrames, DbgFrames);
+    std::fprintf(stderr, "[stage debug] per frame, us: garbage+adopt %.1f | wait for the look-ahead thread %.1f | ego-motion before its loop %.1f | after the maps %.1f | registration error %.1f | localization outside its stage timers %.1f | of the first: garbage %.1f (%ld frames)\n",
+                 1e6 * DbgAcc[0] / DbgFrames, 1e6 * DbgAcc[1] / DbgFrames, 1e6 * DbgAcc[2] / DbgFrames, 1e6 * DbgAcc[3] / DbgFrames, 1e6 * DbgAcc[4] / DbgFrames, 1e6 * DbgAcc[5] / DbgFrames, 1e6 * DbgAcc[6] / DbgFrames, DbgFrames);
   WaitMaps();
   for (auto* g : DevMaps)
     if (g) lsa_device_grid_destroy(g);
@@ -275,6 +275,7 @@ int SlamCore::AddFrame(const lsa_point_t* pts, int n, uint64_t stampUs, uint32_t
   Tick total;
   Stats = FrameStats();
   (void)lsa_collect_garbage(Ctx);  // buffers outgrown during the last frame (nothing on the device waits for the host here)
+  DbgAcc[6] += total.Stop();
   if (!pts || n <= 0) { LastError = "SLAM input only contains empty pointclouds : exiting."; return LSA_OK; }
   if (stampUs == CurrentStamp) { LastError = "SLAM frames have the same timestamp as previous ones : frames ignored."; return LSA_OK; }
   if (pts[0].device_id != 0 && (!OtherExtractors.empty() || !OtherBaseToLidarOffsets.empty()))
@@ -880,6 +881,8 @@ int SlamCore::ComputeEgoMotion()
 // Slam::Localization (Slam.cxx:975-1175)
 int SlamCore::Localization()
 {
+  Tick tloc;
+  struct AtExit { SlamCore* c; Tick* t; ~AtExit() { c->DbgAcc[5] += t->Stop() - (c->Stats.loc_icp + c->Stats.loc_lm + c->Stats.submap + c->Stats.undistort); } } atExit{this, &tloc};
   PreviousTworld = Tworld;
   Tworld = PreviousTworld * Trelative;
   // With the maps on the device the reset, the first undistortion and the keypoints' boxes under the pose guess (which the
@@ -1277,7 +1280,9 @@ int SlamCore::Localization()
     Stats.loc_lm += tlm.Stop();
     if (lastIteration)
     {
+      Tick terr;
       LSA_TRY(optimizer.EstimateRegistrationError(LocalizationUncertainty));
+      DbgAcc[4] += terr.Stop();
       break;
     }
     if (ticket >= 0)

@@ -89,7 +89,10 @@ int ensure_target(lsa_ctx* ctx, int ti, int m)
     LSA_HIP(ctx, hipMemcpy(t.bbox_bits, init, sizeof(init), hipMemcpyHostToDevice));
   }
   if (m <= t.cap) return LSA_OK;
-  int cap = std::max(2 * m, 16384);  // doubling: a growing sub-map re-allocates a handful of times
+  // doubling from 64 k points (7 MB a target): a growing sub-map re-allocates a handful of times in a sequence's life -- each
+  // time eight buffers are retired and freed at the next frame's start, where every hipFree waits for the device (0.3-0.6 ms:
+  // with a floor of 16 k a map's first hundred keyframes crossed it for every target, 15 us a frame over bench.py's window)
+  int cap = std::max(2 * m, 65536);
   // (no synchronisation: the outgrown buffers are retired, launches in flight keep them; the new ones are filled before
   // they are read.  This runs on worker threads too, beside ICP iterations that wait behind a gate)
   LSA_HIP(ctx, dev_alloc(ctx, &t.pts, (size_t)cap));

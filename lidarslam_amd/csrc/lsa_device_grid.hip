@@ -1215,7 +1215,9 @@ int ensure_map(lsa_device_grid* g, int want)
 int ensure_batch(lsa_device_grid* g, int n)
 {
   if (n <= g->bcap) return LSA_OK;
-  const int cap = std::max(n + n / 4, 1 << 14);
+  // (twice what is asked for: outgrowing the batch retires eight buffers, and freeing them at the next frame's start waits for
+  //  the device eight times -- 0.2-0.6 ms; a keyframe's keypoint count wanders by a quarter over the first hundred frames)
+  const int cap = std::max(2 * n, 1 << 15);
   auto fr = [g](void* p) { retire_dev(g->ctx, p); };
   fr(g->batch); fr(g->bkeys); fr(g->skeys); fr(g->border); fr(g->sorder); fr(g->heads); fr(g->fresh_flag); fr(g->vrank);
   retire_view(g, g->fresh);
@@ -1500,6 +1502,11 @@ int lsa_device_grid_size(lsa_device_grid* g)
 {
   if (!g) return LSA_E_ARG;
   if (hipSetDevice(g->ctx->device) != hipSuccess || hipEventSynchronize(g->ev_state) != hipSuccess) return LSA_E_HIP;
+  // every modification has landed: the bound on the number of voxels is the number itself.  (tighten() alone seldom found the
+  // event complete in the pipeline -- something had always just been enqueued behind it --, the bound then grew by every
+  // keyframe's points and the map's buffers were "outgrown" and doubled every twenty keyframes: a stall of the maps' stream,
+  // three device-wide copies and eight buffers to free at the next frame's start, 0.3-0.6 ms each time.)
+  if (g->n_upper > 0) g->n_upper = std::min(g->n_upper, std::max(g->host_st[kStN], 0));
   return g->host_st[kStNbPoints];
 }
 

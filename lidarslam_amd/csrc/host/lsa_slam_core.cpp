@@ -140,8 +140,8 @@ SlamCore::SlamCore(int device)
 SlamCore::~SlamCore()
 {
   if (std::getenv("LSA_STAGE_DEBUG") && DbgFrames > 0)
-    std::fprintf(stderr, "[stage debug] per frame, us: garbage+adopt %.1f | wait for the look-ahead thread %.1f | ego-motion before its loop %.1f | after the maps %.1f | registration error %.1f | localization outside its stage timers %.1f | of the first: garbage %.1f (%ld frames)\n",
-                 1e6 * DbgAcc[0] / DbgFrames, 1e6 * DbgAcc[1] / DbgFrames, 1e6 * DbgAcc[2] / DbgFrames, 1e6 * DbgAcc[3] / DbgFrames, 1e6 * DbgAcc[4] / DbgFrames, 1e6 * DbgAcc[5] / DbgFrames, 1e6 * DbgAcc[6] / DbgFrames, DbgFrames);
+    std::fprintf(stderr, "[stage debug] per frame, us: garbage+adopt %.1f | wait for the look-ahead thread %.1f | ego-motion before its loop %.1f | after the maps %.1f | registration error %.1f | localization outside its stage timers %.1f | of the first: garbage %.1f, up to the hand-over %.1f (%ld frames)\n",
+                 1e6 * DbgAcc[0] / DbgFrames, 1e6 * DbgAcc[1] / DbgFrames, 1e6 * DbgAcc[2] / DbgFrames, 1e6 * DbgAcc[3] / DbgFrames, 1e6 * DbgAcc[4] / DbgFrames, 1e6 * DbgAcc[5] / DbgFrames, 1e6 * DbgAcc[6] / DbgFrames, 1e6 * DbgAcc[7] / DbgFrames, DbgFrames);
   WaitMaps();
   for (auto* g : DevMaps)
     if (g) lsa_device_grid_destroy(g);
@@ -285,6 +285,7 @@ int SlamCore::AddFrame(const lsa_point_t* pts, int n, uint64_t stampUs, uint32_t
     return AddFrames(&f, 1);
   }
   CurrentFrames.clear();
+  DbgAcc[7] += total.Stop();
   {
     // the cloud may have been announced and uploaded ahead (HintNextFrame): it is taken over, otherwise copied now
     const int adopted = lsa_upload_frame_adopt(Ctx, pts, n);

@@ -402,13 +402,9 @@ int lsa_upload_frame_ready(const lsa_ctx* ctx)
   return ctx->inbox[ctx->inbox_queue.front()].state.load(std::memory_order_acquire) == 2 ? 1 : 0;
 }
 
-static double g_adopt_dbg[5] = {0, 0, 0, 0, 0};
-static long g_adopt_n = 0;
-static double adopt_now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 int lsa_upload_frame_adopt(lsa_ctx* ctx, const lsa_point_t* pts, int n)
 {
   if (!ctx) return LSA_E_ARG;
-  const double tdbg0 = adopt_now();
   // the announced cloud this one is, if any (clouds announced before it were skipped by the caller: given up)
   size_t at = ctx->inbox_queue.size();
   for (size_t i = 0; i < ctx->inbox_queue.size() && at == ctx->inbox_queue.size(); ++i)
@@ -432,10 +428,7 @@ int lsa_upload_frame_adopt(lsa_ctx* ctx, const lsa_point_t* pts, int n)
     in.state.store(0);
     return ctx->fail(LSA_E_HIP, "lsa_upload_frame_adopt: the upload failed");
   }
-  const double tdbg1 = adopt_now();
-  const unsigned long long fp = cloud_fingerprint(pts, n);
-  const double tdbg2 = adopt_now();
-  if (in.fingerprint != fp)
+  if (in.fingerprint != cloud_fingerprint(pts, n))
   {
     // same address and size, other contents: the buffer was reused for another scan since it was announced (a driver's
     // ring buffer, an allocator handing the same block out again) -- the copy made then is stale, the caller uploads
@@ -451,16 +444,7 @@ int lsa_upload_frame_adopt(lsa_ctx* ctx, const lsa_point_t* pts, int n)
   int rc = ensure_capacity(ctx, n);
   if (rc) return rc;
   maybe_estimate_resolution(ctx, pts, n);
-  const double tdbg3 = adopt_now();
   LSA_HIP(ctx, hipStreamWaitEvent(ctx->stream, in.ev, 0));
-  const double tdbg4 = adopt_now();
-  if (std::getenv("LSA_STAGE_DEBUG"))
-  {
-    g_adopt_dbg[0] += tdbg1 - tdbg0; g_adopt_dbg[1] += tdbg2 - tdbg1; g_adopt_dbg[2] += tdbg3 - tdbg2; g_adopt_dbg[3] += tdbg4 - tdbg3;
-    if (++g_adopt_n % 40 == 0)
-      std::fprintf(stderr, "[adopt debug] us: wait for the uploader %.1f | fingerprint %.1f | capacity %.1f | stream waits for the copy %.1f\n", 1e6 * g_adopt_dbg[0] / g_adopt_n,
-                   1e6 * g_adopt_dbg[1] / g_adopt_n, 1e6 * g_adopt_dbg[2] / g_adopt_n, 1e6 * g_adopt_dbg[3] / g_adopt_n);
-  }
   ctx->frame = in.dev;
   ctx->frame_n = n;
   ctx->inbox_current = slot;

@@ -620,26 +620,34 @@ __global__ __launch_bounds__(kLabelThreads) void k_label(const float* __restrict
 }
 
 // --------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_compact(const float4* __restrict__ frame, const uint32_t* __restrict__ orig,
+constexpr int kCompactThreads = 1024;  // two points of a 2 048-point ring per thread: the dependent loads (label -> original index -> point) side by side
+__global__ __launch_bounds__(kCompactThreads) void k_compact(const float4* __restrict__ frame, const uint32_t* __restrict__ orig,
                                                  const uint8_t* __restrict__ label, const int* __restrict__ ring_start,
                                                  const int* __restrict__ ring_len, const int* __restrict__ ring_meta,
                                                  const int* __restrict__ ring_counts, float4* __restrict__ out_e,
                                                  float4* __restrict__ out_p, float4* __restrict__ out_b, int* __restrict__ kp_count,
                                                  unsigned type_mask, unsigned long long* __restrict__ time_range)
 {
+  constexpr int kWaves = kCompactThreads / 64;
   __shared__ int base[3];
-  __shared__ unsigned long long part[256];
-  __shared__ unsigned long long tlo[4], thi[4];
+  __shared__ unsigned long long wtot[kWaves];
+  __shared__ unsigned long long tlo[kWaves], thi[kWaves];
   const int r = blockIdx.x;
   const int nr = ring_meta[0];
   if (r >= nr) return;
-  if (threadIdx.x < 3)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (wave < 3)
   {
+    // keypoints of type `wave` in the rings in front of this one: the lanes share the rings, one reduction
     int s = 0;
-    for (int q = 0; q < r; ++q) s += ring_counts[q * 3 + threadIdx.x];
-    base[threadIdx.x] = s;
-    // a type the caller does not use (Slam::UseKeypoints) is dropped here: count 0, nothing written
-    if (r == nr - 1) kp_count[threadIdx.x] = ((type_mask >> threadIdx.x) & 1u) ? s + ring_counts[r * 3 + threadIdx.x] : 0;
+    for (int q = lane; q < r; q += 64) s += ring_counts[q * 3 + wave];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
+    if (lane == 0)
+    {
+      base[wave] = s;
+      // a type the caller does not use (Slam::UseKeypoints) is dropped here: count 0, nothing written
+      if (r == nr - 1) kp_count[wave] = ((type_mask >> wave) & 1u) ? s + ring_counts[r * 3 + wave] : 0;
+    }
   }
   const int s0 = ring_start[r];
   const int np = ring_len[r];
@@ -651,16 +659,19 @@ __global__ __launch_bounds__(256) void k_compact(const float4* __restrict__ fram
     const uint8_t l = label[s0 + j] & type_mask;
     mine += (unsigned long long)(l & 1) | ((unsigned long long)((l >> 1) & 1) << 21) | ((unsigned long long)((l >> 2) & 1) << 42);
   }
-  part[threadIdx.x] = mine;
-  __syncthreads();
-  for (int o = 1; o < 256; o <<= 1)
+  // exclusive scan of the (packed) counts over the block: inside the wavefront by shuffles, across by the wavefronts' totals
+  unsigned long long inc = mine;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1)
   {
-    unsigned long long v = (threadIdx.x >= (unsigned)o) ? part[threadIdx.x - o] : 0ull;
-    __syncthreads();
-    part[threadIdx.x] += v;
-    __syncthreads();
+    const unsigned long long t = __shfl_up(inc, o);
+    if (lane >= o) inc += t;
   }
-  unsigned long long excl = part[threadIdx.x] - mine;
+  if (lane == 63) wtot[wave] = inc;
+  __syncthreads();
+  unsigned long long before = 0;
+  for (int w = 0; w < wave; ++w) before += wtot[w];
+  unsigned long long excl = before + inc - mine;
   int pe = base[0] + (int)(excl & 0x1fffff);
   int pp = base[1] + (int)((excl >> 21) & 0x1fffff);
   int pb = base[2] + (int)((excl >> 42) & 0x1fffff);
@@ -689,7 +700,7 @@ __global__ __launch_bounds__(256) void k_compact(const float4* __restrict__ fram
   __syncthreads();
   if (threadIdx.x == 0)
   {
-    for (int w = 1; w < 4; ++w) { lo = tlo[w] < lo ? tlo[w] : lo; hi = thi[w] > hi ? thi[w] : hi; }
+    for (int w = 1; w < kWaves; ++w) { lo = tlo[w] < lo ? tlo[w] : lo; hi = thi[w] > hi ? thi[w] : hi; }
     if (hi >= lo) { atomicMin(&time_range[0], lo); atomicMax(&time_range[1], hi); }
   }
 }
@@ -786,7 +797,7 @@ static void enqueue_extract(lsa_ctx* ctx, const float4* frame4, int n, const Ext
   }
   {
     ProfScope ps(ctx, "compact", (double)n * (1 + 4), st);
-    hipLaunchKernelGGL(k_compact, dim3(kMaxRings), dim3(256), 0, st, frame4, ctx->orig, ctx->label, ctx->ring_start, ctx->ring_len,
+    hipLaunchKernelGGL(k_compact, dim3(kMaxRings), dim3(kCompactThreads), 0, st, frame4, ctx->orig, ctx->label, ctx->ring_start, ctx->ring_len,
                        ring_meta, ctx->ring_counts, reinterpret_cast<float4*>(kp_out[0]),
                        reinterpret_cast<float4*>(kp_out[1]), reinterpret_cast<float4*>(kp_out[2]),
                        out, type_mask, reinterpret_cast<unsigned long long*>(out + 12));

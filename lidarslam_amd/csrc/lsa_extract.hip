@@ -141,7 +141,10 @@ __global__ __launch_bounds__(256) void k_ring_scatter(const float4* __restrict__
   __shared__ uint16_t ids[kBucketChunk];
   __shared__ uint32_t dest[kBucketChunk];
   __shared__ uint32_t slot[kMaxRings];  // next free slot of every ring for this chunk
+  __shared__ uint32_t wcnt[4][kMaxRings];   // points of every ring in each wavefront's quarter of the chunk ...
+  __shared__ uint32_t wslot[4][kMaxRings];  // ... and the next free slot of every ring for that quarter
   __shared__ int scan[kMaxRings];
+  static_assert(kBucketChunk % 256 == 0, "a quarter of the chunk per wavefront, whole batches of 64");
   const int base = blockIdx.x * kBucketChunk;
   const int cnt = min(kBucketChunk, n - base);
   for (int i = threadIdx.x; i < cnt; i += blockDim.x) ids[i] = (uint16_t)laser_of(frame[2 * (size_t)(base + i) + 1]);
@@ -173,22 +176,38 @@ __global__ __launch_bounds__(256) void k_ring_scatter(const float4* __restrict__
     }
   }
   __syncthreads();
-  if (threadIdx.x < 64)
+  // The four wavefronts rank a quarter of the chunk each (the first version left it all to the first one: sixteen batches
+  // one after the other): the rings' points per quarter are counted first, a quarter's slots start behind the quarters
+  // in front of it.
+  constexpr int kQuarter = kBucketChunk / 4;
   {
-    const int lane = threadIdx.x;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int r = threadIdx.x; r < 4 * kMaxRings; r += blockDim.x) wcnt[r / kMaxRings][r % kMaxRings] = 0u;
+    __syncthreads();
+    for (int i = wave * kQuarter + lane; i < min(cnt, (wave + 1) * kQuarter); i += 64)
+      if (ids[i] < kMaxRings) atomicAdd(&wcnt[wave][ids[i]], 1u);
+    __syncthreads();
+    for (int r = threadIdx.x; r < kMaxRings; r += blockDim.x)
+    {
+      uint32_t s = slot[r];
+      for (int w = 0; w < 4; ++w) { wslot[w][r] = s; s += wcnt[w][r]; }
+    }
+    __syncthreads();
     const unsigned long long below = (1ull << lane) - 1ull;
-    for (int b = 0; b < cnt; b += 64)
+    uint32_t* const myslot = wslot[wave];
+    for (int b = wave * kQuarter; b < min(cnt, (wave + 1) * kQuarter); b += 64)
     {
       const int i = b + lane;
-      const unsigned id = i < cnt ? ids[i] : 0u;
-      const bool active = i < cnt && id < (unsigned)kMaxRings;
+      const bool in = i < cnt && i < (wave + 1) * kQuarter;
+      const unsigned id = in ? ids[i] : 0u;
+      const bool active = in && id < (unsigned)kMaxRings;
       const unsigned long long same = same_ring_lanes(id, active);
       if (active)
       {
-        const uint32_t s = slot[id];
+        const uint32_t s = myslot[id];
         dest[i] = s + (uint32_t)__popcll(same & below);
         // the last lane of the ring in this batch advances the ring's slot for the next batch
-        if ((same >> lane) == 1ull) slot[id] = s + (uint32_t)__popcll(same);
+        if ((same >> lane) == 1ull) myslot[id] = s + (uint32_t)__popcll(same);
       }
     }
   }

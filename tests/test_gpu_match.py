@@ -170,7 +170,7 @@ def setup_residuals(ctx, O, L, kps, model=16, sat=5.0):
     return np.concatenate(recs), np.concatenate(sts)
 
 
-@pytest.mark.parametrize("model", [16, 128])
+@pytest.mark.parametrize("model", [16, 64, 128])  # VLP-16, HDL-64 (BASELINE config 3), VLS-128
 def test_normal_equations_match_the_oracle(gpu_ctx, O, L, kps, model):
     rec, st = setup_residuals(gpu_ctx, O, L, kps, model)
     for w6 in (np.zeros(6), np.array([0.45, 0.01, -0.02, 0.001, -0.002, 0.012]), np.array([3.0, -2.0, 1.0, 0.3, -0.2, 1.5])):
@@ -331,7 +331,7 @@ def test_normal_equations_arrive_through_the_mailbox(gpu_ctx, O, L, kps):
 
 
 @pytest.mark.parametrize("two_d", [False, True])
-@pytest.mark.parametrize("model", [16, 128])
+@pytest.mark.parametrize("model", [16, 64, 128])  # VLP-16, HDL-64 (BASELINE config 3), VLS-128
 def test_one_launch_solve_equals_the_host_driven_loop(gpu_ctx, O, L, kps, two_d, model):
     """lsa_solve_device: the trust-region loop of LocalOptimizer::Solve inside one kernel (blocks exchanging their
     partial sums through tagged granules) takes the decisions of the host-driven loop and of the oracle"""
@@ -454,7 +454,7 @@ def test_undistortion_inside_the_search_kernel(L, kps):
     b.close()
 
 
-@pytest.mark.parametrize("model", [16, 128])
+@pytest.mark.parametrize("model", [16, 64, 128])  # VLP-16, HDL-64 (BASELINE config 3), VLS-128
 def test_fused_and_staged_matching_agree(O, L, kps, model):
     """lsa_set_fused_match: one launch per ICP iteration (adaptive block search by the cell counts, per-lane sorted
     lists, model fit in the same kernel, tail kernel for what no block settles) against the staged kernels (first
